@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/sec of the env.step() hot path on MI355X (BASELINE.json metric).
+
+A "step" is one FlexibleGymEnv.step() over one batch of 4096 robots per GPU (8 physics substeps at 4 kHz +
+observation + 8 reward terms + termination + masked in-step reset), with the action batch already resident
+in HBM.  Workload at N=1: BASELINE config 2 ("4096 envs on 1xMI355X, imitation reward, pure env-step
+kernel"), synthetic actions a = clip(0.3*N(0,1), -1, 1).  Multi-GPU: one process per GPU
+(launched by torch.distributed.run), 4096 envs per rank, no data-path collective (envs never interact,
+RaisimGymEnv.hpp:56) -> weak scaling; the only collectives are the timing barrier and the max-over-ranks.
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel = irrl_step_kernel, HIP-event
+timed inside this run), `roofline_fp32` (the VALU-FP32 view: this path is latency/issue bound, not HBM
+bound), `cpu_baseline` (the f64 oracle with the reference's OpenMP-over-envs threading on the
+GPU box's host cores, bounded sample, rank 0 / N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic cost of one env-step (SURVEY 8d / BASELINE.md section 4)
+ALG_BYTES_PER_ENV_STEP = 1521.0
+ALG_FLOPS_PER_ENV_STEP = 1.5e5   # estimate; DESIGN.md section 6 explains the count
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+FP32_PEAK_TFLOPS = 157.3
+
+
+def cpu_baseline(env_cfg, target_seconds):
+    """Oracle (kind "port": the build's own CPU restatement; the RaiSim reference is closed source and absent)
+    timed with `#pragma omp parallel for schedule(dynamic)` over envs like VectorizedEnvironment.hpp:273."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    cfg = dict(env_cfg)
+    n = int(cfg["num_envs"])
+    env = O.OracleVecEnv(cfg)
+    rng = np.random.RandomState(1)
+    acts = [np.clip(0.3 * rng.normal(size=(n, 12)), -1, 1).astype(np.float32) for _ in range(8)]
+    t0 = time.perf_counter()
+    for k in range(4):
+        env.step(acts[k])
+    per_step = (time.perf_counter() - t0) / 4
+    steps = int(max(8, min(750, target_seconds / max(per_step, 1e-6))))
+    t0 = time.perf_counter()
+    for k in range(steps):
+        env.step(acts[k % 8])
+    dt = time.perf_counter() - t0
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d envs x %d control steps (f64 oracle, OpenMP dynamic over envs, %d threads, %.1f s)" % (n, steps, cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--cfg", default="bp5_imitation.yaml")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget (0 disables)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import yaml
+    import high_speed_quadrupedal_locomotion_by_irrl_amd as pkg
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.flexible_robot import FlexibleGymEnv
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the env kernels have no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    with open(os.path.join(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY__, args.cfg)) as f:
+        env_cfg = yaml.safe_load(f)["environment"]
+    env_cfg["num_envs"] = args.envs
+    env_cfg["seedd"] = int(env_cfg.get("seedd", 1)) + 7919 * rank   # different robots on every rank
+    n = args.envs
+    env = FlexibleGymEnv(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY__, yaml.safe_dump(env_cfg), device=local_rank)
+    env.init()
+
+    # synthetic action pool resident in HBM (Philox-free here: torch generator seeded per rank)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1 + rank)
+    pool = [torch.clamp(0.3 * torch.randn(n, 12, device=dev, generator=g), -1, 1).contiguous() for _ in range(64)]
+    ob = torch.zeros(n, 35, device=dev)
+    rew = torch.zeros(n, device=dev)
+    done = torch.zeros(n, dtype=torch.bool, device=dev)
+    extra = torch.zeros(n, 6, device=dev)
+    n_done = torch.zeros((), device=dev)
+
+    def run(k_steps, count_done=False):
+        for k in range(k_steps):
+            env.step(pool[k % 64], ob, rew, done, extra)
+            if count_done:
+                n_done.add_(done.sum())
+
+    run(args.warmup)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    run(args.steps)
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps   # events on the stream the kernel is launched on
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # sanity on the timed work: finite outputs, episodes really terminate and reset inside the step
+    run(50, count_done=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(ob).all() and torch.isfinite(rew).all(), "non-finite env outputs"
+
+    if rank == 0:
+        total_env_steps = float(n) * world * args.steps
+        value = total_env_steps / elapsed
+        launch_s = kernel_ms * 1e-3
+        ach_gbs = ALG_BYTES_PER_ENV_STEP * n / launch_s / 1e9
+        ach_tf = ALG_FLOPS_PER_ENV_STEP * n / launch_s / 1e12
+        out = {
+            "metric": "env-steps/sec (4096 envs per MI355X)", "value": value, "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: %d envs/GPU x 1 env.step (8 substeps @4 kHz + obs + reward + "
+                                   "termination + in-step reset), cfg %s, actions clip(0.3 N(0,1))" % (n, args.cfg),
+                       "envs_per_gpu": n, "global_envs": n * world, "parallelism": "env-sharded x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "irrl_step_kernel", "avg_launch_us": kernel_ms * 1e3,
+                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n},
+            "roofline_fp32": {"bound": "valu_fp32 (latency/issue bound: 1 wave per CU at 4096 envs)", "achieved": ach_tf,
+                              "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP32_PEAK_TFLOPS,
+                              "algorithmic_flops_per_launch": ALG_FLOPS_PER_ENV_STEP * n},
+            "resets_in_50_steps": float(n_done.item()),
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(env_cfg, args.cpu_seconds)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

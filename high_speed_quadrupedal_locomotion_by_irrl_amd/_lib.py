@@ -1,0 +1,81 @@
+"""ctypes binding of libirrl_env.so (include/irrl_env.h).  Fails loudly: there is no fallback."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libirrl_env.so")
+_lib = None
+
+fp = C.POINTER(C.c_float)
+dp = C.POINTER(C.c_double)
+u8 = C.POINTER(C.c_uint8)
+vp = C.c_void_p
+
+# name -> (restype, argtypes); exactly the symbols declared in include/irrl_env.h
+SIGNATURES = {
+    "irrl_last_error": (C.c_char_p, []),
+    "irrl_version": (C.c_char_p, []),
+    "irrl_env_create": (vp, [C.c_char_p, C.c_char_p, C.c_int]),
+    "irrl_env_destroy": (None, [vp]),
+    "irrl_env_init": (C.c_int, [vp]),
+    "irrl_env_set_stream": (C.c_int, [vp, vp]),
+    "irrl_env_num_envs": (C.c_int, [vp]),
+    "irrl_env_ob_dim": (C.c_int, [vp]),
+    "irrl_env_action_dim": (C.c_int, [vp]),
+    "irrl_env_extra_dim": (C.c_int, [vp]),
+    "irrl_env_extra_name": (C.c_char_p, [vp, C.c_int]),
+    "irrl_env_step": (C.c_int, [vp, vp, vp, vp, vp, vp]),
+    "irrl_env_step_host": (C.c_int, [vp, fp, fp, fp, u8, fp]),
+    "irrl_env_test_step_host": (C.c_int, [vp, fp, fp, fp, u8, fp]),
+    "irrl_env_reset": (C.c_int, [vp, vp]),
+    "irrl_env_reset_host": (C.c_int, [vp, fp]),
+    "irrl_env_observe": (C.c_int, [vp, vp]),
+    "irrl_env_observe_host": (C.c_int, [vp, fp]),
+    "irrl_env_is_terminal": (C.c_int, [vp, vp]),
+    "irrl_env_is_terminal_host": (C.c_int, [vp, u8]),
+    "irrl_env_set_seed": (C.c_int, [vp, C.c_int]),
+    "irrl_env_set_simulation_dt": (C.c_int, [vp, C.c_double]),
+    "irrl_env_set_control_dt": (C.c_int, [vp, C.c_double]),
+    "irrl_env_close": (C.c_int, [vp]),
+    "irrl_env_curriculum_update": (C.c_int, [vp]),
+    "irrl_env_origin_state_host": (C.c_int, [vp, fp]),
+    "irrl_env_reference_state_host": (C.c_int, [vp, fp]),
+    "irrl_env_joint_effort_host": (C.c_int, [vp, fp]),
+    "irrl_env_generalized_force_host": (C.c_int, [vp, fp]),
+    "irrl_env_inverse_mass_matrix_host": (C.c_int, [vp, fp]),
+    "irrl_env_nonlinear_host": (C.c_int, [vp, fp]),
+    "irrl_env_set_contact_coeff_host": (C.c_int, [vp, fp]),
+    "irrl_env_sphere_info_host": (C.c_int, [vp, fp]),
+    "irrl_env_get_state_host": (C.c_int, [vp, dp]),
+    "irrl_env_set_state_host": (C.c_int, [vp, dp]),
+    "irrl_env_cfg_value": (C.c_double, [vp, C.c_char_p]),
+    "irrl_gae": (C.c_int, [C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp]),
+}
+
+
+def load():
+    """Load the HIP library.  Raises if it has not been built -- build it with
+    ``python -m high_speed_quadrupedal_locomotion_by_irrl_amd.build`` (or __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libirrl_env.so is missing: build the gfx950 extension first "
+                           "(python -m high_speed_quadrupedal_locomotion_by_irrl_amd.build). "
+                           "There is no CPU or PyTorch fallback for the env kernels.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().irrl_last_error().decode("utf-8", "replace")
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("irrl_env: " + last_error())

@@ -1,0 +1,1204 @@
+// env_core.hpp -- the env.step() hot path of the BlackPanther quadruped task as lane-generic code.
+//
+// Included AFTER a lane-primitive header (lanes_hip.hpp on the GPU) that defines vf/vi/vu/vm and the
+// `lanes::` helpers.  Mapping: one DPP quad per robot, one leg per lane (lanes_hip.hpp).  All control
+// flow on per-lane conditions is written as selects; the only branches are wave-uniform
+// (`wave_any(...)`, kernel parameters), so a wave of 16 robots runs in lockstep without divergence.
+//
+// What the reference computes here (file:line under
+// /root/reference/IRRL/FlexibleRobotRaisimGym/flex_gym/env/, ENV = env/BlackPanther_V55/Environment.hpp,
+// VEC = VectorizedEnvironment.hpp):
+//   step prologue ENV:700-708, substep loop ENV:758-774 (PD law, torque_clamp ENV:1273-1312, RaiSim
+//   integrate ENV:768), updateObservation ENV:956-1004, contact_information_update ENV:1199-1243,
+//   DeepMimicRewardUpdate ENV:1444-1548, command_obs_update ENV:1010-1109, gait_generator_manual
+//   ENV:1756-1890, inverse_kinematics ENV:1687-1751, contact_obs_update ENV:1116-1194,
+//   isTerminalState ENV:1553-1578, reset ENV:547-635, observe ENV:1248-1268, perAgentStep VEC:352-372,
+//   constructor randomisation ENV:435-477.
+//
+// Dynamics formulation (RaiSim is closed source; this is the build's own):
+//   u~ = [R^T v, R^T w, qd];  M_B(q) a + b(q,u~) = tau + sum J^T f,  a = physical accelerations in
+//   base-frame components.  M_B has the arrow structure  [[A, B_1..B_4], [B_l^T, C_l]]  (legs couple
+//   only through the base), so each lane factors its own 3x3 block C_l, the quad reduces the 6x6 Schur
+//   complement S = A - sum_l B_l C_l^-1 B_l^T (21 numbers), every lane Cholesky-factors S redundantly,
+//   and all solves with M are a 6x6 triangular solve plus lane-local 3x3 work.  The Delassus operator of
+//   the toe contacts is G_ll' = Y_l^T Y_l' + delta_ll' E_l with Y_l = L^-1 K_l^T (6x3, lane-local), so
+//   the Gauss-Seidel contact sweep only exchanges one 6-vector z = sum_l Y_l lambda_l inside the quad.
+#pragma once
+#include "env_params.h"
+
+namespace irrl {
+using namespace lanes;
+
+// ---------------------------------------------------------------------------------------------
+// small vector helpers
+// ---------------------------------------------------------------------------------------------
+struct v3 { vf x, y, z; };
+struct sym3 { vf xx, xy, xz, yy, yz, zz; };
+
+IRRL_DEV v3 mk3(vf x, vf y, vf z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+IRRL_DEV v3 operator+(v3 a, v3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+IRRL_DEV v3 operator-(v3 a, v3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+IRRL_DEV v3 operator*(vf s, v3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+IRRL_DEV vf dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+IRRL_DEV v3 cross(v3 a, v3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+IRRL_DEV v3 mul(sym3 A, v3 v) {
+  return mk3(A.xx * v.x + A.xy * v.y + A.xz * v.z, A.xy * v.x + A.yy * v.y + A.yz * v.z,
+             A.xz * v.x + A.yz * v.y + A.zz * v.z);
+}
+IRRL_DEV sym3 operator+(sym3 a, sym3 b) {
+  sym3 r; r.xx = a.xx + b.xx; r.xy = a.xy + b.xy; r.xz = a.xz + b.xz; r.yy = a.yy + b.yy; r.yz = a.yz + b.yz; r.zz = a.zz + b.zz;
+  return r;
+}
+// I = Ix ex ex^T + Iy ey ey^T + Iz ez ez^T + Iyz (ey ez^T + ez ey^T): body inertia rotated into the base frame
+IRRL_DEV sym3 rot_inertia(v3 ex, v3 ey, v3 ez, vf Ix, vf Iy, vf Iz, vf Iyz) {
+  sym3 r;
+  r.xx = Ix * ex.x * ex.x + Iy * ey.x * ey.x + Iz * ez.x * ez.x + Iyz * (2.0f * ey.x * ez.x);
+  r.xy = Ix * ex.x * ex.y + Iy * ey.x * ey.y + Iz * ez.x * ez.y + Iyz * (ey.x * ez.y + ez.x * ey.y);
+  r.xz = Ix * ex.x * ex.z + Iy * ey.x * ey.z + Iz * ez.x * ez.z + Iyz * (ey.x * ez.z + ez.x * ey.z);
+  r.yy = Ix * ex.y * ex.y + Iy * ey.y * ey.y + Iz * ez.y * ez.y + Iyz * (2.0f * ey.y * ez.y);
+  r.yz = Ix * ex.y * ex.z + Iy * ey.y * ey.z + Iz * ez.y * ez.z + Iyz * (ey.y * ez.z + ez.y * ey.z);
+  r.zz = Ix * ex.z * ex.z + Iy * ey.z * ey.z + Iz * ez.z * ez.z + Iyz * (2.0f * ey.z * ez.z);
+  return r;
+}
+// inertia about the base origin: I_B + m (|c|^2 1 - c c^T)
+IRRL_DEV sym3 shift_to_origin(sym3 I, vf m, v3 c) {
+  vf cc = dot(c, c);
+  sym3 r;
+  r.xx = I.xx + m * (cc - c.x * c.x); r.xy = I.xy - m * c.x * c.y; r.xz = I.xz - m * c.x * c.z;
+  r.yy = I.yy + m * (cc - c.y * c.y); r.yz = I.yz - m * c.y * c.z; r.zz = I.zz + m * (cc - c.z * c.z);
+  return r;
+}
+IRRL_DEV v3 quad_sum3(v3 a) { return mk3(quad_sum(a.x), quad_sum(a.y), quad_sum(a.z)); }
+
+// rotation matrix body->world from quaternion (w,x,y,z); rows r0,r1,r2
+struct rot3 { v3 r0, r1, r2; };
+IRRL_DEV rot3 quat_to_rot(vf w, vf x, vf y, vf z) {
+  rot3 R;
+  R.r0 = mk3(1.0f - 2.0f * (y * y + z * z), 2.0f * (x * y - w * z), 2.0f * (x * z + w * y));
+  R.r1 = mk3(2.0f * (x * y + w * z), 1.0f - 2.0f * (x * x + z * z), 2.0f * (y * z - w * x));
+  R.r2 = mk3(2.0f * (x * z - w * y), 2.0f * (y * z + w * x), 1.0f - 2.0f * (x * x + y * y));
+  return R;
+}
+IRRL_DEV v3 rot_mul(rot3 R, v3 v) { return mk3(dot(R.r0, v), dot(R.r1, v), dot(R.r2, v)); }          // R v
+IRRL_DEV v3 rot_tmul(rot3 R, v3 v) {                                                                  // R^T v
+  return mk3(R.r0.x * v.x + R.r1.x * v.y + R.r2.x * v.z, R.r0.y * v.x + R.r1.y * v.y + R.r2.y * v.z,
+             R.r0.z * v.x + R.r1.z * v.y + R.r2.z * v.z);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 counter RNG: counter = (env, episode, step, purpose), key = (seed, "IRR1")
+// ---------------------------------------------------------------------------------------------
+struct rng4 { vf u0, u1, u2, u3; };
+IRRL_DEV rng4 philox_u01(vu seed, vu env, vu episode, vu step, vu purpose) {
+  vu c0 = env, c1 = episode, c2 = step, c3 = purpose;
+  vu k0 = seed, k1 = 0x49525231u;
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    vu hi0 = mulhi_u32(c0, 0xD2511F53u), lo0 = c0 * 0xD2511F53u;
+    vu hi1 = mulhi_u32(c2, 0xCD9E8D57u), lo1 = c2 * 0xCD9E8D57u;
+    vu n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 = k0 + 0x9E3779B9u; k1 = k1 + 0xBB67AE85u;
+  }
+  const float s = 1.0f / 16777216.0f;
+  rng4 o;
+  o.u0 = u2f(c0 >> 8) * s; o.u1 = u2f(c1 >> 8) * s; o.u2 = u2f(c2 >> 8) * s; o.u3 = u2f(c3 >> 8) * s;
+  return o;
+}
+// 16 consecutive uniforms (purposes p .. p+3): lane l of the quad generates block l, DPP broadcasts
+// make all 16 visible to every lane.  out[i] == slot (i&3) of purpose p + (i>>2).
+IRRL_DEV void quad_rng16(vu seed, vu env, vu episode, vu step, vu purpose, vf out[16]) {
+  rng4 r = philox_u01(seed, env, episode, step, purpose + to_u(leg_id()));
+  out[0] = quad_bcast<0>(r.u0); out[1] = quad_bcast<0>(r.u1); out[2] = quad_bcast<0>(r.u2); out[3] = quad_bcast<0>(r.u3);
+  out[4] = quad_bcast<1>(r.u0); out[5] = quad_bcast<1>(r.u1); out[6] = quad_bcast<1>(r.u2); out[7] = quad_bcast<1>(r.u3);
+  out[8] = quad_bcast<2>(r.u0); out[9] = quad_bcast<2>(r.u1); out[10] = quad_bcast<2>(r.u2); out[11] = quad_bcast<2>(r.u3);
+  out[12] = quad_bcast<3>(r.u0); out[13] = quad_bcast<3>(r.u1); out[14] = quad_bcast<3>(r.u2); out[15] = quad_bcast<3>(r.u3);
+}
+// pick element (3*leg + k) of a 12-vector that every lane holds
+IRRL_DEV vf pick_leg(const vf v[12], vi leg, int k) {
+  return vsel(leg == 0, v[k], vsel(leg == 1, v[3 + k], vsel(leg == 2, v[6 + k], v[9 + k])));
+}
+IRRL_DEV vf pick4(vf a, vf b, vf c, vf d, vi leg) { return vsel(leg == 0, a, vsel(leg == 1, b, vsel(leg == 2, c, d))); }
+
+// ---------------------------------------------------------------------------------------------
+// robot model constants (black_panther.urdf:18-165; numbers in SURVEY 8a-M)
+// ---------------------------------------------------------------------------------------------
+#define IRRL_PI_REF 3.1415926f          /* ENV:45 */
+#define IRRL_TOE_RADIUS 0.0275f         /* URDF:148 */
+#define IRRL_TOE_Z (-0.19f)             /* URDF:163 */
+#define IRRL_GRAV 9.81f
+#define IRRL_L_HIP 0.085f               /* ENV:1949-1952 */
+#define IRRL_L_THIGH 0.209f
+#define IRRL_L_CALF 0.2175f
+
+// per-lane (per-leg) model + the shared base body
+struct LegModel {
+  vf mA, mT, mS;          // abad, thigh, shank(+toe) masses
+  v3 comA, comT, comS;    // COMs in the body frames
+  vf m0; v3 com0;         // base body
+  vf mu, rest, rest_thr;  // contact material
+  vf dz;                  // shank-joint z offset (ENV:472-476)
+  vf sf, sy;              // +1 front / -1 hind ; -1 right / +1 left
+};
+// shank + toe merged through the fixed joint (URDF:104-165): inertia about the merged COM (z axis only moves)
+#define IRRL_S_M1 0.064f
+#define IRRL_S_Z1 (-0.0865f)
+#define IRRL_S_M2 0.05f
+#define IRRL_S_Z2 (-0.19f)
+
+IRRL_DEV void model_signs(LegModel &m, vi leg) {
+  m.sf = vsel(leg < 2, 1.0f, -1.0f);
+  m.sy = vsel((leg & 1) == 0, -1.0f, 1.0f);
+}
+IRRL_DEV void model_nominal(LegModel &m, vi leg) {
+  model_signs(m, leg);
+  m.m0 = 3.72f; m.com0 = mk3(0.0f, 0.0f, -0.003f);
+  m.mA = 0.54f; m.comA = mk3(m.sf * 0.058f, m.sy * 0.00485f, 0.0f);
+  m.mT = 0.636f; m.comT = mk3(0.0f, -m.sy * 0.019f, -0.01865f);
+  const float mt = IRRL_S_M1 + IRRL_S_M2;
+  const float zc = (IRRL_S_M1 * IRRL_S_Z1 + IRRL_S_M2 * IRRL_S_Z2) / mt;
+  m.mS = mt; m.comS = mk3(0.0f, 0.0f, zc);
+  m.mu = 0.6f; m.rest = 0.2f; m.rest_thr = 0.01f;  // ENV:433
+  m.dz = 0.0f;
+}
+// ENV:435-477 with the counter RNG (purposes DR_*); identical draw addresses in the oracle
+IRRL_DEV void model_randomize(LegModel &m, vi leg, vu seed, vu env, vu episode) {
+  model_nominal(m, leg);
+  vf u[16];
+  rng4 r = philox_u01(seed, env, episode, 0u, IRRL_P_DR_MATERIAL);
+  m.mu = r.u0 * 0.6f + 0.4f; m.rest = r.u1 * 0.3f; m.rest_thr = r.u2 * 2.0f;
+  quad_rng16(seed, env, episode, 0u, IRRL_P_DR_MASS, u);
+  vf f[13];
+#pragma unroll
+  for (int i = 0; i < 13; i++) f[i] = (u[i] - 0.5f) / 0.5f * 0.15f + 1.0f;
+  m.m0 = m.m0 * f[0];
+  m.mA = m.mA * pick4(f[1], f[4], f[7], f[10], leg);
+  m.mT = m.mT * pick4(f[2], f[5], f[8], f[11], leg);
+  m.mS = m.mS * pick4(f[3], f[6], f[9], f[12], leg);
+  vf c[48];
+  quad_rng16(seed, env, episode, 0u, IRRL_P_DR_COM, c);
+  quad_rng16(seed, env, episode, 0u, IRRL_P_DR_COM + 4u, c + 16);
+  quad_rng16(seed, env, episode, 0u, IRRL_P_DR_COM + 8u, c + 32);
+#pragma unroll
+  for (int i = 0; i < 39; i++) c[i] = (2.0f * c[i] - 1.0f) * 0.02f;
+  m.com0 = m.com0 + mk3(c[0], c[1], c[2]);
+  // body index of leg l: abad 1+3l, thigh 2+3l, shank 3+3l -> element 3*body + axis
+  m.comA = m.comA + mk3(pick4(c[3], c[12], c[21], c[30], leg), pick4(c[4], c[13], c[22], c[31], leg), pick4(c[5], c[14], c[23], c[32], leg));
+  m.comT = m.comT + mk3(pick4(c[6], c[15], c[24], c[33], leg), pick4(c[7], c[16], c[25], c[34], leg), pick4(c[8], c[17], c[26], c[35], leg));
+  m.comS = m.comS + mk3(pick4(c[9], c[18], c[27], c[36], leg), pick4(c[10], c[19], c[28], c[37], leg), pick4(c[11], c[20], c[29], c[38], leg));
+  rng4 t = philox_u01(seed, env, episode, 0u, IRRL_P_DR_THIGH);
+  m.dz = (t.u0 - 0.5f) / 0.5f * 0.01f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// curve helpers / IK / torque clamp (ENV:86-156, 1273-1312, 1687-1751)
+// ---------------------------------------------------------------------------------------------
+IRRL_DEV vf bezier_w(vf s) { return s * s * s + 3.0f * (s * s * (1.0f - s)); }
+IRRL_DEV vf gauss_bump(vf x, vf width, vf height) {
+  return height * v_exp(-(x - width / 2.0f) * (x - width / 2.0f) / (2.0f * (width / 6.0f) * (width / 6.0f)));
+}
+IRRL_DEV vf smooth_raw(vf phase, vf slope, vf lam) {
+  vf f = v_fmod(phase, 1.0f);
+  vf a = (v_sin(f / lam * 2.0f * IRRL_PI_REF) * slope) + 0.5f;
+  vf b = (-v_sin((f - lam) / (1.0f - lam) * 2.0f * IRRL_PI_REF) * slope) + 0.5f;
+  return vsel(f < lam, a, b);
+}
+IRRL_DEV vf smooth_function(vf phase, vf slope, vf lam) {
+  vf t = smooth_raw(phase, slope, lam);
+  return vsel(t > 1.0f, 1.0f, vsel(t < 0.0f, 0.0f, t));
+}
+IRRL_DEV vf smooth_function2(vf phase, vf slope, vf lam) {
+  vf t = smooth_raw(phase, slope, lam);
+  return vsel(t > 1.0f, 0.0f, vsel(t < 0.0f, 1.0f, 1.0f - t));
+}
+// ENV:1687-1751.  th0/th1/th2 hold the previous ("stale") values on entry; `valid*` report which
+// slots were overwritten so the caller can reproduce the shared temp[3] chaining across legs.
+IRRL_DEV void inverse_kinematics(vf x, vf y, vf z, vf max_len, vm is_right, vf &th0, vf &th1, vf &th2, vm &ok0, vm &ok1, vm &ok2) {
+  const float l_hip = IRRL_L_HIP, l_thigh = IRRL_L_THIGH, l_calf = IRRL_L_CALF;
+  vf ll = v_sqrt(x * x + y * y + z * z);
+  vm too_long = ll > max_len;
+  vf sc = (max_len - 1e-5f) / ll;
+  x = vsel(too_long, x * sc, x); y = vsel(too_long, y * sc, y); z = vsel(too_long, z * sc, z);
+  vf root = v_sqrt(y * y * (z * z + y * y - l_hip * l_hip));
+  vf den = z * z + y * y;
+  vf temp = vsel(is_right, (-z * l_hip - root) / den, (z * l_hip + root) / den);
+  ok0 = v_abs(temp) <= 1.0f;
+  th0 = vsel(ok0, v_asin(temp), th0);
+  vf lr = v_sqrt(x * x + y * y + z * z - l_hip * l_hip);
+  lr = vsel(lr > (l_thigh + l_calf), (l_thigh + l_calf - 1e-4f), lr);
+  vf t2 = (l_thigh * l_thigh + l_calf * l_calf - lr * lr) / 2.0f / l_thigh / l_calf + 1e-5f;
+  ok2 = v_abs(t2) <= 1.0f;
+  th2 = vsel(ok2, -(IRRL_PI_REF - v_acos(t2)), th2);
+  vf a1 = x / lr;
+  vf a2 = (lr * lr + l_thigh * l_thigh - l_calf * l_calf) / 2.0f / lr / l_thigh - 1e-5f;
+  ok1 = (v_abs(a1) <= 1.0f) & (v_abs(a2) <= 1.0f);
+  th1 = vsel(ok1, v_acos(a2) - v_asin(a1), th1);
+}
+// ENV:1273-1312 for one joint; knee (k == 2) carries the 1.55f ratio
+IRRL_DEV vf torque_clamp1(vf tau, vf qd, int k, const EnvParams &P) {
+  const float ratio = (k == 2) ? 1.55f : 1.0f;
+  float r = P.tau_max / (P.w_max - P.w_crit);
+  vf w = qd * ratio;
+  vf up = vsel(w > P.w_crit, P.tau_max - (w - P.w_crit) * r, P.tau_max) * ratio;
+  vf low = vsel(w < -P.w_crit, (-P.w_max - w) / (-P.w_max + P.w_crit) * -P.tau_max, -P.tau_max) * ratio;
+  return v_max(v_min(tau, up), low);
+}
+
+// ---------------------------------------------------------------------------------------------
+// lane context: everything one leg-lane keeps in registers across the step
+// ---------------------------------------------------------------------------------------------
+struct EnvLane {
+  // leg-local
+  vf q[3], qd[3];
+  vf ptl[3], tql[3], tq[3];
+  vf jr[3], jrl[3], jdr[3], eer[3];
+  vf lamw[3];
+  vi in_contact; vf contact;
+  // per-env (replicated in the 4 lanes of the quad)
+  v3 pos; vf qw, qx, qy, qz; v3 vw, ww;
+  vf cmd[3], cmdf[3];
+  vf t0; vi frame; vu episode; vf up_height;
+  vf ob_cmd[3], ob_phase[2], ob_post[3], ob_omega[3];  // env-level part of the raw observation
+  vf ob_q[3], ob_qd[3];                                // leg-level part (joint angles / rates + noise)
+  vf obl_env[11], obl_q[3], obl_qd[3];                 // obDouble_last_ (only meaningful with ObsFilter)
+  LegModel m;
+  // scratch carried from the dynamics to the epilogue
+  v3 bodyLinVel, bodyAngVel;
+};
+
+// leg kinematics in the base frame
+struct LegKin {
+  v3 ay, az;            // abad frame axes (ax = e_x)
+  v3 tx, tz;            // thigh frame axes (ty = ay)
+  v3 sx, sz;            // shank frame axes (sy = ay)
+  v3 h;                 // hip / knee joint axis = -ay
+  v3 pA, pT, pS, ptoe;  // joint origins and toe frame origin
+};
+IRRL_DEV LegKin leg_fk(const LegModel &m, vf q0, vf q1, vf q2) {
+  LegKin k;
+  vf s0, c0, s1, c1, s12, c12;
+  v_sincos(q0, s0, c0); v_sincos(q1, s1, c1); v_sincos(q1 + q2, s12, c12);
+  k.ay = mk3(0.0f, c0, s0); k.az = mk3(0.0f, -s0, c0);
+  k.tx = mk3(c1, -s0 * s1, c0 * s1); k.tz = mk3(-s1, -s0 * c1, c0 * c1);
+  k.sx = mk3(c12, -s0 * s12, c0 * s12); k.sz = mk3(-s12, -s0 * c12, c0 * c12);
+  k.h = mk3(0.0f, -c0, -s0);
+  k.pA = mk3(m.sf * 0.212f, m.sy * 0.051f, 0.0f);
+  k.pT = k.pA + (m.sy * 0.085f) * k.ay;
+  k.pS = k.pT + (-0.201f + m.dz) * k.tz;
+  k.ptoe = k.pS + IRRL_TOE_Z * k.sz;
+  return k;
+}
+
+// Everything the velocity update needs from the factorised dynamics.
+struct LegDyn {
+  vf L6[21];      // Cholesky factor of the 6x6 base Schur complement, lower-tri row-major, diagonal stored INVERTED
+  sym3 Ci;        // C_l^-1
+  vf X[6][3];     // B_l C_l^-1  (so D_l = X^T)
+  vf bias_b[6];   // base rows of b (quad-reduced)
+  vf bias_l[3];   // leg rows of b
+};
+#define L6I(i, j) ((i) * ((i) + 1) / 2 + (j))
+
+// forward substitution L y = r (diagonal already inverted)
+IRRL_DEV void l6_fwd(const vf L[21], vf r[6]) {
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    vf v = r[i];
+#pragma unroll
+    for (int j = 0; j < i; j++) v -= L[L6I(i, j)] * r[j];
+    r[i] = v * L[L6I(i, i)];
+  }
+}
+// back substitution L^T x = y
+IRRL_DEV void l6_bwd(const vf L[21], vf r[6]) {
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    vf v = r[i];
+#pragma unroll
+    for (int j = i + 1; j < 6; j++) v -= L[L6I(j, i)] * r[j];
+    r[i] = v * L[L6I(i, i)];
+  }
+}
+
+// CRBA + RNEA + Schur factorisation for the whole robot, leg-parallel.
+// wB: base angular velocity (base comps), a0: fictitious base acceleration = 9.81 * R^T e_z.
+IRRL_DEV void leg_dynamics(const LegModel &m, const LegKin &k, const vf qd[3], v3 wB, v3 a0, LegDyn &D) {
+  const v3 ex = mk3(1.0f, 0.0f, 0.0f);
+  // ---- body COMs and inertias in the base frame ----
+  v3 rcA = m.comA.x * ex + m.comA.y * k.ay + m.comA.z * k.az;
+  v3 rcT = m.comT.x * k.tx + m.comT.y * k.ay + m.comT.z * k.tz;
+  v3 rcS = m.comS.x * k.sx + m.comS.y * k.ay + m.comS.z * k.sz;
+  v3 cA = k.pA + rcA, cT = k.pT + rcT, cS = k.pS + rcS;
+  sym3 IA = rot_inertia(ex, k.ay, k.az, 0.000391f, 0.000739f, 0.000488f, 0.0f);                 // URDF:62
+  sym3 IT = rot_inertia(k.tx, k.ay, k.tz, 0.001724f, 0.001907f, 0.000468f, -m.sy * 0.000228f);  // URDF:90
+  const float zc = (IRRL_S_M1 * IRRL_S_Z1 + IRRL_S_M2 * IRRL_S_Z2) / (IRRL_S_M1 + IRRL_S_M2);
+  const float d1 = IRRL_S_Z1 - zc, d2 = IRRL_S_Z2 - zc;
+  const float ISx = 0.000716f + IRRL_S_M1 * d1 * d1 + 0.000025f + IRRL_S_M2 * d2 * d2;           // URDF:116,153
+  const float ISy = 0.000721f + IRRL_S_M1 * d1 * d1 + 0.000025f + IRRL_S_M2 * d2 * d2;
+  const float ISz = 0.000012f + 0.000025f;
+  sym3 IS = rot_inertia(k.sx, k.ay, k.sz, ISx, ISy, ISz, 0.0f);
+
+  // ---- CRBA: composite (mass, first moment, inertia about the base origin) up the chain ----
+  vf mcS = m.mS, mcT = m.mT + m.mS, mcA = m.mA + mcT;
+  v3 hS = m.mS * cS, hT = m.mT * cT + hS, hA = m.mA * cA + hT;
+  sym3 IoS = shift_to_origin(IS, m.mS, cS);
+  sym3 IoT = shift_to_origin(IT, m.mT, cT) + IoS;
+  sym3 IoA = shift_to_origin(IA, m.mA, cA) + IoT;
+  // columns: P_j = s_j x (h_j - m_j p_j),  L_j = Io_j s_j - h_j x (s_j x p_j)
+  v3 PA = cross(ex, hA - mcA * k.pA), LA = mul(IoA, ex) - cross(hA, cross(ex, k.pA));
+  v3 PT = cross(k.h, hT - mcT * k.pT), LT = mul(IoT, k.h) - cross(hT, cross(k.h, k.pT));
+  v3 PS = cross(k.h, hS - mcS * k.pS), LS = mul(IoS, k.h) - cross(hS, cross(k.h, k.pS));
+  vf B[6][3];
+  B[0][0] = PA.x; B[1][0] = PA.y; B[2][0] = PA.z; B[3][0] = LA.x; B[4][0] = LA.y; B[5][0] = LA.z;
+  B[0][1] = PT.x; B[1][1] = PT.y; B[2][1] = PT.z; B[3][1] = LT.x; B[4][1] = LT.y; B[5][1] = LT.z;
+  B[0][2] = PS.x; B[1][2] = PS.y; B[2][2] = PS.z; B[3][2] = LS.x; B[4][2] = LS.y; B[5][2] = LS.z;
+  // C_l (3x3 sym): M[k,j] = s_k . (L_j - p_k x P_j), rotor inertia on the diagonal (URDF:56,84,110)
+  vf C00 = dot(ex, LA - cross(k.pA, PA)) + 0.003708f;
+  vf C01 = dot(ex, LT - cross(k.pA, PT));
+  vf C02 = dot(ex, LS - cross(k.pA, PS));
+  vf C11 = dot(k.h, LT - cross(k.pT, PT)) + 0.003708f;
+  vf C12 = dot(k.h, LS - cross(k.pT, PS));
+  vf C22 = dot(k.h, LS - cross(k.pS, PS)) + 0.008966f;
+  // inverse of the symmetric 3x3 by cofactors
+  {
+    vf a = C11 * C22 - C12 * C12, b = C02 * C12 - C01 * C22, c = C01 * C12 - C02 * C11;
+    vf idet = v_rcp(C00 * a + C01 * b + C02 * c);
+    D.Ci.xx = a * idet; D.Ci.xy = b * idet; D.Ci.xz = c * idet;
+    D.Ci.yy = (C00 * C22 - C02 * C02) * idet; D.Ci.yz = (C01 * C02 - C00 * C12) * idet; D.Ci.zz = (C00 * C11 - C01 * C01) * idet;
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    D.X[i][0] = B[i][0] * D.Ci.xx + B[i][1] * D.Ci.xy + B[i][2] * D.Ci.xz;
+    D.X[i][1] = B[i][0] * D.Ci.xy + B[i][1] * D.Ci.yy + B[i][2] * D.Ci.yz;
+    D.X[i][2] = B[i][0] * D.Ci.xz + B[i][1] * D.Ci.yz + B[i][2] * D.Ci.zz;
+  }
+  // ---- base block from the quad-reduced whole-robot composite ----
+  vf mtot = m.m0 + quad_sum(mcA);
+  v3 htot = m.m0 * m.com0 + quad_sum3(hA);
+  sym3 I0;  // base body inertia about its COM is diagonal in the base frame (URDF:21)
+  I0.xx = 0.016269f; I0.xy = 0.0f; I0.xz = 0.0f; I0.yy = 0.050813f; I0.yz = 0.0f; I0.zz = 0.060989f;
+  sym3 Io0 = shift_to_origin(I0, m.m0, m.com0);
+  sym3 Iot;
+  Iot.xx = Io0.xx + quad_sum(IoA.xx); Iot.xy = Io0.xy + quad_sum(IoA.xy); Iot.xz = Io0.xz + quad_sum(IoA.xz);
+  Iot.yy = Io0.yy + quad_sum(IoA.yy); Iot.yz = Io0.yz + quad_sum(IoA.yz); Iot.zz = Io0.zz + quad_sum(IoA.zz);
+  // Schur complement S = A - sum_l X_l B_l^T  (lower triangle, 21 entries)
+  vf S[21];
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++) S[L6I(i, j)] = quad_sum(D.X[i][0] * B[j][0] + D.X[i][1] * B[j][1] + D.X[i][2] * B[j][2]);
+  // A = [[m 1, -[h]x], [[h]x, Io]] ; lower triangle: rows 3-5 x cols 0-2 hold [h]x
+  vf A[21];
+#pragma unroll
+  for (int i = 0; i < 21; i++) A[i] = 0.0f;
+  A[L6I(0, 0)] = mtot; A[L6I(1, 1)] = mtot; A[L6I(2, 2)] = mtot;
+  A[L6I(3, 1)] = -htot.z; A[L6I(3, 2)] = htot.y;
+  A[L6I(4, 0)] = htot.z; A[L6I(4, 2)] = -htot.x;
+  A[L6I(5, 0)] = -htot.y; A[L6I(5, 1)] = htot.x;
+  A[L6I(3, 3)] = Iot.xx; A[L6I(4, 3)] = Iot.xy; A[L6I(4, 4)] = Iot.yy; A[L6I(5, 3)] = Iot.xz; A[L6I(5, 4)] = Iot.yz; A[L6I(5, 5)] = Iot.zz;
+#pragma unroll
+  for (int i = 0; i < 21; i++) S[i] = A[i] - S[i];
+  // Cholesky S = L L^T, diagonal stored inverted
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    vf d = S[L6I(j, j)];
+#pragma unroll
+    for (int c = 0; c < j; c++) d -= D.L6[L6I(j, c)] * D.L6[L6I(j, c)];
+    vf inv = v_rcp(v_sqrt(d));
+    D.L6[L6I(j, j)] = inv;
+#pragma unroll
+    for (int i = j + 1; i < 6; i++) {
+      vf v = S[L6I(i, j)];
+#pragma unroll
+      for (int c = 0; c < j; c++) v -= D.L6[L6I(i, c)] * D.L6[L6I(j, c)];
+      D.L6[L6I(i, j)] = v * inv;
+    }
+  }
+
+  // ---- RNEA bias (classical Newton-Euler, gravity folded into a0) ----
+  v3 sq0 = mk3(qd[0], 0.0f, 0.0f);
+  v3 wA = wB + sq0;
+  v3 alA = cross(wB, sq0);
+  v3 aA = a0 + cross(wB, cross(wB, k.pA));
+  v3 sq1 = qd[1] * k.h;
+  v3 dT = k.pT - k.pA;
+  v3 wT = wA + sq1;
+  v3 alT = alA + cross(wA, sq1);
+  v3 aT = aA + cross(alA, dT) + cross(wA, cross(wA, dT));
+  v3 sq2 = qd[2] * k.h;
+  v3 dS = k.pS - k.pT;
+  v3 wS = wT + sq2;
+  v3 alS = alT + cross(wT, sq2);
+  v3 aS = aT + cross(alT, dS) + cross(wT, cross(wT, dS));
+  v3 fA = m.mA * (aA + cross(alA, rcA) + cross(wA, cross(wA, rcA)));
+  v3 fT = m.mT * (aT + cross(alT, rcT) + cross(wT, cross(wT, rcT)));
+  v3 fS = m.mS * (aS + cross(alS, rcS) + cross(wS, cross(wS, rcS)));
+  v3 nA = mul(IA, alA) + cross(wA, mul(IA, wA)) + cross(rcA, fA);
+  v3 nT = mul(IT, alT) + cross(wT, mul(IT, wT)) + cross(rcT, fT);
+  v3 nS = mul(IS, alS) + cross(wS, mul(IS, wS)) + cross(rcS, fS);
+  D.bias_l[2] = dot(k.h, nS);
+  v3 NT = nT + nS + cross(dS, fS);
+  v3 FT = fT + fS;
+  D.bias_l[1] = dot(k.h, NT);
+  v3 NA = nA + NT + cross(dT, FT);
+  v3 FA = fA + FT;
+  D.bias_l[0] = NA.x;
+  v3 Nleg = NA + cross(k.pA, FA);
+  v3 f0 = m.m0 * (a0 + cross(wB, cross(wB, m.com0)));
+  v3 n0 = cross(wB, mul(I0, wB)) + cross(m.com0, f0);
+  v3 Fb = f0 + quad_sum3(FA);
+  v3 Nb = n0 + quad_sum3(Nleg);
+  D.bias_b[0] = Fb.x; D.bias_b[1] = Fb.y; D.bias_b[2] = Fb.z; D.bias_b[3] = Nb.x; D.bias_b[4] = Nb.y; D.bias_b[5] = Nb.z;
+}
+
+// x = M_B^-1 r for r = (rb: shared base rows, rl: this leg's rows).  Results: xb (replicated), xl.
+IRRL_DEV void solve_M(const LegDyn &D, const vf rb[6], const vf rl[3], vf xb[6], vf xl[3]) {
+#pragma unroll
+  for (int i = 0; i < 6; i++) xb[i] = rb[i] - quad_sum(D.X[i][0] * rl[0] + D.X[i][1] * rl[1] + D.X[i][2] * rl[2]);
+  l6_fwd(D.L6, xb);
+  l6_bwd(D.L6, xb);
+  vf c0 = D.Ci.xx * rl[0] + D.Ci.xy * rl[1] + D.Ci.xz * rl[2];
+  vf c1 = D.Ci.xy * rl[0] + D.Ci.yy * rl[1] + D.Ci.yz * rl[2];
+  vf c2 = D.Ci.xz * rl[0] + D.Ci.yz * rl[1] + D.Ci.zz * rl[2];
+#pragma unroll
+  for (int i = 0; i < 6; i++) { c0 -= D.X[i][0] * xb[i]; c1 -= D.X[i][1] * xb[i]; c2 -= D.X[i][2] * xb[i]; }
+  xl[0] = c0; xl[1] = c1; xl[2] = c2;
+}
+
+// one-contact solve (same branch structure as the oracle's solve_contact)
+IRRL_DEV v3 solve_contact(sym3 G, v3 c, v3 n, vf vstar, vf mu) {
+  vf cn = dot(c, n) - vstar;
+  v3 rhs = mk3(-(c.x - vstar * n.x), -(c.y - vstar * n.y), -(c.z - vstar * n.z));
+  // G^-1 rhs by cofactors (symmetric)
+  vf a = G.yy * G.zz - G.yz * G.yz, b = G.xz * G.yz - G.xy * G.zz, cc = G.xy * G.yz - G.xz * G.yy;
+  vf idet = v_rcp(G.xx * a + G.xy * b + G.xz * cc);
+  vf e = G.xx * G.zz - G.xz * G.xz, f = G.xy * G.xz - G.xx * G.yz, g = G.xx * G.yy - G.xy * G.xy;
+  v3 l = mk3((a * rhs.x + b * rhs.y + cc * rhs.z) * idet, (b * rhs.x + e * rhs.y + f * rhs.z) * idet, (cc * rhs.x + f * rhs.y + g * rhs.z) * idet);
+  v3 Gn = mul(G, n);
+  vf nGn = dot(n, Gn);
+  v3 frictionless = (-cn / nGn) * n;
+  vf ln = dot(l, n);
+  v3 lt = l - ln * n;
+  vf lt2 = dot(lt, lt);
+  vm sticking = lt2 <= mu * mu * ln * ln;
+  vf inv = v_rcp(v_sqrt(lt2));
+  v3 w = n + (mu * inv) * lt;
+  vf nGw = dot(n, mul(G, w));
+  // select chain in the oracle's priority order
+  vm sep = cn >= 0.0f;
+  vm pull = ln <= 0.0f;
+  vm degenerate = nGw <= 1e-6f * nGn;
+  v3 slide = mk3(vsel(degenerate, frictionless.x, (-cn / nGw) * w.x), vsel(degenerate, frictionless.y, (-cn / nGw) * w.y), vsel(degenerate, frictionless.z, (-cn / nGw) * w.z));
+  v3 r;
+  r.x = vsel(sep, 0.0f, vsel(pull, frictionless.x, vsel(sticking, l.x, slide.x)));
+  r.y = vsel(sep, 0.0f, vsel(pull, frictionless.y, vsel(sticking, l.y, slide.y)));
+  r.z = vsel(sep, 0.0f, vsel(pull, frictionless.z, vsel(sticking, l.z, slide.z)));
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// one physics substep (ENV:761-768): PD + clamp, then the build's integrate()
+// ---------------------------------------------------------------------------------------------
+IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
+  const float dt = P.sim_dt;
+  // PD law, 1 % blend with the normalised torque_last, speed-dependent clamp
+  vf tau[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    vf t = (pT[k] - L.q[k]) * P.kp[k] - L.qd[k] * P.kd[k];
+    t = 0.99f * t + (1.0f - 0.99f) * L.tql[k];
+    tau[k] = torque_clamp1(t, L.qd[k], k, P);
+    L.tq[k] = tau[k];
+  }
+  rot3 R = quat_to_rot(L.qw, L.qx, L.qy, L.qz);
+  v3 nB = R.r2;                          // R^T e_z
+  v3 vB = rot_tmul(R, L.vw), wB = rot_tmul(R, L.ww);
+  v3 a0 = IRRL_GRAV * nB;
+  LegKin k = leg_fk(L.m, L.q[0], L.q[1], L.q[2]);
+  LegDyn D;
+  leg_dynamics(L.m, k, L.qd, wB, a0, D);
+  // free velocity u_free = u + dt M^-1 (tau - damping qd - b)
+  vf rb[6], rl[3], xb[6], xl[3];
+#pragma unroll
+  for (int i = 0; i < 6; i++) rb[i] = -D.bias_b[i];
+#pragma unroll
+  for (int j = 0; j < 3; j++) rl[j] = tau[j] - 0.01f * L.qd[j] - D.bias_l[j];  // joint damping URDF:56
+  solve_M(D, rb, rl, xb, xl);
+  vf ub[6], ul[3];
+  ub[0] = vB.x + dt * xb[0]; ub[1] = vB.y + dt * xb[1]; ub[2] = vB.z + dt * xb[2];
+  ub[3] = wB.x + dt * xb[3]; ub[4] = wB.y + dt * xb[4]; ub[5] = wB.z + dt * xb[5];
+#pragma unroll
+  for (int j = 0; j < 3; j++) ul[j] = L.qd[j] + dt * xl[j];
+
+  // ---- contact: toe sphere against the plane z = 0 ----
+  vf gap = L.pos.z + dot(nB, k.ptoe) - IRRL_TOE_RADIUS;
+  vm active = gap <= 0.0f;
+  if (wave_any(active)) {
+    v3 x = k.ptoe - IRRL_TOE_RADIUS * nB;
+    // leg columns of the contact Jacobian
+    v3 jA = cross(mk3(1.0f, 0.0f, 0.0f), x - k.pA), jT = cross(k.h, x - k.pT), jS = cross(k.h, x - k.pS);
+    vf Jl[3][3] = {{jA.x, jT.x, jS.x}, {jA.y, jT.y, jS.y}, {jA.z, jT.z, jS.z}};
+    // base columns [1 | -[x]x]
+    vf Jb[3][6] = {{1.0f, 0.0f, 0.0f, 0.0f, x.z, -x.y}, {0.0f, 1.0f, 0.0f, -x.z, 0.0f, x.x}, {0.0f, 0.0f, 1.0f, x.y, -x.x, 0.0f}};
+    // K = Jb - Jl D, Y = L^-1 K^T
+    vf Y[3][6];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) Y[r][i] = Jb[r][i] - (Jl[r][0] * D.X[i][0] + Jl[r][1] * D.X[i][1] + Jl[r][2] * D.X[i][2]);
+      l6_fwd(D.L6, Y[r]);
+    }
+    // JC = Jl C^-1, E = JC Jl^T, G = Y Y^T + E
+    vf JC[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      JC[r][0] = Jl[r][0] * D.Ci.xx + Jl[r][1] * D.Ci.xy + Jl[r][2] * D.Ci.xz;
+      JC[r][1] = Jl[r][0] * D.Ci.xy + Jl[r][1] * D.Ci.yy + Jl[r][2] * D.Ci.yz;
+      JC[r][2] = Jl[r][0] * D.Ci.xz + Jl[r][1] * D.Ci.yz + Jl[r][2] * D.Ci.zz;
+    }
+    vf Gm[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = r; c < 3; c++) {
+        vf acc = JC[r][0] * Jl[c][0] + JC[r][1] * Jl[c][1] + JC[r][2] * Jl[c][2];
+#pragma unroll
+        for (int i = 0; i < 6; i++) acc += Y[r][i] * Y[c][i];
+        Gm[r][c] = acc;
+      }
+    sym3 G; G.xx = Gm[0][0]; G.xy = Gm[0][1]; G.xz = Gm[0][2]; G.yy = Gm[1][1]; G.yz = Gm[1][2]; G.zz = Gm[2][2];
+    // contact-point velocities: before the step (restitution) and free
+    vf vpre[3], cfree[3];
+    const vf upre[6] = {vB.x, vB.y, vB.z, wB.x, wB.y, wB.z};
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      vf a1 = Jl[r][0] * L.qd[0] + Jl[r][1] * L.qd[1] + Jl[r][2] * L.qd[2];
+      vf a2 = Jl[r][0] * ul[0] + Jl[r][1] * ul[1] + Jl[r][2] * ul[2];
+#pragma unroll
+      for (int i = 0; i < 6; i++) { a1 += Jb[r][i] * upre[i]; a2 += Jb[r][i] * ub[i]; }
+      vpre[r] = a1; cfree[r] = a2;
+    }
+    vf vn = vpre[0] * nB.x + vpre[1] * nB.y + vpre[2] * nB.z;
+    vf vstar = vsel(vn < -L.m.rest_thr, -L.m.rest * vn, 0.0f);
+    // warm start (world -> base components); zero unless the foot was already in the contact list
+    v3 lam = rot_tmul(R, mk3(L.lamw[0], L.lamw[1], L.lamw[2]));
+    vm warm = active & (L.in_contact != 0);
+    lam.x = vsel(warm, lam.x, 0.0f); lam.y = vsel(warm, lam.y, 0.0f); lam.z = vsel(warm, lam.z, 0.0f);
+    // z = sum_l Y_l^T lam_l  (6-vector shared by the quad)
+    vf z[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) z[i] = quad_sum(Y[0][i] * lam.x + Y[1][i] * lam.y + Y[2][i] * lam.z);
+    // rank of this contact among the robot's active contacts (leg order FR,FL,HR,HL)
+    vi act_i = vsel_i(active, 1, 0);
+    vi a0i = quad_bcast_i<0>(act_i), a1i = quad_bcast_i<1>(act_i), a2i = quad_bcast_i<2>(act_i);
+    vi leg = leg_id();
+    vi rank = vsel_i(leg == 0, 0, vsel_i(leg == 1, a0i, vsel_i(leg == 2, a0i + a1i, a0i + a1i + a2i)));
+    int nrank = wave_max_small(quad_sum_i(act_i));
+    for (int it = 0; it < P.contact_iters; it++) {
+      for (int rk = 0; rk < nrank; rk++) {
+        // velocity at this contact without its own impulse: cfree + Y (z - Y^T lam) + ... (E cancels)
+        vf zo[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) zo[i] = z[i] - (Y[0][i] * lam.x + Y[1][i] * lam.y + Y[2][i] * lam.z);
+        v3 cv;
+        cv.x = cfree[0]; cv.y = cfree[1]; cv.z = cfree[2];
+#pragma unroll
+        for (int i = 0; i < 6; i++) { cv.x += Y[0][i] * zo[i]; cv.y += Y[1][i] * zo[i]; cv.z += Y[2][i] * zo[i]; }
+        v3 ln = solve_contact(G, cv, nB, vstar, L.m.mu);
+        vm commit = active & (rank == rk);
+        v3 dl = mk3(vsel(commit, ln.x - lam.x, 0.0f), vsel(commit, ln.y - lam.y, 0.0f), vsel(commit, ln.z - lam.z, 0.0f));
+        lam = lam + dl;
+#pragma unroll
+        for (int i = 0; i < 6; i++) z[i] += quad_sum(Y[0][i] * dl.x + Y[1][i] * dl.y + Y[2][i] * dl.z);
+      }
+    }
+    lam.x = vsel(active, lam.x, 0.0f); lam.y = vsel(active, lam.y, 0.0f); lam.z = vsel(active, lam.z, 0.0f);
+    // velocity update: base part L^-T z, leg part C^-1 Jl^T lam - D xb
+    vf xbc[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) xbc[i] = z[i];
+    l6_bwd(D.L6, xbc);
+#pragma unroll
+    for (int i = 0; i < 6; i++) ub[i] += xbc[i];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      vf v = JC[0][j] * lam.x + JC[1][j] * lam.y + JC[2][j] * lam.z;
+#pragma unroll
+      for (int i = 0; i < 6; i++) v -= D.X[i][j] * xbc[i];
+      ul[j] += v;
+    }
+    v3 lw = rot_mul(R, lam);
+    L.lamw[0] = lw.x; L.lamw[1] = lw.y; L.lamw[2] = lw.z;
+  } else {
+    L.lamw[0] = 0.0f; L.lamw[1] = 0.0f; L.lamw[2] = 0.0f;
+  }
+  L.in_contact = vsel_i(active, 1, 0);
+  // back to world-frame gv, then positions (semi-implicit Euler)
+  L.vw = rot_mul(R, mk3(ub[0], ub[1], ub[2]));
+  L.ww = rot_mul(R, mk3(ub[3], ub[4], ub[5]));
+#pragma unroll
+  for (int j = 0; j < 3; j++) { L.qd[j] = ul[j]; L.q[j] += dt * ul[j]; }
+  L.pos = L.pos + dt * L.vw;
+  {
+    vf hx = 0.5f * dt * L.ww.x, hy = 0.5f * dt * L.ww.y, hz = 0.5f * dt * L.ww.z;
+    vf w1 = L.qw - hx * L.qx - hy * L.qy - hz * L.qz;
+    vf x1 = L.qx + hx * L.qw + hy * L.qz - hz * L.qy;
+    vf y1 = L.qy - hx * L.qz + hy * L.qw + hz * L.qx;
+    vf z1 = L.qz + hx * L.qy - hy * L.qx + hz * L.qw;
+    vf inv = v_rcp(v_sqrt(w1 * w1 + x1 * x1 + y1 * y1 + z1 * z1));
+    L.qw = w1 * inv; L.qx = x1 * inv; L.qy = y1 * inv; L.qz = z1 * inv;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// task logic
+// ---------------------------------------------------------------------------------------------
+IRRL_DEV vf env_time(const EnvParams &P, const EnvLane &L) { return L.t0 + i2f(L.frame) * P.control_dt; }
+
+// ENV:1756-1890 for this lane's leg.  The reference keeps ONE temp[3] across the legs (and across the
+// two passes of the first call), so a failed asin/acos slot inherits the previous leg's angle: the
+// chain is replayed with three DPP hand-offs.
+IRRL_DEV void gait_leg_pass(const EnvParams &P, const EnvLane &L, vf t_eval, vf gait_step, vf side_step, vf rot_step, vf up_height,
+                            vf prev[3] /* temp[] entering leg 0 */, vf th_out[3], v3 &toe_out) {
+  vi leg = leg_id();
+  vf phase_l = pick4(P.phase[0], P.phase[1], P.phase[2], P.phase[3], leg);
+  vf rp = v_fmod(t_eval + phase_l * P.period, P.period) / P.period;
+  vf anti = vsel(leg < 2, 1.0f, -1.0f);
+  vf hx = gait_step / 2.0f, hy = side_step / 2.0f + anti * rot_step / 2.0f, hy2 = -side_step / 2.0f + -anti * rot_step / 2.0f;
+  // stance: bezier from (+hx, hy) to (-hx, hy2); swing: from (-hx, hy2) to (+hx, hy) with a gaussian lift
+  vm stance = rp < P.lam;
+  vf s = vsel(stance, rp / P.lam, (rp - P.lam) / (1.0f - P.lam));
+  vf bw = bezier_w(s);
+  vf p0x = vsel(stance, hx, -hx), pfx = vsel(stance, -hx, hx);
+  vf p0y = vsel(stance, hy, hy2), pfy = vsel(stance, hy2, hy);
+  v3 toe;
+  toe.x = p0x + bw * (pfx - p0x);
+  toe.y = p0y + bw * (pfy - p0y);
+  vf zst = -P.stand_height + bw * (-P.stand_height - -P.stand_height);
+  toe.z = vsel(stance, zst, -P.stand_height + gauss_bump(s, 1.0f, up_height));
+  vf toff = pick4(-IRRL_L_HIP + P.lean_front, IRRL_L_HIP - P.lean_front, -IRRL_L_HIP + P.lean_hind, IRRL_L_HIP - P.lean_hind, leg);
+  vf th0 = 0.0f, th1 = 0.0f, th2 = 0.0f;
+  vm ok0, ok1, ok2;
+  inverse_kinematics(toe.x, toe.y + toff, toe.z, P.max_len, (leg & 1) == 0, th0, th1, th2, ok0, ok1, ok2);
+  // chain the stale values: leg 0 falls back to prev[], leg i to leg i-1's final value
+  vf f0 = vsel(ok0, th0, prev[0]), f1 = vsel(ok1, th1, prev[1]), f2 = vsel(ok2, th2, prev[2]);
+  {
+    vf p0 = quad_bcast<0>(f0), p1 = quad_bcast<0>(f1), p2 = quad_bcast<0>(f2);
+    vm me = leg == 1;
+    f0 = vsel(me & !ok0, p0, f0); f1 = vsel(me & !ok1, p1, f1); f2 = vsel(me & !ok2, p2, f2);
+  }
+  {
+    vf p0 = quad_bcast<1>(f0), p1 = quad_bcast<1>(f1), p2 = quad_bcast<1>(f2);
+    vm me = leg == 2;
+    f0 = vsel(me & !ok0, p0, f0); f1 = vsel(me & !ok1, p1, f1); f2 = vsel(me & !ok2, p2, f2);
+  }
+  {
+    vf p0 = quad_bcast<2>(f0), p1 = quad_bcast<2>(f1), p2 = quad_bcast<2>(f2);
+    vm me = leg == 3;
+    f0 = vsel(me & !ok0, p0, f0); f1 = vsel(me & !ok1, p1, f1); f2 = vsel(me & !ok2, p2, f2);
+  }
+  th_out[0] = f0; th_out[1] = f1; th_out[2] = f2;
+  // temp[] leaving leg 3 (input of the next pass)
+  prev[0] = quad_bcast<3>(f0); prev[1] = quad_bcast<3>(f1); prev[2] = quad_bcast<3>(f2);
+  toe_out = toe;
+}
+IRRL_DEV void gait_generator_manual(const EnvParams &P, EnvLane &L, bool is_first) {
+  vf t = env_time(P, L);
+  vf gait_step = L.cmdf[0] * P.lam * P.period;
+  if (P.wildcat) gait_step = -gait_step;
+  vf side_step = L.cmdf[1] * P.lam * P.period;
+  vf rot_step = L.cmdf[2] * P.period * 0.4f;
+  if (P.height_variable) {  // ENV:1779-1792
+    vf ratio = v_abs(L.cmdf[0]) / P.Vx;
+    if (P.Vy > 0.0f) ratio = v_max(ratio, v_abs(L.cmdf[1]) / P.Vy);
+    if (P.Omega > 0.0f) ratio = v_max(ratio, v_abs(L.cmdf[2] / P.Omega));
+    L.up_height = vsel(ratio > 0.1f, P.up_height_max, ratio * P.up_height_max);
+  }
+  vf prev[3] = {0.0f, 0.0f, 0.0f};
+  vf th[3];
+  v3 toe;
+  if (is_first) {
+    gait_leg_pass(P, L, t - P.control_dt, gait_step, side_step, rot_step, L.up_height, prev, th, toe);
+    L.jrl[0] = th[0]; L.jrl[1] = -th[1]; L.jrl[2] = -th[2];
+  }
+  gait_leg_pass(P, L, t, gait_step, side_step, rot_step, L.up_height, prev, th, toe);
+  L.jr[0] = th[0]; L.jr[1] = -th[1]; L.jr[2] = -th[2];
+#pragma unroll
+  for (int j = 0; j < 3; j++) { L.jdr[j] = (L.jr[j] - L.jrl[j]) / P.control_dt; L.jrl[j] = L.jr[j]; }
+  // EndEffectorRef = toe + hip offset (ENV:331-334)
+  L.eer[0] = toe.x + L.m.sf * 0.19f; L.eer[1] = toe.y + L.m.sy * 0.058f; L.eer[2] = toe.z + 0.0f;
+}
+
+// ENV:1010-1109, ManualTraj branch
+IRRL_DEV void command_obs_update(const EnvParams &P, EnvLane &L, vu env, bool flag_reset) {
+  if (P.manual) return;
+  rng4 r = philox_u01(P.seed, env, L.episode, to_u(L.frame), flag_reset ? IRRL_P_RESET_CMD : IRRL_P_CMD);
+  vm resample = r.u0 < 0.5f / (P.max_time / P.control_dt);
+  if (flag_reset) resample = resample | vm(true);
+  vf t = r.u1, v = r.u2;
+  vm bx = (0.2f < t) & (t <= 0.7f);
+  vm by = (!bx) & (0.7f < t) & (t <= 0.85f);
+  vm bw = (!bx) & (!by);
+  L.cmd[0] = vsel(resample & bx, v * P.Vx + (1.0f - v) * 0.0f, L.cmd[0]);
+  L.cmd[1] = vsel(resample & by, v * P.Vy + (1.0f - v) * -P.Vy, L.cmd[1]);
+  L.cmd[2] = vsel(resample & bw, v * P.Omega + (1.0f - v) * -P.Omega, L.cmd[2]);
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    L.cmdf[i] = flag_reset ? L.cmd[i] : (L.cmdf[i] * 0.995f + L.cmd[i] * (1.0f - 0.995f));
+    L.ob_cmd[i] = L.cmdf[i];
+  }
+  gait_generator_manual(P, L, flag_reset);
+}
+
+// ENV:1116-1194
+IRRL_DEV void contact_obs_update(const EnvParams &P, EnvLane &L) {
+  if (!P.time_based_contact) {
+    L.contact = vsel(L.in_contact != 0, 1.0f, 0.0f);
+  } else {
+    vf phase_l = pick4(P.phase[0], P.phase[1], P.phase[2], P.phase[3], leg_id());
+    vf rp = v_fmod(env_time(P, L) + phase_l * P.period, P.period) / P.period;
+    L.contact = vsel(rp < P.lam, 1.0f, 0.0f);
+  }
+}
+
+// ENV:956-1004
+IRRL_DEV void update_observation(const EnvParams &P, EnvLane &L, vu env) {
+  vi leg = leg_id();
+  vf t = env_time(P, L);
+  L.ob_cmd[0] = 0.0f; L.ob_cmd[1] = 0.0f; L.ob_cmd[2] = 0.0f;  // ENV:960 zeroes the buffer
+  L.ob_phase[0] = v_sin(2.0f * IRRL_PI_REF * t / P.period);
+  L.ob_phase[1] = v_cos(2.0f * IRRL_PI_REF * t / P.period);
+  vf nj[3] = {0.0f, 0.0f, 0.0f}, nv[3] = {0.0f, 0.0f, 0.0f}, nn[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  if (P.obs_noise != 0.0f) {
+    vf u[16];
+    quad_rng16(P.seed, env, L.episode, to_u(L.frame), IRRL_P_OBS_JOINT, u);
+#pragma unroll
+    for (int k = 0; k < 3; k++) nj[k] = (2.0f * pick_leg(u, leg, k) - 1.0f) * 0.002f * P.obs_noise;
+    quad_rng16(P.seed, env, L.episode, to_u(L.frame), IRRL_P_OBS_JVEL, u);
+#pragma unroll
+    for (int k = 0; k < 3; k++) nv[k] = (2.0f * pick_leg(u, leg, k) - 1.0f) * 0.8f * P.obs_noise;
+    quad_rng16(P.seed, env, L.episode, to_u(L.frame), IRRL_P_OBS_NORMAL, u);
+    // Box-Muller: normal k from uniforms (2k, 2k+1); lane l evaluates normals l and 4 + (l & 1)
+    vf ua = pick4(u[0], u[2], u[4], u[6], leg), ub = pick4(u[1], u[3], u[5], u[7], leg);
+    vf uc = vsel((leg & 1) == 0, u[8], u[10]), ud = vsel((leg & 1) == 0, u[9], u[11]);
+    vf na = v_sqrt(-2.0f * v_log(1.0f - ua)) * v_cos(6.283185307179586f * ub);
+    vf nb = v_sqrt(-2.0f * v_log(1.0f - uc)) * v_cos(6.283185307179586f * ud);
+    nn[0] = quad_bcast<0>(na); nn[1] = quad_bcast<1>(na); nn[2] = quad_bcast<2>(na); nn[3] = quad_bcast<3>(na);
+    nn[4] = quad_bcast<0>(nb); nn[5] = quad_bcast<1>(nb);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) { L.ob_q[k] = nj[k] + L.q[k]; L.ob_qd[k] = nv[k] + L.qd[k]; }
+  rot3 R = quat_to_rot(L.qw, L.qx, L.qy, L.qz);
+  L.ob_post[0] = R.r2.x + (nn[0] * 0.02f) * P.obs_noise;
+  L.ob_post[1] = R.r2.y + (nn[1] * 0.02f) * P.obs_noise;
+  L.ob_post[2] = R.r2.z + (nn[2] * 0.02f) * P.obs_noise;
+  L.bodyLinVel = rot_tmul(R, L.vw);
+  L.bodyAngVel = rot_tmul(R, L.ww);
+  L.ob_omega[0] = L.bodyAngVel.x + P.obs_noise * (nn[3] * 0.5f);
+  L.ob_omega[1] = L.bodyAngVel.y + P.obs_noise * (nn[4] * 0.5f);
+  L.ob_omega[2] = L.bodyAngVel.z + P.obs_noise * (nn[5] * 0.5f);
+}
+
+// toe frame position (base comps) and world-frame linear speed (ENV:1224-1231)
+IRRL_DEV void toe_state(const EnvLane &L, v3 &xB, vf &speed) {
+  LegKin k = leg_fk(L.m, L.q[0], L.q[1], L.q[2]);
+  xB = k.ptoe;
+  v3 v = L.bodyLinVel + cross(L.bodyAngVel, k.ptoe);
+  v = v + L.qd[0] * cross(mk3(1.0f, 0.0f, 0.0f), k.ptoe - k.pA) + L.qd[1] * cross(k.h, k.ptoe - k.pT) + L.qd[2] * cross(k.h, k.ptoe - k.pS);
+  speed = v_sqrt(dot(v, v));  // |R v| = |v|
+}
+
+// ENV:1199-1243 + 1444-1548.  Returns the reward; fills extra[6] (ENV:942-950 order fixed by this build).
+IRRL_DEV vf reward_update(const EnvParams &P, EnvLane &L, vf extra[6]) {
+  vi leg = leg_id();
+  v3 xB; vf vel_norm;
+  toe_state(L, xB, vel_norm);
+  vf force_norm = vsel(L.in_contact != 0, v_sqrt(L.lamw[0] * L.lamw[0] + L.lamw[1] * L.lamw[1] + L.lamw[2] * L.lamw[2]) / P.control_dt, 0.0f);
+  // per-leg partial sums, summed FR,FL,HR,HL by the quad reduction
+  vf d0 = xB.x - L.eer[0], d1 = xB.y - L.eer[1], d2 = xB.z - L.eer[2];
+  vf ee2 = quad_sum(d0 * d0 + d1 * d1 + d2 * d2);
+  vf j2 = 0.0f, jd2 = 0.0f, tn2 = 0.0f, td2 = 0.0f, tn[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    vf a = L.jr[k] - L.q[k]; j2 += a * a;
+    vf b = L.jdr[k] - L.qd[k]; jd2 += b * b;
+    tn[k] = L.tq[k] / ((k == 2) ? 27.0f : 18.0f);  // ENV:354
+    tn2 += tn[k] * tn[k];
+    vf c = tn[k] - L.tql[k]; td2 += c * c;
+  }
+  j2 = quad_sum(j2); jd2 = quad_sum(jd2); tn2 = quad_sum(tn2); td2 = quad_sum(td2);
+#pragma unroll
+  for (int k = 0; k < 3; k++) L.tql[k] = tn[k];  // ENV:1515 keeps the NORMALISED torque
+  vf EE = P.c_ee * v_exp(-40.0f * ee2);
+  vf dz = L.pos.z - P.stand_height;
+  vf BC = P.c_pos * v_exp(-80.0f * (dz * dz));
+  vf BA = P.c_att * v_exp(-80.0f * (L.ob_post[0] * L.ob_post[0] + L.ob_post[1] * L.ob_post[1]));
+  vf JR = P.c_joint * 0.25f * v_exp(-2.0f * j2);
+  vf JD = P.c_joint * 0.75f * v_exp(-P.control_dt * jd2);
+  vf lx = P.wildcat ? -L.cmdf[0] : L.cmdf[0];
+  vf e0 = L.bodyLinVel.x - lx, e1 = L.bodyLinVel.y - L.cmdf[1], e2 = L.bodyLinVel.z;
+  vf g0 = L.bodyAngVel.x, g1 = L.bodyAngVel.y, g2 = L.bodyAngVel.z - L.cmdf[2];
+  vf VR = P.c_vel / 2.0f * v_exp(-2.0f * (e0 * e0 + e1 * e1 + e2 * e2)) + P.c_vel / 2.0f * v_exp(-2.0f * (g0 * g0 + g1 * g1 + g2 * g2));
+  vf TR = P.c_torque / 2.0f * v_exp(-0.1f * tn2) + P.c_torque / 2.0f * v_exp(-0.1f / P.control_dt * td2);
+  vf phase_l = pick4(P.phase[0], P.phase[1], P.phase[2], P.phase[3], leg);
+  vf rp = v_fmod(env_time(P, L) + phase_l * P.period, P.period) / P.period;
+  vf cr = 4.0f * vel_norm * vel_norm * smooth_function(rp, 2.0f, P.lam) +
+          2.0f * (force_norm / 12.5f) * (force_norm / 12.5f) * smooth_function2(rp, 2.0f, P.lam);
+  vf CR = P.c_contact * v_exp(-2.0f * quad_sum(cr));
+  extra[0] = EE; extra[1] = BC; extra[2] = L.pos.z; extra[3] = BA; extra[4] = JR; extra[5] = VR;
+  return EE + BC + JR + JD + VR + BA + TR + CR;  // ENV:1546-1547 order
+}
+
+// ENV:547-635 for every lane (callers mask the result)
+IRRL_DEV void reset_lane(const EnvParams &P, EnvLane &L, vu env) {
+  vi leg = leg_id();
+  L.episode = L.episode + 1u;
+  L.frame = 0;
+  if (P.randomize_per_episode && P.stochastic) model_randomize(L.m, leg, P.seed, env, L.episode);
+  rng4 rt = philox_u01(P.seed, env, L.episode, 0u, IRRL_P_RESET_TIME);
+  L.t0 = P.manual ? 0.0f : rt.u0;
+#pragma unroll
+  for (int i = 0; i < 3; i++) { L.cmdf[i] = 0.0f; L.tql[i] = 0.0f; }
+  command_obs_update(P, L, env, true);
+  contact_obs_update(P, L);
+  float nominal[3] = {0.0f, -0.78f, 1.57f};
+  L.pos.z = 0.35f; L.qw = 1.0f; L.qx = 0.0f; L.qy = 0.0f; L.qz = 0.0f;
+  L.vw = mk3(0.0f, 0.0f, 0.0f); L.ww = mk3(0.0f, 0.0f, 0.0f);
+  if (P.manual) {
+    L.pos.x = 0.0f; L.pos.y = 0.0f;
+    L.q[0] = L.m.sy * P.abad; L.q[1] = nominal[1]; L.q[2] = nominal[2];
+    L.qd[0] = 0.0f; L.qd[1] = 0.0f; L.qd[2] = 0.0f;
+  } else {
+    vf nj[3], nv[3];
+    if (P.shared_noise) {
+      rng4 r = philox_u01(P.seed, env, L.episode, 0u, IRRL_P_RESET_JOINT);
+#pragma unroll
+      for (int k = 0; k < 3; k++) { nj[k] = 2.0f * r.u0 - 1.0f; nv[k] = 2.0f * r.u1 - 1.0f; }
+    } else {
+      vf ua[16], ub[16];
+      quad_rng16(P.seed, env, L.episode, 0u, IRRL_P_RESET_JOINT_IND, ua);
+      quad_rng16(P.seed, env, L.episode, 0u, IRRL_P_RESET_JOINT_IND + 3u, ub);
+      // 24 consecutive uniforms: joints 0..11 then rates 0..11; the second call starts at element 12
+#pragma unroll
+      for (int k = 0; k < 3; k++) { nj[k] = 2.0f * pick_leg(ua, leg, k) - 1.0f; nv[k] = 2.0f * pick_leg(ub, leg, k) - 1.0f; }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      L.q[k] = L.jr[k] * (nj[k] * 0.3f) + L.jr[k];
+      L.qd[k] = L.jdr[k] * (nv[k] * 0.3f) + L.jdr[k];
+    }
+    rng4 rb = philox_u01(P.seed, env, L.episode, 0u, IRRL_P_RESET_BASE);
+    vf vx = L.cmdf[0] * ((2.0f * rb.u0 - 1.0f) * 0.2f + 1.0f);
+    L.vw.x = P.wildcat ? -vx : vx;
+    L.vw.y = L.cmdf[1] * ((2.0f * rb.u1 - 1.0f) * 0.2f + 1.0f);
+    L.ww.z = L.cmdf[2] * ((2.0f * rb.u2 - 1.0f) * 0.2f + 1.0f);
+    rng4 rx = philox_u01(P.seed, env, L.episode, 0u, IRRL_P_RESET_XY);
+    L.pos.x = rx.u0 * 5.0f + (1.0f - rx.u0) * -5.0f;
+    L.pos.y = rx.u1 * 5.0f + (1.0f - rx.u1) * -5.0f;
+  }
+  update_observation(P, L, env);
+  // obDouble_last_ = obDouble_ (ENV:626)
+  L.obl_env[0] = L.ob_cmd[0]; L.obl_env[1] = L.ob_cmd[1]; L.obl_env[2] = L.ob_cmd[2];
+  L.obl_env[3] = L.ob_phase[0]; L.obl_env[4] = L.ob_phase[1];
+#pragma unroll
+  for (int k = 0; k < 3; k++) { L.obl_env[5 + k] = L.ob_post[k]; L.obl_env[8 + k] = L.ob_omega[k]; L.obl_q[k] = L.ob_q[k]; L.obl_qd[k] = L.ob_qd[k]; }
+  contact_obs_update(P, L);
+  command_obs_update(P, L, env, false);
+  L.frame = L.frame + 1;
+}
+
+// field-wise select of two lane contexts (done ? a : b)
+IRRL_DEV void select_lane(vm m, const EnvLane &a, EnvLane &b) {
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    b.q[k] = vsel(m, a.q[k], b.q[k]); b.qd[k] = vsel(m, a.qd[k], b.qd[k]);
+    b.tql[k] = vsel(m, a.tql[k], b.tql[k]);
+    b.jr[k] = vsel(m, a.jr[k], b.jr[k]); b.jrl[k] = vsel(m, a.jrl[k], b.jrl[k]); b.jdr[k] = vsel(m, a.jdr[k], b.jdr[k]);
+    b.eer[k] = vsel(m, a.eer[k], b.eer[k]);
+    b.cmd[k] = vsel(m, a.cmd[k], b.cmd[k]); b.cmdf[k] = vsel(m, a.cmdf[k], b.cmdf[k]);
+    b.ob_cmd[k] = vsel(m, a.ob_cmd[k], b.ob_cmd[k]); b.ob_post[k] = vsel(m, a.ob_post[k], b.ob_post[k]);
+    b.ob_omega[k] = vsel(m, a.ob_omega[k], b.ob_omega[k]); b.ob_q[k] = vsel(m, a.ob_q[k], b.ob_q[k]); b.ob_qd[k] = vsel(m, a.ob_qd[k], b.ob_qd[k]);
+    b.obl_q[k] = vsel(m, a.obl_q[k], b.obl_q[k]); b.obl_qd[k] = vsel(m, a.obl_qd[k], b.obl_qd[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < 11; k++) b.obl_env[k] = vsel(m, a.obl_env[k], b.obl_env[k]);
+  b.ob_phase[0] = vsel(m, a.ob_phase[0], b.ob_phase[0]); b.ob_phase[1] = vsel(m, a.ob_phase[1], b.ob_phase[1]);
+  b.contact = vsel(m, a.contact, b.contact);
+  b.pos.x = vsel(m, a.pos.x, b.pos.x); b.pos.y = vsel(m, a.pos.y, b.pos.y); b.pos.z = vsel(m, a.pos.z, b.pos.z);
+  b.qw = vsel(m, a.qw, b.qw); b.qx = vsel(m, a.qx, b.qx); b.qy = vsel(m, a.qy, b.qy); b.qz = vsel(m, a.qz, b.qz);
+  b.vw.x = vsel(m, a.vw.x, b.vw.x); b.vw.y = vsel(m, a.vw.y, b.vw.y); b.vw.z = vsel(m, a.vw.z, b.vw.z);
+  b.ww.x = vsel(m, a.ww.x, b.ww.x); b.ww.y = vsel(m, a.ww.y, b.ww.y); b.ww.z = vsel(m, a.ww.z, b.ww.z);
+  b.t0 = vsel(m, a.t0, b.t0); b.frame = vsel_i(m, a.frame, b.frame); b.episode = vsel_u(m, a.episode, b.episode);
+  b.up_height = vsel(m, a.up_height, b.up_height);
+  b.bodyLinVel.x = vsel(m, a.bodyLinVel.x, b.bodyLinVel.x); b.bodyLinVel.y = vsel(m, a.bodyLinVel.y, b.bodyLinVel.y); b.bodyLinVel.z = vsel(m, a.bodyLinVel.z, b.bodyLinVel.z);
+  b.bodyAngVel.x = vsel(m, a.bodyAngVel.x, b.bodyAngVel.x); b.bodyAngVel.y = vsel(m, a.bodyAngVel.y, b.bodyAngVel.y); b.bodyAngVel.z = vsel(m, a.bodyAngVel.z, b.bodyAngVel.z);
+  // model (only changes with RandomizePerEpisode)
+  b.m.mA = vsel(m, a.m.mA, b.m.mA); b.m.mT = vsel(m, a.m.mT, b.m.mT); b.m.mS = vsel(m, a.m.mS, b.m.mS); b.m.m0 = vsel(m, a.m.m0, b.m.m0);
+  b.m.comA.x = vsel(m, a.m.comA.x, b.m.comA.x); b.m.comA.y = vsel(m, a.m.comA.y, b.m.comA.y); b.m.comA.z = vsel(m, a.m.comA.z, b.m.comA.z);
+  b.m.comT.x = vsel(m, a.m.comT.x, b.m.comT.x); b.m.comT.y = vsel(m, a.m.comT.y, b.m.comT.y); b.m.comT.z = vsel(m, a.m.comT.z, b.m.comT.z);
+  b.m.comS.x = vsel(m, a.m.comS.x, b.m.comS.x); b.m.comS.y = vsel(m, a.m.comS.y, b.m.comS.y); b.m.comS.z = vsel(m, a.m.comS.z, b.m.comS.z);
+  b.m.com0.x = vsel(m, a.m.com0.x, b.m.com0.x); b.m.com0.y = vsel(m, a.m.com0.y, b.m.com0.y); b.m.com0.z = vsel(m, a.m.com0.z, b.m.com0.z);
+  b.m.mu = vsel(m, a.m.mu, b.m.mu); b.m.rest = vsel(m, a.m.rest, b.m.rest); b.m.rest_thr = vsel(m, a.m.rest_thr, b.m.rest_thr); b.m.dz = vsel(m, a.m.dz, b.m.dz);
+}
+
+// ---------------------------------------------------------------------------------------------
+// state pool <-> lane context
+// ---------------------------------------------------------------------------------------------
+IRRL_DEV void load_lane(const EnvState &S, vi env, vi leg, EnvLane &L) {
+  vi j12 = env * 12 + leg * 3, gcb = env * 19, gvb = env * 18;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    L.q[k] = ld(S.gc, gcb + 7 + leg * 3 + k); L.qd[k] = ld(S.gv, gvb + 6 + leg * 3 + k);
+    L.ptl[k] = ld(S.ptarget_last, j12 + k); L.tql[k] = ld(S.torque_last, j12 + k); L.tq[k] = ld(S.torque, j12 + k);
+    L.jr[k] = ld(S.joint_ref, j12 + k); L.jrl[k] = ld(S.joint_ref_last, j12 + k); L.jdr[k] = ld(S.joint_dot_ref, j12 + k);
+    L.eer[k] = ld(S.ee_ref, j12 + k); L.lamw[k] = ld(S.lam_w, j12 + k);
+    L.cmd[k] = ld(S.command, env * 3 + k); L.cmdf[k] = ld(S.command_filtered, env * 3 + k);
+  }
+  L.in_contact = ld_i(S.in_contact, env * 4 + leg); L.contact = ld(S.contact, env * 4 + leg);
+  L.pos = mk3(ld(S.gc, gcb), ld(S.gc, gcb + 1), ld(S.gc, gcb + 2));
+  L.qw = ld(S.gc, gcb + 3); L.qx = ld(S.gc, gcb + 4); L.qy = ld(S.gc, gcb + 5); L.qz = ld(S.gc, gcb + 6);
+  L.vw = mk3(ld(S.gv, gvb), ld(S.gv, gvb + 1), ld(S.gv, gvb + 2));
+  L.ww = mk3(ld(S.gv, gvb + 3), ld(S.gv, gvb + 4), ld(S.gv, gvb + 5));
+  L.t0 = ld(S.t0, env); L.frame = ld_i(S.frame_idx, env); L.episode = ld_u(S.episode, env); L.up_height = ld(S.up_height, env);
+  model_signs(L.m, leg);
+  L.m.mu = ld(S.material, env * 3); L.m.rest = ld(S.material, env * 3 + 1); L.m.rest_thr = ld(S.material, env * 3 + 2);
+  L.m.m0 = ld(S.mass, env * 13); L.m.mA = ld(S.mass, env * 13 + 1 + leg * 3); L.m.mT = ld(S.mass, env * 13 + 2 + leg * 3); L.m.mS = ld(S.mass, env * 13 + 3 + leg * 3);
+  vi cb = env * 39;
+  L.m.com0 = mk3(ld(S.com, cb), ld(S.com, cb + 1), ld(S.com, cb + 2));
+  L.m.comA = mk3(ld(S.com, cb + 3 + leg * 9), ld(S.com, cb + 4 + leg * 9), ld(S.com, cb + 5 + leg * 9));
+  L.m.comT = mk3(ld(S.com, cb + 6 + leg * 9), ld(S.com, cb + 7 + leg * 9), ld(S.com, cb + 8 + leg * 9));
+  L.m.comS = mk3(ld(S.com, cb + 9 + leg * 9), ld(S.com, cb + 10 + leg * 9), ld(S.com, cb + 11 + leg * 9));
+  L.m.dz = ld(S.thigh_dz, env);
+  // raw observation (needed by observe()/isTerminalState() between steps, and by the ObsFilter history)
+  vi ob = env * 35;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    L.ob_cmd[k] = ld(S.ob, ob + k); L.ob_post[k] = ld(S.ob, ob + 29 + k); L.ob_omega[k] = ld(S.ob, ob + 32 + k);
+    L.ob_q[k] = ld(S.ob, ob + 5 + leg * 3 + k); L.ob_qd[k] = ld(S.ob, ob + 17 + leg * 3 + k);
+    L.obl_q[k] = ld(S.ob_last, ob + 5 + leg * 3 + k); L.obl_qd[k] = ld(S.ob_last, ob + 17 + leg * 3 + k);
+  }
+  L.ob_phase[0] = ld(S.ob, ob + 3); L.ob_phase[1] = ld(S.ob, ob + 4);
+#pragma unroll
+  for (int k = 0; k < 5; k++) L.obl_env[k] = ld(S.ob_last, ob + k);
+#pragma unroll
+  for (int k = 0; k < 6; k++) L.obl_env[5 + k] = ld(S.ob_last, ob + 29 + k);
+  L.bodyLinVel = mk3(0.0f, 0.0f, 0.0f); L.bodyAngVel = mk3(0.0f, 0.0f, 0.0f);
+}
+
+IRRL_DEV void store_lane(const EnvState &S, vi env, vi leg, vm valid, const EnvLane &L, bool store_model) {
+  vi j12 = env * 12 + leg * 3, gcb = env * 19, gvb = env * 18, ob = env * 35;
+  vm lead = valid & (leg == 0);
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    st_if(valid, S.gc, gcb + 7 + leg * 3 + k, L.q[k]); st_if(valid, S.gv, gvb + 6 + leg * 3 + k, L.qd[k]);
+    st_if(valid, S.ptarget_last, j12 + k, L.ptl[k]); st_if(valid, S.torque_last, j12 + k, L.tql[k]); st_if(valid, S.torque, j12 + k, L.tq[k]);
+    st_if(valid, S.joint_ref, j12 + k, L.jr[k]); st_if(valid, S.joint_ref_last, j12 + k, L.jrl[k]); st_if(valid, S.joint_dot_ref, j12 + k, L.jdr[k]);
+    st_if(valid, S.ee_ref, j12 + k, L.eer[k]); st_if(valid, S.lam_w, j12 + k, L.lamw[k]);
+    st_if(lead, S.command, env * 3 + k, L.cmd[k]); st_if(lead, S.command_filtered, env * 3 + k, L.cmdf[k]);
+    st_if(valid, S.ob, ob + 5 + leg * 3 + k, L.ob_q[k]); st_if(valid, S.ob, ob + 17 + leg * 3 + k, L.ob_qd[k]);
+    st_if(valid, S.ob_last, ob + 5 + leg * 3 + k, L.obl_q[k]); st_if(valid, S.ob_last, ob + 17 + leg * 3 + k, L.obl_qd[k]);
+    st_if(lead, S.ob, ob + k, L.ob_cmd[k]); st_if(lead, S.ob, ob + 29 + k, L.ob_post[k]); st_if(lead, S.ob, ob + 32 + k, L.ob_omega[k]);
+  }
+  st_i_if(valid, S.in_contact, env * 4 + leg, L.in_contact); st_if(valid, S.contact, env * 4 + leg, L.contact);
+  st_if(lead, S.gc, gcb, L.pos.x); st_if(lead, S.gc, gcb + 1, L.pos.y); st_if(lead, S.gc, gcb + 2, L.pos.z);
+  st_if(lead, S.gc, gcb + 3, L.qw); st_if(lead, S.gc, gcb + 4, L.qx); st_if(lead, S.gc, gcb + 5, L.qy); st_if(lead, S.gc, gcb + 6, L.qz);
+  st_if(lead, S.gv, gvb, L.vw.x); st_if(lead, S.gv, gvb + 1, L.vw.y); st_if(lead, S.gv, gvb + 2, L.vw.z);
+  st_if(lead, S.gv, gvb + 3, L.ww.x); st_if(lead, S.gv, gvb + 4, L.ww.y); st_if(lead, S.gv, gvb + 5, L.ww.z);
+  st_if(lead, S.t0, env, L.t0); st_i_if(lead, S.frame_idx, env, L.frame); st_u_if(lead, S.episode, env, L.episode); st_if(lead, S.up_height, env, L.up_height);
+  st_if(lead, S.ob, ob + 3, L.ob_phase[0]); st_if(lead, S.ob, ob + 4, L.ob_phase[1]);
+#pragma unroll
+  for (int k = 0; k < 5; k++) st_if(lead, S.ob_last, ob + k, L.obl_env[k]);
+#pragma unroll
+  for (int k = 0; k < 6; k++) st_if(lead, S.ob_last, ob + 29 + k, L.obl_env[5 + k]);
+  if (store_model) {
+    st_if(lead, S.material, env * 3, L.m.mu); st_if(lead, S.material, env * 3 + 1, L.m.rest); st_if(lead, S.material, env * 3 + 2, L.m.rest_thr);
+    st_if(lead, S.mass, env * 13, L.m.m0);
+    st_if(valid, S.mass, env * 13 + 1 + leg * 3, L.m.mA); st_if(valid, S.mass, env * 13 + 2 + leg * 3, L.m.mT); st_if(valid, S.mass, env * 13 + 3 + leg * 3, L.m.mS);
+    vi cb = env * 39;
+    st_if(lead, S.com, cb, L.m.com0.x); st_if(lead, S.com, cb + 1, L.m.com0.y); st_if(lead, S.com, cb + 2, L.m.com0.z);
+    st_if(valid, S.com, cb + 3 + leg * 9, L.m.comA.x); st_if(valid, S.com, cb + 4 + leg * 9, L.m.comA.y); st_if(valid, S.com, cb + 5 + leg * 9, L.m.comA.z);
+    st_if(valid, S.com, cb + 6 + leg * 9, L.m.comT.x); st_if(valid, S.com, cb + 7 + leg * 9, L.m.comT.y); st_if(valid, S.com, cb + 8 + leg * 9, L.m.comT.z);
+    st_if(valid, S.com, cb + 9 + leg * 9, L.m.comS.x); st_if(valid, S.com, cb + 10 + leg * 9, L.m.comS.y); st_if(valid, S.com, cb + 11 + leg * 9, L.m.comS.z);
+    st_if(lead, S.thigh_dz, env, L.m.dz);
+  }
+}
+
+// ENV:1248-1268 + obs scaling ENV:375-393: writes this lane's share of the scaled [N,35] row
+IRRL_DEV void observe_lane(const EnvParams &P, vi env, vi leg, vm valid, EnvLane &L, float *ob_out) {
+  vm lead = valid & (leg == 0);
+  if (P.obs_filter) {  // filter touches obs[5:35]
+    float al = P.obs_filter_alpha;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      L.ob_q[k] = L.ob_q[k] * al + L.obl_q[k] * (1.0f - al);
+      L.ob_qd[k] = L.ob_qd[k] * al + L.obl_qd[k] * (1.0f - al);
+      L.ob_post[k] = L.ob_post[k] * al + L.obl_env[5 + k] * (1.0f - al);
+      L.ob_omega[k] = L.ob_omega[k] * al + L.obl_env[8 + k] * (1.0f - al);
+      L.obl_q[k] = L.ob_q[k]; L.obl_qd[k] = L.ob_qd[k]; L.obl_env[5 + k] = L.ob_post[k]; L.obl_env[8 + k] = L.ob_omega[k];
+      L.obl_env[k] = L.ob_cmd[k];
+    }
+    L.obl_env[3] = L.ob_phase[0]; L.obl_env[4] = L.ob_phase[1];
+  }
+  vi ob = env * 35;
+  const float jstd[3] = {5.0f, 35.0f, 40.0f};
+  vf nominal[3] = {L.m.sy * P.abad, -0.78f, 1.57f};
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    st_if(valid, ob_out, ob + 5 + leg * 3 + k, (L.ob_q[k] - nominal[k]) / 1.0f);
+    st_if(valid, ob_out, ob + 17 + leg * 3 + k, (L.ob_qd[k] - 0.0f) / jstd[k]);
+    st_if(lead, ob_out, ob + 29 + k, (L.ob_post[k] - ((k == 2) ? 1.0f : 0.0f)) / 0.7f);
+    st_if(lead, ob_out, ob + 32 + k, (L.ob_omega[k] - 0.0f) / 3.0f);
+  }
+  st_if(lead, ob_out, ob + 0, (L.ob_cmd[0] - (P.Vx + 0.0f) / 2.0f) / 1.0f);
+  st_if(lead, ob_out, ob + 1, (L.ob_cmd[1] - (P.Vy + -P.Vy) / 2.0f) / 1.0f);
+  st_if(lead, ob_out, ob + 2, (L.ob_cmd[2] - (P.Omega + -P.Omega) / 2.0f) / 1.0f);
+  st_if(lead, ob_out, ob + 3, L.ob_phase[0]);
+  st_if(lead, ob_out, ob + 4, L.ob_phase[1]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// whole-step bodies (one call per lane); the __global__ wrappers live in env_kernels.hip
+// ---------------------------------------------------------------------------------------------
+// VEC:268-278 + 352-372 around ENV:692-809
+IRRL_DEV void step_body(const EnvParams &P, const EnvState &S, vi env, vi leg, vm valid, const float *action, float *ob_out,
+                        float *reward_out, uint8_t *done_out, float *extra_out) {
+  EnvLane L;
+  load_lane(S, env, leg, L);
+  vu envu = to_u(env);
+  // ENV:700-708
+  vf pT[3];
+  {
+    vf an[3] = {0.0f, 0.0f, 0.0f};
+    if (P.action_noise != 0.0f) {
+      if (P.shared_noise) {
+        rng4 r = philox_u01(P.seed, envu, L.episode, to_u(L.frame), IRRL_P_ACTION_NOISE);
+        an[0] = an[1] = an[2] = 2.0f * r.u0 - 1.0f;
+      } else {
+        vf u[16];
+        quad_rng16(P.seed, envu, L.episode, to_u(L.frame), IRRL_P_ACTION_NOISE, u);
+#pragma unroll
+        for (int k = 0; k < 3; k++) an[k] = 2.0f * pick_leg(u, leg, k) - 1.0f;
+      }
+    }
+    vf nominal[3] = {L.m.sy * P.abad, -0.78f, 1.57f};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      vf p = ld(action, env * 12 + leg * 3 + k) * 1.0f + nominal[k];
+      p = (1.0f - P.filter_para) * p + P.filter_para * L.ptl[k];
+      p = p * (P.action_noise * an[k]) + p;
+      pT[k] = p; L.ptl[k] = p;
+    }
+  }
+  for (int i = 0; i < P.loop_count; i++) physics_substep(P, L, pT);
+  update_observation(P, L, envu);
+  vf extra[6];
+  vf rew = reward_update(P, L, extra);
+  command_obs_update(P, L, envu, false);
+  contact_obs_update(P, L);
+  L.frame = L.frame + 1;
+  // VEC:358-371
+  vm done = (L.pos.z < 0.15f) | (L.pos.z > 0.65f) | (L.ob_post[2] < 0.5f);
+  if (wave_any(done & valid)) {
+    EnvLane Rn = L;
+    reset_lane(P, Rn, envu);
+    select_lane(done, Rn, L);
+    rew = vsel(done, rew + P.c_term, rew);
+  }
+  observe_lane(P, env, leg, valid, L, ob_out);
+  vm lead = valid & (leg == 0);
+  st_if(lead, reward_out, env, rew);
+  st_u8_if(lead, done_out, env, vsel_i(done, 1, 0));
+#pragma unroll
+  for (int j = 0; j < 6; j++) st_if(lead, extra_out, env * 6 + j, extra[j]);
+  store_lane(S, env, leg, valid, L, P.randomize_per_episode != 0);
+}
+
+// VEC:145-194 per env: constructor randomisation (ENV:435-477) + first reset
+IRRL_DEV void init_body(const EnvParams &P, const EnvState &S, vi env, vi leg, vm valid) {
+  EnvLane L;
+  // zero-initialised members of a fresh ENVIRONMENT (ENV:2045-2051, 412-418)
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    L.q[k] = 0.0f; L.qd[k] = 0.0f; L.ptl[k] = 0.0f; L.tql[k] = 0.0f; L.tq[k] = 0.0f; L.jr[k] = 0.0f; L.jrl[k] = 0.0f; L.jdr[k] = 0.0f;
+    L.eer[k] = 0.0f; L.lamw[k] = 0.0f; L.cmd[k] = 0.0f; L.cmdf[k] = 0.0f; L.ob_cmd[k] = 0.0f; L.ob_post[k] = 0.0f; L.ob_omega[k] = 0.0f;
+    L.ob_q[k] = 0.0f; L.ob_qd[k] = 0.0f; L.obl_q[k] = 0.0f; L.obl_qd[k] = 0.0f;
+  }
+#pragma unroll
+  for (int k = 0; k < 11; k++) L.obl_env[k] = 0.0f;
+  L.ob_phase[0] = 0.0f; L.ob_phase[1] = 0.0f;
+  L.in_contact = 0; L.contact = 0.0f;
+  L.pos = mk3(0.0f, 0.0f, 0.0f); L.qw = 1.0f; L.qx = 0.0f; L.qy = 0.0f; L.qz = 0.0f;
+  L.vw = mk3(0.0f, 0.0f, 0.0f); L.ww = mk3(0.0f, 0.0f, 0.0f);
+  L.t0 = 0.0f; L.frame = 0; L.episode = 0u; L.up_height = P.up_height_max;
+  L.bodyLinVel = mk3(0.0f, 0.0f, 0.0f); L.bodyAngVel = mk3(0.0f, 0.0f, 0.0f);
+  if (P.stochastic) model_randomize(L.m, leg, P.seed, to_u(env), 0u); else model_nominal(L.m, leg);
+  L.jr[0] = L.m.sy * P.abad;  // ENV:415-418
+  reset_lane(P, L, to_u(env));
+  store_lane(S, env, leg, valid, L, true);
+}
+
+// VEC:201-207: reset every env, then observe
+IRRL_DEV void reset_body(const EnvParams &P, const EnvState &S, vi env, vi leg, vm valid, float *ob_out) {
+  EnvLane L;
+  load_lane(S, env, leg, L);
+  reset_lane(P, L, to_u(env));
+  observe_lane(P, env, leg, valid, L, ob_out);
+  store_lane(S, env, leg, valid, L, P.randomize_per_episode != 0);
+}
+
+// VEC:209-212
+IRRL_DEV void observe_body(const EnvParams &P, const EnvState &S, vi env, vi leg, vm valid, float *ob_out) {
+  EnvLane L;
+  load_lane(S, env, leg, L);
+  observe_lane(P, env, leg, valid, L, ob_out);
+  if (P.obs_filter) store_lane(S, env, leg, valid, L, false);
+}
+
+// Diagnostics (ENV:1375-1402): world-frame inverse mass matrix (column-major [18x18]) and nonlinear term.
+// M_w^-1 = T M_B^-1 T^T with  M_B^-1 = [[S^-1, -S^-1 D^T], [-D S^-1, C^-1 + D S^-1 D^T]].
+IRRL_DEV void dynamics_probe_body(const EnvParams &P, const EnvState &S, vi env, vi leg, vm valid, float *minv_out, float *nonlin_out) {
+  EnvLane L;
+  load_lane(S, env, leg, L);
+  rot3 R = quat_to_rot(L.qw, L.qx, L.qy, L.qz);
+  v3 wB = rot_tmul(R, L.ww);
+  LegKin k = leg_fk(L.m, L.q[0], L.q[1], L.q[2]);
+  LegDyn D;
+  leg_dynamics(L.m, k, L.qd, wB, IRRL_GRAV * R.r2, D);
+  vm lead = valid & (leg == 0);
+  if (nonlin_out) {
+    v3 fw = rot_mul(R, mk3(D.bias_b[0], D.bias_b[1], D.bias_b[2])), nw = rot_mul(R, mk3(D.bias_b[3], D.bias_b[4], D.bias_b[5]));
+    st_if(lead, nonlin_out, env * 18 + 0, fw.x); st_if(lead, nonlin_out, env * 18 + 1, fw.y); st_if(lead, nonlin_out, env * 18 + 2, fw.z);
+    st_if(lead, nonlin_out, env * 18 + 3, nw.x); st_if(lead, nonlin_out, env * 18 + 4, nw.y); st_if(lead, nonlin_out, env * 18 + 5, nw.z);
+#pragma unroll
+    for (int j = 0; j < 3; j++) st_if(valid, nonlin_out, env * 18 + 6 + leg * 3 + j, D.bias_l[j]);
+  }
+  if (minv_out) {
+    // columns of M_B^-1 by unit right-hand sides, then rotate the base rows/columns into the world frame.
+    // Column c of M_w^-1 = T M_B^-1 T^T e_c.  For a base column, T^T e_c is a row of R spread over the base
+    // block; for a joint column it is e_c itself.
+    vi base = env * 324;
+    for (int c = 0; c < 18; c++) {
+      vf rb[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f}, rl[3] = {0.0f, 0.0f, 0.0f};
+      if (c < 3) {
+        v3 row = (c == 0) ? R.r0 : ((c == 1) ? R.r1 : R.r2);  // T^T e_c = R^T e_c
+        rb[0] = row.x; rb[1] = row.y; rb[2] = row.z;
+      } else if (c < 6) {
+        v3 row = (c == 3) ? R.r0 : ((c == 4) ? R.r1 : R.r2);
+        rb[3] = row.x; rb[4] = row.y; rb[5] = row.z;
+      } else {
+        int jl = (c - 6) / 3, jk = (c - 6) % 3;
+        vf one = vsel(leg == jl, 1.0f, 0.0f);
+        rl[0] = (jk == 0) ? one : vf(0.0f); rl[1] = (jk == 1) ? one : vf(0.0f); rl[2] = (jk == 2) ? one : vf(0.0f);
+      }
+      vf xb[6], xl[3];
+      solve_M(D, rb, rl, xb, xl);
+      v3 lw = rot_mul(R, mk3(xb[0], xb[1], xb[2])), aw = rot_mul(R, mk3(xb[3], xb[4], xb[5]));
+      st_if(lead, minv_out, base + c * 18 + 0, lw.x); st_if(lead, minv_out, base + c * 18 + 1, lw.y); st_if(lead, minv_out, base + c * 18 + 2, lw.z);
+      st_if(lead, minv_out, base + c * 18 + 3, aw.x); st_if(lead, minv_out, base + c * 18 + 4, aw.y); st_if(lead, minv_out, base + c * 18 + 5, aw.z);
+#pragma unroll
+      for (int j = 0; j < 3; j++) st_if(valid, minv_out, base + c * 18 + 6 + leg * 3 + j, xl[j]);
+    }
+  }
+}
+
+}  // namespace irrl

@@ -1,0 +1,52 @@
+// env_kernels.hip -- __global__ wrappers of the lane bodies in env_core.hpp (gfx950 only).
+// Launch shape: 64-thread workgroups = one wave = 16 robots (one DPP quad each); grid = ceil(N / 16).
+// At N = 4096 that is 256 workgroups -> one wave on each of the 256 CUs; the kernel keeps the whole
+// robot state in VGPRs across the 8 substeps (no LDS, no scratch), so __launch_bounds__(64, 1) lets the
+// allocator use the full 512-register budget of a SIMD that hosts a single wave.
+#include "lanes_hip.hpp"
+#include "env_core.hpp"
+
+#define IRRL_LANE_PROLOGUE                                     \
+  const int lane_ = (int)threadIdx.x;                          \
+  int env_ = (int)blockIdx.x * 16 + (lane_ >> 2);              \
+  const int leg_ = lane_ & 3;                                  \
+  const bool valid_ = env_ < P.n_envs;                         \
+  if (!valid_) env_ = P.n_envs - 1; /* idle quads shadow the last robot; their stores are masked */
+
+extern "C" {
+
+__global__ void __launch_bounds__(64, 1)
+irrl_step_kernel(EnvParams P, EnvState S, const float *action, float *ob, float *reward, uint8_t *done, float *extra) {
+  IRRL_LANE_PROLOGUE
+  irrl::step_body(P, S, env_, leg_, valid_, action, ob, reward, done, extra);
+}
+
+__global__ void __launch_bounds__(64, 1) irrl_init_kernel(EnvParams P, EnvState S) {
+  IRRL_LANE_PROLOGUE
+  irrl::init_body(P, S, env_, leg_, valid_);
+}
+
+__global__ void __launch_bounds__(64, 1) irrl_reset_kernel(EnvParams P, EnvState S, float *ob) {
+  IRRL_LANE_PROLOGUE
+  irrl::reset_body(P, S, env_, leg_, valid_, ob);
+}
+
+__global__ void __launch_bounds__(64, 1) irrl_observe_kernel(EnvParams P, EnvState S, float *ob) {
+  IRRL_LANE_PROLOGUE
+  irrl::observe_body(P, S, env_, leg_, valid_, ob);
+}
+
+__global__ void __launch_bounds__(64, 1) irrl_probe_kernel(EnvParams P, EnvState S, float *minv, float *nonlin) {
+  IRRL_LANE_PROLOGUE
+  irrl::dynamics_probe_body(P, S, env_, leg_, valid_, minv, nonlin);
+}
+
+// isTerminalState (ENV:1553-1578) on the stored state; one thread per robot
+__global__ void irrl_terminal_kernel(EnvParams P, EnvState S, uint8_t *done) {
+  int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (e >= P.n_envs) return;
+  float z = S.gc[e * 19 + 2], up = S.ob[e * 35 + 31];
+  done[e] = (z < 0.15f || z > 0.65f || up < 0.5f) ? 1 : 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,59 @@
+// env_params.h -- plain-old-data shared by the host side (C-ABI, config parser) and the kernels.
+#pragma once
+#include <stdint.h>
+
+// Configuration scalars the kernels need, derived from the `environment:` YAML sub-tree
+// (reference keys: Environment.hpp:1594-1659, VectorizedEnvironment.hpp:136-171).  Passed BY VALUE as
+// a kernel argument, so the compiler keeps it in SGPRs / scalar loads.
+struct EnvParams {
+  int32_t n_envs;
+  int32_t loop_count;      // int(control_dt / simulation_dt + 1e-10), Environment.hpp:711
+  uint32_t seed;           // seedd
+  int32_t contact_iters;   // [ext] ContactIterations
+  float sim_dt, control_dt, max_time;
+  float abad, period, lam, stand_height, up_height_max;
+  float Vx, Vy, Omega, lean_front, lean_hind;
+  int32_t manual, height_variable, time_based_contact, wildcat, stochastic, obs_filter;
+  int32_t shared_noise, randomize_per_episode;
+  float c_term, c_ee, c_pos, c_att, c_joint, c_vel, c_torque, c_contact;
+  float kp[3], kd[3];      // abad / hip / knee gains (AbadRatio folded in), Environment.hpp:338-350
+  float filter_para;       // Environment.hpp:396 (evaluated with the base-class control_dt_ = 0.01)
+  float obs_filter_alpha;  // Environment.hpp:423-427 (same quirk)
+  float action_noise, obs_noise;
+  float tau_max, w_crit, w_max;
+  float phase[4];          // Environment.hpp:398-409
+  float max_len;           // Environment.hpp:395
+};
+
+// Device-resident state pool, structure of arrays in the reference's natural row-major shapes so the
+// diagnostics getters are plain copies.  N = n_envs.
+struct EnvState {
+  float *gc;            // [N,19]  x y z, quat wxyz, 12 joint angles            (RaiSim gc)
+  float *gv;            // [N,18]  world lin vel, world ang vel, 12 joint rates   (RaiSim gv)
+  float *ptarget_last;  // [N,12]
+  float *torque_last;   // [N,12]  NORMALISED torque of the previous reward evaluation
+  float *torque;        // [N,12]  last applied joint torque
+  float *joint_ref, *joint_ref_last, *joint_dot_ref, *ee_ref;  // [N,12] each
+  float *lam_w;         // [N,12]  contact impulses of the last substep, world components (warm start)
+  int32_t *in_contact;  // [N,4]
+  float *contact;       // [N,4]
+  float *command, *command_filtered;  // [N,3]
+  float *t0;            // [N]
+  int32_t *frame_idx;   // [N]   control steps since reset; time = t0 + frame_idx * control_dt
+  uint32_t *episode;    // [N]
+  float *up_height;     // [N]
+  float *material;      // [N,3]  mu, restitution, restitution threshold
+  float *mass;          // [N,13]
+  float *com;           // [N,39]
+  float *thigh_dz;      // [N]
+  float *ob;            // [N,35] unscaled observation (obDouble_)
+  float *ob_last;       // [N,35]
+};
+
+// RNG purposes -- (purpose, slot) addresses every random draw; identical table in the oracle.
+enum {
+  IRRL_P_DR_MATERIAL = 1, IRRL_P_DR_MASS = 2, IRRL_P_DR_COM = 6, IRRL_P_DR_THIGH = 16,
+  IRRL_P_RESET_TIME = 20, IRRL_P_RESET_CMD = 21, IRRL_P_RESET_JOINT = 22, IRRL_P_RESET_JOINT_IND = 23,
+  IRRL_P_RESET_BASE = 29, IRRL_P_RESET_XY = 30,
+  IRRL_P_ACTION_NOISE = 40, IRRL_P_OBS_JOINT = 44, IRRL_P_OBS_JVEL = 47, IRRL_P_OBS_NORMAL = 50, IRRL_P_CMD = 56
+};

@@ -1,0 +1,150 @@
+// irrl_config.hpp -- host-side configuration: a minimal parser for the flat `environment:` YAML
+// mapping the reference hands to its C++ side as a STRING (run_bp_v5.py:205-207 ->
+// VectorizedEnvironment.hpp:135 YAML::Load), and the derivation of the kernel parameters.
+//
+// The reference aborts the process when a key is missing (READ_YAML -> RSFATAL_IF,
+// RaisimGymEnv.hpp:41-42; key list Environment.hpp:1594-1659).  Here a missing key is an error
+// string returned through the C-ABI (irrl_last_error) -- same contract ("every key is mandatory"),
+// recoverable failure mode.
+#pragma once
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+
+#include "env_params.h"
+
+namespace irrl_host {
+
+struct Config {
+  std::map<std::string, std::string> kv;
+
+  static std::string trim(const std::string &s) {
+    size_t a = s.find_first_not_of(" \t\r\n"), b = s.find_last_not_of(" \t\r\n");
+    return (a == std::string::npos) ? std::string() : s.substr(a, b - a + 1);
+  }
+  // Accepts block style ("key: value" per line, any indentation, '#' comments) and the flow style
+  // ruamel/PyYAML emit for small mappings ("{a: 1, b: 2}").
+  bool parse(const std::string &text, std::string &err) {
+    std::string t = trim(text);
+    if (!t.empty() && t[0] == '{') {
+      if (t[t.size() - 1] != '}') { err = "unterminated flow mapping"; return false; }
+      t = t.substr(1, t.size() - 2);
+      for (size_t i = 0; i < t.size(); i++) if (t[i] == ',') t[i] = '\n';
+    }
+    size_t pos = 0;
+    while (pos <= t.size()) {
+      size_t nl = t.find('\n', pos);
+      std::string line = t.substr(pos, nl == std::string::npos ? std::string::npos : nl - pos);
+      pos = (nl == std::string::npos) ? t.size() + 1 : nl + 1;
+      // strip comments (a '#' preceded by start-of-line or whitespace)
+      for (size_t i = 0; i < line.size(); i++)
+        if (line[i] == '#' && (i == 0 || line[i - 1] == ' ' || line[i - 1] == '\t')) { line = line.substr(0, i); break; }
+      line = trim(line);
+      if (line.empty() || line == "---") continue;
+      size_t c = line.find(':');
+      if (c == std::string::npos) { err = "cannot parse line: '" + line + "'"; return false; }
+      std::string k = trim(line.substr(0, c)), v = trim(line.substr(c + 1));
+      if (v.size() >= 2 && ((v[0] == '"' && v[v.size() - 1] == '"') || (v[0] == '\'' && v[v.size() - 1] == '\''))) v = v.substr(1, v.size() - 2);
+      if (k.size() >= 2 && (k[0] == '"' || k[0] == '\'')) k = k.substr(1, k.size() - 2);
+      kv[k] = v;
+    }
+    return true;
+  }
+  bool has(const std::string &k) const { return kv.find(k) != kv.end(); }
+  bool get_double(const std::string &k, double &out, std::string &err) const {
+    auto it = kv.find(k);
+    if (it == kv.end()) { err = "Node cfg[\"" + k + "\"] doesn't exist"; return false; }
+    const std::string &v = it->second;
+    if (v == ".inf" || v == ".Inf") { out = INFINITY; return true; }
+    char *end = nullptr;
+    out = std::strtod(v.c_str(), &end);
+    if (end == v.c_str() || *end != 0) {
+      bool b;
+      if (to_bool(v, b)) { out = b ? 1.0 : 0.0; return true; }
+      err = "cfg[\"" + k + "\"] = '" + v + "' is not a number"; return false;
+    }
+    return true;
+  }
+  static bool to_bool(const std::string &v, bool &b) {
+    if (v == "True" || v == "true" || v == "TRUE" || v == "yes" || v == "Yes" || v == "on") { b = true; return true; }
+    if (v == "False" || v == "false" || v == "FALSE" || v == "no" || v == "No" || v == "off") { b = false; return true; }
+    return false;
+  }
+  bool get_bool(const std::string &k, bool &out, std::string &err) const {
+    auto it = kv.find(k);
+    if (it == kv.end()) { err = "Node cfg[\"" + k + "\"] doesn't exist"; return false; }
+    if (to_bool(it->second, out)) return true;
+    double d;
+    if (!get_double(k, d, err)) return false;
+    out = (d != 0.0);
+    return true;
+  }
+};
+
+// Every key the reference reads, in its own order (Environment.hpp:1598-1658), then the vectorizer's
+// (VectorizedEnvironment.hpp:146-171).  "RefTraj"/"render" are optional there too (try/catch, if()).
+static const char *const kMandatoryKeys[] = {
+    "abad", "period", "lam", "stand_height", "up_height", "down_height", "gait_step", "Vx", "Vy", "Omega", "LeanFront",
+    "LeanHind", "Terrain", "Manual", "Crutial", "Filter", "Camera", "StochasticDynamics", "HeightVariable",
+    "TimeBasedContact", "ManualTraj", "MotorDynamics", "ObsFilter", "WILDCAT", "ForceDisturbance", "Convert2Torque",
+    "terminalRewardCoeff", "EndEffectorRewardCoeff", "BodyPosRewardCoeff", "BodyAttitudeRewardCoeff", "JointRewardCoeff",
+    "VelRewardCoeff", "TorqueCoeff", "ContactCoeff", "Stiffness", "Stiffness_Low", "AbadRatio", "Damping", "Freq",
+    "max_time", "CubeNum", "FPS", "ActionNoise", "ObsNoise", "GaitType", "MotorMaxTorque", "MotorCriticalSpeed",
+    "MotorMaxSpeed", "num_envs", "num_threads", "simulation_dt", "control_dt", "seedd"};
+
+inline bool build_params(const Config &c, EnvParams &P, std::string &err) {
+  for (const char *k : kMandatoryKeys)
+    if (!c.has(k)) { err = std::string("Node cfg[\"") + k + "\"] doesn't exist"; return false; }
+  auto num = [&](const char *k) { double v = NAN; std::string e; if (!c.get_double(k, v, e) && err.empty()) err = e; return v; };
+  auto flag = [&](const char *k) { bool v = false; std::string e; if (!c.get_bool(k, v, e) && err.empty()) err = e; return v; };
+  std::memset(&P, 0, sizeof(P));
+  P.n_envs = (int32_t)num("num_envs");
+  const double sim_dt = num("simulation_dt"), control_dt = num("control_dt");
+  P.sim_dt = (float)sim_dt;
+  P.control_dt = (float)control_dt;
+  P.loop_count = (int32_t)(control_dt / sim_dt + 1e-10);  // Environment.hpp:711
+  P.seed = (uint32_t)(int32_t)num("seedd");
+  P.max_time = (float)num("max_time");
+  P.abad = (float)num("abad"); P.period = (float)num("period"); P.lam = (float)num("lam");
+  P.stand_height = (float)num("stand_height"); P.up_height_max = (float)num("up_height");
+  P.Vx = (float)num("Vx"); P.Vy = (float)num("Vy"); P.Omega = (float)num("Omega");
+  P.lean_front = (float)num("LeanFront"); P.lean_hind = (float)num("LeanHind");
+  P.manual = flag("Manual"); P.height_variable = flag("HeightVariable"); P.time_based_contact = flag("TimeBasedContact");
+  P.wildcat = flag("WILDCAT"); P.stochastic = flag("StochasticDynamics"); P.obs_filter = flag("ObsFilter");
+  P.c_term = (float)num("terminalRewardCoeff"); P.c_ee = (float)num("EndEffectorRewardCoeff");
+  P.c_pos = (float)num("BodyPosRewardCoeff"); P.c_att = (float)num("BodyAttitudeRewardCoeff");
+  P.c_joint = (float)num("JointRewardCoeff"); P.c_vel = (float)num("VelRewardCoeff");
+  P.c_torque = (float)num("TorqueCoeff"); P.c_contact = (float)num("ContactCoeff");
+  const double stiff = num("Stiffness"), damp = num("Damping"), ratio = num("AbadRatio");
+  P.kp[0] = (float)(stiff * ratio); P.kp[1] = (float)stiff; P.kp[2] = (float)stiff;  // Environment.hpp:338-350
+  P.kd[0] = (float)(damp * ratio); P.kd[1] = (float)damp; P.kd[2] = (float)damp;
+  // Environment.hpp:396 / 423-427 run in the constructor, before setControlTimeStep (VectorizedEnvironment.hpp:
+  // 150-152), so they see the base-class default control_dt_ = 0.01 (RaisimGymEnv.hpp:111).
+  P.filter_para = flag("Filter") ? (float)(1.0 - num("Freq") * 0.01) : 0.0f;
+  P.obs_filter_alpha = P.obs_filter ? (float)(2.0 * 3.14 * 0.01 * 20.0 / (2.0 * 3.14 * 0.01 * 20.0 + 1.0)) : 1.0f;
+  P.action_noise = (float)num("ActionNoise"); P.obs_noise = (float)num("ObsNoise");
+  P.tau_max = (float)num("MotorMaxTorque"); P.w_crit = (float)num("MotorCriticalSpeed"); P.w_max = (float)num("MotorMaxSpeed");
+  const int gait = (int)num("GaitType");
+  const float ph[3][4] = {{0.5f, 0.0f, 0.0f, 0.5f}, {0.5f, 0.5f, 0.0f, 0.0f}, {0.0f, 0.25f, 0.5f, 0.75f}};  // Environment.hpp:398-409
+  for (int i = 0; i < 4; i++) P.phase[i] = (gait >= 0 && gait <= 2) ? ph[gait][i] : 0.0f;
+  const double lh = 0.085, lt = 0.209, lc = 0.2175;  // Environment.hpp:1949-1952
+  P.max_len = (float)std::sqrt(lh * lh + (lc + lt) * (lc + lt));
+  // build-defined extension keys (optional)
+  P.contact_iters = c.has("ContactIterations") ? (int32_t)num("ContactIterations") : 6;
+  if (P.contact_iters <= 0) P.contact_iters = 6;
+  P.shared_noise = c.has("SharedNoiseScalar") ? (int32_t)flag("SharedNoiseScalar") : 1;
+  P.randomize_per_episode = c.has("RandomizePerEpisode") ? (int32_t)flag("RandomizePerEpisode") : 0;
+  if (!err.empty()) return false;
+  if (P.n_envs <= 0) { err = "num_envs must be positive"; return false; }
+  if (P.loop_count <= 0) { err = "control_dt / simulation_dt must be >= 1"; return false; }
+  const bool crutial = flag("Crutial"), terrain = flag("Terrain"), manual_traj = flag("ManualTraj"), force = flag("ForceDisturbance");
+  if (crutial) { err = "Crutial: True (meteorite spheres, Environment.hpp:815-861) is not built in this engine"; return false; }
+  if (terrain) { err = "Terrain: True (Perlin height map, Environment.hpp:254-264) is a later row (SURVEY 8f) and not built yet"; return false; }
+  if (!manual_traj && !P.manual) { err = "ManualTraj: False needs the RefTraj CSV path (SURVEY 8f-4), not built yet"; return false; }
+  if (force && P.manual) { err = "ForceDisturbance with Manual (state_disturbance, Environment.hpp:912-940) is not built"; return false; }
+  return true;
+}
+
+}  // namespace irrl_host

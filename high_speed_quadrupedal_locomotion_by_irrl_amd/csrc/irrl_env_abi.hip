@@ -1,0 +1,361 @@
+// irrl_env_abi.hip -- C-ABI (include/irrl_env.h) over the gfx950 env kernels.
+//
+// Host side of the drop-in boundary: owns the device state pool (the role of
+// VectorizedEnvironment<ENVIRONMENT>, VectorizedEnvironment.hpp:127-382), parses the YAML string the
+// reference hands over, and launches the kernels stream-ordered.  No CPU compute path exists here:
+// without a usable gfx950 device irrl_env_create fails.
+#include "env_kernels.hip"
+
+#include "irrl_config.hpp"
+#include "irrl_state_pool.hpp"
+#include "../../include/irrl_env.h"
+
+#include <cmath>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+
+#define HIP_TRY(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess) {                                                                             \
+      g_err = std::string(#expr) + " failed: " + hipGetErrorString(e_);                                \
+      return 1;                                                                                         \
+    }                                                                                                   \
+  } while (0)
+
+struct irrl_env {
+  EnvParams P;
+  irrl_host::Config cfg;
+  irrl_host::StatePool pool;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  void *d_pool = nullptr;
+  EnvState S;
+  // device-side I/O used by the *_host entry points
+  float *d_action = nullptr, *d_ob = nullptr, *d_reward = nullptr, *d_extra = nullptr, *d_scratch = nullptr;
+  uint8_t *d_done = nullptr;
+  // pinned host staging
+  char *h_pinned = nullptr;
+  size_t pinned_bytes = 0;
+  bool initialised = false;
+  std::string resource_dir;
+};
+
+static const char *const kExtraNames[IRRL_EXTRA_DIM] = {"EndEffectorReward(0.15)", "Height_Keep_Reward(0.1)", "base height",
+                                                        "Balance_Keep_Reward(0.1)", "JointReward(0.65)", "VelocityReward(0.2)"};
+
+static inline dim3 quad_grid(int n) { return dim3((unsigned)((n + 15) / 16)); }
+
+extern "C" {
+
+const char *irrl_last_error(void) { return g_err.c_str(); }
+const char *irrl_version(void) { return "gfx950;irrl-env r1"; }
+
+irrl_env *irrl_env_create(const char *resource_dir, const char *cfg_yaml, int device) {
+  g_err.clear();
+  if (!cfg_yaml) { g_err = "cfg_yaml is NULL"; return nullptr; }
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    g_err = "no HIP device visible: this library is gfx950 (MI355X) only and has no CPU path";
+    return nullptr;
+  }
+  if (device < 0 || device >= count) { g_err = "device ordinal out of range"; return nullptr; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) { g_err = "hipGetDeviceProperties failed"; return nullptr; }
+  if (std::string(prop.gcnArchName).find("gfx950") != 0) {
+    g_err = std::string("device arch is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+    return nullptr;
+  }
+  irrl_env *h = new irrl_env();
+  h->device = device;
+  h->resource_dir = resource_dir ? resource_dir : "";
+  if (!h->cfg.parse(cfg_yaml, g_err) || !irrl_host::build_params(h->cfg, h->P, g_err)) { delete h; return nullptr; }
+  h->pool = irrl_host::StatePool(h->P.n_envs);
+  const size_t n = (size_t)h->P.n_envs;
+  bool ok = hipSetDevice(device) == hipSuccess && hipMalloc(&h->d_pool, h->pool.bytes) == hipSuccess &&
+            hipMemset(h->d_pool, 0, h->pool.bytes) == hipSuccess && hipMalloc((void **)&h->d_action, n * 12 * 4) == hipSuccess &&
+            hipMalloc((void **)&h->d_ob, n * 35 * 4) == hipSuccess && hipMalloc((void **)&h->d_reward, n * 4) == hipSuccess &&
+            hipMalloc((void **)&h->d_extra, n * 6 * 4) == hipSuccess && hipMalloc((void **)&h->d_done, n) == hipSuccess &&
+            hipMalloc((void **)&h->d_scratch, n * 342 * 4) == hipSuccess;
+  h->pinned_bytes = n * 342 * 4 + h->pool.bytes + 4096;
+  ok = ok && hipHostMalloc((void **)&h->h_pinned, h->pinned_bytes, hipHostMallocDefault) == hipSuccess;
+  if (!ok) { g_err = "device / pinned allocation failed"; irrl_env_destroy(h); return nullptr; }
+  h->S = h->pool.view(h->d_pool);
+  return h;
+}
+
+void irrl_env_destroy(irrl_env *h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->d_pool) (void)hipFree(h->d_pool);
+  if (h->d_action) (void)hipFree(h->d_action);
+  if (h->d_ob) (void)hipFree(h->d_ob);
+  if (h->d_reward) (void)hipFree(h->d_reward);
+  if (h->d_extra) (void)hipFree(h->d_extra);
+  if (h->d_done) (void)hipFree(h->d_done);
+  if (h->d_scratch) (void)hipFree(h->d_scratch);
+  if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+  delete h;
+}
+
+int irrl_env_set_stream(irrl_env *h, void *hip_stream) { h->stream = (hipStream_t)hip_stream; return 0; }
+
+int irrl_env_init(irrl_env *h) {
+  HIP_TRY(hipSetDevice(h->device));
+  hipLaunchKernelGGL(irrl_init_kernel, quad_grid(h->P.n_envs), dim3(64), 0, h->stream, h->P, h->S);
+  HIP_TRY(hipGetLastError());
+  h->initialised = true;
+  return 0;
+}
+
+int irrl_env_num_envs(const irrl_env *h) { return h->P.n_envs; }
+int irrl_env_ob_dim(const irrl_env *) { return IRRL_OB_DIM; }
+int irrl_env_action_dim(const irrl_env *) { return IRRL_ACTION_DIM; }
+int irrl_env_extra_dim(const irrl_env *) { return IRRL_EXTRA_DIM; }
+const char *irrl_env_extra_name(const irrl_env *, int j) { return (j >= 0 && j < IRRL_EXTRA_DIM) ? kExtraNames[j] : ""; }
+
+static int need_init(irrl_env *h) {
+  if (!h->initialised) { g_err = "irrl_env_init has not been called"; return 1; }
+  return 0;
+}
+
+int irrl_env_step(irrl_env *h, const float *action, float *ob, float *reward, uint8_t *done, float *extra) {
+  if (need_init(h)) return 1;
+  hipLaunchKernelGGL(irrl_step_kernel, quad_grid(h->P.n_envs), dim3(64), 0, h->stream, h->P, h->S, action, ob, reward, done, extra);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// pinned staging layout: action | ob | reward | extra | done
+static void staging(irrl_env *h, float **a, float **o, float **r, float **x, uint8_t **d) {
+  const size_t n = (size_t)h->P.n_envs;
+  char *p = h->h_pinned;
+  *a = (float *)p; p += n * 12 * 4;
+  *o = (float *)p; p += n * 35 * 4;
+  *r = (float *)p; p += n * 4;
+  *x = (float *)p; p += n * 6 * 4;
+  *d = (uint8_t *)p;
+}
+
+static int step_host_impl(irrl_env *h, int n_step, const float *action, float *ob, float *reward, uint8_t *done, float *extra) {
+  if (need_init(h)) return 1;
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t n = (size_t)n_step;
+  float *pa, *po, *pr, *px; uint8_t *pd;
+  staging(h, &pa, &po, &pr, &px, &pd);
+  std::memcpy(pa, action, n * 12 * 4);
+  HIP_TRY(hipMemcpyAsync(h->d_action, pa, n * 12 * 4, hipMemcpyHostToDevice, h->stream));
+  EnvParams P = h->P;
+  P.n_envs = n_step;
+  hipLaunchKernelGGL(irrl_step_kernel, quad_grid(n_step), dim3(64), 0, h->stream, P, h->S, h->d_action, h->d_ob, h->d_reward, h->d_done, h->d_extra);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(po, h->d_ob, n * 35 * 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(pr, h->d_reward, n * 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(px, h->d_extra, n * 6 * 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(pd, h->d_done, n, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  std::memcpy(ob, po, n * 35 * 4);
+  std::memcpy(reward, pr, n * 4);
+  std::memcpy(extra, px, n * 6 * 4);
+  std::memcpy(done, pd, n);
+  return 0;
+}
+int irrl_env_step_host(irrl_env *h, const float *action, float *ob, float *reward, uint8_t *done, float *extra) {
+  return step_host_impl(h, h->P.n_envs, action, ob, reward, done, extra);
+}
+int irrl_env_test_step_host(irrl_env *h, const float *action, float *ob, float *reward, uint8_t *done, float *extra) {
+  return step_host_impl(h, 1, action, ob, reward, done, extra);
+}
+
+int irrl_env_reset(irrl_env *h, float *ob) {
+  if (need_init(h)) return 1;
+  hipLaunchKernelGGL(irrl_reset_kernel, quad_grid(h->P.n_envs), dim3(64), 0, h->stream, h->P, h->S, ob);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int irrl_env_observe(irrl_env *h, float *ob) {
+  if (need_init(h)) return 1;
+  hipLaunchKernelGGL(irrl_observe_kernel, quad_grid(h->P.n_envs), dim3(64), 0, h->stream, h->P, h->S, ob);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int irrl_env_is_terminal(irrl_env *h, uint8_t *done) {
+  if (need_init(h)) return 1;
+  hipLaunchKernelGGL(irrl_terminal_kernel, dim3((unsigned)((h->P.n_envs + 255) / 256)), dim3(256), 0, h->stream, h->P, h->S, done);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+static int d2h(irrl_env *h, void *dst, const void *src, size_t bytes) {
+  HIP_TRY(hipSetDevice(h->device));
+  if (bytes > h->pinned_bytes) { g_err = "staging buffer too small"; return 1; }
+  HIP_TRY(hipMemcpyAsync(h->h_pinned, src, bytes, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  std::memcpy(dst, h->h_pinned, bytes);
+  return 0;
+}
+int irrl_env_reset_host(irrl_env *h, float *ob) {
+  if (irrl_env_reset(h, h->d_ob)) return 1;
+  return d2h(h, ob, h->d_ob, (size_t)h->P.n_envs * 35 * 4);
+}
+int irrl_env_observe_host(irrl_env *h, float *ob) {
+  if (irrl_env_observe(h, h->d_ob)) return 1;
+  return d2h(h, ob, h->d_ob, (size_t)h->P.n_envs * 35 * 4);
+}
+int irrl_env_is_terminal_host(irrl_env *h, uint8_t *done) {
+  if (irrl_env_is_terminal(h, h->d_done)) return 1;
+  return d2h(h, done, h->d_done, (size_t)h->P.n_envs);
+}
+
+int irrl_env_set_seed(irrl_env *h, int seed) { h->P.seed = (uint32_t)seed; return 0; }
+int irrl_env_set_simulation_dt(irrl_env *h, double dt) {
+  if (!(dt > 0)) { g_err = "simulation dt must be positive"; return 1; }
+  h->P.sim_dt = (float)dt;
+  h->P.loop_count = (int32_t)((double)h->P.control_dt / dt + 1e-6);
+  if (h->P.loop_count < 1) h->P.loop_count = 1;
+  return 0;
+}
+int irrl_env_set_control_dt(irrl_env *h, double dt) {
+  if (!(dt > 0)) { g_err = "control dt must be positive"; return 1; }
+  h->P.control_dt = (float)dt;
+  h->P.loop_count = (int32_t)(dt / (double)h->P.sim_dt + 1e-6);
+  if (h->P.loop_count < 1) h->P.loop_count = 1;
+  return 0;
+}
+int irrl_env_close(irrl_env *) { return 0; }
+int irrl_env_curriculum_update(irrl_env *) { return 0; }
+
+// ---- diagnostics getters ----
+static int host_pool(irrl_env *h, std::vector<char> &mirror) {
+  if (need_init(h)) return 1;
+  HIP_TRY(hipSetDevice(h->device));
+  mirror.resize(h->pool.bytes);
+  HIP_TRY(hipMemcpyAsync(h->h_pinned, h->d_pool, h->pool.bytes, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  std::memcpy(mirror.data(), h->h_pinned, h->pool.bytes);
+  return 0;
+}
+int irrl_env_origin_state_host(irrl_env *h, float *out) {
+  std::vector<char> m;
+  if (host_pool(h, m)) return 1;
+  EnvState S = h->pool.view(m.data());
+  for (int e = 0; e < h->P.n_envs; e++) {
+    float *o = out + (size_t)e * 41;
+    for (int k = 0; k < 19; k++) o[k] = S.gc[e * 19 + k];
+    for (int k = 0; k < 18; k++) o[19 + k] = S.gv[e * 18 + k];
+    for (int k = 0; k < 4; k++) o[37 + k] = S.contact[e * 4 + k];
+  }
+  return 0;
+}
+int irrl_env_reference_state_host(irrl_env *h, float *out) {
+  std::vector<char> m;
+  if (host_pool(h, m)) return 1;
+  EnvState S = h->pool.view(m.data());
+  for (int e = 0; e < h->P.n_envs; e++)
+    for (int k = 0; k < 12; k++) { out[(size_t)e * 24 + k] = S.joint_ref[e * 12 + k]; out[(size_t)e * 24 + 12 + k] = S.joint_dot_ref[e * 12 + k]; }
+  return 0;
+}
+int irrl_env_joint_effort_host(irrl_env *h, float *out) {
+  std::vector<char> m;
+  if (host_pool(h, m)) return 1;
+  EnvState S = h->pool.view(m.data());
+  std::memcpy(out, S.torque, (size_t)h->P.n_envs * 12 * 4);
+  return 0;
+}
+int irrl_env_generalized_force_host(irrl_env *h, float *out) {
+  std::vector<char> m;
+  if (host_pool(h, m)) return 1;
+  EnvState S = h->pool.view(m.data());
+  for (int e = 0; e < h->P.n_envs; e++) {
+    for (int k = 0; k < 6; k++) out[(size_t)e * 18 + k] = 0.0f;  // no base wrench (ForceDisturbance never fires, ENV:751)
+    for (int k = 0; k < 12; k++) out[(size_t)e * 18 + 6 + k] = S.torque[e * 12 + k];
+  }
+  return 0;
+}
+static int probe(irrl_env *h, float *minv_host, float *nonlin_host) {
+  if (need_init(h)) return 1;
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t n = (size_t)h->P.n_envs;
+  float *d_minv = h->d_scratch, *d_nl = h->d_scratch + n * 324;
+  hipLaunchKernelGGL(irrl_probe_kernel, quad_grid(h->P.n_envs), dim3(64), 0, h->stream, h->P, h->S, minv_host ? d_minv : (float *)nullptr,
+                     nonlin_host ? d_nl : (float *)nullptr);
+  HIP_TRY(hipGetLastError());
+  if (minv_host && d2h(h, minv_host, d_minv, n * 324 * 4)) return 1;
+  if (nonlin_host && d2h(h, nonlin_host, d_nl, n * 18 * 4)) return 1;
+  return 0;
+}
+int irrl_env_inverse_mass_matrix_host(irrl_env *h, float *out) { return probe(h, out, nullptr); }
+int irrl_env_nonlinear_host(irrl_env *h, float *out) { return probe(h, nullptr, out); }
+int irrl_env_set_contact_coeff_host(irrl_env *h, const float *in) {
+  if (need_init(h)) return 1;
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t bytes = (size_t)h->P.n_envs * 3 * 4;
+  std::memcpy(h->h_pinned, in, bytes);
+  HIP_TRY(hipMemcpyAsync(h->S.material, h->h_pinned, bytes, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+int irrl_env_sphere_info_host(irrl_env *, float *) {
+  g_err = "GetSphereInfo needs Crutial: True (Environment.hpp:1423-1436), which this engine does not build";
+  return 1;
+}
+
+int irrl_env_get_state_host(irrl_env *h, double *out) {
+  std::vector<char> m;
+  if (host_pool(h, m)) return 1;
+  h->pool.pack(m.data(), out);
+  return 0;
+}
+int irrl_env_set_state_host(irrl_env *h, const double *in) {
+  std::vector<char> m;
+  if (host_pool(h, m)) return 1;
+  h->pool.unpack(in, m.data());
+  std::memcpy(h->h_pinned, m.data(), h->pool.bytes);
+  HIP_TRY(hipMemcpyAsync(h->d_pool, h->h_pinned, h->pool.bytes, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+double irrl_env_cfg_value(const irrl_env *h, const char *key) {
+  double d = NAN;
+  std::string e;
+  bool b;
+  auto it = h->cfg.kv.find(key);
+  if (it == h->cfg.kv.end()) return NAN;
+  if (irrl_host::Config::to_bool(it->second, b)) return b ? 1.0 : 0.0;
+  if (!h->cfg.get_double(key, d, e)) return NAN;
+  return d;
+}
+
+// ---- GAE reverse scan (ppo2.py:554-568): one lane per env, coalesced [T,N] rows ----
+__global__ void irrl_gae_kernel(int T, int N, const float *__restrict__ rewards, const float *__restrict__ values,
+                                const uint8_t *__restrict__ dones, const float *__restrict__ last_values,
+                                const uint8_t *__restrict__ last_dones, float gamma, float lam, float *__restrict__ adv,
+                                float *__restrict__ returns) {
+  int n = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (n >= N) return;
+  float last = 0.0f;
+  float nextv = last_values[n];
+  float nonterm = 1.0f - (float)last_dones[n];
+  for (int t = T - 1; t >= 0; t--) {
+    size_t i = (size_t)t * N + n;
+    float v = values[i];
+    float delta = rewards[i] + gamma * nextv * nonterm - v;
+    last = delta + gamma * lam * nonterm * last;
+    adv[i] = last;
+    returns[i] = last + v;
+    nextv = v;
+    nonterm = 1.0f - (float)dones[i];
+  }
+}
+int irrl_gae(int T, int N, const float *rewards, const float *values, const uint8_t *dones, const float *last_values,
+             const uint8_t *last_dones, float gamma, float lam, float *adv, float *returns, void *hip_stream) {
+  if (T <= 0 || N <= 0) { g_err = "irrl_gae: empty rollout"; return 1; }
+  hipLaunchKernelGGL(irrl_gae_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, (hipStream_t)hip_stream, T, N, rewards, values, dones,
+                     last_values, last_dones, gamma, lam, adv, returns);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

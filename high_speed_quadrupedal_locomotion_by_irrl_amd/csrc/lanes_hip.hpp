@@ -1,0 +1,102 @@
+// lanes_hip.hpp -- lane primitives for gfx950 (CDNA4), wave64.
+//
+// Mapping used by every env kernel: ONE DPP QUAD PER ROBOT, ONE LEG PER LANE.
+//   lane = threadIdx.x & 63, leg = lane & 3 (FR, FL, HR, HL), env = blockIdx.x * 16 + (lane >> 2).
+// The four legs of a robot only couple through the floating base, so every cross-lane exchange of
+// the dynamics is a reduction or a broadcast inside a quad -- exactly what DPP quad_perm does in the
+// VALU operand path (no LDS, no ds_bpermute).  A wave carries 16 robots.
+//
+// env_core.hpp is written against the names defined here (vf/vi/vu/vm + helpers) so that the very
+// same algorithm source can also be instantiated by the host-side lane emulation under
+// tests/host_emulation (a debugging aid for the no-GPU build container; never part of the product).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define IRRL_DEV __device__ __forceinline__
+
+typedef float vf;
+typedef int32_t vi;
+typedef uint32_t vu;
+typedef bool vm;
+
+namespace lanes {
+
+IRRL_DEV vi leg_id() { return (vi)(threadIdx.x & 3u); }
+
+// ---- DPP quad primitives ----
+template <int CTRL>
+IRRL_DEV float dpp_quad(float x) {
+  int xi = __builtin_bit_cast(int, x);
+  int r = __builtin_amdgcn_update_dpp(xi, xi, CTRL, 0xF, 0xF, false);
+  return __builtin_bit_cast(float, r);
+}
+template <int CTRL>
+IRRL_DEV int dpp_quad_i(int x) { return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xF, 0xF, false); }
+
+// sum over the 4 lanes of the quad, result in every lane (quad_perm [1,0,3,2] then [2,3,0,1])
+IRRL_DEV vf quad_sum(vf x) {
+  x += dpp_quad<0xB1>(x);
+  x += dpp_quad<0x4E>(x);
+  return x;
+}
+IRRL_DEV vi quad_sum_i(vi x) {
+  x += dpp_quad_i<0xB1>(x);
+  x += dpp_quad_i<0x4E>(x);
+  return x;
+}
+// value of lane K of the quad in every lane (quad_perm [K,K,K,K]); K is a compile-time constant
+template <int K>
+IRRL_DEV vf quad_bcast(vf x) { return dpp_quad<K * 0x55>(x); }
+template <int K>
+IRRL_DEV vi quad_bcast_i(vi x) { return dpp_quad_i<K * 0x55>(x); }
+
+// ---- masks / selects ----
+IRRL_DEV vf vsel(vm m, vf a, vf b) { return m ? a : b; }
+IRRL_DEV vi vsel_i(vm m, vi a, vi b) { return m ? a : b; }
+IRRL_DEV vu vsel_u(vm m, vu a, vu b) { return m ? a : b; }
+IRRL_DEV bool wave_any(vm m) { return __ballot(m) != 0ull; }
+// wave-uniform maximum of a small non-negative per-lane integer (0..4)
+IRRL_DEV int wave_max_small(vi x) {
+  int r = 0;
+  if (__ballot(x >= 1) != 0ull) r = 1;
+  if (__ballot(x >= 2) != 0ull) r = 2;
+  if (__ballot(x >= 3) != 0ull) r = 3;
+  if (__ballot(x >= 4) != 0ull) r = 4;
+  return r;
+}
+
+// ---- math (full-precision OCML forms: parity with the f64 oracle is judged at fp32 tolerance) ----
+IRRL_DEV vf v_sqrt(vf x) { return sqrtf(x); }
+IRRL_DEV vf v_rcp(vf x) { return 1.0f / x; }
+IRRL_DEV vf v_sin(vf x) { return sinf(x); }
+IRRL_DEV vf v_cos(vf x) { return cosf(x); }
+IRRL_DEV void v_sincos(vf x, vf &s, vf &c) { sincosf(x, &s, &c); }
+IRRL_DEV vf v_asin(vf x) { return asinf(x); }
+IRRL_DEV vf v_acos(vf x) { return acosf(x); }
+IRRL_DEV vf v_exp(vf x) { return expf(x); }
+IRRL_DEV vf v_log(vf x) { return logf(x); }
+IRRL_DEV vf v_fmod(vf x, vf y) { return fmodf(x, y); }
+IRRL_DEV vf v_abs(vf x) { return fabsf(x); }
+IRRL_DEV vf v_min(vf a, vf b) { return a < b ? a : b; }   // fmin(a,b) for non-NaN operands
+IRRL_DEV vf v_max(vf a, vf b) { return a > b ? a : b; }
+IRRL_DEV vu to_u(vi x) { return (vu)x; }
+IRRL_DEV vf u2f(vu x) { return (float)x; }
+IRRL_DEV vf i2f(vi x) { return (float)x; }
+IRRL_DEV vu mulhi_u32(vu a, vu b) { return __umulhi(a, b); }
+
+// ---- memory ----
+IRRL_DEV vf ld(const float *p, vi idx) { return p[idx]; }
+IRRL_DEV vi ld_i(const int32_t *p, vi idx) { return p[idx]; }
+IRRL_DEV vu ld_u(const uint32_t *p, vi idx) { return p[idx]; }
+IRRL_DEV void st(float *p, vi idx, vf v) { p[idx] = v; }
+IRRL_DEV void st_i(int32_t *p, vi idx, vi v) { p[idx] = v; }
+IRRL_DEV void st_u(uint32_t *p, vi idx, vu v) { p[idx] = v; }
+IRRL_DEV void st_u8(uint8_t *p, vi idx, vi v) { p[idx] = (uint8_t)v; }
+// store only from the lanes whose mask is set
+IRRL_DEV void st_if(vm m, float *p, vi idx, vf v) { if (m) p[idx] = v; }
+IRRL_DEV void st_i_if(vm m, int32_t *p, vi idx, vi v) { if (m) p[idx] = v; }
+IRRL_DEV void st_u_if(vm m, uint32_t *p, vi idx, vu v) { if (m) p[idx] = v; }
+IRRL_DEV void st_u8_if(vm m, uint8_t *p, vi idx, vi v) { if (m) p[idx] = (uint8_t)v; }
+
+}  // namespace lanes

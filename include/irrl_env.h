@@ -1,0 +1,123 @@
+/*
+ * irrl_env.h -- C-ABI of the MI355X-native BlackPanther vector environment (libirrl_env.so).
+ *
+ * This is the drop-in boundary for the hot path  FlexibleGymEnv.step()  of
+ * WoodenJin/High_Speed_Quadrupedal_Locomotion_by_IRRL.  Every entry point names the reference
+ * interface it replaces; paths are under IRRL/FlexibleRobotRaisimGym/flex_gym/env/ :
+ *   PYB = raisim_gym.cpp (pybind11 module `_flexible_robot`, class `FlexibleGymEnv`)
+ *   VEC = VectorizedEnvironment.hpp,  ENV = env/BlackPanther_V55/Environment.hpp
+ *
+ * Conventions
+ *   - plain C: opaque handle, pointers and sizes only; no torch / pybind / Eigen types.
+ *   - every function returns 0 on success, non-zero on failure (irrl_last_error() has the text);
+ *     the reference has no error channel: it aborts on a missing YAML key (RaisimGymEnv.hpp:41-42).
+ *   - "device pointer" entry points (suffix-less) take HIP device pointers and are stream-ordered on the
+ *     stream given to irrl_env_set_stream (default: the null stream); they never synchronise.
+ *     "_host" entry points take host pointers like the reference's numpy arrays
+ *     (Eigen::Ref<RowMajor float/bool>, RaisimGymEnv.hpp:46-49), copy through a pinned staging buffer and
+ *     return after the outputs are valid on the host.
+ *   - the library needs a gfx950 GPU: irrl_env_create fails (returns NULL) when none is usable.
+ *     There is no CPU fallback of any kind behind this ABI.
+ *   - array shapes: ob [N,35] f32, action [N,12] f32, reward [N] f32, done [N] u8 (numpy bool),
+ *     extraInfo [N,6] f32, all C-contiguous, caller-owned, written in place (RaisimGymVecEnv.py:16-20).
+ */
+#ifndef IRRL_ENV_H
+#define IRRL_ENV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct irrl_env irrl_env;
+
+#define IRRL_OB_DIM 35      /* ENV:360 */
+#define IRRL_ACTION_DIM 12  /* ENV:361 */
+#define IRRL_EXTRA_DIM 6    /* ENV:942-950 */
+#define IRRL_ORIGIN_STATE_DIM 41 /* ENV:1330-1334: gc 19 + gv 18 + contact 4 */
+
+const char *irrl_last_error(void);
+/* build identification: "gfx950;<git-describe or date>" */
+const char *irrl_version(void);
+
+/* PYB:16 ctor (std::string resourceDir, std::string cfg) -> VEC:132-138.  cfg_yaml is the dumped
+ * `environment:` mapping (run_bp_v5.py:205-207).  device = HIP device ordinal.  NULL on failure. */
+irrl_env *irrl_env_create(const char *resource_dir, const char *cfg_yaml, int device);
+/* VEC:140-143 destructor */
+void irrl_env_destroy(irrl_env *h);
+/* PYB:17 init -> VEC:145-194 (constructor randomisation ENV:435-477 + first reset of every env) */
+int irrl_env_init(irrl_env *h);
+/* use `hip_stream` (a hipStream_t) for all later launches / async copies of this handle */
+int irrl_env_set_stream(irrl_env *h, void *hip_stream);
+
+/* PYB:28-31 */
+int irrl_env_num_envs(const irrl_env *h);
+int irrl_env_ob_dim(const irrl_env *h);
+int irrl_env_action_dim(const irrl_env *h);
+int irrl_env_extra_dim(const irrl_env *h);
+/* PYB:18 getExtraInfoNames (VEC:191-193): name j in [0, 6); order fixed by this build */
+const char *irrl_env_extra_name(const irrl_env *h, int j);
+
+/* PYB:21,23 step -> VEC:268-278 (+ perAgentStep VEC:352-372, ENVIRONMENT::step ENV:692-809) */
+int irrl_env_step(irrl_env *h, const float *action, float *ob, float *reward, uint8_t *done, float *extra);
+int irrl_env_step_host(irrl_env *h, const float *action, float *ob, float *reward, uint8_t *done, float *extra);
+/* PYB:24 testStep -> VEC:280-290: env 0 only in the reference (visual eval); here it steps env 0 only and
+ * leaves rows 1.. of the outputs untouched (headless: no rendering). */
+int irrl_env_test_step_host(irrl_env *h, const float *action, float *ob, float *reward, uint8_t *done, float *extra);
+/* PYB:19 reset -> VEC:201-207 (all envs, then observe) */
+int irrl_env_reset(irrl_env *h, float *ob);
+int irrl_env_reset_host(irrl_env *h, float *ob);
+/* PYB:20 observe -> VEC:209-212 */
+int irrl_env_observe(irrl_env *h, float *ob);
+int irrl_env_observe_host(irrl_env *h, float *ob);
+/* PYB:26 isTerminalState -> VEC:314-319 */
+int irrl_env_is_terminal(irrl_env *h, uint8_t *done);
+int irrl_env_is_terminal_host(irrl_env *h, uint8_t *done);
+/* PYB:22 setSeed -> VEC:308-312.  The reference seeds the process-global std::srand per env
+ * (last call wins); here it re-keys the counter RNG for all later draws. */
+int irrl_env_set_seed(irrl_env *h, int seed);
+/* PYB:27-28 setSimulationTimeStep / setControlTimeStep -> VEC:321-329 */
+int irrl_env_set_simulation_dt(irrl_env *h, double dt);
+int irrl_env_set_control_dt(irrl_env *h, double dt);
+/* PYB:25 close (no-op, ENV:1585), PYB:36 curriculumUpdate (no-op, RaisimGymEnv.hpp:76) */
+int irrl_env_close(irrl_env *h);
+int irrl_env_curriculum_update(irrl_env *h);
+
+/* diagnostics getters, host pointers (PYB:37-45; RaisimGymVecEnv.py:54-93) */
+int irrl_env_origin_state_host(irrl_env *h, float *out /* [N,41]  ENV:1317-1325 */);
+int irrl_env_reference_state_host(irrl_env *h, float *out /* [N,24] ENV:1339-1345 jointRef, jointDotRef */);
+int irrl_env_joint_effort_host(irrl_env *h, float *out /* [N,12] ENV:1350-1358 */);
+int irrl_env_generalized_force_host(irrl_env *h, float *out /* [N,18] ENV:1363-1370 */);
+int irrl_env_inverse_mass_matrix_host(irrl_env *h, float *out /* [N,324] column-major, ENV:1375-1391 */);
+int irrl_env_nonlinear_host(irrl_env *h, float *out /* [N,18] ENV:1396-1402 */);
+int irrl_env_set_contact_coeff_host(irrl_env *h, const float *in /* [N,3] mu, e, thr; ENV:1407-1418 */);
+/* PYB:46 GetSphereInfo needs Crutial: True (ENV:1423-1436), which this engine does not build: returns an error */
+int irrl_env_sphere_info_host(irrl_env *h, float *out /* [N,4] */);
+
+/* Full state exchange (build-defined, for checkpoint/parity): flat [N, IRRL_STATE_DIM] doubles per env,
+ * fields at the IRRL_S_* offsets below. */
+#define IRRL_STATE_DIM 288
+enum {
+  IRRL_S_GC = 0, IRRL_S_GV = 19, IRRL_S_PTARGET_LAST = 37, IRRL_S_TORQUE_LAST = 49, IRRL_S_TORQUE = 61,
+  IRRL_S_JOINT_REF = 73, IRRL_S_JOINT_REF_LAST = 85, IRRL_S_JOINT_DOT_REF = 97, IRRL_S_EE_REF = 109,
+  IRRL_S_COMMAND = 121, IRRL_S_COMMAND_FILTERED = 124, IRRL_S_T0 = 127, IRRL_S_FRAME = 128, IRRL_S_EPISODE = 129,
+  IRRL_S_UP_HEIGHT = 130, IRRL_S_CONTACT = 131, IRRL_S_LAMBDA_W = 135, IRRL_S_IN_CONTACT = 147,
+  IRRL_S_MATERIAL = 151, IRRL_S_MASS = 154, IRRL_S_COM = 167, IRRL_S_THIGH_DZ = 206, IRRL_S_OB = 207,
+  IRRL_S_OB_LAST = 242, IRRL_S_END = 277
+};
+int irrl_env_get_state_host(irrl_env *h, double *out);
+int irrl_env_set_state_host(irrl_env *h, const double *in);
+/* value of a numeric/bool config key as parsed by the library (tests the YAML reader); NaN if absent */
+double irrl_env_cfg_value(const irrl_env *h, const char *key);
+
+/* ---- learner-side device ops on the same path (ppo2.py:554-568): GAE reverse scan ---- */
+/* rewards/values/adv/returns [T,N] f32 row-major, dones [T,N] u8 (flag stored BEFORE step t, ppo2.py:526),
+ * last_values [N], last_dones [N]; device pointers, stream-ordered on `hip_stream`. */
+int irrl_gae(int T, int N, const float *rewards, const float *values, const uint8_t *dones, const float *last_values,
+             const uint8_t *last_dones, float gamma, float lam, float *adv, float *returns, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

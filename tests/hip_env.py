@@ -1,0 +1,44 @@
+"""Test adapter: the product path (HIP kernels behind the C-ABI, via the reference-style FlexibleGymEnv
+shim) wrapped to the tiny interface parity_lib.py drives.  Imports nothing from oracle/."""
+import numpy as np
+import yaml
+
+import high_speed_quadrupedal_locomotion_by_irrl_amd as pkg
+from high_speed_quadrupedal_locomotion_by_irrl_amd.flexible_robot import FlexibleGymEnv
+
+
+class HipVecEnv(object):
+    def __init__(self, env_cfg):
+        text = yaml.safe_dump(dict(env_cfg), default_flow_style=False)
+        self.impl = FlexibleGymEnv(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY__, text)
+        self.impl.init()
+        self.n = self.impl.getNumOfEnvs()
+        self._ob = np.zeros((self.n, 35), np.float32)
+        self._rew = np.zeros(self.n, np.float32)
+        self._done = np.zeros(self.n, np.bool_)
+        self._extra = np.zeros((self.n, 6), np.float32)
+
+    def observe(self):
+        self.impl.observe(self._ob)
+        return self._ob.copy()
+
+    def reset(self):
+        self.impl.reset(self._ob)
+        return self._ob.copy()
+
+    def step(self, action):
+        self.impl.step(np.ascontiguousarray(action, np.float32), self._ob, self._rew, self._done, self._extra)
+        return self._ob.copy(), self._rew.copy(), self._done.copy(), self._extra.copy()
+
+    def probe(self):
+        minv = np.zeros((self.n, 324), np.float32)
+        nl = np.zeros((self.n, 18), np.float32)
+        self.impl.GetInverseMassMatrix(minv)
+        self.impl.GetNonlinear(nl)
+        return minv, nl
+
+    def get_state(self):
+        return self.impl.get_state()
+
+    def set_state(self, st):
+        self.impl.set_state(st)

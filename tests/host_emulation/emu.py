@@ -1,0 +1,96 @@
+"""ctypes wrapper of the TEST-ONLY host emulation of the env kernels (see emu_main.cpp)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import yaml
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "..", "..", "high_speed_quadrupedal_locomotion_by_irrl_amd", "csrc")
+_LIB = None
+STATE_DIM = 288
+
+
+def build():
+    out = os.path.join(_HERE, "_build", "libirrl_emu.so")
+    srcs = [os.path.join(_HERE, f) for f in ("emu_main.cpp", "lanes_cpu.hpp")] + \
+           [os.path.join(_CSRC, f) for f in ("env_core.hpp", "env_params.h", "irrl_config.hpp", "irrl_state_pool.hpp")]
+    if (not os.path.exists(out)) or os.path.getmtime(out) < max(os.path.getmtime(s) for s in srcs):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-I" + _CSRC,
+                               "-o", out, os.path.join(_HERE, "emu_main.cpp")])
+    return out
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        l = C.CDLL(build())
+        l.emu_create.restype = C.c_void_p
+        l.emu_create.argtypes = [C.c_char_p]
+        l.emu_last_error.restype = C.c_char_p
+        vp, fp, dp, u8 = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_uint8)
+        for n, a in dict(emu_destroy=[vp], emu_init=[vp], emu_reset=[vp, fp], emu_observe=[vp, fp],
+                         emu_step=[vp, fp, fp, fp, u8, fp], emu_probe=[vp, fp, fp], emu_get_state=[vp, dp],
+                         emu_set_state=[vp, dp]).items():
+            getattr(l, n).restype = None
+            getattr(l, n).argtypes = a
+        l.emu_num_envs.restype = C.c_int
+        l.emu_num_envs.argtypes = [vp]
+        _LIB = l
+    return _LIB
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class EmuVecEnv(object):
+    def __init__(self, env_cfg):
+        self.l = lib()
+        text = yaml.safe_dump(dict(env_cfg), default_flow_style=False)
+        self.h = self.l.emu_create(text.encode())
+        if not self.h:
+            raise RuntimeError(self.l.emu_last_error().decode())
+        self.n = self.l.emu_num_envs(self.h)
+        self.l.emu_init(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.l.emu_destroy(self.h)
+            self.h = None
+
+    def reset(self):
+        ob = np.zeros((self.n, 35), np.float32)
+        self.l.emu_reset(self.h, _fp(ob))
+        return ob
+
+    def observe(self):
+        ob = np.zeros((self.n, 35), np.float32)
+        self.l.emu_observe(self.h, _fp(ob))
+        return ob
+
+    def step(self, action):
+        action = np.ascontiguousarray(action, np.float32)
+        ob = np.zeros((self.n, 35), np.float32)
+        rew = np.zeros(self.n, np.float32)
+        done = np.zeros(self.n, np.uint8)
+        extra = np.zeros((self.n, 6), np.float32)
+        self.l.emu_step(self.h, _fp(action), _fp(ob), _fp(rew), done.ctypes.data_as(C.POINTER(C.c_uint8)), _fp(extra))
+        return ob, rew, done.astype(bool), extra
+
+    def probe(self):
+        minv = np.zeros((self.n, 324), np.float32)
+        nl = np.zeros((self.n, 18), np.float32)
+        self.l.emu_probe(self.h, _fp(minv), _fp(nl))
+        return minv, nl
+
+    def get_state(self):
+        out = np.zeros((self.n, STATE_DIM), np.float64)
+        self.l.emu_get_state(self.h, out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
+
+    def set_state(self, st):
+        st = np.ascontiguousarray(st, np.float64)
+        self.l.emu_set_state(self.h, st.ctypes.data_as(C.POINTER(C.c_double)))

@@ -1,0 +1,66 @@
+// emu_main.cpp -- TEST-ONLY host emulation of the env kernels.
+//
+// Compiles the product's kernel source (csrc/env_core.hpp) against tests/host_emulation/lanes_cpu.hpp,
+// where a "quad" is four array slots stepped in lockstep.  Purpose: let the CPU test-suite (no GPU in
+// the build container) exercise the exact lane algorithm -- Schur-complement dynamics, DPP-style quad
+// reductions, masked reset -- against the f64 oracle before the kernels ever reach an MI355X.
+// It is NOT a product path: nothing in the package loads this library, and the C-ABI has no CPU mode.
+#include "lanes_cpu.hpp"
+
+#include "env_core.hpp"
+#include "irrl_config.hpp"
+#include "irrl_state_pool.hpp"
+
+#include <string>
+#include <vector>
+
+struct Emu {
+  EnvParams P;
+  irrl_host::StatePool pool;
+  std::vector<char> mem;
+  EnvState S;
+};
+static std::string g_err;
+
+static inline vi lanes_env(int e) { return vi(e); }
+
+extern "C" {
+const char *emu_last_error() { return g_err.c_str(); }
+void *emu_create(const char *cfg_yaml) {
+  g_err.clear();
+  irrl_host::Config c;
+  Emu *h = new Emu();
+  if (!c.parse(cfg_yaml, g_err) || !irrl_host::build_params(c, h->P, g_err)) { delete h; return nullptr; }
+  h->pool = irrl_host::StatePool(h->P.n_envs);
+  h->mem.assign(h->pool.bytes, 0);
+  h->S = h->pool.view(h->mem.data());
+  return h;
+}
+void emu_destroy(void *hv) { delete (Emu *)hv; }
+int emu_num_envs(void *hv) { return ((Emu *)hv)->P.n_envs; }
+void emu_init(void *hv) {
+  Emu *h = (Emu *)hv;
+  for (int e = 0; e < h->P.n_envs; e++) irrl::init_body(h->P, h->S, lanes_env(e), lanes::leg_id(), vm(true));
+}
+void emu_reset(void *hv, float *ob) {
+  Emu *h = (Emu *)hv;
+  for (int e = 0; e < h->P.n_envs; e++) irrl::reset_body(h->P, h->S, lanes_env(e), lanes::leg_id(), vm(true), ob);
+}
+void emu_observe(void *hv, float *ob) {
+  Emu *h = (Emu *)hv;
+  for (int e = 0; e < h->P.n_envs; e++) irrl::observe_body(h->P, h->S, lanes_env(e), lanes::leg_id(), vm(true), ob);
+}
+void emu_step(void *hv, const float *action, float *ob, float *reward, uint8_t *done, float *extra) {
+  Emu *h = (Emu *)hv;
+  for (int e = 0; e < h->P.n_envs; e++)
+    irrl::step_body(h->P, h->S, lanes_env(e), lanes::leg_id(), vm(true), action, ob, reward, done, extra);
+}
+void emu_probe(void *hv, float *minv, float *nonlin) {
+  Emu *h = (Emu *)hv;
+  for (int e = 0; e < h->P.n_envs; e++)
+    irrl::dynamics_probe_body(h->P, h->S, lanes_env(e), lanes::leg_id(), vm(true), minv, nonlin);
+}
+void emu_get_state(void *hv, double *out) { Emu *h = (Emu *)hv; h->pool.pack(h->mem.data(), out); }
+void emu_set_state(void *hv, const double *in) { Emu *h = (Emu *)hv; h->pool.unpack(in, h->mem.data()); }
+void emu_get_params(void *hv, EnvParams *out) { *out = ((Emu *)hv)->P; }
+}

@@ -1,0 +1,79 @@
+// lanes_cpu.hpp -- host-side emulation of ONE DPP quad (4 lanes in lockstep) so that the kernel source
+// env_core.hpp can be executed and debugged in the GPU-less build container.
+//
+// TEST-ONLY: compiled into tests/host_emulation/_build/libirrl_emu.so by the test-suite; it is not part
+// of the product library, is not reachable from the C-ABI (include/irrl_env.h) and is never used for a
+// result the product reports.  A "wave" here is a single quad, so wave_any == quad_any.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+#define IRRL_DEV inline
+
+struct vm { bool v[4]; vm() {} vm(bool b) { for (int i = 0; i < 4; i++) v[i] = b; } };
+struct vf { float v[4]; vf() {} vf(float s) { for (int i = 0; i < 4; i++) v[i] = s; } };
+struct vi { int32_t v[4]; vi() {} vi(int32_t s) { for (int i = 0; i < 4; i++) v[i] = s; } };
+struct vu { uint32_t v[4]; vu() {} vu(uint32_t s) { for (int i = 0; i < 4; i++) v[i] = s; } };
+
+#define LANEWISE_BIN(T, R, OP)                                                                         \
+  inline R operator OP(T a, T b) { R r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] OP b.v[i]; return r; }
+LANEWISE_BIN(vf, vf, +) LANEWISE_BIN(vf, vf, -) LANEWISE_BIN(vf, vf, *) LANEWISE_BIN(vf, vf, /)
+LANEWISE_BIN(vf, vm, <) LANEWISE_BIN(vf, vm, >) LANEWISE_BIN(vf, vm, <=) LANEWISE_BIN(vf, vm, >=)
+LANEWISE_BIN(vi, vi, +) LANEWISE_BIN(vi, vi, -) LANEWISE_BIN(vi, vi, *) LANEWISE_BIN(vi, vi, &)
+LANEWISE_BIN(vi, vm, ==) LANEWISE_BIN(vi, vm, !=) LANEWISE_BIN(vi, vm, <) LANEWISE_BIN(vi, vm, >=)
+LANEWISE_BIN(vu, vu, +) LANEWISE_BIN(vu, vu, *) LANEWISE_BIN(vu, vu, ^)
+LANEWISE_BIN(vm, vm, &) LANEWISE_BIN(vm, vm, |)
+// scalar on either side
+#define SCALAR_BIN(T, S, R, OP)                          \
+  inline R operator OP(T a, S b) { return a OP T(b); }   \
+  inline R operator OP(S a, T b) { return T(a) OP b; }
+SCALAR_BIN(vf, float, vf, +) SCALAR_BIN(vf, float, vf, -) SCALAR_BIN(vf, float, vf, *) SCALAR_BIN(vf, float, vf, /)
+SCALAR_BIN(vf, float, vm, <) SCALAR_BIN(vf, float, vm, >) SCALAR_BIN(vf, float, vm, <=) SCALAR_BIN(vf, float, vm, >=)
+SCALAR_BIN(vi, int, vi, +) SCALAR_BIN(vi, int, vi, -) SCALAR_BIN(vi, int, vi, *) SCALAR_BIN(vi, int, vi, &)
+SCALAR_BIN(vi, int, vm, ==) SCALAR_BIN(vi, int, vm, !=) SCALAR_BIN(vi, int, vm, <) SCALAR_BIN(vi, int, vm, >=)
+SCALAR_BIN(vu, uint32_t, vu, +) SCALAR_BIN(vu, uint32_t, vu, *) SCALAR_BIN(vu, uint32_t, vu, ^)
+inline vf operator-(vf a) { vf r; for (int i = 0; i < 4; i++) r.v[i] = -a.v[i]; return r; }
+inline vm operator!(vm a) { vm r; for (int i = 0; i < 4; i++) r.v[i] = !a.v[i]; return r; }
+inline vu operator>>(vu a, int s) { vu r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] >> s; return r; }
+inline vf &operator+=(vf &a, vf b) { a = a + b; return a; }
+inline vf &operator-=(vf &a, vf b) { a = a - b; return a; }
+
+namespace lanes {
+inline vi leg_id() { vi r; for (int i = 0; i < 4; i++) r.v[i] = i; return r; }
+inline vf quad_sum(vf x) {
+  // same association as the two DPP steps: (x_i + x_{i^1}) + (x_{i^2} + x_{i^3})
+  vf a, r;
+  for (int i = 0; i < 4; i++) a.v[i] = x.v[i] + x.v[i ^ 1];
+  for (int i = 0; i < 4; i++) r.v[i] = a.v[i] + a.v[i ^ 2];
+  return r;
+}
+inline vi quad_sum_i(vi x) { int s = x.v[0] + x.v[1] + x.v[2] + x.v[3]; return vi(s); }
+template <int K> inline vf quad_bcast(vf x) { return vf(x.v[K]); }
+template <int K> inline vi quad_bcast_i(vi x) { return vi(x.v[K]); }
+inline vf vsel(vm m, vf a, vf b) { vf r; for (int i = 0; i < 4; i++) r.v[i] = m.v[i] ? a.v[i] : b.v[i]; return r; }
+inline vi vsel_i(vm m, vi a, vi b) { vi r; for (int i = 0; i < 4; i++) r.v[i] = m.v[i] ? a.v[i] : b.v[i]; return r; }
+inline vu vsel_u(vm m, vu a, vu b) { vu r; for (int i = 0; i < 4; i++) r.v[i] = m.v[i] ? a.v[i] : b.v[i]; return r; }
+inline bool wave_any(vm m) { return m.v[0] || m.v[1] || m.v[2] || m.v[3]; }
+inline int wave_max_small(vi x) { int r = 0; for (int i = 0; i < 4; i++) r = x.v[i] > r ? x.v[i] : r; return r; }
+#define LANEWISE_FN(name, expr) inline vf name(vf x) { vf r; for (int i = 0; i < 4; i++) { float a = x.v[i]; r.v[i] = (expr); } return r; }
+LANEWISE_FN(v_sqrt, std::sqrt(a)) LANEWISE_FN(v_rcp, 1.0f / a) LANEWISE_FN(v_sin, std::sin(a)) LANEWISE_FN(v_cos, std::cos(a))
+LANEWISE_FN(v_asin, std::asin(a)) LANEWISE_FN(v_acos, std::acos(a)) LANEWISE_FN(v_exp, std::exp(a)) LANEWISE_FN(v_log, std::log(a))
+LANEWISE_FN(v_abs, std::fabs(a))
+inline void v_sincos(vf x, vf &s, vf &c) { s = v_sin(x); c = v_cos(x); }
+inline vf v_fmod(vf x, vf y) { vf r; for (int i = 0; i < 4; i++) r.v[i] = std::fmod(x.v[i], y.v[i]); return r; }
+inline vf v_min(vf a, vf b) { return vsel(a < b, a, b); }
+inline vf v_max(vf a, vf b) { return vsel(a > b, a, b); }
+inline vu to_u(vi x) { vu r; for (int i = 0; i < 4; i++) r.v[i] = (uint32_t)x.v[i]; return r; }
+inline vf u2f(vu x) { vf r; for (int i = 0; i < 4; i++) r.v[i] = (float)x.v[i]; return r; }
+inline vf i2f(vi x) { vf r; for (int i = 0; i < 4; i++) r.v[i] = (float)x.v[i]; return r; }
+inline vu mulhi_u32(vu a, vu b) { vu r; for (int i = 0; i < 4; i++) r.v[i] = (uint32_t)(((uint64_t)a.v[i] * b.v[i]) >> 32); return r; }
+inline vu mulhi_u32(vu a, uint32_t b) { return mulhi_u32(a, vu(b)); }
+inline vf ld(const float *p, vi idx) { vf r; for (int i = 0; i < 4; i++) r.v[i] = p[idx.v[i]]; return r; }
+inline vi ld_i(const int32_t *p, vi idx) { vi r; for (int i = 0; i < 4; i++) r.v[i] = p[idx.v[i]]; return r; }
+inline vu ld_u(const uint32_t *p, vi idx) { vu r; for (int i = 0; i < 4; i++) r.v[i] = p[idx.v[i]]; return r; }
+inline void st_if(vm m, float *p, vi idx, vf v) { for (int i = 0; i < 4; i++) if (m.v[i]) p[idx.v[i]] = v.v[i]; }
+inline void st_i_if(vm m, int32_t *p, vi idx, vi v) { for (int i = 0; i < 4; i++) if (m.v[i]) p[idx.v[i]] = v.v[i]; }
+inline void st_u_if(vm m, uint32_t *p, vi idx, vu v) { for (int i = 0; i < 4; i++) if (m.v[i]) p[idx.v[i]] = v.v[i]; }
+inline void st_u8_if(vm m, uint8_t *p, vi idx, vi v) { for (int i = 0; i < 4; i++) if (m.v[i]) p[idx.v[i]] = (uint8_t)v.v[i]; }
+}  // namespace lanes
