@@ -63,6 +63,10 @@ def load():
         raise RuntimeError("libirrl_env.so is missing: build the gfx950 extension first "
                            "(python -m high_speed_quadrupedal_locomotion_by_irrl_amd.build). "
                            "There is no CPU or PyTorch fallback for the env kernels.")
+    # PyTorch-ROCm is the device-memory / stream plumbing of this engine and ships its own HIP runtime
+    # (libamdhip64).  Import it BEFORE dlopen-ing the kernels so that the process holds exactly one HIP runtime
+    # (two copies in one process cannot both open the device: the second one sees no GPU).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported

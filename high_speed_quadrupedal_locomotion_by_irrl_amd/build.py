@@ -32,7 +32,7 @@ def is_stale():
 def build(force=False, verbose=False, extra_flags=()):
     if not force and not is_stale():
         return LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-signed-zeros",
            os.path.join(CSRC, "irrl_env_abi.hip"), "-o", LIB] + list(extra_flags)
     if verbose:
         print(" ".join(cmd))

@@ -60,6 +60,28 @@ IRRL_DEV sym3 rot_inertia(v3 ex, v3 ey, v3 ez, vf Ix, vf Iy, vf Iz, vf Iyz) {
   r.zz = Ix * ex.z * ex.z + Iy * ey.z * ey.z + Iz * ez.z * ez.z + Iyz * (2.0f * ey.z * ez.z);
   return r;
 }
+// same with ey.x == 0 (hip/knee frames share the abad y axis (0, c0, s0))
+IRRL_DEV sym3 rot_inertia_y0(v3 ex, v3 ey, v3 ez, vf Ix, vf Iy, vf Iz, vf Iyz) {
+  sym3 r;
+  r.xx = Ix * ex.x * ex.x + Iz * ez.x * ez.x;
+  r.xy = Ix * ex.x * ex.y + Iz * ez.x * ez.y + Iyz * (ez.x * ey.y);
+  r.xz = Ix * ex.x * ex.z + Iz * ez.x * ez.z + Iyz * (ez.x * ey.z);
+  r.yy = Ix * ex.y * ex.y + Iy * ey.y * ey.y + Iz * ez.y * ez.y + Iyz * (2.0f * ey.y * ez.y);
+  r.yz = Ix * ex.y * ex.z + Iy * ey.y * ey.z + Iz * ez.y * ez.z + Iyz * (ey.y * ez.z + ez.y * ey.z);
+  r.zz = Ix * ex.z * ex.z + Iy * ey.z * ey.z + Iz * ez.z * ez.z + Iyz * (2.0f * ey.z * ez.z);
+  return r;
+}
+// ... and no product of inertia (shank)
+IRRL_DEV sym3 rot_inertia_y0d(v3 ex, v3 ey, v3 ez, vf Ix, vf Iy, vf Iz) {
+  sym3 r;
+  r.xx = Ix * ex.x * ex.x + Iz * ez.x * ez.x;
+  r.xy = Ix * ex.x * ex.y + Iz * ez.x * ez.y;
+  r.xz = Ix * ex.x * ex.z + Iz * ez.x * ez.z;
+  r.yy = Ix * ex.y * ex.y + Iy * ey.y * ey.y + Iz * ez.y * ez.y;
+  r.yz = Ix * ex.y * ex.z + Iy * ey.y * ey.z + Iz * ez.y * ez.z;
+  r.zz = Ix * ex.z * ex.z + Iy * ey.z * ey.z + Iz * ez.z * ez.z;
+  return r;
+}
 // inertia about the base origin: I_B + m (|c|^2 1 - c c^T)
 IRRL_DEV sym3 shift_to_origin(sym3 I, vf m, v3 c) {
   vf cc = dot(c, c);
@@ -237,10 +259,9 @@ IRRL_DEV void inverse_kinematics(vf x, vf y, vf z, vf max_len, vm is_right, vf &
 // ENV:1273-1312 for one joint; knee (k == 2) carries the 1.55f ratio
 IRRL_DEV vf torque_clamp1(vf tau, vf qd, int k, const EnvParams &P) {
   const float ratio = (k == 2) ? 1.55f : 1.0f;
-  float r = P.tau_max / (P.w_max - P.w_crit);
   vf w = qd * ratio;
-  vf up = vsel(w > P.w_crit, P.tau_max - (w - P.w_crit) * r, P.tau_max) * ratio;
-  vf low = vsel(w < -P.w_crit, (-P.w_max - w) / (-P.w_max + P.w_crit) * -P.tau_max, -P.tau_max) * ratio;
+  vf up = vsel(w > P.w_crit, P.tau_max - (w - P.w_crit) * P.clamp_r, P.tau_max) * ratio;
+  vf low = vsel(w < -P.w_crit, (-P.w_max - w) * P.clamp_inv_den * -P.tau_max, -P.tau_max) * ratio;
   return v_max(v_min(tau, up), low);
 }
 
@@ -266,6 +287,22 @@ struct EnvLane {
   v3 bodyLinVel, bodyAngVel;
 };
 
+// sin/cos for joint angles: Cody-Waite reduction by pi/2 (three-part constant, exact products for |k| < 2^8)
+// and the Cephes single-precision minimax polynomials on [-pi/4, pi/4]; ~1e-7 absolute error, branch-free,
+// no large-argument slow path (joint angles stay within a few radians).
+IRRL_DEV void sincos_fast(vf x, vf &s, vf &c) {
+  vf kf = v_floor(x * 0.63661977236758134f + 0.5f);
+  vf r = ((x - kf * 1.5703125f) - kf * 4.837512969970703125e-4f) - kf * 7.54978995489188216e-8f;
+  vf z = r * r;
+  vf sp = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+  vf cp = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+  vi q = f2i(kf) & 3;
+  vm swap = (q & 1) != 0;
+  vf ss = vsel(swap, cp, sp), cc = vsel(swap, sp, cp);
+  s = vsel((q & 2) != 0, -ss, ss);
+  c = vsel(((q + 1) & 2) != 0, -cc, cc);
+}
+
 // leg kinematics in the base frame
 struct LegKin {
   v3 ay, az;            // abad frame axes (ax = e_x)
@@ -277,7 +314,7 @@ struct LegKin {
 IRRL_DEV LegKin leg_fk(const LegModel &m, vf q0, vf q1, vf q2) {
   LegKin k;
   vf s0, c0, s1, c1, s12, c12;
-  v_sincos(q0, s0, c0); v_sincos(q1, s1, c1); v_sincos(q1 + q2, s12, c12);
+  sincos_fast(q0, s0, c0); sincos_fast(q1, s1, c1); sincos_fast(q1 + q2, s12, c12);
   k.ay = mk3(0.0f, c0, s0); k.az = mk3(0.0f, -s0, c0);
   k.tx = mk3(c1, -s0 * s1, c0 * s1); k.tz = mk3(-s1, -s0 * c1, c0 * c1);
   k.sx = mk3(c12, -s0 * s12, c0 * s12); k.sz = mk3(-s12, -s0 * c12, c0 * c12);
@@ -325,18 +362,22 @@ IRRL_DEV void l6_bwd(const vf L[21], vf r[6]) {
 IRRL_DEV void leg_dynamics(const LegModel &m, const LegKin &k, const vf qd[3], v3 wB, v3 a0, LegDyn &D) {
   const v3 ex = mk3(1.0f, 0.0f, 0.0f);
   // ---- body COMs and inertias in the base frame ----
-  v3 rcA = m.comA.x * ex + m.comA.y * k.ay + m.comA.z * k.az;
+  v3 rcA = mk3(m.comA.x, m.comA.y * k.ay.y + m.comA.z * k.az.y, m.comA.y * k.ay.z + m.comA.z * k.az.z);  // ay.x = az.x = 0
   v3 rcT = m.comT.x * k.tx + m.comT.y * k.ay + m.comT.z * k.tz;
   v3 rcS = m.comS.x * k.sx + m.comS.y * k.ay + m.comS.z * k.sz;
   v3 cA = k.pA + rcA, cT = k.pT + rcT, cS = k.pS + rcS;
-  sym3 IA = rot_inertia(ex, k.ay, k.az, 0.000391f, 0.000739f, 0.000488f, 0.0f);                 // URDF:62
-  sym3 IT = rot_inertia(k.tx, k.ay, k.tz, 0.001724f, 0.001907f, 0.000468f, -m.sy * 0.000228f);  // URDF:90
+  sym3 IA;  // URDF:62, diagonal in the abad frame whose x axis is the base x axis
+  IA.xx = 0.000391f; IA.xy = 0.0f; IA.xz = 0.0f;
+  IA.yy = 0.000739f * k.ay.y * k.ay.y + 0.000488f * k.az.y * k.az.y;
+  IA.yz = 0.000739f * k.ay.y * k.ay.z + 0.000488f * k.az.y * k.az.z;
+  IA.zz = 0.000739f * k.ay.z * k.ay.z + 0.000488f * k.az.z * k.az.z;
+  sym3 IT = rot_inertia_y0(k.tx, k.ay, k.tz, 0.001724f, 0.001907f, 0.000468f, -m.sy * 0.000228f);  // URDF:90
   const float zc = (IRRL_S_M1 * IRRL_S_Z1 + IRRL_S_M2 * IRRL_S_Z2) / (IRRL_S_M1 + IRRL_S_M2);
   const float d1 = IRRL_S_Z1 - zc, d2 = IRRL_S_Z2 - zc;
   const float ISx = 0.000716f + IRRL_S_M1 * d1 * d1 + 0.000025f + IRRL_S_M2 * d2 * d2;           // URDF:116,153
   const float ISy = 0.000721f + IRRL_S_M1 * d1 * d1 + 0.000025f + IRRL_S_M2 * d2 * d2;
   const float ISz = 0.000012f + 0.000025f;
-  sym3 IS = rot_inertia(k.sx, k.ay, k.sz, ISx, ISy, ISz, 0.0f);
+  sym3 IS = rot_inertia_y0d(k.sx, k.ay, k.sz, ISx, ISy, ISz);
 
   // ---- CRBA: composite (mass, first moment, inertia about the base origin) up the chain ----
   vf mcS = m.mS, mcT = m.mT + m.mS, mcA = m.mA + mcT;
@@ -345,7 +386,10 @@ IRRL_DEV void leg_dynamics(const LegModel &m, const LegKin &k, const vf qd[3], v
   sym3 IoT = shift_to_origin(IT, m.mT, cT) + IoS;
   sym3 IoA = shift_to_origin(IA, m.mA, cA) + IoT;
   // columns: P_j = s_j x (h_j - m_j p_j),  L_j = Io_j s_j - h_j x (s_j x p_j)
-  v3 PA = cross(ex, hA - mcA * k.pA), LA = mul(IoA, ex) - cross(hA, cross(ex, k.pA));
+  v3 dA = hA - mcA * k.pA;
+  v3 PA = mk3(0.0f, -dA.z, dA.y);                               // e_x x dA
+  v3 exp_ = mk3(0.0f, -k.pA.z, k.pA.y);                         // e_x x pA
+  v3 LA = mk3(IoA.xx, IoA.xy, IoA.xz) - cross(hA, exp_);        // Io e_x - h x (e_x x pA)
   v3 PT = cross(k.h, hT - mcT * k.pT), LT = mul(IoT, k.h) - cross(hT, cross(k.h, k.pT));
   v3 PS = cross(k.h, hS - mcS * k.pS), LS = mul(IoS, k.h) - cross(hS, cross(k.h, k.pS));
   vf B[6][3];
@@ -353,9 +397,9 @@ IRRL_DEV void leg_dynamics(const LegModel &m, const LegKin &k, const vf qd[3], v
   B[0][1] = PT.x; B[1][1] = PT.y; B[2][1] = PT.z; B[3][1] = LT.x; B[4][1] = LT.y; B[5][1] = LT.z;
   B[0][2] = PS.x; B[1][2] = PS.y; B[2][2] = PS.z; B[3][2] = LS.x; B[4][2] = LS.y; B[5][2] = LS.z;
   // C_l (3x3 sym): M[k,j] = s_k . (L_j - p_k x P_j), rotor inertia on the diagonal (URDF:56,84,110)
-  vf C00 = dot(ex, LA - cross(k.pA, PA)) + 0.003708f;
-  vf C01 = dot(ex, LT - cross(k.pA, PT));
-  vf C02 = dot(ex, LS - cross(k.pA, PS));
+  vf C00 = (LA.x - (k.pA.y * PA.z - k.pA.z * PA.y)) + 0.003708f;
+  vf C01 = LT.x - (k.pA.y * PT.z - k.pA.z * PT.y);
+  vf C02 = LS.x - (k.pA.y * PS.z - k.pA.z * PS.y);
   vf C11 = dot(k.h, LT - cross(k.pT, PT)) + 0.003708f;
   vf C12 = dot(k.h, LS - cross(k.pT, PS));
   vf C22 = dot(k.h, LS - cross(k.pS, PS)) + 0.008966f;
@@ -404,7 +448,7 @@ IRRL_DEV void leg_dynamics(const LegModel &m, const LegKin &k, const vf qd[3], v
     vf d = S[L6I(j, j)];
 #pragma unroll
     for (int c = 0; c < j; c++) d -= D.L6[L6I(j, c)] * D.L6[L6I(j, c)];
-    vf inv = v_rcp(v_sqrt(d));
+    vf inv = v_rsqrt(d);
     D.L6[L6I(j, j)] = inv;
 #pragma unroll
     for (int i = j + 1; i < 6; i++) {
@@ -418,7 +462,7 @@ IRRL_DEV void leg_dynamics(const LegModel &m, const LegKin &k, const vf qd[3], v
   // ---- RNEA bias (classical Newton-Euler, gravity folded into a0) ----
   v3 sq0 = mk3(qd[0], 0.0f, 0.0f);
   v3 wA = wB + sq0;
-  v3 alA = cross(wB, sq0);
+  v3 alA = mk3(0.0f, wB.z * qd[0], -wB.y * qd[0]);  // wB x (qd0 e_x)
   v3 aA = a0 + cross(wB, cross(wB, k.pA));
   v3 sq1 = qd[1] * k.h;
   v3 dT = k.pT - k.pA;
@@ -465,34 +509,41 @@ IRRL_DEV void solve_M(const LegDyn &D, const vf rb[6], const vf rl[3], vf xb[6],
   xl[0] = c0; xl[1] = c1; xl[2] = c2;
 }
 
-// one-contact solve (same branch structure as the oracle's solve_contact)
-IRRL_DEV v3 solve_contact(sym3 G, v3 c, v3 n, vf vstar, vf mu) {
+// Per-contact constants of the block solve: G^-1 (cofactors), G n and n.G n.
+struct ContactBlock { sym3 G, Gi; v3 Gn; vf nGn; };
+IRRL_DEV ContactBlock make_contact_block(sym3 G, v3 n) {
+  ContactBlock B;
+  B.G = G;
+  vf a = G.yy * G.zz - G.yz * G.yz, b = G.xz * G.yz - G.xy * G.zz, c = G.xy * G.yz - G.xz * G.yy;
+  vf idet = v_rcp(G.xx * a + G.xy * b + G.xz * c);
+  B.Gi.xx = a * idet; B.Gi.xy = b * idet; B.Gi.xz = c * idet;
+  B.Gi.yy = (G.xx * G.zz - G.xz * G.xz) * idet; B.Gi.yz = (G.xy * G.xz - G.xx * G.yz) * idet; B.Gi.zz = (G.xx * G.yy - G.xy * G.xy) * idet;
+  B.Gn = mul(G, n);
+  B.nGn = dot(n, B.Gn);
+  return B;
+}
+// one-contact solve (same decision order as the oracle's solve_contact): separating -> 0; sticking solution
+// inside the cone -> keep; pulling -> frictionless; else slide along the sticking direction with the normal
+// velocity condition kept exact.
+IRRL_DEV v3 solve_contact(const ContactBlock &B, v3 c, v3 n, vf vstar, vf mu) {
   vf cn = dot(c, n) - vstar;
-  v3 rhs = mk3(-(c.x - vstar * n.x), -(c.y - vstar * n.y), -(c.z - vstar * n.z));
-  // G^-1 rhs by cofactors (symmetric)
-  vf a = G.yy * G.zz - G.yz * G.yz, b = G.xz * G.yz - G.xy * G.zz, cc = G.xy * G.yz - G.xz * G.yy;
-  vf idet = v_rcp(G.xx * a + G.xy * b + G.xz * cc);
-  vf e = G.xx * G.zz - G.xz * G.xz, f = G.xy * G.xz - G.xx * G.yz, g = G.xx * G.yy - G.xy * G.xy;
-  v3 l = mk3((a * rhs.x + b * rhs.y + cc * rhs.z) * idet, (b * rhs.x + e * rhs.y + f * rhs.z) * idet, (cc * rhs.x + f * rhs.y + g * rhs.z) * idet);
-  v3 Gn = mul(G, n);
-  vf nGn = dot(n, Gn);
-  v3 frictionless = (-cn / nGn) * n;
+  v3 rhs = mk3(vstar * n.x - c.x, vstar * n.y - c.y, vstar * n.z - c.z);
+  v3 l = mul(B.Gi, rhs);
+  vf mcn = -cn;
+  v3 frictionless = (mcn * v_rcp(B.nGn)) * n;
   vf ln = dot(l, n);
   v3 lt = l - ln * n;
   vf lt2 = dot(lt, lt);
   vm sticking = lt2 <= mu * mu * ln * ln;
-  vf inv = v_rcp(v_sqrt(lt2));
-  v3 w = n + (mu * inv) * lt;
-  vf nGw = dot(n, mul(G, w));
-  // select chain in the oracle's priority order
+  v3 w = n + (mu * v_rsqrt(lt2)) * lt;
+  vf nGw = dot(B.Gn, w);  // n.G w == (G n).w, G symmetric
   vm sep = cn >= 0.0f;
-  vm pull = ln <= 0.0f;
-  vm degenerate = nGw <= 1e-6f * nGn;
-  v3 slide = mk3(vsel(degenerate, frictionless.x, (-cn / nGw) * w.x), vsel(degenerate, frictionless.y, (-cn / nGw) * w.y), vsel(degenerate, frictionless.z, (-cn / nGw) * w.z));
+  vm use_fl = (ln <= 0.0f) | ((!sticking) & (nGw <= 1e-6f * B.nGn));
+  v3 slide = (mcn * v_rcp(nGw)) * w;
   v3 r;
-  r.x = vsel(sep, 0.0f, vsel(pull, frictionless.x, vsel(sticking, l.x, slide.x)));
-  r.y = vsel(sep, 0.0f, vsel(pull, frictionless.y, vsel(sticking, l.y, slide.y)));
-  r.z = vsel(sep, 0.0f, vsel(pull, frictionless.z, vsel(sticking, l.z, slide.z)));
+  r.x = vsel(sep, 0.0f, vsel(use_fl, frictionless.x, vsel(sticking, l.x, slide.x)));
+  r.y = vsel(sep, 0.0f, vsel(use_fl, frictionless.y, vsel(sticking, l.y, slide.y)));
+  r.z = vsel(sep, 0.0f, vsel(use_fl, frictionless.z, vsel(sticking, l.z, slide.z)));
   return r;
 }
 
@@ -567,6 +618,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
         Gm[r][c] = acc;
       }
     sym3 G; G.xx = Gm[0][0]; G.xy = Gm[0][1]; G.xz = Gm[0][2]; G.yy = Gm[1][1]; G.yz = Gm[1][2]; G.zz = Gm[2][2];
+    ContactBlock CB = make_contact_block(G, nB);
     // contact-point velocities: before the step (restitution) and free
     vf vpre[3], cfree[3];
     const vf upre[6] = {vB.x, vB.y, vB.z, wB.x, wB.y, wB.z};
@@ -584,35 +636,63 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     v3 lam = rot_tmul(R, mk3(L.lamw[0], L.lamw[1], L.lamw[2]));
     vm warm = active & (L.in_contact != 0);
     lam.x = vsel(warm, lam.x, 0.0f); lam.y = vsel(warm, lam.y, 0.0f); lam.z = vsel(warm, lam.z, 0.0f);
-    // z = sum_l Y_l^T lam_l  (6-vector shared by the quad)
-    vf z[6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) z[i] = quad_sum(Y[0][i] * lam.x + Y[1][i] * lam.y + Y[2][i] * lam.z);
+    // off-diagonal Delassus blocks of this lane's row: Gx[l'] = Y_l Y_l'^T (zero for l' == l), built from the
+    // partners' Y through DPP broadcasts
+    vi leg = leg_id();
+    vf Gx[4][3][3];
+    {
+      vf Ym[3][6];  // partner's Y, masked by its activity
+#define IRRL_GX_BLOCK(LP)                                                                                      \
+      {                                                                                                        \
+        vm other = leg != LP; /* an inactive partner carries lambda = 0, only the own block must vanish */     \
+        _Pragma("unroll") for (int c = 0; c < 3; c++) _Pragma("unroll") for (int i = 0; i < 6; i++) Ym[c][i] = quad_bcast<LP>(Y[c][i]); \
+        _Pragma("unroll") for (int r = 0; r < 3; r++) _Pragma("unroll") for (int c = 0; c < 3; c++) {          \
+          vf acc = Y[r][0] * Ym[c][0];                                                                         \
+          _Pragma("unroll") for (int i = 1; i < 6; i++) acc += Y[r][i] * Ym[c][i];                             \
+          Gx[LP][r][c] = vsel(other, acc, 0.0f);                                                               \
+        }                                                                                                      \
+      }
+      IRRL_GX_BLOCK(0) IRRL_GX_BLOCK(1) IRRL_GX_BLOCK(2) IRRL_GX_BLOCK(3)
+#undef IRRL_GX_BLOCK
+    }
     // rank of this contact among the robot's active contacts (leg order FR,FL,HR,HL)
     vi act_i = vsel_i(active, 1, 0);
     vi a0i = quad_bcast_i<0>(act_i), a1i = quad_bcast_i<1>(act_i), a2i = quad_bcast_i<2>(act_i);
-    vi leg = leg_id();
     vi rank = vsel_i(leg == 0, 0, vsel_i(leg == 1, a0i, vsel_i(leg == 2, a0i + a1i, a0i + a1i + a2i)));
     int nrank = wave_max_small(quad_sum_i(act_i));
+    const float tol2 = P.contact_tol * P.contact_tol;
     for (int it = 0; it < P.contact_iters; it++) {
+      vf d2 = 0.0f;
       for (int rk = 0; rk < nrank; rk++) {
-        // velocity at this contact without its own impulse: cfree + Y (z - Y^T lam) + ... (E cancels)
-        vf zo[6];
-#pragma unroll
-        for (int i = 0; i < 6; i++) zo[i] = z[i] - (Y[0][i] * lam.x + Y[1][i] * lam.y + Y[2][i] * lam.z);
-        v3 cv;
-        cv.x = cfree[0]; cv.y = cfree[1]; cv.z = cfree[2];
-#pragma unroll
-        for (int i = 0; i < 6; i++) { cv.x += Y[0][i] * zo[i]; cv.y += Y[1][i] * zo[i]; cv.z += Y[2][i] * zo[i]; }
-        v3 ln = solve_contact(G, cv, nB, vstar, L.m.mu);
+        // velocity at this contact without its own impulse: cfree + sum_{l' != l} G_ll' lam_l'
+        v3 cv = mk3(cfree[0], cfree[1], cfree[2]);
+#define IRRL_GX_APPLY(LP)                                                                       \
+        {                                                                                       \
+          vf bx = quad_bcast<LP>(lam.x), by = quad_bcast<LP>(lam.y), bz = quad_bcast<LP>(lam.z); \
+          cv.x += Gx[LP][0][0] * bx + Gx[LP][0][1] * by + Gx[LP][0][2] * bz;                    \
+          cv.y += Gx[LP][1][0] * bx + Gx[LP][1][1] * by + Gx[LP][1][2] * bz;                    \
+          cv.z += Gx[LP][2][0] * bx + Gx[LP][2][1] * by + Gx[LP][2][2] * bz;                    \
+        }
+        IRRL_GX_APPLY(0) IRRL_GX_APPLY(1) IRRL_GX_APPLY(2) IRRL_GX_APPLY(3)
+#undef IRRL_GX_APPLY
+        v3 ln = solve_contact(CB, cv, nB, vstar, L.m.mu);
         vm commit = active & (rank == rk);
         v3 dl = mk3(vsel(commit, ln.x - lam.x, 0.0f), vsel(commit, ln.y - lam.y, 0.0f), vsel(commit, ln.z - lam.z, 0.0f));
         lam = lam + dl;
-#pragma unroll
-        for (int i = 0; i < 6; i++) z[i] += quad_sum(Y[0][i] * dl.x + Y[1][i] * dl.y + Y[2][i] * dl.z);
+        d2 += dot(dl, dl);
+      }
+      // build-defined early exit: every robot of the wave has sum |dlam|^2 <= tol^2 sum |lam|^2
+      if (tol2 > 0.0f) {
+        vf l2 = quad_sum(vsel(active, dot(lam, lam), 0.0f));
+        vm unconverged = quad_sum(d2) > tol2 * l2 + 1e-20f;
+        if (!wave_any(unconverged)) break;
       }
     }
+    // z = sum_l Y_l^T lam_l (6-vector shared by the quad) drives the base velocity update
     lam.x = vsel(active, lam.x, 0.0f); lam.y = vsel(active, lam.y, 0.0f); lam.z = vsel(active, lam.z, 0.0f);
+    vf z[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) z[i] = quad_sum(Y[0][i] * lam.x + Y[1][i] * lam.y + Y[2][i] * lam.z);
     // velocity update: base part L^-T z, leg part C^-1 Jl^T lam - D xb
     vf xbc[6];
 #pragma unroll
@@ -645,7 +725,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     vf x1 = L.qx + hx * L.qw + hy * L.qz - hz * L.qy;
     vf y1 = L.qy - hx * L.qz + hy * L.qw + hz * L.qx;
     vf z1 = L.qz + hx * L.qy - hy * L.qx + hz * L.qw;
-    vf inv = v_rcp(v_sqrt(w1 * w1 + x1 * x1 + y1 * y1 + z1 * z1));
+    vf inv = v_rsqrt(w1 * w1 + x1 * x1 + y1 * y1 + z1 * z1);
     L.qw = w1 * inv; L.qx = x1 * inv; L.qy = y1 * inv; L.qz = z1 * inv;
   }
 }

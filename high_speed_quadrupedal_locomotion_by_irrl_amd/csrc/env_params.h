@@ -23,6 +23,9 @@ struct EnvParams {
   float tau_max, w_crit, w_max;
   float phase[4];          // Environment.hpp:398-409
   float max_len;           // Environment.hpp:395
+  float contact_tol;       // [ext] ContactTolerance: early exit of the contact sweeps (0 = fixed sweep count)
+  float clamp_r;           // tau_max / (w_max - w_crit)            (Environment.hpp:1279)
+  float clamp_inv_den;     // 1 / (-w_max + w_crit)                 (Environment.hpp:1296-1297)
 };
 
 // Device-resident state pool, structure of arrays in the reference's natural row-major shapes so the

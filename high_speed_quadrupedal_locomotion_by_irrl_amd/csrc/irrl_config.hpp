@@ -134,6 +134,9 @@ inline bool build_params(const Config &c, EnvParams &P, std::string &err) {
   // build-defined extension keys (optional)
   P.contact_iters = c.has("ContactIterations") ? (int32_t)num("ContactIterations") : 6;
   if (P.contact_iters <= 0) P.contact_iters = 6;
+  P.contact_tol = c.has("ContactTolerance") ? (float)num("ContactTolerance") : 0.0f;
+  P.clamp_r = P.tau_max / (P.w_max - P.w_crit);
+  P.clamp_inv_den = 1.0f / (-P.w_max + P.w_crit);
   P.shared_noise = c.has("SharedNoiseScalar") ? (int32_t)flag("SharedNoiseScalar") : 1;
   P.randomize_per_episode = c.has("RandomizePerEpisode") ? (int32_t)flag("RandomizePerEpisode") : 0;
   if (!err.empty()) return false;

@@ -67,8 +67,14 @@ IRRL_DEV int wave_max_small(vi x) {
 }
 
 // ---- math (full-precision OCML forms: parity with the f64 oracle is judged at fp32 tolerance) ----
-IRRL_DEV vf v_sqrt(vf x) { return sqrtf(x); }
-IRRL_DEV vf v_rcp(vf x) { return 1.0f / x; }
+// v_sqrt_f32 / v_rcp_f32 / v_rsq_f32: one instruction each, ~1 ulp -- far inside the fp32 parity tolerance;
+// the IEEE-exact expansions of sqrtf() and 1.0f/x cost ~10 VALU instructions apiece in a kernel that is bound
+// by single-wave issue rate.
+IRRL_DEV vf v_sqrt(vf x) { return __builtin_amdgcn_sqrtf(x); }
+IRRL_DEV vf v_rcp(vf x) { return __builtin_amdgcn_rcpf(x); }
+IRRL_DEV vf v_rsqrt(vf x) { return __builtin_amdgcn_rsqf(x); }
+IRRL_DEV vf v_floor(vf x) { return __builtin_floorf(x); }
+IRRL_DEV vi f2i(vf x) { return (vi)x; }
 IRRL_DEV vf v_sin(vf x) { return sinf(x); }
 IRRL_DEV vf v_cos(vf x) { return cosf(x); }
 IRRL_DEV void v_sincos(vf x, vf &s, vf &c) { sincosf(x, &s, &c); }

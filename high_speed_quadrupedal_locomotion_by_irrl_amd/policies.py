@@ -1,0 +1,209 @@
+"""Actor-critic policies of the reference, in PyTorch (runs on the env's MI355X; no host round-trip).
+
+  CustomLSTMPolicy  run_bp_v5.py:117-193: actor LSTM(35->48)->LSTM(48->48)->linear 12 (mean), state-independent
+                    logstd[1,12]; critic LSTM(35->48)->LSTM(48->48)->linear 1; an unused `q` head on the critic
+                    latent.  The LSTM is stable-baselines 2.8 `a2c.utils.lstm`: wx[n_in,4h], wh[h,4h], b[4h],
+                    gate order i,f,o,g, state tensor [c,h], state*(1-mask) before every step (pinned in-repo by
+                    script/utils/CustomerLstmNN.py:116-130).  states [N,384] = pi-L0(96) pi-L1(96) v-L0(96) v-L1(96).
+  MlpPolicy         flex_gym/archi/policies.py:395-462,524-541: separate pi / vf MLPs [64,64] tanh, pi head
+                    init_scale 0.01.
+
+Parameter order of CustomLSTMPolicy.sb_parameters() == the 19 tensors of the reference checkpoint
+(script/pkl/bp5_155.pkl): pi-L0 (wx,wh,b) pi-L1 v-L0 v-L1, vf (w,b), pi (w,b), logstd, q (w,b).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+LOG_2PI = math.log(2.0 * math.pi)
+
+
+def _ortho(shape, scale=1.0):
+    """stable-baselines `ortho_init` (a2c/utils.py): orthogonal matrix from the SVD of a gaussian."""
+    a = torch.randn(shape[0], shape[1])
+    u, _, vt = torch.linalg.svd(a, full_matrices=False)
+    q = u if u.shape == tuple(shape) else vt
+    return (scale * q[: shape[0], : shape[1]]).contiguous()
+
+
+class SBLstm(nn.Module):
+    """One stable-baselines lstm layer (see module docstring)."""
+
+    def __init__(self, n_in, n_hidden):
+        super().__init__()
+        self.n_hidden = n_hidden
+        self.wx = nn.Parameter(_ortho((n_in, 4 * n_hidden)))
+        self.wh = nn.Parameter(_ortho((n_hidden, 4 * n_hidden)))
+        self.b = nn.Parameter(torch.zeros(4 * n_hidden))
+
+    def cell(self, zx, c, h, mask):
+        """zx = x @ wx + b precomputed; mask [N,1] = done flag before this step."""
+        keep = 1.0 - mask
+        c = c * keep
+        h = h * keep
+        z = zx + h @ self.wh
+        n = self.n_hidden
+        i, f, o, g = z[:, :n], z[:, n:2 * n], z[:, 2 * n:3 * n], z[:, 3 * n:]
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        return c, h
+
+    def sequence(self, x, state, masks):
+        """x [T,N,n_in], state [N,2h] = [c,h], masks [T,N] -> outputs [T,N,h], final state [N,2h].
+        The input projection of the whole sequence is one GEMM; only h @ wh stays sequential."""
+        T, N, _ = x.shape
+        n = self.n_hidden
+        zx = (x.reshape(T * N, -1) @ self.wx + self.b).reshape(T, N, 4 * n)
+        c, h = state[:, :n], state[:, n:]
+        m = masks.unsqueeze(-1)
+        outs = []
+        for t in range(T):
+            c, h = self.cell(zx[t], c, h, m[t])
+            outs.append(h)
+        return torch.stack(outs, 0), torch.cat([c, h], 1)
+
+
+class SBLinear(nn.Module):
+    """stable-baselines `linear`: x @ w + b, w orthogonal * init_scale, b constant."""
+
+    def __init__(self, n_in, n_out, init_scale=1.0, init_bias=0.0):
+        super().__init__()
+        self.w = nn.Parameter(_ortho((n_in, n_out), init_scale))
+        self.b = nn.Parameter(torch.full((n_out,), float(init_bias)))
+
+    def forward(self, x):
+        return x @ self.w + self.b
+
+
+def diag_gaussian_neglogp(actions, mean, logstd):
+    """DiagGaussianProbabilityDistribution.neglogp (SB distributions.py)."""
+    std = torch.exp(logstd)
+    return 0.5 * (((actions - mean) / std) ** 2).sum(-1) + 0.5 * LOG_2PI * actions.shape[-1] + logstd.sum(-1)
+
+
+def diag_gaussian_entropy(logstd, like):
+    return (logstd + 0.5 * (LOG_2PI + 1.0)).sum(-1).expand(like.shape[:-1])
+
+
+class ActorCriticPolicy(nn.Module):
+    """Common surface used by PPO2 / Runner (step, value, evaluate)."""
+    recurrent = False
+    state_dim = 0
+
+    def initial_state(self, n_env, device):
+        return torch.zeros(n_env, max(self.state_dim, 1), device=device)
+
+
+class CustomLSTMPolicy(ActorCriticPolicy):
+    recurrent = True
+
+    def __init__(self, ob_dim=35, act_dim=12, n_lstm=(48, 48)):
+        super().__init__()
+        self.n_lstm = list(n_lstm)
+        self.act_dim = act_dim
+        dims = [ob_dim] + self.n_lstm
+        self.lstm_pi = nn.ModuleList([SBLstm(dims[i], dims[i + 1]) for i in range(len(self.n_lstm))])
+        self.lstm_v = nn.ModuleList([SBLstm(dims[i], dims[i + 1]) for i in range(len(self.n_lstm))])
+        self.vf = SBLinear(dims[-1], 1)
+        self.pi = SBLinear(dims[-1], act_dim, init_scale=1.0, init_bias=0.0)
+        self.logstd = nn.Parameter(torch.zeros(1, act_dim))
+        self.q = SBLinear(dims[-1], act_dim)  # created by proba_distribution_from_latent, never used
+        self.state_dim = sum(self.n_lstm) * 2 * 2  # run_bp_v5.py:136-137
+
+    def sb_parameters(self):
+        out = []
+        for stack in (self.lstm_pi, self.lstm_v):
+            for l in stack:
+                out += [l.wx, l.wh, l.b]
+        out += [self.vf.w, self.vf.b, self.pi.w, self.pi.b, self.logstd, self.q.w, self.q.b]
+        return out
+
+    def _split(self, states):
+        sizes = [2 * k for k in (self.n_lstm + self.n_lstm)]  # run_bp_v5.py:139-140
+        return list(torch.split(states, sizes, dim=1))
+
+    def _run(self, obs_seq, states, masks_seq):
+        parts = self._split(states)
+        new = []
+        x = obs_seq
+        for i, l in enumerate(self.lstm_pi):
+            x, s = l.sequence(x, parts[i], masks_seq)
+            new.append(s)
+        latent_pi = x
+        x = obs_seq
+        for i, l in enumerate(self.lstm_v):
+            x, s = l.sequence(x, parts[len(self.n_lstm) + i], masks_seq)
+            new.append(s)
+        latent_v = x
+        mean = self.pi(latent_pi)
+        value = self.vf(latent_v).squeeze(-1)
+        return mean, value, torch.cat(new, 1)
+
+    @torch.no_grad()
+    def step(self, obs, states, masks, deterministic=False, generator=None):
+        """run_bp_v5.py:178-185: -> action (unclipped sample), value, new states, neglogp."""
+        mean, value, snew = self._run(obs.unsqueeze(0), states, masks.to(obs.dtype).unsqueeze(0))
+        mean, value = mean[0], value[0]
+        if deterministic:
+            action = mean
+        else:
+            noise = torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator)
+            action = mean + torch.exp(self.logstd) * noise
+        return action, value, snew, diag_gaussian_neglogp(action, mean, self.logstd)
+
+    @torch.no_grad()
+    def value(self, obs, states, masks):
+        return self._run(obs.unsqueeze(0), states, masks.to(obs.dtype).unsqueeze(0))[1][0]
+
+    def evaluate(self, obs_seq, states, masks_seq, actions_seq):
+        """Train-graph forward: obs [T,N,35], states [N,384] at the rollout start, masks [T,N], actions [T,N,12]
+        -> neglogp [T,N], value [T,N], entropy [T,N] (full 750-step BPTT, ppo2.py:132-134)."""
+        mean, value, _ = self._run(obs_seq, states, masks_seq.to(obs_seq.dtype))
+        return diag_gaussian_neglogp(actions_seq, mean, self.logstd), value, diag_gaussian_entropy(self.logstd, mean)
+
+
+class MlpPolicy(ActorCriticPolicy):
+    """FeedForwardPolicy with net_arch [dict(vf=[64,64], pi=[64,64])], tanh (policies.py:430-446)."""
+
+    def __init__(self, ob_dim=35, act_dim=12, layers=(64, 64)):
+        super().__init__()
+        dims = [ob_dim] + list(layers)
+        sq2 = math.sqrt(2.0)
+        self.pi_fc = nn.ModuleList([SBLinear(dims[i], dims[i + 1], init_scale=sq2) for i in range(len(layers))])
+        self.vf_fc = nn.ModuleList([SBLinear(dims[i], dims[i + 1], init_scale=sq2) for i in range(len(layers))])
+        self.vf = SBLinear(dims[-1], 1)
+        self.pi = SBLinear(dims[-1], act_dim, init_scale=0.01, init_bias=0.0)  # policies.py:443-444
+        self.logstd = nn.Parameter(torch.zeros(1, act_dim))
+        self.q = SBLinear(dims[-1], act_dim, init_scale=0.01)
+        self.act_dim = act_dim
+
+    def _run(self, obs):
+        p = obs
+        for l in self.pi_fc:
+            p = torch.tanh(l(p))
+        v = obs
+        for l in self.vf_fc:
+            v = torch.tanh(l(v))
+        return self.pi(p), self.vf(v).squeeze(-1)
+
+    @torch.no_grad()
+    def step(self, obs, states=None, masks=None, deterministic=False, generator=None):
+        mean, value = self._run(obs)
+        if deterministic:
+            action = mean
+        else:
+            action = mean + torch.exp(self.logstd) * torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator)
+        return action, value, states, diag_gaussian_neglogp(action, mean, self.logstd)
+
+    @torch.no_grad()
+    def value(self, obs, states=None, masks=None):
+        return self._run(obs)[1]
+
+    def evaluate(self, obs, states, masks, actions):
+        mean, value = self._run(obs)
+        return diag_gaussian_neglogp(actions, mean, self.logstd), value, diag_gaussian_entropy(self.logstd, mean)
+
+
+# name kept for `from flex_gym.archi.policies import ActorCriticPolicy, LstmPolicy, MlpPolicy` (run_bp_v5.py:11)
+LstmPolicy = CustomLSTMPolicy

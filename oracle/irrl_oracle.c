@@ -574,6 +574,7 @@ typedef struct {
   real rew_terms[8];
   real extra[6];
   real gen_force[NV]; /* last generalized force handed to the integrator (world comps for the base) */
+  long gs_sweeps, gs_substeps; /* statistics: contact sweeps executed / substeps */
   robot_model model;
 } env_t;
 
@@ -907,11 +908,13 @@ static void physics_substep(orc_env *h, env_t *e, const real *pTarget) {
             for (int cc = 0; cc < NV; cc++) acc += J[la][r][cc] * MiJt[lb][r2][cc];
             G[la][lb][3 * r + r2] = acc;
           }
-  for (int it = 0; it < c->ContactIterations; it++)
+  for (int it = 0; it < c->ContactIterations; it++) {
+    real d2 = RC(0), l2 = RC(0);
     for (int l = 0; l < 4; l++) {
       if (!active[l]) continue;
-      real cv[3];
+      real cv[3], old[3];
       v3_copy(cv, cfree[l]);
+      v3_copy(old, lamB[l]);
       for (int lb = 0; lb < 4; lb++) {
         if (lb == l || !active[lb]) continue;
         real t[3];
@@ -919,7 +922,14 @@ static void physics_substep(orc_env *h, env_t *e, const real *pTarget) {
         v3_add(cv, cv, t);
       }
       solve_contact(G[l][l], cv, nB, vstar[l], m->mu, lamB[l]);
+      for (int a = 0; a < 3; a++) { real dd = lamB[l][a] - old[a]; d2 += dd * dd; l2 += lamB[l][a] * lamB[l][a]; }
     }
+    /* build-defined early exit (same rule in the kernels, evaluated per wave there) */
+    if (c->ContactTolerance > 0 && d2 <= RC(c->ContactTolerance * c->ContactTolerance) * l2 + RC(1e-20)) { it++; e->gs_sweeps += it; goto gs_done; }
+  }
+  e->gs_sweeps += c->ContactIterations;
+gs_done:
+  e->gs_substeps += 1;
   for (int l = 0; l < 4; l++) {
     e->in_contact[l] = active[l];
     if (!active[l]) { v3_set(e->lam_w[l], RC(0), RC(0), RC(0)); continue; }
@@ -1351,3 +1361,8 @@ void orc_rng_u01(uint32_t seed, uint32_t env, uint32_t episode, uint32_t step, u
   for (int i = 0; i < 4; i++) out[i] = R_TO_DOUBLE(u[i]);
 }
 double orc_last_step_flops(const orc_env *h) { return h->flops; }
+double orc_mean_contact_sweeps(const orc_env *h) {
+  double a = 0, b = 0;
+  for (int i = 0; i < h->n; i++) { a += (double)h->envs[i].gs_sweeps; b += (double)h->envs[i].gs_substeps; }
+  return b > 0 ? a / b : 0.0;
+}

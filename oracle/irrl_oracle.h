@@ -60,6 +60,7 @@ typedef struct orc_cfg {
   int32_t ContactIterations;    /* Gauss-Seidel sweeps per substep (default 6) */
   int32_t SharedNoiseScalar;    /* 1: Eigen 12x1*12x1 pitfall => one shared factor (ENV:584,586,705) */
   int32_t RandomizePerEpisode;  /* 1: redo the ctor domain randomisation at every reset (config 5) */
+  double ContactTolerance;      /* stop the sweeps once sum|dlambda|^2 <= tol^2 sum|lambda|^2 (0: always ContactIterations sweeps) */
 } orc_cfg;
 
 typedef struct orc_env orc_env; /* opaque vector-env handle */
@@ -128,6 +129,8 @@ void orc_rng_u01(uint32_t seed, uint32_t env, uint32_t episode, uint32_t step, u
                  double out[4]);
 /* algorithmic flop count of the last orc_step (per env, averaged); 0 unless built -DORC_COUNT_FLOPS */
 double orc_last_step_flops(const orc_env *h);
+/* mean number of contact sweeps per substep since creation (statistics for DESIGN.md) */
+double orc_mean_contact_sweeps(const orc_env *h);
 
 #ifdef __cplusplus
 }

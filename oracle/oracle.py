@@ -41,10 +41,11 @@ class OrcCfg(C.Structure):
         ("FPS", C.c_double), ("ActionNoise", C.c_double), ("ObsNoise", C.c_double), ("GaitType", C.c_int32),
         ("MotorMaxTorque", C.c_double), ("MotorCriticalSpeed", C.c_double), ("MotorMaxSpeed", C.c_double),
         ("ContactIterations", C.c_int32), ("SharedNoiseScalar", C.c_int32), ("RandomizePerEpisode", C.c_int32),
+        ("ContactTolerance", C.c_double),
     ]
 
 
-_EXT_DEFAULTS = {"ContactIterations": 6, "SharedNoiseScalar": 1, "RandomizePerEpisode": 0}
+_EXT_DEFAULTS = {"ContactIterations": 6, "SharedNoiseScalar": 1, "RandomizePerEpisode": 0, "ContactTolerance": 0.0}
 
 
 def cfg_from_dict(env_cfg):
@@ -98,6 +99,8 @@ def _lib(precision="f64"):
     lib.orc_num_envs.restype = C.c_int
     lib.orc_num_envs.argtypes = [vp]
     lib.orc_real_bytes.restype = C.c_int
+    lib.orc_mean_contact_sweeps.restype = C.c_double
+    lib.orc_mean_contact_sweeps.argtypes = [vp]
     d3 = C.c_double * 3
     lib.orc_cubic_bezier.argtypes = [d3, d3, C.c_double, d3]
     lib.orc_bezier2.argtypes = [d3, d3, C.c_double, C.c_double, d3]
@@ -154,6 +157,9 @@ class OracleVecEnv(object):
         if getattr(self, "h", None):
             self.lib.orc_destroy(self.h)
             self.h = None
+
+    def mean_contact_sweeps(self):
+        return self.lib.orc_mean_contact_sweeps(self.h)
 
     def reset(self):
         ob = np.zeros((self.n, 35), np.float32)

@@ -59,7 +59,8 @@ inline int wave_max_small(vi x) { int r = 0; for (int i = 0; i < 4; i++) r = x.v
 #define LANEWISE_FN(name, expr) inline vf name(vf x) { vf r; for (int i = 0; i < 4; i++) { float a = x.v[i]; r.v[i] = (expr); } return r; }
 LANEWISE_FN(v_sqrt, std::sqrt(a)) LANEWISE_FN(v_rcp, 1.0f / a) LANEWISE_FN(v_sin, std::sin(a)) LANEWISE_FN(v_cos, std::cos(a))
 LANEWISE_FN(v_asin, std::asin(a)) LANEWISE_FN(v_acos, std::acos(a)) LANEWISE_FN(v_exp, std::exp(a)) LANEWISE_FN(v_log, std::log(a))
-LANEWISE_FN(v_abs, std::fabs(a))
+LANEWISE_FN(v_abs, std::fabs(a)) LANEWISE_FN(v_rsqrt, 1.0f / std::sqrt(a)) LANEWISE_FN(v_floor, std::floor(a))
+inline vi f2i(vf x) { vi r; for (int i = 0; i < 4; i++) r.v[i] = (int32_t)x.v[i]; return r; }
 inline void v_sincos(vf x, vf &s, vf &c) { s = v_sin(x); c = v_cos(x); }
 inline vf v_fmod(vf x, vf y) { vf r; for (int i = 0; i < 4; i++) r.v[i] = std::fmod(x.v[i], y.v[i]); return r; }
 inline vf v_min(vf a, vf b) { return vsel(a < b, a, b); }
