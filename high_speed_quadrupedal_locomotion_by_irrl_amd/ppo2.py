@@ -1,0 +1,317 @@
+"""PPO2 of the reference (flex_gym/algo/ppo2/ppo2.py = stable-baselines 2.8 PPO2 + raisimGym edits) on
+PyTorch-ROCm, with the rollout buffer, GAE scan and policy/value update resident on the env's MI355X.
+
+Reference semantics reproduced (file:line = ppo2.py unless noted):
+  Runner.run 494-582      n_steps x [policy step (stochastic) -> clip to [-1,1] for the env only (529-531; the
+                          buffer keeps the UNCLIPPED action, 523) -> env.step]; dones stored BEFORE the step (526);
+                          last_values bootstrap (552); GAE (554-568); env-major flatten (572-574, 603-611);
+                          global env reset after every rollout (577) WITHOUT resetting the LSTM state / dones.
+  loss 136-175            ratio = exp(nlp_old - nlp); pg = mean(max(-A r, -A clip(r, 1 +- eps)));
+                          vf = .5 mean(max((v - R)^2, (v_old + clip(v - v_old, +-eps) - R)^2));
+                          loss = pg - ent_coef * H + vf_coef * vf; approxkl, clipfrac as logged there.
+  _train_step 262-263     advantages normalised per minibatch: (A - mean) / (std + 1e-8)  (population std).
+  update 190-197          tf.clip_by_global_norm(max_grad_norm) then Adam(lr, eps 1e-5, beta .9/.999).
+  minibatching 364-404    non-recurrent: shuffled flat indices; recurrent: shuffled ENV indices, whole sequences,
+                          LSTM state at the rollout start, done-masks inside the unroll.
+  learn 325-435           nupdates = total_timesteps // (n_envs * n_steps); fps = n_batch / (rollout + update time);
+                          logged keys of 419-435; checkpoint every `eval_every_n` updates when update % n == 1 (331-341).
+
+Multi-GPU: one process per GPU, env shards of n_envs per rank, replicated parameters; per optimizer
+step ONE flat all-reduce of the gradient (sum / world, clip after averaging) and one 3-float all-reduce of the
+advantage moments so that normalisation equals the single-process full batch.  `torch.distributed` with backend
+"nccl" is RCCL over xGMI on ROCm; "gloo" is used by the CPU tests.
+
+The GAE scan runs in the HIP kernel `irrl_gae` (include/irrl_env.h) for CUDA tensors; CPU tensors (only the
+gloo / unit tests create those) take the literal torch transcription below.
+"""
+import ctypes as C
+import math
+import os
+import pickle
+import time
+
+import numpy as np
+import torch
+
+from .policies import ActorCriticPolicy, CustomLSTMPolicy, MlpPolicy  # noqa: F401
+
+
+def gae_reference(rewards, values, dones, last_values, last_dones, gamma, lam):
+    """Literal transcription of ppo2.py:554-568 on [T,N] tensors."""
+    T = rewards.shape[0]
+    adv = torch.zeros_like(rewards)
+    last = torch.zeros_like(last_values)
+    for t in reversed(range(T)):
+        if t == T - 1:
+            nonterm = 1.0 - last_dones.to(rewards.dtype)
+            nextv = last_values
+        else:
+            nonterm = 1.0 - dones[t + 1].to(rewards.dtype)
+            nextv = values[t + 1]
+        delta = rewards[t] + gamma * nextv * nonterm - values[t]
+        last = delta + gamma * lam * nonterm * last
+        adv[t] = last
+    return adv, adv + values
+
+
+def gae(rewards, values, dones, last_values, last_dones, gamma, lam):
+    """[T,N] f32 rewards/values, [T,N] bool dones (flag before step t), [N] last_values/last_dones."""
+    if rewards.is_cuda:
+        from . import _lib
+        lib = _lib.load()
+        rewards, values = rewards.contiguous(), values.contiguous()
+        d8 = dones.to(torch.uint8).contiguous()
+        ld8 = last_dones.to(torch.uint8).contiguous()
+        lv = last_values.contiguous()
+        adv, ret = torch.empty_like(rewards), torch.empty_like(rewards)
+        T, N = rewards.shape
+        stream = torch.cuda.current_stream(rewards.device).cuda_stream
+        _lib.check(lib.irrl_gae(T, N, C.c_void_p(rewards.data_ptr()), C.c_void_p(values.data_ptr()), C.c_void_p(d8.data_ptr()),
+                                C.c_void_p(lv.data_ptr()), C.c_void_p(ld8.data_ptr()), float(gamma), float(lam),
+                                C.c_void_p(adv.data_ptr()), C.c_void_p(ret.data_ptr()), C.c_void_p(stream)))
+        return adv, ret
+    return gae_reference(rewards, values, dones, last_values, last_dones, gamma, lam)
+
+
+def ppo_loss(neglogpac, vpred, entropy, actions_unused, advs, returns, old_neglogpac, old_vpred, cliprange, ent_coef, vf_coef):
+    """ppo2.py:152-175 on flat tensors; returns (loss, pg_loss, vf_loss, entropy, approxkl, clipfrac)."""
+    ent = entropy.mean()
+    vpredclipped = old_vpred + torch.clamp(vpred - old_vpred, -cliprange, cliprange)
+    vf_loss = 0.5 * torch.maximum((vpred - returns) ** 2, (vpredclipped - returns) ** 2).mean()
+    ratio = torch.exp(old_neglogpac - neglogpac)
+    pg_loss = torch.maximum(-advs * ratio, -advs * torch.clamp(ratio, 1.0 - cliprange, 1.0 + cliprange)).mean()
+    approxkl = 0.5 * ((neglogpac - old_neglogpac) ** 2).mean()
+    clipfrac = (torch.abs(ratio - 1.0) > cliprange).to(ratio.dtype).mean()
+    loss = pg_loss - ent * ent_coef + vf_loss * vf_coef
+    return loss, pg_loss, vf_loss, ent, approxkl, clipfrac
+
+
+class Runner(object):
+    """ppo2.py:479-582 with every buffer a device tensor of shape [T, N, ...]."""
+
+    def __init__(self, env, model, n_steps, gamma, lam):
+        self.env, self.model, self.n_steps, self.gamma, self.lam = env, model, n_steps, gamma, lam
+        dev = model.device
+        n = env.num_envs
+        self.obs = env.reset().clone()                               # AbstractEnvRunner.__init__: obs = env.reset()
+        self.states = model.policy.initial_state(n, dev)             # zeros [N, 384]
+        self.dones = torch.zeros(n, dtype=torch.bool, device=dev)    # [False] * n_envs
+        T = n_steps
+        self.mb_obs = torch.zeros(T, n, env.num_obs, device=dev)
+        self.mb_actions = torch.zeros(T, n, env.num_acts, device=dev)
+        self.mb_values = torch.zeros(T, n, device=dev)
+        self.mb_neglogpacs = torch.zeros(T, n, device=dev)
+        self.mb_dones = torch.zeros(T, n, dtype=torch.bool, device=dev)
+        self.mb_rewards = torch.zeros(T, n, device=dev)
+
+    def run(self):
+        pol = self.model.policy
+        mb_states = self.states.clone()
+        for t in range(self.n_steps):
+            actions, values, self.states, neglogpacs = pol.step(self.obs, self.states, self.dones, generator=self.model.generator)
+            self.mb_obs[t].copy_(self.obs)
+            self.mb_actions[t].copy_(actions)
+            self.mb_values[t].copy_(values)
+            self.mb_neglogpacs[t].copy_(neglogpacs)
+            self.mb_dones[t].copy_(self.dones)
+            clipped = torch.clamp(actions, -1.0, 1.0)
+            obs, rewards, dones = self.env.step(clipped)
+            self.obs.copy_(obs)
+            self.dones = dones.clone()
+            self.mb_rewards[t].copy_(rewards)
+        last_values = pol.value(self.obs, self.states, self.dones)
+        advs, returns = gae(self.mb_rewards, self.mb_values, self.mb_dones, last_values, self.dones, self.gamma, self.lam)
+        # resetting environments (ppo2.py:577); LSTM states and dones deliberately survive
+        self.obs.copy_(self.env.reset_and_update_info())
+        return dict(obs=self.mb_obs, returns=returns, masks=self.mb_dones, actions=self.mb_actions, values=self.mb_values,
+                    neglogpacs=self.mb_neglogpacs, states=mb_states if pol.recurrent else None, true_reward=self.mb_rewards)
+
+
+class PPO2(object):
+    """PPO2(policy, env, gamma, n_steps, ent_coef, learning_rate, vf_coef, max_grad_norm, lam, nminibatches,
+    noptepochs, cliprange, verbose, tensorboard_log, policy_kwargs)   (ppo2.py:45-48, run_bp_v5.py:227-242)."""
+
+    def __init__(self, policy, env, gamma=0.99, n_steps=128, ent_coef=0.01, learning_rate=2.5e-4, vf_coef=0.5,
+                 max_grad_norm=0.5, lam=0.95, nminibatches=4, noptepochs=4, cliprange=0.2, verbose=0,
+                 tensorboard_log=None, _init_setup_model=True, policy_kwargs=None, full_tensorboard_log=False, seed=None,
+                 device=None):
+        self.env = env
+        self.gamma, self.n_steps, self.ent_coef, self.learning_rate = gamma, n_steps, ent_coef, learning_rate
+        self.vf_coef, self.max_grad_norm, self.lam = vf_coef, max_grad_norm, lam
+        self.nminibatches, self.noptepochs, self.cliprange, self.verbose = nminibatches, noptepochs, cliprange, verbose
+        self.tensorboard_log = tensorboard_log
+        self.policy_kwargs = dict(policy_kwargs or {})
+        self.policy_class = policy
+        self.n_envs = env.num_envs if env is not None else None
+        self.device = torch.device(device) if device is not None else (env.device if env is not None and hasattr(env, "device") else torch.device("cpu"))
+        self.num_timesteps = 0
+        self.world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
+        self.rank = torch.distributed.get_rank() if self.world > 1 else 0
+        self.seed = 0 if seed is None else int(seed)
+        # identical initial weights on every rank, different sampling noise per rank
+        torch.manual_seed(self.seed)
+        if isinstance(policy, type):
+            self.policy = policy(**self.policy_kwargs)
+        else:
+            self.policy = policy
+        self.policy.to(self.device)
+        self.generator = torch.Generator(device=self.device)
+        self.generator.manual_seed(self.seed * 1000003 + 7919 * self.rank + 1)
+        self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=float(learning_rate) if not callable(learning_rate) else 1e-3,
+                                          eps=1e-5, betas=(0.9, 0.999))
+        self.loss_names = ['policy_loss', 'value_loss', 'policy_entropy', 'approxkl', 'clipfrac']
+        self.log = []
+
+    # -- one optimizer step on one minibatch (ppo2.py:243-298) --
+    def _train_step(self, lr_now, cliprange_now, obs, returns, masks, actions, values, neglogpacs, states=None):
+        advs = returns - values
+        n_local = torch.tensor([float(advs.numel())], device=advs.device, dtype=torch.float64)
+        moments = torch.stack([advs.double().sum(), (advs.double() ** 2).sum(), n_local[0]])
+        if self.world > 1:
+            torch.distributed.all_reduce(moments)                     # C2: 3 floats
+        mean = moments[0] / moments[2]
+        var = torch.clamp(moments[1] / moments[2] - mean * mean, min=0.0)
+        advs = (advs - mean.to(advs.dtype)) / (torch.sqrt(var).to(advs.dtype) + 1e-8)
+        neglogpac, vpred, entropy = self.policy.evaluate(obs, states, masks, actions)
+        loss, pg, vf, ent, kl, cf = ppo_loss(neglogpac, vpred, entropy, actions, advs, returns, neglogpacs, values, cliprange_now,
+                                             self.ent_coef, self.vf_coef)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        params = [p for p in self.policy.parameters() if p.grad is not None]
+        if self.world > 1:
+            flat = torch.cat([p.grad.reshape(-1) for p in params])    # C1: one flat bucket (283 KB for the LSTM policy)
+            torch.distributed.all_reduce(flat)
+            flat /= self.world
+            off = 0
+            for p in params:
+                p.grad.copy_(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+        if self.max_grad_norm is not None:
+            torch.nn.utils.clip_grad_norm_(params, self.max_grad_norm)  # clip_by_global_norm AFTER averaging
+        for g in self.optimizer.param_groups:
+            g['lr'] = lr_now
+        self.optimizer.step()
+        return torch.stack([pg.detach(), vf.detach(), ent.detach(), kl.detach(), cf.detach()])
+
+    def update(self, batch, lr_now, cliprange_now):
+        """All epochs / minibatches of one PPO iteration (ppo2.py:362-404)."""
+        T, N = batch["values"].shape
+        losses = []
+        recurrent = batch["states"] is not None
+        if recurrent:
+            assert N % self.nminibatches == 0, "For recurrent policies, the number of environments run in parallel " \
+                                               "should be a multiple of nminibatches."
+            envs_per_batch = N // self.nminibatches
+            for _ in range(self.noptepochs):
+                perm = torch.randperm(N, device=self.device, generator=self.generator)
+                for start in range(0, N, envs_per_batch):
+                    idx = perm[start:start + envs_per_batch]
+                    if self.nminibatches == 1:
+                        sl = lambda x: x                               # whole batch: the env order does not matter
+                        st = batch["states"]
+                    else:
+                        sl = lambda x: x[:, idx]
+                        st = batch["states"][idx]
+                    losses.append(self._train_step(lr_now, cliprange_now, sl(batch["obs"]), sl(batch["returns"]), sl(batch["masks"]),
+                                                   sl(batch["actions"]), sl(batch["values"]), sl(batch["neglogpacs"]), states=st))
+        else:
+            n_batch = T * N
+            assert n_batch % self.nminibatches == 0
+            bs = n_batch // self.nminibatches
+            flat = {k: batch[k].transpose(0, 1).reshape(n_batch, *batch[k].shape[2:]) for k in
+                    ("obs", "returns", "masks", "actions", "values", "neglogpacs")}   # swap_and_flatten: env-major
+            for _ in range(self.noptepochs):
+                inds = torch.randperm(n_batch, device=self.device, generator=self.generator)
+                for start in range(0, n_batch, bs):
+                    mb = inds[start:start + bs]
+                    losses.append(self._train_step(lr_now, cliprange_now, flat["obs"][mb], flat["returns"][mb], flat["masks"][mb],
+                                                   flat["actions"][mb], flat["values"][mb], flat["neglogpacs"][mb]))
+        return torch.stack(losses).mean(0)
+
+    def learn(self, total_timesteps, callback=None, seed=None, log_interval=1, tb_log_name="PPO2", eval_every_n=5,
+              reset_num_timesteps=True, record_video=False, log_dir=""):
+        lr_fn = self.learning_rate if callable(self.learning_rate) else (lambda _f: float(self.learning_rate))
+        clip_fn = self.cliprange if callable(self.cliprange) else (lambda _f: float(self.cliprange))
+        runner = Runner(self.env, self, self.n_steps, self.gamma, self.lam)
+        n_batch = self.n_envs * self.n_steps
+        nupdates = int(total_timesteps) // (n_batch * self.world)       # total_timesteps counts all ranks' samples
+        t_first = time.time()
+        for update in range(1, nupdates + 1):
+            if eval_every_n and update % eval_every_n == 1 and self.rank == 0 and log_dir:
+                # ppo2.py:331-341: visual test rollout (headless here: skipped) + checkpoint
+                self.save(log_dir + "_Iteration_{}".format(update - 1))
+            t_start = time.time()
+            frac = 1.0 - (update - 1.0) / nupdates
+            lr_now, clip_now = lr_fn(frac), clip_fn(frac)
+            batch = runner.run()
+            loss_vals = self.update(batch, lr_now, clip_now)
+            self.num_timesteps += n_batch * self.world
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+            t_now = time.time()
+            fps = int(n_batch * self.world / (t_now - t_start))
+            if self.verbose >= 1 and (update % log_interval == 0 or update == 1):
+                y, ypred = batch["returns"].reshape(-1), batch["values"].reshape(-1)
+                vary = y.var(unbiased=False)
+                ev = float("nan") if float(vary) == 0 else float(1 - (y - ypred).var(unbiased=False) / vary)
+                ep_r, ep_l, ep_n = self.env.pop_episode_stats() if hasattr(self.env, "pop_episode_stats") else (float("nan"), float("nan"), 0)
+                row = {"serial_timesteps": update * self.n_steps, "nupdates": update, "total_timesteps": self.num_timesteps, "fps": fps,
+                       "explained_variance": ev, "ep_reward_mean": ep_r, "ep_len_mean": ep_l, "time_elapsed": t_start - t_first,
+                       "iters_per_sec": 1.0 / (t_now - t_start)}
+                row.update({k: float(v) for k, v in zip(self.loss_names, loss_vals.tolist())})
+                self.log.append(row)
+                if self.rank == 0:
+                    print(" | ".join("%s %s" % (k, ("%.4g" % v) if isinstance(v, float) else v) for k, v in row.items()), flush=True)
+            if callback is not None and callback(locals(), globals()) is False:
+                break
+        return self
+
+    # -- checkpoints (ppo2.py:452-476): (data dict, parameter list in stable-baselines order) --
+    def _data(self):
+        return {"gamma": self.gamma, "n_steps": self.n_steps, "vf_coef": self.vf_coef, "ent_coef": self.ent_coef,
+                "max_grad_norm": self.max_grad_norm, "learning_rate": self.learning_rate if not callable(self.learning_rate) else None,
+                "lam": self.lam, "nminibatches": self.nminibatches, "noptepochs": self.noptepochs,
+                "cliprange": self.cliprange if not callable(self.cliprange) else None, "verbose": self.verbose,
+                "policy": type(self.policy).__name__, "n_envs": self.n_envs, "policy_kwargs": self.policy_kwargs}
+
+    def get_parameter_list(self):
+        ps = self.policy.sb_parameters() if hasattr(self.policy, "sb_parameters") else list(self.policy.parameters())
+        return [p.detach().cpu().numpy().copy() for p in ps]
+
+    def save(self, save_path):
+        d = os.path.dirname(save_path)
+        if d:
+            os.makedirs(d, exist_ok=True)
+        path = save_path if save_path.endswith(".pkl") else save_path + ".pkl"
+        with open(path, "wb") as f:
+            pickle.dump((self._data(), self.get_parameter_list()), f)
+        return path
+
+    def load_parameters(self, params):
+        ps = self.policy.sb_parameters() if hasattr(self.policy, "sb_parameters") else list(self.policy.parameters())
+        assert len(ps) == len(params), "expected %d tensors, got %d" % (len(ps), len(params))
+        with torch.no_grad():
+            for p, a in zip(ps, params):
+                a = torch.as_tensor(np.asarray(a), dtype=p.dtype)
+                assert tuple(a.shape) == tuple(p.shape), (tuple(a.shape), tuple(p.shape))
+                p.copy_(a.to(p.device))
+
+    @classmethod
+    def load(cls, load_path, env=None, device=None, **kwargs):
+        """Loads this build's checkpoints AND the reference's stable-baselines pickles (e.g. script/pkl/bp5_155.pkl,
+        decoded without tensorflow / stable_baselines / gym by a stub unpickler) -- the IRRL stage-2 warm start
+        (run_bp_v5.py:244-249, readme.md:66-70)."""
+        from .checkpoint import read_checkpoint
+        data, params = read_checkpoint(load_path)
+        pk = data.get("policy_kwargs") or {}
+        n_lstm = pk.get("n_lstm", [48, 48])
+        is_lstm = len(params) == 19 or data.get("policy") in ("CustomLSTMPolicy",)
+        policy = CustomLSTMPolicy(n_lstm=n_lstm) if is_lstm else MlpPolicy()
+        hp = {k: data[k] for k in ("gamma", "n_steps", "ent_coef", "vf_coef", "max_grad_norm", "lam", "nminibatches", "noptepochs")
+              if k in data and isinstance(data[k], (int, float))}
+        for k in ("learning_rate", "cliprange"):
+            hp[k] = data[k] if isinstance(data.get(k), float) else {"learning_rate": 1e-3, "cliprange": 0.2}[k]
+        hp.update(kwargs)
+        model = cls(policy=policy, env=env, device=device, **hp)
+        model.load_parameters(params)
+        return model
