@@ -204,10 +204,104 @@ def gen_lstm():
     print("wrote lstm_bp5_155.json; n_params", meta["n_params"], "csv-vs-pkl", meta["csv_vs_pkl_wx0_maxdiff"])
 
 
+def gen_lstm_synthetic():
+    """The reference's numpy LSTM actor (CustomerLstmNN.predict, NN:112-135) driven with SEEDED RANDOM weights,
+    so the fixture pins the recurrence (gate order, state handling, clipping) without shipping trained weights:
+    the test regenerates the same weights from the seed."""
+    sys.modules.setdefault("raisim_gym", types.ModuleType("raisim_gym"))
+    sys.modules.setdefault("raisim_gym.algo", types.ModuleType("raisim_gym.algo"))
+    m = types.ModuleType("raisim_gym.algo.ppo2")
+    m.PPO2 = object
+    sys.modules.setdefault("raisim_gym.algo.ppo2", m)
+    sys.path.insert(0, os.path.join(REF, "utils"))
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            from CustomerLstmNN import CustomerLstmNN
+            nn = CustomerLstmNN("./pkl/bp5_155.pkl", n_lstm=[48, 48])
+    finally:
+        os.chdir(cwd)
+    seed = 424242
+    rng = np.random.RandomState(seed)
+    shapes = [(35, 192), (48, 192), (192,), (48, 192), (48, 192), (192,), (48, 12), (12,)]
+    w = [rng.uniform(-0.4, 0.4, sh) for sh in shapes]          # wx0 wh0 b0 wx1 wh1 b1 pi_w pi_b
+    nn.lstm_wx, nn.lstm_wh, nn.lstm_b = [w[0], w[3]], [w[1], w[4]], [w[2], w[5]]
+    nn.pi_w, nn.pi_b = w[6], w[7]
+    nn.reset()
+    obs_seq = rng.uniform(-2, 2, (8, 35))
+    outs, hid = [], []
+    for t in range(8):
+        nn.predict(obs_seq[t])
+        outs.append(np.array(nn.output).tolist())
+        hid.append([np.array(nn.cell_state[1]).tolist(), np.array(nn.hidden[1]).tolist()])
+    with open(os.path.join(OUT, "lstm_synthetic.json"), "w") as f:
+        json.dump(dict(seed=seed, shapes=[list(sh) for sh in shapes], weight_range=[-0.4, 0.4], obs_range=[-2, 2],
+                       steps=8, actor_out=outs, layer1_c_h=hid), f, indent=1)
+    print("wrote lstm_synthetic.json")
+
+
+def gen_ppo_math():
+    """GAE and PPO2 loss known answers from a literal numpy transcription of ppo2.py:554-568 and 152-175
+    (tensorflow is absent, so the TF graph itself cannot be run)."""
+    rng = np.random.RandomState(7)
+    T, N = 12, 5
+    rewards = rng.uniform(-1, 1, (T, N)).astype(np.float32)
+    values = rng.uniform(-2, 2, (T, N)).astype(np.float32)
+    dones = rng.uniform(size=(T, N)) < 0.2
+    last_values = rng.uniform(-2, 2, N).astype(np.float32)
+    last_dones = rng.uniform(size=N) < 0.3
+    gamma, lam = 0.99, 0.998
+    # --- ppo2.py:554-568 ---
+    mb_advs = np.zeros_like(rewards)
+    last_gae_lam = 0
+    for step in reversed(range(T)):
+        if step == T - 1:
+            nextnonterminal = 1.0 - last_dones
+            nextvalues = last_values
+        else:
+            nextnonterminal = 1.0 - dones[step + 1]
+            nextvalues = values[step + 1]
+        delta = rewards[step] + gamma * nextvalues * nextnonterminal - values[step]
+        mb_advs[step] = last_gae_lam = delta + gamma * lam * nextnonterminal * last_gae_lam
+    mb_returns = mb_advs + values
+    # --- ppo2.py:152-175 + 262-263 ---
+    B = 64
+    neglogpac = rng.uniform(5, 15, B)
+    old_neglogpac = neglogpac + rng.normal(0, 0.3, B)
+    vpred = rng.uniform(-2, 2, B)
+    old_vpred = vpred + rng.normal(0, 0.4, B)
+    returns = rng.uniform(-2, 2, B)
+    entropy = np.full(B, 17.03)
+    clip, ent_coef, vf_coef = 0.2, 0.01, 0.5
+    advs = returns - old_vpred
+    advs = (advs - advs.mean()) / (advs.std() + 1e-8)
+    vpredclipped = old_vpred + np.clip(vpred - old_vpred, -clip, clip)
+    vf_loss = .5 * np.mean(np.maximum(np.square(vpred - returns), np.square(vpredclipped - returns)))
+    ratio = np.exp(old_neglogpac - neglogpac)
+    pg_loss = np.mean(np.maximum(-advs * ratio, -advs * np.clip(ratio, 1.0 - clip, 1.0 + clip)))
+    approxkl = .5 * np.mean(np.square(neglogpac - old_neglogpac))
+    clipfrac = np.mean((np.abs(ratio - 1.0) > clip).astype(np.float32))
+    loss = pg_loss - np.mean(entropy) * ent_coef + vf_loss * vf_coef
+    out = dict(gae=dict(rewards=rewards.tolist(), values=values.tolist(), dones=dones.tolist(), last_values=last_values.tolist(),
+                        last_dones=last_dones.tolist(), gamma=gamma, lam=lam, advs=mb_advs.tolist(), returns=mb_returns.tolist()),
+               loss=dict(neglogpac=neglogpac.tolist(), old_neglogpac=old_neglogpac.tolist(), vpred=vpred.tolist(),
+                         old_vpred=old_vpred.tolist(), returns=returns.tolist(), entropy=entropy.tolist(), cliprange=clip,
+                         ent_coef=ent_coef, vf_coef=vf_coef, normalized_advs=advs.tolist(), pg_loss=float(pg_loss),
+                         vf_loss=float(vf_loss), approxkl=float(approxkl), clipfrac=float(clipfrac), loss=float(loss)))
+    with open(os.path.join(OUT, "ppo_math.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote ppo_math.json")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["task", "lstm"]
+    which = sys.argv[1:] or ["task", "lstm", "lstm_syn", "ppo"]
     if "task" in which:
         gen_task_math()
     if "lstm" in which:
         gen_lstm()
+    if "lstm_syn" in which:
+        gen_lstm_synthetic()
+    if "ppo" in which:
+        gen_ppo_math()
