@@ -1,0 +1,52 @@
+"""Learner-side device ops on an MI355X: the HIP GAE scan against its C oracle (bit-exact: same f32 operation
+order), and the on-device PPO2 loop (rollout buffers, policy step, env.step on device tensors, update)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import oracle as O
+from conftest import load_env_cfg
+
+
+def _env(n, cfg="default_cfg.yaml"):
+    import yaml
+    import high_speed_quadrupedal_locomotion_by_irrl_amd as pkg
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.flexible_robot import FlexibleGymEnv
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.vec_env import TorchVecEnv
+    return TorchVecEnv(FlexibleGymEnv(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY__, yaml.safe_dump(load_env_cfg(cfg, num_envs=n))))
+
+
+@pytest.mark.parametrize("T,N", [(750, 4096), (1, 7), (13, 1), (64, 100)])
+def test_gae_kernel_matches_oracle_bit_exact(T, N):
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.ppo2 import gae
+    rng = np.random.RandomState(T * 1000 + N)
+    r = rng.uniform(-1, 1, (T, N)).astype(np.float32)
+    v = rng.uniform(-3, 3, (T, N)).astype(np.float32)
+    d = rng.uniform(size=(T, N)) < 0.05
+    lv = rng.uniform(-3, 3, N).astype(np.float32)
+    ld = rng.uniform(size=N) < 0.1
+    adv_o, ret_o = O.gae(r, v, d, lv, ld, 0.99, 0.998)
+    dev = torch.device("cuda")
+    adv, ret = gae(torch.from_numpy(r).to(dev), torch.from_numpy(v).to(dev), torch.from_numpy(d).to(dev),
+                   torch.from_numpy(lv).to(dev), torch.from_numpy(ld).to(dev), 0.99, 0.998)
+    # same operation order in f32; the only freedom is FMA contraction, so allow 2 ulp of the running magnitude
+    np.testing.assert_allclose(adv.cpu().numpy(), adv_o, rtol=3e-6, atol=3e-6)
+    np.testing.assert_allclose(ret.cpu().numpy(), ret_o, rtol=3e-6, atol=3e-6)
+
+
+@pytest.mark.parametrize("kind", ["mlp", "lstm"])
+def test_on_device_ppo_iteration(kind):
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import CustomLSTMPolicy, MlpPolicy
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.ppo2 import PPO2
+    env = _env(256)
+    pol = CustomLSTMPolicy if kind == "lstm" else MlpPolicy
+    model = PPO2(policy=pol, env=env, n_steps=40, nminibatches=1 if kind == "lstm" else 4, noptepochs=2, gamma=0.99, lam=0.998,
+                 ent_coef=0.0, learning_rate=1e-3, vf_coef=0.5, max_grad_norm=0.5, cliprange=0.2, verbose=1, seed=2)
+    before = np.concatenate([p.reshape(-1) for p in model.get_parameter_list()])
+    model.learn(total_timesteps=2 * 40 * 256, eval_every_n=0)
+    after = np.concatenate([p.reshape(-1) for p in model.get_parameter_list()])
+    assert np.isfinite(after).all() and np.abs(after - before).max() > 1e-5
+    assert len(model.log) == 2 and np.isfinite(model.log[-1]["policy_loss"])
+    assert next(model.policy.parameters()).is_cuda
