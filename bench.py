@@ -24,9 +24,29 @@ sys.path.insert(0, ROOT)
 
 # algorithmic cost of one env-step (SURVEY 8d / BASELINE.md section 4)
 ALG_BYTES_PER_ENV_STEP = 1521.0
-ALG_FLOPS_PER_ENV_STEP = 1.5e5   # estimate; DESIGN.md section 6 explains the count
+ALG_FLOPS_PER_ENV_STEP = 1.10e5  # instrumented oracle (tools/flopcount): 109 771 flop/env-step, 4 grounded feet, 1.5 sweeps
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 FP32_PEAK_TFLOPS = 157.3
+
+
+def usable_cores():
+    """Cores this process may really use: scheduler affinity capped by the cgroup CPU quota (a container can
+    report 256 hardware threads while being throttled to a fraction of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, n)
 
 
 def cpu_baseline(env_cfg, target_seconds):
@@ -35,8 +55,8 @@ def cpu_baseline(env_cfg, target_seconds):
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
-    cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    cores = usable_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     cfg = dict(env_cfg)
     n = int(cfg["num_envs"])
     env = O.OracleVecEnv(cfg)

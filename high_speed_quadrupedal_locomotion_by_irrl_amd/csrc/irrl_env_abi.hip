@@ -333,6 +333,7 @@ __global__ void irrl_gae_kernel(int T, int N, const float *__restrict__ rewards,
                                 const uint8_t *__restrict__ dones, const float *__restrict__ last_values,
                                 const uint8_t *__restrict__ last_dones, float gamma, float lam, float *__restrict__ adv,
                                 float *__restrict__ returns) {
+#pragma clang fp contract(off)  // keep the reference's operation order exactly (no FMA fusion): bit-equal to the oracle
   int n = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (n >= N) return;
   float last = 0.0f;

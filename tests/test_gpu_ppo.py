@@ -31,9 +31,9 @@ def test_gae_kernel_matches_oracle_bit_exact(T, N):
     dev = torch.device("cuda")
     adv, ret = gae(torch.from_numpy(r).to(dev), torch.from_numpy(v).to(dev), torch.from_numpy(d).to(dev),
                    torch.from_numpy(lv).to(dev), torch.from_numpy(ld).to(dev), 0.99, 0.998)
-    # same operation order in f32; the only freedom is FMA contraction, so allow 2 ulp of the running magnitude
-    np.testing.assert_allclose(adv.cpu().numpy(), adv_o, rtol=3e-6, atol=3e-6)
-    np.testing.assert_allclose(ret.cpu().numpy(), ret_o, rtol=3e-6, atol=3e-6)
+    # same f32 operation order, FMA contraction off on both sides -> bit-exact
+    assert np.array_equal(adv.cpu().numpy(), adv_o)
+    assert np.array_equal(ret.cpu().numpy(), ret_o)
 
 
 @pytest.mark.parametrize("kind", ["mlp", "lstm"])
