@@ -5,6 +5,7 @@
 // reference hands over, and launches the kernels stream-ordered.  No CPU compute path exists here:
 // without a usable gfx950 device irrl_env_create fails.
 #include "env_kernels.hip"
+#include "lstm_kernels.hip"
 
 #include "irrl_config.hpp"
 #include "irrl_state_pool.hpp"

@@ -1,0 +1,107 @@
+"""autograd wrapper of the persistent LSTM sequence kernels (csrc/lstm_kernels.hip).
+
+forward : zx = x @ wx + b as one GEMM over all T*N rows (gate columns permuted to [unit][gate]); the recurrence runs
+          in ONE kernel launch per layer (`irrl_lstm_seq_forward`), saving post-activation gates and c for the
+          backward pass.
+backward: `irrl_lstm_seq_backward` walks the sequence in reverse and emits dz [T,N,H,4]; the weight / input gradients
+          are then four large GEMMs (dwx = x^T dz, dwh = (h_prev keep)^T dz, db = sum dz, dx = dz wx^T).
+Semantics = stable-baselines `lstm` (policies.SBLstm.sequence is the eager definition the tests compare with).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+_PERM_CACHE = {}
+
+
+def _perm(hid, device):
+    """permuted column u*4+g  <-  reference column g*hid+u (gate order i,f,o,g)."""
+    key = (hid, str(device))
+    if key not in _PERM_CACHE:
+        u = torch.arange(hid, device=device).repeat_interleave(4)
+        g = torch.arange(4, device=device).repeat(hid)
+        perm = g * hid + u
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(4 * hid, device=device)
+        _PERM_CACHE[key] = (perm, inv)
+    return _PERM_CACHE[key]
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+class _LstmSeqFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, wx, wh, b, state0, masks):
+        lib = _lib.load()
+        T, N, n_in = x.shape
+        hid = wh.shape[0]
+        perm, inv = _perm(hid, x.device)
+        wx_p = wx[:, perm].contiguous()
+        wh_p = wh[:, perm].contiguous()
+        x = x.contiguous()
+        masks = masks.to(torch.float32).contiguous()
+        state0 = state0.contiguous()
+        pad = (-N) % 16
+        if pad:
+            x_k = torch.cat([x, x.new_zeros(T, pad, n_in)], 1)
+            masks_k = torch.cat([masks, masks.new_zeros(T, pad)], 1)
+            state0_k = torch.cat([state0, state0.new_zeros(pad, 2 * hid)], 0)
+        else:
+            x_k, masks_k, state0_k = x, masks, state0
+        Np = N + pad
+        zx = torch.addmm(b[perm], x_k.reshape(T * Np, n_in), wx_p)          # [T*Np, 4H] in [unit][gate] order
+        gates = torch.empty(T, Np, hid, 4, device=x.device, dtype=torch.float32)
+        cseq = torch.empty(T, Np, hid, device=x.device, dtype=torch.float32)
+        hseq = torch.empty(T, Np, hid, device=x.device, dtype=torch.float32)
+        state_out = torch.empty(Np, 2 * hid, device=x.device, dtype=torch.float32)
+        stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        rc = lib.irrl_lstm_seq_forward(hid, T, Np, _ptr(zx), _ptr(wh_p), _ptr(masks_k), _ptr(state0_k), _ptr(gates), _ptr(cseq),
+                                       _ptr(hseq), _ptr(state_out), stream)
+        if rc != 0:
+            raise RuntimeError("irrl_lstm_seq_forward failed (rc=%d, hid=%d, T=%d, N=%d)" % (rc, hid, T, Np))
+        ctx.save_for_backward(x_k, wx_p, wh_p, gates, cseq, hseq, masks_k, state0_k)
+        ctx.dims = (T, N, Np, n_in, hid)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(state_out)
+        return (hseq[:, :N] if pad else hseq), (state_out[:N] if pad else state_out)
+
+    @staticmethod
+    def backward(ctx, dh_seq, _dstate):
+        lib = _lib.load()
+        x_k, wx_p, wh_p, gates, cseq, hseq, masks_k, state0_k = ctx.saved_tensors
+        T, N, Np, n_in, hid = ctx.dims
+        perm, inv = _perm(hid, x_k.device)
+        if dh_seq is None:
+            dh_seq = torch.zeros(T, N, hid, device=x_k.device)
+        dh_seq = dh_seq.contiguous()
+        if Np != N:
+            dh_seq = torch.cat([dh_seq, dh_seq.new_zeros(T, Np - N, hid)], 1)
+        dz = torch.empty(T, Np, hid, 4, device=x_k.device, dtype=torch.float32)
+        stream = C.c_void_p(torch.cuda.current_stream(x_k.device).cuda_stream)
+        rc = lib.irrl_lstm_seq_backward(hid, T, Np, _ptr(gates), _ptr(cseq), _ptr(masks_k), _ptr(state0_k), _ptr(dh_seq), _ptr(wh_p),
+                                        _ptr(dz), stream)
+        if rc != 0:
+            raise RuntimeError("irrl_lstm_seq_backward failed (rc=%d)" % rc)
+        dzf = dz.reshape(T * Np, 4 * hid)
+        keep = (1.0 - masks_k).unsqueeze(-1)
+        hprev = torch.cat([state0_k[:, hid:].unsqueeze(0), hseq[:-1]], 0) * keep     # h_{t-1} as it entered step t
+        dwh = (hprev.reshape(T * Np, hid).t() @ dzf)[:, inv]
+        dwx = (x_k.reshape(T * Np, n_in).t() @ dzf)[:, inv]
+        db = dzf.sum(0)[inv]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = (dzf @ wx_p.t()).reshape(T, Np, n_in)[:, :N]
+        return dx, dwx, dwh, db, None, None
+
+
+def lstm_sequence(x, wx, wh, b, state0, masks):
+    """x [T,N,n_in], state0 [N,2H] = [c|h], masks [T,N] -> (h_seq [T,N,H], final state [N,2H]) on the MI355X."""
+    return _LstmSeqFn.apply(x, wx, wh, b, state0, masks)
+
+
+def supported(x, hid):
+    return x.is_cuda and x.dtype == torch.float32 and hid in (32, 48, 64)

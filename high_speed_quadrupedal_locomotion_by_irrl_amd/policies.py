@@ -30,6 +30,8 @@ def _ortho(shape, scale=1.0):
 class SBLstm(nn.Module):
     """One stable-baselines lstm layer (see module docstring)."""
 
+    use_fused = True   # class-wide switch (tests flip it to compare the kernels with this eager definition)
+
     def __init__(self, n_in, n_hidden):
         super().__init__()
         self.n_hidden = n_hidden
@@ -54,6 +56,11 @@ class SBLstm(nn.Module):
         The input projection of the whole sequence is one GEMM; only h @ wh stays sequential."""
         T, N, _ = x.shape
         n = self.n_hidden
+        if x.is_cuda and self.use_fused:
+            from . import lstm_fused
+            if lstm_fused.supported(x, n):
+                # persistent MFMA kernel: the whole sequence in one launch (csrc/lstm_kernels.hip)
+                return lstm_fused.lstm_sequence(x, self.wx, self.wh, self.b, state, masks)
         zx = (x.reshape(T * N, -1) @ self.wx + self.b).reshape(T, N, 4 * n)
         c, h = state[:, :n], state[:, n:]
         m = masks.unsqueeze(-1)

@@ -117,6 +117,16 @@ double irrl_env_cfg_value(const irrl_env *h, const char *key);
 int irrl_gae(int T, int N, const float *rewards, const float *values, const uint8_t *dones, const float *last_values,
              const uint8_t *last_dones, float gamma, float lam, float *adv, float *returns, void *hip_stream);
 
+/* ---- persistent LSTM sequence kernels for the PPO2 update (stable-baselines lstm of CustomLSTMPolicy,
+ * run_bp_v5.py:143-176; the train graph unrolls all n_steps, ppo2.py:132-134).  Device pointers, f32.
+ * Gate columns are in [unit][gate] order (gate = i,f,o,g): zx/gates/dz [T,N,hid,4], cseq/hseq/dh_in [T,N,hid],
+ * masks [T,N] (1.0 = done before step t), state0/state_out [N,2*hid] = [c|h], wh_p [hid][hid][4].
+ * hid in {32,48,64}, N % 16 == 0.  Returns 0, or 1 for an unsupported shape, 2 for a launch error. */
+int irrl_lstm_seq_forward(int hid, int T, int N, const float *zx, const float *wh_p, const float *masks, const float *state0,
+                          float *gates, float *cseq, float *hseq, float *state_out, void *hip_stream);
+int irrl_lstm_seq_backward(int hid, int T, int N, const float *gates, const float *cseq, const float *masks, const float *state0,
+                           const float *dh_in, const float *wh_p, float *dz, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif
