@@ -33,6 +33,47 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+_WCACHE = {}
+
+
+def _permuted_weights(wx, wh, b, perm):
+    """[unit][gate]-ordered copies of the layer's weights, rebuilt only when a parameter changed (optimizer steps
+    bump `_version`): the 750 policy steps of a rollout and the 4 sequence passes of an epoch reuse them."""
+    key = (wx.data_ptr(), wh.data_ptr(), b.data_ptr())
+    ver = (wx._version, wh._version, b._version)
+    hit = _WCACHE.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    with torch.no_grad():
+        if hit is not None:
+            # refresh IN PLACE: a captured hipGraph of the rollout step keeps reading these very buffers
+            out = hit[1]
+            torch.index_select(wx, 1, perm, out=out[0])
+            torch.index_select(wh, 1, perm, out=out[1])
+            torch.index_select(b, 0, perm, out=out[2])
+        else:
+            out = (wx[:, perm].contiguous(), wh[:, perm].contiguous(), b[perm].contiguous())
+    _WCACHE[key] = (ver, out)
+    return out
+
+
+def refresh_weights(wx, wh, b):
+    """Bring the cached [unit][gate] copies up to date (call before replaying a captured rollout step)."""
+    if wx.is_cuda:
+        _permuted_weights(wx, wh, b, _perm(wh.shape[0], wx.device)[0])
+
+
+def _tall_gemm_t(a, b, chunks=256):
+    """a^T @ b for a [K, m], b [K, n] with K in the millions and m, n <= 192: a batched GEMM over K-chunks followed
+    by a small sum exposes enough parallelism (one skinny GEMM with K = 3e6 runs on a handful of CUs)."""
+    K = a.shape[0]
+    if K % chunks != 0 or K < 64 * chunks:
+        return a.t() @ b
+    ac = a.reshape(chunks, K // chunks, a.shape[1])
+    bc = b.reshape(chunks, K // chunks, b.shape[1])
+    return torch.bmm(ac.transpose(1, 2), bc).sum(0)
+
+
 class _LstmSeqFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, wx, wh, b, state0, masks):
@@ -40,8 +81,7 @@ class _LstmSeqFn(torch.autograd.Function):
         T, N, n_in = x.shape
         hid = wh.shape[0]
         perm, inv = _perm(hid, x.device)
-        wx_p = wx[:, perm].contiguous()
-        wh_p = wh[:, perm].contiguous()
+        wx_p, wh_p, b_p = _permuted_weights(wx, wh, b, perm)
         x = x.contiguous()
         masks = masks.to(torch.float32).contiguous()
         state0 = state0.contiguous()
@@ -53,7 +93,7 @@ class _LstmSeqFn(torch.autograd.Function):
         else:
             x_k, masks_k, state0_k = x, masks, state0
         Np = N + pad
-        zx = torch.addmm(b[perm], x_k.reshape(T * Np, n_in), wx_p)          # [T*Np, 4H] in [unit][gate] order
+        zx = torch.addmm(b_p, x_k.reshape(T * Np, n_in), wx_p)             # [T*Np, 4H] in [unit][gate] order
         gates = torch.empty(T, Np, hid, 4, device=x.device, dtype=torch.float32)
         cseq = torch.empty(T, Np, hid, device=x.device, dtype=torch.float32)
         hseq = torch.empty(T, Np, hid, device=x.device, dtype=torch.float32)
@@ -89,8 +129,8 @@ class _LstmSeqFn(torch.autograd.Function):
         dzf = dz.reshape(T * Np, 4 * hid)
         keep = (1.0 - masks_k).unsqueeze(-1)
         hprev = torch.cat([state0_k[:, hid:].unsqueeze(0), hseq[:-1]], 0) * keep     # h_{t-1} as it entered step t
-        dwh = (hprev.reshape(T * Np, hid).t() @ dzf)[:, inv]
-        dwx = (x_k.reshape(T * Np, n_in).t() @ dzf)[:, inv]
+        dwh = _tall_gemm_t(hprev.reshape(T * Np, hid), dzf)[:, inv]
+        dwx = _tall_gemm_t(x_k.reshape(T * Np, n_in), dzf)[:, inv]
         db = dzf.sum(0)[inv]
         dx = None
         if ctx.needs_input_grad[0]:

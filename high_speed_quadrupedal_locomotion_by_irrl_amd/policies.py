@@ -39,6 +39,13 @@ class SBLstm(nn.Module):
         self.wh = nn.Parameter(_ortho((n_hidden, 4 * n_hidden)))
         self.b = nn.Parameter(torch.zeros(4 * n_hidden))
 
+    def prepare(self):
+        """Refresh the fused kernels' permuted weight copies after an optimizer step (needed before replaying a
+        captured rollout graph, which cannot call back into Python)."""
+        if self.wx.is_cuda and self.use_fused:
+            from . import lstm_fused
+            lstm_fused.refresh_weights(self.wx, self.wh, self.b)
+
     def cell(self, zx, c, h, mask):
         """zx = x @ wx + b precomputed; mask [N,1] = done flag before this step."""
         keep = 1.0 - mask
@@ -125,6 +132,10 @@ class CustomLSTMPolicy(ActorCriticPolicy):
                 out += [l.wx, l.wh, l.b]
         out += [self.vf.w, self.vf.b, self.pi.w, self.pi.b, self.logstd, self.q.w, self.q.b]
         return out
+
+    def prepare(self):
+        for l in list(self.lstm_pi) + list(self.lstm_v):
+            l.prepare()
 
     def _split(self, states):
         sizes = [2 * k for k in (self.n_lstm + self.n_lstm)]  # run_bp_v5.py:139-140

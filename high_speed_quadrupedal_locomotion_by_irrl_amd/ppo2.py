@@ -89,7 +89,7 @@ def ppo_loss(neglogpac, vpred, entropy, actions_unused, advs, returns, old_neglo
 class Runner(object):
     """ppo2.py:479-582 with every buffer a device tensor of shape [T, N, ...]."""
 
-    def __init__(self, env, model, n_steps, gamma, lam):
+    def __init__(self, env, model, n_steps, gamma, lam, use_graph=None):
         self.env, self.model, self.n_steps, self.gamma, self.lam = env, model, n_steps, gamma, lam
         dev = model.device
         n = env.num_envs
@@ -103,22 +103,71 @@ class Runner(object):
         self.mb_neglogpacs = torch.zeros(T, n, device=dev)
         self.mb_dones = torch.zeros(T, n, dtype=torch.bool, device=dev)
         self.mb_rewards = torch.zeros(T, n, device=dev)
+        self.t_idx = torch.zeros(1, dtype=torch.long, device=dev)
+        self.use_graph = (dev.type == "cuda") if use_graph is None else bool(use_graph)
+        self._graph = None
+        # sampling noise: the model's seeded generator; under graph capture it is registered with the graph
+        self._gen = model.generator
+
+    def _one_step(self):
+        """One rollout step with every index on the device, so the same sequence of kernels can be replayed from a
+        hipGraph: policy step -> buffer rows [t] -> clip -> env.step -> obs/dones update -> t += 1."""
+        pol = self.model.policy
+        actions, values, states, neglogpacs = pol.step(self.obs, self.states, self.dones, generator=self._gen)
+        self.mb_obs.index_copy_(0, self.t_idx, self.obs.unsqueeze(0))
+        self.mb_actions.index_copy_(0, self.t_idx, actions.unsqueeze(0))
+        self.mb_values.index_copy_(0, self.t_idx, values.unsqueeze(0))
+        self.mb_neglogpacs.index_copy_(0, self.t_idx, neglogpacs.unsqueeze(0))
+        self.mb_dones.index_copy_(0, self.t_idx, self.dones.unsqueeze(0))
+        if states is not None:
+            self.states.copy_(states)
+        clipped = torch.clamp(actions, -1.0, 1.0)
+        obs, rewards, dones = self.env.step(clipped)
+        self.mb_rewards.index_copy_(0, self.t_idx, rewards.unsqueeze(0))
+        self.obs.copy_(obs)
+        self.dones.copy_(dones)
+        self.t_idx += 1
+
+    def _maybe_capture(self):
+        """Capture `_one_step` into a hipGraph (torch.cuda.CUDAGraph) after a short warm-up on a side stream.  The env
+        kernel is launched through the C-ABI on torch's current stream, so it is recorded like any torch op."""
+        if self._graph is not None or not self.use_graph:
+            return
+        dev = self.model.device
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    self._one_step()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            self.t_idx.zero_()
+            g = torch.cuda.CUDAGraph()
+            if self._gen is not None and hasattr(g, "register_generator_state"):
+                g.register_generator_state(self._gen)
+            with torch.cuda.graph(g):
+                self._one_step()
+            self._graph = g
+            self.t_idx.zero_()
+        except Exception as exc:  # capture is an optimisation only; the eager loop below is the same code
+            print("[PPO2] hipGraph capture of the rollout step unavailable (%s); running eagerly" % (str(exc).splitlines()[0],))
+            self.use_graph = False
+            self._graph = None
+            self.t_idx.zero_()
 
     def run(self):
         pol = self.model.policy
+        if hasattr(pol, "prepare"):
+            pol.prepare()
+        if self.use_graph:
+            self._maybe_capture()
         mb_states = self.states.clone()
-        for t in range(self.n_steps):
-            actions, values, self.states, neglogpacs = pol.step(self.obs, self.states, self.dones, generator=self.model.generator)
-            self.mb_obs[t].copy_(self.obs)
-            self.mb_actions[t].copy_(actions)
-            self.mb_values[t].copy_(values)
-            self.mb_neglogpacs[t].copy_(neglogpacs)
-            self.mb_dones[t].copy_(self.dones)
-            clipped = torch.clamp(actions, -1.0, 1.0)
-            obs, rewards, dones = self.env.step(clipped)
-            self.obs.copy_(obs)
-            self.dones = dones.clone()
-            self.mb_rewards[t].copy_(rewards)
+        self.t_idx.zero_()
+        for _ in range(self.n_steps):
+            if self._graph is not None:
+                self._graph.replay()
+            else:
+                self._one_step()
         last_values = pol.value(self.obs, self.states, self.dones)
         advs, returns = gae(self.mb_rewards, self.mb_values, self.mb_dones, last_values, self.dones, self.gamma, self.lam)
         # resetting environments (ppo2.py:577); LSTM states and dones deliberately survive
