@@ -329,6 +329,17 @@ double irrl_env_cfg_value(const irrl_env *h, const char *key) {
   return d;
 }
 
+// ---- PMC calibration: a copy with the env kernels' access width (one dword per lane), known byte count ----
+__global__ void irrl_calib_copy_kernel(const float *__restrict__ src, float *__restrict__ dst, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+int irrl_calib_copy_dword(const float *src, float *dst, size_t n, void *hip_stream) {
+  hipLaunchKernelGGL(irrl_calib_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, src, dst, n);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // ---- GAE reverse scan (ppo2.py:554-568): one lane per env, coalesced [T,N] rows ----
 __global__ void irrl_gae_kernel(int T, int N, const float *__restrict__ rewards, const float *__restrict__ values,
                                 const uint8_t *__restrict__ dones, const float *__restrict__ last_values,

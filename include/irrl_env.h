@@ -117,6 +117,10 @@ double irrl_env_cfg_value(const irrl_env *h, const char *key);
 int irrl_gae(int T, int N, const float *rewards, const float *values, const uint8_t *dones, const float *last_values,
              const uint8_t *last_dones, float gamma, float lam, float *adv, float *returns, void *hip_stream);
 
+/* PMC calibration helper: copies n floats with one dword per lane (the env kernels' access width) so that
+ * FETCH_SIZE / WRITE_SIZE can be calibrated on a known byte count (MI355X_MICROARCH.md, HBM section). */
+int irrl_calib_copy_dword(const float *src, float *dst, size_t n, void *hip_stream);
+
 /* ---- persistent LSTM sequence kernels for the PPO2 update (stable-baselines lstm of CustomLSTMPolicy,
  * run_bp_v5.py:143-176; the train graph unrolls all n_steps, ppo2.py:132-134).  Device pointers, f32.
  * Gate columns are in [unit][gate] order (gate = i,f,o,g): zx/gates/dz [T,N,hid,4], cseq/hseq/dh_in [T,N,hid],

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Workload for the rocprofv3 --pmc passes: 1 calibration copy of 256 MiB with dword-per-lane accesses (known byte
+count) followed by N env steps at 4096 envs.  Run once per counter group (TCC slots do not fit FETCH_SIZE and
+WRITE_SIZE in one pass), see tools/gpu_pmc.sh."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+import yaml  # noqa: E402
+import high_speed_quadrupedal_locomotion_by_irrl_amd as pkg  # noqa: E402
+from high_speed_quadrupedal_locomotion_by_irrl_amd import _lib  # noqa: E402
+from high_speed_quadrupedal_locomotion_by_irrl_amd.flexible_robot import FlexibleGymEnv  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+envs = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+dev = torch.device("cuda", 0)
+lib = _lib.load()
+n = 64 * 1024 * 1024  # 256 MiB of floats
+src = torch.ones(n, device=dev)
+dst = torch.empty(n, device=dev)
+torch.cuda.synchronize()
+lib.irrl_calib_copy_dword(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_size_t(n), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+torch.cuda.synchronize()
+cfg = yaml.safe_load(open(os.path.join(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY__, "bp5_imitation.yaml")))["environment"]
+cfg["num_envs"] = envs
+env = FlexibleGymEnv(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY__, yaml.safe_dump(cfg))
+env.init()
+g = torch.Generator(device=dev)
+g.manual_seed(1)
+pool = [torch.clamp(0.3 * torch.randn(envs, 12, device=dev, generator=g), -1, 1).contiguous() for _ in range(16)]
+ob = torch.zeros(envs, 35, device=dev)
+rew = torch.zeros(envs, device=dev)
+done = torch.zeros(envs, dtype=torch.bool, device=dev)
+extra = torch.zeros(envs, 6, device=dev)
+for k in range(steps):
+    env.step(pool[k % 16], ob, rew, done, extra)
+torch.cuda.synchronize()
+print("ok", float(rew.mean()))
