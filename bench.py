@@ -154,6 +154,15 @@ def main():
     assert torch.isfinite(ob).all() and torch.isfinite(rew).all(), "non-finite env outputs"
 
     if rank == 0:
+        # HBM bytes per launch from the PMC passes (FETCH_SIZE x calibrated correction + WRITE_SIZE), collected with
+        # rocprofv3 in separate runs (tools/gpu_pmc.sh) and committed under profiles/ -- not measurable in-process
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary_latest.json")))
+            if int(pmc.get("envs", 4096)) == n:
+                traffic = float(pmc["hbm_bytes_per_launch"]["total"])
+        except Exception:
+            pass
         total_env_steps = float(n) * world * args.steps
         value = total_env_steps / elapsed
         launch_s = kernel_ms * 1e-3
@@ -167,7 +176,7 @@ def main():
                                    "termination + in-step reset), cfg %s, actions clip(0.3 N(0,1))" % (n, args.cfg),
                        "envs_per_gpu": n, "global_envs": n * world, "parallelism": "env-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "irrl_step_kernel", "avg_launch_us": kernel_ms * 1e3,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n},
             "roofline_fp32": {"bound": "valu_fp32 (latency/issue bound: 1 wave per CU at 4096 envs)", "achieved": ach_tf,

@@ -1024,7 +1024,7 @@ IRRL_DEV void select_lane(vm m, const EnvLane &a, EnvLane &b) {
 // ---------------------------------------------------------------------------------------------
 // state pool <-> lane context
 // ---------------------------------------------------------------------------------------------
-IRRL_DEV void load_lane(const EnvState &S, vi env, vi leg, EnvLane &L) {
+IRRL_DEV void load_lane(const EnvParams &P, const EnvState &S, vi env, vi leg, EnvLane &L) {
   vi j12 = env * 12 + leg * 3, gcb = env * 19, gvb = env * 18;
 #pragma unroll
   for (int k = 0; k < 3; k++) {
@@ -1055,17 +1055,26 @@ IRRL_DEV void load_lane(const EnvState &S, vi env, vi leg, EnvLane &L) {
   for (int k = 0; k < 3; k++) {
     L.ob_cmd[k] = ld(S.ob, ob + k); L.ob_post[k] = ld(S.ob, ob + 29 + k); L.ob_omega[k] = ld(S.ob, ob + 32 + k);
     L.ob_q[k] = ld(S.ob, ob + 5 + leg * 3 + k); L.ob_qd[k] = ld(S.ob, ob + 17 + leg * 3 + k);
-    L.obl_q[k] = ld(S.ob_last, ob + 5 + leg * 3 + k); L.obl_qd[k] = ld(S.ob_last, ob + 17 + leg * 3 + k);
   }
   L.ob_phase[0] = ld(S.ob, ob + 3); L.ob_phase[1] = ld(S.ob, ob + 4);
+  // obDouble_last_ is only read by the observation filter (ENV:1251-1256): leave it in HBM otherwise
+  if (P.obs_filter) {
 #pragma unroll
-  for (int k = 0; k < 5; k++) L.obl_env[k] = ld(S.ob_last, ob + k);
+    for (int k = 0; k < 3; k++) { L.obl_q[k] = ld(S.ob_last, ob + 5 + leg * 3 + k); L.obl_qd[k] = ld(S.ob_last, ob + 17 + leg * 3 + k); }
 #pragma unroll
-  for (int k = 0; k < 6; k++) L.obl_env[5 + k] = ld(S.ob_last, ob + 29 + k);
+    for (int k = 0; k < 5; k++) L.obl_env[k] = ld(S.ob_last, ob + k);
+#pragma unroll
+    for (int k = 0; k < 6; k++) L.obl_env[5 + k] = ld(S.ob_last, ob + 29 + k);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { L.obl_q[k] = 0.0f; L.obl_qd[k] = 0.0f; }
+#pragma unroll
+    for (int k = 0; k < 11; k++) L.obl_env[k] = 0.0f;
+  }
   L.bodyLinVel = mk3(0.0f, 0.0f, 0.0f); L.bodyAngVel = mk3(0.0f, 0.0f, 0.0f);
 }
 
-IRRL_DEV void store_lane(const EnvState &S, vi env, vi leg, vm valid, const EnvLane &L, bool store_model) {
+IRRL_DEV void store_lane(const EnvParams &P, const EnvState &S, vi env, vi leg, vm valid, const EnvLane &L, bool store_model) {
   vi j12 = env * 12 + leg * 3, gcb = env * 19, gvb = env * 18, ob = env * 35;
   vm lead = valid & (leg == 0);
 #pragma unroll
@@ -1076,7 +1085,7 @@ IRRL_DEV void store_lane(const EnvState &S, vi env, vi leg, vm valid, const EnvL
     st_if(valid, S.ee_ref, j12 + k, L.eer[k]); st_if(valid, S.lam_w, j12 + k, L.lamw[k]);
     st_if(lead, S.command, env * 3 + k, L.cmd[k]); st_if(lead, S.command_filtered, env * 3 + k, L.cmdf[k]);
     st_if(valid, S.ob, ob + 5 + leg * 3 + k, L.ob_q[k]); st_if(valid, S.ob, ob + 17 + leg * 3 + k, L.ob_qd[k]);
-    st_if(valid, S.ob_last, ob + 5 + leg * 3 + k, L.obl_q[k]); st_if(valid, S.ob_last, ob + 17 + leg * 3 + k, L.obl_qd[k]);
+    if (P.obs_filter) { st_if(valid, S.ob_last, ob + 5 + leg * 3 + k, L.obl_q[k]); st_if(valid, S.ob_last, ob + 17 + leg * 3 + k, L.obl_qd[k]); }
     st_if(lead, S.ob, ob + k, L.ob_cmd[k]); st_if(lead, S.ob, ob + 29 + k, L.ob_post[k]); st_if(lead, S.ob, ob + 32 + k, L.ob_omega[k]);
   }
   st_i_if(valid, S.in_contact, env * 4 + leg, L.in_contact); st_if(valid, S.contact, env * 4 + leg, L.contact);
@@ -1086,10 +1095,12 @@ IRRL_DEV void store_lane(const EnvState &S, vi env, vi leg, vm valid, const EnvL
   st_if(lead, S.gv, gvb + 3, L.ww.x); st_if(lead, S.gv, gvb + 4, L.ww.y); st_if(lead, S.gv, gvb + 5, L.ww.z);
   st_if(lead, S.t0, env, L.t0); st_i_if(lead, S.frame_idx, env, L.frame); st_u_if(lead, S.episode, env, L.episode); st_if(lead, S.up_height, env, L.up_height);
   st_if(lead, S.ob, ob + 3, L.ob_phase[0]); st_if(lead, S.ob, ob + 4, L.ob_phase[1]);
+  if (P.obs_filter) {
 #pragma unroll
-  for (int k = 0; k < 5; k++) st_if(lead, S.ob_last, ob + k, L.obl_env[k]);
+    for (int k = 0; k < 5; k++) st_if(lead, S.ob_last, ob + k, L.obl_env[k]);
 #pragma unroll
-  for (int k = 0; k < 6; k++) st_if(lead, S.ob_last, ob + 29 + k, L.obl_env[5 + k]);
+    for (int k = 0; k < 6; k++) st_if(lead, S.ob_last, ob + 29 + k, L.obl_env[5 + k]);
+  }
   if (store_model) {
     st_if(lead, S.material, env * 3, L.m.mu); st_if(lead, S.material, env * 3 + 1, L.m.rest); st_if(lead, S.material, env * 3 + 2, L.m.rest_thr);
     st_if(lead, S.mass, env * 13, L.m.m0);
@@ -1143,7 +1154,7 @@ IRRL_DEV void observe_lane(const EnvParams &P, vi env, vi leg, vm valid, EnvLane
 IRRL_DEV void step_body(const EnvParams &P, const EnvState &S, vi env, vi leg, vm valid, const float *action, float *ob_out,
                         float *reward_out, uint8_t *done_out, float *extra_out) {
   EnvLane L;
-  load_lane(S, env, leg, L);
+  load_lane(P, S, env, leg, L);
   vu envu = to_u(env);
   // ENV:700-708
   vf pT[3];
@@ -1190,7 +1201,7 @@ IRRL_DEV void step_body(const EnvParams &P, const EnvState &S, vi env, vi leg, v
   st_u8_if(lead, done_out, env, vsel_i(done, 1, 0));
 #pragma unroll
   for (int j = 0; j < 6; j++) st_if(lead, extra_out, env * 6 + j, extra[j]);
-  store_lane(S, env, leg, valid, L, P.randomize_per_episode != 0);
+  store_lane(P, S, env, leg, valid, L, P.randomize_per_episode != 0);
 }
 
 // VEC:145-194 per env: constructor randomisation (ENV:435-477) + first reset
@@ -1214,31 +1225,31 @@ IRRL_DEV void init_body(const EnvParams &P, const EnvState &S, vi env, vi leg, v
   if (P.stochastic) model_randomize(L.m, leg, P.seed, to_u(env), 0u); else model_nominal(L.m, leg);
   L.jr[0] = L.m.sy * P.abad;  // ENV:415-418
   reset_lane(P, L, to_u(env));
-  store_lane(S, env, leg, valid, L, true);
+  store_lane(P, S, env, leg, valid, L, true);
 }
 
 // VEC:201-207: reset every env, then observe
 IRRL_DEV void reset_body(const EnvParams &P, const EnvState &S, vi env, vi leg, vm valid, float *ob_out) {
   EnvLane L;
-  load_lane(S, env, leg, L);
+  load_lane(P, S, env, leg, L);
   reset_lane(P, L, to_u(env));
   observe_lane(P, env, leg, valid, L, ob_out);
-  store_lane(S, env, leg, valid, L, P.randomize_per_episode != 0);
+  store_lane(P, S, env, leg, valid, L, P.randomize_per_episode != 0);
 }
 
 // VEC:209-212
 IRRL_DEV void observe_body(const EnvParams &P, const EnvState &S, vi env, vi leg, vm valid, float *ob_out) {
   EnvLane L;
-  load_lane(S, env, leg, L);
+  load_lane(P, S, env, leg, L);
   observe_lane(P, env, leg, valid, L, ob_out);
-  if (P.obs_filter) store_lane(S, env, leg, valid, L, false);
+  if (P.obs_filter) store_lane(P, S, env, leg, valid, L, false);
 }
 
 // Diagnostics (ENV:1375-1402): world-frame inverse mass matrix (column-major [18x18]) and nonlinear term.
 // M_w^-1 = T M_B^-1 T^T with  M_B^-1 = [[S^-1, -S^-1 D^T], [-D S^-1, C^-1 + D S^-1 D^T]].
 IRRL_DEV void dynamics_probe_body(const EnvParams &P, const EnvState &S, vi env, vi leg, vm valid, float *minv_out, float *nonlin_out) {
   EnvLane L;
-  load_lane(S, env, leg, L);
+  load_lane(P, S, env, leg, L);
   rot3 R = quat_to_rot(L.qw, L.qx, L.qy, L.qz);
   v3 wB = rot_tmul(R, L.ww);
   LegKin k = leg_fk(L.m, L.q[0], L.q[1], L.q[2]);
