@@ -547,6 +547,23 @@ IRRL_DEV v3 solve_contact(const ContactBlock &B, v3 c, v3 n, vf vstar, vf mu) {
   return r;
 }
 
+// height and unit normal of the ground below world point (x, y): bilinear cell of the shared height field
+IRRL_DEV void terrain_sample(const EnvParams &P, vf x, vf y, vf &h, v3 &n) {
+  vf fx = (x - P.hf_x0) * P.hf_inv_dx, fy = (y - P.hf_y0) * P.hf_inv_dy;
+  fx = v_min(v_max(fx, 0.0f), (float)P.hf_nx - 1.001f);
+  fy = v_min(v_max(fy, 0.0f), (float)P.hf_ny - 1.001f);
+  vf fi = v_floor(fx), fj = v_floor(fy);
+  vi idx = f2i(fi) * P.hf_ny + f2i(fj);
+  vf tx = fx - fi, ty = fy - fj;
+  vf h00 = ld(P.height, idx), h01 = ld(P.height, idx + 1), h10 = ld(P.height, idx + P.hf_ny), h11 = ld(P.height, idx + P.hf_ny + 1);
+  vf a = h00 + ty * (h01 - h00), b = h10 + ty * (h11 - h10);
+  h = a + tx * (b - a);
+  vf dhdx = (b - a) * P.hf_inv_dx;
+  vf dhdy = ((h01 - h00) + tx * ((h11 - h10) - (h01 - h00))) * P.hf_inv_dy;
+  vf inv = v_rsqrt(dhdx * dhdx + dhdy * dhdy + 1.0f);
+  n = mk3(-dhdx * inv, -dhdy * inv, inv);
+}
+
 // ---------------------------------------------------------------------------------------------
 // one physics substep (ENV:761-768): PD + clamp, then the build's integrate()
 // ---------------------------------------------------------------------------------------------
@@ -562,10 +579,20 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     L.tq[k] = tau[k];
   }
   rot3 R = quat_to_rot(L.qw, L.qx, L.qy, L.qz);
-  v3 nB = R.r2;                          // R^T e_z
   v3 vB = rot_tmul(R, L.vw), wB = rot_tmul(R, L.ww);
-  v3 a0 = IRRL_GRAV * nB;
+  v3 a0 = IRRL_GRAV * R.r2;              // gravity folded into the base acceleration: g R^T e_z
   LegKin k = leg_fk(L.m, L.q[0], L.q[1], L.q[2]);
+  // ground under this lane's toe (issued early: the four table loads overlap the dynamics below)
+  v3 nB = R.r2;                          // contact normal in base components; R^T e_z on the plane
+  vf hgt = 0.0f;
+  vf nwz = 1.0f;
+  if (P.terrain) {
+    v3 cw = rot_mul(R, k.ptoe);
+    v3 nw;
+    terrain_sample(P, L.pos.x + cw.x, L.pos.y + cw.y, hgt, nw);
+    nB = rot_tmul(R, nw);
+    nwz = nw.z;
+  }
   LegDyn D;
   leg_dynamics(L.m, k, L.qd, wB, a0, D);
   // free velocity u_free = u + dt M^-1 (tau - damping qd - b)
@@ -582,7 +609,8 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
   for (int j = 0; j < 3; j++) ul[j] = L.qd[j] + dt * xl[j];
 
   // ---- contact: toe sphere against the plane z = 0 ----
-  vf gap = L.pos.z + dot(nB, k.ptoe) - IRRL_TOE_RADIUS;
+  // sphere against the locally planar ground: centre-to-tangent-plane distance minus the radius
+  vf gap = (L.pos.z + dot(R.r2, k.ptoe) - hgt) * nwz - IRRL_TOE_RADIUS;
   vm active = gap <= 0.0f;
   if (wave_any(active)) {
     v3 x = k.ptoe - IRRL_TOE_RADIUS * nB;

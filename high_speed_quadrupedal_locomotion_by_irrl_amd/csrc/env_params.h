@@ -26,6 +26,10 @@ struct EnvParams {
   float contact_tol;       // [ext] ContactTolerance: early exit of the contact sweeps (0 = fixed sweep count)
   float clamp_r;           // tau_max / (w_max - w_crit)            (Environment.hpp:1279)
   float clamp_inv_den;     // 1 / (-w_max + w_crit)                 (Environment.hpp:1296-1297)
+  // height field (Terrain: True, Environment.hpp:254-264); height == nullptr / terrain == 0 means the plane z = 0
+  int32_t terrain, hf_nx, hf_ny;
+  float hf_x0, hf_y0, hf_inv_dx, hf_inv_dy;
+  const float *height;     // [hf_nx, hf_ny] row-major, shared by every robot of the pool
 };
 
 // Device-resident state pool, structure of arrays in the reference's natural row-major shapes so the

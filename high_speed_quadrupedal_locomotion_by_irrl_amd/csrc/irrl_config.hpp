@@ -144,7 +144,11 @@ inline bool build_params(const Config &c, EnvParams &P, std::string &err) {
   if (P.loop_count <= 0) { err = "control_dt / simulation_dt must be >= 1"; return false; }
   const bool crutial = flag("Crutial"), terrain = flag("Terrain"), manual_traj = flag("ManualTraj"), force = flag("ForceDisturbance");
   if (crutial) { err = "Crutial: True (meteorite spheres, Environment.hpp:815-861) is not built in this engine"; return false; }
-  if (terrain) { err = "Terrain: True (Perlin height map, Environment.hpp:254-264) is a later row (SURVEY 8f) and not built yet"; return false; }
+  P.terrain = terrain ? 1 : 0;  // the table itself is attached by the owner of the pool (irrl_terrain.hpp)
+  P.hf_nx = 5000; P.hf_ny = 500;  // Environment.hpp:259-260
+  P.hf_x0 = -250.0f; P.hf_y0 = -10.0f;
+  P.hf_inv_dx = (float)((5000 - 1) / 500.0); P.hf_inv_dy = (float)((500 - 1) / 20.0);
+  P.height = nullptr;
   if (!manual_traj && !P.manual) { err = "ManualTraj: False needs the RefTraj CSV path (SURVEY 8f-4), not built yet"; return false; }
   if (force && P.manual) { err = "ForceDisturbance with Manual (state_disturbance, Environment.hpp:912-940) is not built"; return false; }
   return true;

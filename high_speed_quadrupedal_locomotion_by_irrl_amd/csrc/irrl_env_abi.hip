@@ -9,6 +9,7 @@
 
 #include "irrl_config.hpp"
 #include "irrl_state_pool.hpp"
+#include "irrl_terrain.hpp"
 #include "../../include/irrl_env.h"
 
 #include <cmath>
@@ -37,6 +38,8 @@ struct irrl_env {
   // device-side I/O used by the *_host entry points
   float *d_action = nullptr, *d_ob = nullptr, *d_reward = nullptr, *d_extra = nullptr, *d_scratch = nullptr;
   uint8_t *d_done = nullptr;
+  float *d_height = nullptr;  // shared height field (Terrain: True)
+  std::vector<float> h_height;
   // pinned host staging
   char *h_pinned = nullptr;
   size_t pinned_bytes = 0;
@@ -82,6 +85,12 @@ irrl_env *irrl_env_create(const char *resource_dir, const char *cfg_yaml, int de
             hipMalloc((void **)&h->d_scratch, n * 342 * 4) == hipSuccess;
   h->pinned_bytes = n * 342 * 4 + h->pool.bytes + 4096;
   ok = ok && hipHostMalloc((void **)&h->h_pinned, h->pinned_bytes, hipHostMallocDefault) == hipSuccess;
+  if (ok && h->P.terrain) {
+    irrl_host::generate_heightfield(irrl_host::TerrainSpec(), h->P.seed, h->h_height);
+    const size_t hb = h->h_height.size() * sizeof(float);
+    ok = hipMalloc((void **)&h->d_height, hb) == hipSuccess && hipMemcpy(h->d_height, h->h_height.data(), hb, hipMemcpyHostToDevice) == hipSuccess;
+    h->P.height = h->d_height;
+  }
   if (!ok) { g_err = "device / pinned allocation failed"; irrl_env_destroy(h); return nullptr; }
   h->S = h->pool.view(h->d_pool);
   return h;
@@ -97,6 +106,7 @@ void irrl_env_destroy(irrl_env *h) {
   if (h->d_extra) (void)hipFree(h->d_extra);
   if (h->d_done) (void)hipFree(h->d_done);
   if (h->d_scratch) (void)hipFree(h->d_scratch);
+  if (h->d_height) (void)hipFree(h->d_height);
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
   delete h;
 }
@@ -316,6 +326,13 @@ int irrl_env_set_state_host(irrl_env *h, const double *in) {
   std::memcpy(h->h_pinned, m.data(), h->pool.bytes);
   HIP_TRY(hipMemcpyAsync(h->d_pool, h->h_pinned, h->pool.bytes, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+int irrl_env_heightfield_host(irrl_env *h, float *out, int *nx, int *ny) {
+  if (nx) *nx = h->P.hf_nx;
+  if (ny) *ny = h->P.hf_ny;
+  if (!h->P.terrain) { g_err = "this pool runs on the plane z = 0 (Terrain: False)"; return 1; }
+  if (out) std::memcpy(out, h->h_height.data(), h->h_height.size() * sizeof(float));
   return 0;
 }
 double irrl_env_cfg_value(const irrl_env *h, const char *key) {

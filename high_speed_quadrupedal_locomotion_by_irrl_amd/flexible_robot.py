@@ -218,5 +218,14 @@ class FlexibleGymEnv(object):
             raise TypeError("state must have shape (%d, 288)" % self._n)
         _lib.check(self._lib.irrl_env_set_state_host(self._h, state.ctypes.data_as(C.POINTER(C.c_double))))
 
+    def heightfield(self):
+        """[5000, 500] float32 height field of a Terrain: True pool (None on flat ground)."""
+        nx, ny = C.c_int(0), C.c_int(0)
+        if self._lib.irrl_env_heightfield_host(self._h, None, C.byref(nx), C.byref(ny)) != 0:
+            return None
+        out = np.zeros((nx.value, ny.value), np.float32)
+        _lib.check(self._lib.irrl_env_heightfield_host(self._h, out.ctypes.data_as(_fp), C.byref(nx), C.byref(ny)))
+        return out
+
     def cfg_value(self, key):
         return self._lib.irrl_env_cfg_value(self._h, key.encode())

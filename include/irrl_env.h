@@ -108,6 +108,9 @@ enum {
 };
 int irrl_env_get_state_host(irrl_env *h, double *out);
 int irrl_env_set_state_host(irrl_env *h, const double *in);
+/* the shared height field of a `Terrain: True` pool (Environment.hpp:254-264), [nx, ny] row-major f32; out may be NULL
+ * to query the shape only; returns non-zero on flat ground */
+int irrl_env_heightfield_host(irrl_env *h, float *out, int *nx, int *ny);
 /* value of a numeric/bool config key as parsed by the library (tests the YAML reader); NaN if absent */
 double irrl_env_cfg_value(const irrl_env *h, const char *key);
 

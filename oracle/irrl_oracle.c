@@ -552,6 +552,78 @@ static void solve_contact(const real *G, const real *c, const real *n, real vsta
   v3_scale(lam, w, -cn / nGw);
 }
 
+/* ---- height field (Terrain: True).  RaiSim's Perlin terrain (ENV:254-264) is closed source; the spec is the
+ * build's own: improved Perlin noise, LCG-shuffled permutation seeded by seedd,
+ * h = zScale * sum_o gain^o noise(freq lac^o (x,y)), 5000 x 500 samples over 500 m x 20 m centred at the origin,
+ * bilinear sampling, normal from the cell gradient.  Written independently of csrc/irrl_terrain.hpp. ---- */
+#define HF_NX 5000
+#define HF_NY 500
+#define HF_XSIZE 500.0
+#define HF_YSIZE 20.0
+static double pn_fade(double t) { return t * t * t * (t * (t * 6.0 - 15.0) + 10.0); }
+static double pn_lerp(double t, double a, double b) { return a + t * (b - a); }
+static double pn_grad(int hash, double x, double y, double z) {
+  int h = hash & 15;
+  double u = (h < 8) ? x : y;
+  double v = (h < 4) ? y : ((h == 12 || h == 14) ? x : z);
+  return (((h & 1) == 0) ? u : -u) + (((h & 2) == 0) ? v : -v);
+}
+static double pn_noise2(const int *perm, double x, double y) {
+  double fx = floor(x), fy = floor(y);
+  int X = ((int)fx) & 255, Y = ((int)fy) & 255;
+  x -= fx; y -= fy;
+  double u = pn_fade(x), v = pn_fade(y), w = pn_fade(0.0);
+  int A = perm[X] + Y, AA = perm[A], AB = perm[A + 1], B = perm[X + 1] + Y, BA = perm[B], BB = perm[B + 1];
+  double lo = pn_lerp(v, pn_lerp(u, pn_grad(perm[AA], x, y, 0.0), pn_grad(perm[BA], x - 1, y, 0.0)),
+                      pn_lerp(u, pn_grad(perm[AB], x, y - 1, 0.0), pn_grad(perm[BB], x - 1, y - 1, 0.0)));
+  double hi = pn_lerp(v, pn_lerp(u, pn_grad(perm[AA + 1], x, y, -1.0), pn_grad(perm[BA + 1], x - 1, y, -1.0)),
+                      pn_lerp(u, pn_grad(perm[AB + 1], x, y - 1, -1.0), pn_grad(perm[BB + 1], x - 1, y - 1, -1.0)));
+  return pn_lerp(w, lo, hi);
+}
+static float *make_heightfield(uint32_t seed) {
+  int base[256], perm[512];
+  for (int i = 0; i < 256; i++) base[i] = i;
+  uint32_t s = seed * 747796405u + 2891336453u;
+  for (int i = 255; i > 0; i--) {
+    s = s * 1664525u + 1013904223u;
+    int j = (int)((s >> 8) % (uint32_t)(i + 1));
+    int t = base[i]; base[i] = base[j]; base[j] = t;
+  }
+  for (int i = 0; i < 512; i++) perm[i] = base[i & 255];
+  float *H = (float *)malloc(sizeof(float) * (size_t)HF_NX * HF_NY);
+  const double dx = HF_XSIZE / (HF_NX - 1), dy = HF_YSIZE / (HF_NY - 1);
+  for (int i = 0; i < HF_NX; i++) {
+    double x = -0.5 * HF_XSIZE + i * dx;
+    for (int j = 0; j < HF_NY; j++) {
+      double y = -0.5 * HF_YSIZE + j * dy;
+      double f = 1.0, a = 1.0, h = 0.0;
+      for (int o = 0; o < 3; o++) { h += a * pn_noise2(perm, x * f, y * f); f *= 2.0; a *= 0.25; }
+      H[(size_t)i * HF_NY + j] = (float)(0.1 * h);
+    }
+  }
+  return H;
+}
+/* height and unit normal at world (x, y); flat ground when H == NULL */
+static void terrain_sample(const float *H, real x, real y, real *h, real *n) {
+  if (!H) { *h = RC(0); n[0] = RC(0); n[1] = RC(0); n[2] = RC(1); return; }
+  const real inv_dx = RC((HF_NX - 1) / HF_XSIZE), inv_dy = RC((HF_NY - 1) / HF_YSIZE);
+  real fx = (x + RC(0.5 * HF_XSIZE)) * inv_dx, fy = (y + RC(0.5 * HF_YSIZE)) * inv_dy;
+  if (fx < RC(0)) fx = RC(0);
+  if (fx > RC(HF_NX - 1.001)) fx = RC(HF_NX - 1.001);
+  if (fy < RC(0)) fy = RC(0);
+  if (fy > RC(HF_NY - 1.001)) fy = RC(HF_NY - 1.001);
+  int i = (int)R_TO_DOUBLE(fx), j = (int)R_TO_DOUBLE(fy);
+  real tx = fx - RC(i), ty = fy - RC(j);
+  real h00 = RC((double)H[(size_t)i * HF_NY + j]), h01 = RC((double)H[(size_t)i * HF_NY + j + 1]);
+  real h10 = RC((double)H[(size_t)(i + 1) * HF_NY + j]), h11 = RC((double)H[(size_t)(i + 1) * HF_NY + j + 1]);
+  real a = h00 + ty * (h01 - h00), b = h10 + ty * (h11 - h10);
+  *h = a + tx * (b - a);
+  real dhdx = (b - a) * inv_dx;
+  real dhdy = ((h01 - h00) + tx * ((h11 - h10) - (h01 - h00))) * inv_dy;
+  real inv = RC(1) / R_SQRT(dhdx * dhdx + dhdy * dhdy + RC(1));
+  n[0] = -dhdx * inv; n[1] = -dhdy * inv; n[2] = inv;
+}
+
 /* ------------------------------------------------------------------ 6. task logic */
 typedef struct {
   /* physics state (RaiSim conventions) */
@@ -588,6 +660,7 @@ struct orc_env {
   real filter_para, obs_filter_alpha;
   real max_len;
   double flops;
+  float *height; /* NULL = flat ground */
 };
 
 static real env_time(const orc_env *h, const env_t *e) { return e->t0 + RC(e->frame_idx) * RC(h->cfg.control_dt); }
@@ -844,11 +917,10 @@ static void physics_substep(orc_env *h, env_t *e, const real *pTarget) {
   forward_kinematics(m, q, &k);
   real M[NV * NV], L[NV * NV], b[NV], u[NV], rhs[NV];
   mass_matrix_B(m, &k, M);
-  real vB[3], wB[3], gB[3], gw[3] = {RC(0), RC(0), RC(-GRAV)}, nB[3], ez[3] = {RC(0), RC(0), RC(1)};
+  real vB[3], wB[3], gB[3], gw[3] = {RC(0), RC(0), RC(-GRAV)};
   m3_tmulv(vB, R, &e->gv[0]);
   m3_tmulv(wB, R, &e->gv[3]);
   m3_tmulv(gB, R, gw);
-  m3_tmulv(nB, R, ez);
   bias_forces_B(m, &k, wB, qd, gB, b);
   for (int a = 0; a < 3; a++) { u[a] = vB[a]; u[3 + a] = wB[a]; }
   for (int j = 0; j < 12; j++) u[6 + j] = qd[j];
@@ -862,16 +934,21 @@ static void physics_substep(orc_env *h, env_t *e, const real *pTarget) {
 
   /* contact detection + Jacobians */
   int active[4];
-  real J[4][3][NV], MiJt[4][3][NV], G[4][4][9], cfree[4][3], vstar[4], lamB[4][3];
+  real J[4][3][NV], MiJt[4][3][NV], G[4][4][9], cfree[4][3], vstar[4], lamB[4][3], nBl[4][3];
   for (int l = 0; l < 4; l++) {
     int s = 3 + 3 * l;
     real off[3] = {RC(0), RC(0), RC(TOE_Z)}, xc[3], cw[3];
     m3_mulv(xc, k.R[s], off);
     v3_add(xc, xc, k.p[s]);
     m3_mulv(cw, R, xc);
-    real gap = e->gc[2] + cw[2] - RC(TOE_RADIUS);
+    /* sphere against the locally planar ground: distance of the centre to the tangent plane minus the radius */
+    real hgt, nw[3];
+    terrain_sample(h->height, e->gc[0] + cw[0], e->gc[1] + cw[1], &hgt, nw);
+    real gap = (e->gc[2] + cw[2] - hgt) * nw[2] - RC(TOE_RADIUS);
     active[l] = (gap <= RC(0));
     if (!active[l]) { v3_set(lamB[l], RC(0), RC(0), RC(0)); continue; }
+    real *nB = nBl[l];
+    m3_tmulv(nB, R, nw);
     real x[3];
     for (int a = 0; a < 3; a++) x[a] = xc[a] - RC(TOE_RADIUS) * nB[a];
     for (int r = 0; r < 3; r++) for (int cc = 0; cc < NV; cc++) J[l][r][cc] = RC(0);
@@ -921,7 +998,7 @@ static void physics_substep(orc_env *h, env_t *e, const real *pTarget) {
         m3_mulv(t, G[l][lb], lamB[lb]);
         v3_add(cv, cv, t);
       }
-      solve_contact(G[l][l], cv, nB, vstar[l], m->mu, lamB[l]);
+      solve_contact(G[l][l], cv, nBl[l], vstar[l], m->mu, lamB[l]);
       for (int a = 0; a < 3; a++) { real dd = lamB[l][a] - old[a]; d2 += dd * dd; l2 += lamB[l][a] * lamB[l][a]; }
     }
     /* build-defined early exit (same rule in the kernels, evaluated per wave there) */
@@ -1070,7 +1147,7 @@ static void obs_scaling(const orc_cfg *c, real *mean, real *std) {
 
 orc_env *orc_create(const orc_cfg *cfg) {
   if (!cfg || cfg->num_envs <= 0) return NULL;
-  if (cfg->Crutial || cfg->Terrain || (!cfg->ManualTraj && !cfg->Manual)) return NULL; /* rows not built yet */
+  if (cfg->Crutial || (!cfg->ManualTraj && !cfg->Manual)) return NULL; /* rows not built yet */
   orc_env *h = (orc_env *)calloc(1, sizeof(orc_env));
   h->cfg = *cfg;
   if (h->cfg.ContactIterations <= 0) h->cfg.ContactIterations = 6;
@@ -1093,9 +1170,10 @@ orc_env *orc_create(const orc_cfg *cfg) {
   h->filter_para = cfg->Filter ? RC(1 - cfg->Freq * 0.01) : RC(0);
   h->obs_filter_alpha = cfg->ObsFilter ? RC(2.0 * 3.14 * 0.01 * 20.0 / (2.0 * 3.14 * 0.01 * 20.0 + 1.0)) : RC(1.0);
   h->max_len = R_SQRT(RC(L_HIP) * RC(L_HIP) + (RC(L_CALF) + RC(L_THIGH)) * (RC(L_CALF) + RC(L_THIGH)));
+  h->height = cfg->Terrain ? make_heightfield((uint32_t)cfg->seedd) : NULL;
   return h;
 }
-void orc_destroy(orc_env *h) { if (h) { free(h->envs); free(h); } }
+void orc_destroy(orc_env *h) { if (h) { free(h->envs); free(h->height); free(h); } }
 int orc_num_envs(const orc_env *h) { return h->n; }
 int orc_real_bytes(void) { return (int)sizeof(real); }
 
@@ -1361,6 +1439,17 @@ void orc_rng_u01(uint32_t seed, uint32_t env, uint32_t episode, uint32_t step, u
   for (int i = 0; i < 4; i++) out[i] = R_TO_DOUBLE(u[i]);
 }
 double orc_last_step_flops(const orc_env *h) { return h->flops; }
+int orc_heightfield(const orc_env *h, float *out, int *nx, int *ny) {
+  *nx = HF_NX; *ny = HF_NY;
+  if (!h->height) return 0;
+  if (out) memcpy(out, h->height, sizeof(float) * (size_t)HF_NX * HF_NY);
+  return 1;
+}
+void orc_terrain_sample(const orc_env *h, double x, double y, double out[4]) {
+  real hh, n[3];
+  terrain_sample(h->height, RC(x), RC(y), &hh, n);
+  out[0] = R_TO_DOUBLE(hh); out[1] = R_TO_DOUBLE(n[0]); out[2] = R_TO_DOUBLE(n[1]); out[3] = R_TO_DOUBLE(n[2]);
+}
 double orc_mean_contact_sweeps(const orc_env *h) {
   double a = 0, b = 0;
   for (int i = 0; i < h->n; i++) { a += (double)h->envs[i].gs_sweeps; b += (double)h->envs[i].gs_substeps; }

@@ -129,6 +129,10 @@ void orc_rng_u01(uint32_t seed, uint32_t env, uint32_t episode, uint32_t step, u
                  double out[4]);
 /* algorithmic flop count of the last orc_step (per env, averaged); 0 unless built -DORC_COUNT_FLOPS */
 double orc_last_step_flops(const orc_env *h);
+/* height field of a Terrain: True pool (returns 0 and leaves `out` alone on flat ground); [nx, ny] row-major */
+int orc_heightfield(const orc_env *h, float *out, int *nx, int *ny);
+/* (height, nx, ny, nz) at world (x, y) */
+void orc_terrain_sample(const orc_env *h, double x, double y, double out[4]);
 /* mean number of contact sweeps per substep since creation (statistics for DESIGN.md) */
 double orc_mean_contact_sweeps(const orc_env *h);
 

@@ -158,6 +158,23 @@ class OracleVecEnv(object):
             self.lib.orc_destroy(self.h)
             self.h = None
 
+    def heightfield(self):
+        nx, ny = C.c_int(0), C.c_int(0)
+        self.lib.orc_heightfield.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        self.lib.orc_heightfield.restype = C.c_int
+        if not self.lib.orc_heightfield(self.h, None, C.byref(nx), C.byref(ny)):
+            return None
+        out = np.zeros((nx.value, ny.value), np.float32)
+        self.lib.orc_heightfield(self.h, _fp(out), C.byref(nx), C.byref(ny))
+        return out
+
+    def terrain_sample(self, x, y):
+        out = (C.c_double * 4)()
+        self.lib.orc_terrain_sample.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double * 4]
+        self.lib.orc_terrain_sample.restype = None
+        self.lib.orc_terrain_sample(self.h, float(x), float(y), out)
+        return np.array(out[:])
+
     def mean_contact_sweeps(self):
         return self.lib.orc_mean_contact_sweeps(self.h)
 

@@ -15,7 +15,7 @@ STATE_DIM = 288
 def build():
     out = os.path.join(_HERE, "_build", "libirrl_emu.so")
     srcs = [os.path.join(_HERE, f) for f in ("emu_main.cpp", "lanes_cpu.hpp")] + \
-           [os.path.join(_CSRC, f) for f in ("env_core.hpp", "env_params.h", "irrl_config.hpp", "irrl_state_pool.hpp")]
+           [os.path.join(_CSRC, f) for f in ("env_core.hpp", "env_params.h", "irrl_config.hpp", "irrl_state_pool.hpp", "irrl_terrain.hpp")]
     if (not os.path.exists(out)) or os.path.getmtime(out) < max(os.path.getmtime(s) for s in srcs):
         os.makedirs(os.path.dirname(out), exist_ok=True)
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-I" + _CSRC,
@@ -85,6 +85,15 @@ class EmuVecEnv(object):
         nl = np.zeros((self.n, 18), np.float32)
         self.l.emu_probe(self.h, _fp(minv), _fp(nl))
         return minv, nl
+
+    def heightfield(self):
+        self.l.emu_heightfield.restype = C.c_int
+        self.l.emu_heightfield.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        if not self.l.emu_heightfield(self.h, None):
+            return None
+        out = np.zeros((5000, 500), np.float32)
+        self.l.emu_heightfield(self.h, _fp(out))
+        return out
 
     def get_state(self):
         out = np.zeros((self.n, STATE_DIM), np.float64)

@@ -10,6 +10,7 @@
 #include "env_core.hpp"
 #include "irrl_config.hpp"
 #include "irrl_state_pool.hpp"
+#include "irrl_terrain.hpp"
 
 #include <string>
 #include <vector>
@@ -18,6 +19,7 @@ struct Emu {
   EnvParams P;
   irrl_host::StatePool pool;
   std::vector<char> mem;
+  std::vector<float> height;
   EnvState S;
 };
 static std::string g_err;
@@ -34,6 +36,10 @@ void *emu_create(const char *cfg_yaml) {
   h->pool = irrl_host::StatePool(h->P.n_envs);
   h->mem.assign(h->pool.bytes, 0);
   h->S = h->pool.view(h->mem.data());
+  if (h->P.terrain) {
+    irrl_host::generate_heightfield(irrl_host::TerrainSpec(), h->P.seed, h->height);
+    h->P.height = h->height.data();
+  }
   return h;
 }
 void emu_destroy(void *hv) { delete (Emu *)hv; }
@@ -63,4 +69,10 @@ void emu_probe(void *hv, float *minv, float *nonlin) {
 void emu_get_state(void *hv, double *out) { Emu *h = (Emu *)hv; h->pool.pack(h->mem.data(), out); }
 void emu_set_state(void *hv, const double *in) { Emu *h = (Emu *)hv; h->pool.unpack(in, h->mem.data()); }
 void emu_get_params(void *hv, EnvParams *out) { *out = ((Emu *)hv)->P; }
+int emu_heightfield(void *hv, float *out) {
+  Emu *h = (Emu *)hv;
+  if (h->height.empty()) return 0;
+  if (out) std::memcpy(out, h->height.data(), h->height.size() * sizeof(float));
+  return 1;
+}
 }

@@ -62,7 +62,7 @@ def check_probe(orc, cand):
     assert np.abs(nl_c - nl_o).max() < 5e-3  # entries up to ~90 N
 
 
-def check_teacher_forced(orc, cand, steps, seed=0, action_scale=0.5, force_terminal_every=0):
+def check_teacher_forced(orc, cand, steps, seed=0, action_scale=0.5, force_terminal_every=0, max_factor=10.0):
     """Every step starts from the oracle's state (rounded to f32) in BOTH implementations."""
     rng = np.random.RandomState(seed)
     n = orc.n
@@ -104,7 +104,7 @@ def check_teacher_forced(orc, cand, steps, seed=0, action_scale=0.5, force_termi
         worst[key] = float(e.max())
         worst[key + "_p99"] = float(np.percentile(e, 99))
         assert worst[key + "_p99"] < tol, (key, worst)
-        assert worst[key] < 10 * tol, (key, worst)
+        assert worst[key] < max_factor * tol, (key, worst)
     return worst, n_done
 
 

@@ -138,3 +138,20 @@ def test_reference_call_surface():
         env.wrapper.step(np.zeros((32, 12), np.float64), env._observation, env._reward, env._done, env._extraInfo)
     ob2, info2 = env.reset_and_update_info()
     assert len(info2) == 32 and "episode" in info2[0]
+
+
+def test_terrain_and_per_episode_randomisation_config5():
+    """BASELINE config 5 ingredients: Perlin height field shared by the pool + friction/mass/COM/thigh randomisation
+    redrawn at every reset."""
+    cfg = load_env_cfg("bp5_terrain.yaml", num_envs=64)
+    orc, cand = _pair(cfg)
+    Ho, Hc = orc.heightfield(), cand.impl.heightfield()
+    assert Ho.shape == (5000, 500) and np.abs(Ho - Hc).max() < 1e-7
+    PL.check_init(orc, cand)
+    worst, n_done = PL.check_teacher_forced(orc, cand, steps=120, force_terminal_every=4, max_factor=1e4)
+    assert n_done >= 20
+    print("terrain teacher-forced:", worst)
+    # model parameters were redrawn by the in-kernel resets and still agree with the oracle's
+    so, sc = orc.get_state(), cand.get_state()
+    np.testing.assert_allclose(sc[:, PL.S["MATERIAL"]:PL.S["OB"]], so[:, PL.S["MATERIAL"]:PL.S["OB"]], atol=2e-7)
+    assert np.unique(np.round(so[:, PL.S["MATERIAL"]], 5)).size > 32
