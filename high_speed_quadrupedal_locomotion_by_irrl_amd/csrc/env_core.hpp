@@ -90,7 +90,7 @@ IRRL_DEV sym3 shift_to_origin(sym3 I, vf m, v3 c) {
   r.yy = I.yy + m * (cc - c.y * c.y); r.yz = I.yz - m * c.y * c.z; r.zz = I.zz + m * (cc - c.z * c.z);
   return r;
 }
-IRRL_DEV v3 quad_sum3(v3 a) { return mk3(quad_sum(a.x), quad_sum(a.y), quad_sum(a.z)); }
+IRRL_DEV v3 legs_sum3(v3 a) { return mk3(legs_sum(a.x), legs_sum(a.y), legs_sum(a.z)); }
 
 // rotation matrix body->world from quaternion (w,x,y,z); rows r0,r1,r2
 struct rot3 { v3 r0, r1, r2; };
@@ -129,12 +129,12 @@ IRRL_DEV rng4 philox_u01(vu seed, vu env, vu episode, vu step, vu purpose) {
 }
 // 16 consecutive uniforms (purposes p .. p+3): lane l of the quad generates block l, DPP broadcasts
 // make all 16 visible to every lane.  out[i] == slot (i&3) of purpose p + (i>>2).
-IRRL_DEV void quad_rng16(vu seed, vu env, vu episode, vu step, vu purpose, vf out[16]) {
+IRRL_DEV void legs_rng16(vu seed, vu env, vu episode, vu step, vu purpose, vf out[16]) {
   rng4 r = philox_u01(seed, env, episode, step, purpose + to_u(leg_id()));
-  out[0] = quad_bcast<0>(r.u0); out[1] = quad_bcast<0>(r.u1); out[2] = quad_bcast<0>(r.u2); out[3] = quad_bcast<0>(r.u3);
-  out[4] = quad_bcast<1>(r.u0); out[5] = quad_bcast<1>(r.u1); out[6] = quad_bcast<1>(r.u2); out[7] = quad_bcast<1>(r.u3);
-  out[8] = quad_bcast<2>(r.u0); out[9] = quad_bcast<2>(r.u1); out[10] = quad_bcast<2>(r.u2); out[11] = quad_bcast<2>(r.u3);
-  out[12] = quad_bcast<3>(r.u0); out[13] = quad_bcast<3>(r.u1); out[14] = quad_bcast<3>(r.u2); out[15] = quad_bcast<3>(r.u3);
+  out[0] = legs_bcast<0>(r.u0); out[1] = legs_bcast<0>(r.u1); out[2] = legs_bcast<0>(r.u2); out[3] = legs_bcast<0>(r.u3);
+  out[4] = legs_bcast<1>(r.u0); out[5] = legs_bcast<1>(r.u1); out[6] = legs_bcast<1>(r.u2); out[7] = legs_bcast<1>(r.u3);
+  out[8] = legs_bcast<2>(r.u0); out[9] = legs_bcast<2>(r.u1); out[10] = legs_bcast<2>(r.u2); out[11] = legs_bcast<2>(r.u3);
+  out[12] = legs_bcast<3>(r.u0); out[13] = legs_bcast<3>(r.u1); out[14] = legs_bcast<3>(r.u2); out[15] = legs_bcast<3>(r.u3);
 }
 // pick element (3*leg + k) of a 12-vector that every lane holds
 IRRL_DEV vf pick_leg(const vf v[12], vi leg, int k) {
@@ -189,7 +189,7 @@ IRRL_DEV void model_randomize(LegModel &m, vi leg, vu seed, vu env, vu episode) 
   vf u[16];
   rng4 r = philox_u01(seed, env, episode, 0u, IRRL_P_DR_MATERIAL);
   m.mu = r.u0 * 0.6f + 0.4f; m.rest = r.u1 * 0.3f; m.rest_thr = r.u2 * 2.0f;
-  quad_rng16(seed, env, episode, 0u, IRRL_P_DR_MASS, u);
+  legs_rng16(seed, env, episode, 0u, IRRL_P_DR_MASS, u);
   vf f[13];
 #pragma unroll
   for (int i = 0; i < 13; i++) f[i] = (u[i] - 0.5f) / 0.5f * 0.15f + 1.0f;
@@ -198,9 +198,9 @@ IRRL_DEV void model_randomize(LegModel &m, vi leg, vu seed, vu env, vu episode) 
   m.mT = m.mT * pick4(f[2], f[5], f[8], f[11], leg);
   m.mS = m.mS * pick4(f[3], f[6], f[9], f[12], leg);
   vf c[48];
-  quad_rng16(seed, env, episode, 0u, IRRL_P_DR_COM, c);
-  quad_rng16(seed, env, episode, 0u, IRRL_P_DR_COM + 4u, c + 16);
-  quad_rng16(seed, env, episode, 0u, IRRL_P_DR_COM + 8u, c + 32);
+  legs_rng16(seed, env, episode, 0u, IRRL_P_DR_COM, c);
+  legs_rng16(seed, env, episode, 0u, IRRL_P_DR_COM + 4u, c + 16);
+  legs_rng16(seed, env, episode, 0u, IRRL_P_DR_COM + 8u, c + 32);
 #pragma unroll
   for (int i = 0; i < 39; i++) c[i] = (2.0f * c[i] - 1.0f) * 0.02f;
   m.com0 = m.com0 + mk3(c[0], c[1], c[2]);
@@ -311,10 +311,8 @@ struct LegKin {
   v3 h;                 // hip / knee joint axis = -ay
   v3 pA, pT, pS, ptoe;  // joint origins and toe frame origin
 };
-IRRL_DEV LegKin leg_fk(const LegModel &m, vf q0, vf q1, vf q2) {
+IRRL_DEV LegKin leg_fk_trig(const LegModel &m, vf s0, vf c0, vf s1, vf c1, vf s12, vf c12) {
   LegKin k;
-  vf s0, c0, s1, c1, s12, c12;
-  sincos_fast(q0, s0, c0); sincos_fast(q1, s1, c1); sincos_fast(q1 + q2, s12, c12);
   k.ay = mk3(0.0f, c0, s0); k.az = mk3(0.0f, -s0, c0);
   k.tx = mk3(c1, -s0 * s1, c0 * s1); k.tz = mk3(-s1, -s0 * c1, c0 * c1);
   k.sx = mk3(c12, -s0 * s12, c0 * s12); k.sz = mk3(-s12, -s0 * c12, c0 * c12);
@@ -324,6 +322,11 @@ IRRL_DEV LegKin leg_fk(const LegModel &m, vf q0, vf q1, vf q2) {
   k.pS = k.pT + (-0.201f + m.dz) * k.tz;
   k.ptoe = k.pS + IRRL_TOE_Z * k.sz;
   return k;
+}
+IRRL_DEV LegKin leg_fk(const LegModel &m, vf q0, vf q1, vf q2) {
+  vf s0, c0, s1, c1, s12, c12;
+  sincos_fast(q0, s0, c0); sincos_fast(q1, s1, c1); sincos_fast(q1 + q2, s12, c12);
+  return leg_fk_trig(m, s0, c0, s1, c1, s12, c12);
 }
 
 // Everything the velocity update needs from the factorised dynamics.
@@ -417,20 +420,20 @@ IRRL_DEV void leg_dynamics(const LegModel &m, const LegKin &k, const vf qd[3], v
     D.X[i][2] = B[i][0] * D.Ci.xz + B[i][1] * D.Ci.yz + B[i][2] * D.Ci.zz;
   }
   // ---- base block from the quad-reduced whole-robot composite ----
-  vf mtot = m.m0 + quad_sum(mcA);
-  v3 htot = m.m0 * m.com0 + quad_sum3(hA);
+  vf mtot = m.m0 + legs_sum(mcA);
+  v3 htot = m.m0 * m.com0 + legs_sum3(hA);
   sym3 I0;  // base body inertia about its COM is diagonal in the base frame (URDF:21)
   I0.xx = 0.016269f; I0.xy = 0.0f; I0.xz = 0.0f; I0.yy = 0.050813f; I0.yz = 0.0f; I0.zz = 0.060989f;
   sym3 Io0 = shift_to_origin(I0, m.m0, m.com0);
   sym3 Iot;
-  Iot.xx = Io0.xx + quad_sum(IoA.xx); Iot.xy = Io0.xy + quad_sum(IoA.xy); Iot.xz = Io0.xz + quad_sum(IoA.xz);
-  Iot.yy = Io0.yy + quad_sum(IoA.yy); Iot.yz = Io0.yz + quad_sum(IoA.yz); Iot.zz = Io0.zz + quad_sum(IoA.zz);
+  Iot.xx = Io0.xx + legs_sum(IoA.xx); Iot.xy = Io0.xy + legs_sum(IoA.xy); Iot.xz = Io0.xz + legs_sum(IoA.xz);
+  Iot.yy = Io0.yy + legs_sum(IoA.yy); Iot.yz = Io0.yz + legs_sum(IoA.yz); Iot.zz = Io0.zz + legs_sum(IoA.zz);
   // Schur complement S = A - sum_l X_l B_l^T  (lower triangle, 21 entries)
   vf S[21];
 #pragma unroll
   for (int i = 0; i < 6; i++)
 #pragma unroll
-    for (int j = 0; j <= i; j++) S[L6I(i, j)] = quad_sum(D.X[i][0] * B[j][0] + D.X[i][1] * B[j][1] + D.X[i][2] * B[j][2]);
+    for (int j = 0; j <= i; j++) S[L6I(i, j)] = legs_sum(D.X[i][0] * B[j][0] + D.X[i][1] * B[j][1] + D.X[i][2] * B[j][2]);
   // A = [[m 1, -[h]x], [[h]x, Io]] ; lower triangle: rows 3-5 x cols 0-2 hold [h]x
   vf A[21];
 #pragma unroll
@@ -490,15 +493,15 @@ IRRL_DEV void leg_dynamics(const LegModel &m, const LegKin &k, const vf qd[3], v
   v3 Nleg = NA + cross(k.pA, FA);
   v3 f0 = m.m0 * (a0 + cross(wB, cross(wB, m.com0)));
   v3 n0 = cross(wB, mul(I0, wB)) + cross(m.com0, f0);
-  v3 Fb = f0 + quad_sum3(FA);
-  v3 Nb = n0 + quad_sum3(Nleg);
+  v3 Fb = f0 + legs_sum3(FA);
+  v3 Nb = n0 + legs_sum3(Nleg);
   D.bias_b[0] = Fb.x; D.bias_b[1] = Fb.y; D.bias_b[2] = Fb.z; D.bias_b[3] = Nb.x; D.bias_b[4] = Nb.y; D.bias_b[5] = Nb.z;
 }
 
 // x = M_B^-1 r for r = (rb: shared base rows, rl: this leg's rows).  Results: xb (replicated), xl.
 IRRL_DEV void solve_M(const LegDyn &D, const vf rb[6], const vf rl[3], vf xb[6], vf xl[3]) {
 #pragma unroll
-  for (int i = 0; i < 6; i++) xb[i] = rb[i] - quad_sum(D.X[i][0] * rl[0] + D.X[i][1] * rl[1] + D.X[i][2] * rl[2]);
+  for (int i = 0; i < 6; i++) xb[i] = rb[i] - legs_sum(D.X[i][0] * rl[0] + D.X[i][1] * rl[1] + D.X[i][2] * rl[2]);
   l6_fwd(D.L6, xb);
   l6_bwd(D.L6, xb);
   vf c0 = D.Ci.xx * rl[0] + D.Ci.xy * rl[1] + D.Ci.xz * rl[2];
@@ -567,6 +570,328 @@ IRRL_DEV void terrain_sample(const EnvParams &P, vf x, vf y, vf &h, v3 &n) {
 // ---------------------------------------------------------------------------------------------
 // one physics substep (ENV:761-768): PD + clamp, then the build's integrate()
 // ---------------------------------------------------------------------------------------------
+
+#ifdef IRRL_L16
+// ---------------------------------------------------------------------------------------------
+// 16 lanes per robot: the quad (lane >> 2) is the leg, the sub-lane s = lane & 3 owns body / joint s of that leg
+// (0 abad, 1 thigh, 2 shank+toe, 3 spare with zero mass).  Per-body work (inertia rotation, Newton-Euler forces),
+// CRBA columns, rows of the contact operators and the joint integration are split over the sub-lanes; composite
+// inertias / subtree forces are SUFFIX SUMS over the quad (2 DPP adds), sums over legs are row rotations.
+// Values tagged (R) are replicated in the quad, (D) differ per sub-lane.
+// ---------------------------------------------------------------------------------------------
+IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
+  const float dt = P.sim_dt;
+  const vi sub = sub_id();
+  const vm is0 = sub == 0, is1 = sub == 1, is3 = sub == 3, ge1 = sub >= 1, ge2 = sub >= 2;
+#define PICK3(a, b, c) vsel(is0, (a), vsel(is1, (b), (c)))   /* sub-lanes 2 and 3 take c */
+  // (D) PD law for joint `sub`, 1 % blend with the normalised torque_last, speed-dependent clamp (ENV:762-765, 1273-1312)
+  vf q_s = PICK3(L.q[0], L.q[1], L.q[2]), qd_s = PICK3(L.qd[0], L.qd[1], L.qd[2]);
+  vf tau_s;
+  {
+    vf pT_s = PICK3(pT[0], pT[1], pT[2]), tql_s = PICK3(L.tql[0], L.tql[1], L.tql[2]);
+    vf kp_s = PICK3(vf(P.kp[0]), vf(P.kp[1]), vf(P.kp[2])), kd_s = PICK3(vf(P.kd[0]), vf(P.kd[1]), vf(P.kd[2]));
+    vf t = (pT_s - q_s) * kp_s - qd_s * kd_s;
+    t = 0.99f * t + (1.0f - 0.99f) * tql_s;
+    vf ratio = vsel(ge2, 1.55f, 1.0f);
+    vf w = qd_s * ratio;
+    vf up = vsel(w > P.w_crit, P.tau_max - (w - P.w_crit) * P.clamp_r, P.tau_max) * ratio;
+    vf low = vsel(w < -P.w_crit, (-P.w_max - w) * P.clamp_inv_den * -P.tau_max, -P.tau_max) * ratio;
+    tau_s = v_max(v_min(t, up), low);
+    L.tq[0] = sub_bcast<0>(tau_s); L.tq[1] = sub_bcast<1>(tau_s); L.tq[2] = sub_bcast<2>(tau_s);
+  }
+  // (R) base frame quantities
+  rot3 R = quat_to_rot(L.qw, L.qx, L.qy, L.qz);
+  v3 vB = rot_tmul(R, L.vw), wB = rot_tmul(R, L.ww);
+  v3 a0 = IRRL_GRAV * R.r2;
+  // FK: each sub-lane evaluates one sincos (q0 | q1 | q1 + q2), the quad shares them
+  LegKin k;
+  {
+    vf ang = PICK3(L.q[0], L.q[1], L.q[1] + L.q[2]), sn, cs;
+    sincos_fast(ang, sn, cs);
+    k = leg_fk_trig(L.m, sub_bcast<0>(sn), sub_bcast<0>(cs), sub_bcast<1>(sn), sub_bcast<1>(cs), sub_bcast<2>(sn), sub_bcast<2>(cs));
+  }
+  v3 nB = R.r2;
+  vf hgt = 0.0f, nwz = 1.0f;
+  if (P.terrain) {
+    v3 cw = rot_mul(R, k.ptoe);
+    v3 nw;
+    terrain_sample(P, L.pos.x + cw.x, L.pos.y + cw.y, hgt, nw);
+    nB = rot_tmul(R, nw);
+    nwz = nw.z;
+  }
+  // (D) the sub-lane's own body: frame, joint axis / origin, inertial parameters (sub-lane 3 carries zero mass)
+  const v3 ex = mk3(PICK3(vf(1.0f), k.tx.x, k.sx.x), PICK3(vf(0.0f), k.tx.y, k.sx.y), PICK3(vf(0.0f), k.tx.z, k.sx.z));
+  const v3 ez = mk3(PICK3(vf(0.0f), k.tz.x, k.sz.x), PICK3(k.az.y, k.tz.y, k.sz.y), PICK3(k.az.z, k.tz.z, k.sz.z));
+  const v3 ey = k.ay;
+  const v3 p_s = mk3(PICK3(k.pA.x, k.pT.x, k.pS.x), PICK3(k.pA.y, k.pT.y, k.pS.y), PICK3(k.pA.z, k.pT.z, k.pS.z));
+  const v3 ax = mk3(vsel(is0, 1.0f, 0.0f), vsel(is0, 0.0f, k.h.y), vsel(is0, 0.0f, k.h.z));
+  const float zc = (IRRL_S_M1 * IRRL_S_Z1 + IRRL_S_M2 * IRRL_S_Z2) / (IRRL_S_M1 + IRRL_S_M2);
+  const float d1 = IRRL_S_Z1 - zc, d2 = IRRL_S_Z2 - zc;
+  const float ISx = 0.000716f + IRRL_S_M1 * d1 * d1 + 0.000025f + IRRL_S_M2 * d2 * d2;
+  const float ISy = 0.000721f + IRRL_S_M1 * d1 * d1 + 0.000025f + IRRL_S_M2 * d2 * d2;
+  const float ISz = 0.000012f + 0.000025f;
+  const vf m_s = vsel(is3, 0.0f, PICK3(L.m.mA, L.m.mT, L.m.mS));
+  const vf live = vsel(is3, 0.0f, 1.0f);
+  const v3 com_s = mk3(PICK3(L.m.comA.x, L.m.comT.x, L.m.comS.x), PICK3(L.m.comA.y, L.m.comT.y, L.m.comS.y), PICK3(L.m.comA.z, L.m.comT.z, L.m.comS.z));
+  const vf Ix = live * PICK3(vf(0.000391f), vf(0.001724f), vf(ISx)), Iy = live * PICK3(vf(0.000739f), vf(0.001907f), vf(ISy));
+  const vf Iz = live * PICK3(vf(0.000488f), vf(0.000468f), vf(ISz)), Iyz = vsel(is1, -L.m.sy * 0.000228f, 0.0f);
+  const vf rotor = PICK3(vf(0.003708f), vf(0.003708f), vf(0.008966f));
+  v3 rc = com_s.x * ex + com_s.y * ey + com_s.z * ez;
+  v3 c = p_s + rc;
+  sym3 IB = rot_inertia_y0(ex, ey, ez, Ix, Iy, Iz, Iyz);
+  // composite (mass, first moment, inertia about the base origin) of the subtree hanging on joint `sub`
+  sym3 Io = shift_to_origin(IB, m_s, c);
+  vf mc = sub_suffix_sum(m_s);
+  v3 hc = mk3(sub_suffix_sum(m_s * c.x), sub_suffix_sum(m_s * c.y), sub_suffix_sum(m_s * c.z));
+  sym3 Ioc;
+  Ioc.xx = sub_suffix_sum(Io.xx); Ioc.xy = sub_suffix_sum(Io.xy); Ioc.xz = sub_suffix_sum(Io.xz);
+  Ioc.yy = sub_suffix_sum(Io.yy); Ioc.yz = sub_suffix_sum(Io.yz); Ioc.zz = sub_suffix_sum(Io.zz);
+  // CRBA column of joint `sub` (D) and its entries of C_l
+  v3 Pc = cross(ax, hc - mc * p_s);
+  v3 Lc = mul(Ioc, ax) - cross(hc, cross(ax, p_s));
+  vf Bs[6] = {Pc.x, Pc.y, Pc.z, Lc.x, Lc.y, Lc.z};
+  vf ck0 = (Lc.x - (k.pA.y * Pc.z - k.pA.z * Pc.y)) + vsel(is0, rotor, 0.0f);        // e_x . (L - pA x P)
+  vf ck1 = dot(k.h, Lc - cross(k.pT, Pc)) + vsel(is1, rotor, 0.0f);
+  vf ck2 = dot(k.h, Lc - cross(k.pS, Pc)) + vsel(sub == 2, rotor, 0.0f);
+  LegDyn D;
+  {
+    vf C00 = sub_bcast<0>(ck0), C01 = sub_bcast<1>(ck0), C02 = sub_bcast<2>(ck0), C11 = sub_bcast<1>(ck1), C12 = sub_bcast<2>(ck1), C22 = sub_bcast<2>(ck2);
+    vf a = C11 * C22 - C12 * C12, b = C02 * C12 - C01 * C22, cc = C01 * C12 - C02 * C11;
+    vf idet = v_rcp(C00 * a + C01 * b + C02 * cc);
+    D.Ci.xx = a * idet; D.Ci.xy = b * idet; D.Ci.xz = cc * idet;
+    D.Ci.yy = (C00 * C22 - C02 * C02) * idet; D.Ci.yz = (C01 * C02 - C00 * C12) * idet; D.Ci.zz = (C00 * C11 - C01 * C01) * idet;
+  }
+  // column `sub` of C^-1 (zero for the spare sub-lane) and of X = B C^-1
+  const vf ci0 = live * PICK3(D.Ci.xx, D.Ci.xy, D.Ci.xz), ci1 = live * PICK3(D.Ci.xy, D.Ci.yy, D.Ci.yz), ci2 = live * PICK3(D.Ci.xz, D.Ci.yz, D.Ci.zz);
+  vf Xs[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) Xs[i] = sub_bcast<0>(Bs[i]) * ci0 + sub_bcast<1>(Bs[i]) * ci1 + sub_bcast<2>(Bs[i]) * ci2;
+  // whole-robot composite -> base block A; Schur complement S = A - sum_legs sum_sub X[:,s] B[:,s]^T
+  vf mtot = L.m.m0 + sub_bcast<0>(legs_sum(mc));
+  v3 htot = L.m.m0 * L.m.com0 + mk3(sub_bcast<0>(legs_sum(hc.x)), sub_bcast<0>(legs_sum(hc.y)), sub_bcast<0>(legs_sum(hc.z)));
+  sym3 I0;
+  I0.xx = 0.016269f; I0.xy = 0.0f; I0.xz = 0.0f; I0.yy = 0.050813f; I0.yz = 0.0f; I0.zz = 0.060989f;
+  sym3 Io0 = shift_to_origin(I0, L.m.m0, L.m.com0);
+  sym3 Iot;
+  Iot.xx = Io0.xx + sub_bcast<0>(legs_sum(Ioc.xx)); Iot.xy = Io0.xy + sub_bcast<0>(legs_sum(Ioc.xy)); Iot.xz = Io0.xz + sub_bcast<0>(legs_sum(Ioc.xz));
+  Iot.yy = Io0.yy + sub_bcast<0>(legs_sum(Ioc.yy)); Iot.yz = Io0.yz + sub_bcast<0>(legs_sum(Ioc.yz)); Iot.zz = Io0.zz + sub_bcast<0>(legs_sum(Ioc.zz));
+  vf S[21];
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++) S[L6I(i, j)] = legs_sum(sub_sum(Xs[i] * Bs[j]));
+  {
+    vf A[21];
+#pragma unroll
+    for (int i = 0; i < 21; i++) A[i] = 0.0f;
+    A[L6I(0, 0)] = mtot; A[L6I(1, 1)] = mtot; A[L6I(2, 2)] = mtot;
+    A[L6I(3, 1)] = -htot.z; A[L6I(3, 2)] = htot.y;
+    A[L6I(4, 0)] = htot.z; A[L6I(4, 2)] = -htot.x;
+    A[L6I(5, 0)] = -htot.y; A[L6I(5, 1)] = htot.x;
+    A[L6I(3, 3)] = Iot.xx; A[L6I(4, 3)] = Iot.xy; A[L6I(4, 4)] = Iot.yy; A[L6I(5, 3)] = Iot.xz; A[L6I(5, 4)] = Iot.yz; A[L6I(5, 5)] = Iot.zz;
+#pragma unroll
+    for (int i = 0; i < 21; i++) S[i] = A[i] - S[i];
+  }
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    vf d = S[L6I(j, j)];
+#pragma unroll
+    for (int cidx = 0; cidx < j; cidx++) d -= D.L6[L6I(j, cidx)] * D.L6[L6I(j, cidx)];
+    vf inv = v_rsqrt(d);
+    D.L6[L6I(j, j)] = inv;
+#pragma unroll
+    for (int i = j + 1; i < 6; i++) {
+      vf v = S[L6I(i, j)];
+#pragma unroll
+      for (int cidx = 0; cidx < j; cidx++) v -= D.L6[L6I(i, cidx)] * D.L6[L6I(j, cidx)];
+      D.L6[L6I(i, j)] = v * inv;
+    }
+  }
+  // RNEA: kinematic recursion down the chain, advanced only as far as the own body (sub-lane s stops after body s)
+  v3 sq0 = mk3(L.qd[0], 0.0f, 0.0f);
+  v3 w = wB + sq0;
+  v3 al = mk3(0.0f, wB.z * L.qd[0], -wB.y * L.qd[0]);
+  v3 a = a0 + cross(wB, cross(wB, k.pA));
+  {
+    v3 sq1 = L.qd[1] * k.h, dT = k.pT - k.pA;
+    v3 w1 = w + sq1, al1 = al + cross(w, sq1), a1 = a + cross(al, dT) + cross(w, cross(w, dT));
+    v3 sq2 = L.qd[2] * k.h, dS = k.pS - k.pT;
+    v3 w2 = w1 + sq2, al2 = al1 + cross(w1, sq2), a2 = a1 + cross(al1, dS) + cross(w1, cross(w1, dS));
+    w = mk3(vsel(ge2, w2.x, vsel(ge1, w1.x, w.x)), vsel(ge2, w2.y, vsel(ge1, w1.y, w.y)), vsel(ge2, w2.z, vsel(ge1, w1.z, w.z)));
+    al = mk3(vsel(ge2, al2.x, vsel(ge1, al1.x, al.x)), vsel(ge2, al2.y, vsel(ge1, al1.y, al.y)), vsel(ge2, al2.z, vsel(ge1, al1.z, al.z)));
+    a = mk3(vsel(ge2, a2.x, vsel(ge1, a1.x, a.x)), vsel(ge2, a2.y, vsel(ge1, a1.y, a.y)), vsel(ge2, a2.z, vsel(ge1, a1.z, a.z)));
+  }
+  v3 f = m_s * (a + cross(al, rc) + cross(w, cross(w, rc)));
+  v3 n0 = mul(IB, al) + cross(w, mul(IB, w)) + cross(c, f);   // moment about the BASE origin: n + (p_s + rc) x f
+  v3 F = mk3(sub_suffix_sum(f.x), sub_suffix_sum(f.y), sub_suffix_sum(f.z));
+  v3 N0 = mk3(sub_suffix_sum(n0.x), sub_suffix_sum(n0.y), sub_suffix_sum(n0.z));
+  vf b_s = dot(ax, N0 - cross(p_s, F));                         // joint bias = axis . moment about the joint origin
+  {
+    v3 fb = L.m.m0 * (a0 + cross(wB, cross(wB, L.m.com0)));
+    v3 nb = cross(wB, mul(I0, wB)) + cross(L.m.com0, fb);
+    D.bias_b[0] = fb.x + sub_bcast<0>(legs_sum(F.x)); D.bias_b[1] = fb.y + sub_bcast<0>(legs_sum(F.y)); D.bias_b[2] = fb.z + sub_bcast<0>(legs_sum(F.z));
+    D.bias_b[3] = nb.x + sub_bcast<0>(legs_sum(N0.x)); D.bias_b[4] = nb.y + sub_bcast<0>(legs_sum(N0.y)); D.bias_b[5] = nb.z + sub_bcast<0>(legs_sum(N0.z));
+  }
+  // free velocity u_free = u + dt M^-1 (tau - damping qd - b)
+  vf rl_s = live * (tau_s - 0.01f * qd_s - b_s);
+  vf xb[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) xb[i] = -D.bias_b[i] - legs_sum(sub_sum(Xs[i] * rl_s));
+  l6_fwd(D.L6, xb);
+  l6_bwd(D.L6, xb);
+  vf xl_s = ci0 * sub_bcast<0>(rl_s) + ci1 * sub_bcast<1>(rl_s) + ci2 * sub_bcast<2>(rl_s);   // row `sub` of C^-1 (symmetric)
+#pragma unroll
+  for (int i = 0; i < 6; i++) xl_s -= Xs[i] * xb[i];
+  vf ub[6];
+  ub[0] = vB.x + dt * xb[0]; ub[1] = vB.y + dt * xb[1]; ub[2] = vB.z + dt * xb[2];
+  ub[3] = wB.x + dt * xb[3]; ub[4] = wB.y + dt * xb[4]; ub[5] = wB.z + dt * xb[5];
+  vf ul_s = qd_s + dt * xl_s;
+
+  // ---- contact: toe sphere against the ground ----
+  vf gap = (L.pos.z + dot(R.r2, k.ptoe) - hgt) * nwz - IRRL_TOE_RADIUS;
+  vm active = gap <= 0.0f;
+  if (wave_any(active)) {
+    v3 x = k.ptoe - IRRL_TOE_RADIUS * nB;
+    // (D) column `sub` of the leg Jacobian, then all of it (R)
+    v3 jc = live * cross(ax, x - p_s);
+    vf Jl[3][3];
+#pragma unroll
+    for (int kk = 0; kk < 3; kk++) {
+      Jl[0][kk] = (kk == 0) ? sub_bcast<0>(jc.x) : ((kk == 1) ? sub_bcast<1>(jc.x) : sub_bcast<2>(jc.x));
+      Jl[1][kk] = (kk == 0) ? sub_bcast<0>(jc.y) : ((kk == 1) ? sub_bcast<1>(jc.y) : sub_bcast<2>(jc.y));
+      Jl[2][kk] = (kk == 0) ? sub_bcast<0>(jc.z) : ((kk == 1) ? sub_bcast<1>(jc.z) : sub_bcast<2>(jc.z));
+    }
+    // row r = sub of every contact operator (sub-lanes 2 and 3 both take row 2; the spare lane's results are never read)
+    const vf jl0 = PICK3(Jl[0][0], Jl[1][0], Jl[2][0]), jl1 = PICK3(Jl[0][1], Jl[1][1], Jl[2][1]), jl2 = PICK3(Jl[0][2], Jl[1][2], Jl[2][2]);
+    // base columns [1 | -[x]x], row r
+    vf jb[6];
+    jb[0] = vsel(is0, 1.0f, 0.0f); jb[1] = vsel(is1, 1.0f, 0.0f); jb[2] = vsel(ge2, 1.0f, 0.0f);
+    jb[3] = PICK3(vf(0.0f), -x.z, x.y); jb[4] = PICK3(x.z, vf(0.0f), -x.x); jb[5] = PICK3(-x.y, x.x, vf(0.0f));
+    // K row = Jb row - Jl row . D, Y row = L^-1 K row
+    vf Yr[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) Yr[i] = jb[i] - (jl0 * sub_bcast<0>(Xs[i]) + jl1 * sub_bcast<1>(Xs[i]) + jl2 * sub_bcast<2>(Xs[i]));
+    l6_fwd(D.L6, Yr);
+    // JC row = Jl row . C^-1
+    vf jc0 = jl0 * D.Ci.xx + jl1 * D.Ci.xy + jl2 * D.Ci.xz, jc1 = jl0 * D.Ci.xy + jl1 * D.Ci.yy + jl2 * D.Ci.yz, jc2 = jl0 * D.Ci.xz + jl1 * D.Ci.yz + jl2 * D.Ci.zz;
+    // all three Y rows in every sub-lane
+    vf Ya[3][6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { Ya[0][i] = sub_bcast<0>(Yr[i]); Ya[1][i] = sub_bcast<1>(Yr[i]); Ya[2][i] = sub_bcast<2>(Yr[i]); }
+    // own Delassus block, row r: Y_r . Y_c + JC_r . Jl_c
+    vf gr[3];
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++) {
+      vf acc = jc0 * Jl[cc][0] + jc1 * Jl[cc][1] + jc2 * Jl[cc][2];
+#pragma unroll
+      for (int i = 0; i < 6; i++) acc += Yr[i] * Ya[cc][i];
+      gr[cc] = acc;
+    }
+    sym3 G;
+    G.xx = sub_bcast<0>(gr[0]); G.xy = sub_bcast<0>(gr[1]); G.xz = sub_bcast<0>(gr[2]);
+    G.yy = sub_bcast<1>(gr[1]); G.yz = sub_bcast<1>(gr[2]); G.zz = sub_bcast<2>(gr[2]);
+    ContactBlock CB = make_contact_block(G, nB);
+    // contact-point velocity rows: before the step (restitution) and free
+    vf ul0 = sub_bcast<0>(ul_s), ul1 = sub_bcast<1>(ul_s), ul2 = sub_bcast<2>(ul_s);
+    vf vpre_r = jl0 * L.qd[0] + jl1 * L.qd[1] + jl2 * L.qd[2] + jb[0] * vB.x + jb[1] * vB.y + jb[2] * vB.z + jb[3] * wB.x + jb[4] * wB.y + jb[5] * wB.z;
+    vf cfree_r = jl0 * ul0 + jl1 * ul1 + jl2 * ul2;
+#pragma unroll
+    for (int i = 0; i < 6; i++) cfree_r += jb[i] * ub[i];
+    const vf nB_r = live * PICK3(nB.x, nB.y, nB.z);
+    vf vn = sub_sum(vpre_r * nB_r);
+    vf vstar = vsel(vn < -L.m.rest_thr, -L.m.rest * vn, 0.0f);
+    // warm start (world -> base components); zero unless the foot was already in the contact list
+    v3 lam = rot_tmul(R, mk3(L.lamw[0], L.lamw[1], L.lamw[2]));
+    vm warm = active & (L.in_contact != 0);
+    lam.x = vsel(warm, lam.x, 0.0f); lam.y = vsel(warm, lam.y, 0.0f); lam.z = vsel(warm, lam.z, 0.0f);
+    // partner blocks, row r: G_{l,p} = Y_l Y_p^T for the three other legs, reached by row rotations
+    vf gx1[3], gx2[3], gx3[3];
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++) {
+      vf a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 6; i++) { a1 += Yr[i] * legs_rot<1>(Ya[cc][i]); a2 += Yr[i] * legs_rot<2>(Ya[cc][i]); a3 += Yr[i] * legs_rot<3>(Ya[cc][i]); }
+      gx1[cc] = a1; gx2[cc] = a2; gx3[cc] = a3;
+    }
+    // rank of this contact among the robot's active contacts (leg order FR,FL,HR,HL)
+    vi leg = leg_id();
+    vi act_i = vsel_i(active, 1, 0);
+    vi a0i = legs_bcast_i<0>(act_i), a1i = legs_bcast_i<1>(act_i), a2i = legs_bcast_i<2>(act_i), a3i = legs_bcast_i<3>(act_i);
+    vi rank = vsel_i(leg == 0, 0, vsel_i(leg == 1, a0i, vsel_i(leg == 2, a0i + a1i, a0i + a1i + a2i)));
+    int nrank = wave_max_small(a0i + a1i + a2i + a3i);
+    const float tol2 = P.contact_tol * P.contact_tol;
+    for (int it = 0; it < P.contact_iters; it++) {
+      vf d2 = 0.0f;
+      for (int rk = 0; rk < nrank; rk++) {
+        vf cvr = cfree_r;
+        {
+          vf bx = legs_rot<1>(lam.x), by = legs_rot<1>(lam.y), bz = legs_rot<1>(lam.z);
+          cvr += gx1[0] * bx + gx1[1] * by + gx1[2] * bz;
+        }
+        {
+          vf bx = legs_rot<2>(lam.x), by = legs_rot<2>(lam.y), bz = legs_rot<2>(lam.z);
+          cvr += gx2[0] * bx + gx2[1] * by + gx2[2] * bz;
+        }
+        {
+          vf bx = legs_rot<3>(lam.x), by = legs_rot<3>(lam.y), bz = legs_rot<3>(lam.z);
+          cvr += gx3[0] * bx + gx3[1] * by + gx3[2] * bz;
+        }
+        v3 cv = mk3(sub_bcast<0>(cvr), sub_bcast<1>(cvr), sub_bcast<2>(cvr));
+        v3 ln = solve_contact(CB, cv, nB, vstar, L.m.mu);
+        vm commit = active & (rank == rk);
+        v3 dl = mk3(vsel(commit, ln.x - lam.x, 0.0f), vsel(commit, ln.y - lam.y, 0.0f), vsel(commit, ln.z - lam.z, 0.0f));
+        lam = lam + dl;
+        d2 += dot(dl, dl);
+      }
+      if (tol2 > 0.0f) {
+        vf l2 = legs_sum(vsel(active, dot(lam, lam), 0.0f));
+        vm unconverged = legs_sum(d2) > tol2 * l2 + 1e-20f;
+        if (!wave_any(unconverged)) break;
+      }
+    }
+    lam.x = vsel(active, lam.x, 0.0f); lam.y = vsel(active, lam.y, 0.0f); lam.z = vsel(active, lam.z, 0.0f);
+    // z = sum_legs sum_rows Y_r lam_r drives the base; the leg gets C^-1 Jl^T lam - D xb
+    const vf lam_r = live * PICK3(lam.x, lam.y, lam.z);
+    vf xbc[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) xbc[i] = legs_sum(sub_sum(Yr[i] * lam_r));
+    l6_bwd(D.L6, xbc);
+#pragma unroll
+    for (int i = 0; i < 6; i++) ub[i] += xbc[i];
+    {
+      vf v0 = sub_sum(jc0 * lam_r), v1 = sub_sum(jc1 * lam_r), v2 = sub_sum(jc2 * lam_r);   // columns of JC^T lam
+      vf v = PICK3(v0, v1, v2);
+#pragma unroll
+      for (int i = 0; i < 6; i++) v -= Xs[i] * xbc[i];
+      ul_s += v;
+    }
+    v3 lw = rot_mul(R, lam);
+    L.lamw[0] = lw.x; L.lamw[1] = lw.y; L.lamw[2] = lw.z;
+  } else {
+    L.lamw[0] = 0.0f; L.lamw[1] = 0.0f; L.lamw[2] = 0.0f;
+  }
+  L.in_contact = vsel_i(active, 1, 0);
+  // back to world-frame gv, then positions (semi-implicit Euler); joint `sub` integrates in its own lane
+  L.vw = rot_mul(R, mk3(ub[0], ub[1], ub[2]));
+  L.ww = rot_mul(R, mk3(ub[3], ub[4], ub[5]));
+  {
+    vf qn = q_s + dt * ul_s;
+    L.q[0] = sub_bcast<0>(qn); L.q[1] = sub_bcast<1>(qn); L.q[2] = sub_bcast<2>(qn);
+    L.qd[0] = sub_bcast<0>(ul_s); L.qd[1] = sub_bcast<1>(ul_s); L.qd[2] = sub_bcast<2>(ul_s);
+  }
+  L.pos = L.pos + dt * L.vw;
+  {
+    vf hx = 0.5f * dt * L.ww.x, hy = 0.5f * dt * L.ww.y, hz = 0.5f * dt * L.ww.z;
+    vf w1 = L.qw - hx * L.qx - hy * L.qy - hz * L.qz;
+    vf x1 = L.qx + hx * L.qw + hy * L.qz - hz * L.qy;
+    vf y1 = L.qy - hx * L.qz + hy * L.qw + hz * L.qx;
+    vf z1 = L.qz + hx * L.qy - hy * L.qx + hz * L.qw;
+    vf inv = v_rsqrt(w1 * w1 + x1 * x1 + y1 * y1 + z1 * z1);
+    L.qw = w1 * inv; L.qx = x1 * inv; L.qy = y1 * inv; L.qz = z1 * inv;
+  }
+#undef PICK3
+}
+#else
 IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
   const float dt = P.sim_dt;
   // PD law, 1 % blend with the normalised torque_last, speed-dependent clamp
@@ -673,7 +998,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
 #define IRRL_GX_BLOCK(LP)                                                                                      \
       {                                                                                                        \
         vm other = leg != LP; /* an inactive partner carries lambda = 0, only the own block must vanish */     \
-        _Pragma("unroll") for (int c = 0; c < 3; c++) _Pragma("unroll") for (int i = 0; i < 6; i++) Ym[c][i] = quad_bcast<LP>(Y[c][i]); \
+        _Pragma("unroll") for (int c = 0; c < 3; c++) _Pragma("unroll") for (int i = 0; i < 6; i++) Ym[c][i] = legs_bcast<LP>(Y[c][i]); \
         _Pragma("unroll") for (int r = 0; r < 3; r++) _Pragma("unroll") for (int c = 0; c < 3; c++) {          \
           vf acc = Y[r][0] * Ym[c][0];                                                                         \
           _Pragma("unroll") for (int i = 1; i < 6; i++) acc += Y[r][i] * Ym[c][i];                             \
@@ -685,9 +1010,9 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     }
     // rank of this contact among the robot's active contacts (leg order FR,FL,HR,HL)
     vi act_i = vsel_i(active, 1, 0);
-    vi a0i = quad_bcast_i<0>(act_i), a1i = quad_bcast_i<1>(act_i), a2i = quad_bcast_i<2>(act_i);
+    vi a0i = legs_bcast_i<0>(act_i), a1i = legs_bcast_i<1>(act_i), a2i = legs_bcast_i<2>(act_i);
     vi rank = vsel_i(leg == 0, 0, vsel_i(leg == 1, a0i, vsel_i(leg == 2, a0i + a1i, a0i + a1i + a2i)));
-    int nrank = wave_max_small(quad_sum_i(act_i));
+    int nrank = wave_max_small(legs_sum_i(act_i));
     const float tol2 = P.contact_tol * P.contact_tol;
     for (int it = 0; it < P.contact_iters; it++) {
       vf d2 = 0.0f;
@@ -696,7 +1021,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
         v3 cv = mk3(cfree[0], cfree[1], cfree[2]);
 #define IRRL_GX_APPLY(LP)                                                                       \
         {                                                                                       \
-          vf bx = quad_bcast<LP>(lam.x), by = quad_bcast<LP>(lam.y), bz = quad_bcast<LP>(lam.z); \
+          vf bx = legs_bcast<LP>(lam.x), by = legs_bcast<LP>(lam.y), bz = legs_bcast<LP>(lam.z); \
           cv.x += Gx[LP][0][0] * bx + Gx[LP][0][1] * by + Gx[LP][0][2] * bz;                    \
           cv.y += Gx[LP][1][0] * bx + Gx[LP][1][1] * by + Gx[LP][1][2] * bz;                    \
           cv.z += Gx[LP][2][0] * bx + Gx[LP][2][1] * by + Gx[LP][2][2] * bz;                    \
@@ -711,8 +1036,8 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
       }
       // build-defined early exit: every robot of the wave has sum |dlam|^2 <= tol^2 sum |lam|^2
       if (tol2 > 0.0f) {
-        vf l2 = quad_sum(vsel(active, dot(lam, lam), 0.0f));
-        vm unconverged = quad_sum(d2) > tol2 * l2 + 1e-20f;
+        vf l2 = legs_sum(vsel(active, dot(lam, lam), 0.0f));
+        vm unconverged = legs_sum(d2) > tol2 * l2 + 1e-20f;
         if (!wave_any(unconverged)) break;
       }
     }
@@ -720,7 +1045,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     lam.x = vsel(active, lam.x, 0.0f); lam.y = vsel(active, lam.y, 0.0f); lam.z = vsel(active, lam.z, 0.0f);
     vf z[6];
 #pragma unroll
-    for (int i = 0; i < 6; i++) z[i] = quad_sum(Y[0][i] * lam.x + Y[1][i] * lam.y + Y[2][i] * lam.z);
+    for (int i = 0; i < 6; i++) z[i] = legs_sum(Y[0][i] * lam.x + Y[1][i] * lam.y + Y[2][i] * lam.z);
     // velocity update: base part L^-T z, leg part C^-1 Jl^T lam - D xb
     vf xbc[6];
 #pragma unroll
@@ -758,6 +1083,8 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
   }
 }
 
+#endif  // IRRL_L16
+
 // ---------------------------------------------------------------------------------------------
 // task logic
 // ---------------------------------------------------------------------------------------------
@@ -791,23 +1118,23 @@ IRRL_DEV void gait_leg_pass(const EnvParams &P, const EnvLane &L, vf t_eval, vf 
   // chain the stale values: leg 0 falls back to prev[], leg i to leg i-1's final value
   vf f0 = vsel(ok0, th0, prev[0]), f1 = vsel(ok1, th1, prev[1]), f2 = vsel(ok2, th2, prev[2]);
   {
-    vf p0 = quad_bcast<0>(f0), p1 = quad_bcast<0>(f1), p2 = quad_bcast<0>(f2);
+    vf p0 = legs_bcast<0>(f0), p1 = legs_bcast<0>(f1), p2 = legs_bcast<0>(f2);
     vm me = leg == 1;
     f0 = vsel(me & !ok0, p0, f0); f1 = vsel(me & !ok1, p1, f1); f2 = vsel(me & !ok2, p2, f2);
   }
   {
-    vf p0 = quad_bcast<1>(f0), p1 = quad_bcast<1>(f1), p2 = quad_bcast<1>(f2);
+    vf p0 = legs_bcast<1>(f0), p1 = legs_bcast<1>(f1), p2 = legs_bcast<1>(f2);
     vm me = leg == 2;
     f0 = vsel(me & !ok0, p0, f0); f1 = vsel(me & !ok1, p1, f1); f2 = vsel(me & !ok2, p2, f2);
   }
   {
-    vf p0 = quad_bcast<2>(f0), p1 = quad_bcast<2>(f1), p2 = quad_bcast<2>(f2);
+    vf p0 = legs_bcast<2>(f0), p1 = legs_bcast<2>(f1), p2 = legs_bcast<2>(f2);
     vm me = leg == 3;
     f0 = vsel(me & !ok0, p0, f0); f1 = vsel(me & !ok1, p1, f1); f2 = vsel(me & !ok2, p2, f2);
   }
   th_out[0] = f0; th_out[1] = f1; th_out[2] = f2;
   // temp[] leaving leg 3 (input of the next pass)
-  prev[0] = quad_bcast<3>(f0); prev[1] = quad_bcast<3>(f1); prev[2] = quad_bcast<3>(f2);
+  prev[0] = legs_bcast<3>(f0); prev[1] = legs_bcast<3>(f1); prev[2] = legs_bcast<3>(f2);
   toe_out = toe;
 }
 IRRL_DEV void gait_generator_manual(const EnvParams &P, EnvLane &L, bool is_first) {
@@ -879,20 +1206,20 @@ IRRL_DEV void update_observation(const EnvParams &P, EnvLane &L, vu env) {
   vf nj[3] = {0.0f, 0.0f, 0.0f}, nv[3] = {0.0f, 0.0f, 0.0f}, nn[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
   if (P.obs_noise != 0.0f) {
     vf u[16];
-    quad_rng16(P.seed, env, L.episode, to_u(L.frame), IRRL_P_OBS_JOINT, u);
+    legs_rng16(P.seed, env, L.episode, to_u(L.frame), IRRL_P_OBS_JOINT, u);
 #pragma unroll
     for (int k = 0; k < 3; k++) nj[k] = (2.0f * pick_leg(u, leg, k) - 1.0f) * 0.002f * P.obs_noise;
-    quad_rng16(P.seed, env, L.episode, to_u(L.frame), IRRL_P_OBS_JVEL, u);
+    legs_rng16(P.seed, env, L.episode, to_u(L.frame), IRRL_P_OBS_JVEL, u);
 #pragma unroll
     for (int k = 0; k < 3; k++) nv[k] = (2.0f * pick_leg(u, leg, k) - 1.0f) * 0.8f * P.obs_noise;
-    quad_rng16(P.seed, env, L.episode, to_u(L.frame), IRRL_P_OBS_NORMAL, u);
+    legs_rng16(P.seed, env, L.episode, to_u(L.frame), IRRL_P_OBS_NORMAL, u);
     // Box-Muller: normal k from uniforms (2k, 2k+1); lane l evaluates normals l and 4 + (l & 1)
     vf ua = pick4(u[0], u[2], u[4], u[6], leg), ub = pick4(u[1], u[3], u[5], u[7], leg);
     vf uc = vsel((leg & 1) == 0, u[8], u[10]), ud = vsel((leg & 1) == 0, u[9], u[11]);
     vf na = v_sqrt(-2.0f * v_log(1.0f - ua)) * v_cos(6.283185307179586f * ub);
     vf nb = v_sqrt(-2.0f * v_log(1.0f - uc)) * v_cos(6.283185307179586f * ud);
-    nn[0] = quad_bcast<0>(na); nn[1] = quad_bcast<1>(na); nn[2] = quad_bcast<2>(na); nn[3] = quad_bcast<3>(na);
-    nn[4] = quad_bcast<0>(nb); nn[5] = quad_bcast<1>(nb);
+    nn[0] = legs_bcast<0>(na); nn[1] = legs_bcast<1>(na); nn[2] = legs_bcast<2>(na); nn[3] = legs_bcast<3>(na);
+    nn[4] = legs_bcast<0>(nb); nn[5] = legs_bcast<1>(nb);
   }
 #pragma unroll
   for (int k = 0; k < 3; k++) { L.ob_q[k] = nj[k] + L.q[k]; L.ob_qd[k] = nv[k] + L.qd[k]; }
@@ -924,7 +1251,7 @@ IRRL_DEV vf reward_update(const EnvParams &P, EnvLane &L, vf extra[6]) {
   vf force_norm = vsel(L.in_contact != 0, v_sqrt(L.lamw[0] * L.lamw[0] + L.lamw[1] * L.lamw[1] + L.lamw[2] * L.lamw[2]) / P.control_dt, 0.0f);
   // per-leg partial sums, summed FR,FL,HR,HL by the quad reduction
   vf d0 = xB.x - L.eer[0], d1 = xB.y - L.eer[1], d2 = xB.z - L.eer[2];
-  vf ee2 = quad_sum(d0 * d0 + d1 * d1 + d2 * d2);
+  vf ee2 = legs_sum(d0 * d0 + d1 * d1 + d2 * d2);
   vf j2 = 0.0f, jd2 = 0.0f, tn2 = 0.0f, td2 = 0.0f, tn[3];
 #pragma unroll
   for (int k = 0; k < 3; k++) {
@@ -934,7 +1261,7 @@ IRRL_DEV vf reward_update(const EnvParams &P, EnvLane &L, vf extra[6]) {
     tn2 += tn[k] * tn[k];
     vf c = tn[k] - L.tql[k]; td2 += c * c;
   }
-  j2 = quad_sum(j2); jd2 = quad_sum(jd2); tn2 = quad_sum(tn2); td2 = quad_sum(td2);
+  j2 = legs_sum(j2); jd2 = legs_sum(jd2); tn2 = legs_sum(tn2); td2 = legs_sum(td2);
 #pragma unroll
   for (int k = 0; k < 3; k++) L.tql[k] = tn[k];  // ENV:1515 keeps the NORMALISED torque
   vf EE = P.c_ee * v_exp(-40.0f * ee2);
@@ -952,7 +1279,7 @@ IRRL_DEV vf reward_update(const EnvParams &P, EnvLane &L, vf extra[6]) {
   vf rp = v_fmod(env_time(P, L) + phase_l * P.period, P.period) / P.period;
   vf cr = 4.0f * vel_norm * vel_norm * smooth_function(rp, 2.0f, P.lam) +
           2.0f * (force_norm / 12.5f) * (force_norm / 12.5f) * smooth_function2(rp, 2.0f, P.lam);
-  vf CR = P.c_contact * v_exp(-2.0f * quad_sum(cr));
+  vf CR = P.c_contact * v_exp(-2.0f * legs_sum(cr));
   extra[0] = EE; extra[1] = BC; extra[2] = L.pos.z; extra[3] = BA; extra[4] = JR; extra[5] = VR;
   return EE + BC + JR + JD + VR + BA + TR + CR;  // ENV:1546-1547 order
 }
@@ -984,8 +1311,8 @@ IRRL_DEV void reset_lane(const EnvParams &P, EnvLane &L, vu env) {
       for (int k = 0; k < 3; k++) { nj[k] = 2.0f * r.u0 - 1.0f; nv[k] = 2.0f * r.u1 - 1.0f; }
     } else {
       vf ua[16], ub[16];
-      quad_rng16(P.seed, env, L.episode, 0u, IRRL_P_RESET_JOINT_IND, ua);
-      quad_rng16(P.seed, env, L.episode, 0u, IRRL_P_RESET_JOINT_IND + 3u, ub);
+      legs_rng16(P.seed, env, L.episode, 0u, IRRL_P_RESET_JOINT_IND, ua);
+      legs_rng16(P.seed, env, L.episode, 0u, IRRL_P_RESET_JOINT_IND + 3u, ub);
       // 24 consecutive uniforms: joints 0..11 then rates 0..11; the second call starts at element 12
 #pragma unroll
       for (int k = 0; k < 3; k++) { nj[k] = 2.0f * pick_leg(ua, leg, k) - 1.0f; nv[k] = 2.0f * pick_leg(ub, leg, k) - 1.0f; }
@@ -1194,7 +1521,7 @@ IRRL_DEV void step_body(const EnvParams &P, const EnvState &S, vi env, vi leg, v
         an[0] = an[1] = an[2] = 2.0f * r.u0 - 1.0f;
       } else {
         vf u[16];
-        quad_rng16(P.seed, envu, L.episode, to_u(L.frame), IRRL_P_ACTION_NOISE, u);
+        legs_rng16(P.seed, envu, L.episode, to_u(L.frame), IRRL_P_ACTION_NOISE, u);
 #pragma unroll
         for (int k = 0; k < 3; k++) an[k] = 2.0f * pick_leg(u, leg, k) - 1.0f;
       }

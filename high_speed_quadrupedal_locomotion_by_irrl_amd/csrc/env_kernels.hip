@@ -3,15 +3,35 @@
 // At N = 4096 that is 256 workgroups -> one wave on each of the 256 CUs; the kernel keeps the whole
 // robot state in VGPRs across the 8 substeps (no LDS, no scratch), so __launch_bounds__(64, 1) lets the
 // allocator use the full 512-register budget of a SIMD that hosts a single wave.
+#ifndef IRRL_LANES_PER_ROBOT
+#define IRRL_LANES_PER_ROBOT 16
+#endif
+#if IRRL_LANES_PER_ROBOT == 16
+#include "lanes_hip16.hpp"
+#define IRRL_ROBOTS_PER_WAVE 4
+#else
 #include "lanes_hip.hpp"
+#define IRRL_ROBOTS_PER_WAVE 16
+#endif
 #include "env_core.hpp"
 
+// env_: robot of this lane; leg_: its leg; valid_: this lane owns the stores of (robot, leg) -- with 16 lanes per robot
+// that is sub-lane 0 of each quad.  Idle rows shadow the last robot with their stores masked.
+#if IRRL_LANES_PER_ROBOT == 16
+#define IRRL_LANE_PROLOGUE                                       \
+  const int lane_ = (int)threadIdx.x;                            \
+  int env_ = (int)blockIdx.x * 4 + (lane_ >> 4);                 \
+  const int leg_ = (lane_ >> 2) & 3;                             \
+  const bool valid_ = (env_ < P.n_envs) && ((lane_ & 3) == 0);   \
+  if (env_ >= P.n_envs) env_ = P.n_envs - 1;
+#else
 #define IRRL_LANE_PROLOGUE                                     \
   const int lane_ = (int)threadIdx.x;                          \
   int env_ = (int)blockIdx.x * 16 + (lane_ >> 2);              \
   const int leg_ = lane_ & 3;                                  \
   const bool valid_ = env_ < P.n_envs;                         \
   if (!valid_) env_ = P.n_envs - 1; /* idle quads shadow the last robot; their stores are masked */
+#endif
 
 extern "C" {
 

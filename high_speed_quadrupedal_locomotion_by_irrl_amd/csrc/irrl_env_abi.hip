@@ -50,7 +50,7 @@ struct irrl_env {
 static const char *const kExtraNames[IRRL_EXTRA_DIM] = {"EndEffectorReward(0.15)", "Height_Keep_Reward(0.1)", "base height",
                                                         "Balance_Keep_Reward(0.1)", "JointReward(0.65)", "VelocityReward(0.2)"};
 
-static inline dim3 quad_grid(int n) { return dim3((unsigned)((n + 15) / 16)); }
+static inline dim3 quad_grid(int n) { return dim3((unsigned)((n + IRRL_ROBOTS_PER_WAVE - 1) / IRRL_ROBOTS_PER_WAVE)); }
 
 extern "C" {
 

@@ -1,19 +1,19 @@
-// lanes_hip.hpp -- lane primitives for gfx950 (CDNA4), wave64.
+// lanes_hip16.hpp -- lane primitives for gfx950 (CDNA4), wave64, SIXTEEN LANES PER ROBOT.
 //
-// Mapping used by every env kernel: ONE DPP QUAD PER ROBOT, ONE LEG PER LANE.
-//   lane = threadIdx.x & 63, leg = lane & 3 (FR, FL, HR, HL), env = blockIdx.x * 16 + (lane >> 2).
-// The four legs of a robot only couple through the floating base, so every cross-lane exchange of
-// the dynamics is a reduction or a broadcast inside a quad -- exactly what DPP quad_perm does in the
-// VALU operand path (no LDS, no ds_bpermute).  A wave carries 16 robots.
-//
-// env_core.hpp is written against the names defined here (vf/vi/vu/vm + helpers) so that the very
-// same algorithm source can also be instantiated by the host-side lane emulation under
-// tests/host_emulation (a debugging aid for the no-GPU build container; never part of the product).
+// Mapping: one DPP ROW (16 lanes) per robot, one DPP QUAD per leg, the lane inside the quad ("sub-lane") owns
+// body / joint s of that leg (0 abad, 1 thigh, 2 shank+toe, 3 spare):
+//   lane = threadIdx.x & 63, env = blockIdx.x * 4 + (lane >> 4), leg = (lane >> 2) & 3, sub = lane & 3.
+// A wave carries 4 robots, so 4096 robots are 1024 waves -- one on every SIMD of the 256 CUs (the 4-lanes-per-robot
+// layout of lanes_hip.hpp left three SIMDs of every CU idle at that batch size; the step kernel is bound by the
+// single-wave issue rate, so spreading a robot over more lanes is what shortens a step).
+// Exchanges: inside a leg -> quad_perm DPP (sum, broadcast, suffix sum over bodies); between legs -> row_ror:4/8/12
+// rotations and row_newbcast; nothing touches LDS.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #define IRRL_DEV __device__ __forceinline__
+#define IRRL_L16 1
 
 typedef float vf;
 typedef int32_t vi;
@@ -22,38 +22,32 @@ typedef bool vm;
 
 namespace lanes {
 
-IRRL_DEV vi leg_id() { return (vi)(threadIdx.x & 3u); }
+IRRL_DEV vi leg_id() { return (vi)((threadIdx.x >> 2) & 3u); }
+IRRL_DEV vi sub_id() { return (vi)(threadIdx.x & 3u); }
 
-// ---- DPP quad primitives ----
+// every source lane of the controls used here is valid, so old = 0 / bound_ctrl:1 is exact and lets the DPP-combine
+// pass fold the move into the consuming VALU instruction
 template <int CTRL>
-IRRL_DEV float dpp_quad(float x) {
-  // old = 0 with bound_ctrl:1 (every source lane of a quad_perm is valid, so `old` is never used): this form lets the
-  // DPP-combine pass fold the move into the consuming VALU op (v_add_f32_dpp, v_mul_f32_dpp, v_fmac_f32_dpp ...)
+IRRL_DEV float dpp_f(float x) {
   int xi = __builtin_bit_cast(int, x);
   int r = __builtin_amdgcn_update_dpp(0, xi, CTRL, 0xF, 0xF, true);
   return __builtin_bit_cast(float, r);
 }
 template <int CTRL>
-IRRL_DEV int dpp_quad_i(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true); }
+IRRL_DEV int dpp_i(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true); }
 
-// layout-neutral names used by env_core.hpp: legs_sum = sum over the robot's four legs (result in every lane),
-// legs_bcast<K> = value held by leg K.  In this layout the four legs are the four lanes of a DPP quad.
-// (quad_perm [1,0,3,2] then [2,3,0,1])
-IRRL_DEV vf legs_sum(vf x) {
-  x += dpp_quad<0xB1>(x);
-  x += dpp_quad<0x4E>(x);
-  return x;
-}
-IRRL_DEV vi legs_sum_i(vi x) {
-  x += dpp_quad_i<0xB1>(x);
-  x += dpp_quad_i<0x4E>(x);
-  return x;
-}
-// value of lane K of the quad in every lane (quad_perm [K,K,K,K]); K is a compile-time constant
-template <int K>
-IRRL_DEV vf legs_bcast(vf x) { return dpp_quad<K * 0x55>(x); }
-template <int K>
-IRRL_DEV vi legs_bcast_i(vi x) { return dpp_quad_i<K * 0x55>(x); }
+// ---- between legs (same sub-lane of the other quads of the row) ----
+IRRL_DEV vf legs_sum(vf x) { x += dpp_f<0x124>(x); x += dpp_f<0x128>(x); return x; }       // row_ror:4, row_ror:8
+IRRL_DEV vi legs_sum_i(vi x) { x += dpp_i<0x124>(x); x += dpp_i<0x128>(x); return x; }
+template <int K> IRRL_DEV vf legs_bcast(vf x) { return dpp_f<0x150 + 4 * K>(x); }          // row_newbcast:4K (sub-lane 0 of leg K)
+template <int K> IRRL_DEV vi legs_bcast_i(vi x) { return dpp_i<0x150 + 4 * K>(x); }
+template <int D> IRRL_DEV vf legs_rot(vf x) { return dpp_f<0x120 + 4 * D>(x); }            // the leg D quads away (direction immaterial)
+// ---- inside a leg (the four sub-lanes of the quad) ----
+IRRL_DEV vf sub_sum(vf x) { x += dpp_f<0xB1>(x); x += dpp_f<0x4E>(x); return x; }          // quad_perm [1,0,3,2], [2,3,0,1]
+template <int K> IRRL_DEV vf sub_bcast(vf x) { return dpp_f<K * 0x55>(x); }                 // quad_perm [K,K,K,K]
+template <int K> IRRL_DEV vi sub_bcast_i(vi x) { return dpp_i<K * 0x55>(x); }
+// inclusive suffix sum over the sub-lanes, x_s + ... + x_3; REQUIRES x_3 == 0: quad_perm [1,2,3,3] then [2,3,3,3]
+IRRL_DEV vf sub_suffix_sum(vf x) { x += dpp_f<0xF9>(x); x += dpp_f<0xFE>(x); return x; }
 
 // ---- masks / selects ----
 IRRL_DEV vf vsel(vm m, vf a, vf b) { return m ? a : b; }

@@ -8,25 +8,24 @@ import yaml
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "..", "..", "high_speed_quadrupedal_locomotion_by_irrl_amd", "csrc")
-_LIB = None
+_LIB = {}
 STATE_DIM = 288
 
 
-def build():
-    out = os.path.join(_HERE, "_build", "libirrl_emu.so")
+def build(width=4):
+    out = os.path.join(_HERE, "_build", "libirrl_emu%d.so" % width)
     srcs = [os.path.join(_HERE, f) for f in ("emu_main.cpp", "lanes_cpu.hpp")] + \
            [os.path.join(_CSRC, f) for f in ("env_core.hpp", "env_params.h", "irrl_config.hpp", "irrl_state_pool.hpp", "irrl_terrain.hpp")]
     if (not os.path.exists(out)) or os.path.getmtime(out) < max(os.path.getmtime(s) for s in srcs):
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-I" + _CSRC,
-                               "-o", out, os.path.join(_HERE, "emu_main.cpp")])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-DIRRL_EMU_W=%d" % width,
+                               "-I" + _CSRC, "-o", out, os.path.join(_HERE, "emu_main.cpp")])
     return out
 
 
-def lib():
-    global _LIB
-    if _LIB is None:
-        l = C.CDLL(build())
+def lib(width=4):
+    if width not in _LIB:
+        l = C.CDLL(build(width))
         l.emu_create.restype = C.c_void_p
         l.emu_create.argtypes = [C.c_char_p]
         l.emu_last_error.restype = C.c_char_p
@@ -38,8 +37,8 @@ def lib():
             getattr(l, n).argtypes = a
         l.emu_num_envs.restype = C.c_int
         l.emu_num_envs.argtypes = [vp]
-        _LIB = l
-    return _LIB
+        _LIB[width] = l
+    return _LIB[width]
 
 
 def _fp(a):
@@ -47,8 +46,10 @@ def _fp(a):
 
 
 class EmuVecEnv(object):
-    def __init__(self, env_cfg):
-        self.l = lib()
+    WIDTH = 4   # lanes per robot: 4 = one leg per lane, 16 = four sub-lanes per leg
+
+    def __init__(self, env_cfg, width=None):
+        self.l = lib(self.WIDTH if width is None else width)
         text = yaml.safe_dump(dict(env_cfg), default_flow_style=False)
         self.h = self.l.emu_create(text.encode())
         if not self.h:
@@ -103,3 +104,8 @@ class EmuVecEnv(object):
     def set_state(self, st):
         st = np.ascontiguousarray(st, np.float64)
         self.l.emu_set_state(self.h, st.ctypes.data_as(C.POINTER(C.c_double)))
+
+
+class EmuVecEnv16(EmuVecEnv):
+    """The 16-lanes-per-robot layout of the same kernel source."""
+    WIDTH = 16

@@ -25,6 +25,14 @@ struct Emu {
 static std::string g_err;
 
 static inline vi lanes_env(int e) { return vi(e); }
+// the lanes that own the stores of a robot: all of them with one lane per leg, sub-lane 0 of every leg with four
+static inline vm store_mask() {
+#if IRRL_EMU_W == 16
+  return lanes::sub_id() == 0;
+#else
+  return vm(true);
+#endif
+}
 
 extern "C" {
 const char *emu_last_error() { return g_err.c_str(); }
@@ -46,25 +54,25 @@ void emu_destroy(void *hv) { delete (Emu *)hv; }
 int emu_num_envs(void *hv) { return ((Emu *)hv)->P.n_envs; }
 void emu_init(void *hv) {
   Emu *h = (Emu *)hv;
-  for (int e = 0; e < h->P.n_envs; e++) irrl::init_body(h->P, h->S, lanes_env(e), lanes::leg_id(), vm(true));
+  for (int e = 0; e < h->P.n_envs; e++) irrl::init_body(h->P, h->S, lanes_env(e), lanes::leg_id(), store_mask());
 }
 void emu_reset(void *hv, float *ob) {
   Emu *h = (Emu *)hv;
-  for (int e = 0; e < h->P.n_envs; e++) irrl::reset_body(h->P, h->S, lanes_env(e), lanes::leg_id(), vm(true), ob);
+  for (int e = 0; e < h->P.n_envs; e++) irrl::reset_body(h->P, h->S, lanes_env(e), lanes::leg_id(), store_mask(), ob);
 }
 void emu_observe(void *hv, float *ob) {
   Emu *h = (Emu *)hv;
-  for (int e = 0; e < h->P.n_envs; e++) irrl::observe_body(h->P, h->S, lanes_env(e), lanes::leg_id(), vm(true), ob);
+  for (int e = 0; e < h->P.n_envs; e++) irrl::observe_body(h->P, h->S, lanes_env(e), lanes::leg_id(), store_mask(), ob);
 }
 void emu_step(void *hv, const float *action, float *ob, float *reward, uint8_t *done, float *extra) {
   Emu *h = (Emu *)hv;
   for (int e = 0; e < h->P.n_envs; e++)
-    irrl::step_body(h->P, h->S, lanes_env(e), lanes::leg_id(), vm(true), action, ob, reward, done, extra);
+    irrl::step_body(h->P, h->S, lanes_env(e), lanes::leg_id(), store_mask(), action, ob, reward, done, extra);
 }
 void emu_probe(void *hv, float *minv, float *nonlin) {
   Emu *h = (Emu *)hv;
   for (int e = 0; e < h->P.n_envs; e++)
-    irrl::dynamics_probe_body(h->P, h->S, lanes_env(e), lanes::leg_id(), vm(true), minv, nonlin);
+    irrl::dynamics_probe_body(h->P, h->S, lanes_env(e), lanes::leg_id(), store_mask(), minv, nonlin);
 }
 void emu_get_state(void *hv, double *out) { Emu *h = (Emu *)hv; h->pool.pack(h->mem.data(), out); }
 void emu_set_state(void *hv, const double *in) { Emu *h = (Emu *)hv; h->pool.unpack(in, h->mem.data()); }

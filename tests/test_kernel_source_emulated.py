@@ -11,8 +11,22 @@ from conftest import load_env_cfg
 from host_emulation import emu as E
 
 
-def _pair(cfg):
-    return O.OracleVecEnv(cfg), E.EmuVecEnv(cfg)
+# the shipped kernels use 16 lanes per robot (lanes_hip16.hpp); the 4-lanes-per-robot layout of the same source
+# (lanes_hip.hpp) is kept as a second instantiation and checked on the core cases
+EMU = E.EmuVecEnv16
+
+
+def _pair(cfg, emu=None):
+    return O.OracleVecEnv(cfg), (emu or EMU)(cfg)
+
+
+@pytest.mark.parametrize("emu", [E.EmuVecEnv, E.EmuVecEnv16])
+def test_both_lane_layouts_match_oracle(emu):
+    orc, cand = _pair(load_env_cfg("default_cfg.yaml", num_envs=8), emu)
+    PL.check_init(orc, cand)
+    PL.check_teacher_forced(orc, cand, steps=60, force_terminal_every=7)
+    orc, cand = _pair(load_env_cfg("bp5_terrain.yaml", num_envs=4), emu)
+    PL.check_teacher_forced(orc, cand, steps=40, force_terminal_every=9, max_factor=1e4)
 
 
 def test_init_matches_oracle_train_cfg():
@@ -50,11 +64,11 @@ def test_teacher_forced_eval_style_cfg():
 
 def test_free_running_horizons():
     cfg = load_env_cfg("bp5_imitation.yaml", num_envs=8)
-    PL.check_free_running(O.OracleVecEnv, E.EmuVecEnv, cfg)
+    PL.check_free_running(O.OracleVecEnv, EMU, cfg)
 
 
 def test_invariants_small():
-    cand = E.EmuVecEnv(load_env_cfg("default_cfg.yaml", num_envs=16))
+    cand = EMU(load_env_cfg("default_cfg.yaml", num_envs=16))
     PL.check_invariants(cand, steps=30)
 
 
@@ -62,7 +76,7 @@ def test_config_parser_matches_pyyaml():
     import yaml
     cfg = load_env_cfg("default_cfg.yaml")
     text = yaml.safe_dump(cfg)
-    cand = E.EmuVecEnv(dict(cfg, num_envs=2))
+    cand = EMU(dict(cfg, num_envs=2))
     assert cand.n == 2
     # missing mandatory key -> error naming the key (reference: RSFATAL "Node ... doesn't exist")
     bad = dict(cfg)
@@ -70,7 +84,7 @@ def test_config_parser_matches_pyyaml():
     with pytest.raises(RuntimeError, match="Stiffness"):
         E.EmuVecEnv(bad)
     with pytest.raises(RuntimeError, match="Crutial"):
-        E.EmuVecEnv(dict(cfg, Crutial=True))
+        EMU(dict(cfg, Crutial=True))
     assert "seedd" in text
 
 
