@@ -1,7 +1,7 @@
 // env_kernels.hip -- __global__ wrappers of the lane bodies in env_core.hpp (gfx950 only).
 // Launch shape: 64-thread workgroups = one wave = 16 robots (one DPP quad each); grid = ceil(N / 16).
 // At N = 4096 that is 256 workgroups -> one wave on each of the 256 CUs; the kernel keeps the whole
-// robot state in VGPRs across the 8 substeps (no LDS, no scratch), so __launch_bounds__(64, 1) lets the
+// robot state in VGPRs across the 8 substeps (no LDS, no scratch), so __launch_bounds__(256, 1) lets the
 // allocator use the full 512-register budget of a SIMD that hosts a single wave.
 #ifndef IRRL_LANES_PER_ROBOT
 #define IRRL_LANES_PER_ROBOT 16
@@ -18,16 +18,17 @@
 // env_: robot of this lane; leg_: its leg; valid_: this lane owns the stores of (robot, leg) -- with 16 lanes per robot
 // that is sub-lane 0 of each quad.  Idle rows shadow the last robot with their stores masked.
 #if IRRL_LANES_PER_ROBOT == 16
-#define IRRL_LANE_PROLOGUE                                       \
-  const int lane_ = (int)threadIdx.x;                            \
-  int env_ = (int)blockIdx.x * 4 + (lane_ >> 4);                 \
-  const int leg_ = (lane_ >> 2) & 3;                             \
-  const bool valid_ = (env_ < P.n_envs) && ((lane_ & 3) == 0);   \
+#define IRRL_LANE_PROLOGUE                                                                   \
+  const int lane_ = (int)(threadIdx.x & 63u);                                                \
+  const int wave_ = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));               \
+  int env_ = wave_ * 4 + (lane_ >> 4);                                                       \
+  const int leg_ = (lane_ >> 2) & 3;                                                         \
+  const bool valid_ = (env_ < P.n_envs) && ((lane_ & 3) == 0);                               \
   if (env_ >= P.n_envs) env_ = P.n_envs - 1;
 #else
 #define IRRL_LANE_PROLOGUE                                     \
-  const int lane_ = (int)threadIdx.x;                          \
-  int env_ = (int)blockIdx.x * 16 + (lane_ >> 2);              \
+  const int lane_ = (int)(threadIdx.x & 63u);                  \
+  int env_ = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (lane_ >> 2); \
   const int leg_ = lane_ & 3;                                  \
   const bool valid_ = env_ < P.n_envs;                         \
   if (!valid_) env_ = P.n_envs - 1; /* idle quads shadow the last robot; their stores are masked */
@@ -35,28 +36,28 @@
 
 extern "C" {
 
-__global__ void __launch_bounds__(64, 1)
+__global__ void __launch_bounds__(256, 1)
 irrl_step_kernel(EnvParams P, EnvState S, const float *action, float *ob, float *reward, uint8_t *done, float *extra) {
   IRRL_LANE_PROLOGUE
   irrl::step_body(P, S, env_, leg_, valid_, action, ob, reward, done, extra);
 }
 
-__global__ void __launch_bounds__(64, 1) irrl_init_kernel(EnvParams P, EnvState S) {
+__global__ void __launch_bounds__(256, 1) irrl_init_kernel(EnvParams P, EnvState S) {
   IRRL_LANE_PROLOGUE
   irrl::init_body(P, S, env_, leg_, valid_);
 }
 
-__global__ void __launch_bounds__(64, 1) irrl_reset_kernel(EnvParams P, EnvState S, float *ob) {
+__global__ void __launch_bounds__(256, 1) irrl_reset_kernel(EnvParams P, EnvState S, float *ob) {
   IRRL_LANE_PROLOGUE
   irrl::reset_body(P, S, env_, leg_, valid_, ob);
 }
 
-__global__ void __launch_bounds__(64, 1) irrl_observe_kernel(EnvParams P, EnvState S, float *ob) {
+__global__ void __launch_bounds__(256, 1) irrl_observe_kernel(EnvParams P, EnvState S, float *ob) {
   IRRL_LANE_PROLOGUE
   irrl::observe_body(P, S, env_, leg_, valid_, ob);
 }
 
-__global__ void __launch_bounds__(64, 1) irrl_probe_kernel(EnvParams P, EnvState S, float *minv, float *nonlin) {
+__global__ void __launch_bounds__(256, 1) irrl_probe_kernel(EnvParams P, EnvState S, float *minv, float *nonlin) {
   IRRL_LANE_PROLOGUE
   irrl::dynamics_probe_body(P, S, env_, leg_, valid_, minv, nonlin);
 }

@@ -50,7 +50,17 @@ struct irrl_env {
 static const char *const kExtraNames[IRRL_EXTRA_DIM] = {"EndEffectorReward(0.15)", "Height_Keep_Reward(0.1)", "base height",
                                                         "Balance_Keep_Reward(0.1)", "JointReward(0.65)", "VelocityReward(0.2)"};
 
-static inline dim3 quad_grid(int n) { return dim3((unsigned)((n + IRRL_ROBOTS_PER_WAVE - 1) / IRRL_ROBOTS_PER_WAVE)); }
+// launch shape of the lane kernels: `waves_per_block()` waves per workgroup (1 by default; IRRL_WAVES_PER_BLOCK=4 packs
+// the four SIMDs of a CU into one workgroup), IRRL_ROBOTS_PER_WAVE robots per wave
+static int waves_per_block() {
+  static int w = [] { const char *e = getenv("IRRL_WAVES_PER_BLOCK"); int v = e ? atoi(e) : 1; return (v == 1 || v == 2 || v == 4) ? v : 1; }();
+  return w;
+}
+static inline dim3 quad_block() { return dim3((unsigned)(64 * waves_per_block())); }
+static inline dim3 quad_grid(int n) {
+  const int per_block = IRRL_ROBOTS_PER_WAVE * waves_per_block();
+  return dim3((unsigned)((n + per_block - 1) / per_block));
+}
 
 extern "C" {
 
@@ -115,7 +125,7 @@ int irrl_env_set_stream(irrl_env *h, void *hip_stream) { h->stream = (hipStream_
 
 int irrl_env_init(irrl_env *h) {
   HIP_TRY(hipSetDevice(h->device));
-  hipLaunchKernelGGL(irrl_init_kernel, quad_grid(h->P.n_envs), dim3(64), 0, h->stream, h->P, h->S);
+  hipLaunchKernelGGL(irrl_init_kernel, quad_grid(h->P.n_envs), quad_block(), 0, h->stream, h->P, h->S);
   HIP_TRY(hipGetLastError());
   h->initialised = true;
   return 0;
@@ -134,7 +144,7 @@ static int need_init(irrl_env *h) {
 
 int irrl_env_step(irrl_env *h, const float *action, float *ob, float *reward, uint8_t *done, float *extra) {
   if (need_init(h)) return 1;
-  hipLaunchKernelGGL(irrl_step_kernel, quad_grid(h->P.n_envs), dim3(64), 0, h->stream, h->P, h->S, action, ob, reward, done, extra);
+  hipLaunchKernelGGL(irrl_step_kernel, quad_grid(h->P.n_envs), quad_block(), 0, h->stream, h->P, h->S, action, ob, reward, done, extra);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -160,7 +170,7 @@ static int step_host_impl(irrl_env *h, int n_step, const float *action, float *o
   HIP_TRY(hipMemcpyAsync(h->d_action, pa, n * 12 * 4, hipMemcpyHostToDevice, h->stream));
   EnvParams P = h->P;
   P.n_envs = n_step;
-  hipLaunchKernelGGL(irrl_step_kernel, quad_grid(n_step), dim3(64), 0, h->stream, P, h->S, h->d_action, h->d_ob, h->d_reward, h->d_done, h->d_extra);
+  hipLaunchKernelGGL(irrl_step_kernel, quad_grid(n_step), quad_block(), 0, h->stream, P, h->S, h->d_action, h->d_ob, h->d_reward, h->d_done, h->d_extra);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(po, h->d_ob, n * 35 * 4, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipMemcpyAsync(pr, h->d_reward, n * 4, hipMemcpyDeviceToHost, h->stream));
@@ -182,13 +192,13 @@ int irrl_env_test_step_host(irrl_env *h, const float *action, float *ob, float *
 
 int irrl_env_reset(irrl_env *h, float *ob) {
   if (need_init(h)) return 1;
-  hipLaunchKernelGGL(irrl_reset_kernel, quad_grid(h->P.n_envs), dim3(64), 0, h->stream, h->P, h->S, ob);
+  hipLaunchKernelGGL(irrl_reset_kernel, quad_grid(h->P.n_envs), quad_block(), 0, h->stream, h->P, h->S, ob);
   HIP_TRY(hipGetLastError());
   return 0;
 }
 int irrl_env_observe(irrl_env *h, float *ob) {
   if (need_init(h)) return 1;
-  hipLaunchKernelGGL(irrl_observe_kernel, quad_grid(h->P.n_envs), dim3(64), 0, h->stream, h->P, h->S, ob);
+  hipLaunchKernelGGL(irrl_observe_kernel, quad_grid(h->P.n_envs), quad_block(), 0, h->stream, h->P, h->S, ob);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -290,7 +300,7 @@ static int probe(irrl_env *h, float *minv_host, float *nonlin_host) {
   HIP_TRY(hipSetDevice(h->device));
   const size_t n = (size_t)h->P.n_envs;
   float *d_minv = h->d_scratch, *d_nl = h->d_scratch + n * 324;
-  hipLaunchKernelGGL(irrl_probe_kernel, quad_grid(h->P.n_envs), dim3(64), 0, h->stream, h->P, h->S, minv_host ? d_minv : (float *)nullptr,
+  hipLaunchKernelGGL(irrl_probe_kernel, quad_grid(h->P.n_envs), quad_block(), 0, h->stream, h->P, h->S, minv_host ? d_minv : (float *)nullptr,
                      nonlin_host ? d_nl : (float *)nullptr);
   HIP_TRY(hipGetLastError());
   if (minv_host && d2h(h, minv_host, d_minv, n * 324 * 4)) return 1;
