@@ -1536,6 +1536,10 @@ IRRL_DEV void step_body(const EnvParams &P, const EnvState &S, vi env, vi leg, v
     }
   }
   for (int i = 0; i < P.loop_count; i++) physics_substep(P, L, pT);
+  // The epilogue is per-leg work: with four sub-lanes per leg it would be executed four times over.  Only sub-lane 0
+  // (the lane that owns the stores) runs it -- same issue time, a quarter of the active lanes, which is what the
+  // power-limited clock of a fully occupied chip responds to.  All cross-leg DPP traffic below is between sub-lanes 0.
+  IRRL_SUB0_ONLY_BEGIN
   update_observation(P, L, envu);
   vf extra[6];
   vf rew = reward_update(P, L, extra);
@@ -1557,6 +1561,7 @@ IRRL_DEV void step_body(const EnvParams &P, const EnvState &S, vi env, vi leg, v
 #pragma unroll
   for (int j = 0; j < 6; j++) st_if(lead, extra_out, env * 6 + j, extra[j]);
   store_lane(P, S, env, leg, valid, L, P.randomize_per_episode != 0);
+  IRRL_SUB0_ONLY_END
 }
 
 // VEC:145-194 per env: constructor randomisation (ENV:435-477) + first reset

@@ -20,6 +20,9 @@ typedef int32_t vi;
 typedef uint32_t vu;
 typedef bool vm;
 
+#define IRRL_SUB0_ONLY_BEGIN {
+#define IRRL_SUB0_ONLY_END }
+
 namespace lanes {
 
 IRRL_DEV vi leg_id() { return (vi)(threadIdx.x & 3u); }

@@ -20,6 +20,10 @@ typedef int32_t vi;
 typedef uint32_t vu;
 typedef bool vm;
 
+// region executed by sub-lane 0 of every leg only (a real branch: the other lanes idle through it)
+#define IRRL_SUB0_ONLY_BEGIN if ((threadIdx.x & 3u) == 0u) {
+#define IRRL_SUB0_ONLY_END }
+
 namespace lanes {
 
 IRRL_DEV vi leg_id() { return (vi)((threadIdx.x >> 2) & 3u); }

@@ -10,6 +10,9 @@
 #include <cstring>
 
 #define IRRL_DEV inline
+// on the GPU this region runs on sub-lane 0 of every leg only; the emulation lets every lane compute (same values)
+#define IRRL_SUB0_ONLY_BEGIN {
+#define IRRL_SUB0_ONLY_END }
 
 // W lanes emulate ONE robot: W = 4 (one DPP quad per robot, one leg per lane) or W = 16 (one DPP row per robot: the quad
 // (i >> 2) is the leg, the lane inside the quad (i & 3) a sub-lane that splits the leg's work)
