@@ -159,7 +159,7 @@ def main():
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary_latest.json")))
-            if int(pmc.get("envs", 4096)) == n:
+            if int(pmc.get("envs", 4096)) == n and env.lanes_per_robot == 16:
                 traffic = float(pmc["hbm_bytes_per_launch"]["total"])
         except Exception:
             pass
@@ -174,7 +174,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE config 2: %d envs/GPU x 1 env.step (8 substeps @4 kHz + obs + reward + "
                                    "termination + in-step reset), cfg %s, actions clip(0.3 N(0,1))" % (n, args.cfg),
-                       "envs_per_gpu": n, "global_envs": n * world, "parallelism": "env-sharded x%d" % world},
+                       "envs_per_gpu": n, "global_envs": n * world, "parallelism": "env-sharded x%d" % world,
+                       "lanes_per_robot": env.lanes_per_robot},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "irrl_step_kernel", "avg_launch_us": kernel_ms * 1e3,

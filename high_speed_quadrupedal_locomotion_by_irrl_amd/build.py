@@ -32,11 +32,26 @@ def is_stale():
 def build(force=False, verbose=False, extra_flags=()):
     if not force and not is_stale():
         return LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-fno-signed-zeros",
-           os.path.join(CSRC, "irrl_env_abi.hip"), "-o", LIB] + list(extra_flags)
+    common = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-fno-signed-zeros"] + list(extra_flags)
+    objdir = os.path.join(_HERE, "csrc", "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    # the env kernels in both lane layouts (same source, different lane-primitive header), then the C-ABI + LSTM kernels
+    units = [("env_kernels.hip", ["-DIRRL_LANES_PER_ROBOT=16"], "env_kernels_l16.o"),
+             ("env_kernels.hip", ["-DIRRL_LANES_PER_ROBOT=4"], "env_kernels_l4.o"),
+             ("irrl_env_abi.hip", [], "irrl_env_abi.o")]
+    procs = []
+    for src, flags, obj in units:
+        cmd = common + flags + ["-c", os.path.join(CSRC, src), "-o", os.path.join(objdir, obj)]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append(subprocess.Popen(cmd))
+    for p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed")
+    link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + [os.path.join(objdir, u[2]) for u in units] + ["-o", LIB]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print(" ".join(link))
+    subprocess.check_call(link)
     return LIB
 
 

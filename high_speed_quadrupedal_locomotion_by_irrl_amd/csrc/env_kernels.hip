@@ -15,6 +15,13 @@
 #endif
 #include "env_core.hpp"
 
+// This file is compiled twice (build.py): once per lane layout, kernel names suffixed _l16 / _l4.
+#if IRRL_LANES_PER_ROBOT == 16
+#define IRRL_K(name) name##_l16
+#else
+#define IRRL_K(name) name##_l4
+#endif
+
 // env_: robot of this lane; leg_: its leg; valid_: this lane owns the stores of (robot, leg) -- with 16 lanes per robot
 // that is sub-lane 0 of each quad.  Idle rows shadow the last robot with their stores masked.
 #if IRRL_LANES_PER_ROBOT == 16
@@ -37,37 +44,39 @@
 extern "C" {
 
 __global__ void __launch_bounds__(256, 1)
-irrl_step_kernel(EnvParams P, EnvState S, const float *action, float *ob, float *reward, uint8_t *done, float *extra) {
+IRRL_K(irrl_step_kernel)(EnvParams P, EnvState S, const float *action, float *ob, float *reward, uint8_t *done, float *extra) {
   IRRL_LANE_PROLOGUE
   irrl::step_body(P, S, env_, leg_, valid_, action, ob, reward, done, extra);
 }
 
-__global__ void __launch_bounds__(256, 1) irrl_init_kernel(EnvParams P, EnvState S) {
+__global__ void __launch_bounds__(256, 1) IRRL_K(irrl_init_kernel)(EnvParams P, EnvState S) {
   IRRL_LANE_PROLOGUE
   irrl::init_body(P, S, env_, leg_, valid_);
 }
 
-__global__ void __launch_bounds__(256, 1) irrl_reset_kernel(EnvParams P, EnvState S, float *ob) {
+__global__ void __launch_bounds__(256, 1) IRRL_K(irrl_reset_kernel)(EnvParams P, EnvState S, float *ob) {
   IRRL_LANE_PROLOGUE
   irrl::reset_body(P, S, env_, leg_, valid_, ob);
 }
 
-__global__ void __launch_bounds__(256, 1) irrl_observe_kernel(EnvParams P, EnvState S, float *ob) {
+__global__ void __launch_bounds__(256, 1) IRRL_K(irrl_observe_kernel)(EnvParams P, EnvState S, float *ob) {
   IRRL_LANE_PROLOGUE
   irrl::observe_body(P, S, env_, leg_, valid_, ob);
 }
 
-__global__ void __launch_bounds__(256, 1) irrl_probe_kernel(EnvParams P, EnvState S, float *minv, float *nonlin) {
+__global__ void __launch_bounds__(256, 1) IRRL_K(irrl_probe_kernel)(EnvParams P, EnvState S, float *minv, float *nonlin) {
   IRRL_LANE_PROLOGUE
   irrl::dynamics_probe_body(P, S, env_, leg_, valid_, minv, nonlin);
 }
 
-// isTerminalState (ENV:1553-1578) on the stored state; one thread per robot
+#if IRRL_LANES_PER_ROBOT == 16
+// isTerminalState (ENV:1553-1578) on the stored state; one thread per robot (layout independent: emitted once)
 __global__ void irrl_terminal_kernel(EnvParams P, EnvState S, uint8_t *done) {
   int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (e >= P.n_envs) return;
   float z = S.gc[e * 19 + 2], up = S.ob[e * 35 + 31];
   done[e] = (z < 0.15f || z > 0.65f || up < 0.5f) ? 1 : 0;
 }
+#endif
 
 }  // extern "C"

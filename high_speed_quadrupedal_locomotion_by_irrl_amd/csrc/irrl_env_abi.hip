@@ -4,8 +4,24 @@
 // VectorizedEnvironment<ENVIRONMENT>, VectorizedEnvironment.hpp:127-382), parses the YAML string the
 // reference hands over, and launches the kernels stream-ordered.  No CPU compute path exists here:
 // without a usable gfx950 device irrl_env_create fails.
-#include "env_kernels.hip"
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "env_params.h"
 #include "lstm_kernels.hip"
+
+// The env kernels are compiled in two lane layouts from the same source (csrc/env_kernels.hip, see build.py):
+//   _l16  16 lanes per robot (lanes_hip16.hpp): 4 robots per wave -- fills all 1024 SIMDs at 4096 robots, shortest step
+//   _l4    4 lanes per robot (lanes_hip.hpp):  16 robots per wave -- 2.3x fewer instructions per robot, the better
+//          throughput once the pool is large enough to occupy the chip on its own
+#define IRRL_DECLARE_KERNELS(sfx)                                                                                            \
+  extern "C" __global__ void irrl_step_kernel##sfx(EnvParams, EnvState, const float *, float *, float *, uint8_t *, float *);   \
+  extern "C" __global__ void irrl_init_kernel##sfx(EnvParams, EnvState);                                                       \
+  extern "C" __global__ void irrl_reset_kernel##sfx(EnvParams, EnvState, float *);                                             \
+  extern "C" __global__ void irrl_observe_kernel##sfx(EnvParams, EnvState, float *);                                           \
+  extern "C" __global__ void irrl_probe_kernel##sfx(EnvParams, EnvState, float *, float *);
+IRRL_DECLARE_KERNELS(_l16)
+IRRL_DECLARE_KERNELS(_l4)
+extern "C" __global__ void irrl_terminal_kernel(EnvParams, EnvState, uint8_t *);
 
 #include "irrl_config.hpp"
 #include "irrl_state_pool.hpp"
@@ -44,6 +60,7 @@ struct irrl_env {
   char *h_pinned = nullptr;
   size_t pinned_bytes = 0;
   bool initialised = false;
+  int lanes = 16;  // lanes per robot of the kernels this pool launches (16 or 4)
   std::string resource_dir;
 };
 
@@ -57,10 +74,22 @@ static int waves_per_block() {
   return w;
 }
 static inline dim3 quad_block() { return dim3((unsigned)(64 * waves_per_block())); }
-static inline dim3 quad_grid(int n) {
-  const int per_block = IRRL_ROBOTS_PER_WAVE * waves_per_block();
+static inline dim3 lane_grid(const irrl_env *h, int n) {
+  const int per_block = (64 / h->lanes) * waves_per_block();
   return dim3((unsigned)((n + per_block - 1) / per_block));
 }
+// layout choice: 16 lanes per robot while that still fits ~1.5 waves per SIMD, 4 lanes per robot beyond;
+// IRRL_LANES_PER_ROBOT=4|16 overrides (used by the tests to cover both layouts on small pools)
+static int pick_lanes(int n_envs) {
+  const char *e = getenv("IRRL_LANES_PER_ROBOT");
+  if (e) { int v = atoi(e); if (v == 4 || v == 16) return v; }
+  return (n_envs <= 6144) ? 16 : 4;
+}
+#define IRRL_LAUNCH(h, name, grid, ...)                                                                                   \
+  do {                                                                                                                    \
+    if ((h)->lanes == 16) hipLaunchKernelGGL(name##_l16, grid, quad_block(), 0, (h)->stream, __VA_ARGS__);                 \
+    else hipLaunchKernelGGL(name##_l4, grid, quad_block(), 0, (h)->stream, __VA_ARGS__);                                   \
+  } while (0)
 
 extern "C" {
 
@@ -87,6 +116,7 @@ irrl_env *irrl_env_create(const char *resource_dir, const char *cfg_yaml, int de
   h->resource_dir = resource_dir ? resource_dir : "";
   if (!h->cfg.parse(cfg_yaml, g_err) || !irrl_host::build_params(h->cfg, h->P, g_err)) { delete h; return nullptr; }
   h->pool = irrl_host::StatePool(h->P.n_envs);
+  h->lanes = pick_lanes(h->P.n_envs);
   const size_t n = (size_t)h->P.n_envs;
   bool ok = hipSetDevice(device) == hipSuccess && hipMalloc(&h->d_pool, h->pool.bytes) == hipSuccess &&
             hipMemset(h->d_pool, 0, h->pool.bytes) == hipSuccess && hipMalloc((void **)&h->d_action, n * 12 * 4) == hipSuccess &&
@@ -125,13 +155,14 @@ int irrl_env_set_stream(irrl_env *h, void *hip_stream) { h->stream = (hipStream_
 
 int irrl_env_init(irrl_env *h) {
   HIP_TRY(hipSetDevice(h->device));
-  hipLaunchKernelGGL(irrl_init_kernel, quad_grid(h->P.n_envs), quad_block(), 0, h->stream, h->P, h->S);
+  IRRL_LAUNCH(h, irrl_init_kernel, lane_grid(h, h->P.n_envs), h->P, h->S);
   HIP_TRY(hipGetLastError());
   h->initialised = true;
   return 0;
 }
 
 int irrl_env_num_envs(const irrl_env *h) { return h->P.n_envs; }
+int irrl_env_lanes_per_robot(const irrl_env *h) { return h->lanes; }
 int irrl_env_ob_dim(const irrl_env *) { return IRRL_OB_DIM; }
 int irrl_env_action_dim(const irrl_env *) { return IRRL_ACTION_DIM; }
 int irrl_env_extra_dim(const irrl_env *) { return IRRL_EXTRA_DIM; }
@@ -144,7 +175,7 @@ static int need_init(irrl_env *h) {
 
 int irrl_env_step(irrl_env *h, const float *action, float *ob, float *reward, uint8_t *done, float *extra) {
   if (need_init(h)) return 1;
-  hipLaunchKernelGGL(irrl_step_kernel, quad_grid(h->P.n_envs), quad_block(), 0, h->stream, h->P, h->S, action, ob, reward, done, extra);
+  IRRL_LAUNCH(h, irrl_step_kernel, lane_grid(h, h->P.n_envs), h->P, h->S, action, ob, reward, done, extra);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -170,7 +201,7 @@ static int step_host_impl(irrl_env *h, int n_step, const float *action, float *o
   HIP_TRY(hipMemcpyAsync(h->d_action, pa, n * 12 * 4, hipMemcpyHostToDevice, h->stream));
   EnvParams P = h->P;
   P.n_envs = n_step;
-  hipLaunchKernelGGL(irrl_step_kernel, quad_grid(n_step), quad_block(), 0, h->stream, P, h->S, h->d_action, h->d_ob, h->d_reward, h->d_done, h->d_extra);
+  IRRL_LAUNCH(h, irrl_step_kernel, lane_grid(h, n_step), P, h->S, (const float *)h->d_action, h->d_ob, h->d_reward, h->d_done, h->d_extra);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(po, h->d_ob, n * 35 * 4, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipMemcpyAsync(pr, h->d_reward, n * 4, hipMemcpyDeviceToHost, h->stream));
@@ -192,13 +223,13 @@ int irrl_env_test_step_host(irrl_env *h, const float *action, float *ob, float *
 
 int irrl_env_reset(irrl_env *h, float *ob) {
   if (need_init(h)) return 1;
-  hipLaunchKernelGGL(irrl_reset_kernel, quad_grid(h->P.n_envs), quad_block(), 0, h->stream, h->P, h->S, ob);
+  IRRL_LAUNCH(h, irrl_reset_kernel, lane_grid(h, h->P.n_envs), h->P, h->S, ob);
   HIP_TRY(hipGetLastError());
   return 0;
 }
 int irrl_env_observe(irrl_env *h, float *ob) {
   if (need_init(h)) return 1;
-  hipLaunchKernelGGL(irrl_observe_kernel, quad_grid(h->P.n_envs), quad_block(), 0, h->stream, h->P, h->S, ob);
+  IRRL_LAUNCH(h, irrl_observe_kernel, lane_grid(h, h->P.n_envs), h->P, h->S, ob);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -300,8 +331,7 @@ static int probe(irrl_env *h, float *minv_host, float *nonlin_host) {
   HIP_TRY(hipSetDevice(h->device));
   const size_t n = (size_t)h->P.n_envs;
   float *d_minv = h->d_scratch, *d_nl = h->d_scratch + n * 324;
-  hipLaunchKernelGGL(irrl_probe_kernel, quad_grid(h->P.n_envs), quad_block(), 0, h->stream, h->P, h->S, minv_host ? d_minv : (float *)nullptr,
-                     nonlin_host ? d_nl : (float *)nullptr);
+  IRRL_LAUNCH(h, irrl_probe_kernel, lane_grid(h, h->P.n_envs), h->P, h->S, minv_host ? d_minv : (float *)nullptr, nonlin_host ? d_nl : (float *)nullptr);
   HIP_TRY(hipGetLastError());
   if (minv_host && d2h(h, minv_host, d_minv, n * 324 * 4)) return 1;
   if (nonlin_host && d2h(h, nonlin_host, d_nl, n * 18 * 4)) return 1;

@@ -75,6 +75,10 @@ class FlexibleGymEnv(object):
     def device_index(self):
         return self._device
 
+    @property
+    def lanes_per_robot(self):
+        return self._lib.irrl_env_lanes_per_robot(self._h)
+
     # -- raisim_gym.cpp:17-46 --
     def init(self):
         _lib.check(self._lib.irrl_env_init(self._h))

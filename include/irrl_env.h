@@ -53,6 +53,9 @@ int irrl_env_set_stream(irrl_env *h, void *hip_stream);
 
 /* PYB:28-31 */
 int irrl_env_num_envs(const irrl_env *h);
+/* lane layout of this pool's kernels: 16 (<= 6144 envs: one DPP row per robot) or 4 (larger pools: one DPP quad per
+ * robot); build-defined, overridable with the environment variable IRRL_LANES_PER_ROBOT */
+int irrl_env_lanes_per_robot(const irrl_env *h);
 int irrl_env_ob_dim(const irrl_env *h);
 int irrl_env_action_dim(const irrl_env *h);
 int irrl_env_extra_dim(const irrl_env *h);

@@ -155,3 +155,24 @@ def test_terrain_and_per_episode_randomisation_config5():
     so, sc = orc.get_state(), cand.get_state()
     np.testing.assert_allclose(sc[:, PL.S["MATERIAL"]:PL.S["OB"]], so[:, PL.S["MATERIAL"]:PL.S["OB"]], atol=2e-7)
     assert np.unique(np.round(so[:, PL.S["MATERIAL"]], 5)).size > 32
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_both_lane_layouts_match_oracle_on_gpu(lanes, monkeypatch):
+    """The library carries the env kernels in two lane layouts (16 lanes per robot for pools <= 6144, 4 beyond);
+    IRRL_LANES_PER_ROBOT forces one so that both are checked on a small pool."""
+    monkeypatch.setenv("IRRL_LANES_PER_ROBOT", str(lanes))
+    cfg = load_env_cfg("default_cfg.yaml", num_envs=48)
+    orc, cand = _pair(cfg)
+    assert cand.impl.lanes_per_robot == lanes
+    PL.check_init(orc, cand)
+    PL.check_teacher_forced(orc, cand, steps=60, force_terminal_every=5)
+    PL.check_probe(orc, cand)
+
+
+def test_layout_is_chosen_by_pool_size(monkeypatch):
+    monkeypatch.delenv("IRRL_LANES_PER_ROBOT", raising=False)
+    assert _hip(load_env_cfg("default_cfg.yaml", num_envs=4096)).impl.lanes_per_robot == 16
+    big = _hip(load_env_cfg("default_cfg.yaml", num_envs=16384))
+    assert big.impl.lanes_per_robot == 4
+    PL.check_invariants(big, steps=20)
