@@ -57,6 +57,9 @@ lstm_seq_fwd_kernel(const float *__restrict__ zx, const float *__restrict__ wh_p
   f32x4 zcur[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) zcur[j] = *(const f32x4 *)&zx[(((size_t)0 * N + e0 + 4 * rq + j) * HID + u) * 4];
+  float mA_cur = masks[e0 + col], mC_cur[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) mC_cur[j] = masks[e0 + 4 * rq + j];
   __syncthreads();
   int cur = 0;
   for (int t = 0; t < T; t++) {
@@ -65,10 +68,14 @@ lstm_seq_fwd_kernel(const float *__restrict__ zx, const float *__restrict__ wh_p
     const int tn = (t + 1 < T) ? t + 1 : t;
 #pragma unroll
     for (int j = 0; j < 4; j++) znext[j] = *(const f32x4 *)&zx[(((size_t)tn * N + e0 + 4 * rq + j) * HID + u) * 4];
-    const float keepA = 1.0f - masks[(size_t)t * N + e0 + col];  // A rows are envs e0 + (l & 15)
+    const float keepA = 1.0f - mA_cur;  // A rows are envs e0 + (l & 15)
     float keepC[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) keepC[j] = 1.0f - masks[(size_t)t * N + e0 + 4 * rq + j];
+    for (int j = 0; j < 4; j++) keepC[j] = 1.0f - mC_cur[j];
+    const float mA_next = masks[(size_t)tn * N + e0 + col];
+    float mC_next[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) mC_next[j] = masks[(size_t)tn * N + e0 + 4 * rq + j];
     f32x4 acc[4];
 #pragma unroll
     for (int g = 0; g < 4; g++) acc[g] = (f32x4){zcur[0][g], zcur[1][g], zcur[2][g], zcur[3][g]};
@@ -94,7 +101,8 @@ lstm_seq_fwd_kernel(const float *__restrict__ zx, const float *__restrict__ wh_p
       hn[(4 * rq + j) * LD + u] = hn_;
     }
 #pragma unroll
-    for (int j = 0; j < 4; j++) zcur[j] = znext[j];
+    for (int j = 0; j < 4; j++) { zcur[j] = znext[j]; mC_cur[j] = mC_next[j]; }
+    mA_cur = mA_next;
     __syncthreads();
     cur ^= 1;
   }
@@ -129,20 +137,38 @@ lstm_seq_bwd_kernel(const float *__restrict__ gates, const float *__restrict__ c
     for (int nt = 0; nt < NW; nt++) bT[kk][nt] = wh_p[(size_t)(16 * nt + col) * HID * 4 + 64 * w + 4 * kk + rq];
   float dc[4] = {0.0f, 0.0f, 0.0f, 0.0f}, dhrec[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   int pb = 0;
-  for (int t = T - 1; t >= 0; t--) {
-    float keepC[4];
-    f32x4 dz4[4];
+  // software pipeline over time: the operands of step t-1 are requested while step t computes (a step is only a few
+  // thousand cycles, so an un-prefetched global load would be most of it)
+  f32x4 g_n[4];
+  float ct_n[4], cp_n[4], dh_n[4], mk_n[4];
+  auto fetch = [&](int t) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const int e = e0 + 4 * rq + j;
       const size_t row = (size_t)t * N + e;
-      keepC[j] = 1.0f - masks[row];
-      const f32x4 g4 = *(const f32x4 *)&gates[(row * HID + u) * 4];
-      const float ct = cseq[row * HID + u];
-      const float cprev = ((t > 0) ? cseq[(row - N) * HID + u] : state0[(size_t)e * 2 * HID + u]) * keepC[j];
-      const float dh = dh_in[row * HID + u] + dhrec[j];
-      const float ig = g4[0], fg = g4[1], og = g4[2], gg = g4[3];
-      const float tc = fast_tanh(ct);
+      mk_n[j] = masks[row];
+      g_n[j] = *(const f32x4 *)&gates[(row * HID + u) * 4];
+      ct_n[j] = cseq[row * HID + u];
+      cp_n[j] = (t > 0) ? cseq[(row - N) * HID + u] : state0[(size_t)e * 2 * HID + u];
+      dh_n[j] = dh_in[row * HID + u];
+    }
+  };
+  fetch(T - 1);
+  for (int t = T - 1; t >= 0; t--) {
+    float keepC[4];
+    f32x4 dz4[4], g4[4];
+    float ct[4], cpv[4], dhv[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { keepC[j] = 1.0f - mk_n[j]; g4[j] = g_n[j]; ct[j] = ct_n[j]; cpv[j] = cp_n[j]; dhv[j] = dh_n[j]; }
+    if (t > 0) fetch(t - 1);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int e = e0 + 4 * rq + j;
+      const size_t row = (size_t)t * N + e;
+      const float cprev = cpv[j] * keepC[j];
+      const float dh = dhv[j] + dhrec[j];
+      const float ig = g4[j][0], fg = g4[j][1], og = g4[j][2], gg = g4[j][3];
+      const float tc = fast_tanh(ct[j]);
       const float d_o = dh * tc;
       const float dct = dc[j] + dh * og * (1.0f - tc * tc);
       const float d_i = dct * gg, d_g = dct * ig, d_f = dct * cprev;

@@ -125,6 +125,15 @@ class CustomLSTMPolicy(ActorCriticPolicy):
         self.q = SBLinear(dims[-1], act_dim)  # created by proba_distribution_from_latent, never used
         self.state_dim = sum(self.n_lstm) * 2 * 2  # run_bp_v5.py:136-137
 
+    two_streams = True
+    _streams = {}
+
+    def _side_stream(self, device):
+        key = str(device)
+        if key not in CustomLSTMPolicy._streams:
+            CustomLSTMPolicy._streams[key] = torch.cuda.Stream(device=device)
+        return CustomLSTMPolicy._streams[key]
+
     def sb_parameters(self):
         out = []
         for stack in (self.lstm_pi, self.lstm_v):
@@ -141,19 +150,32 @@ class CustomLSTMPolicy(ActorCriticPolicy):
         sizes = [2 * k for k in (self.n_lstm + self.n_lstm)]  # run_bp_v5.py:139-140
         return list(torch.split(states, sizes, dim=1))
 
+    def _stack(self, layers, x, parts, masks_seq):
+        new = []
+        for l, st in zip(layers, parts):
+            x, s = l.sequence(x, st, masks_seq)
+            new.append(s)
+        return x, new
+
     def _run(self, obs_seq, states, masks_seq):
         parts = self._split(states)
-        new = []
-        x = obs_seq
-        for i, l in enumerate(self.lstm_pi):
-            x, s = l.sequence(x, parts[i], masks_seq)
-            new.append(s)
-        latent_pi = x
-        x = obs_seq
-        for i, l in enumerate(self.lstm_v):
-            x, s = l.sequence(x, parts[len(self.n_lstm) + i], masks_seq)
-            new.append(s)
-        latent_v = x
+        k = len(self.n_lstm)
+        if obs_seq.is_cuda and self.two_streams and obs_seq.shape[0] > 1 and not torch.cuda.is_current_stream_capturing():
+            # actor and critic stacks are independent until the heads: run the critic on a second HIP stream so the two
+            # persistent sequence kernels (768 waves each) share the chip; autograd replays the same stream assignment
+            cur = torch.cuda.current_stream(obs_seq.device)
+            side = self._side_stream(obs_seq.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                latent_v, new_v = self._stack(self.lstm_v, obs_seq, parts[k:], masks_seq)
+            latent_pi, new_pi = self._stack(self.lstm_pi, obs_seq, parts[:k], masks_seq)
+            cur.wait_stream(side)
+            for t in [latent_v] + new_v:
+                t.record_stream(cur)
+        else:
+            latent_pi, new_pi = self._stack(self.lstm_pi, obs_seq, parts[:k], masks_seq)
+            latent_v, new_v = self._stack(self.lstm_v, obs_seq, parts[k:], masks_seq)
+        new = new_pi + new_v
         mean = self.pi(latent_pi)
         value = self.vf(latent_v).squeeze(-1)
         return mean, value, torch.cat(new, 1)

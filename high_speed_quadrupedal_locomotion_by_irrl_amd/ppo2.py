@@ -206,8 +206,11 @@ class PPO2(object):
         self.policy.to(self.device)
         self.generator = torch.Generator(device=self.device)
         self.generator.manual_seed(self.seed * 1000003 + 7919 * self.rank + 1)
-        self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=float(learning_rate) if not callable(learning_rate) else 1e-3,
-                                          eps=1e-5, betas=(0.9, 0.999))
+        adam_kw = dict(lr=float(learning_rate) if not callable(learning_rate) else 1e-3, eps=1e-5, betas=(0.9, 0.999))
+        try:  # one fused kernel over the 19 parameter tensors on the GPU
+            self.optimizer = torch.optim.Adam(self.policy.parameters(), fused=(self.device.type == "cuda"), **adam_kw)
+        except Exception:
+            self.optimizer = torch.optim.Adam(self.policy.parameters(), **adam_kw)
         self.loss_names = ['policy_loss', 'value_loss', 'policy_entropy', 'approxkl', 'clipfrac']
         self.log = []
 
