@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libirrl_env.so")
+LIB_PATH = os.environ.get("IRRL_ENV_LIB") or os.path.join(_HERE, "libirrl_env.so")  # override: A/B builds of the same ABI
 _lib = None
 
 fp = C.POINTER(C.c_float)
@@ -55,6 +55,7 @@ SIGNATURES = {
     "irrl_calib_copy_dword": (C.c_int, [vp, vp, C.c_size_t, vp]),
     "irrl_lstm_seq_forward": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "irrl_lstm_seq_backward": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "irrl_lstm_policy_step": (C.c_int, [C.c_int] * 4 + [vp] * 11 + [C.c_int, C.c_uint, C.c_longlong] + [vp] * 13),
 }
 
 

@@ -528,19 +528,26 @@ IRRL_DEV ContactBlock make_contact_block(sym3 G, v3 n) {
 // one-contact solve (same decision order as the oracle's solve_contact): separating -> 0; sticking solution
 // inside the cone -> keep; pulling -> frictionless; else slide along the sticking direction with the normal
 // velocity condition kept exact.
-IRRL_DEV v3 solve_contact(const ContactBlock &B, v3 c, v3 n, vf vstar, vf mu) {
+IRRL_DEV v3 solve_contact(const ContactBlock &B, v3 c, v3 n, vf vstar, vf mu, vm relevant) {
   vf cn = dot(c, n) - vstar;
   v3 rhs = mk3(vstar * n.x - c.x, vstar * n.y - c.y, vstar * n.z - c.z);
   v3 l = mul(B.Gi, rhs);
-  vf mcn = -cn;
-  v3 frictionless = (mcn * v_rcp(B.nGn)) * n;
   vf ln = dot(l, n);
   v3 lt = l - ln * n;
   vf lt2 = dot(lt, lt);
   vm sticking = lt2 <= mu * mu * ln * ln;
+  vm sep = cn >= 0.0f;
+#ifndef IRRL_NO_GS_FASTPATH
+  // Common case (feet planted): every contact whose result is kept (`relevant`) presses (cn < 0), pushes (ln > 0) and
+  // stays inside the friction cone -> the sticking solution IS the answer; the sliding / frictionless algebra below
+  // is skipped by a wave-uniform branch.
+  vm plain = (!sep) & sticking & (ln > 0.0f);
+  if (!wave_any(relevant & !plain)) return l;
+#endif
+  vf mcn = -cn;
+  v3 frictionless = (mcn * v_rcp(B.nGn)) * n;
   v3 w = n + (mu * v_rsqrt(lt2)) * lt;
   vf nGw = dot(B.Gn, w);  // n.G w == (G n).w, G symmetric
-  vm sep = cn >= 0.0f;
   vm use_fl = (ln <= 0.0f) | ((!sticking) & (nGw <= 1e-6f * B.nGn));
   v3 slide = (mcn * v_rcp(nGw)) * w;
   v3 r;
@@ -707,6 +714,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
       D.L6[L6I(i, j)] = v * inv;
     }
   }
+#ifdef IRRL_RNEA_SERIAL
   // RNEA: kinematic recursion down the chain, advanced only as far as the own body (sub-lane s stops after body s)
   v3 sq0 = mk3(L.qd[0], 0.0f, 0.0f);
   v3 w = wB + sq0;
@@ -721,6 +729,23 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     al = mk3(vsel(ge2, al2.x, vsel(ge1, al1.x, al.x)), vsel(ge2, al2.y, vsel(ge1, al1.y, al.y)), vsel(ge2, al2.z, vsel(ge1, al1.z, al.z)));
     a = mk3(vsel(ge2, a2.x, vsel(ge1, a1.x, a.x)), vsel(ge2, a2.y, vsel(ge1, a1.y, a.y)), vsel(ge2, a2.z, vsel(ge1, a1.z, a.z)));
   }
+#else
+  // RNEA: kinematic recursion down the chain as PREFIX sums over the sub-lanes.  Joint s contributes
+  //   w += s_s qd_s,   al += w_parent x (s_s qd_s),   a += al_parent x d_s + w_parent x (w_parent x d_s)
+  // with d_s the joint origin relative to the parent's; every lane forms its own joint's terms from its parent's
+  // (w, al) = own prefix minus own term, then two DPP adds per component accumulate them down the chain.
+  v3 sq = qd_s * ax;
+  sq = mk3(vsel(is3, 0.0f, sq.x), vsel(is3, 0.0f, sq.y), vsel(is3, 0.0f, sq.z));   // the spare lane repeats the shank: no joint of its own
+  v3 w = wB + mk3(sub_prefix_sum(sq.x), sub_prefix_sum(sq.y), sub_prefix_sum(sq.z));
+  v3 wp = w - sq;                                              // parent's angular velocity
+  v3 dal = cross(wp, sq);
+  v3 al = mk3(sub_prefix_sum(dal.x), sub_prefix_sum(dal.y), sub_prefix_sum(dal.z));
+  v3 alp = al - dal;                                           // parent's angular acceleration
+  v3 dj = mk3(vsel(is3, 0.0f, PICK3(k.pA.x, k.pT.x - k.pA.x, k.pS.x - k.pT.x)), vsel(is3, 0.0f, PICK3(k.pA.y, k.pT.y - k.pA.y, k.pS.y - k.pT.y)),
+              vsel(is3, 0.0f, PICK3(k.pA.z, k.pT.z - k.pA.z, k.pS.z - k.pT.z)));
+  v3 da = cross(alp, dj) + cross(wp, cross(wp, dj));
+  v3 a = a0 + mk3(sub_prefix_sum(da.x), sub_prefix_sum(da.y), sub_prefix_sum(da.z));
+#endif
   v3 f = m_s * (a + cross(al, rc) + cross(w, cross(w, rc)));
   v3 n0 = mul(IB, al) + cross(w, mul(IB, w)) + cross(c, f);   // moment about the BASE origin: n + (p_s + rc) x f
   v3 F = mk3(sub_suffix_sum(f.x), sub_suffix_sum(f.y), sub_suffix_sum(f.z));
@@ -837,8 +862,8 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
           cvr += gx3[0] * bx + gx3[1] * by + gx3[2] * bz;
         }
         v3 cv = mk3(sub_bcast<0>(cvr), sub_bcast<1>(cvr), sub_bcast<2>(cvr));
-        v3 ln = solve_contact(CB, cv, nB, vstar, L.m.mu);
         vm commit = active & (rank == rk);
+        v3 ln = solve_contact(CB, cv, nB, vstar, L.m.mu, commit);
         v3 dl = mk3(vsel(commit, ln.x - lam.x, 0.0f), vsel(commit, ln.y - lam.y, 0.0f), vsel(commit, ln.z - lam.z, 0.0f));
         lam = lam + dl;
         d2 += dot(dl, dl);
@@ -1028,8 +1053,8 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
         }
         IRRL_GX_APPLY(0) IRRL_GX_APPLY(1) IRRL_GX_APPLY(2) IRRL_GX_APPLY(3)
 #undef IRRL_GX_APPLY
-        v3 ln = solve_contact(CB, cv, nB, vstar, L.m.mu);
         vm commit = active & (rank == rk);
+        v3 ln = solve_contact(CB, cv, nB, vstar, L.m.mu, commit);
         v3 dl = mk3(vsel(commit, ln.x - lam.x, 0.0f), vsel(commit, ln.y - lam.y, 0.0f), vsel(commit, ln.z - lam.z, 0.0f));
         lam = lam + dl;
         d2 += dot(dl, dl);

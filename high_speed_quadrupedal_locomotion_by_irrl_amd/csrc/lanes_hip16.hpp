@@ -52,6 +52,14 @@ template <int K> IRRL_DEV vf sub_bcast(vf x) { return dpp_f<K * 0x55>(x); }     
 template <int K> IRRL_DEV vi sub_bcast_i(vi x) { return dpp_i<K * 0x55>(x); }
 // inclusive suffix sum over the sub-lanes, x_s + ... + x_3; REQUIRES x_3 == 0: quad_perm [1,2,3,3] then [2,3,3,3]
 IRRL_DEV vf sub_suffix_sum(vf x) { x += dpp_f<0xF9>(x); x += dpp_f<0xFE>(x); return x; }
+// inclusive prefix sum over the sub-lanes, x_0 + ... + x_s (quad_perm shifts re-read lane 0, so lanes 0 / 0,1 mask the add)
+IRRL_DEV vf sub_prefix_sum(vf x) {
+  const unsigned s = threadIdx.x & 3u;
+  const float m1 = (s >= 1u) ? 1.0f : 0.0f, m2 = (s >= 2u) ? 1.0f : 0.0f;   // as multipliers: v_fmac_f32_dpp does move+mask+add
+  x = __builtin_fmaf(dpp_f<0x90>(x), m1, x);   // quad_perm [0,0,1,2]: lane s reads lane s-1
+  x = __builtin_fmaf(dpp_f<0x40>(x), m2, x);   // quad_perm [0,0,0,1]: lane s reads lane s-2
+  return x;
+}
 
 // ---- masks / selects ----
 IRRL_DEV vf vsel(vm m, vf a, vf b) { return m ? a : b; }

@@ -207,6 +207,217 @@ lstm_seq_bwd_kernel(const float *__restrict__ gates, const float *__restrict__ c
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// One ROLLOUT step of the whole CustomLSTMPolicy in a single launch (run_bp_v5.py:178-185 `step`): actor stack and
+// critic stack (two LSTM layers each), the action / value heads, the Gaussian sample, its neglogp, the [-1, 1] clip the
+// runner applies (ppo2.py:533-535) and the rollout-buffer rows of step t (ppo2.py:521-531), including the reward row
+// of the PREVIOUS step and the row counter itself, so that a rollout step is exactly two launches (this + env step).
+// A workgroup owns 16 envs; waves [0, NW) run the actor stack, waves [NW, 2 NW) the critic stack, each wave 16 hidden
+// units with their four gates (same MFMA mapping as the sequence kernels).  Weights are read once per workgroup from
+// L2 (all workgroups read the same ~260 KB), the LSTM state [N, 8 HID] is updated in place.
+struct PolicyStepArgs {
+  const float *obs;        // [N, ob_dim]
+  const uint8_t *dones;    // [N] episode ended before this step (mask of the state)
+  const float *states_in;  // [N, 8 HID]: pi0 [c|h], pi1 [c|h], v0 [c|h], v1 [c|h]  (run_bp_v5.py:136-140)
+  float *states_out;       // may alias states_in
+  const float *w[12];      // layer (pi0, pi1, v0, v1) x (wx_p [n_in][HID][4], wh_p [HID][HID][4], b_p [HID][4])
+  const float *pi_w, *pi_b, *vf_w, *vf_b, *logstd;
+  const float *noise;      // [N, act_dim] standard normal, or NULL
+  float *action, *clipped, *value, *neglogp;
+  long long *counters;     // device [3]: rollout row t, global step g, ticket; NULL: no rollout buffers, g = rng_step
+  float *mb_obs, *mb_actions, *mb_values, *mb_neglogp, *mb_rewards;
+  uint8_t *mb_dones;
+  const float *prev_reward;  // [N] reward of the previous env step -> mb_rewards[t-1] (t > 0)
+  long long rng_step;
+  unsigned rng_seed;
+  int rng_on;              // noise == NULL: 1 = counter-RNG sample (Philox keyed like the env's), 0 = deterministic
+  int N, ob_dim, act_dim;
+};
+
+// Philox4x32-10, key (seed, 'IRR1') -- the env engine's generator (env_core.hpp philox_u01): 4 uniforms in [0, 1)
+LSTM_DEV void policy_philox(unsigned seed, unsigned c0, unsigned c1, unsigned c2, unsigned c3, float out[4]) {
+  unsigned k0 = seed, k1 = 0x49525231u;
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    const unsigned hi0 = __umulhi(c0, 0xD2511F53u), lo0 = c0 * 0xD2511F53u;
+    const unsigned hi1 = __umulhi(c2, 0xCD9E8D57u), lo1 = c2 * 0xCD9E8D57u;
+    const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  const float s = 1.0f / 16777216.0f;
+  out[0] = (float)(c0 >> 8) * s; out[1] = (float)(c1 >> 8) * s; out[2] = (float)(c2 >> 8) * s; out[3] = (float)(c3 >> 8) * s;
+}
+#define IRRL_P_POLICY_NOISE 0x50u  /* purpose word of the sampling noise: block q = action index / 4 uses purpose 0x50 + q */
+
+// OBK = k-steps of the observation projection ((ob_dim + 3) / 4) when known at compile time, 0 = runtime loop
+template <int HID, int OBK>
+__global__ void __launch_bounds__(2 * (HID / 16) * 64)
+lstm_policy_step_kernel(PolicyStepArgs a) {
+  constexpr int NW = HID / 16;
+  constexpr int KS = HID / 4;
+  constexpr int LD = HID + 1;
+  constexpr int SD = 8 * HID;
+  __shared__ float hbuf[2][16 * LD];   // per stack: the h of the layer just computed, [env][unit]
+  __shared__ float terms[16][17];
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, l = tid & 63;
+  const int col = l & 15, rq = l >> 4;
+  const int stack = w / NW, ws = w - stack * NW;
+  const int e0 = blockIdx.x * 16;
+  const int u = 16 * ws + col;
+  const long long t = a.counters ? a.counters[0] : 0;
+  const long long gstep = a.counters ? a.counters[1] : a.rng_step;
+  const float keepA = a.dones[e0 + col] ? 0.0f : 1.0f;
+  float keepC[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) keepC[j] = a.dones[e0 + 4 * rq + j] ? 0.0f : 1.0f;
+#pragma unroll
+  for (int layer = 0; layer < 2; layer++) {
+    const int li = stack * 2 + layer;
+    const float *__restrict__ wx = a.w[li * 3 + 0];
+    const float *__restrict__ wh = a.w[li * 3 + 1];
+    const float *__restrict__ b = a.w[li * 3 + 2];
+    const size_t soff = (size_t)li * 2 * HID;
+    // operands that do not depend on the previous layer: issue their loads first
+    float hprev[KS], cprev[4];
+#pragma unroll
+    for (int kk = 0; kk < KS; kk++) hprev[kk] = a.states_in[(size_t)(e0 + col) * SD + soff + HID + 4 * kk + rq];
+#pragma unroll
+    for (int j = 0; j < 4; j++) cprev[j] = a.states_in[(size_t)(e0 + 4 * rq + j) * SD + soff + u];
+    f32x4 acc[4];
+    {
+      const f32x4 b4 = *(const f32x4 *)&b[u * 4];
+#pragma unroll
+      for (int g = 0; g < 4; g++) acc[g] = (f32x4){b4[g], b4[g], b4[g], b4[g]};
+    }
+#pragma unroll
+    for (int kk = 0; kk < KS; kk++) {
+      const float av = hprev[kk] * keepA;
+      const f32x4 bw = *(const f32x4 *)&wh[((size_t)(4 * kk + rq) * HID + u) * 4];
+#pragma unroll
+      for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[g], acc[g], 0, 0, 0);
+    }
+    if (layer == 0) {
+      if (OBK > 0) {
+#pragma unroll
+        for (int kk = 0; kk < OBK; kk++) {
+          const int k = 4 * kk + rq;
+          const bool ok = k < a.ob_dim;
+          const float av = ok ? a.obs[(size_t)(e0 + col) * a.ob_dim + k] : 0.0f;
+          const f32x4 bw = ok ? *(const f32x4 *)&wx[((size_t)k * HID + u) * 4] : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+          for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[g], acc[g], 0, 0, 0);
+        }
+      } else {
+        const int ksx = (a.ob_dim + 3) >> 2;
+        for (int kk = 0; kk < ksx; kk++) {
+          const int k = 4 * kk + rq;
+          const bool ok = k < a.ob_dim;
+          const float av = ok ? a.obs[(size_t)(e0 + col) * a.ob_dim + k] : 0.0f;
+          const f32x4 bw = ok ? *(const f32x4 *)&wx[((size_t)k * HID + u) * 4] : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+          for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[g], acc[g], 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < KS; kk++) {
+        const float av = hbuf[stack][col * LD + 4 * kk + rq];
+        const f32x4 bw = *(const f32x4 *)&wx[((size_t)(4 * kk + rq) * HID + u) * 4];
+#pragma unroll
+        for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[g], acc[g], 0, 0, 0);
+      }
+    }
+    // every wave has read the previous h of this layer (and, for layer 1, the hbuf rows of layer 0) before anyone
+    // overwrites them: states_out may alias states_in
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float ig = fast_sigmoid(acc[0][j]), fg = fast_sigmoid(acc[1][j]), og = fast_sigmoid(acc[2][j]), gg = fast_tanh(acc[3][j]);
+      const float cn = fg * (cprev[j] * keepC[j]) + ig * gg;
+      const float hn = og * fast_tanh(cn);
+      const size_t row = (size_t)(e0 + 4 * rq + j) * SD + soff;
+      a.states_out[row + u] = cn;
+      a.states_out[row + HID + u] = hn;
+      hbuf[stack][(4 * rq + j) * LD + u] = hn;
+    }
+    __syncthreads();
+  }
+  // heads: thread (env, action) for the mean / sample, 16 more threads for the value and the neglogp sum
+  const int A = a.act_dim;
+  if (tid < 16 * A) {
+    const int env = tid / A, ai = tid - env * A;
+    float mean = a.pi_b[ai];
+#pragma unroll 8
+    for (int k = 0; k < HID; k++) mean = __builtin_fmaf(hbuf[0][env * LD + k], a.pi_w[k * A + ai], mean);
+    const float ls = a.logstd[ai];
+    const float sd = __expf(ls);
+    const size_t o = (size_t)(e0 + env) * A + ai;
+    float z = 0.0f;
+    if (a.noise) {
+      z = a.noise[o];
+    } else if (a.rng_on) {
+      float r[4];
+      policy_philox(a.rng_seed, (unsigned)(e0 + env), (unsigned)((unsigned long long)gstep >> 32), (unsigned)gstep, IRRL_P_POLICY_NOISE + (unsigned)(ai >> 2), r);
+      // Box-Muller on the pair (r0, r1) for slots 0/1 and (r2, r3) for slots 2/3; 1 - u is in (0, 1]
+      const int pair = (ai >> 1) & 1;
+      const float ua = pair ? r[2] : r[0], ub = pair ? r[3] : r[1];
+      const float rad = __builtin_sqrtf(-2.0f * __logf(1.0f - ua));
+      const float ang = 6.283185307179586f * ub;
+      z = rad * ((ai & 1) ? __sinf(ang) : __cosf(ang));
+    }
+    const float act = mean + sd * z;
+    const float d = (act - mean) / sd;
+    terms[env][ai] = 0.5f * d * d + ls;
+    const float cl = fminf(fmaxf(act, -1.0f), 1.0f);
+    a.action[o] = act;
+    a.clipped[o] = cl;
+    if (a.mb_actions) a.mb_actions[(size_t)t * a.N * A + o] = act;
+  }
+  float val = 0.0f;
+  const int vt = tid - 16 * A;
+  if (vt >= 0 && vt < 16) {
+    val = a.vf_b[0];
+#pragma unroll 8
+    for (int k = 0; k < HID; k++) val = __builtin_fmaf(hbuf[1][vt * LD + k], a.vf_w[k], val);
+  }
+  __syncthreads();
+  if (vt >= 0 && vt < 16) {
+    float nl = 0.0f;
+    for (int ai = 0; ai < A; ai++) nl += terms[vt][ai];
+    nl += 0.918938533204672742f * (float)A;   // 0.5 log(2 pi) per action dimension
+    const int e = e0 + vt;
+    a.value[e] = val;
+    a.neglogp[e] = nl;
+    if (a.mb_values) {
+      a.mb_values[(size_t)t * a.N + e] = val;
+      a.mb_neglogp[(size_t)t * a.N + e] = nl;
+      a.mb_dones[(size_t)t * a.N + e] = a.dones[e];
+      if (a.prev_reward && t > 0) a.mb_rewards[(size_t)(t - 1) * a.N + e] = a.prev_reward[e];
+    }
+  }
+  if (a.mb_obs) {
+    const int n = 16 * a.ob_dim;
+    const float *src = a.obs + (size_t)e0 * a.ob_dim;
+    float *dst = a.mb_obs + ((size_t)t * a.N + e0) * a.ob_dim;
+    for (int i = tid; i < n; i += blockDim.x) dst[i] = src[i];
+  }
+  if (a.counters) {
+    // the workgroup that finishes last advances the row / step counters: every workgroup read them at its start,
+    // i.e. before it took its ticket
+    if (tid == 0) {
+      __threadfence();
+      const unsigned long long tk = atomicAdd((unsigned long long *)&a.counters[2], 1ull);
+      if (tk == (unsigned long long)gridDim.x - 1ull) {
+        a.counters[2] = 0;
+        a.counters[0] = t + 1;
+        a.counters[1] = gstep + 1;
+      }
+    }
+  }
+}
+
 extern "C" {
 
 // returns 0 on success; 1 = unsupported shape, 2 = launch error
@@ -229,6 +440,45 @@ int irrl_lstm_seq_backward(int hid, int T, int N, const float *gates, const floa
   else if (hid == 32) hipLaunchKernelGGL(lstm_seq_bwd_kernel<32>, dim3(N / 16), dim3(128), 0, s, gates, cseq, masks, state0, dh_in, wh_p, dz, T, N);
   else if (hid == 64) hipLaunchKernelGGL(lstm_seq_bwd_kernel<64>, dim3(N / 16), dim3(256), 0, s, gates, cseq, masks, state0, dh_in, wh_p, dz, T, N);
   else return 1;
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+// One rollout step of the two-stack LSTM policy (see PolicyStepArgs).  lstm_w: HOST array of 12 device pointers.
+// returns 0 on success; 1 = unsupported shape, 2 = launch error
+int irrl_lstm_policy_step(int hid, int ob_dim, int act_dim, int N, const float *obs, const uint8_t *dones, const float *states_in,
+                          float *states_out, const float *const *lstm_w, const float *pi_w, const float *pi_b, const float *vf_w,
+                          const float *vf_b, const float *logstd, const float *noise, int rng_on, unsigned rng_seed, long long rng_step,
+                          float *action, float *clipped, float *value, float *neglogp, long long *counters, float *mb_obs,
+                          float *mb_actions, float *mb_values, float *mb_neglogp, uint8_t *mb_dones, float *mb_rewards,
+                          const float *prev_reward, void *hip_stream) {
+  if (N <= 0 || (N % 16) != 0 || ob_dim <= 0 || act_dim <= 0 || act_dim > 16) return 1;
+  const int threads = 2 * (hid / 16) * 64;
+  if (16 * act_dim + 16 > threads) return 1;
+  PolicyStepArgs a;
+  a.obs = obs; a.dones = dones; a.states_in = states_in; a.states_out = states_out;
+  for (int i = 0; i < 12; i++) a.w[i] = lstm_w[i];
+  a.pi_w = pi_w; a.pi_b = pi_b; a.vf_w = vf_w; a.vf_b = vf_b; a.logstd = logstd; a.noise = noise;
+  a.action = action; a.clipped = clipped; a.value = value; a.neglogp = neglogp;
+  a.counters = counters;
+  const bool rows = counters != nullptr;
+  a.mb_obs = rows ? mb_obs : nullptr; a.mb_actions = rows ? mb_actions : nullptr; a.mb_values = rows ? mb_values : nullptr;
+  a.mb_neglogp = rows ? mb_neglogp : nullptr; a.mb_dones = rows ? mb_dones : nullptr; a.mb_rewards = rows ? mb_rewards : nullptr;
+  a.prev_reward = (rows && mb_rewards) ? prev_reward : nullptr;
+  if (rows && !(mb_obs && mb_actions && mb_values && mb_neglogp && mb_dones)) return 1;
+  a.rng_step = rng_step; a.rng_seed = rng_seed; a.rng_on = rng_on;
+  a.N = N; a.ob_dim = ob_dim; a.act_dim = act_dim;
+  hipStream_t s = (hipStream_t)hip_stream;
+  const int obk = (ob_dim + 3) / 4;
+#define IRRL_PS_LAUNCH(H) \
+  do { \
+    if (obk == 9) hipLaunchKernelGGL((lstm_policy_step_kernel<H, 9>), dim3(N / 16), dim3(threads), 0, s, a); \
+    else hipLaunchKernelGGL((lstm_policy_step_kernel<H, 0>), dim3(N / 16), dim3(threads), 0, s, a); \
+  } while (0)
+  if (hid == 48) IRRL_PS_LAUNCH(48);
+  else if (hid == 32) IRRL_PS_LAUNCH(32);
+  else if (hid == 64) IRRL_PS_LAUNCH(64);
+  else return 1;
+#undef IRRL_PS_LAUNCH
   return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

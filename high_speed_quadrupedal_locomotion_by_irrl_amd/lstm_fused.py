@@ -8,6 +8,7 @@ backward: `irrl_lstm_seq_backward` walks the sequence in reverse and emits dz [T
 Semantics = stable-baselines `lstm` (policies.SBLstm.sequence is the eager definition the tests compare with).
 """
 import ctypes as C
+import weakref
 
 import torch
 
@@ -42,6 +43,8 @@ def _permuted_weights(wx, wh, b, perm):
     key = (wx.data_ptr(), wh.data_ptr(), b.data_ptr())
     ver = (wx._version, wh._version, b._version)
     hit = _WCACHE.get(key)
+    if hit is not None and hit[2]() is None:
+        hit = None   # the parameter these copies were made from is gone: another tensor now lives at its address
     if hit is not None and hit[0] == ver:
         return hit[1]
     with torch.no_grad():
@@ -53,7 +56,7 @@ def _permuted_weights(wx, wh, b, perm):
             torch.index_select(b, 0, perm, out=out[2])
         else:
             out = (wx[:, perm].contiguous(), wh[:, perm].contiguous(), b[perm].contiguous())
-    _WCACHE[key] = (ver, out)
+    _WCACHE[key] = (ver, out, weakref.ref(wx))
     return out
 
 
@@ -145,3 +148,56 @@ def lstm_sequence(x, wx, wh, b, state0, masks):
 
 def supported(x, hid):
     return x.is_cuda and x.dtype == torch.float32 and hid in (32, 48, 64)
+
+
+# ---- the whole policy step of a rollout in one launch (csrc/lstm_kernels.hip: lstm_policy_step_kernel) ----
+def policy_step_supported(policy, obs):
+    n = policy.n_lstm
+    return (obs.is_cuda and obs.dtype == torch.float32 and len(n) == 2 and n[0] == n[1] and n[0] in (32, 48, 64)
+            and obs.shape[0] % 16 == 0 and 16 * policy.act_dim + 16 <= 8 * n[0] and policy.act_dim <= 16)
+
+
+def policy_step(policy, obs, states, dones, noise=None, rng=None, states_out=None, rollout=None):
+    """obs [N,ob], states [N,8H], dones [N] bool/u8 -> action, clipped, value, neglogp, states_out.
+    Sampling: `noise` [N,act] if given; else rng = (seed, step) draws it in the kernel (counter RNG); else deterministic.
+    `rollout` = dict(counters int64[3] (row t, global step, 0), mb_obs, mb_actions, mb_values, mb_neglogpacs, mb_dones,
+    and optionally mb_rewards + prev_reward): row t of each buffer is written, the reward of the previous step goes to row
+    t-1, and the counters advance; the kernel's RNG step is then counters[1]."""
+    lib = _lib.load()
+    N, ob_dim = obs.shape
+    hid, act = policy.n_lstm[0], policy.act_dim
+    dev = obs.device
+    perm = _perm(hid, dev)[0]
+    ptrs = []
+    keep = []
+    for l in list(policy.lstm_pi) + list(policy.lstm_v):
+        wx_p, wh_p, b_p = _permuted_weights(l.wx, l.wh, l.b, perm)
+        keep += [wx_p, wh_p, b_p]
+        ptrs += [wx_p.data_ptr(), wh_p.data_ptr(), b_p.data_ptr()]
+    warr = (C.c_void_p * 12)(*ptrs)
+    obs = obs.contiguous()
+    states = states.contiguous()
+    if states_out is None:
+        states_out = torch.empty_like(states)
+    assert states_out.is_contiguous() and dones.is_contiguous() and dones.element_size() == 1
+    action = torch.empty(N, act, device=dev)
+    clipped = torch.empty(N, act, device=dev)
+    value = torch.empty(N, device=dev)
+    neglogp = torch.empty(N, device=dev)
+    if noise is not None:
+        noise = noise.contiguous()
+    rng_on, seed, step = (1, int(rng[0]) & 0xFFFFFFFF, int(rng[1])) if (rng is not None and noise is None) else (0, 0, 0)
+    if rollout is not None:
+        opt = lambda k: _ptr(rollout[k]) if rollout.get(k) is not None else None
+        rptr = [_ptr(rollout["counters"]), _ptr(rollout["mb_obs"]), _ptr(rollout["mb_actions"]), _ptr(rollout["mb_values"]),
+                _ptr(rollout["mb_neglogpacs"]), _ptr(rollout["mb_dones"]), opt("mb_rewards"), opt("prev_reward")]
+    else:
+        rptr = [None] * 8
+    rc = lib.irrl_lstm_policy_step(hid, ob_dim, act, N, _ptr(obs), _ptr(dones), _ptr(states), _ptr(states_out), warr,
+                                   _ptr(policy.pi.w), _ptr(policy.pi.b), _ptr(policy.vf.w), _ptr(policy.vf.b), _ptr(policy.logstd),
+                                   _ptr(noise) if noise is not None else None, rng_on, seed, step,
+                                   _ptr(action), _ptr(clipped), _ptr(value), _ptr(neglogp),
+                                   *rptr, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise RuntimeError("irrl_lstm_policy_step failed (rc=%d)" % rc)
+    return action, clipped, value, neglogp, states_out

@@ -180,9 +180,28 @@ class CustomLSTMPolicy(ActorCriticPolicy):
         value = self.vf(latent_v).squeeze(-1)
         return mean, value, torch.cat(new, 1)
 
+    def fused_step_supported(self, obs):
+        if not (obs.is_cuda and SBLstm.use_fused):
+            return False
+        from . import lstm_fused
+        return lstm_fused.policy_step_supported(self, obs)
+
+    @torch.no_grad()
+    def fused_step(self, obs, states, dones, noise=None, rng=None, states_out=None, rollout=None):
+        """The whole step in ONE kernel launch (both stacks, heads, sample, neglogp, clip, rollout-buffer rows):
+        -> action, clipped action, value, neglogp, new states (written to `states_out`, which may be `states`).
+        See lstm_fused.policy_step for `noise` / `rng` / `rollout`."""
+        from . import lstm_fused
+        d = dones if dones.element_size() == 1 else (dones != 0)
+        return lstm_fused.policy_step(self, obs, states, d.contiguous(), noise=noise, rng=rng, states_out=states_out, rollout=rollout)
+
     @torch.no_grad()
     def step(self, obs, states, masks, deterministic=False, generator=None):
         """run_bp_v5.py:178-185: -> action (unclipped sample), value, new states, neglogp."""
+        if self.fused_step_supported(obs):
+            noise = None if deterministic else torch.randn((obs.shape[0], self.act_dim), device=obs.device, dtype=obs.dtype, generator=generator)
+            action, _, value, neglogp, snew = self.fused_step(obs, states, masks, noise=noise)
+            return action, value, snew, neglogp
         mean, value, snew = self._run(obs.unsqueeze(0), states, masks.to(obs.dtype).unsqueeze(0))
         mean, value = mean[0], value[0]
         if deterministic:

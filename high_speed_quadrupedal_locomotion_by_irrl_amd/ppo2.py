@@ -103,16 +103,36 @@ class Runner(object):
         self.mb_neglogpacs = torch.zeros(T, n, device=dev)
         self.mb_dones = torch.zeros(T, n, dtype=torch.bool, device=dev)
         self.mb_rewards = torch.zeros(T, n, device=dev)
-        self.t_idx = torch.zeros(1, dtype=torch.long, device=dev)
+        self.counters = torch.zeros(3, dtype=torch.long, device=dev)   # rollout row t, global step (RNG counter), ticket
+        self.t_idx = self.counters[0:1]
         self.use_graph = (dev.type == "cuda") if use_graph is None else bool(use_graph)
         self._graph = None
         # sampling noise: the model's seeded generator; under graph capture it is registered with the graph
         self._gen = model.generator
+        # single-launch policy step + raw env step when the policy / env pair supports it (LSTM policy on the GPU)
+        self._fused = bool(hasattr(model.policy, "fused_step_supported") and hasattr(env, "step_into")
+                           and model.policy.fused_step_supported(self.obs))
+        self.rew = torch.zeros(n, device=dev)
+        # sampling noise of the fused path: "kernel" = the engine's counter RNG inside the policy kernel (no extra launch),
+        # "torch" = torch.randn from the model's generator (what the generic path uses; tests compare the two paths with it)
+        self.noise_source = "kernel"
+        self._rollout = dict(counters=self.counters, mb_obs=self.mb_obs, mb_actions=self.mb_actions, mb_values=self.mb_values,
+                             mb_neglogpacs=self.mb_neglogpacs, mb_dones=self.mb_dones, mb_rewards=self.mb_rewards, prev_reward=self.rew)
 
     def _one_step(self):
         """One rollout step with every index on the device, so the same sequence of kernels can be replayed from a
         hipGraph: policy step -> buffer rows [t] -> clip -> env.step -> obs/dones update -> t += 1."""
         pol = self.model.policy
+        if self._fused:
+            # two launches: the whole policy step (sample, clip, buffer rows incl. the previous reward, row counter) and
+            # the env step, which writes obs / reward / dones straight into the runner's tensors
+            noise = None
+            if self.noise_source == "torch":
+                noise = torch.randn((self.obs.shape[0], self.mb_actions.shape[2]), device=self.obs.device, dtype=self.obs.dtype, generator=self._gen)
+            _, clipped, _, _, _ = pol.fused_step(self.obs, self.states, self.dones, noise=noise, rng=(self.model.noise_seed, 0),
+                                                 states_out=self.states, rollout=self._rollout)
+            self.env.step_into(clipped, self.obs, self.rew, self.dones)
+            return
         actions, values, states, neglogpacs = pol.step(self.obs, self.states, self.dones, generator=self._gen)
         self.mb_obs.index_copy_(0, self.t_idx, self.obs.unsqueeze(0))
         self.mb_actions.index_copy_(0, self.t_idx, actions.unsqueeze(0))
@@ -137,9 +157,15 @@ class Runner(object):
         try:
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
+            # the warm-up steps are real env steps (the rollout simply continues from there) but must not leak into the
+            # episode statistics of the first rollout
+            stat_names = ("ep_ret", "ep_len", "finished_ret_sum", "finished_len_sum", "finished_count")
+            stats = [(getattr(self.env, k), getattr(self.env, k).clone()) for k in stat_names if hasattr(self.env, k)]
             with torch.cuda.stream(side):
                 for _ in range(3):
                     self._one_step()
+                for live, saved in stats:
+                    live.copy_(saved)
             torch.cuda.current_stream(dev).wait_stream(side)
             self.t_idx.zero_()
             g = torch.cuda.CUDAGraph()
@@ -168,10 +194,17 @@ class Runner(object):
                 self._graph.replay()
             else:
                 self._one_step()
+        if self._fused:
+            self.mb_rewards[self.n_steps - 1].copy_(self.rew)       # rows 0 .. T-2 were written by the following policy step
         last_values = pol.value(self.obs, self.states, self.dones)
         advs, returns = gae(self.mb_rewards, self.mb_values, self.mb_dones, last_values, self.dones, self.gamma, self.lam)
         # resetting environments (ppo2.py:577); LSTM states and dones deliberately survive
-        self.obs.copy_(self.env.reset_and_update_info())
+        if self._fused:
+            n_done = self.mb_dones[1:].sum() + self.dones.sum()
+            self.env.account_rollout(self.mb_rewards.sum(), float(self.n_steps * self.env.num_envs), n_done + float(self.env.num_envs))
+            self.obs.copy_(self.env.reset())
+        else:
+            self.obs.copy_(self.env.reset_and_update_info())
         return dict(obs=self.mb_obs, returns=returns, masks=self.mb_dones, actions=self.mb_actions, values=self.mb_values,
                     neglogpacs=self.mb_neglogpacs, states=mb_states if pol.recurrent else None, true_reward=self.mb_rewards)
 
@@ -206,6 +239,7 @@ class PPO2(object):
         self.policy.to(self.device)
         self.generator = torch.Generator(device=self.device)
         self.generator.manual_seed(self.seed * 1000003 + 7919 * self.rank + 1)
+        self.noise_seed = (self.seed * 1000003 + 7919 * self.rank + 1) & 0xFFFFFFFF   # key of the in-kernel sampling noise
         adam_kw = dict(lr=float(learning_rate) if not callable(learning_rate) else 1e-3, eps=1e-5, betas=(0.9, 0.999))
         try:  # one fused kernel over the 19 parameter tensors on the GPU
             self.optimizer = torch.optim.Adam(self.policy.parameters(), fused=(self.device.type == "cuda"), **adam_kw)

@@ -213,6 +213,18 @@ class TorchVecEnv(object):
         self.ep_len *= (1.0 - d)
         return self.obs, self.reward, self.done
 
+    def step_into(self, action, obs, reward, done):
+        """step() writing straight into the caller's tensors and WITHOUT the per-step episode bookkeeping (one launch);
+        the caller accounts whole rollouts with `account_rollout`."""
+        self.wrapper.step(action, obs, reward, done, self.extra)
+
+    def account_rollout(self, reward_sum, n_steps, n_episodes):
+        """Episode statistics of a whole rollout that ends with a global reset: every episode is counted exactly once
+        (finished ones plus the N cut off by the reset), so the sums are just the rollout's totals."""
+        self.finished_ret_sum += reward_sum
+        self.finished_len_sum += n_steps
+        self.finished_count += n_episodes
+
     def reset(self):
         self.wrapper.reset(self.obs)
         return self.obs

@@ -137,6 +137,26 @@ int irrl_lstm_seq_forward(int hid, int T, int N, const float *zx, const float *w
 int irrl_lstm_seq_backward(int hid, int T, int N, const float *gates, const float *cseq, const float *masks, const float *state0,
                            const float *dh_in, const float *wh_p, float *dz, void *hip_stream);
 
+/* ---- one ROLLOUT step of CustomLSTMPolicy in a single launch (run_bp_v5.py:178-185 `step`; the runner's clip and
+ * buffer rows, ppo2.py:521-535).  Two stacks (actor, critic) of two LSTM layers of `hid` units, heads pi [hid,act],
+ * vf [hid,1], logstd [act].  lstm_w is a HOST array of 12 device pointers: for layer in (pi0, pi1, v0, v1):
+ * wx_p [n_in][hid][4], wh_p [hid][hid][4], b_p [hid][4] (gate columns in [unit][gate] order).  states [N, 8 hid] =
+ * pi0 [c|h], pi1 [c|h], v0 [c|h], v1 [c|h]; states_out may alias states_in.
+ * Sampling noise: `noise` [N,act] ~ N(0,1) if not NULL; else rng_on = 1 draws it in the kernel from the engine's
+ * counter RNG (Philox4x32-10, key (rng_seed,'IRR1'), counter (env, step >> 32, step, 0x50 + a/4), Box-Muller on the
+ * pairs (u0,u1), (u2,u3)); else deterministic (action = mean).
+ * Outputs action (unclipped sample), clipped (to [-1,1]), value [N], neglogp [N].  With `counters` (device int64[3] =
+ * rollout row t, global step g, scratch ticket = 0) also row t of mb_obs [T,N,ob], mb_actions [T,N,act], mb_values /
+ * mb_neglogp [T,N], mb_dones [T,N] u8, and, if mb_rewards and prev_reward [N] are given and t > 0, row t-1 of
+ * mb_rewards; then t and g are advanced by one (g is the RNG step; without counters it is rng_step).
+ * N % 16 == 0, hid in {32,48,64}, 16 act + 16 <= 8 hid. */
+int irrl_lstm_policy_step(int hid, int ob_dim, int act_dim, int N, const float *obs, const uint8_t *dones, const float *states_in,
+                          float *states_out, const float *const *lstm_w, const float *pi_w, const float *pi_b, const float *vf_w,
+                          const float *vf_b, const float *logstd, const float *noise, int rng_on, unsigned rng_seed, long long rng_step,
+                          float *action, float *clipped, float *value, float *neglogp, long long *counters, float *mb_obs,
+                          float *mb_actions, float *mb_values, float *mb_neglogp, uint8_t *mb_dones, float *mb_rewards,
+                          const float *prev_reward, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -101,6 +101,13 @@ inline vf sub_suffix_sum(vf x) {
   for (int i = 0; i < 16; i++) r.v[i] = a.v[i] + a.v[(i & ~3) | p2[i & 3]];
   return r;
 }
+// inclusive prefix sum over the sub-lanes (sub-lane s gets x_0 + .. + x_s)
+inline vf sub_prefix_sum(vf x) {
+  vf a, r;
+  for (int i = 0; i < 16; i++) a.v[i] = x.v[i] + (((i & 3) >= 1) ? x.v[i - 1] : 0.0f);
+  for (int i = 0; i < 16; i++) r.v[i] = a.v[i] + (((i & 3) >= 2) ? a.v[i - 2] : 0.0f);
+  return r;
+}
 #endif
 inline vf vsel(vm m, vf a, vf b) { vf r; for (int i = 0; i < W; i++) r.v[i] = m.v[i] ? a.v[i] : b.v[i]; return r; }
 inline vi vsel_i(vm m, vi a, vi b) { vi r; for (int i = 0; i < W; i++) r.v[i] = m.v[i] ? a.v[i] : b.v[i]; return r; }

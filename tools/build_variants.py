@@ -1,0 +1,25 @@
+"""Build A/B variants of libirrl_env.so (same ABI, different -D switches) into csrc/_variants/ for one-call GPU comparisons.
+usage: python tools/build_variants.py name=-DFLAG[,-DFLAG2] ...   (name 'base' = no extra flags)"""
+import os, subprocess, sys
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from high_speed_quadrupedal_locomotion_by_irrl_amd import build as B
+
+out = os.path.join(B.CSRC, "_variants")
+os.makedirs(out, exist_ok=True)
+for spec in sys.argv[1:]:
+    name, _, flags = spec.partition("=")
+    flags = [f for f in flags.split(",") if f]
+    objs = []
+    procs = []
+    common = [B.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-fno-signed-zeros"] + flags
+    for src, fl, obj in (("env_kernels.hip", ["-DIRRL_LANES_PER_ROBOT=16"], "l16"), ("env_kernels.hip", ["-DIRRL_LANES_PER_ROBOT=4"], "l4"),
+                         ("irrl_env_abi.hip", [], "abi")):
+        o = os.path.join(out, f"{name}_{obj}.o")
+        objs.append(o)
+        procs.append(subprocess.Popen(common + fl + ["-c", os.path.join(B.CSRC, src), "-o", o]))
+    assert all(p.wait() == 0 for p in procs)
+    lib = os.path.join(out, f"libirrl_env_{name}.so")
+    subprocess.check_call([B.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib])
+    for o in objs:
+        os.remove(o)
+    print(lib)
