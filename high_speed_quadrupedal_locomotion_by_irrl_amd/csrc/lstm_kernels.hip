@@ -211,7 +211,8 @@ lstm_seq_bwd_kernel(const float *__restrict__ gates, const float *__restrict__ c
 // One ROLLOUT step of the whole CustomLSTMPolicy in a single launch (run_bp_v5.py:178-185 `step`): actor stack and
 // critic stack (two LSTM layers each), the action / value heads, the Gaussian sample, its neglogp, the [-1, 1] clip the
 // runner applies (ppo2.py:533-535) and the rollout-buffer rows of step t (ppo2.py:521-531), including the reward row
-// of the PREVIOUS step and the row counter itself, so that a rollout step is exactly two launches (this + env step).
+// of the PREVIOUS step, so that a rollout step is exactly two launches (this + env step); the row index is a launch
+// argument (the runner captures the whole rollout, one node pair per step, into a hipGraph).
 // A workgroup owns 16 envs; waves [0, NW) run the actor stack, waves [NW, 2 NW) the critic stack, each wave 16 hidden
 // units with their four gates (same MFMA mapping as the sequence kernels).  Weights are read once per workgroup from
 // L2 (all workgroups read the same ~260 KB), the LSTM state [N, 8 HID] is updated in place.
@@ -224,7 +225,8 @@ struct PolicyStepArgs {
   const float *pi_w, *pi_b, *vf_w, *vf_b, *logstd;
   const float *noise;      // [N, act_dim] standard normal, or NULL
   float *action, *clipped, *value, *neglogp;
-  long long *counters;     // device [3]: rollout row t, global step g, ticket; NULL: no rollout buffers, g = rng_step
+  long long row;           // rollout row t written in the mb_* buffers, or -1: none
+  const long long *rng_base;  // device scalar added to rng_step (e.g. steps of all earlier rollouts), or NULL
   float *mb_obs, *mb_actions, *mb_values, *mb_neglogp, *mb_rewards;
   uint8_t *mb_dones;
   const float *prev_reward;  // [N] reward of the previous env step -> mb_rewards[t-1] (t > 0)
@@ -250,6 +252,7 @@ LSTM_DEV void policy_philox(unsigned seed, unsigned c0, unsigned c1, unsigned c2
 }
 #define IRRL_P_POLICY_NOISE 0x50u  /* purpose word of the sampling noise: block q = action index / 4 uses purpose 0x50 + q */
 
+#define PS_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b_, c_, 0, 0, 0)
 // OBK = k-steps of the observation projection ((ob_dim + 3) / 4) when known at compile time, 0 = runtime loop
 template <int HID, int OBK>
 __global__ void __launch_bounds__(2 * (HID / 16) * 64)
@@ -260,97 +263,136 @@ lstm_policy_step_kernel(PolicyStepArgs a) {
   constexpr int SD = 8 * HID;
   __shared__ float hbuf[2][16 * LD];   // per stack: the h of the layer just computed, [env][unit]
   __shared__ float terms[16][17];
+  __shared__ float head_w[HID * 17];   // pi_w [HID][act] then vf_w [HID]: staged once, read by the head threads
   const int tid = threadIdx.x;
   const int w = tid >> 6, l = tid & 63;
   const int col = l & 15, rq = l >> 4;
   const int stack = w / NW, ws = w - stack * NW;
   const int e0 = blockIdx.x * 16;
   const int u = 16 * ws + col;
-  const long long t = a.counters ? a.counters[0] : 0;
-  const long long gstep = a.counters ? a.counters[1] : a.rng_step;
+  const long long t = a.row;
+  const long long gstep = a.rng_step + (a.rng_base ? *a.rng_base : 0ll);
   const float keepA = a.dones[e0 + col] ? 0.0f : 1.0f;
   float keepC[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) keepC[j] = a.dones[e0 + 4 * rq + j] ? 0.0f : 1.0f;
+  for (int i = tid; i < HID * a.act_dim; i += blockDim.x) head_w[i] = a.pi_w[i];
+  if (tid < HID) head_w[HID * a.act_dim + tid] = a.vf_w[tid];
+  // Everything that does not depend on layer 0's output is requested up front, in program order, so that the L2 / HBM
+  // latency of ~60 independent loads overlaps instead of being paid once per k-step: both layers' previous h and c,
+  // the observation slice, wh of both layers and wx of layer 0.  The recurrent half of layer 1 is accumulated before
+  // layer 0's cell math; only h0 wx1 has to wait for it.
+  // selects between kernel arguments (scalar registers), not an indexed load of the argument block
+  const float *__restrict__ wx0 = stack ? a.w[6] : a.w[0], *__restrict__ wh0 = stack ? a.w[7] : a.w[1], *__restrict__ b0 = stack ? a.w[8] : a.w[2];
+  const float *__restrict__ wx1 = stack ? a.w[9] : a.w[3], *__restrict__ wh1 = stack ? a.w[10] : a.w[4], *__restrict__ b1 = stack ? a.w[11] : a.w[5];
+  const size_t soff0 = (size_t)(stack * 2 + 0) * 2 * HID, soff1 = (size_t)(stack * 2 + 1) * 2 * HID;
+  constexpr int OBKC = OBK > 0 ? OBK : 1;
+  float hp0[KS], hp1[KS], cp0[4], cp1[4], ob[OBKC];
+  f32x4 Wh0[KS], Wh1[KS], Wx0[OBKC];
 #pragma unroll
-  for (int layer = 0; layer < 2; layer++) {
-    const int li = stack * 2 + layer;
-    const float *__restrict__ wx = a.w[li * 3 + 0];
-    const float *__restrict__ wh = a.w[li * 3 + 1];
-    const float *__restrict__ b = a.w[li * 3 + 2];
-    const size_t soff = (size_t)li * 2 * HID;
-    // operands that do not depend on the previous layer: issue their loads first
-    float hprev[KS], cprev[4];
+  for (int kk = 0; kk < KS; kk++) hp0[kk] = a.states_in[(size_t)(e0 + col) * SD + soff0 + HID + 4 * kk + rq];
+  if (OBK > 0) {
 #pragma unroll
-    for (int kk = 0; kk < KS; kk++) hprev[kk] = a.states_in[(size_t)(e0 + col) * SD + soff + HID + 4 * kk + rq];
-#pragma unroll
-    for (int j = 0; j < 4; j++) cprev[j] = a.states_in[(size_t)(e0 + 4 * rq + j) * SD + soff + u];
-    f32x4 acc[4];
-    {
-      const f32x4 b4 = *(const f32x4 *)&b[u * 4];
-#pragma unroll
-      for (int g = 0; g < 4; g++) acc[g] = (f32x4){b4[g], b4[g], b4[g], b4[g]};
+    for (int kk = 0; kk < OBKC; kk++) {
+      const int k = 4 * kk + rq, kc = k < a.ob_dim ? k : a.ob_dim - 1;   // clamped: the load is unconditional, the value masked
+      ob[kk] = a.obs[(size_t)(e0 + col) * a.ob_dim + kc];
     }
-#pragma unroll
-    for (int kk = 0; kk < KS; kk++) {
-      const float av = hprev[kk] * keepA;
-      const f32x4 bw = *(const f32x4 *)&wh[((size_t)(4 * kk + rq) * HID + u) * 4];
-#pragma unroll
-      for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[g], acc[g], 0, 0, 0);
-    }
-    if (layer == 0) {
-      if (OBK > 0) {
-#pragma unroll
-        for (int kk = 0; kk < OBK; kk++) {
-          const int k = 4 * kk + rq;
-          const bool ok = k < a.ob_dim;
-          const float av = ok ? a.obs[(size_t)(e0 + col) * a.ob_dim + k] : 0.0f;
-          const f32x4 bw = ok ? *(const f32x4 *)&wx[((size_t)k * HID + u) * 4] : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-          for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[g], acc[g], 0, 0, 0);
-        }
-      } else {
-        const int ksx = (a.ob_dim + 3) >> 2;
-        for (int kk = 0; kk < ksx; kk++) {
-          const int k = 4 * kk + rq;
-          const bool ok = k < a.ob_dim;
-          const float av = ok ? a.obs[(size_t)(e0 + col) * a.ob_dim + k] : 0.0f;
-          const f32x4 bw = ok ? *(const f32x4 *)&wx[((size_t)k * HID + u) * 4] : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-          for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[g], acc[g], 0, 0, 0);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int kk = 0; kk < KS; kk++) {
-        const float av = hbuf[stack][col * LD + 4 * kk + rq];
-        const f32x4 bw = *(const f32x4 *)&wx[((size_t)(4 * kk + rq) * HID + u) * 4];
-#pragma unroll
-        for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[g], acc[g], 0, 0, 0);
-      }
-    }
-    // every wave has read the previous h of this layer (and, for layer 1, the hbuf rows of layer 0) before anyone
-    // overwrites them: states_out may alias states_in
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const float ig = fast_sigmoid(acc[0][j]), fg = fast_sigmoid(acc[1][j]), og = fast_sigmoid(acc[2][j]), gg = fast_tanh(acc[3][j]);
-      const float cn = fg * (cprev[j] * keepC[j]) + ig * gg;
-      const float hn = og * fast_tanh(cn);
-      const size_t row = (size_t)(e0 + 4 * rq + j) * SD + soff;
-      a.states_out[row + u] = cn;
-      a.states_out[row + HID + u] = hn;
-      hbuf[stack][(4 * rq + j) * LD + u] = hn;
-    }
-    __syncthreads();
   }
+#pragma unroll
+  for (int kk = 0; kk < KS; kk++) Wh0[kk] = *(const f32x4 *)&wh0[((size_t)(4 * kk + rq) * HID + u) * 4];
+  if (OBK > 0) {
+#pragma unroll
+    for (int kk = 0; kk < OBKC; kk++) {
+      const int k = 4 * kk + rq, kc = k < a.ob_dim ? k : a.ob_dim - 1;
+      Wx0[kk] = *(const f32x4 *)&wx0[((size_t)kc * HID + u) * 4];
+    }
+  }
+#pragma unroll
+  for (int kk = 0; kk < KS; kk++) hp1[kk] = a.states_in[(size_t)(e0 + col) * SD + soff1 + HID + 4 * kk + rq];
+#pragma unroll
+  for (int kk = 0; kk < KS; kk++) Wh1[kk] = *(const f32x4 *)&wh1[((size_t)(4 * kk + rq) * HID + u) * 4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    cp0[j] = a.states_in[(size_t)(e0 + 4 * rq + j) * SD + soff0 + u];
+    cp1[j] = a.states_in[(size_t)(e0 + 4 * rq + j) * SD + soff1 + u];
+  }
+  const f32x4 bias0 = *(const f32x4 *)&b0[u * 4], bias1 = *(const f32x4 *)&b1[u * 4];
+  __builtin_amdgcn_sched_barrier(0);   // keep the loads above clustered: the scheduler must not sink them between the MFMAs
+  f32x4 acc0[4], acc1[4];
+#pragma unroll
+  for (int g = 0; g < 4; g++) { acc0[g] = (f32x4){bias0[g], bias0[g], bias0[g], bias0[g]}; acc1[g] = (f32x4){bias1[g], bias1[g], bias1[g], bias1[g]}; }
+#pragma unroll
+  for (int kk = 0; kk < KS; kk++) {
+    const float av = hp0[kk] * keepA;
+#pragma unroll
+    for (int g = 0; g < 4; g++) acc0[g] = PS_MFMA(av, Wh0[kk][g], acc0[g]);
+  }
+  if (OBK > 0) {
+#pragma unroll
+    for (int kk = 0; kk < OBKC; kk++) {
+      const float av = (4 * kk + rq < a.ob_dim) ? ob[kk] : 0.0f;
+#pragma unroll
+      for (int g = 0; g < 4; g++) acc0[g] = PS_MFMA(av, Wx0[kk][g], acc0[g]);
+    }
+  } else {
+    const int ksx = (a.ob_dim + 3) >> 2;
+    for (int kk = 0; kk < ksx; kk++) {
+      const int k = 4 * kk + rq, kc = k < a.ob_dim ? k : a.ob_dim - 1;
+      const float av = (k < a.ob_dim) ? a.obs[(size_t)(e0 + col) * a.ob_dim + kc] : 0.0f;
+      const f32x4 bw = *(const f32x4 *)&wx0[((size_t)kc * HID + u) * 4];
+#pragma unroll
+      for (int g = 0; g < 4; g++) acc0[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[g], acc0[g], 0, 0, 0);
+    }
+  }
+  // layer 1's input weights: requested now, consumed after layer 0's cell
+  f32x4 Wx1[KS];
+#pragma unroll
+  for (int kk = 0; kk < KS; kk++) Wx1[kk] = *(const f32x4 *)&wx1[((size_t)(4 * kk + rq) * HID + u) * 4];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int kk = 0; kk < KS; kk++) {
+    const float av = hp1[kk] * keepA;
+#pragma unroll
+    for (int g = 0; g < 4; g++) acc1[g] = PS_MFMA(av, Wh1[kk][g], acc1[g]);
+  }
+  // every wave has read the previous h of both layers before anyone overwrites them: states_out may alias states_in
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const float ig = fast_sigmoid(acc0[0][j]), fg = fast_sigmoid(acc0[1][j]), og = fast_sigmoid(acc0[2][j]), gg = fast_tanh(acc0[3][j]);
+    const float cn = fg * (cp0[j] * keepC[j]) + ig * gg;
+    const float hn = og * fast_tanh(cn);
+    const size_t row = (size_t)(e0 + 4 * rq + j) * SD + soff0;
+    a.states_out[row + u] = cn;
+    a.states_out[row + HID + u] = hn;
+    hbuf[stack][(4 * rq + j) * LD + u] = hn;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int kk = 0; kk < KS; kk++) {
+    const float av = hbuf[stack][col * LD + 4 * kk + rq];
+#pragma unroll
+    for (int g = 0; g < 4; g++) acc1[g] = PS_MFMA(av, Wx1[kk][g], acc1[g]);
+  }
+  __syncthreads();   // all reads of layer 0's h are done before hbuf is reused for layer 1's h
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const float ig = fast_sigmoid(acc1[0][j]), fg = fast_sigmoid(acc1[1][j]), og = fast_sigmoid(acc1[2][j]), gg = fast_tanh(acc1[3][j]);
+    const float cn = fg * (cp1[j] * keepC[j]) + ig * gg;
+    const float hn = og * fast_tanh(cn);
+    const size_t row = (size_t)(e0 + 4 * rq + j) * SD + soff1;
+    a.states_out[row + u] = cn;
+    a.states_out[row + HID + u] = hn;
+    hbuf[stack][(4 * rq + j) * LD + u] = hn;
+  }
+  __syncthreads();
   // heads: thread (env, action) for the mean / sample, 16 more threads for the value and the neglogp sum
   const int A = a.act_dim;
   if (tid < 16 * A) {
     const int env = tid / A, ai = tid - env * A;
     float mean = a.pi_b[ai];
-#pragma unroll 8
-    for (int k = 0; k < HID; k++) mean = __builtin_fmaf(hbuf[0][env * LD + k], a.pi_w[k * A + ai], mean);
+#pragma unroll
+    for (int k = 0; k < HID; k++) mean = __builtin_fmaf(hbuf[0][env * LD + k], head_w[k * A + ai], mean);
     const float ls = a.logstd[ai];
     const float sd = __expf(ls);
     const size_t o = (size_t)(e0 + env) * A + ai;
@@ -379,8 +421,8 @@ lstm_policy_step_kernel(PolicyStepArgs a) {
   const int vt = tid - 16 * A;
   if (vt >= 0 && vt < 16) {
     val = a.vf_b[0];
-#pragma unroll 8
-    for (int k = 0; k < HID; k++) val = __builtin_fmaf(hbuf[1][vt * LD + k], a.vf_w[k], val);
+#pragma unroll
+    for (int k = 0; k < HID; k++) val = __builtin_fmaf(hbuf[1][vt * LD + k], head_w[HID * A + k], val);
   }
   __syncthreads();
   if (vt >= 0 && vt < 16) {
@@ -402,19 +444,6 @@ lstm_policy_step_kernel(PolicyStepArgs a) {
     const float *src = a.obs + (size_t)e0 * a.ob_dim;
     float *dst = a.mb_obs + ((size_t)t * a.N + e0) * a.ob_dim;
     for (int i = tid; i < n; i += blockDim.x) dst[i] = src[i];
-  }
-  if (a.counters) {
-    // the workgroup that finishes last advances the row / step counters: every workgroup read them at its start,
-    // i.e. before it took its ticket
-    if (tid == 0) {
-      __threadfence();
-      const unsigned long long tk = atomicAdd((unsigned long long *)&a.counters[2], 1ull);
-      if (tk == (unsigned long long)gridDim.x - 1ull) {
-        a.counters[2] = 0;
-        a.counters[0] = t + 1;
-        a.counters[1] = gstep + 1;
-      }
-    }
   }
 }
 
@@ -448,7 +477,7 @@ int irrl_lstm_seq_backward(int hid, int T, int N, const float *gates, const floa
 int irrl_lstm_policy_step(int hid, int ob_dim, int act_dim, int N, const float *obs, const uint8_t *dones, const float *states_in,
                           float *states_out, const float *const *lstm_w, const float *pi_w, const float *pi_b, const float *vf_w,
                           const float *vf_b, const float *logstd, const float *noise, int rng_on, unsigned rng_seed, long long rng_step,
-                          float *action, float *clipped, float *value, float *neglogp, long long *counters, float *mb_obs,
+                          const long long *rng_base, float *action, float *clipped, float *value, float *neglogp, long long row, float *mb_obs,
                           float *mb_actions, float *mb_values, float *mb_neglogp, uint8_t *mb_dones, float *mb_rewards,
                           const float *prev_reward, void *hip_stream) {
   if (N <= 0 || (N % 16) != 0 || ob_dim <= 0 || act_dim <= 0 || act_dim > 16) return 1;
@@ -459,8 +488,8 @@ int irrl_lstm_policy_step(int hid, int ob_dim, int act_dim, int N, const float *
   for (int i = 0; i < 12; i++) a.w[i] = lstm_w[i];
   a.pi_w = pi_w; a.pi_b = pi_b; a.vf_w = vf_w; a.vf_b = vf_b; a.logstd = logstd; a.noise = noise;
   a.action = action; a.clipped = clipped; a.value = value; a.neglogp = neglogp;
-  a.counters = counters;
-  const bool rows = counters != nullptr;
+  a.row = row; a.rng_base = rng_base;
+  const bool rows = row >= 0;
   a.mb_obs = rows ? mb_obs : nullptr; a.mb_actions = rows ? mb_actions : nullptr; a.mb_values = rows ? mb_values : nullptr;
   a.mb_neglogp = rows ? mb_neglogp : nullptr; a.mb_dones = rows ? mb_dones : nullptr; a.mb_rewards = rows ? mb_rewards : nullptr;
   a.prev_reward = (rows && mb_rewards) ? prev_reward : nullptr;

@@ -157,22 +157,21 @@ def policy_step_supported(policy, obs):
             and obs.shape[0] % 16 == 0 and 16 * policy.act_dim + 16 <= 8 * n[0] and policy.act_dim <= 16)
 
 
-def policy_step(policy, obs, states, dones, noise=None, rng=None, states_out=None, rollout=None):
+def policy_step(policy, obs, states, dones, noise=None, rng=None, states_out=None, rollout=None, out=None):
     """obs [N,ob], states [N,8H], dones [N] bool/u8 -> action, clipped, value, neglogp, states_out.
-    Sampling: `noise` [N,act] if given; else rng = (seed, step) draws it in the kernel (counter RNG); else deterministic.
-    `rollout` = dict(counters int64[3] (row t, global step, 0), mb_obs, mb_actions, mb_values, mb_neglogpacs, mb_dones,
-    and optionally mb_rewards + prev_reward): row t of each buffer is written, the reward of the previous step goes to row
-    t-1, and the counters advance; the kernel's RNG step is then counters[1]."""
+    Sampling: `noise` [N,act] if given; else rng = (seed, step[, base]) draws it in the kernel (counter RNG at step
+    `step + base`, base an int64 device scalar); else deterministic.
+    `rollout` = dict(row=t, mb_obs, mb_actions, mb_values, mb_neglogpacs, mb_dones, and optionally mb_rewards +
+    prev_reward): row t of each buffer is written and the reward of the previous step goes to row t-1.
+    `out` = preallocated (action, clipped, value, neglogp) (graph capture of many steps without allocations)."""
     lib = _lib.load()
     N, ob_dim = obs.shape
     hid, act = policy.n_lstm[0], policy.act_dim
     dev = obs.device
     perm = _perm(hid, dev)[0]
     ptrs = []
-    keep = []
     for l in list(policy.lstm_pi) + list(policy.lstm_v):
         wx_p, wh_p, b_p = _permuted_weights(l.wx, l.wh, l.b, perm)
-        keep += [wx_p, wh_p, b_p]
         ptrs += [wx_p.data_ptr(), wh_p.data_ptr(), b_p.data_ptr()]
     warr = (C.c_void_p * 12)(*ptrs)
     obs = obs.contiguous()
@@ -180,23 +179,26 @@ def policy_step(policy, obs, states, dones, noise=None, rng=None, states_out=Non
     if states_out is None:
         states_out = torch.empty_like(states)
     assert states_out.is_contiguous() and dones.is_contiguous() and dones.element_size() == 1
-    action = torch.empty(N, act, device=dev)
-    clipped = torch.empty(N, act, device=dev)
-    value = torch.empty(N, device=dev)
-    neglogp = torch.empty(N, device=dev)
+    if out is None:
+        out = (torch.empty(N, act, device=dev), torch.empty(N, act, device=dev), torch.empty(N, device=dev), torch.empty(N, device=dev))
+    action, clipped, value, neglogp = out
     if noise is not None:
         noise = noise.contiguous()
-    rng_on, seed, step = (1, int(rng[0]) & 0xFFFFFFFF, int(rng[1])) if (rng is not None and noise is None) else (0, 0, 0)
+    rng_on, seed, step, base = 0, 0, 0, None
+    if rng is not None and noise is None:
+        rng_on, seed, step = 1, int(rng[0]) & 0xFFFFFFFF, int(rng[1])
+        base = _ptr(rng[2]) if len(rng) > 2 and rng[2] is not None else None
     if rollout is not None:
         opt = lambda k: _ptr(rollout[k]) if rollout.get(k) is not None else None
-        rptr = [_ptr(rollout["counters"]), _ptr(rollout["mb_obs"]), _ptr(rollout["mb_actions"]), _ptr(rollout["mb_values"]),
+        row = int(rollout["row"])
+        rptr = [_ptr(rollout["mb_obs"]), _ptr(rollout["mb_actions"]), _ptr(rollout["mb_values"]),
                 _ptr(rollout["mb_neglogpacs"]), _ptr(rollout["mb_dones"]), opt("mb_rewards"), opt("prev_reward")]
     else:
-        rptr = [None] * 8
+        row, rptr = -1, [None] * 7
     rc = lib.irrl_lstm_policy_step(hid, ob_dim, act, N, _ptr(obs), _ptr(dones), _ptr(states), _ptr(states_out), warr,
                                    _ptr(policy.pi.w), _ptr(policy.pi.b), _ptr(policy.vf.w), _ptr(policy.vf.b), _ptr(policy.logstd),
-                                   _ptr(noise) if noise is not None else None, rng_on, seed, step,
-                                   _ptr(action), _ptr(clipped), _ptr(value), _ptr(neglogp),
+                                   _ptr(noise) if noise is not None else None, rng_on, seed, step, base,
+                                   _ptr(action), _ptr(clipped), _ptr(value), _ptr(neglogp), row,
                                    *rptr, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     if rc != 0:
         raise RuntimeError("irrl_lstm_policy_step failed (rc=%d)" % rc)

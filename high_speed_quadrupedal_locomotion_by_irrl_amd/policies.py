@@ -187,19 +187,23 @@ class CustomLSTMPolicy(ActorCriticPolicy):
         return lstm_fused.policy_step_supported(self, obs)
 
     @torch.no_grad()
-    def fused_step(self, obs, states, dones, noise=None, rng=None, states_out=None, rollout=None):
+    def fused_step(self, obs, states, dones, noise=None, rng=None, states_out=None, rollout=None, out=None):
         """The whole step in ONE kernel launch (both stacks, heads, sample, neglogp, clip, rollout-buffer rows):
         -> action, clipped action, value, neglogp, new states (written to `states_out`, which may be `states`).
-        See lstm_fused.policy_step for `noise` / `rng` / `rollout`."""
+        See lstm_fused.policy_step for `noise` / `rng` / `rollout` / `out`."""
         from . import lstm_fused
         d = dones if dones.element_size() == 1 else (dones != 0)
-        return lstm_fused.policy_step(self, obs, states, d.contiguous(), noise=noise, rng=rng, states_out=states_out, rollout=rollout)
+        return lstm_fused.policy_step(self, obs, states, d.contiguous(), noise=noise, rng=rng, states_out=states_out, rollout=rollout, out=out)
 
     @torch.no_grad()
-    def step(self, obs, states, masks, deterministic=False, generator=None):
-        """run_bp_v5.py:178-185: -> action (unclipped sample), value, new states, neglogp."""
+    def step(self, obs, states, masks, deterministic=False, generator=None, noise=None):
+        """run_bp_v5.py:178-185: -> action (unclipped sample), value, new states, neglogp.  `noise` [N,act] overrides the
+        generator draw (pre-drawn standard normals)."""
         if self.fused_step_supported(obs):
-            noise = None if deterministic else torch.randn((obs.shape[0], self.act_dim), device=obs.device, dtype=obs.dtype, generator=generator)
+            if deterministic:
+                noise = None
+            elif noise is None:
+                noise = torch.randn((obs.shape[0], self.act_dim), device=obs.device, dtype=obs.dtype, generator=generator)
             action, _, value, neglogp, snew = self.fused_step(obs, states, masks, noise=noise)
             return action, value, snew, neglogp
         mean, value, snew = self._run(obs.unsqueeze(0), states, masks.to(obs.dtype).unsqueeze(0))
@@ -207,7 +211,8 @@ class CustomLSTMPolicy(ActorCriticPolicy):
         if deterministic:
             action = mean
         else:
-            noise = torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator)
+            if noise is None:
+                noise = torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator)
             action = mean + torch.exp(self.logstd) * noise
         return action, value, snew, diag_gaussian_neglogp(action, mean, self.logstd)
 

@@ -103,8 +103,7 @@ class Runner(object):
         self.mb_neglogpacs = torch.zeros(T, n, device=dev)
         self.mb_dones = torch.zeros(T, n, dtype=torch.bool, device=dev)
         self.mb_rewards = torch.zeros(T, n, device=dev)
-        self.counters = torch.zeros(3, dtype=torch.long, device=dev)   # rollout row t, global step (RNG counter), ticket
-        self.t_idx = self.counters[0:1]
+        self.t_idx = torch.zeros(1, dtype=torch.long, device=dev)     # device row counter of the generic (per-step graph) path
         self.use_graph = (dev.type == "cuda") if use_graph is None else bool(use_graph)
         self._graph = None
         # sampling noise: the model's seeded generator; under graph capture it is registered with the graph
@@ -113,27 +112,33 @@ class Runner(object):
         self._fused = bool(hasattr(model.policy, "fused_step_supported") and hasattr(env, "step_into")
                            and model.policy.fused_step_supported(self.obs))
         self.rew = torch.zeros(n, device=dev)
-        # sampling noise of the fused path: "kernel" = the engine's counter RNG inside the policy kernel (no extra launch),
-        # "torch" = torch.randn from the model's generator (what the generic path uses; tests compare the two paths with it)
+        # sampling noise: "kernel" = the engine's counter RNG inside the fused policy kernel (fused path only; the generic
+        # path draws from the model's generator per step), "torch" = standard normals for the whole rollout drawn up front
+        # from the model's generator and used by either path (tests compare the two paths with it)
         self.noise_source = "kernel"
-        self._rollout = dict(counters=self.counters, mb_obs=self.mb_obs, mb_actions=self.mb_actions, mb_values=self.mb_values,
-                             mb_neglogpacs=self.mb_neglogpacs, mb_dones=self.mb_dones, mb_rewards=self.mb_rewards, prev_reward=self.rew)
+        self.noise_all = None
+        self.rng_base = torch.zeros(1, dtype=torch.long, device=dev)   # policy steps of all earlier rollouts (RNG counter)
+        self._out = (torch.empty(n, env.num_acts, device=dev), torch.empty(n, env.num_acts, device=dev), torch.empty(n, device=dev),
+                     torch.empty(n, device=dev))
+
+    def _fused_step(self, t):
+        """Rollout step t as two launches: the whole policy step (sample, clip, buffer rows incl. the previous reward) and
+        the env step, which writes obs / reward / dones straight into the runner's tensors."""
+        noise = self.noise_all[t] if self.noise_all is not None else None
+        _, clipped, _, _, _ = self.model.policy.fused_step(
+            self.obs, self.states, self.dones, noise=noise, rng=(self.model.noise_seed, t, self.rng_base), states_out=self.states, out=self._out,
+            rollout=dict(row=t, mb_obs=self.mb_obs, mb_actions=self.mb_actions, mb_values=self.mb_values, mb_neglogpacs=self.mb_neglogpacs,
+                         mb_dones=self.mb_dones, mb_rewards=self.mb_rewards, prev_reward=self.rew))
+        self.env.step_into(clipped, self.obs, self.rew, self.dones)
 
     def _one_step(self):
-        """One rollout step with every index on the device, so the same sequence of kernels can be replayed from a
-        hipGraph: policy step -> buffer rows [t] -> clip -> env.step -> obs/dones update -> t += 1."""
+        """One rollout step of the generic path with every index on the device, so the same sequence of kernels can be
+        replayed from a hipGraph: policy step -> buffer rows [t] -> clip -> env.step -> obs/dones update -> t += 1."""
         pol = self.model.policy
-        if self._fused:
-            # two launches: the whole policy step (sample, clip, buffer rows incl. the previous reward, row counter) and
-            # the env step, which writes obs / reward / dones straight into the runner's tensors
-            noise = None
-            if self.noise_source == "torch":
-                noise = torch.randn((self.obs.shape[0], self.mb_actions.shape[2]), device=self.obs.device, dtype=self.obs.dtype, generator=self._gen)
-            _, clipped, _, _, _ = pol.fused_step(self.obs, self.states, self.dones, noise=noise, rng=(self.model.noise_seed, 0),
-                                                 states_out=self.states, rollout=self._rollout)
-            self.env.step_into(clipped, self.obs, self.rew, self.dones)
-            return
-        actions, values, states, neglogpacs = pol.step(self.obs, self.states, self.dones, generator=self._gen)
+        if self.noise_all is not None:
+            actions, values, states, neglogpacs = pol.step(self.obs, self.states, self.dones, noise=self.noise_all.index_select(0, self.t_idx)[0])
+        else:
+            actions, values, states, neglogpacs = pol.step(self.obs, self.states, self.dones, generator=self._gen)
         self.mb_obs.index_copy_(0, self.t_idx, self.obs.unsqueeze(0))
         self.mb_actions.index_copy_(0, self.t_idx, actions.unsqueeze(0))
         self.mb_values.index_copy_(0, self.t_idx, values.unsqueeze(0))
@@ -162,17 +167,23 @@ class Runner(object):
             stat_names = ("ep_ret", "ep_len", "finished_ret_sum", "finished_len_sum", "finished_count")
             stats = [(getattr(self.env, k), getattr(self.env, k).clone()) for k in stat_names if hasattr(self.env, k)]
             with torch.cuda.stream(side):
-                for _ in range(3):
-                    self._one_step()
+                for i in range(3):
+                    self._fused_step(min(i, self.n_steps - 1)) if self._fused else self._one_step()
                 for live, saved in stats:
                     live.copy_(saved)
             torch.cuda.current_stream(dev).wait_stream(side)
             self.t_idx.zero_()
             g = torch.cuda.CUDAGraph()
-            if self._gen is not None and hasattr(g, "register_generator_state"):
-                g.register_generator_state(self._gen)
-            with torch.cuda.graph(g):
-                self._one_step()
+            if self._fused:
+                # the WHOLE rollout as one graph: 2 kernel nodes per step, the row index a launch argument
+                with torch.cuda.graph(g):
+                    for t in range(self.n_steps):
+                        self._fused_step(t)
+            else:
+                if self._gen is not None and hasattr(g, "register_generator_state"):
+                    g.register_generator_state(self._gen)
+                with torch.cuda.graph(g):
+                    self._one_step()
             self._graph = g
             self.t_idx.zero_()
         except Exception as exc:  # capture is an optimisation only; the eager loop below is the same code
@@ -185,17 +196,29 @@ class Runner(object):
         pol = self.model.policy
         if hasattr(pol, "prepare"):
             pol.prepare()
+        if self.noise_source == "torch":
+            shape = (self.n_steps,) + tuple(self.mb_actions.shape[1:])
+            if self.noise_all is None:
+                self.noise_all = torch.empty(shape, device=self.obs.device, dtype=self.obs.dtype)   # fixed address: graphs read it
+            self.noise_all.copy_(torch.randn(shape, device=self.obs.device, dtype=self.obs.dtype, generator=self._gen))
         if self.use_graph:
             self._maybe_capture()
         mb_states = self.states.clone()
         self.t_idx.zero_()
-        for _ in range(self.n_steps):
+        if self._fused:
             if self._graph is not None:
                 self._graph.replay()
             else:
-                self._one_step()
-        if self._fused:
+                for t in range(self.n_steps):
+                    self._fused_step(t)
+            self.rng_base += self.n_steps
             self.mb_rewards[self.n_steps - 1].copy_(self.rew)       # rows 0 .. T-2 were written by the following policy step
+        else:
+            for _ in range(self.n_steps):
+                if self._graph is not None:
+                    self._graph.replay()
+                else:
+                    self._one_step()
         last_values = pol.value(self.obs, self.states, self.dones)
         advs, returns = gae(self.mb_rewards, self.mb_values, self.mb_dones, last_values, self.dones, self.gamma, self.lam)
         # resetting environments (ppo2.py:577); LSTM states and dones deliberately survive

@@ -144,16 +144,16 @@ int irrl_lstm_seq_backward(int hid, int T, int N, const float *gates, const floa
  * pi0 [c|h], pi1 [c|h], v0 [c|h], v1 [c|h]; states_out may alias states_in.
  * Sampling noise: `noise` [N,act] ~ N(0,1) if not NULL; else rng_on = 1 draws it in the kernel from the engine's
  * counter RNG (Philox4x32-10, key (rng_seed,'IRR1'), counter (env, step >> 32, step, 0x50 + a/4), Box-Muller on the
- * pairs (u0,u1), (u2,u3)); else deterministic (action = mean).
- * Outputs action (unclipped sample), clipped (to [-1,1]), value [N], neglogp [N].  With `counters` (device int64[3] =
- * rollout row t, global step g, scratch ticket = 0) also row t of mb_obs [T,N,ob], mb_actions [T,N,act], mb_values /
- * mb_neglogp [T,N], mb_dones [T,N] u8, and, if mb_rewards and prev_reward [N] are given and t > 0, row t-1 of
- * mb_rewards; then t and g are advanced by one (g is the RNG step; without counters it is rng_step).
+ * pairs (u0,u1), (u2,u3)) with step = rng_step + *rng_base (rng_base: device int64 scalar or NULL); else
+ * deterministic (action = mean).
+ * Outputs action (unclipped sample), clipped (to [-1,1]), value [N], neglogp [N].  With row >= 0 also row `row` of
+ * mb_obs [T,N,ob], mb_actions [T,N,act], mb_values / mb_neglogp [T,N], mb_dones [T,N] u8, and, if mb_rewards and
+ * prev_reward [N] are given and row > 0, row-1 of mb_rewards (the reward of the previous env step).
  * N % 16 == 0, hid in {32,48,64}, 16 act + 16 <= 8 hid. */
 int irrl_lstm_policy_step(int hid, int ob_dim, int act_dim, int N, const float *obs, const uint8_t *dones, const float *states_in,
                           float *states_out, const float *const *lstm_w, const float *pi_w, const float *pi_b, const float *vf_w,
                           const float *vf_b, const float *logstd, const float *noise, int rng_on, unsigned rng_seed, long long rng_step,
-                          float *action, float *clipped, float *value, float *neglogp, long long *counters, float *mb_obs,
+                          const long long *rng_base, float *action, float *clipped, float *value, float *neglogp, long long row, float *mb_obs,
                           float *mb_actions, float *mb_values, float *mb_neglogp, uint8_t *mb_dones, float *mb_rewards,
                           const float *prev_reward, void *hip_stream);
 

@@ -122,13 +122,12 @@ def test_fused_policy_step_matches_eager_step(N, hid, deterministic):
     noise = None if deterministic else torch.randn(N, 12, device=dev)
     assert pol.fused_step_supported(obs)
     T = 3
-    counters = torch.tensor([1, 77, 0], device=dev, dtype=torch.long)
     prev_rew = torch.randn(N, device=dev)
     mb_rew = torch.zeros(T, N, device=dev)
     mb = [torch.zeros(T, N, 35, device=dev), torch.zeros(T, N, 12, device=dev), torch.zeros(T, N, device=dev), torch.zeros(T, N, device=dev),
           torch.zeros(T, N, dtype=torch.bool, device=dev)]
     act, clipped, val, nlp, snew = pol.fused_step(obs, st, dones, noise=noise, rollout=dict(
-        counters=counters, mb_obs=mb[0], mb_actions=mb[1], mb_values=mb[2], mb_neglogpacs=mb[3], mb_dones=mb[4], mb_rewards=mb_rew, prev_reward=prev_rew))
+        row=1, mb_obs=mb[0], mb_actions=mb[1], mb_values=mb[2], mb_neglogpacs=mb[3], mb_dones=mb[4], mb_rewards=mb_rew, prev_reward=prev_rew))
     # eager definition
     SBLstm.use_fused = False
     try:
@@ -145,9 +144,8 @@ def test_fused_policy_step_matches_eager_step(N, hid, deterministic):
     assert torch.equal(mb[0][1], obs) and torch.equal(mb[1][1], act) and torch.equal(mb[2][1], val) and torch.equal(mb[3][1], nlp) and torch.equal(mb[4][1], dones)
     for b in mb:
         assert not b[0].any() and not b[2].any()
-    # the previous step's reward lands in row t-1, and the counters advance (row, global step; the ticket is back to 0)
+    # the previous step's reward lands in row t-1
     assert torch.equal(mb_rew[0], prev_rew) and not mb_rew[1:].any()
-    assert counters.tolist() == [2, 78, 0]
     # in-place state update gives the same result
     st2 = st.clone()
     pol.fused_step(obs, st2, dones, noise=noise, states_out=st2)
@@ -210,7 +208,9 @@ def test_fused_policy_step_kernel_noise_is_the_counter_rng():
     assert np.abs(np.corrcoef(z.T) - np.eye(12)).max() < 0.06
     # same (seed, step) -> same sample; next step -> independent sample
     act2 = pol.fused_step(obs, st, dones, rng=(seed, step))[0]
-    act3 = pol.fused_step(obs, st, dones, rng=(seed, step + 1))[0]
+    base = torch.tensor([1], device=dev, dtype=torch.long)
+    act3 = pol.fused_step(obs, st, dones, rng=(seed, step, base))[0]           # step + *base
+    assert torch.equal(act3, pol.fused_step(obs, st, dones, rng=(seed, step + 1))[0])
     assert torch.equal(act, act2)
     z3 = ((act3 - mean) / torch.exp(pol.logstd.detach())).cpu().numpy()
     assert abs(np.corrcoef(z.reshape(-1), z3.reshape(-1))[0, 1]) < 0.02

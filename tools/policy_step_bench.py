@@ -1,0 +1,39 @@
+"""Times the single-launch LSTM policy step (4096 envs) with HIP events; prints us per launch."""
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import torch
+from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import CustomLSTMPolicy
+
+dev = torch.device("cuda")
+N, T = 4096, 64
+pol = CustomLSTMPolicy().to(dev)
+obs = torch.randn(N, 35, device=dev)
+st = torch.randn(N, 384, device=dev) * 0.3
+dones = torch.zeros(N, dtype=torch.bool, device=dev)
+ro = dict(row=5, mb_obs=torch.zeros(T, N, 35, device=dev), mb_actions=torch.zeros(T, N, 12, device=dev), mb_values=torch.zeros(T, N, device=dev),
+          mb_neglogpacs=torch.zeros(T, N, device=dev), mb_dones=torch.zeros(T, N, dtype=torch.bool, device=dev), mb_rewards=torch.zeros(T, N, device=dev),
+          prev_reward=torch.zeros(N, device=dev))
+for mode in ("plain", "rollout"):
+    kw = dict(rng=(1, 0), states_out=st)
+    if mode == "rollout":
+        kw["rollout"] = ro
+    for _ in range(20):
+        pol.fused_step(obs, st, dones, **kw)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(T):
+        pol.fused_step(obs, st, dones, **kw)
+    e1.record()
+    torch.cuda.synchronize()
+    print(mode, "%.2f us / launch (host loop)" % (e0.elapsed_time(e1) * 1e3 / T))
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    for i in range(T):
+        pol.fused_step(obs, st, dones, rng=(1, 0), states_out=st, rollout=ro)
+for _ in range(3):
+    g.replay()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+print("graph of %d rollout launches: %.2f us / launch" % (T, e0.elapsed_time(e1) * 1e3 / T))
