@@ -178,7 +178,7 @@ def main():
                        "lanes_per_robot": env.lanes_per_robot},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "irrl_step_kernel", "avg_launch_us": kernel_ms * 1e3,
+                         "kernel": "irrl_step_kernel_l%d" % env.lanes_per_robot, "avg_launch_us": kernel_ms * 1e3,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n},
             "roofline_fp32": {"bound": "valu_fp32 (latency/issue bound: 1 wave per CU at 4096 envs)", "achieved": ach_tf,
                               "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP32_PEAK_TFLOPS,

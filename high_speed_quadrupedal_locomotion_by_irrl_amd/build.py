@@ -29,6 +29,12 @@ def is_stale():
     return os.path.getmtime(LIB) < max(os.path.getmtime(d) for d in deps)
 
 
+# Env kernels only (measured on MI355X, 4096 envs, same box): the SLP vectorizer's packed-f32 pairs cost more v_mov than
+# they save in this scalar-per-lane code (56.6 -> 51.4 us per step without it), and the single resident wave per SIMD
+# wants ILP-first scheduling (-> 50.1 us).
+ENV_FLAGS = ["-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+
+
 def build(force=False, verbose=False, extra_flags=()):
     if not force and not is_stale():
         return LIB
@@ -36,8 +42,8 @@ def build(force=False, verbose=False, extra_flags=()):
     objdir = os.path.join(_HERE, "csrc", "_obj")
     os.makedirs(objdir, exist_ok=True)
     # the env kernels in both lane layouts (same source, different lane-primitive header), then the C-ABI + LSTM kernels
-    units = [("env_kernels.hip", ["-DIRRL_LANES_PER_ROBOT=16"], "env_kernels_l16.o"),
-             ("env_kernels.hip", ["-DIRRL_LANES_PER_ROBOT=4"], "env_kernels_l4.o"),
+    units = [("env_kernels.hip", ["-DIRRL_LANES_PER_ROBOT=16"] + ENV_FLAGS, "env_kernels_l16.o"),
+             ("env_kernels.hip", ["-DIRRL_LANES_PER_ROBOT=4"] + ENV_FLAGS, "env_kernels_l4.o"),
              ("irrl_env_abi.hip", [], "irrl_env_abi.o")]
     procs = []
     for src, flags, obj in units:

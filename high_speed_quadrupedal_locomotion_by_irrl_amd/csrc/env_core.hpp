@@ -111,6 +111,12 @@ IRRL_DEV v3 rot_tmul(rot3 R, v3 v) {                                            
 // Philox4x32-10 counter RNG: counter = (env, episode, step, purpose), key = (seed, "IRR1")
 // ---------------------------------------------------------------------------------------------
 struct rng4 { vf u0, u1, u2, u3; };
+// section markers for instruction-count breakdowns of the ISA (tools/isa_sections.py builds with -DIRRL_MARKS)
+#if defined(IRRL_MARKS) && defined(__HIP_DEVICE_COMPILE__)
+#define IRRL_MARK(name) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; IRRL_MARK " name); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define IRRL_MARK(name) do { } while (0)
+#endif
 IRRL_DEV rng4 philox_u01(vu seed, vu env, vu episode, vu step, vu purpose) {
   vu c0 = env, c1 = episode, c2 = step, c3 = purpose;
   vu k0 = seed, k1 = 0x49525231u;
@@ -537,10 +543,9 @@ IRRL_DEV v3 solve_contact(const ContactBlock &B, v3 c, v3 n, vf vstar, vf mu, vm
   vf lt2 = dot(lt, lt);
   vm sticking = lt2 <= mu * mu * ln * ln;
   vm sep = cn >= 0.0f;
-#ifndef IRRL_NO_GS_FASTPATH
-  // Common case (feet planted): every contact whose result is kept (`relevant`) presses (cn < 0), pushes (ln > 0) and
-  // stays inside the friction cone -> the sticking solution IS the answer; the sliding / frictionless algebra below
-  // is skipped by a wave-uniform branch.
+#ifdef IRRL_GS_FASTPATH
+  // (measured slower on gfx950, 62 vs 57 us per step at 4096 envs: the wave-uniform branch breaks the interleaving of
+  // independent dependency chains and most waves hold at least one sliding / lifting foot; kept for reference)
   vm plain = (!sep) & sticking & (ln > 0.0f);
   if (!wave_any(relevant & !plain)) return l;
 #endif
@@ -591,6 +596,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
   const vi sub = sub_id();
   const vm is0 = sub == 0, is1 = sub == 1, is3 = sub == 3, ge1 = sub >= 1, ge2 = sub >= 2;
 #define PICK3(a, b, c) vsel(is0, (a), vsel(is1, (b), (c)))   /* sub-lanes 2 and 3 take c */
+  IRRL_MARK("pd");
   // (D) PD law for joint `sub`, 1 % blend with the normalised torque_last, speed-dependent clamp (ENV:762-765, 1273-1312)
   vf q_s = PICK3(L.q[0], L.q[1], L.q[2]), qd_s = PICK3(L.qd[0], L.qd[1], L.qd[2]);
   vf tau_s;
@@ -606,6 +612,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     tau_s = v_max(v_min(t, up), low);
     L.tq[0] = sub_bcast<0>(tau_s); L.tq[1] = sub_bcast<1>(tau_s); L.tq[2] = sub_bcast<2>(tau_s);
   }
+  IRRL_MARK("fk");
   // (R) base frame quantities
   rot3 R = quat_to_rot(L.qw, L.qx, L.qy, L.qz);
   v3 vB = rot_tmul(R, L.vw), wB = rot_tmul(R, L.ww);
@@ -626,6 +633,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     nB = rot_tmul(R, nw);
     nwz = nw.z;
   }
+  IRRL_MARK("body");
   // (D) the sub-lane's own body: frame, joint axis / origin, inertial parameters (sub-lane 3 carries zero mass)
   const v3 ex = mk3(PICK3(vf(1.0f), k.tx.x, k.sx.x), PICK3(vf(0.0f), k.tx.y, k.sx.y), PICK3(vf(0.0f), k.tx.z, k.sx.z));
   const v3 ez = mk3(PICK3(vf(0.0f), k.tz.x, k.sz.x), PICK3(k.az.y, k.tz.y, k.sz.y), PICK3(k.az.z, k.tz.z, k.sz.z));
@@ -646,6 +654,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
   v3 rc = com_s.x * ex + com_s.y * ey + com_s.z * ez;
   v3 c = p_s + rc;
   sym3 IB = rot_inertia_y0(ex, ey, ez, Ix, Iy, Iz, Iyz);
+  IRRL_MARK("composite");
   // composite (mass, first moment, inertia about the base origin) of the subtree hanging on joint `sub`
   sym3 Io = shift_to_origin(IB, m_s, c);
   vf mc = sub_suffix_sum(m_s);
@@ -653,6 +662,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
   sym3 Ioc;
   Ioc.xx = sub_suffix_sum(Io.xx); Ioc.xy = sub_suffix_sum(Io.xy); Ioc.xz = sub_suffix_sum(Io.xz);
   Ioc.yy = sub_suffix_sum(Io.yy); Ioc.yz = sub_suffix_sum(Io.yz); Ioc.zz = sub_suffix_sum(Io.zz);
+  IRRL_MARK("crba_ci");
   // CRBA column of joint `sub` (D) and its entries of C_l
   v3 Pc = cross(ax, hc - mc * p_s);
   v3 Lc = mul(Ioc, ax) - cross(hc, cross(ax, p_s));
@@ -673,6 +683,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
   vf Xs[6];
 #pragma unroll
   for (int i = 0; i < 6; i++) Xs[i] = sub_bcast<0>(Bs[i]) * ci0 + sub_bcast<1>(Bs[i]) * ci1 + sub_bcast<2>(Bs[i]) * ci2;
+  IRRL_MARK("schur");
   // whole-robot composite -> base block A; Schur complement S = A - sum_legs sum_sub X[:,s] B[:,s]^T
   vf mtot = L.m.m0 + sub_bcast<0>(legs_sum(mc));
   v3 htot = L.m.m0 * L.m.com0 + mk3(sub_bcast<0>(legs_sum(hc.x)), sub_bcast<0>(legs_sum(hc.y)), sub_bcast<0>(legs_sum(hc.z)));
@@ -699,6 +710,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
 #pragma unroll
     for (int i = 0; i < 21; i++) S[i] = A[i] - S[i];
   }
+  IRRL_MARK("chol");
 #pragma unroll
   for (int j = 0; j < 6; j++) {
     vf d = S[L6I(j, j)];
@@ -714,6 +726,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
       D.L6[L6I(i, j)] = v * inv;
     }
   }
+  IRRL_MARK("rnea");
 #ifdef IRRL_RNEA_SERIAL
   // RNEA: kinematic recursion down the chain, advanced only as far as the own body (sub-lane s stops after body s)
   v3 sq0 = mk3(L.qd[0], 0.0f, 0.0f);
@@ -757,6 +770,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     D.bias_b[0] = fb.x + sub_bcast<0>(legs_sum(F.x)); D.bias_b[1] = fb.y + sub_bcast<0>(legs_sum(F.y)); D.bias_b[2] = fb.z + sub_bcast<0>(legs_sum(F.z));
     D.bias_b[3] = nb.x + sub_bcast<0>(legs_sum(N0.x)); D.bias_b[4] = nb.y + sub_bcast<0>(legs_sum(N0.y)); D.bias_b[5] = nb.z + sub_bcast<0>(legs_sum(N0.z));
   }
+  IRRL_MARK("free");
   // free velocity u_free = u + dt M^-1 (tau - damping qd - b)
   vf rl_s = live * (tau_s - 0.01f * qd_s - b_s);
   vf xb[6];
@@ -772,6 +786,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
   ub[3] = wB.x + dt * xb[3]; ub[4] = wB.y + dt * xb[4]; ub[5] = wB.z + dt * xb[5];
   vf ul_s = qd_s + dt * xl_s;
 
+  IRRL_MARK("contact_setup");
   // ---- contact: toe sphere against the ground ----
   vf gap = (L.pos.z + dot(R.r2, k.ptoe) - hgt) * nwz - IRRL_TOE_RADIUS;
   vm active = gap <= 0.0f;
@@ -838,6 +853,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
       for (int i = 0; i < 6; i++) { a1 += Yr[i] * legs_rot<1>(Ya[cc][i]); a2 += Yr[i] * legs_rot<2>(Ya[cc][i]); a3 += Yr[i] * legs_rot<3>(Ya[cc][i]); }
       gx1[cc] = a1; gx2[cc] = a2; gx3[cc] = a3;
     }
+  IRRL_MARK("gs");
     // rank of this contact among the robot's active contacts (leg order FR,FL,HR,HL)
     vi leg = leg_id();
     vi act_i = vsel_i(active, 1, 0);
@@ -874,6 +890,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
         if (!wave_any(unconverged)) break;
       }
     }
+  IRRL_MARK("contact_apply");
     lam.x = vsel(active, lam.x, 0.0f); lam.y = vsel(active, lam.y, 0.0f); lam.z = vsel(active, lam.z, 0.0f);
     // z = sum_legs sum_rows Y_r lam_r drives the base; the leg gets C^-1 Jl^T lam - D xb
     const vf lam_r = live * PICK3(lam.x, lam.y, lam.z);
@@ -895,6 +912,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
   } else {
     L.lamw[0] = 0.0f; L.lamw[1] = 0.0f; L.lamw[2] = 0.0f;
   }
+  IRRL_MARK("integrate");
   L.in_contact = vsel_i(active, 1, 0);
   // back to world-frame gv, then positions (semi-implicit Euler); joint `sub` integrates in its own lane
   L.vw = rot_mul(R, mk3(ub[0], ub[1], ub[2]));
@@ -914,6 +932,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     vf inv = v_rsqrt(w1 * w1 + x1 * x1 + y1 * y1 + z1 * z1);
     L.qw = w1 * inv; L.qx = x1 * inv; L.qy = y1 * inv; L.qz = z1 * inv;
   }
+  IRRL_MARK("end");
 #undef PICK3
 }
 #else

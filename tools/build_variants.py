@@ -12,7 +12,7 @@ for spec in sys.argv[1:]:
     objs = []
     procs = []
     common = [B.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-fno-signed-zeros"] + flags
-    for src, fl, obj in (("env_kernels.hip", ["-DIRRL_LANES_PER_ROBOT=16"], "l16"), ("env_kernels.hip", ["-DIRRL_LANES_PER_ROBOT=4"], "l4"),
+    for src, fl, obj in (("env_kernels.hip", ["-DIRRL_LANES_PER_ROBOT=16"] + B.ENV_FLAGS, "l16"), ("env_kernels.hip", ["-DIRRL_LANES_PER_ROBOT=4"] + B.ENV_FLAGS, "l4"),
                          ("irrl_env_abi.hip", [], "abi")):
         o = os.path.join(out, f"{name}_{obj}.o")
         objs.append(o)

@@ -1,0 +1,38 @@
+"""Instruction-count breakdown of one physics substep of the step kernel (16-lane layout) by source section.
+Builds csrc/env_kernels.hip to assembly with -DIRRL_MARKS (section markers + scheduling barriers at the section borders, so
+the total is a few percent above the production build) and counts VALU / SALU / other instructions between markers.
+usage: python tools/isa_sections.py [extra -D flags]"""
+import os, re, subprocess, sys, tempfile, collections
+
+root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+src = os.path.join(root, "high_speed_quadrupedal_locomotion_by_irrl_amd", "csrc", "env_kernels.hip")
+out = os.path.join(tempfile.mkdtemp(), "marks.s")
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-fno-signed-zeros",
+       "-DIRRL_LANES_PER_ROBOT=16", "-DIRRL_MARKS", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-S", "--cuda-device-only", "-o", out, src] + sys.argv[1:]
+subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+sec, counts, order = None, collections.OrderedDict(), []
+for line in open(out):
+    t = line.strip()
+    m = re.match(r"; IRRL_MARK (\w+)", t)
+    if m:
+        sec = m.group(1)
+        counts.setdefault(sec, collections.Counter())
+        continue
+    if sec is None or sec == "end" or not t or t.startswith((";", ".", "//")) or t.endswith(":"):
+        continue
+    op = t.split()[0]
+    kind = "valu" if op.startswith("v_") else "salu" if op.startswith("s_") else "mem" if op.startswith(("ds_", "global_", "buffer_", "scratch_", "flat_")) else "other"
+    counts[sec][kind] += 1
+    if op.endswith("_dpp") or "_dpp" in t:
+        counts[sec]["dpp"] += 1
+    if op.startswith("v_pk_"):
+        counts[sec]["pk"] += 1
+    if op in ("v_mov_b32_e32", "v_mov_b32_dpp", "v_accvgpr_read_b32", "v_accvgpr_write_b32", "v_cndmask_b32_e32", "v_cndmask_b32_e64"):
+        counts[sec]["mov_sel"] += 1
+tot = collections.Counter()
+print("%-14s %6s %6s %5s %5s %5s %7s" % ("section", "valu", "salu", "mem", "dpp", "pk", "mov/sel"))
+for k, c in counts.items():
+    print("%-14s %6d %6d %5d %5d %5d %7d" % (k, c["valu"], c["salu"], c["mem"], c["dpp"], c["pk"], c["mov_sel"]))
+    tot.update(c)
+print("%-14s %6d %6d %5d %5d %5d %7d" % ("total", tot["valu"], tot["salu"], tot["mem"], tot["dpp"], tot["pk"], tot["mov_sel"]))
+print("(gs = ONE Gauss-Seidel rank-step loop body + convergence check; it runs (sweeps x ranks) times per substep)")
