@@ -114,6 +114,116 @@ lstm_seq_fwd_kernel(const float *__restrict__ zx, const float *__restrict__ wh_p
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Forward sequence kernel with the INPUT PROJECTION fused in: z_t = b + x_t wx + (h_{t-1} keep_t) wh.  Same mapping
+// as lstm_seq_fwd_kernel, plus the wave's slice of wx as a second set of resident B fragments; x_t is read straight
+// from the layer input [T, N, n_in] (prefetched one step ahead), so the [T, N, 4H] zx tensor -- 2.4 GB written by a
+// GEMM and read back here at the training shape -- never exists.  KXS = ceil(n_in / 4) k-steps.
+template <int HID, int KXS>
+__global__ void __launch_bounds__(HID / 16 * 64)
+lstm_seq_fwd_x_kernel(const float *__restrict__ x, const float *__restrict__ wx_p, const float *__restrict__ b_p,
+                      const float *__restrict__ wh_p, const float *__restrict__ masks, const float *__restrict__ state0,
+                      float *__restrict__ gates, float *__restrict__ cseq, float *__restrict__ hseq,
+                      float *__restrict__ state_out, int T, int N, int n_in) {
+  constexpr int KS = HID / 4;
+  constexpr int LD = HID + 1;
+  __shared__ float hbuf[2][16 * LD];
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int col = l & 15, rq = l >> 4;
+  const int e0 = blockIdx.x * 16;
+  const int u = 16 * w + col;
+  float bw[KS][4], bx[KXS][4];
+#pragma unroll
+  for (int kk = 0; kk < KS; kk++)
+#pragma unroll
+    for (int g = 0; g < 4; g++) bw[kk][g] = wh_p[((size_t)(4 * kk + rq) * HID + u) * 4 + g];
+#pragma unroll
+  for (int kk = 0; kk < KXS; kk++) {
+    const int k = 4 * kk + rq;
+#pragma unroll
+    for (int g = 0; g < 4; g++) bx[kk][g] = (k < n_in) ? wx_p[((size_t)k * HID + u) * 4 + g] : 0.0f;
+  }
+  const f32x4 bias = *(const f32x4 *)&b_p[u * 4];
+  float c[4], hlast[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int e = e0 + 4 * rq + j;
+    c[j] = state0[(size_t)e * 2 * HID + u];
+    hlast[j] = state0[(size_t)e * 2 * HID + HID + u];
+    hbuf[0][(4 * rq + j) * LD + u] = hlast[j];
+  }
+  // A fragments of x_t: A[i = env col][k = 4kk + rq]; columns >= n_in are clamped (their B rows are zero)
+  float xa[KXS], xn[KXS];
+  auto fetch_x = [&](int t, float (&dst)[KXS]) {
+    const float *row = x + ((size_t)t * N + e0 + col) * n_in;
+#pragma unroll
+    for (int kk = 0; kk < KXS; kk++) {
+      const int k = 4 * kk + rq;
+      dst[kk] = row[k < n_in ? k : n_in - 1];
+    }
+  };
+  fetch_x(0, xa);
+  float mA_cur = masks[e0 + col], mC_cur[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) mC_cur[j] = masks[e0 + 4 * rq + j];
+  __syncthreads();
+  int cur = 0;
+  for (int t = 0; t < T; t++) {
+    const int tn = (t + 1 < T) ? t + 1 : t;
+    fetch_x(tn, xn);
+    const float keepA = 1.0f - mA_cur;
+    float keepC[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) keepC[j] = 1.0f - mC_cur[j];
+    const float mA_next = masks[(size_t)tn * N + e0 + col];
+    float mC_next[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) mC_next[j] = masks[(size_t)tn * N + e0 + 4 * rq + j];
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) acc[g] = (f32x4){bias[g], bias[g], bias[g], bias[g]};
+    // the input half first: it does not depend on the previous step's h (issued while the other waves still publish it)
+#pragma unroll
+    for (int kk = 0; kk < KXS; kk++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kk], bx[kk][g], acc[g], 0, 0, 0);
+    const float *hb = hbuf[cur];
+#pragma unroll
+    for (int kk = 0; kk < KS; kk++) {
+      const float a = hb[col * LD + 4 * kk + rq] * keepA;
+#pragma unroll
+      for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[kk][g], acc[g], 0, 0, 0);
+    }
+    float *hn = hbuf[cur ^ 1];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float ig = fast_sigmoid(acc[0][j]), fg = fast_sigmoid(acc[1][j]), og = fast_sigmoid(acc[2][j]), gg = fast_tanh(acc[3][j]);
+      const float cn = fg * (c[j] * keepC[j]) + ig * gg;
+      const float hn_ = og * fast_tanh(cn);
+      c[j] = cn;
+      hlast[j] = hn_;
+      const size_t row = (size_t)t * N + e0 + 4 * rq + j;
+      *(f32x4 *)&gates[(row * HID + u) * 4] = (f32x4){ig, fg, og, gg};
+      cseq[row * HID + u] = cn;
+      hseq[row * HID + u] = hn_;
+      hn[(4 * rq + j) * LD + u] = hn_;
+    }
+#pragma unroll
+    for (int kk = 0; kk < KXS; kk++) xa[kk] = xn[kk];
+#pragma unroll
+    for (int j = 0; j < 4; j++) mC_cur[j] = mC_next[j];
+    mA_cur = mA_next;
+    __syncthreads();
+    cur ^= 1;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int e = e0 + 4 * rq + j;
+    state_out[(size_t)e * 2 * HID + u] = c[j];
+    state_out[(size_t)e * 2 * HID + HID + u] = hlast[j];
+  }
+}
+
 template <int HID>
 __global__ void __launch_bounds__(HID / 16 * 64)
 lstm_seq_bwd_kernel(const float *__restrict__ gates, const float *__restrict__ cseq, const float *__restrict__ masks,
@@ -458,6 +568,25 @@ int irrl_lstm_seq_forward(int hid, int T, int N, const float *zx, const float *w
   else if (hid == 32) hipLaunchKernelGGL(lstm_seq_fwd_kernel<32>, dim3(N / 16), dim3(128), 0, s, zx, wh_p, masks, state0, gates, cseq, hseq, state_out, T, N);
   else if (hid == 64) hipLaunchKernelGGL(lstm_seq_fwd_kernel<64>, dim3(N / 16), dim3(256), 0, s, zx, wh_p, masks, state0, gates, cseq, hseq, state_out, T, N);
   else return 1;
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+// forward with the input projection fused: x [T,N,n_in], wx_p [n_in][hid][4], b_p [hid][4]; n_in <= 48
+int irrl_lstm_seq_forward_x(int hid, int T, int N, int n_in, const float *x, const float *wx_p, const float *b_p, const float *wh_p,
+                            const float *masks, const float *state0, float *gates, float *cseq, float *hseq, float *state_out,
+                            void *hip_stream) {
+  if (N <= 0 || T <= 0 || (N % 16) != 0 || n_in <= 0 || n_in > 48) return 1;
+  hipStream_t s = (hipStream_t)hip_stream;
+  const int kxs = (n_in + 3) / 4;
+#define IRRL_FX(H, K) hipLaunchKernelGGL((lstm_seq_fwd_x_kernel<H, K>), dim3(N / 16), dim3(H / 16 * 64), 0, s, x, wx_p, b_p, wh_p, masks, state0, gates, cseq, hseq, state_out, T, N, n_in)
+  if (hid == 48 && kxs <= 9) IRRL_FX(48, 9);
+  else if (hid == 48) IRRL_FX(48, 12);
+  else if (hid == 32 && kxs <= 9) IRRL_FX(32, 9);
+  else if (hid == 32) IRRL_FX(32, 12);
+  else if (hid == 64 && kxs <= 9) IRRL_FX(64, 9);
+  else if (hid == 64) IRRL_FX(64, 12);
+  else return 1;
+#undef IRRL_FX
   return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

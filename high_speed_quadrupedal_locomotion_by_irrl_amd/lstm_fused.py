@@ -15,6 +15,7 @@ import torch
 from . import _lib
 
 _PERM_CACHE = {}
+FUSE_INPUT_PROJECTION = True   # module switch (benchmarks / tests compare the two forward kernels)
 
 
 def _perm(hid, device):
@@ -96,14 +97,19 @@ class _LstmSeqFn(torch.autograd.Function):
         else:
             x_k, masks_k, state0_k = x, masks, state0
         Np = N + pad
-        zx = torch.addmm(b_p, x_k.reshape(T * Np, n_in), wx_p)             # [T*Np, 4H] in [unit][gate] order
         gates = torch.empty(T, Np, hid, 4, device=x.device, dtype=torch.float32)
         cseq = torch.empty(T, Np, hid, device=x.device, dtype=torch.float32)
         hseq = torch.empty(T, Np, hid, device=x.device, dtype=torch.float32)
         state_out = torch.empty(Np, 2 * hid, device=x.device, dtype=torch.float32)
         stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        rc = lib.irrl_lstm_seq_forward(hid, T, Np, _ptr(zx), _ptr(wh_p), _ptr(masks_k), _ptr(state0_k), _ptr(gates), _ptr(cseq),
-                                       _ptr(hseq), _ptr(state_out), stream)
+        if n_in <= 48 and FUSE_INPUT_PROJECTION:
+            # x wx + b inside the sequence kernel: no [T*N, 4H] zx round trip through HBM
+            rc = lib.irrl_lstm_seq_forward_x(hid, T, Np, n_in, _ptr(x_k), _ptr(wx_p), _ptr(b_p), _ptr(wh_p), _ptr(masks_k), _ptr(state0_k),
+                                             _ptr(gates), _ptr(cseq), _ptr(hseq), _ptr(state_out), stream)
+        else:
+            zx = torch.addmm(b_p, x_k.reshape(T * Np, n_in), wx_p)             # [T*Np, 4H] in [unit][gate] order
+            rc = lib.irrl_lstm_seq_forward(hid, T, Np, _ptr(zx), _ptr(wh_p), _ptr(masks_k), _ptr(state0_k), _ptr(gates), _ptr(cseq),
+                                           _ptr(hseq), _ptr(state_out), stream)
         if rc != 0:
             raise RuntimeError("irrl_lstm_seq_forward failed (rc=%d, hid=%d, T=%d, N=%d)" % (rc, hid, T, Np))
         ctx.save_for_backward(x_k, wx_p, wh_p, gates, cseq, hseq, masks_k, state0_k)

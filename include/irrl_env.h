@@ -134,6 +134,11 @@ int irrl_calib_copy_dword(const float *src, float *dst, size_t n, void *hip_stre
  * hid in {32,48,64}, N % 16 == 0.  Returns 0, or 1 for an unsupported shape, 2 for a launch error. */
 int irrl_lstm_seq_forward(int hid, int T, int N, const float *zx, const float *wh_p, const float *masks, const float *state0,
                           float *gates, float *cseq, float *hseq, float *state_out, void *hip_stream);
+/* the same forward pass with the input projection fused in (no zx tensor): x [T,N,n_in] is the layer input,
+ * wx_p [n_in][hid][4], b_p [hid][4]; n_in <= 48 */
+int irrl_lstm_seq_forward_x(int hid, int T, int N, int n_in, const float *x, const float *wx_p, const float *b_p, const float *wh_p,
+                            const float *masks, const float *state0, float *gates, float *cseq, float *hseq, float *state_out,
+                            void *hip_stream);
 int irrl_lstm_seq_backward(int hid, int T, int N, const float *gates, const float *cseq, const float *masks, const float *state0,
                            const float *dh_in, const float *wh_p, float *dz, void *hip_stream);
 
