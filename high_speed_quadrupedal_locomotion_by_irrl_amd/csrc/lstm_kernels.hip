@@ -318,6 +318,207 @@ lstm_seq_bwd_kernel(const float *__restrict__ gates, const float *__restrict__ c
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Backward sequence kernel with EVERYTHING that consumes dz fused in.  Besides the recurrence dh_{t-1} = keep_t (dz_t
+// wh^T) of lstm_seq_bwd_kernel, every step also feeds the same LDS-staged dz tile into
+//   dx_t   = dz_t wx^T                      (second K-split MFMA product, summed over the waves like dh)
+//   dwh   += (h_{t-1} keep_t)^T dz_t,  dwx += x_t^T dz_t      (per-workgroup accumulators held in registers for all T)
+//   db    += sum_env dz_t                   (per-lane running sums)
+// so dz [T, N, 4H] is never written and the three tall GEMMs + the bias reduction that used to re-read it (4 x 2.4 GB
+// per layer and pass at the training shape) disappear.  Each workgroup ends with the weight gradients of its 16 envs;
+// they are stored as partials [N/16, ...] and summed by one small deterministic reduction on the host side.
+// MX = 3 M-tiles cover an input width of up to 48.
+template <int HID, bool NEED_DX>
+__global__ void __launch_bounds__(HID / 16 * 64)
+lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__ cseq, const float *__restrict__ hseq,
+                      const float *__restrict__ x, const float *__restrict__ masks, const float *__restrict__ state0,
+                      const float *__restrict__ dh_in, const float *__restrict__ wh_p, const float *__restrict__ wx_p,
+                      float *__restrict__ dx, float *__restrict__ dwx_part, float *__restrict__ dwh_part,
+                      float *__restrict__ db_part, int T, int N, int n_in) {
+  constexpr int NW = HID / 16;
+  constexpr int MX = 3;                       // input M-tiles (n_in <= 48)
+  constexpr int XPW = (MX + NW - 1) / NW;     // input tiles staged / reduced per wave
+  constexpr int LDZ = 64 + 4;
+  constexpr int LDH = HID + 1;
+  constexpr int LDX = 16 * MX + 1;
+  constexpr int LDP = HID + (NEED_DX ? 16 * MX : 0) + 1;
+  __shared__ float dzbuf[NW][16 * LDZ];
+  __shared__ float hpbuf[2][16 * LDH];
+  __shared__ float xbuf[2][16 * LDX];
+  __shared__ float part[2][NW][16 * LDP];
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int col = l & 15, rq = l >> 4;
+  const int e0 = blockIdx.x * 16;
+  const int u = 16 * w + col;
+  // B fragments (K = this wave's 64 permuted gate columns): dh_prev tiles over the hidden index, dx tiles over the input
+  float bT[16][NW];
+#pragma unroll
+  for (int kk = 0; kk < 16; kk++)
+#pragma unroll
+    for (int nt = 0; nt < NW; nt++) bT[kk][nt] = wh_p[(size_t)(16 * nt + col) * HID * 4 + 64 * w + 4 * kk + rq];
+  float bX[NEED_DX ? 16 : 1][MX];
+  if (NEED_DX) {
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++)
+#pragma unroll
+      for (int nx = 0; nx < MX; nx++) {
+        const int i = 16 * nx + col;
+        bX[kk][nx] = (i < n_in) ? wx_p[(size_t)i * HID * 4 + 64 * w + 4 * kk + rq] : 0.0f;
+      }
+  }
+  f32x4 accWh[NW][4], accWx[MX][4];
+#pragma unroll
+  for (int nt = 0; nt < 4; nt++) {
+#pragma unroll
+    for (int mt = 0; mt < NW; mt++) accWh[mt][nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int mx = 0; mx < MX; mx++) accWx[mx][nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+  }
+  float dbacc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  float dc[4] = {0.0f, 0.0f, 0.0f, 0.0f}, dhrec[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  int pb = 0;
+  f32x4 g_n[4];
+  float ct_n[4], cp_n[4], dh_n[4], mk_n[4], hp_n[4], xs_n[XPW][4];
+  auto fetch = [&](int t) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int e = e0 + 4 * rq + j;
+      const size_t row = (size_t)t * N + e;
+      mk_n[j] = masks[row];
+      g_n[j] = *(const f32x4 *)&gates[(row * HID + u) * 4];
+      ct_n[j] = cseq[row * HID + u];
+      cp_n[j] = (t > 0) ? cseq[(row - N) * HID + u] : state0[(size_t)e * 2 * HID + u];
+      hp_n[j] = (t > 0) ? hseq[(row - N) * HID + u] : state0[(size_t)e * 2 * HID + HID + u];
+      dh_n[j] = dh_in[row * HID + u];
+#pragma unroll
+      for (int q = 0; q < XPW; q++) {
+        const int i = 16 * (w + q * NW) + col;
+        xs_n[q][j] = (w + q * NW < MX && i < n_in) ? x[row * n_in + i] : 0.0f;
+      }
+    }
+  };
+  fetch(T - 1);
+  for (int t = T - 1; t >= 0; t--) {
+    float keepC[4];
+    f32x4 dz4[4], g4[4];
+    float ct[4], cpv[4], dhv[4];
+    float *hp = hpbuf[pb], *xb = xbuf[pb];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      keepC[j] = 1.0f - mk_n[j]; g4[j] = g_n[j]; ct[j] = ct_n[j]; cpv[j] = cp_n[j]; dhv[j] = dh_n[j];
+      hp[(4 * rq + j) * LDH + u] = hp_n[j] * keepC[j];          // h_{t-1} as it entered step t
+#pragma unroll
+      for (int q = 0; q < XPW; q++)
+        if (w + q * NW < MX) xb[(4 * rq + j) * LDX + 16 * (w + q * NW) + col] = xs_n[q][j];
+    }
+    if (t > 0) fetch(t - 1);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float cprev = cpv[j] * keepC[j];
+      const float dh = dhv[j] + dhrec[j];
+      const float ig = g4[j][0], fg = g4[j][1], og = g4[j][2], gg = g4[j][3];
+      const float tc = fast_tanh(ct[j]);
+      const float d_o = dh * tc;
+      const float dct = dc[j] + dh * og * (1.0f - tc * tc);
+      const float d_i = dct * gg, d_g = dct * ig, d_f = dct * cprev;
+      dc[j] = dct * fg * keepC[j];
+      dz4[j] = (f32x4){d_i * ig * (1.0f - ig), d_f * fg * (1.0f - fg), d_o * og * (1.0f - og), d_g * (1.0f - gg * gg)};
+      *(f32x4 *)&dzbuf[w][(4 * rq + j) * LDZ + 4 * col] = dz4[j];
+#pragma unroll
+      for (int g = 0; g < 4; g++) dbacc[g] += dz4[j][g];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    f32x4 acc[NW], accx[NEED_DX ? MX : 1];
+#pragma unroll
+    for (int nt = 0; nt < NW; nt++) acc[nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    if (NEED_DX) {
+#pragma unroll
+      for (int nx = 0; nx < MX; nx++) accx[nx] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    }
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) {
+      const float a = dzbuf[w][col * LDZ + 4 * kk + rq];  // A[i = env col][k = 4kk + rq]
+#pragma unroll
+      for (int nt = 0; nt < NW; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bT[kk][nt], acc[nt], 0, 0, 0);
+      if (NEED_DX) {
+#pragma unroll
+        for (int nx = 0; nx < MX; nx++) accx[nx] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bX[kk][nx], accx[nx], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+#pragma unroll
+      for (int nt = 0; nt < NW; nt++) part[pb][w][(4 * rq + j) * LDP + 16 * nt + col] = acc[nt][j];
+      if (NEED_DX) {
+#pragma unroll
+        for (int nx = 0; nx < MX; nx++) part[pb][w][(4 * rq + j) * LDP + HID + 16 * nx + col] = accx[nx][j];
+      }
+    }
+    __syncthreads();   // partials of all waves, and this step's h_prev / x tiles, are now visible
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float sacc = 0.0f;
+#pragma unroll
+      for (int ww = 0; ww < NW; ww++) sacc += part[pb][ww][(4 * rq + j) * LDP + u];
+      dhrec[j] = sacc * keepC[j];
+    }
+    if (NEED_DX) {
+#pragma unroll
+      for (int q = 0; q < XPW; q++) {
+        const int nx = w + q * NW;
+        const int i = 16 * nx + col;
+        if (nx < MX && i < n_in) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            float sacc = 0.0f;
+#pragma unroll
+            for (int ww = 0; ww < NW; ww++) sacc += part[pb][ww][(4 * rq + j) * LDP + HID + i];
+            dx[((size_t)t * N + e0 + 4 * rq + j) * n_in + i] = sacc;
+          }
+        }
+      }
+    }
+    // weight-gradient accumulation: D[m][c] += sum_env A[m][env] B[env][c], env = 4s + rq
+#pragma unroll
+    for (int sk = 0; sk < 4; sk++) {
+      float bz[4], ah[NW], ax[MX];
+#pragma unroll
+      for (int nt = 0; nt < 4; nt++) bz[nt] = dzbuf[w][(4 * sk + rq) * LDZ + 16 * nt + col];
+#pragma unroll
+      for (int mt = 0; mt < NW; mt++) ah[mt] = hp[(4 * sk + rq) * LDH + 16 * mt + col];
+#pragma unroll
+      for (int mx = 0; mx < MX; mx++) ax[mx] = xb[(4 * sk + rq) * LDX + 16 * mx + col];
+#pragma unroll
+      for (int nt = 0; nt < 4; nt++) {
+#pragma unroll
+        for (int mt = 0; mt < NW; mt++) accWh[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[mt], bz[nt], accWh[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mx = 0; mx < MX; mx++) accWx[mx][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[mx], bz[nt], accWx[mx][nt], 0, 0, 0);
+      }
+    }
+    pb ^= 1;
+  }
+  // per-workgroup partial gradients; C/D slot (row 4 rq + r, column col) of tile (m, nt) = (input / hidden index, gate column)
+  const size_t blk = blockIdx.x;
+#pragma unroll
+  for (int nt = 0; nt < 4; nt++) {
+    const int c = 64 * w + 16 * nt + col;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+      for (int mt = 0; mt < NW; mt++) dwh_part[(blk * HID + 16 * mt + 4 * rq + r) * (4 * HID) + c] = accWh[mt][nt][r];
+#pragma unroll
+      for (int mx = 0; mx < MX; mx++) {
+        const int i = 16 * mx + 4 * rq + r;
+        if (i < n_in) dwx_part[(blk * n_in + i) * (4 * HID) + c] = accWx[mx][nt][r];
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 4; g++) db_part[(blk * 4 + rq) * (4 * HID) + u * 4 + g] = dbacc[g];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // One ROLLOUT step of the whole CustomLSTMPolicy in a single launch (run_bp_v5.py:178-185 `step`): actor stack and
 // critic stack (two LSTM layers each), the action / value heads, the Gaussian sample, its neglogp, the [-1, 1] clip the
 // runner applies (ppo2.py:533-535) and the rollout-buffer rows of step t (ppo2.py:521-531), including the reward row
@@ -637,6 +838,26 @@ int irrl_lstm_policy_step(int hid, int ob_dim, int act_dim, int N, const float *
   else if (hid == 64) IRRL_PS_LAUNCH(64);
   else return 1;
 #undef IRRL_PS_LAUNCH
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+// backward with dx / dwx / dwh / db fused in (no dz tensor).  dx [T,N,n_in] or NULL (no input gradient wanted);
+// dwx_part [N/16, n_in, 4 hid], dwh_part [N/16, hid, 4 hid], db_part [N/16 * 4, 4 hid] are per-workgroup partials in the
+// permuted column order: the caller sums them over the first axis.  n_in <= 48.
+int irrl_lstm_seq_backward_x(int hid, int T, int N, int n_in, const float *gates, const float *cseq, const float *hseq, const float *x,
+                             const float *masks, const float *state0, const float *dh_in, const float *wh_p, const float *wx_p,
+                             float *dx, float *dwx_part, float *dwh_part, float *db_part, void *hip_stream) {
+  if (N <= 0 || T <= 0 || (N % 16) != 0 || n_in <= 0 || n_in > 48) return 1;
+  hipStream_t s = (hipStream_t)hip_stream;
+#define IRRL_BX(H, D) hipLaunchKernelGGL((lstm_seq_bwd_x_kernel<H, D>), dim3(N / 16), dim3(H / 16 * 64), 0, s, gates, cseq, hseq, x, masks, state0, dh_in, wh_p, wx_p, dx, dwx_part, dwh_part, db_part, T, N, n_in)
+  if (hid == 48 && dx) IRRL_BX(48, true);
+  else if (hid == 48) IRRL_BX(48, false);
+  else if (hid == 32 && dx) IRRL_BX(32, true);
+  else if (hid == 32) IRRL_BX(32, false);
+  else if (hid == 64 && dx) IRRL_BX(64, true);
+  else if (hid == 64) IRRL_BX(64, false);
+  else return 1;
+#undef IRRL_BX
   return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

@@ -87,6 +87,9 @@ class SBLinear(nn.Module):
         self.b = nn.Parameter(torch.full((n_out,), float(init_bias)))
 
     def forward(self, x):
+        if x.is_cuda and x.requires_grad and x.numel() // x.shape[-1] >= (1 << 16) and SBLstm.use_fused:
+            from . import lstm_fused
+            return lstm_fused.tall_linear(x, self.w, self.b)      # split-K weight gradient (see _TallLinearFn)
         return x @ self.w + self.b
 
 

@@ -142,6 +142,14 @@ int irrl_lstm_seq_forward_x(int hid, int T, int N, int n_in, const float *x, con
 int irrl_lstm_seq_backward(int hid, int T, int N, const float *gates, const float *cseq, const float *masks, const float *state0,
                            const float *dh_in, const float *wh_p, float *dz, void *hip_stream);
 
+/* backward pass with everything that consumes dz fused in (no dz tensor, no separate weight-gradient GEMMs):
+ * hseq / x are the forward outputs / inputs; dx [T,N,n_in] or NULL; dwx_part [N/16, n_in, 4 hid], dwh_part [N/16, hid,
+ * 4 hid], db_part [N/16 * 4, 4 hid] receive per-workgroup partial sums (permuted gate columns) that the caller adds up
+ * over their first axis.  n_in <= 48. */
+int irrl_lstm_seq_backward_x(int hid, int T, int N, int n_in, const float *gates, const float *cseq, const float *hseq, const float *x,
+                             const float *masks, const float *state0, const float *dh_in, const float *wh_p, const float *wx_p,
+                             float *dx, float *dwx_part, float *dwh_part, float *db_part, void *hip_stream);
+
 /* ---- one ROLLOUT step of CustomLSTMPolicy in a single launch (run_bp_v5.py:178-185 `step`; the runner's clip and
  * buffer rows, ppo2.py:521-535).  Two stacks (actor, critic) of two LSTM layers of `hid` units, heads pi [hid,act],
  * vf [hid,1], logstd [act].  lstm_w is a HOST array of 12 device pointers: for layer in (pi0, pi1, v0, v1):
