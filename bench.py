@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--cfg", default="bp5_imitation.yaml")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget (0 disables)")
+    ap.add_argument("--ppo-iters", type=int, default=2, help="timed PPO iterations of the LSTM policy at N=1 (0 disables)")
     args = ap.parse_args()
 
     import numpy as np
@@ -180,13 +181,21 @@ def main():
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "irrl_step_kernel_l%d" % env.lanes_per_robot, "avg_launch_us": kernel_ms * 1e3,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n},
-            "roofline_fp32": {"bound": "valu_fp32 (latency/issue bound: 1 wave per CU at 4096 envs)", "achieved": ach_tf,
+            "roofline_fp32": {"bound": "valu_fp32 (latency/issue bound: 1 wave per SIMD at 4096 envs)", "achieved": ach_tf,
                               "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP32_PEAK_TFLOPS,
                               "algorithmic_flops_per_launch": ALG_FLOPS_PER_ENV_STEP * n},
             "resets_in_50_steps": float(n_done.item()),
         }
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(env_cfg, args.cpu_seconds)
+        if world == 1 and args.ppo_iters > 0:
+            # second half of BASELINE.json's metric ("PPO iters/sec"): the reference's training iteration (750-step rollout of
+            # all envs with the 2x48 + 2x48 LSTM policy, GAE, 10 epochs of full-length BPTT, global reset) on this GPU;
+            # reported beside the headline value, never mixed into it
+            del env
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import ppo_bench
+            out["ppo"] = ppo_bench.measure("lstm", n, 750, args.ppo_iters + 1, 10, "default_cfg.yaml", verbose=False)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

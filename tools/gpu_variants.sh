@@ -7,7 +7,7 @@ for f in $V/libirrl_env_*.so; do
   n=$(basename $f .so)
   for lanes in 16 4; do
     envs=4096; [ $lanes = 4 ] && envs=32768
-    IRRL_ENV_LIB=$PWD/$f IRRL_LANES_PER_ROBOT=$lanes timeout 300 python bench.py --cpu-seconds 0 --steps 2000 --envs $envs 2>/dev/null | grep metric | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$n L$lanes', round(d['value']/1e6,2), 'M env-steps/s', round(d['roofline']['avg_launch_us'],2), 'us')" >> gpurun_out/variants.log
+    IRRL_ENV_LIB=$PWD/$f IRRL_LANES_PER_ROBOT=$lanes timeout 300 python bench.py --cpu-seconds 0 --ppo-iters 0 --steps 2000 --envs $envs 2>/dev/null | grep metric | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$n L$lanes', round(d['value']/1e6,2), 'M env-steps/s', round(d['roofline']['avg_launch_us'],2), 'us')" >> gpurun_out/variants.log
   done
 done
 done

@@ -12,15 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--policy", default="mlp")
-    ap.add_argument("--envs", type=int, default=4096)
-    ap.add_argument("--steps", type=int, default=750)
-    ap.add_argument("--iters", type=int, default=3)
-    ap.add_argument("--epochs", type=int, default=10)
-    ap.add_argument("--cfg", default="default_cfg.yaml")
-    a = ap.parse_args()
+def measure(policy="lstm", envs=4096, steps=750, iters=3, epochs=10, cfg_name="default_cfg.yaml", verbose=True):
+    """Runs `iters` PPO iterations (the first one also captures the rollout graph and warms the allocator) and returns
+    the mean rollout / update time of the others."""
     import torch
     import yaml
     import high_speed_quadrupedal_locomotion_by_irrl_amd as pkg
@@ -28,15 +22,15 @@ def main():
     from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import CustomLSTMPolicy, MlpPolicy
     from high_speed_quadrupedal_locomotion_by_irrl_amd.ppo2 import PPO2, Runner
     from high_speed_quadrupedal_locomotion_by_irrl_amd.vec_env import TorchVecEnv
-    cfg = yaml.safe_load(open(os.path.join(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY__, a.cfg)))["environment"]
-    cfg["num_envs"] = a.envs
+    cfg = yaml.safe_load(open(os.path.join(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY__, cfg_name)))["environment"]
+    cfg["num_envs"] = envs
     env = TorchVecEnv(FlexibleGymEnv(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY__, yaml.safe_dump(cfg)))
-    lstm = a.policy == "lstm"
-    model = PPO2(policy=CustomLSTMPolicy if lstm else MlpPolicy, env=env, gamma=0.99, n_steps=a.steps, ent_coef=0.0, learning_rate=1e-3,
-                 vf_coef=0.5, max_grad_norm=0.5, lam=0.998, nminibatches=1 if lstm else 4, noptepochs=a.epochs, cliprange=0.2, verbose=0, seed=1)
-    runner = Runner(env, model, a.steps, 0.99, 0.998)
+    lstm = policy == "lstm"
+    model = PPO2(policy=CustomLSTMPolicy if lstm else MlpPolicy, env=env, gamma=0.99, n_steps=steps, ent_coef=0.0, learning_rate=1e-3,
+                 vf_coef=0.5, max_grad_norm=0.5, lam=0.998, nminibatches=1 if lstm else 4, noptepochs=epochs, cliprange=0.2, verbose=0, seed=1)
+    runner = Runner(env, model, steps, 0.99, 0.998)
     rows = []
-    for it in range(a.iters):
+    for it in range(iters):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         batch = runner.run()
@@ -46,12 +40,26 @@ def main():
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         rows.append((t1 - t0, t2 - t1))
-        print("iter %d rollout %.3f s update %.3f s" % (it, t1 - t0, t2 - t1), flush=True)
-    ro = min(r[0] for r in rows)
-    up = min(r[1] for r in rows)
-    print(json.dumps({"policy": a.policy, "envs": a.envs, "n_steps": a.steps, "epochs": a.epochs, "rollout_s": ro, "update_s": up,
-                      "ppo_iters_per_sec": 1.0 / (ro + up), "env_steps_per_sec_in_rollout": a.envs * a.steps / ro,
-                      "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}))
+        if verbose:
+            print("iter %d rollout %.3f s update %.3f s" % (it, t1 - t0, t2 - t1), flush=True)
+    timed = rows[1:] if len(rows) > 1 else rows
+    ro = sum(r[0] for r in timed) / len(timed)
+    up = sum(r[1] for r in timed) / len(timed)
+    return {"policy": policy, "envs": envs, "n_steps": steps, "epochs": epochs, "timed_iters": len(timed), "rollout_s": ro, "update_s": up,
+            "ppo_iters_per_sec": 1.0 / (ro + up), "env_steps_per_sec_in_rollout": envs * steps / ro,
+            "samples_per_sec": envs * steps / (ro + up), "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--policy", default="mlp")
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--steps", type=int, default=750)
+    ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--epochs", type=int, default=10)
+    ap.add_argument("--cfg", default="default_cfg.yaml")
+    a = ap.parse_args()
+    print(json.dumps(measure(a.policy, a.envs, a.steps, a.iters, a.epochs, a.cfg)))
 
 
 if __name__ == "__main__":
