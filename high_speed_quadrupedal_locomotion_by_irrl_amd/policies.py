@@ -87,7 +87,7 @@ class SBLinear(nn.Module):
         self.b = nn.Parameter(torch.full((n_out,), float(init_bias)))
 
     def forward(self, x):
-        if x.is_cuda and x.requires_grad and x.numel() // x.shape[-1] >= (1 << 16) and SBLstm.use_fused:
+        if x.is_cuda and torch.is_grad_enabled() and self.w.requires_grad and x.numel() // x.shape[-1] >= (1 << 16) and SBLstm.use_fused:
             from . import lstm_fused
             return lstm_fused.tall_linear(x, self.w, self.b)      # split-K weight gradient (see _TallLinearFn)
         return x @ self.w + self.b

@@ -112,6 +112,7 @@ class Runner(object):
         self._fused = bool(hasattr(model.policy, "fused_step_supported") and hasattr(env, "step_into")
                            and model.policy.fused_step_supported(self.obs))
         self.rew = torch.zeros(n, device=dev)
+        self._raw_env = hasattr(env, "step_into") and hasattr(env, "account_rollout") and dev.type == "cuda"
         # sampling noise: "kernel" = the engine's counter RNG inside the fused policy kernel (fused path only; the generic
         # path draws from the model's generator per step), "torch" = standard normals for the whole rollout drawn up front
         # from the model's generator and used by either path (tests compare the two paths with it)
@@ -147,10 +148,15 @@ class Runner(object):
         if states is not None:
             self.states.copy_(states)
         clipped = torch.clamp(actions, -1.0, 1.0)
-        obs, rewards, dones = self.env.step(clipped)
-        self.mb_rewards.index_copy_(0, self.t_idx, rewards.unsqueeze(0))
-        self.obs.copy_(obs)
-        self.dones.copy_(dones)
+        if self._raw_env:
+            # the env kernel writes straight into the runner's tensors; episode statistics are accounted per rollout
+            self.env.step_into(clipped, self.obs, self.rew, self.dones)
+            self.mb_rewards.index_copy_(0, self.t_idx, self.rew.unsqueeze(0))
+        else:
+            obs, rewards, dones = self.env.step(clipped)
+            self.mb_rewards.index_copy_(0, self.t_idx, rewards.unsqueeze(0))
+            self.obs.copy_(obs)
+            self.dones.copy_(dones)
         self.t_idx += 1
 
     def _maybe_capture(self):
@@ -222,7 +228,7 @@ class Runner(object):
         last_values = pol.value(self.obs, self.states, self.dones)
         advs, returns = gae(self.mb_rewards, self.mb_values, self.mb_dones, last_values, self.dones, self.gamma, self.lam)
         # resetting environments (ppo2.py:577); LSTM states and dones deliberately survive
-        if self._fused:
+        if self._fused or self._raw_env:
             n_done = self.mb_dones[1:].sum() + self.dones.sum()
             self.env.account_rollout(self.mb_rewards.sum(), float(self.n_steps * self.env.num_envs), n_done + float(self.env.num_envs))
             self.obs.copy_(self.env.reset())

@@ -164,6 +164,7 @@ def test_fused_runner_matches_stepwise_runner():
         runner = Runner(env, model, 30, 0.99, 0.998)
         assert runner._fused
         runner._fused = fused
+        runner._raw_env = fused           # the stepwise runner keeps the per-step episode bookkeeping of TorchVecEnv.step
         runner.noise_source = "torch"     # same sampling noise on both paths
         b1 = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in runner.run().items()}
         b2 = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in runner.run().items()}   # second rollout: replayed graph, carried states / dones
