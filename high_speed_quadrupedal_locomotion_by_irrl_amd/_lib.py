@@ -50,6 +50,7 @@ SIGNATURES = {
     "irrl_env_get_state_host": (C.c_int, [vp, dp]),
     "irrl_env_set_state_host": (C.c_int, [vp, dp]),
     "irrl_env_heightfield_host": (C.c_int, [vp, fp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "irrl_env_set_ref_host": (C.c_int, [vp, fp, C.c_int, C.c_int]),
     "irrl_env_cfg_value": (C.c_double, [vp, C.c_char_p]),
     "irrl_gae": (C.c_int, [C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp]),
     "irrl_calib_copy_dword": (C.c_int, [vp, vp, C.c_size_t, vp]),

@@ -1209,8 +1209,24 @@ IRRL_DEV void gait_generator_manual(const EnvParams &P, EnvLane &L, bool is_firs
 }
 
 // ENV:1010-1109, ManualTraj branch
+IRRL_DEV vi ref_row_base(const EnvParams &P, const EnvLane &L) {
+  vf fr = v_min(v_max(i2f(L.frame), 0.0f), (float)(P.ref_rows - 1));   // row index clamped to the table (exact in f32)
+  return f2i(fr) * 30;
+}
 IRRL_DEV void command_obs_update(const EnvParams &P, EnvLane &L, vu env, bool flag_reset) {
   if (P.manual) return;
+  if (P.ref_traj) {
+    // ENV:1100-1107 + gait_generator() ENV:1667-1671: command and joint reference straight from row frame_idx of the table
+    const vi b = ref_row_base(P, L), leg3 = leg_id() * 3;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      L.ob_cmd[i] = ld(P.ref, b + (27 + i));
+      L.cmdf[i] = L.ob_cmd[i];
+      L.jr[i] = ld(P.ref, b + leg3 + i);
+      L.jdr[i] = ld(P.ref, b + leg3 + (12 + i));
+    }
+    return;
+  }
   rng4 r = philox_u01(P.seed, env, L.episode, to_u(L.frame), flag_reset ? IRRL_P_RESET_CMD : IRRL_P_CMD);
   vm resample = r.u0 < 0.5f / (P.max_time / P.control_dt);
   if (flag_reset) resample = resample | vm(true);
@@ -1245,8 +1261,14 @@ IRRL_DEV void update_observation(const EnvParams &P, EnvLane &L, vu env) {
   vi leg = leg_id();
   vf t = env_time(P, L);
   L.ob_cmd[0] = 0.0f; L.ob_cmd[1] = 0.0f; L.ob_cmd[2] = 0.0f;  // ENV:960 zeroes the buffer
-  L.ob_phase[0] = v_sin(2.0f * IRRL_PI_REF * t / P.period);
-  L.ob_phase[1] = v_cos(2.0f * IRRL_PI_REF * t / P.period);
+  if (P.ref_traj) {   // ENV:972: phase columns 25-26 of the table
+    const vi b = ref_row_base(P, L);
+    L.ob_phase[0] = ld(P.ref, b + 25);
+    L.ob_phase[1] = ld(P.ref, b + 26);
+  } else {
+    L.ob_phase[0] = v_sin(2.0f * IRRL_PI_REF * t / P.period);
+    L.ob_phase[1] = v_cos(2.0f * IRRL_PI_REF * t / P.period);
+  }
   vf nj[3] = {0.0f, 0.0f, 0.0f}, nv[3] = {0.0f, 0.0f, 0.0f}, nn[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
   if (P.obs_noise != 0.0f) {
     vf u[16];
@@ -1336,6 +1358,13 @@ IRRL_DEV void reset_lane(const EnvParams &P, EnvLane &L, vu env) {
   if (P.randomize_per_episode && P.stochastic) model_randomize(L.m, leg, P.seed, env, L.episode);
   rng4 rt = philox_u01(P.seed, env, L.episode, 0u, IRRL_P_RESET_TIME);
   L.t0 = P.manual ? 0.0f : rt.u0;
+  if (P.ref_traj) {
+    // ENV:538-539, 571: random start frame in the first half of the table, frame_len + 10 rows before its end
+    const int span = P.ref_rows / 2 - (int)(P.max_time / P.control_dt) - 10;
+    vf u = rt.u1;
+    vf shaped = vsel((0.0f < u) & (u < 0.5f), u * 4.0f / 3.0f, (u * 2.0f + 1.0f) / 3.0f);   // sampling_reshape ENV:71-81
+    L.frame = span > 0 ? f2i(v_floor((float)span * shaped)) : 0;
+  }
 #pragma unroll
   for (int i = 0; i < 3; i++) { L.cmdf[i] = 0.0f; L.tql[i] = 0.0f; }
   command_obs_update(P, L, env, true);
@@ -1577,6 +1606,28 @@ IRRL_DEV void step_body(const EnvParams &P, const EnvState &S, vi env, vi leg, v
       p = (1.0f - P.filter_para) * p + P.filter_para * L.ptl[k];
       p = p * (P.action_noise * an[k]) + p;
       pT[k] = p; L.ptl[k] = p;
+    }
+  }
+  if (P.state_disturbance) {
+    // ENV:743-748, 912-940 (Manual evaluation runs): every 10 gait periods the base state is kicked -- z, the four
+    // quaternion components, v_z and the roll / pitch rates get uniform(-1, 1) noise scaled 0.03 | 0.1 | 0.1 | 0.3 times 0.5.
+    // The quaternion is re-normalised here (the reference hands the perturbed one to RaiSim's setState).
+    const float kf = (float)P.disturb_every;
+    const vf fr = i2f(L.frame);
+    const vm fire = (fr - v_floor(fr / kf) * kf) < 0.5f;   // frame % K == 0 (exact in f32)
+    if (wave_any(fire)) {
+      rng4 a = philox_u01(P.seed, envu, L.episode, to_u(L.frame), IRRL_P_DISTURB);
+      rng4 b = philox_u01(P.seed, envu, L.episode, to_u(L.frame), IRRL_P_DISTURB + 1u);
+      const float r = 0.5f;
+      vf pz = L.pos.z + 0.03f * (2.0f * a.u0 - 1.0f) * r;
+      vf qw = L.qw + 0.1f * (2.0f * a.u1 - 1.0f) * r, qx = L.qx + 0.1f * (2.0f * a.u2 - 1.0f) * r;
+      vf qy = L.qy + 0.1f * (2.0f * a.u3 - 1.0f) * r, qz = L.qz + 0.1f * (2.0f * b.u0 - 1.0f) * r;
+      vf inv = v_rsqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+      L.pos.z = vsel(fire, pz, L.pos.z);
+      L.qw = vsel(fire, qw * inv, L.qw); L.qx = vsel(fire, qx * inv, L.qx); L.qy = vsel(fire, qy * inv, L.qy); L.qz = vsel(fire, qz * inv, L.qz);
+      L.vw.z = vsel(fire, L.vw.z + 0.1f * (2.0f * b.u1 - 1.0f) * r, L.vw.z);
+      L.ww.x = vsel(fire, L.ww.x + 0.3f * (2.0f * b.u2 - 1.0f) * r, L.ww.x);
+      L.ww.y = vsel(fire, L.ww.y + 0.3f * (2.0f * b.u3 - 1.0f) * r, L.ww.y);
     }
   }
   for (int i = 0; i < P.loop_count; i++) physics_substep(P, L, pT);

@@ -30,6 +30,12 @@ struct EnvParams {
   int32_t terrain, hf_nx, hf_ny;
   float hf_x0, hf_y0, hf_inv_dx, hf_inv_dy;
   const float *height;     // [hf_nx, hf_ny] row-major, shared by every robot of the pool
+  // reference-trajectory mode (ManualTraj: False, Manual: False; Environment.hpp:17-21, 565-573, 972, 1100-1107, 1667-1671):
+  // table [ref_rows, 30] f32 = theta 12 | theta_dot 12 | z | phase 2 | cmd 3, one row per control step
+  int32_t ref_traj, ref_rows;
+  int32_t state_disturbance;   // Manual + ForceDisturbance: periodic kick of the base state (Environment.hpp:912-940)
+  int32_t disturb_every;       // int(period / control_dt * 10) evaluated in double like ENV:747 (in f32, 0.02 / 0.002 * 10 truncates to 99)
+  const float *ref;
 };
 
 // Device-resident state pool, structure of arrays in the reference's natural row-major shapes so the
@@ -62,5 +68,5 @@ enum {
   IRRL_P_DR_MATERIAL = 1, IRRL_P_DR_MASS = 2, IRRL_P_DR_COM = 6, IRRL_P_DR_THIGH = 16,
   IRRL_P_RESET_TIME = 20, IRRL_P_RESET_CMD = 21, IRRL_P_RESET_JOINT = 22, IRRL_P_RESET_JOINT_IND = 23,
   IRRL_P_RESET_BASE = 29, IRRL_P_RESET_XY = 30,
-  IRRL_P_ACTION_NOISE = 40, IRRL_P_OBS_JOINT = 44, IRRL_P_OBS_JVEL = 47, IRRL_P_OBS_NORMAL = 50, IRRL_P_CMD = 56
+  IRRL_P_ACTION_NOISE = 40, IRRL_P_OBS_JOINT = 44, IRRL_P_OBS_JVEL = 47, IRRL_P_OBS_NORMAL = 50, IRRL_P_CMD = 56, IRRL_P_DISTURB = 60 /* ..61 */
 };

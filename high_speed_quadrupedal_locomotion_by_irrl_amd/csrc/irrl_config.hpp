@@ -149,8 +149,18 @@ inline bool build_params(const Config &c, EnvParams &P, std::string &err) {
   P.hf_x0 = -250.0f; P.hf_y0 = -10.0f;
   P.hf_inv_dx = (float)((5000 - 1) / 500.0); P.hf_inv_dy = (float)((500 - 1) / 20.0);
   P.height = nullptr;
-  if (!manual_traj && !P.manual) { err = "ManualTraj: False needs the RefTraj CSV path (SURVEY 8f-4), not built yet"; return false; }
-  if (force && P.manual) { err = "ForceDisturbance with Manual (state_disturbance, Environment.hpp:912-940) is not built"; return false; }
+  P.ref_traj = (!manual_traj && !P.manual) ? 1 : 0;   // table attached by the owner of the pool (RefTraj CSV or irrl_env_set_ref_host)
+  P.ref_rows = 0; P.ref = nullptr;
+  // ForceDisturbance: with Manual it is state_disturbance (ENV:912-940, built); without Manual it is force_attack, whose trigger
+  // `random() < 2 dt / T` (ENV:751) compares a 31-bit integer with a number < 1 and never fires -> nothing to build
+  P.state_disturbance = (force && P.manual) ? 1 : 0;
+  {
+    double period = 0.0, cdt = 0.0;
+    std::string e2;
+    c.get_double("period", period, e2); c.get_double("control_dt", cdt, e2);
+    P.disturb_every = cdt > 0.0 ? (int32_t)(period / cdt * 10.0) : 0;
+    if (P.disturb_every <= 0) P.state_disturbance = 0;
+  }
   return true;
 }
 

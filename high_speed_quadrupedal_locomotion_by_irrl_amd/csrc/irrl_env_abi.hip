@@ -26,6 +26,7 @@ extern "C" __global__ void irrl_terminal_kernel(EnvParams, EnvState, uint8_t *);
 #include "irrl_config.hpp"
 #include "irrl_state_pool.hpp"
 #include "irrl_terrain.hpp"
+#include "irrl_csv.hpp"
 #include "../../include/irrl_env.h"
 
 #include <cmath>
@@ -55,6 +56,7 @@ struct irrl_env {
   float *d_action = nullptr, *d_ob = nullptr, *d_reward = nullptr, *d_extra = nullptr, *d_scratch = nullptr;
   uint8_t *d_done = nullptr;
   float *d_height = nullptr;  // shared height field (Terrain: True)
+  float *d_ref = nullptr;     // reference-trajectory table [rows, 30] (ManualTraj: False)
   std::vector<float> h_height;
   // pinned host staging
   char *h_pinned = nullptr;
@@ -133,7 +135,34 @@ irrl_env *irrl_env_create(const char *resource_dir, const char *cfg_yaml, int de
   }
   if (!ok) { g_err = "device / pinned allocation failed"; irrl_env_destroy(h); return nullptr; }
   h->S = h->pool.view(h->d_pool);
+  if (h->P.ref_traj) {
+    // VEC:158-169: the table named by cfg["RefTraj"]; a missing file is only a console message there (and a crash at the
+    // first step) -- here the pool is created, and init() refuses to run until irrl_env_set_ref_host supplied a table
+    auto it = h->cfg.kv.find("RefTraj");
+    std::vector<float> tab;
+    int rows = 0, cols = 0;
+    std::string e;
+    if (it != h->cfg.kv.end() && irrl_host::read_csv_f32(it->second, tab, rows, cols, e)) {
+      if (irrl_env_set_ref_host(h, tab.data(), rows, cols) != 0) { irrl_env_destroy(h); return nullptr; }
+    }
+  }
   return h;
+}
+
+// ENV:1895 set_ref (VEC:173-176): reference-trajectory table, [rows, cols >= 30] row-major f32; only the first 30 columns
+// are kept (theta 12 | theta_dot 12 | z | phase 2 | cmd 3)
+int irrl_env_set_ref_host(irrl_env *h, const float *table, int rows, int cols) {
+  if (!h->P.ref_traj) { g_err = "this pool generates its own reference (ManualTraj / Manual): no table is used"; return 1; }
+  if (!table || rows < 2 || cols < 30) { g_err = "reference table needs at least 2 rows and 30 columns (Environment.hpp:17-21)"; return 1; }
+  std::vector<float> packed((size_t)rows * 30);
+  for (int r = 0; r < rows; r++) std::memcpy(&packed[(size_t)r * 30], table + (size_t)r * cols, 30 * sizeof(float));
+  HIP_TRY(hipSetDevice(h->device));
+  if (h->d_ref) { (void)hipFree(h->d_ref); h->d_ref = nullptr; }
+  HIP_TRY(hipMalloc((void **)&h->d_ref, packed.size() * sizeof(float)));
+  HIP_TRY(hipMemcpy(h->d_ref, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+  h->P.ref = h->d_ref;
+  h->P.ref_rows = rows;
+  return 0;
 }
 
 void irrl_env_destroy(irrl_env *h) {
@@ -147,6 +176,7 @@ void irrl_env_destroy(irrl_env *h) {
   if (h->d_done) (void)hipFree(h->d_done);
   if (h->d_scratch) (void)hipFree(h->d_scratch);
   if (h->d_height) (void)hipFree(h->d_height);
+  if (h->d_ref) (void)hipFree(h->d_ref);
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
   delete h;
 }
@@ -154,6 +184,10 @@ void irrl_env_destroy(irrl_env *h) {
 int irrl_env_set_stream(irrl_env *h, void *hip_stream) { h->stream = (hipStream_t)hip_stream; return 0; }
 
 int irrl_env_init(irrl_env *h) {
+  if (h->P.ref_traj && !h->P.ref) {
+    g_err = "ManualTraj: False needs the reference-trajectory table: RefTraj file not readable and irrl_env_set_ref_host not called";
+    return 1;
+  }
   HIP_TRY(hipSetDevice(h->device));
   IRRL_LAUNCH(h, irrl_init_kernel, lane_grid(h, h->P.n_envs), h->P, h->S);
   HIP_TRY(hipGetLastError());

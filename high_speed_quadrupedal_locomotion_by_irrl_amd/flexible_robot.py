@@ -222,6 +222,14 @@ class FlexibleGymEnv(object):
             raise TypeError("state must have shape (%d, 288)" % self._n)
         _lib.check(self._lib.irrl_env_set_state_host(self._h, state.ctypes.data_as(C.POINTER(C.c_double))))
 
+    def set_ref(self, table):
+        """Reference-trajectory table of a `ManualTraj: False` pool (Environment.hpp:1895 `set_ref`): [rows, >= 30] float32,
+        one row per control step = theta 12 | theta_dot 12 | z | phase 2 | cmd 3.  Call before init() when cfg["RefTraj"]
+        does not name a readable CSV."""
+        table = np.ascontiguousarray(table, dtype=np.float32)
+        assert table.ndim == 2
+        _lib.check(self._lib.irrl_env_set_ref_host(self._h, table.ctypes.data_as(_fp), table.shape[0], table.shape[1]))
+
     def heightfield(self):
         """[5000, 500] float32 height field of a Terrain: True pool (None on flat ground)."""
         nx, ny = C.c_int(0), C.c_int(0)

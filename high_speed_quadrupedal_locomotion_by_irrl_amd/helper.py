@@ -23,3 +23,26 @@ def TensorboardLauncher(directory_path):
     """The reference spawns tensorboard + a browser (raisim_gym_helper.py:17-29); the headless engine only
     reports where the logs are."""
     print("[IRRL] logs under", directory_path)
+
+
+class DelayTool(object):
+    """Observation / command delay line of the evaluation script (IRRL/script/utils/DelayTool.py:5-21): the first sample
+    fills the line, afterwards `input_output(s)` returns the sample from int(delay_time / dt) calls ago.
+    With a zero-length line the reference blocks forever on an empty queue; here the sample passes straight through."""
+
+    def __init__(self, dt, delay_time):
+        import collections
+        self.num = int(delay_time / dt)
+        self.Q = collections.deque()
+        self.flag_first = True
+
+    def input_output(self, s0):
+        if self.num <= 0:
+            return s0
+        if self.flag_first:
+            self.flag_first = False
+            for _ in range(self.num):
+                self.Q.append(s0)
+        res = self.Q.popleft()
+        self.Q.append(s0)
+        return res

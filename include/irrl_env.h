@@ -111,6 +111,10 @@ enum {
 };
 int irrl_env_get_state_host(irrl_env *h, double *out);
 int irrl_env_set_state_host(irrl_env *h, const double *in);
+/* ENV:1895 set_ref / VEC:158-176: the reference-trajectory table of a `ManualTraj: False` pool, [rows, cols >= 30] row-major
+ * f32 (theta 12 | theta_dot 12 | z | phase 2 | cmd 3 per control step, Environment.hpp:17-21).  create() loads the CSV named
+ * by cfg["RefTraj"] when it is readable (VectorizedEnvironment.hpp:33-76 format); otherwise call this before init(). */
+int irrl_env_set_ref_host(irrl_env *h, const float *table, int rows, int cols);
 /* the shared height field of a `Terrain: True` pool (Environment.hpp:254-264), [nx, ny] row-major f32; out may be NULL
  * to query the shape only; returns non-zero on flat ground */
 int irrl_env_heightfield_host(irrl_env *h, float *out, int *nx, int *ny);

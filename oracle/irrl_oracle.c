@@ -38,6 +38,7 @@ typedef ORC_REAL real;
 #define R_COS(x) ((real)cos((double)(x)))
 #define R_ASIN(x) ((real)asin((double)(x)))
 #define R_ACOS(x) ((real)acos((double)(x)))
+#define R_FLOOR(x) ((real)floor((double)(x)))
 #define R_EXP(x) ((real)exp((double)(x)))
 #define R_LOG(x) ((real)log((double)(x)))
 #define R_FMOD(x, y) ((real)fmod((double)(x), (double)(y)))
@@ -135,7 +136,7 @@ enum {
   P_RESET_TIME = 20, P_RESET_CMD = 21, P_RESET_JOINT = 22, P_RESET_JOINT_IND = 23 /* ..28 */,
   P_RESET_BASE = 29, P_RESET_XY = 30,
   P_ACTION_NOISE = 40 /* ..42 */, P_OBS_JOINT = 44 /* ..46 */, P_OBS_JVEL = 47 /* ..49 */,
-  P_OBS_NORMAL = 50 /* ..52 */, P_CMD = 56
+  P_OBS_NORMAL = 50 /* ..52 */, P_CMD = 56, P_DISTURB = 60 /* ..61 */
 };
 typedef struct { uint32_t seed, env, episode, step; } rng_addr;
 static void rng_u01x4(const rng_addr *a, uint32_t purpose, real u[4]) {
@@ -661,6 +662,8 @@ struct orc_env {
   real max_len;
   double flops;
   float *height; /* NULL = flat ground */
+  float *ref;    /* reference-trajectory table [ref_rows, 30] (ManualTraj: False), NULL otherwise */
+  int ref_rows;
 };
 
 static real env_time(const orc_env *h, const env_t *e) { return e->t0 + RC(e->frame_idx) * RC(h->cfg.control_dt); }
@@ -722,10 +725,26 @@ static void gait_generator_manual(const orc_cfg *cfg, const real *phase, real ma
   }
 }
 
-/* ENV:1010-1109 (ManualTraj branch; the RefTraj-CSV branch is a "next" row). */
+static int ref_traj_mode(const orc_cfg *c) { return !c->ManualTraj && !c->Manual; }
+/* row frame_idx of the table (ENV:972,1102,1670: ref.row(frame_idx)), clamped to the table */
+static const float *ref_row(const orc_env *h, const env_t *e) {
+  static const float zero_row[30] = {0};
+  if (!h->ref) return zero_row;
+  int f = e->frame_idx;
+  if (f < 0) f = 0;
+  if (f > h->ref_rows - 1) f = h->ref_rows - 1;
+  return h->ref + (size_t)f * 30;
+}
+/* ENV:1010-1109: ManualTraj branch, and the reference-trajectory branch ENV:1100-1107 + gait_generator() ENV:1667-1671. */
 static void command_obs_update(orc_env *h, env_t *e, int env_id, int flag_reset) {
   const orc_cfg *c = &h->cfg;
   if (c->Manual) return;
+  if (ref_traj_mode(c)) {
+    const float *row = ref_row(h, e);
+    for (int i = 0; i < 3; i++) { e->ob[i] = RC((double)row[27 + i]); e->command_filtered[i] = e->ob[i]; }
+    for (int j = 0; j < 12; j++) { e->jointRef[j] = RC((double)row[j]); e->jointDotRef[j] = RC((double)row[12 + j]); }
+    return;
+  }
   rng_addr a = {(uint32_t)c->seedd, (uint32_t)env_id, e->episode, (uint32_t)e->frame_idx};
   real u[4];
   rng_u01x4(&a, flag_reset ? P_RESET_CMD : P_CMD, u);
@@ -776,8 +795,14 @@ static void update_observation(orc_env *h, env_t *e, int env_id) {
   rng_addr a = {(uint32_t)c->seedd, (uint32_t)env_id, e->episode, (uint32_t)e->frame_idx};
   for (int i = 0; i < 35; i++) e->ob[i] = RC(0); /* ENV:960 zeroes all 35; obs[0:3] is rewritten by command_obs_update */
   real t = env_time(h, e);
-  e->ob[3] = R_SIN(RC(2) * RC(REF_PI) * t / RC(c->period));
-  e->ob[4] = R_COS(RC(2) * RC(REF_PI) * t / RC(c->period));
+  if (ref_traj_mode(c)) { /* ENV:972 */
+    const float *row = ref_row(h, e);
+    e->ob[3] = RC((double)row[25]);
+    e->ob[4] = RC((double)row[26]);
+  } else {
+    e->ob[3] = R_SIN(RC(2) * RC(REF_PI) * t / RC(c->period));
+    e->ob[4] = R_COS(RC(2) * RC(REF_PI) * t / RC(c->period));
+  }
   real nf = RC(c->ObsNoise);
   real uj[12], uv[12], nn[6];
   int noisy = (c->ObsNoise != 0.0);
@@ -1042,6 +1067,10 @@ static void env_reset(orc_env *h, env_t *e, int env_id) {
   if (c->RandomizePerEpisode && c->StochasticDynamics) model_randomize(&e->model, &a);
   rng_u01x4(&a, P_RESET_TIME, u);
   e->t0 = c->Manual ? RC(0.0) : u[0];
+  if (ref_traj_mode(c)) { /* ENV:538-539, 571: frame_max = rows / 2, frame_len = max_time / control_dt */
+    int span = h->ref_rows / 2 - (int)(c->max_time / c->control_dt) - 10;
+    e->frame_idx = span > 0 ? (int)R_TO_DOUBLE(R_FLOOR(RC((double)span) * sampling_reshape(u[1]))) : 0;
+  }
   for (int i = 0; i < 3; i++) e->command_filtered[i] = RC(0);
   for (int j = 0; j < 12; j++) e->torque_last[j] = RC(0);
   command_obs_update(h, e, env_id, 1);
@@ -1106,6 +1135,25 @@ static real env_step(orc_env *h, env_t *e, int env_id, const float *action) {
     pT[j] = p;
     e->pTargetLast[j] = p;
   }
+  if (c->ForceDisturbance && c->Manual) { /* ENV:743-748 -> state_disturbance ENV:912-940 */
+    int K = (int)(c->period / c->control_dt * 10.0);
+    if (K > 0 && e->frame_idx % K == 0) {
+      real ua[4], ub[4];
+      rng_u01x4(&a, P_DISTURB, ua);
+      rng_u01x4(&a, P_DISTURB + 1, ub);
+      const real r = RC(0.5);
+      e->gc[2] += RC(0.03) * (RC(2) * ua[0] - RC(1)) * r;
+      e->gc[3] += RC(0.1) * (RC(2) * ua[1] - RC(1)) * r;
+      e->gc[4] += RC(0.1) * (RC(2) * ua[2] - RC(1)) * r;
+      e->gc[5] += RC(0.1) * (RC(2) * ua[3] - RC(1)) * r;
+      e->gc[6] += RC(0.1) * (RC(2) * ub[0] - RC(1)) * r;
+      real nq = R_SQRT(e->gc[3] * e->gc[3] + e->gc[4] * e->gc[4] + e->gc[5] * e->gc[5] + e->gc[6] * e->gc[6]);
+      for (int k = 3; k < 7; k++) e->gc[k] /= nq; /* build-defined: unit quaternion before it reaches the integrator */
+      e->gv[2] += RC(0.1) * (RC(2) * ub[1] - RC(1)) * r;
+      e->gv[3] += RC(0.3) * (RC(2) * ub[2] - RC(1)) * r;
+      e->gv[4] += RC(0.3) * (RC(2) * ub[3] - RC(1)) * r;
+    }
+  }
   int loop = (int)(c->control_dt / c->simulation_dt + 1e-10); /* ENV:711 */
   for (int i = 0; i < loop; i++) physics_substep(h, e, pT);
   update_observation(h, e, env_id);
@@ -1147,7 +1195,7 @@ static void obs_scaling(const orc_cfg *c, real *mean, real *std) {
 
 orc_env *orc_create(const orc_cfg *cfg) {
   if (!cfg || cfg->num_envs <= 0) return NULL;
-  if (cfg->Crutial || (!cfg->ManualTraj && !cfg->Manual)) return NULL; /* rows not built yet */
+  if (cfg->Crutial) return NULL; /* row not built */
   orc_env *h = (orc_env *)calloc(1, sizeof(orc_env));
   h->cfg = *cfg;
   if (h->cfg.ContactIterations <= 0) h->cfg.ContactIterations = 6;
@@ -1173,7 +1221,16 @@ orc_env *orc_create(const orc_cfg *cfg) {
   h->height = cfg->Terrain ? make_heightfield((uint32_t)cfg->seedd) : NULL;
   return h;
 }
-void orc_destroy(orc_env *h) { if (h) { free(h->envs); free(h->height); free(h); } }
+void orc_destroy(orc_env *h) { if (h) { free(h->envs); free(h->height); free(h->ref); free(h); } }
+/* ENV:1895 set_ref: [rows, cols >= 30] row-major f32; call before orc_init */
+int orc_set_ref(orc_env *h, const float *table, int rows, int cols) {
+  if (!ref_traj_mode(&h->cfg) || !table || rows < 2 || cols < 30) return 1;
+  free(h->ref);
+  h->ref = (float *)malloc((size_t)rows * 30 * sizeof(float));
+  for (int r = 0; r < rows; r++) memcpy(h->ref + (size_t)r * 30, table + (size_t)r * cols, 30 * sizeof(float));
+  h->ref_rows = rows;
+  return 0;
+}
 int orc_num_envs(const orc_env *h) { return h->n; }
 int orc_real_bytes(void) { return (int)sizeof(real); }
 

@@ -68,6 +68,8 @@ typedef struct orc_env orc_env; /* opaque vector-env handle */
 /* lifecycle (VEC:132-194) */
 orc_env *orc_create(const orc_cfg *cfg);
 void orc_destroy(orc_env *h);
+/* reference-trajectory table of a ManualTraj: False pool (Environment.hpp:1895 set_ref), [rows, cols >= 30] f32 */
+int orc_set_ref(orc_env *h, const float *table, int rows, int cols);
 void orc_init(orc_env *h); /* ctor randomisation + first reset of every env (VEC:145-194) */
 int orc_num_envs(const orc_env *h);
 int orc_real_bytes(void); /* sizeof(ORC_REAL) of this build */

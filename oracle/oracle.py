@@ -146,11 +146,19 @@ class OracleVecEnv(object):
 
     def __init__(self, env_cfg, precision="f64"):
         self.lib = _lib(precision)
+        env_cfg = dict(env_cfg)
+        ref = env_cfg.pop("_ref_table", None)     # reference-trajectory table of a ManualTraj: False config
         self.cfg = cfg_from_dict(env_cfg)
         self.n = self.cfg.num_envs
         self.h = self.lib.orc_create(C.byref(self.cfg))
         if not self.h:
-            raise RuntimeError("orc_create refused this configuration (Crutial/Terrain/RefTraj rows not built)")
+            raise RuntimeError("orc_create refused this configuration (Crutial row not built)")
+        if ref is not None:
+            ref = np.ascontiguousarray(ref, np.float32)
+            self.lib.orc_set_ref.restype = C.c_int
+            self.lib.orc_set_ref.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int]
+            if self.lib.orc_set_ref(self.h, _fp(ref), ref.shape[0], ref.shape[1]) != 0:
+                raise RuntimeError("orc_set_ref refused the table")
         self.lib.orc_init(self.h)
 
     def __del__(self):

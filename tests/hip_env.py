@@ -9,8 +9,12 @@ from high_speed_quadrupedal_locomotion_by_irrl_amd.flexible_robot import Flexibl
 
 class HipVecEnv(object):
     def __init__(self, env_cfg):
-        text = yaml.safe_dump(dict(env_cfg), default_flow_style=False)
+        env_cfg = dict(env_cfg)
+        ref = env_cfg.pop("_ref_table", None)     # reference-trajectory table of a ManualTraj: False config (test plumbing)
+        text = yaml.safe_dump(env_cfg, default_flow_style=False)
         self.impl = FlexibleGymEnv(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY__, text)
+        if ref is not None:
+            self.impl.set_ref(ref)
         self.impl.init()
         self.n = self.impl.getNumOfEnvs()
         self._ob = np.zeros((self.n, 35), np.float32)

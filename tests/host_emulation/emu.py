@@ -50,11 +50,18 @@ class EmuVecEnv(object):
 
     def __init__(self, env_cfg, width=None):
         self.l = lib(self.WIDTH if width is None else width)
-        text = yaml.safe_dump(dict(env_cfg), default_flow_style=False)
+        env_cfg = dict(env_cfg)
+        ref = env_cfg.pop("_ref_table", None)     # reference-trajectory table of a ManualTraj: False config (test plumbing)
+        text = yaml.safe_dump(env_cfg, default_flow_style=False)
         self.h = self.l.emu_create(text.encode())
         if not self.h:
             raise RuntimeError(self.l.emu_last_error().decode())
         self.n = self.l.emu_num_envs(self.h)
+        if ref is not None:
+            ref = np.ascontiguousarray(ref, np.float32)
+            self.l.emu_set_ref.restype = C.c_int
+            self.l.emu_set_ref.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int]
+            assert self.l.emu_set_ref(self.h, _fp(ref), ref.shape[0], ref.shape[1]) == 0
         self.l.emu_init(self.h)
 
     def __del__(self):

@@ -20,6 +20,7 @@ struct Emu {
   irrl_host::StatePool pool;
   std::vector<char> mem;
   std::vector<float> height;
+  std::vector<float> ref;
   EnvState S;
 };
 static std::string g_err;
@@ -51,6 +52,15 @@ void *emu_create(const char *cfg_yaml) {
   return h;
 }
 void emu_destroy(void *hv) { delete (Emu *)hv; }
+int emu_set_ref(void *hv, const float *table, int rows, int cols) {
+  Emu *h = (Emu *)hv;
+  if (!h->P.ref_traj || rows < 2 || cols < 30) return 1;
+  h->ref.resize((size_t)rows * 30);
+  for (int r = 0; r < rows; r++) std::memcpy(&h->ref[(size_t)r * 30], table + (size_t)r * cols, 30 * sizeof(float));
+  h->P.ref = h->ref.data();
+  h->P.ref_rows = rows;
+  return 0;
+}
 int emu_num_envs(void *hv) { return ((Emu *)hv)->P.n_envs; }
 void emu_init(void *hv) {
   Emu *h = (Emu *)hv;

@@ -167,3 +167,24 @@ def check_invariants(cand, steps=40, seed=3):
     assert np.all(np.abs(lam[inc == 0]) == 0)                                  # no impulse without contact
     assert np.all((st[:, 2] > 0.1) & (st[:, 2] < 0.7))                          # base height inside the episode band
     return st
+
+
+def ref_table(rows=900, seed=5):
+    """Synthetic 30-column reference trajectory (the reference's own CSV is absent from the repository): a smooth trot-like
+    joint trajectory around the nominal pose, its rates, body height, phase (sin, cos) and a slowly varying command."""
+    t = np.arange(rows) * 0.002
+    rng = np.random.RandomState(seed)
+    tab = np.zeros((rows, 30), np.float32)
+    nominal = np.array([-0.1, -0.78, 1.57, 0.1, -0.78, 1.57, -0.1, -0.78, 1.57, 0.1, -0.78, 1.57])
+    amp = rng.uniform(0.05, 0.25, 12)
+    ph = rng.uniform(0, 2 * np.pi, 12)
+    w = 2 * np.pi / 0.4
+    tab[:, 0:12] = nominal + amp * np.sin(w * t[:, None] + ph)
+    tab[:, 12:24] = amp * w * np.cos(w * t[:, None] + ph)
+    tab[:, 24] = 0.3
+    tab[:, 25] = np.sin(w * t)
+    tab[:, 26] = np.cos(w * t)
+    tab[:, 27] = 0.5 + 0.3 * np.sin(0.7 * t)
+    tab[:, 28] = 0.1 * np.cos(0.9 * t)
+    tab[:, 29] = 0.2 * np.sin(1.3 * t)
+    return tab

@@ -108,3 +108,54 @@ def test_terrain_heightfield_and_teacher_forced_parity():
     toes = R.toe_positions(st[0, :19])
     hs = np.array([orc.terrain_sample(t[0], t[1])[0] for t in toes])
     assert np.all(toes[:, 2] - 0.0275 - hs > -5e-3)
+
+
+@pytest.mark.parametrize("cand", [E.EmuVecEnv, E.EmuVecEnv16])
+def test_reference_trajectory_mode(cand):
+    """ManualTraj: False: command, joint reference and phase come from row frame_idx of the table, episodes
+    start at a random frame; oracle and kernel source agree teacher-forced, and the observation really shows the table."""
+    tab = PL.ref_table()
+    cfg = load_env_cfg("default_cfg.yaml", num_envs=16, ManualTraj=False, max_time=0.4)
+    cfg["_ref_table"] = tab
+    orc, c = O.OracleVecEnv(cfg), cand(cfg)
+    PL.check_init(orc, c)
+    st = orc.get_state()
+    frames = st[:, PL.S["FRAME"]].astype(int)
+    span = 900 // 2 - int(0.4 / 0.002) - 10
+    assert frames.min() >= 1 and frames.max() <= span and len(set(frames.tolist())) > 4   # random start frames (ENV:571), +1 after reset
+    ob = orc.observe()
+    mean, std = O.obs_scaling(cfg)
+    raw = ob * std + mean
+    # obs[0:3] = cmd columns, obs[3:5] = phase columns of the row the reset's command update used (frame - 1 ... ) / observed
+    for i in range(16):
+        f = frames[i] - 1                                   # the observation was built before frame_idx++ (ENV:624-630)
+        assert np.abs(raw[i, 3:5] - tab[f, 25:27]).max() < 1e-5
+        assert np.abs(raw[i, 0:3] - tab[f, 27:30]).max() < 1e-5
+    PL.check_teacher_forced(orc, c, steps=30, seed=4)
+
+
+@pytest.mark.parametrize("cand", [E.EmuVecEnv, E.EmuVecEnv16])
+def test_manual_eval_mode_with_state_disturbance(cand):
+    """The evaluation configuration (Manual: True = bp5_test.yaml: fixed start pose, no command process, t0 = 0) with
+    ForceDisturbance: the base state is kicked every 10 gait periods (ENV:912-940); period 0.02 s makes that every 100 steps."""
+    cfg = load_env_cfg("default_cfg.yaml", num_envs=6, Manual=True, ForceDisturbance=True, period=0.02, ObsNoise=0.0, ActionNoise=0.0)
+    orc, c = O.OracleVecEnv(cfg), cand(cfg)
+    PL.check_init(orc, c)
+    st0 = orc.get_state()
+    assert np.allclose(st0[:, 0:2], 0.0) and np.allclose(st0[:, PL.S["T0"]], 0.0)       # Manual: origin start, t0 = 0
+    rng = np.random.RandomState(3)
+    K = int(0.02 / 0.002 * 10)          # evaluated in double like ENV:747 (in f32 it would be 99)
+    assert K == 100
+    plain = O.OracleVecEnv(dict(cfg, ForceDisturbance=False))
+    kicked = []
+    for k in range(210):
+        a = PL.random_actions(rng, 6, 0.1)
+        before = orc.get_state()
+        plain.set_state(before)
+        orc.step(a)
+        plain.step(a)
+        if np.abs(orc.get_state()[:, 0:37] - plain.get_state()[:, 0:37]).max() > 1e-3:
+            kicked.append(int(before[0, PL.S["FRAME"]]))
+    assert kicked == [100, 200], kicked
+    orc2, c2 = O.OracleVecEnv(cfg), cand(cfg)
+    PL.check_teacher_forced(orc2, c2, steps=120, seed=9, action_scale=0.1)

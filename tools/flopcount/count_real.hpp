@@ -36,5 +36,6 @@ inline bool operator!(CountReal a) { return !(a.v != 0.0); }
 CR1(R_SQRT, std::sqrt) CR1(R_SIN, std::sin) CR1(R_COS, std::cos) CR1(R_ASIN, std::asin) CR1(R_ACOS, std::acos)
 CR1(R_EXP, std::exp) CR1(R_LOG, std::log)
 inline CountReal R_FABS(CountReal x) { return CountReal(std::fabs(x.v)); }
+inline CountReal R_FLOOR(CountReal x) { CountReal::n++; return CountReal(std::floor(x.v)); }
 inline CountReal R_FMOD(CountReal x, CountReal y) { CountReal::n++; return CountReal(std::fmod(x.v, y.v)); }
 inline double R_TO_DOUBLE(CountReal x) { return x.v; }
