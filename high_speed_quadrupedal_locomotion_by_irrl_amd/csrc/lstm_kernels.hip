@@ -580,13 +580,19 @@ lstm_policy_step_kernel(PolicyStepArgs a) {
   const int col = l & 15, rq = l >> 4;
   const int stack = w / NW, ws = w - stack * NW;
   const int e0 = blockIdx.x * 16;
+  // N need not be a multiple of 16: rows past the pool read the last env (clamped index) and store nothing
+  const int eA = (e0 + col < a.N) ? e0 + col : a.N - 1;
+  int eC[4];
+  bool okC[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) { okC[j] = e0 + 4 * rq + j < a.N; eC[j] = okC[j] ? e0 + 4 * rq + j : a.N - 1; }
   const int u = 16 * ws + col;
   const long long t = a.row;
   const long long gstep = a.rng_step + (a.rng_base ? *a.rng_base : 0ll);
-  const float keepA = a.dones[e0 + col] ? 0.0f : 1.0f;
+  const float keepA = a.dones[eA] ? 0.0f : 1.0f;
   float keepC[4];
 #pragma unroll
-  for (int j = 0; j < 4; j++) keepC[j] = a.dones[e0 + 4 * rq + j] ? 0.0f : 1.0f;
+  for (int j = 0; j < 4; j++) keepC[j] = a.dones[eC[j]] ? 0.0f : 1.0f;
   for (int i = tid; i < HID * a.act_dim; i += blockDim.x) head_w[i] = a.pi_w[i];
   if (tid < HID) head_w[HID * a.act_dim + tid] = a.vf_w[tid];
   // Everything that does not depend on layer 0's output is requested up front, in program order, so that the L2 / HBM
@@ -601,12 +607,12 @@ lstm_policy_step_kernel(PolicyStepArgs a) {
   float hp0[KS], hp1[KS], cp0[4], cp1[4], ob[OBKC];
   f32x4 Wh0[KS], Wh1[KS], Wx0[OBKC];
 #pragma unroll
-  for (int kk = 0; kk < KS; kk++) hp0[kk] = a.states_in[(size_t)(e0 + col) * SD + soff0 + HID + 4 * kk + rq];
+  for (int kk = 0; kk < KS; kk++) hp0[kk] = a.states_in[(size_t)eA * SD + soff0 + HID + 4 * kk + rq];
   if (OBK > 0) {
 #pragma unroll
     for (int kk = 0; kk < OBKC; kk++) {
       const int k = 4 * kk + rq, kc = k < a.ob_dim ? k : a.ob_dim - 1;   // clamped: the load is unconditional, the value masked
-      ob[kk] = a.obs[(size_t)(e0 + col) * a.ob_dim + kc];
+      ob[kk] = a.obs[(size_t)eA * a.ob_dim + kc];
     }
   }
 #pragma unroll
@@ -619,13 +625,13 @@ lstm_policy_step_kernel(PolicyStepArgs a) {
     }
   }
 #pragma unroll
-  for (int kk = 0; kk < KS; kk++) hp1[kk] = a.states_in[(size_t)(e0 + col) * SD + soff1 + HID + 4 * kk + rq];
+  for (int kk = 0; kk < KS; kk++) hp1[kk] = a.states_in[(size_t)eA * SD + soff1 + HID + 4 * kk + rq];
 #pragma unroll
   for (int kk = 0; kk < KS; kk++) Wh1[kk] = *(const f32x4 *)&wh1[((size_t)(4 * kk + rq) * HID + u) * 4];
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    cp0[j] = a.states_in[(size_t)(e0 + 4 * rq + j) * SD + soff0 + u];
-    cp1[j] = a.states_in[(size_t)(e0 + 4 * rq + j) * SD + soff1 + u];
+    cp0[j] = a.states_in[(size_t)eC[j] * SD + soff0 + u];
+    cp1[j] = a.states_in[(size_t)eC[j] * SD + soff1 + u];
   }
   const f32x4 bias0 = *(const f32x4 *)&b0[u * 4], bias1 = *(const f32x4 *)&b1[u * 4];
   __builtin_amdgcn_sched_barrier(0);   // keep the loads above clustered: the scheduler must not sink them between the MFMAs
@@ -649,7 +655,7 @@ lstm_policy_step_kernel(PolicyStepArgs a) {
     const int ksx = (a.ob_dim + 3) >> 2;
     for (int kk = 0; kk < ksx; kk++) {
       const int k = 4 * kk + rq, kc = k < a.ob_dim ? k : a.ob_dim - 1;
-      const float av = (k < a.ob_dim) ? a.obs[(size_t)(e0 + col) * a.ob_dim + kc] : 0.0f;
+      const float av = (k < a.ob_dim) ? a.obs[(size_t)eA * a.ob_dim + kc] : 0.0f;
       const f32x4 bw = *(const f32x4 *)&wx0[((size_t)kc * HID + u) * 4];
 #pragma unroll
       for (int g = 0; g < 4; g++) acc0[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[g], acc0[g], 0, 0, 0);
@@ -673,9 +679,8 @@ lstm_policy_step_kernel(PolicyStepArgs a) {
     const float ig = fast_sigmoid(acc0[0][j]), fg = fast_sigmoid(acc0[1][j]), og = fast_sigmoid(acc0[2][j]), gg = fast_tanh(acc0[3][j]);
     const float cn = fg * (cp0[j] * keepC[j]) + ig * gg;
     const float hn = og * fast_tanh(cn);
-    const size_t row = (size_t)(e0 + 4 * rq + j) * SD + soff0;
-    a.states_out[row + u] = cn;
-    a.states_out[row + HID + u] = hn;
+    const size_t row = (size_t)eC[j] * SD + soff0;
+    if (okC[j]) { a.states_out[row + u] = cn; a.states_out[row + HID + u] = hn; }
     hbuf[stack][(4 * rq + j) * LD + u] = hn;
   }
   __syncthreads();
@@ -691,15 +696,14 @@ lstm_policy_step_kernel(PolicyStepArgs a) {
     const float ig = fast_sigmoid(acc1[0][j]), fg = fast_sigmoid(acc1[1][j]), og = fast_sigmoid(acc1[2][j]), gg = fast_tanh(acc1[3][j]);
     const float cn = fg * (cp1[j] * keepC[j]) + ig * gg;
     const float hn = og * fast_tanh(cn);
-    const size_t row = (size_t)(e0 + 4 * rq + j) * SD + soff1;
-    a.states_out[row + u] = cn;
-    a.states_out[row + HID + u] = hn;
+    const size_t row = (size_t)eC[j] * SD + soff1;
+    if (okC[j]) { a.states_out[row + u] = cn; a.states_out[row + HID + u] = hn; }
     hbuf[stack][(4 * rq + j) * LD + u] = hn;
   }
   __syncthreads();
   // heads: thread (env, action) for the mean / sample, 16 more threads for the value and the neglogp sum
   const int A = a.act_dim;
-  if (tid < 16 * A) {
+  if (tid < 16 * A && e0 + tid / A < a.N) {
     const int env = tid / A, ai = tid - env * A;
     float mean = a.pi_b[ai];
 #pragma unroll
@@ -730,13 +734,14 @@ lstm_policy_step_kernel(PolicyStepArgs a) {
   }
   float val = 0.0f;
   const int vt = tid - 16 * A;
-  if (vt >= 0 && vt < 16) {
+  const bool vok = vt >= 0 && vt < 16 && e0 + vt < a.N;
+  if (vok) {
     val = a.vf_b[0];
 #pragma unroll
     for (int k = 0; k < HID; k++) val = __builtin_fmaf(hbuf[1][vt * LD + k], head_w[HID * A + k], val);
   }
   __syncthreads();
-  if (vt >= 0 && vt < 16) {
+  if (vok) {
     float nl = 0.0f;
     for (int ai = 0; ai < A; ai++) nl += terms[vt][ai];
     nl += 0.918938533204672742f * (float)A;   // 0.5 log(2 pi) per action dimension
@@ -751,7 +756,7 @@ lstm_policy_step_kernel(PolicyStepArgs a) {
     }
   }
   if (a.mb_obs) {
-    const int n = 16 * a.ob_dim;
+    const int n = ((a.N - e0 < 16) ? a.N - e0 : 16) * a.ob_dim;
     const float *src = a.obs + (size_t)e0 * a.ob_dim;
     float *dst = a.mb_obs + ((size_t)t * a.N + e0) * a.ob_dim;
     for (int i = tid; i < n; i += blockDim.x) dst[i] = src[i];
@@ -810,7 +815,7 @@ int irrl_lstm_policy_step(int hid, int ob_dim, int act_dim, int N, const float *
                           const long long *rng_base, float *action, float *clipped, float *value, float *neglogp, long long row, float *mb_obs,
                           float *mb_actions, float *mb_values, float *mb_neglogp, uint8_t *mb_dones, float *mb_rewards,
                           const float *prev_reward, void *hip_stream) {
-  if (N <= 0 || (N % 16) != 0 || ob_dim <= 0 || act_dim <= 0 || act_dim > 16) return 1;
+  if (N <= 0 || ob_dim <= 0 || act_dim <= 0 || act_dim > 16) return 1;
   const int threads = 2 * (hid / 16) * 64;
   if (16 * act_dim + 16 > threads) return 1;
   PolicyStepArgs a;
@@ -830,8 +835,8 @@ int irrl_lstm_policy_step(int hid, int ob_dim, int act_dim, int N, const float *
   const int obk = (ob_dim + 3) / 4;
 #define IRRL_PS_LAUNCH(H) \
   do { \
-    if (obk == 9) hipLaunchKernelGGL((lstm_policy_step_kernel<H, 9>), dim3(N / 16), dim3(threads), 0, s, a); \
-    else hipLaunchKernelGGL((lstm_policy_step_kernel<H, 0>), dim3(N / 16), dim3(threads), 0, s, a); \
+    if (obk == 9) hipLaunchKernelGGL((lstm_policy_step_kernel<H, 9>), dim3((N + 15) / 16), dim3(threads), 0, s, a); \
+    else hipLaunchKernelGGL((lstm_policy_step_kernel<H, 0>), dim3((N + 15) / 16), dim3(threads), 0, s, a); \
   } while (0)
   if (hid == 48) IRRL_PS_LAUNCH(48);
   else if (hid == 32) IRRL_PS_LAUNCH(32);

@@ -202,7 +202,7 @@ def supported(x, hid):
 def policy_step_supported(policy, obs):
     n = policy.n_lstm
     return (obs.is_cuda and obs.dtype == torch.float32 and len(n) == 2 and n[0] == n[1] and n[0] in (32, 48, 64)
-            and obs.shape[0] % 16 == 0 and 16 * policy.act_dim + 16 <= 8 * n[0] and policy.act_dim <= 16)
+            and 16 * policy.act_dim + 16 <= 8 * n[0] and policy.act_dim <= 16)
 
 
 def policy_step(policy, obs, states, dones, noise=None, rng=None, states_out=None, rollout=None, out=None):

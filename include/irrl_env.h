@@ -166,7 +166,7 @@ int irrl_lstm_seq_backward_x(int hid, int T, int N, int n_in, const float *gates
  * Outputs action (unclipped sample), clipped (to [-1,1]), value [N], neglogp [N].  With row >= 0 also row `row` of
  * mb_obs [T,N,ob], mb_actions [T,N,act], mb_values / mb_neglogp [T,N], mb_dones [T,N] u8, and, if mb_rewards and
  * prev_reward [N] are given and row > 0, row-1 of mb_rewards (the reward of the previous env step).
- * N % 16 == 0, hid in {32,48,64}, 16 act + 16 <= 8 hid. */
+ * Any N (workgroups of 16 envs, the last one partially filled), hid in {32,48,64}, 16 act + 16 <= 8 hid. */
 int irrl_lstm_policy_step(int hid, int ob_dim, int act_dim, int N, const float *obs, const uint8_t *dones, const float *states_in,
                           float *states_out, const float *const *lstm_w, const float *pi_w, const float *pi_b, const float *vf_w,
                           const float *vf_b, const float *logstd, const float *noise, int rng_on, unsigned rng_seed, long long rng_step,

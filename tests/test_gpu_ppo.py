@@ -105,7 +105,7 @@ def test_fused_lstm_policy_full_size_agrees_with_eager():
         assert float((a - b).abs().max()) / (float(a.abs().max()) + 1e-6) < 1e-4
 
 
-@pytest.mark.parametrize("N,hid,deterministic", [(4096, 48, False), (48, 48, True), (16, 32, False), (160, 64, False)])
+@pytest.mark.parametrize("N,hid,deterministic", [(4096, 48, False), (48, 48, True), (16, 32, False), (160, 64, False), (200, 48, False), (7, 48, False)])
 def test_fused_policy_step_matches_eager_step(N, hid, deterministic):
     """The single-launch rollout step (both LSTM stacks, heads, sample, neglogp, clip, buffer rows) against the eager
     CustomLSTMPolicy.step built from torch ops, same weights / state / noise."""
