@@ -563,6 +563,74 @@ LSTM_DEV void policy_philox(unsigned seed, unsigned c0, unsigned c1, unsigned c2
 }
 #define IRRL_P_POLICY_NOISE 0x50u  /* purpose word of the sampling noise: block q = action index / 4 uses purpose 0x50 + q */
 
+// Heads, sample, neglogp, clip and rollout-buffer rows shared by the LSTM and MLP policy-step kernels: thread (env, action)
+// for the mean / sample, 16 more threads for the value and the neglogp sum.  hpi / hv: the two nets' last hidden
+// activations [16 envs][LD] in LDS; head_w: pi_w [HID][act] then vf_w [HID] staged in LDS.
+template <int HID>
+LSTM_DEV void policy_heads(const PolicyStepArgs &a, const float *hpi, const float *hv, int LD, const float *head_w, float (*terms)[17],
+                           int e0, int tid, long long t, long long gstep) {
+  // heads: thread (env, action) for the mean / sample, 16 more threads for the value and the neglogp sum
+  const int A = a.act_dim;
+  if (tid < 16 * A && e0 + tid / A < a.N) {
+    const int env = tid / A, ai = tid - env * A;
+    float mean = a.pi_b[ai];
+#pragma unroll
+    for (int k = 0; k < HID; k++) mean = __builtin_fmaf(hpi[env * LD + k], head_w[k * A + ai], mean);
+    const float ls = a.logstd[ai];
+    const float sd = __expf(ls);
+    const size_t o = (size_t)(e0 + env) * A + ai;
+    float z = 0.0f;
+    if (a.noise) {
+      z = a.noise[o];
+    } else if (a.rng_on) {
+      float r[4];
+      policy_philox(a.rng_seed, (unsigned)(e0 + env), (unsigned)((unsigned long long)gstep >> 32), (unsigned)gstep, IRRL_P_POLICY_NOISE + (unsigned)(ai >> 2), r);
+      // Box-Muller on the pair (r0, r1) for slots 0/1 and (r2, r3) for slots 2/3; 1 - u is in (0, 1]
+      const int pair = (ai >> 1) & 1;
+      const float ua = pair ? r[2] : r[0], ub = pair ? r[3] : r[1];
+      const float rad = __builtin_sqrtf(-2.0f * __logf(1.0f - ua));
+      const float ang = 6.283185307179586f * ub;
+      z = rad * ((ai & 1) ? __sinf(ang) : __cosf(ang));
+    }
+    const float act = mean + sd * z;
+    const float d = (act - mean) / sd;
+    terms[env][ai] = 0.5f * d * d + ls;
+    const float cl = fminf(fmaxf(act, -1.0f), 1.0f);
+    a.action[o] = act;
+    a.clipped[o] = cl;
+    if (a.mb_actions) a.mb_actions[(size_t)t * a.N * A + o] = act;
+  }
+  float val = 0.0f;
+  const int vt = tid - 16 * A;
+  const bool vok = vt >= 0 && vt < 16 && e0 + vt < a.N;
+  if (vok) {
+    val = a.vf_b[0];
+#pragma unroll
+    for (int k = 0; k < HID; k++) val = __builtin_fmaf(hv[vt * LD + k], head_w[HID * A + k], val);
+  }
+  __syncthreads();
+  if (vok) {
+    float nl = 0.0f;
+    for (int ai = 0; ai < A; ai++) nl += terms[vt][ai];
+    nl += 0.918938533204672742f * (float)A;   // 0.5 log(2 pi) per action dimension
+    const int e = e0 + vt;
+    a.value[e] = val;
+    a.neglogp[e] = nl;
+    if (a.mb_values) {
+      a.mb_values[(size_t)t * a.N + e] = val;
+      a.mb_neglogp[(size_t)t * a.N + e] = nl;
+      a.mb_dones[(size_t)t * a.N + e] = a.dones[e];
+      if (a.prev_reward && t > 0) a.mb_rewards[(size_t)(t - 1) * a.N + e] = a.prev_reward[e];
+    }
+  }
+  if (a.mb_obs) {
+    const int n = ((a.N - e0 < 16) ? a.N - e0 : 16) * a.ob_dim;
+    const float *src = a.obs + (size_t)e0 * a.ob_dim;
+    float *dst = a.mb_obs + ((size_t)t * a.N + e0) * a.ob_dim;
+    for (int i = tid; i < n; i += blockDim.x) dst[i] = src[i];
+  }
+}
+
 #define PS_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b_, c_, 0, 0, 0)
 // OBK = k-steps of the observation projection ((ob_dim + 3) / 4) when known at compile time, 0 = runtime loop
 template <int HID, int OBK>
@@ -701,66 +769,62 @@ lstm_policy_step_kernel(PolicyStepArgs a) {
     hbuf[stack][(4 * rq + j) * LD + u] = hn;
   }
   __syncthreads();
-  // heads: thread (env, action) for the mean / sample, 16 more threads for the value and the neglogp sum
-  const int A = a.act_dim;
-  if (tid < 16 * A && e0 + tid / A < a.N) {
-    const int env = tid / A, ai = tid - env * A;
-    float mean = a.pi_b[ai];
+  policy_heads<HID>(a, hbuf[0], hbuf[1], LD, head_w, terms, e0, tid, t, gstep);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same single-launch rollout step for MlpPolicy (policies.py:430-446: separate pi / vf nets of two tanh layers of H
+// units).  A workgroup owns 16 envs; waves 0-1 run the pi net, waves 2-3 the vf net, two 16-column tiles each.
+// a.w[] = pi_w1 [ob][H], pi_b1, pi_w2 [H][H], pi_b2, vf_w1, vf_b1, vf_w2, vf_b2 (plain row-major, no permutation).
+template <int H>
+__global__ void __launch_bounds__(256)
+mlp_policy_step_kernel(PolicyStepArgs a) {
+  constexpr int LD = H + 1;
+  constexpr int NT = H / 32;                 // 16-column tiles per wave (two waves per net)
+  __shared__ float h1[2][16 * LD], h2[2][16 * LD];
+  __shared__ float terms[16][17];
+  __shared__ float head_w[H * 17];
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, l = tid & 63;
+  const int col = l & 15, rq = l >> 4;
+  const int net = w >> 1, half = w & 1;
+  const int e0 = blockIdx.x * 16;
+  const long long t = a.row;
+  const long long gstep = a.rng_step + (a.rng_base ? *a.rng_base : 0ll);
+  const int eA = (e0 + col < a.N) ? e0 + col : a.N - 1;
+  const float *__restrict__ w1 = net ? a.w[4] : a.w[0], *__restrict__ b1 = net ? a.w[5] : a.w[1];
+  const float *__restrict__ w2 = net ? a.w[6] : a.w[2], *__restrict__ b2 = net ? a.w[7] : a.w[3];
+  for (int i = tid; i < H * a.act_dim; i += blockDim.x) head_w[i] = a.pi_w[i];
+  if (tid < H) head_w[H * a.act_dim + tid] = a.vf_w[tid];
+  const int ksx = (a.ob_dim + 3) >> 2;
+  f32x4 acc[NT];
 #pragma unroll
-    for (int k = 0; k < HID; k++) mean = __builtin_fmaf(hbuf[0][env * LD + k], head_w[k * A + ai], mean);
-    const float ls = a.logstd[ai];
-    const float sd = __expf(ls);
-    const size_t o = (size_t)(e0 + env) * A + ai;
-    float z = 0.0f;
-    if (a.noise) {
-      z = a.noise[o];
-    } else if (a.rng_on) {
-      float r[4];
-      policy_philox(a.rng_seed, (unsigned)(e0 + env), (unsigned)((unsigned long long)gstep >> 32), (unsigned)gstep, IRRL_P_POLICY_NOISE + (unsigned)(ai >> 2), r);
-      // Box-Muller on the pair (r0, r1) for slots 0/1 and (r2, r3) for slots 2/3; 1 - u is in (0, 1]
-      const int pair = (ai >> 1) & 1;
-      const float ua = pair ? r[2] : r[0], ub = pair ? r[3] : r[1];
-      const float rad = __builtin_sqrtf(-2.0f * __logf(1.0f - ua));
-      const float ang = 6.283185307179586f * ub;
-      z = rad * ((ai & 1) ? __sinf(ang) : __cosf(ang));
-    }
-    const float act = mean + sd * z;
-    const float d = (act - mean) / sd;
-    terms[env][ai] = 0.5f * d * d + ls;
-    const float cl = fminf(fmaxf(act, -1.0f), 1.0f);
-    a.action[o] = act;
-    a.clipped[o] = cl;
-    if (a.mb_actions) a.mb_actions[(size_t)t * a.N * A + o] = act;
-  }
-  float val = 0.0f;
-  const int vt = tid - 16 * A;
-  const bool vok = vt >= 0 && vt < 16 && e0 + vt < a.N;
-  if (vok) {
-    val = a.vf_b[0];
+  for (int nt = 0; nt < NT; nt++) { const float bv = b1[16 * (half * NT + nt) + col]; acc[nt] = (f32x4){bv, bv, bv, bv}; }
+  for (int kk = 0; kk < ksx; kk++) {
+    const int k = 4 * kk + rq, kc = k < a.ob_dim ? k : a.ob_dim - 1;
+    const float av = (k < a.ob_dim) ? a.obs[(size_t)eA * a.ob_dim + kc] : 0.0f;
 #pragma unroll
-    for (int k = 0; k < HID; k++) val = __builtin_fmaf(hbuf[1][vt * LD + k], head_w[HID * A + k], val);
+    for (int nt = 0; nt < NT; nt++) acc[nt] = PS_MFMA(av, w1[(size_t)kc * H + 16 * (half * NT + nt) + col], acc[nt]);
   }
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) h1[net][(4 * rq + j) * LD + 16 * (half * NT + nt) + col] = fast_tanh(acc[nt][j]);
   __syncthreads();
-  if (vok) {
-    float nl = 0.0f;
-    for (int ai = 0; ai < A; ai++) nl += terms[vt][ai];
-    nl += 0.918938533204672742f * (float)A;   // 0.5 log(2 pi) per action dimension
-    const int e = e0 + vt;
-    a.value[e] = val;
-    a.neglogp[e] = nl;
-    if (a.mb_values) {
-      a.mb_values[(size_t)t * a.N + e] = val;
-      a.mb_neglogp[(size_t)t * a.N + e] = nl;
-      a.mb_dones[(size_t)t * a.N + e] = a.dones[e];
-      if (a.prev_reward && t > 0) a.mb_rewards[(size_t)(t - 1) * a.N + e] = a.prev_reward[e];
-    }
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++) { const float bv = b2[16 * (half * NT + nt) + col]; acc[nt] = (f32x4){bv, bv, bv, bv}; }
+#pragma unroll
+  for (int kk = 0; kk < H / 4; kk++) {
+    const float av = h1[net][col * LD + 4 * kk + rq];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) acc[nt] = PS_MFMA(av, w2[(size_t)(4 * kk + rq) * H + 16 * (half * NT + nt) + col], acc[nt]);
   }
-  if (a.mb_obs) {
-    const int n = ((a.N - e0 < 16) ? a.N - e0 : 16) * a.ob_dim;
-    const float *src = a.obs + (size_t)e0 * a.ob_dim;
-    float *dst = a.mb_obs + ((size_t)t * a.N + e0) * a.ob_dim;
-    for (int i = tid; i < n; i += blockDim.x) dst[i] = src[i];
-  }
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) h2[net][(4 * rq + j) * LD + 16 * (half * NT + nt) + col] = fast_tanh(acc[nt][j]);
+  __syncthreads();
+  policy_heads<H>(a, h2[0], h2[1], LD, head_w, terms, e0, tid, t, gstep);
 }
 
 extern "C" {
@@ -863,6 +927,32 @@ int irrl_lstm_seq_backward_x(int hid, int T, int N, int n_in, const float *gates
   else if (hid == 64) IRRL_BX(64, false);
   else return 1;
 #undef IRRL_BX
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+// One rollout step of MlpPolicy (two tanh layers of `hid` units per net; hid in {64}).  mlp_w: HOST array of 8 device
+// pointers pi_w1 [ob][hid], pi_b1, pi_w2 [hid][hid], pi_b2, vf_w1, vf_b1, vf_w2, vf_b2; everything else as irrl_lstm_policy_step
+// (no recurrent state).
+int irrl_mlp_policy_step(int hid, int ob_dim, int act_dim, int N, const float *obs, const uint8_t *dones, const float *const *mlp_w,
+                         const float *pi_w, const float *pi_b, const float *vf_w, const float *vf_b, const float *logstd, const float *noise,
+                         int rng_on, unsigned rng_seed, long long rng_step, const long long *rng_base, float *action, float *clipped,
+                         float *value, float *neglogp, long long row, float *mb_obs, float *mb_actions, float *mb_values, float *mb_neglogp,
+                         uint8_t *mb_dones, float *mb_rewards, const float *prev_reward, void *hip_stream) {
+  if (N <= 0 || ob_dim <= 0 || act_dim <= 0 || act_dim > 15 || hid != 64) return 1;
+  PolicyStepArgs a;
+  a.obs = obs; a.dones = dones; a.states_in = nullptr; a.states_out = nullptr;
+  for (int i = 0; i < 12; i++) a.w[i] = i < 8 ? mlp_w[i] : nullptr;
+  a.pi_w = pi_w; a.pi_b = pi_b; a.vf_w = vf_w; a.vf_b = vf_b; a.logstd = logstd; a.noise = noise;
+  a.action = action; a.clipped = clipped; a.value = value; a.neglogp = neglogp;
+  a.row = row; a.rng_base = rng_base;
+  const bool rows = row >= 0;
+  a.mb_obs = rows ? mb_obs : nullptr; a.mb_actions = rows ? mb_actions : nullptr; a.mb_values = rows ? mb_values : nullptr;
+  a.mb_neglogp = rows ? mb_neglogp : nullptr; a.mb_dones = rows ? mb_dones : nullptr; a.mb_rewards = rows ? mb_rewards : nullptr;
+  a.prev_reward = (rows && mb_rewards) ? prev_reward : nullptr;
+  if (rows && !(mb_obs && mb_actions && mb_values && mb_neglogp && mb_dones)) return 1;
+  a.rng_step = rng_step; a.rng_seed = rng_seed; a.rng_on = rng_on;
+  a.N = N; a.ob_dim = ob_dim; a.act_dim = act_dim;
+  hipLaunchKernelGGL((mlp_policy_step_kernel<64>), dim3((N + 15) / 16), dim3(256), 0, (hipStream_t)hip_stream, a);
   return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

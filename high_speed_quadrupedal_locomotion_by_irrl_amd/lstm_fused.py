@@ -251,3 +251,44 @@ def policy_step(policy, obs, states, dones, noise=None, rng=None, states_out=Non
     if rc != 0:
         raise RuntimeError("irrl_lstm_policy_step failed (rc=%d)" % rc)
     return action, clipped, value, neglogp, states_out
+
+
+def mlp_policy_step_supported(policy, obs):
+    return (obs.is_cuda and obs.dtype == torch.float32 and len(policy.pi_fc) == 2 and policy.pi_fc[0].w.shape[1] == 64
+            and policy.pi_fc[1].w.shape == (64, 64) and policy.act_dim <= 15)
+
+
+def mlp_policy_step(policy, obs, dones, noise=None, rng=None, rollout=None, out=None):
+    """MlpPolicy counterpart of `policy_step` (no recurrent state): -> action, clipped, value, neglogp."""
+    lib = _lib.load()
+    N, ob_dim = obs.shape
+    act = policy.act_dim
+    dev = obs.device
+    ws = [policy.pi_fc[0].w, policy.pi_fc[0].b, policy.pi_fc[1].w, policy.pi_fc[1].b,
+          policy.vf_fc[0].w, policy.vf_fc[0].b, policy.vf_fc[1].w, policy.vf_fc[1].b]
+    warr = (C.c_void_p * 8)(*[t.data_ptr() for t in ws])
+    obs = obs.contiguous()
+    assert dones.is_contiguous() and dones.element_size() == 1
+    if out is None:
+        out = (torch.empty(N, act, device=dev), torch.empty(N, act, device=dev), torch.empty(N, device=dev), torch.empty(N, device=dev))
+    action, clipped, value, neglogp = out
+    if noise is not None:
+        noise = noise.contiguous()
+    rng_on, seed, step, base = 0, 0, 0, None
+    if rng is not None and noise is None:
+        rng_on, seed, step = 1, int(rng[0]) & 0xFFFFFFFF, int(rng[1])
+        base = _ptr(rng[2]) if len(rng) > 2 and rng[2] is not None else None
+    if rollout is not None:
+        opt = lambda k: _ptr(rollout[k]) if rollout.get(k) is not None else None
+        row = int(rollout["row"])
+        rptr = [_ptr(rollout["mb_obs"]), _ptr(rollout["mb_actions"]), _ptr(rollout["mb_values"]),
+                _ptr(rollout["mb_neglogpacs"]), _ptr(rollout["mb_dones"]), opt("mb_rewards"), opt("prev_reward")]
+    else:
+        row, rptr = -1, [None] * 7
+    rc = lib.irrl_mlp_policy_step(64, ob_dim, act, N, _ptr(obs), _ptr(dones), warr, _ptr(policy.pi.w), _ptr(policy.pi.b), _ptr(policy.vf.w),
+                                  _ptr(policy.vf.b), _ptr(policy.logstd), _ptr(noise) if noise is not None else None, rng_on, seed, step, base,
+                                  _ptr(action), _ptr(clipped), _ptr(value), _ptr(neglogp), row, *rptr,
+                                  C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise RuntimeError("irrl_mlp_policy_step failed (rc=%d)" % rc)
+    return action, clipped, value, neglogp

@@ -254,13 +254,29 @@ class MlpPolicy(ActorCriticPolicy):
             v = torch.tanh(l(v))
         return self.pi(p), self.vf(v).squeeze(-1)
 
+    def fused_step_supported(self, obs):
+        if not (obs.is_cuda and SBLstm.use_fused):
+            return False
+        from . import lstm_fused
+        return lstm_fused.mlp_policy_step_supported(self, obs)
+
     @torch.no_grad()
-    def step(self, obs, states=None, masks=None, deterministic=False, generator=None):
+    def fused_step(self, obs, states, dones, noise=None, rng=None, states_out=None, rollout=None, out=None):
+        """Whole step in one launch (csrc/lstm_kernels.hip: mlp_policy_step_kernel); same surface as the LSTM policy's."""
+        from . import lstm_fused
+        d = dones if dones.element_size() == 1 else (dones != 0)
+        action, clipped, value, neglogp = lstm_fused.mlp_policy_step(self, obs, d.contiguous(), noise=noise, rng=rng, rollout=rollout, out=out)
+        return action, clipped, value, neglogp, states
+
+    @torch.no_grad()
+    def step(self, obs, states=None, masks=None, deterministic=False, generator=None, noise=None):
         mean, value = self._run(obs)
         if deterministic:
             action = mean
         else:
-            action = mean + torch.exp(self.logstd) * torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator)
+            if noise is None:
+                noise = torch.randn(mean.shape, device=mean.device, dtype=mean.dtype, generator=generator)
+            action = mean + torch.exp(self.logstd) * noise
         return action, value, states, diag_gaussian_neglogp(action, mean, self.logstd)
 
     @torch.no_grad()

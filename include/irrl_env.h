@@ -174,6 +174,15 @@ int irrl_lstm_policy_step(int hid, int ob_dim, int act_dim, int N, const float *
                           float *mb_actions, float *mb_values, float *mb_neglogp, uint8_t *mb_dones, float *mb_rewards,
                           const float *prev_reward, void *hip_stream);
 
+/* the same single-launch rollout step for MlpPolicy (flex_gym/archi/policies.py:430-446: separate pi / vf nets of two tanh
+ * layers of `hid` = 64 units).  mlp_w: HOST array of 8 device pointers pi_w1 [ob][hid], pi_b1, pi_w2 [hid][hid], pi_b2,
+ * vf_w1, vf_b1, vf_w2, vf_b2; heads, sampling, outputs and rollout rows as above; act <= 15. */
+int irrl_mlp_policy_step(int hid, int ob_dim, int act_dim, int N, const float *obs, const uint8_t *dones, const float *const *mlp_w,
+                         const float *pi_w, const float *pi_b, const float *vf_w, const float *vf_b, const float *logstd, const float *noise,
+                         int rng_on, unsigned rng_seed, long long rng_step, const long long *rng_base, float *action, float *clipped,
+                         float *value, float *neglogp, long long row, float *mb_obs, float *mb_actions, float *mb_values, float *mb_neglogp,
+                         uint8_t *mb_dones, float *mb_rewards, const float *prev_reward, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

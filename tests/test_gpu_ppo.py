@@ -215,3 +215,33 @@ def test_fused_policy_step_kernel_noise_is_the_counter_rng():
     assert torch.equal(act, act2)
     z3 = ((act3 - mean) / torch.exp(pol.logstd.detach())).cpu().numpy()
     assert abs(np.corrcoef(z.reshape(-1), z3.reshape(-1))[0, 1]) < 0.02
+
+
+@pytest.mark.parametrize("N,deterministic", [(4096, False), (200, False), (5, True)])
+def test_fused_mlp_policy_step_matches_eager_step(N, deterministic):
+    """mlp_policy_step_kernel (both tanh nets on MFMA, heads, sample, neglogp, clip, buffer rows) against MlpPolicy._run."""
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import MlpPolicy, diag_gaussian_neglogp
+    torch.manual_seed(N)
+    dev = torch.device("cuda")
+    pol = MlpPolicy().to(dev)
+    with torch.no_grad():
+        for p in pol.parameters():
+            p.add_(torch.randn_like(p) * 0.05)
+    obs = torch.randn(N, 35, device=dev)
+    dones = torch.rand(N, device=dev) < 0.2
+    noise = None if deterministic else torch.randn(N, 12, device=dev)
+    assert pol.fused_step_supported(obs)
+    T = 3
+    mb = dict(row=2, mb_obs=torch.zeros(T, N, 35, device=dev), mb_actions=torch.zeros(T, N, 12, device=dev), mb_values=torch.zeros(T, N, device=dev),
+              mb_neglogpacs=torch.zeros(T, N, device=dev), mb_dones=torch.zeros(T, N, dtype=torch.bool, device=dev),
+              mb_rewards=torch.zeros(T, N, device=dev), prev_reward=torch.randn(N, device=dev))
+    act, clipped, val, nlp, _ = pol.fused_step(obs, None, dones, noise=noise, rollout=mb)
+    with torch.no_grad():
+        mean, v_ref = pol._run(obs)
+        a_ref = mean if deterministic else mean + torch.exp(pol.logstd) * noise
+        nlp_ref = diag_gaussian_neglogp(a_ref, mean, pol.logstd)
+    for name, a, b, tol in (("action", a_ref, act, 2e-5), ("value", v_ref, val, 2e-5), ("neglogp", nlp_ref, nlp, 1e-4)):
+        assert float((a - b).abs().max()) <= tol * (1.0 + float(a.abs().max())), (name, float((a - b).abs().max()))
+    assert torch.equal(clipped, act.clamp(-1.0, 1.0))
+    assert torch.equal(mb["mb_obs"][2], obs) and torch.equal(mb["mb_actions"][2], act) and torch.equal(mb["mb_values"][2], val)
+    assert torch.equal(mb["mb_dones"][2], dones) and torch.equal(mb["mb_rewards"][1], mb["prev_reward"]) and not mb["mb_rewards"][2].any()
