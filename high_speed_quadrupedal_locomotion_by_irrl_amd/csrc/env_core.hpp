@@ -531,9 +531,9 @@ IRRL_DEV ContactBlock make_contact_block(sym3 G, v3 n) {
   B.nGn = dot(n, B.Gn);
   return B;
 }
-// one-contact solve (same decision order as the oracle's solve_contact): separating -> 0; sticking solution
-// inside the cone -> keep; pulling -> frictionless; else slide along the sticking direction with the normal
-// velocity condition kept exact.
+// one-contact solve (same decision order as the oracle's solve_contact): separating -> 0; sticking solution that pushes
+// and lies inside the cone -> keep; else slide: friction mu lam_n along the sticking impulse's tangential direction with
+// the normal velocity condition kept exact (normal impulse capped at 5 x the frictionless one near the jamming corner).
 IRRL_DEV v3 solve_contact(const ContactBlock &B, v3 c, v3 n, vf vstar, vf mu, vm relevant) {
   vf cn = dot(c, n) - vstar;
   v3 rhs = mk3(vstar * n.x - c.x, vstar * n.y - c.y, vstar * n.z - c.z);
@@ -541,7 +541,7 @@ IRRL_DEV v3 solve_contact(const ContactBlock &B, v3 c, v3 n, vf vstar, vf mu, vm
   vf ln = dot(l, n);
   v3 lt = l - ln * n;
   vf lt2 = dot(lt, lt);
-  vm sticking = lt2 <= mu * mu * ln * ln;
+  vm sticking = (lt2 <= mu * mu * ln * ln) & (ln > 0.0f);   // admissible sticking impulse: pushes, inside the cone
   vm sep = cn >= 0.0f;
 #ifdef IRRL_GS_FASTPATH
   // (measured slower on gfx950, 62 vs 57 us per step at 4096 envs: the wave-uniform branch breaks the interleaving of
@@ -550,15 +550,14 @@ IRRL_DEV v3 solve_contact(const ContactBlock &B, v3 c, v3 n, vf vstar, vf mu, vm
   if (!wave_any(relevant & !plain)) return l;
 #endif
   vf mcn = -cn;
-  v3 frictionless = (mcn * v_rcp(B.nGn)) * n;
-  v3 w = n + (mu * v_rsqrt(lt2)) * lt;
+  v3 w = n + (mu * v_rsqrt(v_max(lt2, 1e-30f))) * lt;
   vf nGw = dot(B.Gn, w);  // n.G w == (G n).w, G symmetric
-  vm use_fl = (ln <= 0.0f) | ((!sticking) & (nGw <= 1e-6f * B.nGn));
-  v3 slide = (mcn * v_rcp(nGw)) * w;
+  // jamming corner n.G w -> 0: normal impulse capped at 5 x the frictionless one (continuous and bounded)
+  v3 slide = (mcn * v_rcp(v_max(nGw, 0.2f * B.nGn))) * w;
   v3 r;
-  r.x = vsel(sep, 0.0f, vsel(use_fl, frictionless.x, vsel(sticking, l.x, slide.x)));
-  r.y = vsel(sep, 0.0f, vsel(use_fl, frictionless.y, vsel(sticking, l.y, slide.y)));
-  r.z = vsel(sep, 0.0f, vsel(use_fl, frictionless.z, vsel(sticking, l.z, slide.z)));
+  r.x = vsel(sep, 0.0f, vsel(sticking, l.x, slide.x));
+  r.y = vsel(sep, 0.0f, vsel(sticking, l.y, slide.y));
+  r.z = vsel(sep, 0.0f, vsel(sticking, l.z, slide.z));
   return r;
 }
 

@@ -540,17 +540,23 @@ static void solve_contact(const real *G, const real *c, const real *n, real vsta
   m3_mulv(Gn, G, n);
   real nGn = v3_dot(n, Gn);
   real ln = v3_dot(l, n);
-  if (ln <= RC(0)) { v3_scale(lam, n, -cn / nGn); return; }
   real lt[3];
   for (int i = 0; i < 3; i++) lt[i] = l[i] - ln * n[i];
   real lt2 = v3_dot(lt, lt);
-  if (lt2 <= mu * mu * ln * ln) { v3_copy(lam, l); return; }
-  real inv = RC(1) / R_SQRT(lt2), w[3], Gw[3];
+  /* the sticking impulse is admissible only if it pushes and stays inside the friction cone */
+  if (ln > RC(0) && lt2 <= mu * mu * ln * ln) { v3_copy(lam, l); return; }
+  /* otherwise the pressing contact slides: friction mu lam_n along the direction in which the sticking impulse would have
+   * pushed (it opposes the slip), normal velocity condition kept exact; frictionless only if that direction cannot carry
+   * the normal condition (see the cap below) */
+  real lt2c = lt2 > RC(1e-30) ? lt2 : RC(1e-30);
+  real inv = RC(1) / R_SQRT(lt2c), w[3], Gw[3];
   for (int i = 0; i < 3; i++) w[i] = n[i] + mu * lt[i] * inv;
   m3_mulv(Gw, G, w);
   real nGw = v3_dot(n, Gw);
-  if (nGw <= RC(1e-6) * nGn) { v3_scale(lam, n, -cn / nGn); return; }
-  v3_scale(lam, w, -cn / nGw);
+  /* n.G w -> 0 is the jamming (Painleve) corner, where the exact sliding impulse diverges: the normal impulse is capped
+   * at 5 times the frictionless one (continuous, bounded; the uncancelled approach velocity is left to the next substep) */
+  real den = nGw > RC(0.2) * nGn ? nGw : RC(0.2) * nGn;
+  v3_scale(lam, w, -cn / den);
 }
 
 /* ---- height field (Terrain: True).  RaiSim's Perlin terrain (ENV:254-264) is closed source; the spec is the

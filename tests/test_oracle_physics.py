@@ -161,3 +161,50 @@ def test_more_contact_sweeps_change_little():
             env.step(np.clip(0.3 * rng.normal(size=(4, 12)), -1, 1).astype(np.float32))
         outs.append(env.get_state()[:, :37])
     assert np.abs(outs[0] - outs[1])[:, :19].max() < 5e-3
+
+
+def test_contact_impulses_obey_momentum_balance_cone_and_stick_slip():
+    """One 0.25 ms substep with the feet on the ground, from sticking (robot at rest) and sliding (1.5 m/s sideways /
+    forwards) starts: the stored world-frame contact impulses must (a) account for the change of the total linear
+    momentum, p1 - p0 = sum(lambda) - m g dt z, up to the O(dt^2) change of configuration, (b) lie in the Coulomb cone,
+    on its boundary and dissipative for sliding feet, (c) leave sticking feet without velocity."""
+    dt = 0.00025
+    cfg = load_env_cfg("bp5_imitation.yaml", num_envs=6, control_dt=dt, simulation_dt=dt, ContactIterations=30, ContactTolerance=0.0)
+    env = O.OracleVecEnv(cfg)
+    st = env.get_state()
+    slide = [np.zeros(3), np.zeros(3), np.array([1.5, 0, 0]), np.array([0, 1.5, 0]), np.array([-1.0, 1.0, 0]), np.array([2.0, 0.3, 0])]
+    for i in range(6):
+        st[i, S["GC"]:S["GC"] + 19] = 0
+        st[i, S["GC"] + 2] = 0.2890          # nominal stance: toes ~1 mm into the ground
+        st[i, S["GC"] + 3] = 1.0
+        st[i, S["GC"] + 7:S["GC"] + 19] = [0, -0.78, 1.57] * 4
+        st[i, S["GV"]:S["GV"] + 18] = 0
+        st[i, S["GV"]:S["GV"] + 3] = slide[i]
+        st[i, S["LAMW"]:S["LAMW"] + 12] = 0
+        st[i, S["INCONTACT"]:S["INCONTACT"] + 4] = 0
+        st[i, S["TQL"]:S["TQL"] + 12] = 0
+    env.set_state(st)
+    s0 = env.get_state()
+    env.step(np.zeros((6, 12), np.float32))
+    s1 = env.get_state()
+    for i in range(6):
+        assert np.all(s1[i, S["INCONTACT"]:S["INCONTACT"] + 4] == 1)
+        lam = s1[i, S["LAMW"]:S["LAMW"] + 12].reshape(4, 3)
+        mu = s1[i, S["MATERIAL"]]
+        p0, _, _ = _momenta(s0[i, :19], s0[i, 19:37])
+        p1, _, _ = _momenta(s1[i, :19], s1[i, 19:37])
+        resid = p1 - p0 - (lam.sum(0) + np.array([0, 0, -8.88 * 9.81 * dt]))
+        assert np.abs(resid).max() < 2e-4 * max(1.0, np.abs(lam).max() / dt) * dt, (i, resid)   # O(dt^2) relative to the forces
+        ln, lt = lam[:, 2], np.linalg.norm(lam[:, :2], axis=1)
+        assert np.all(ln > 0) and np.all(lt <= mu * ln * (1 + 1e-6) + 1e-12)
+        _, vel = O.toe_kinematics(s1[i, :19], s1[i, 19:37])
+        vel = np.asarray(vel).reshape(4, 3)
+        for f in range(4):
+            vt = vel[f, :2]
+            if i < 2:      # at rest: sticking, no residual foot velocity, impulse strictly inside the cone
+                # (the probe reports the toe-sphere CENTRE: it may still roll about the resting contact point, r = 27.5 mm)
+                assert np.linalg.norm(vt) < 5e-4 and abs(vel[f, 2]) < 1e-6 and lt[f] < 0.9 * mu * ln[f]
+            else:          # sliding: on the cone boundary, opposing the slip, normal velocity removed
+                assert abs(lt[f] - mu * ln[f]) < 1e-6 * ln[f] + 1e-12
+                assert np.dot(lam[f, :2], vt) < 0 and np.dot(lam[f, :2], vt) < -0.9 * lt[f] * np.linalg.norm(vt)
+                assert abs(vel[f, 2]) < 1e-6
