@@ -546,8 +546,7 @@ static void solve_contact(const real *G, const real *c, const real *n, real vsta
   /* the sticking impulse is admissible only if it pushes and stays inside the friction cone */
   if (ln > RC(0) && lt2 <= mu * mu * ln * ln) { v3_copy(lam, l); return; }
   /* otherwise the pressing contact slides: friction mu lam_n along the direction in which the sticking impulse would have
-   * pushed (it opposes the slip), normal velocity condition kept exact; frictionless only if that direction cannot carry
-   * the normal condition (see the cap below) */
+   * pushed (it opposes the slip), normal velocity condition kept exact (up to the cap below) */
   real lt2c = lt2 > RC(1e-30) ? lt2 : RC(1e-30);
   real inv = RC(1) / R_SQRT(lt2c), w[3], Gw[3];
   for (int i = 0; i < 3; i++) w[i] = n[i] + mu * lt[i] * inv;
@@ -1154,7 +1153,7 @@ static real env_step(orc_env *h, env_t *e, int env_id, const float *action) {
       e->gc[5] += RC(0.1) * (RC(2) * ua[3] - RC(1)) * r;
       e->gc[6] += RC(0.1) * (RC(2) * ub[0] - RC(1)) * r;
       real nq = R_SQRT(e->gc[3] * e->gc[3] + e->gc[4] * e->gc[4] + e->gc[5] * e->gc[5] + e->gc[6] * e->gc[6]);
-      for (int k = 3; k < 7; k++) e->gc[k] /= nq; /* build-defined: unit quaternion before it reaches the integrator */
+      for (int k = 3; k < 7; k++) e->gc[k] = e->gc[k] / nq; /* build-defined: unit quaternion before it reaches the integrator */
       e->gv[2] += RC(0.1) * (RC(2) * ub[1] - RC(1)) * r;
       e->gv[3] += RC(0.3) * (RC(2) * ub[2] - RC(1)) * r;
       e->gv[4] += RC(0.3) * (RC(2) * ub[3] - RC(1)) * r;
