@@ -97,13 +97,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the env kernels have no CPU path")
+    # IRRL_BENCH_BACKEND=gloo + IRRL_BENCH_ONE_DEVICE=1 let the multi-rank control flow be exercised on a 1-GPU box
+    # (both ranks on cuda:0, barrier / max-reduce over gloo); the driver's runs use the defaults: one GPU per rank, RCCL
+    backend = os.environ.get("IRRL_BENCH_BACKEND", "nccl")
+    if os.environ.get("IRRL_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     with open(os.path.join(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY__, args.cfg)) as f:
         env_cfg = yaml.safe_load(f)["environment"]
@@ -146,7 +154,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps   # events on the stream the kernel is launched on
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # sanity on the timed work: finite outputs, episodes really terminate and reset inside the step
