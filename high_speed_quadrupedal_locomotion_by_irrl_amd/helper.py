@@ -46,3 +46,15 @@ class DelayTool(object):
         res = self.Q.popleft()
         self.Q.append(s0)
         return res
+
+
+def obs_normalisation(env_cfg):
+    """(obs_mean[35], obs_std[35], action_mean[12], action_std[12]) of the environment (Environment.hpp:371-393; the script-side
+    copy is IRRL/script/bp5_config.py:19-55): obs = [cmd 3 | phase 2 | joint 12 | joint rate 12 | body z-axis 3 | body omega 3]."""
+    import numpy as np
+    abad = float(env_cfg["abad"])
+    nominal = np.array([-abad, -0.78, 1.57, abad, -0.78, 1.57, -abad, -0.78, 1.57, abad, -0.78, 1.57])
+    vx, vy, om = float(env_cfg["Vx"]), float(env_cfg["Vy"]), float(env_cfg["Omega"])
+    mean = np.concatenate([[(vx + 0.0) / 2.0, (vy - vy) / 2.0, (om - om) / 2.0], [0.0, 0.0], nominal, np.zeros(12), [0.0, 0.0, 1.0], np.zeros(3)])
+    std = np.concatenate([np.ones(3), np.ones(2), np.ones(12), np.tile([5.0, 35.0, 40.0], 4), np.full(3, 0.7), np.full(3, 3.0)])
+    return mean, std, nominal.copy(), np.ones(12)

@@ -7,8 +7,13 @@ reference's own (run_bp_v5.py:8-13), resolved by the compat packages at the repo
     python scripts/run_bp_v5.py --train --load data/..._Iteration_100.pkl  # relaxation stage (new reward coeffs in --cfg)
     torchrun --nproc-per-node 8 --master-addr 127.0.0.1 scripts/run_bp_v5.py --train   # 8 x 4096 envs, RCCL grads
 
-The `--test` branch of the reference (gamepad-driven evaluation + ~700 lines of matplotlib analysis,
-run_bp_v5.py:261-1121) is out of scope; `--o` (CSV export of the actor) is kept.
+    python scripts/run_bp_v5.py --test --model data/..._final.pkl --cmd 1.5 --steps 2000   # headless evaluation
+
+`--test` keeps the evaluation LOOP of the reference (run_bp_v5.py:353-470: Manual-mode env, externally supplied command in
+obs[0:3], observation delay line, velocity / action low-pass filters, numpy LSTM actor, per-step records of joint state,
+posture, effort and the true simulator state) with a fixed command (`--cmd`, the reference's `flag_fix_cmd`) instead of
+the gamepad, and writes the records to an .npz instead of the ~700 lines of matplotlib analysis (run_bp_v5.py:471-1121),
+which stay out of scope.  `--o` (CSV export of the actor) is kept.
 """
 import argparse
 import math
@@ -44,7 +49,75 @@ def parse_args(argv):
     p.add_argument("--policy", choices=["lstm", "mlp"], default="lstm", help="lstm = CustomLSTMPolicy (bp5), mlp = MlpPolicy")
     p.add_argument("--num_envs", type=int, default=None, help="override environment.num_envs (per GPU)")
     p.add_argument("--eval_every_n", type=int, default=100)
+    # --test (run_bp_v5.py:61-108 flag_fix_cmd, delay, vel_filter_freq, act_filter_freq)
+    p.add_argument("--cmd", dest="flag_fix_cmd", type=float, default=1.0, help="fixed forward-velocity command of --test [m/s]")
+    p.add_argument("--steps", type=int, default=1500, help="control steps of --test")
+    p.add_argument("--delay", type=int, default=0, help="observation delay in control steps (DelayTool)")
+    p.add_argument("--vel_filter_freq", type=float, default=1.0e6, help="low-pass on the joint-rate / omega observations [Hz]")
+    p.add_argument("--act_filter_freq", type=float, default=1.0e6, help="low-pass on the action [Hz]")
+    p.add_argument("--out", type=str, default=None, help="--test: .npz with the per-step records")
     return p.parse_args(argv)
+
+
+def run_test(args, cfg):
+    """Headless evaluation loop (run_bp_v5.py:300-470 without gamepad, window and plots).  One Manual-mode env on the
+    numpy boundary (testStep-style single env), the trained actor as a numpy LSTM (CustomerLstmNN twin)."""
+    import numpy as np
+    from flex_gym.env.RaisimGymVecEnv import RaisimGymVecEnv
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.checkpoint import NumpyLstmActor, read_checkpoint
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.helper import DelayTool, obs_normalisation
+    if args.trained_model is None:
+        raise SystemExit("model path can't be ignored during test mode (--model)")
+    ecfg = dict(cfg["environment"])
+    ecfg["num_envs"] = 1
+    if not ecfg.get("Manual"):
+        print("*" * 50 + "\nMake sure the Manual flag is opened!!! (forcing Manual: True for this run)\n" + "*" * 50)
+        ecfg["Manual"] = True
+    env = RaisimGymVecEnv(FlexibleGymEnv(__RSCDIR__, yaml.safe_dump(ecfg)))
+    _, params = read_checkpoint(args.trained_model)
+    ctrl = NumpyLstmActor.from_parameter_list(params, n_layers=len(N_LSTM))
+    obs_mean, obs_std, action_mean, action_std = obs_normalisation(ecfg)
+    dt = float(ecfg["control_dt"])
+    alpha = lambda f: 2 * math.pi * dt * f / (2 * math.pi * dt * f + 1.0)
+    a_vel, a_act = alpha(args.vel_filter_freq), alpha(args.act_filter_freq)
+    env.SetContactCoefficient(np.array([[0.8, 0.2, 0.01]], dtype=np.float32))      # run_bp_v5.py:317-318
+    obs = env.reset()
+    d_tool = DelayTool(dt, dt * args.delay)
+    vel_his, act_his = np.zeros(35), np.zeros(12)
+    action_total = np.zeros([env.num_envs, env.num_acts], dtype=np.float32)
+    rec = {k: [] for k in ("joint", "joint_dot", "posture", "omega", "phase", "act", "oss", "contact", "joint_effort", "cmd", "reward")}
+    cmd = np.array([args.flag_fix_cmd, 0.0, 0.0])
+    n_done = 0
+    for t in range(args.steps):
+        o = np.array(d_tool.input_output(obs[0, :].copy()), dtype=np.float64)
+        o[32:35] = (1 - a_vel) * vel_his[32:35] + a_vel * o[32:35]
+        o[17:29] = (1 - a_vel) * vel_his[17:29] + a_vel * o[17:29]
+        vel_his = o.copy()
+        o[0:3] = (cmd - obs_mean[0:3]) / obs_std[0:3]                                # Manual: the script owns obs[0:3]
+        action = ctrl.predict(o)
+        action = (1 - a_act) * act_his + a_act * action
+        act_his = action
+        action_total[0, :] = action
+        ob_double = o * obs_std + obs_mean
+        state = env.OriginState()[0, :]
+        rec["joint"].append(ob_double[5:17]); rec["joint_dot"].append(ob_double[17:29]); rec["posture"].append(ob_double[29:32])
+        rec["omega"].append(ob_double[32:35]); rec["phase"].append(ob_double[3:5]); rec["act"].append(action * action_std + action_mean)
+        rec["oss"].append(state[0:37]); rec["contact"].append(state[37:41]); rec["joint_effort"].append(env.GetJointEffort()[0, :])
+        rec["cmd"].append(cmd.copy())
+        obs, reward, done, _ = env.step(action_total, visualize=False)
+        rec["reward"].append(float(reward[0]))
+        if done[0]:
+            n_done += 1
+            ctrl.reset()
+    out = {k: np.asarray(v) for k, v in rec.items()}
+    vx = out["oss"][:, 19]
+    print("test: %d steps (%.2f s), command %.2f m/s, mean forward velocity %.3f m/s (last half %.3f), falls %d, mean reward %.4f"
+          % (args.steps, args.steps * dt, args.flag_fix_cmd, float(vx.mean()), float(vx[len(vx) // 2:].mean()), n_done,
+             float(np.mean(out["reward"]))))
+    if args.out:
+        np.savez_compressed(args.out, **out)
+        print("records written to", args.out)
+    return out
 
 
 def main(argv=None):
@@ -58,6 +131,8 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
+    if not args.train and not args.flag_output:
+        return run_test(args, cfg)
     if args.num_envs:
         cfg["environment"]["num_envs"] = args.num_envs
     cfg["environment"]["seedd"] = int(cfg["environment"]["seedd"]) + 7919 * rank   # each rank owns different robots
@@ -71,8 +146,6 @@ def main(argv=None):
         print("exported to", export_actor_csv(model, os.path.join(os.getcwd(), "model", name)))
         return
 
-    if not args.train:
-        raise SystemExit("--test (gamepad evaluation + plotting) is outside this engine's scope; see the module docstring")
 
     saver = None
     if args.save_flag and rank == 0:

@@ -245,3 +245,26 @@ def test_fused_mlp_policy_step_matches_eager_step(N, deterministic):
     assert torch.equal(clipped, act.clamp(-1.0, 1.0))
     assert torch.equal(mb["mb_obs"][2], obs) and torch.equal(mb["mb_actions"][2], act) and torch.equal(mb["mb_values"][2], val)
     assert torch.equal(mb["mb_dones"][2], dones) and torch.equal(mb["mb_rewards"][1], mb["prev_reward"]) and not mb["mb_rewards"][2].any()
+
+
+def test_run_bp_v5_test_branch_headless(tmp_path):
+    """`run_bp_v5.py --test` (headless): Manual-mode env, command injected into obs[0:3], delay line + filters, numpy LSTM actor
+    from a saved checkpoint, records written to an .npz (run_bp_v5.py:300-470 without gamepad / plots)."""
+    import importlib.util, os, sys
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import CustomLSTMPolicy
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.ppo2 import PPO2
+    env = _env(16)
+    model = PPO2(policy=CustomLSTMPolicy, env=env, n_steps=8, nminibatches=1, noptepochs=1, seed=3)
+    ckpt = model.save(str(tmp_path / "rand_policy"))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("run_bp_v5_script", os.path.join(root, "scripts", "run_bp_v5.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = str(tmp_path / "rec.npz")
+    mod.main(["--test", "--model", ckpt, "--cmd", "0.8", "--steps", "120", "--delay", "2", "--vel_filter_freq", "50", "--act_filter_freq", "30", "--out", out])
+    rec = np.load(out)
+    assert rec["oss"].shape == (120, 37) and rec["joint"].shape == (120, 12) and rec["contact"].shape == (120, 4)
+    assert np.isfinite(rec["oss"]).all() and np.isfinite(rec["act"]).all()
+    assert np.allclose(rec["cmd"][:, 0], 0.8)
+    # Manual start pose: origin, nominal height, then the robot moves
+    assert abs(rec["oss"][0, 0]) < 1e-6 and abs(rec["oss"][0, 2] - 0.35) < 0.02
