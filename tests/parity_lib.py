@@ -196,3 +196,29 @@ def ref_table(rows=900, seed=5):
     tab[:, 28] = 0.1 * np.cos(0.9 * t)
     tab[:, 29] = 0.2 * np.sin(1.3 * t)
     return tab
+
+
+def closed_loop_reference_policy(env, cfg, cmd_vx, steps):
+    """Drive `env` (1 Manual-mode env with reset/step of the test adapters) with the reference's RaiSim-trained bp5_155 actor
+    (tests/golden/actor_bp5_155.npz, decoded from IRRL/script/pkl/bp5_155.pkl by tools/gen_golden.py) exactly like the
+    evaluation script does (run_bp_v5.py:397-409: the command is written into obs[0:3]).  -> (vx per step, falls)."""
+    import os
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.checkpoint import NumpyLstmActor
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.helper import obs_normalisation
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "actor_bp5_155.npz"))
+    ctrl = NumpyLstmActor([z["wx0"].astype(np.float64), z["wx1"].astype(np.float64)], [z["wh0"].astype(np.float64), z["wh1"].astype(np.float64)],
+                          [z["b0"].astype(np.float64), z["b1"].astype(np.float64)], z["pi_w"].astype(np.float64), z["pi_b"].astype(np.float64))
+    mean, std, _, _ = obs_normalisation(cfg)
+    cmd = np.array([cmd_vx, 0.0, 0.0])
+    ob = env.reset()
+    vx, falls = [], 0
+    for _ in range(steps):
+        o = np.array(ob[0], np.float64)
+        o[0:3] = (cmd - mean[0:3]) / std[0:3]
+        a = ctrl.predict(o)
+        ob, _, d, _ = env.step(a[None, :].astype(np.float32))
+        vx.append(env.get_state()[0, S["GV"]])
+        if d[0]:
+            falls += 1
+            ctrl.reset()
+    return np.array(vx), falls

@@ -294,9 +294,25 @@ def gen_ppo_math():
     print("wrote ppo_math.json")
 
 
+def gen_actor_weights():
+    """The eight actor tensors of the trained bp5_155 checkpoint (a data file of the reference: 35 340 f32 numbers) as a
+    fixture for the closed-loop sim-to-sim tests: the RaiSim-trained controller must trot in this build's physics."""
+    _, params = load_bp5_pickle()
+    params = [np.asarray(p, np.float32) for p in params]
+    # SB order (run_bp_v5.py:143-176): pi-lstm0 (wx, wh, b), pi-lstm1, vf-lstm0, vf-lstm1, vf (w, b), pi (w, b), logstd, q (w, b)
+    names = ["wx0", "wh0", "b0", "wx1", "wh1", "b1"]
+    out = {n: params[i] for i, n in enumerate(names)}
+    out["pi_w"], out["pi_b"] = params[14], params[15]
+    assert out["wx0"].shape == (35, 192) and out["wh1"].shape == (48, 192) and out["pi_w"].shape == (48, 12)
+    np.savez_compressed(os.path.join(OUT, "actor_bp5_155.npz"), **out)
+    print("wrote actor_bp5_155.npz", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["task", "lstm", "lstm_syn", "ppo"]
+    which = sys.argv[1:] or ["task", "lstm", "lstm_syn", "ppo", "actor"]
+    if "actor" in which:
+        gen_actor_weights()
     if "task" in which:
         gen_task_math()
     if "lstm" in which:
