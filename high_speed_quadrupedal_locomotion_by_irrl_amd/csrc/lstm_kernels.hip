@@ -20,6 +20,7 @@
 // N must be a multiple of 16 (the Python side pads).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -327,8 +328,12 @@ lstm_seq_bwd_kernel(const float *__restrict__ gates, const float *__restrict__ c
 // per layer and pass at the training shape) disappear.  Each workgroup ends with the weight gradients of its 16 envs;
 // they are stored as partials [N/16, ...] and summed by one small deterministic reduction on the host side.
 // MX = 3 M-tiles cover an input width of up to 48.
-template <int HID, bool NEED_DX>
-__global__ void __launch_bounds__(HID / 16 * 64)
+// HELPER adds one wave that does nothing but the dwh accumulation for all 4 HID gate columns (HID/16 x 4 HID/16 tiles,
+// 144 MFMAs per step at HID = 48) from the double-buffered dz / h_prev tiles of the step the other waves just finished:
+// with HID = 48 that is a fourth wave for the CU's fourth SIMD (the kernel's register budget allows one workgroup per
+// CU), and the recurrence waves drop from 192 to 144 MFMAs per step.
+template <int HID, bool NEED_DX, bool HELPER>
+__global__ void __launch_bounds__((HID / 16 + (HELPER ? 1 : 0)) * 64)
 lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__ cseq, const float *__restrict__ hseq,
                       const float *__restrict__ x, const float *__restrict__ masks, const float *__restrict__ state0,
                       const float *__restrict__ dh_in, const float *__restrict__ wh_p, const float *__restrict__ wx_p,
@@ -341,7 +346,7 @@ lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__
   constexpr int LDH = HID + 1;
   constexpr int LDX = 16 * MX + 1;
   constexpr int LDP = HID + (NEED_DX ? 16 * MX : 0) + 1;
-  __shared__ float dzbuf[NW][16 * LDZ];
+  __shared__ float dzbuf[HELPER ? 2 : 1][NW][16 * LDZ];
   __shared__ float hpbuf[2][16 * LDH];
   __shared__ float xbuf[2][16 * LDX];
   __shared__ float part[2][NW][16 * LDP];
@@ -349,6 +354,42 @@ lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__
   const int col = l & 15, rq = l >> 4;
   const int e0 = blockIdx.x * 16;
   const int u = 16 * w + col;
+  if (HELPER && w == NW) {
+    // ---- helper wave: dwh[k][c] += sum_env hprev[env][k] dz[env][c] for every column c, one step behind the barrier ----
+    f32x4 accH[NW][4 * NW];
+#pragma unroll
+    for (int mt = 0; mt < NW; mt++)
+#pragma unroll
+      for (int ct = 0; ct < 4 * NW; ct++) accH[mt][ct] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    int pbh = 0;
+    for (int t = T - 1; t >= 0; t--) {
+      __syncthreads();   // the recurrence waves have published dz_t and h_prev_t in buffers [pbh]
+      const float *hpp = hpbuf[pbh];
+#pragma unroll
+      for (int sk = 0; sk < 4; sk++) {
+        float ah[NW];
+#pragma unroll
+        for (int mt = 0; mt < NW; mt++) ah[mt] = hpp[(4 * sk + rq) * LDH + 16 * mt + col];
+#pragma unroll
+        for (int ws = 0; ws < NW; ws++)
+#pragma unroll
+          for (int nt = 0; nt < 4; nt++) {
+            const float bz = dzbuf[HELPER ? pbh : 0][ws][(4 * sk + rq) * LDZ + 16 * nt + col];
+#pragma unroll
+            for (int mt = 0; mt < NW; mt++) accH[mt][4 * ws + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[mt], bz, accH[mt][4 * ws + nt], 0, 0, 0);
+          }
+      }
+      pbh ^= 1;
+    }
+    const size_t blk = blockIdx.x;
+#pragma unroll
+    for (int ct = 0; ct < 4 * NW; ct++)
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int mt = 0; mt < NW; mt++) dwh_part[(blk * HID + 16 * mt + 4 * rq + r) * (4 * HID) + 16 * ct + col] = accH[mt][ct][r];
+    return;
+  }
   // B fragments (K = this wave's 64 permuted gate columns): dh_prev tiles over the hidden index, dx tiles over the input
   float bT[16][NW];
 #pragma unroll
@@ -422,7 +463,7 @@ lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__
       const float d_i = dct * gg, d_g = dct * ig, d_f = dct * cprev;
       dc[j] = dct * fg * keepC[j];
       dz4[j] = (f32x4){d_i * ig * (1.0f - ig), d_f * fg * (1.0f - fg), d_o * og * (1.0f - og), d_g * (1.0f - gg * gg)};
-      *(f32x4 *)&dzbuf[w][(4 * rq + j) * LDZ + 4 * col] = dz4[j];
+      *(f32x4 *)&dzbuf[HELPER ? pb : 0][w][(4 * rq + j) * LDZ + 4 * col] = dz4[j];
 #pragma unroll
       for (int g = 0; g < 4; g++) dbacc[g] += dz4[j][g];
     }
@@ -437,7 +478,7 @@ lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__
     }
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) {
-      const float a = dzbuf[w][col * LDZ + 4 * kk + rq];  // A[i = env col][k = 4kk + rq]
+      const float a = dzbuf[HELPER ? pb : 0][w][col * LDZ + 4 * kk + rq];  // A[i = env col][k = 4kk + rq]
 #pragma unroll
       for (int nt = 0; nt < NW; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bT[kk][nt], acc[nt], 0, 0, 0);
       if (NEED_DX) {
@@ -483,15 +524,17 @@ lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__
     for (int sk = 0; sk < 4; sk++) {
       float bz[4], ah[NW], ax[MX];
 #pragma unroll
-      for (int nt = 0; nt < 4; nt++) bz[nt] = dzbuf[w][(4 * sk + rq) * LDZ + 16 * nt + col];
+      for (int nt = 0; nt < 4; nt++) bz[nt] = dzbuf[HELPER ? pb : 0][w][(4 * sk + rq) * LDZ + 16 * nt + col];
+      if (!HELPER) {
 #pragma unroll
-      for (int mt = 0; mt < NW; mt++) ah[mt] = hp[(4 * sk + rq) * LDH + 16 * mt + col];
+        for (int mt = 0; mt < NW; mt++) ah[mt] = hp[(4 * sk + rq) * LDH + 16 * mt + col];
+      }
 #pragma unroll
       for (int mx = 0; mx < MX; mx++) ax[mx] = xb[(4 * sk + rq) * LDX + 16 * mx + col];
 #pragma unroll
       for (int nt = 0; nt < 4; nt++) {
 #pragma unroll
-        for (int mt = 0; mt < NW; mt++) accWh[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[mt], bz[nt], accWh[mt][nt], 0, 0, 0);
+        for (int mt = 0; mt < (HELPER ? 0 : NW); mt++) accWh[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[mt], bz[nt], accWh[mt][nt], 0, 0, 0);
 #pragma unroll
         for (int mx = 0; mx < MX; mx++) accWx[mx][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[mx], bz[nt], accWx[mx][nt], 0, 0, 0);
       }
@@ -506,7 +549,7 @@ lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__
 #pragma unroll
     for (int r = 0; r < 4; r++) {
 #pragma unroll
-      for (int mt = 0; mt < NW; mt++) dwh_part[(blk * HID + 16 * mt + 4 * rq + r) * (4 * HID) + c] = accWh[mt][nt][r];
+      for (int mt = 0; mt < (HELPER ? 0 : NW); mt++) dwh_part[(blk * HID + 16 * mt + 4 * rq + r) * (4 * HID) + c] = accWh[mt][nt][r];
 #pragma unroll
       for (int mx = 0; mx < MX; mx++) {
         const int i = 16 * mx + 4 * rq + r;
@@ -918,7 +961,13 @@ int irrl_lstm_seq_backward_x(int hid, int T, int N, int n_in, const float *gates
                              float *dx, float *dwx_part, float *dwh_part, float *db_part, void *hip_stream) {
   if (N <= 0 || T <= 0 || (N % 16) != 0 || n_in <= 0 || n_in > 48) return 1;
   hipStream_t s = (hipStream_t)hip_stream;
-#define IRRL_BX(H, D) hipLaunchKernelGGL((lstm_seq_bwd_x_kernel<H, D>), dim3(N / 16), dim3(H / 16 * 64), 0, s, gates, cseq, hseq, x, masks, state0, dh_in, wh_p, wx_p, dx, dwx_part, dwh_part, db_part, T, N, n_in)
+  // HID = 32 / 48: one extra wave for the dwh accumulation (IRRL_LSTM_BWD_HELPER=0 selects the plain kernel for A/B runs)
+  static const bool helper = [] { const char *e = getenv("IRRL_LSTM_BWD_HELPER"); return !(e && e[0] == '0'); }();
+#define IRRL_BX(H, D) \
+  do { \
+    if (helper && H <= 48) hipLaunchKernelGGL((lstm_seq_bwd_x_kernel<H, D, true>), dim3(N / 16), dim3((H / 16 + 1) * 64), 0, s, gates, cseq, hseq, x, masks, state0, dh_in, wh_p, wx_p, dx, dwx_part, dwh_part, db_part, T, N, n_in); \
+    else hipLaunchKernelGGL((lstm_seq_bwd_x_kernel<H, D, false>), dim3(N / 16), dim3(H / 16 * 64), 0, s, gates, cseq, hseq, x, masks, state0, dh_in, wh_p, wx_p, dx, dwx_part, dwh_part, db_part, T, N, n_in); \
+  } while (0)
   if (hid == 48 && dx) IRRL_BX(48, true);
   else if (hid == 48) IRRL_BX(48, false);
   else if (hid == 32 && dx) IRRL_BX(32, true);
