@@ -340,6 +340,10 @@ lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__
                       float *__restrict__ dx, float *__restrict__ dwx_part, float *__restrict__ dwh_part,
                       float *__restrict__ db_part, int T, int N, int n_in) {
   constexpr int NW = HID / 16;
+  // dwh M-tiles (16 hidden rows each) kept by the recurrence waves: all of them without the helper, none with it (giving them
+  // one tile back when they do not carry the dx product -- 112 : 96 MFMAs instead of 96 : 144 -- measured slower: the
+  // recurrence waves are the critical path)
+  constexpr int HM = HELPER ? 0 : NW;
   constexpr int MX = 3;                       // input M-tiles (n_in <= 48)
   constexpr int XPW = (MX + NW - 1) / NW;     // input tiles staged / reduced per wave
   constexpr int LDZ = 64 + 4;
@@ -358,7 +362,7 @@ lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__
     // ---- helper wave: dwh[k][c] += sum_env hprev[env][k] dz[env][c] for every column c, one step behind the barrier ----
     f32x4 accH[NW][4 * NW];
 #pragma unroll
-    for (int mt = 0; mt < NW; mt++)
+    for (int mt = HM; mt < NW; mt++)
 #pragma unroll
       for (int ct = 0; ct < 4 * NW; ct++) accH[mt][ct] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     int pbh = 0;
@@ -369,14 +373,14 @@ lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__
       for (int sk = 0; sk < 4; sk++) {
         float ah[NW];
 #pragma unroll
-        for (int mt = 0; mt < NW; mt++) ah[mt] = hpp[(4 * sk + rq) * LDH + 16 * mt + col];
+        for (int mt = HM; mt < NW; mt++) ah[mt] = hpp[(4 * sk + rq) * LDH + 16 * mt + col];
 #pragma unroll
         for (int ws = 0; ws < NW; ws++)
 #pragma unroll
           for (int nt = 0; nt < 4; nt++) {
             const float bz = dzbuf[HELPER ? pbh : 0][ws][(4 * sk + rq) * LDZ + 16 * nt + col];
 #pragma unroll
-            for (int mt = 0; mt < NW; mt++) accH[mt][4 * ws + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[mt], bz, accH[mt][4 * ws + nt], 0, 0, 0);
+            for (int mt = HM; mt < NW; mt++) accH[mt][4 * ws + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[mt], bz, accH[mt][4 * ws + nt], 0, 0, 0);
           }
       }
       pbh ^= 1;
@@ -387,7 +391,7 @@ lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__
 #pragma unroll
       for (int r = 0; r < 4; r++)
 #pragma unroll
-        for (int mt = 0; mt < NW; mt++) dwh_part[(blk * HID + 16 * mt + 4 * rq + r) * (4 * HID) + 16 * ct + col] = accH[mt][ct][r];
+        for (int mt = HM; mt < NW; mt++) dwh_part[(blk * HID + 16 * mt + 4 * rq + r) * (4 * HID) + 16 * ct + col] = accH[mt][ct][r];
     return;
   }
   // B fragments (K = this wave's 64 permuted gate columns): dh_prev tiles over the hidden index, dx tiles over the input
@@ -525,16 +529,14 @@ lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__
       float bz[4], ah[NW], ax[MX];
 #pragma unroll
       for (int nt = 0; nt < 4; nt++) bz[nt] = dzbuf[HELPER ? pb : 0][w][(4 * sk + rq) * LDZ + 16 * nt + col];
-      if (!HELPER) {
 #pragma unroll
-        for (int mt = 0; mt < NW; mt++) ah[mt] = hp[(4 * sk + rq) * LDH + 16 * mt + col];
-      }
+      for (int mt = 0; mt < HM; mt++) ah[mt] = hp[(4 * sk + rq) * LDH + 16 * mt + col];
 #pragma unroll
       for (int mx = 0; mx < MX; mx++) ax[mx] = xb[(4 * sk + rq) * LDX + 16 * mx + col];
 #pragma unroll
       for (int nt = 0; nt < 4; nt++) {
 #pragma unroll
-        for (int mt = 0; mt < (HELPER ? 0 : NW); mt++) accWh[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[mt], bz[nt], accWh[mt][nt], 0, 0, 0);
+        for (int mt = 0; mt < HM; mt++) accWh[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[mt], bz[nt], accWh[mt][nt], 0, 0, 0);
 #pragma unroll
         for (int mx = 0; mx < MX; mx++) accWx[mx][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[mx], bz[nt], accWx[mx][nt], 0, 0, 0);
       }
@@ -549,7 +551,7 @@ lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__
 #pragma unroll
     for (int r = 0; r < 4; r++) {
 #pragma unroll
-      for (int mt = 0; mt < (HELPER ? 0 : NW); mt++) dwh_part[(blk * HID + 16 * mt + 4 * rq + r) * (4 * HID) + c] = accWh[mt][nt][r];
+      for (int mt = 0; mt < HM; mt++) dwh_part[(blk * HID + 16 * mt + 4 * rq + r) * (4 * HID) + c] = accWh[mt][nt][r];
 #pragma unroll
       for (int mx = 0; mx < MX; mx++) {
         const int i = 16 * mx + 4 * rq + r;
