@@ -120,29 +120,78 @@ lstm_seq_fwd_kernel(const float *__restrict__ zx, const float *__restrict__ wh_p
 // as lstm_seq_fwd_kernel, plus the wave's slice of wx as a second set of resident B fragments; x_t is read straight
 // from the layer input [T, N, n_in] (prefetched one step ahead), so the [T, N, 4H] zx tensor -- 2.4 GB written by a
 // GEMM and read back here at the training shape -- never exists.  KXS = ceil(n_in / 4) k-steps.
-template <int HID, int KXS>
-__global__ void __launch_bounds__(HID / 16 * 64)
+// HELPER adds one wave that computes the input projection b + x_{t+1} wx for ALL gate columns one step ahead (it does not
+// depend on h) and hands it over through a double-buffered LDS tile; the recurrence waves then start from that tile and issue
+// only the HID/4 x 4 recurrent MFMAs before their gate arithmetic.
+template <int HID, int KXS, bool HELPER>
+__global__ void __launch_bounds__((HID / 16 + (HELPER ? 1 : 0)) * 64)
 lstm_seq_fwd_x_kernel(const float *__restrict__ x, const float *__restrict__ wx_p, const float *__restrict__ b_p,
                       const float *__restrict__ wh_p, const float *__restrict__ masks, const float *__restrict__ state0,
                       float *__restrict__ gates, float *__restrict__ cseq, float *__restrict__ hseq,
                       float *__restrict__ state_out, int T, int N, int n_in) {
   constexpr int KS = HID / 4;
   constexpr int LD = HID + 1;
+  constexpr int NW = HID / 16;
+  constexpr int LDZX = 4 * HID + 4;
   __shared__ float hbuf[2][16 * LD];
+  __shared__ float zxbuf[HELPER ? 2 : 1][HELPER ? 16 * LDZX : 1];
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
   const int col = l & 15, rq = l >> 4;
   const int e0 = blockIdx.x * 16;
   const int u = 16 * w + col;
-  float bw[KS][4], bx[KXS][4];
+  if (HELPER && w == NW) {
+    // ---- helper wave: zx_t[env][c] = b[c] + sum_k x_t[env][k] wx[k][c] for every permuted gate column c, one step ahead ----
+    float bxh[KXS][4 * NW], bias_h[4 * NW];
+#pragma unroll
+    for (int ct = 0; ct < 4 * NW; ct++) {
+      bias_h[ct] = b_p[16 * ct + col];
+#pragma unroll
+      for (int kk = 0; kk < KXS; kk++) {
+        const int k = 4 * kk + rq;
+        bxh[kk][ct] = (k < n_in) ? wx_p[(size_t)k * HID * 4 + 16 * ct + col] : 0.0f;
+      }
+    }
+    float xh[KXS], xhn[KXS];
+    auto fetch_h = [&](int t, float (&dst)[KXS]) {
+      const float *row = x + ((size_t)t * N + e0 + col) * n_in;
+#pragma unroll
+      for (int kk = 0; kk < KXS; kk++) {
+        const int k = 4 * kk + rq;
+        dst[kk] = row[k < n_in ? k : n_in - 1];
+      }
+    };
+    fetch_h(0, xh);
+    for (int t = 0; t <= T; t++) {          // iteration t produces zx_t; the barrier at its end pairs with the recurrence waves'
+      if (t < T) {
+        if (t + 1 < T) fetch_h(t + 1, xhn);
+        float *zb = zxbuf[t & 1];
+#pragma unroll
+        for (int ct = 0; ct < 4 * NW; ct++) {
+          f32x4 acc = (f32x4){bias_h[ct], bias_h[ct], bias_h[ct], bias_h[ct]};
+#pragma unroll
+          for (int kk = 0; kk < KXS; kk++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xh[kk], bxh[kk][ct], acc, 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 4; j++) zb[(4 * rq + j) * LDZX + 16 * ct + col] = acc[j];
+        }
+#pragma unroll
+        for (int kk = 0; kk < KXS; kk++) xh[kk] = xhn[kk];
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  float bw[KS][4], bx[HELPER ? 1 : KXS][4];
 #pragma unroll
   for (int kk = 0; kk < KS; kk++)
 #pragma unroll
     for (int g = 0; g < 4; g++) bw[kk][g] = wh_p[((size_t)(4 * kk + rq) * HID + u) * 4 + g];
+  if (!HELPER) {
 #pragma unroll
-  for (int kk = 0; kk < KXS; kk++) {
-    const int k = 4 * kk + rq;
+    for (int kk = 0; kk < KXS; kk++) {
+      const int k = 4 * kk + rq;
 #pragma unroll
-    for (int g = 0; g < 4; g++) bx[kk][g] = (k < n_in) ? wx_p[((size_t)k * HID + u) * 4 + g] : 0.0f;
+      for (int g = 0; g < 4; g++) bx[kk][g] = (k < n_in) ? wx_p[((size_t)k * HID + u) * 4 + g] : 0.0f;
+    }
   }
   const f32x4 bias = *(const f32x4 *)&b_p[u * 4];
   float c[4], hlast[4];
@@ -154,7 +203,7 @@ lstm_seq_fwd_x_kernel(const float *__restrict__ x, const float *__restrict__ wx_
     hbuf[0][(4 * rq + j) * LD + u] = hlast[j];
   }
   // A fragments of x_t: A[i = env col][k = 4kk + rq]; columns >= n_in are clamped (their B rows are zero)
-  float xa[KXS], xn[KXS];
+  float xa[KXS], xn[KXS];   // (unused with the helper wave)
   auto fetch_x = [&](int t, float (&dst)[KXS]) {
     const float *row = x + ((size_t)t * N + e0 + col) * n_in;
 #pragma unroll
@@ -163,7 +212,7 @@ lstm_seq_fwd_x_kernel(const float *__restrict__ x, const float *__restrict__ wx_
       dst[kk] = row[k < n_in ? k : n_in - 1];
     }
   };
-  fetch_x(0, xa);
+  if (!HELPER) fetch_x(0, xa);
   float mA_cur = masks[e0 + col], mC_cur[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) mC_cur[j] = masks[e0 + 4 * rq + j];
@@ -171,7 +220,7 @@ lstm_seq_fwd_x_kernel(const float *__restrict__ x, const float *__restrict__ wx_
   int cur = 0;
   for (int t = 0; t < T; t++) {
     const int tn = (t + 1 < T) ? t + 1 : t;
-    fetch_x(tn, xn);
+    if (!HELPER) fetch_x(tn, xn);
     const float keepA = 1.0f - mA_cur;
     float keepC[4];
 #pragma unroll
@@ -181,13 +230,23 @@ lstm_seq_fwd_x_kernel(const float *__restrict__ x, const float *__restrict__ wx_
 #pragma unroll
     for (int j = 0; j < 4; j++) mC_next[j] = masks[(size_t)tn * N + e0 + 4 * rq + j];
     f32x4 acc[4];
+    if (HELPER) {
+      // b + x_t wx from the helper wave's tile (published before the barrier that ended the previous step)
+      const float *zb = zxbuf[t & 1];
+      f32x4 zr[4];
 #pragma unroll
-    for (int g = 0; g < 4; g++) acc[g] = (f32x4){bias[g], bias[g], bias[g], bias[g]};
-    // the input half first: it does not depend on the previous step's h (issued while the other waves still publish it)
+      for (int j = 0; j < 4; j++) zr[j] = *(const f32x4 *)&zb[(4 * rq + j) * LDZX + 4 * u];
 #pragma unroll
-    for (int kk = 0; kk < KXS; kk++)
+      for (int g = 0; g < 4; g++) acc[g] = (f32x4){zr[0][g], zr[1][g], zr[2][g], zr[3][g]};
+    } else {
 #pragma unroll
-      for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kk], bx[kk][g], acc[g], 0, 0, 0);
+      for (int g = 0; g < 4; g++) acc[g] = (f32x4){bias[g], bias[g], bias[g], bias[g]};
+      // the input half first: it does not depend on the previous step's h (issued while the other waves still publish it)
+#pragma unroll
+      for (int kk = 0; kk < KXS; kk++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kk], bx[kk][g], acc[g], 0, 0, 0);
+    }
     const float *hb = hbuf[cur];
 #pragma unroll
     for (int kk = 0; kk < KS; kk++) {
@@ -893,7 +952,13 @@ int irrl_lstm_seq_forward_x(int hid, int T, int N, int n_in, const float *x, con
   if (N <= 0 || T <= 0 || (N % 16) != 0 || n_in <= 0 || n_in > 48) return 1;
   hipStream_t s = (hipStream_t)hip_stream;
   const int kxs = (n_in + 3) / 4;
-#define IRRL_FX(H, K) hipLaunchKernelGGL((lstm_seq_fwd_x_kernel<H, K>), dim3(N / 16), dim3(H / 16 * 64), 0, s, x, wx_p, b_p, wh_p, masks, state0, gates, cseq, hseq, state_out, T, N, n_in)
+  // HID = 32 / 48: one extra wave computes the input projection one step ahead (IRRL_LSTM_FWD_HELPER=0: plain kernel, for A/B runs)
+  static const bool fhelper = [] { const char *e = getenv("IRRL_LSTM_FWD_HELPER"); return !(e && e[0] == '0'); }();
+#define IRRL_FX(H, K) \
+  do { \
+    if (fhelper && H <= 48) hipLaunchKernelGGL((lstm_seq_fwd_x_kernel<H, K, true>), dim3(N / 16), dim3((H / 16 + 1) * 64), 0, s, x, wx_p, b_p, wh_p, masks, state0, gates, cseq, hseq, state_out, T, N, n_in); \
+    else hipLaunchKernelGGL((lstm_seq_fwd_x_kernel<H, K, false>), dim3(N / 16), dim3(H / 16 * 64), 0, s, x, wx_p, b_p, wh_p, masks, state0, gates, cseq, hseq, state_out, T, N, n_in); \
+  } while (0)
   if (hid == 48 && kxs <= 9) IRRL_FX(48, 9);
   else if (hid == 48) IRRL_FX(48, 12);
   else if (hid == 32 && kxs <= 9) IRRL_FX(32, 9);
