@@ -122,8 +122,7 @@ irrl_env *irrl_env_create(const char *resource_dir, const char *cfg_yaml, int de
   const size_t n = (size_t)h->P.n_envs;
   bool ok = hipSetDevice(device) == hipSuccess && hipMalloc(&h->d_pool, h->pool.bytes) == hipSuccess &&
             hipMemset(h->d_pool, 0, h->pool.bytes) == hipSuccess && hipMalloc((void **)&h->d_action, n * 12 * 4) == hipSuccess &&
-            hipMalloc((void **)&h->d_ob, n * 35 * 4) == hipSuccess && hipMalloc((void **)&h->d_reward, n * 4) == hipSuccess &&
-            hipMalloc((void **)&h->d_extra, n * 6 * 4) == hipSuccess && hipMalloc((void **)&h->d_done, n) == hipSuccess &&
+            hipMalloc((void **)&h->d_ob, n * (35 * 4 + 4 + 6 * 4 + 1)) == hipSuccess &&   // ob | reward | extra | done: ONE D2H copy per host step
             hipMalloc((void **)&h->d_scratch, n * 342 * 4) == hipSuccess;
   h->pinned_bytes = n * 342 * 4 + h->pool.bytes + 4096;
   ok = ok && hipHostMalloc((void **)&h->h_pinned, h->pinned_bytes, hipHostMallocDefault) == hipSuccess;
@@ -132,6 +131,11 @@ irrl_env *irrl_env_create(const char *resource_dir, const char *cfg_yaml, int de
     const size_t hb = h->h_height.size() * sizeof(float);
     ok = hipMalloc((void **)&h->d_height, hb) == hipSuccess && hipMemcpy(h->d_height, h->h_height.data(), hb, hipMemcpyHostToDevice) == hipSuccess;
     h->P.height = h->d_height;
+  }
+  if (ok) {
+    h->d_reward = h->d_ob + n * 35;
+    h->d_extra = h->d_reward + n;
+    h->d_done = (uint8_t *)(h->d_extra + n * 6);
   }
   if (!ok) { g_err = "device / pinned allocation failed"; irrl_env_destroy(h); return nullptr; }
   h->S = h->pool.view(h->d_pool);
@@ -170,10 +174,7 @@ void irrl_env_destroy(irrl_env *h) {
   (void)hipSetDevice(h->device);
   if (h->d_pool) (void)hipFree(h->d_pool);
   if (h->d_action) (void)hipFree(h->d_action);
-  if (h->d_ob) (void)hipFree(h->d_ob);
-  if (h->d_reward) (void)hipFree(h->d_reward);
-  if (h->d_extra) (void)hipFree(h->d_extra);
-  if (h->d_done) (void)hipFree(h->d_done);
+  if (h->d_ob) (void)hipFree(h->d_ob);   // reward / extra / done live in the same allocation
   if (h->d_scratch) (void)hipFree(h->d_scratch);
   if (h->d_height) (void)hipFree(h->d_height);
   if (h->d_ref) (void)hipFree(h->d_ref);
@@ -237,10 +238,15 @@ static int step_host_impl(irrl_env *h, int n_step, const float *action, float *o
   P.n_envs = n_step;
   IRRL_LAUNCH(h, irrl_step_kernel, lane_grid(h, n_step), P, h->S, (const float *)h->d_action, h->d_ob, h->d_reward, h->d_done, h->d_extra);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(po, h->d_ob, n * 35 * 4, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipMemcpyAsync(pr, h->d_reward, n * 4, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipMemcpyAsync(px, h->d_extra, n * 6 * 4, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipMemcpyAsync(pd, h->d_done, n, hipMemcpyDeviceToHost, h->stream));
+  if (n_step == h->P.n_envs) {
+    // device outputs and their pinned staging are laid out alike (ob | reward | extra | done): one copy
+    HIP_TRY(hipMemcpyAsync(po, h->d_ob, n * (35 * 4 + 4 + 6 * 4 + 1), hipMemcpyDeviceToHost, h->stream));
+  } else {
+    HIP_TRY(hipMemcpyAsync(po, h->d_ob, n * 35 * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(pr, h->d_reward, n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(px, h->d_extra, n * 6 * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(pd, h->d_done, n, hipMemcpyDeviceToHost, h->stream));
+  }
   HIP_TRY(hipStreamSynchronize(h->stream));
   std::memcpy(ob, po, n * 35 * 4);
   std::memcpy(reward, pr, n * 4);
