@@ -468,4 +468,17 @@ int irrl_gae(int T, int N, const float *rewards, const float *values, const uint
   return 0;
 }
 
+// ---- PPO2 clipped-surrogate loss (kernel template: csrc/lstm_kernels.hip, irrl_ppo_loss_kernel) ----
+int irrl_ppo_loss(size_t M, int act_dim, const float *mean, const float *logstd, const float *vpred, const float *actions,
+                  const float *returns, const float *old_values, const float *old_neglogp, const float *adv_stats, float cliprange,
+                  float vf_coef, float *d_mean, float *d_vpred, float *partials, int n_blocks, void *hip_stream) {
+  if (M == 0 || n_blocks <= 0) { g_err = "irrl_ppo_loss: empty batch"; return 1; }
+  const float inv_m = 1.0f / (float)M;
+  hipStream_t s = (hipStream_t)hip_stream;
+  if (act_dim == 12) hipLaunchKernelGGL(irrl_ppo_loss_kernel<12>, dim3((unsigned)n_blocks), dim3(256), 0, s, M, mean, logstd, vpred, actions, returns, old_values, old_neglogp, adv_stats, cliprange, vf_coef, inv_m, d_mean, d_vpred, partials);
+  else { g_err = "irrl_ppo_loss: act_dim must be 12"; return 1; }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 }  // extern "C"

@@ -931,6 +931,74 @@ mlp_policy_step_kernel(PolicyStepArgs a) {
   policy_heads<H>(a, h2[0], h2[1], LD, head_w, terms, e0, tid, t, gstep);
 }
 
+// ---- PPO2 clipped-surrogate loss, forward AND backward in one pass (ppo2.py:152-175 + DiagGaussian neglogp / entropy) ----
+// One lane per sample.  Because every term of the loss is a mean over samples, the gradient of a sample's row does not
+// depend on the other rows: the kernel writes d loss / d mean [M, A] and d loss / d vpred [M] directly and leaves per-workgroup
+// partial sums of the scalars (policy loss, value loss, approx KL, clip fraction) and of d loss / d logstd [A]
+// in `partials` [blocks, 4 + A]; the caller adds them up (deterministic order).  adv_stats = (mean, std) of the raw
+// advantages (device scalars: with several ranks they are all-reduced first); the kernel normalises on the fly.
+template <int A>
+__global__ void __launch_bounds__(256)
+irrl_ppo_loss_kernel(size_t M, const float *__restrict__ mean, const float *__restrict__ logstd, const float *__restrict__ vpred,
+                     const float *__restrict__ actions, const float *__restrict__ returns, const float *__restrict__ old_values,
+                     const float *__restrict__ old_neglogp, const float *__restrict__ adv_stats, float cliprange, float vf_coef,
+                     float inv_m, float *__restrict__ d_mean, float *__restrict__ d_vpred, float *__restrict__ partials) {
+  __shared__ float red[4][4 + A];
+  float sd_inv[A], ls_sum = 0.0f;
+#pragma unroll
+  for (int a = 0; a < A; a++) { const float ls = logstd[a]; sd_inv[a] = __expf(-ls); ls_sum += ls; }
+  const float a_mean = adv_stats[0], a_istd = 1.0f / (adv_stats[1] + 1e-8f);
+  float acc[4 + A];
+#pragma unroll
+  for (int i = 0; i < 4 + A; i++) acc[i] = 0.0f;
+  for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < M; r += (size_t)gridDim.x * blockDim.x) {
+    float diff[A], q = 0.0f;
+#pragma unroll
+    for (int a = 0; a < A; a++) { diff[a] = (actions[r * A + a] - mean[r * A + a]) * sd_inv[a]; q += diff[a] * diff[a]; }
+    const float nlp = 0.5f * q + 0.918938533204672742f * (float)A + ls_sum;
+    const float onlp = old_neglogp[r];
+    const float adv = (returns[r] - old_values[r] - a_mean) * a_istd;
+    const float ratio = __expf(onlp - nlp);
+    const float rc = fminf(fmaxf(ratio, 1.0f - cliprange), 1.0f + cliprange);
+    const float pg1 = -adv * ratio, pg2 = -adv * rc;
+    const bool inside = (ratio >= 1.0f - cliprange) && (ratio <= 1.0f + cliprange);
+    // torch.maximum: a tie splits the gradient evenly; inside the clip range both branches carry d/d ratio = -adv
+    const float dpg_dratio = inside ? -adv : ((pg1 > pg2) ? -adv : ((pg1 == pg2) ? -0.5f * adv : 0.0f));
+    const float dl_dnlp = inv_m * dpg_dratio * (-ratio);
+    const float v = vpred[r], ov = old_values[r], R = returns[r];
+    const float dv = v - ov;
+    const float vc = ov + fminf(fmaxf(dv, -cliprange), cliprange);
+    const float l1 = (v - R) * (v - R), l2 = (vc - R) * (vc - R);
+    const float g_clamp = (dv >= -cliprange && dv <= cliprange) ? 1.0f : 0.0f;
+    const float dvf = (l1 > l2) ? (v - R) : ((l1 < l2) ? (vc - R) * g_clamp : 0.5f * (v - R) + 0.5f * (vc - R) * g_clamp);
+    d_vpred[r] = inv_m * vf_coef * dvf;
+#pragma unroll
+    for (int a = 0; a < A; a++) {
+      d_mean[r * A + a] = dl_dnlp * (-diff[a] * sd_inv[a]);
+      acc[4 + a] += dl_dnlp * (1.0f - diff[a] * diff[a]);
+    }
+    acc[0] += fmaxf(pg1, pg2);
+    acc[1] += 0.5f * fmaxf(l1, l2);
+    acc[2] += 0.5f * (nlp - onlp) * (nlp - onlp);
+    acc[3] += (fabsf(ratio - 1.0f) > cliprange) ? 1.0f : 0.0f;
+  }
+  // wave reduction, then across the four waves
+#pragma unroll
+  for (int i = 0; i < 4 + A; i++) {
+    float x = acc[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    acc[i] = x;
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < 4 + A; i++) red[w][i] = acc[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4 + A) partials[(size_t)blockIdx.x * (4 + A) + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
 extern "C" {
 
 // returns 0 on success; 1 = unsupported shape, 2 = launch error

@@ -223,6 +223,12 @@ class CustomLSTMPolicy(ActorCriticPolicy):
     def value(self, obs, states, masks):
         return self._run(obs.unsqueeze(0), states, masks.to(obs.dtype).unsqueeze(0))[1][0]
 
+    def evaluate_raw(self, obs_seq, states, masks_seq):
+        """Train-graph forward up to the distribution parameters: -> mean [T,N,act], value [T,N] (the fused loss kernel
+        computes neglogp / entropy / the clipped objectives and their gradients from these)."""
+        mean, value, _ = self._run(obs_seq, states, masks_seq.to(obs_seq.dtype))
+        return mean, value
+
     def evaluate(self, obs_seq, states, masks_seq, actions_seq):
         """Train-graph forward: obs [T,N,35], states [N,384] at the rollout start, masks [T,N], actions [T,N,12]
         -> neglogp [T,N], value [T,N], entropy [T,N] (full 750-step BPTT, ppo2.py:132-134)."""
@@ -282,6 +288,9 @@ class MlpPolicy(ActorCriticPolicy):
     @torch.no_grad()
     def value(self, obs, states=None, masks=None):
         return self._run(obs)[1]
+
+    def evaluate_raw(self, obs, states=None, masks=None):
+        return self._run(obs)
 
     def evaluate(self, obs, states, masks, actions):
         mean, value = self._run(obs)

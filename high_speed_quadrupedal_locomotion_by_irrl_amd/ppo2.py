@@ -86,6 +86,44 @@ def ppo_loss(neglogpac, vpred, entropy, actions_unused, advs, returns, old_neglo
     return loss, pg_loss, vf_loss, ent, approxkl, clipfrac
 
 
+class _FusedPPOLoss(torch.autograd.Function):
+    """ppo_loss + DiagGaussian neglogp / entropy with forward and backward in ONE kernel launch (`irrl_ppo_loss`): the eager
+    graph is ~60 elementwise / reduction kernels over [T*N] and [T*N, 12] tensors per optimizer step."""
+    N_BLOCKS = 2048
+
+    @staticmethod
+    def forward(ctx, mean, vpred, logstd, actions, returns, old_values, old_neglogp, adv_stats, cliprange, ent_coef, vf_coef):
+        from . import _lib
+        lib = _lib.load()
+        A = mean.shape[-1]
+        M = vpred.numel()
+        mean_c, v_c = mean.contiguous(), vpred.contiguous()
+        d_mean, d_v = torch.empty_like(mean_c), torch.empty_like(v_c)
+        partials = torch.empty(_FusedPPOLoss.N_BLOCKS, 4 + A, device=mean.device, dtype=torch.float32)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        _lib.check(lib.irrl_ppo_loss(M, A, p(mean_c), p(logstd.contiguous()), p(v_c), p(actions.contiguous()), p(returns.contiguous()),
+                                     p(old_values.contiguous()), p(old_neglogp.contiguous()), p(adv_stats), float(cliprange), float(vf_coef),
+                                     p(d_mean), p(d_v), p(partials), _FusedPPOLoss.N_BLOCKS,
+                                     C.c_void_p(torch.cuda.current_stream(mean.device).cuda_stream)))
+        sums = partials.sum(0)
+        pg, vf, kl, cf = sums[0] / M, sums[1] / M, sums[2] / M, sums[3] / M
+        ent = (logstd + 0.5 * (math.log(2.0 * math.pi) + 1.0)).sum()
+        loss = pg - ent * ent_coef + vf * vf_coef
+        ctx.save_for_backward(d_mean, d_v, (sums[4:] - ent_coef).reshape(logstd.shape))
+        stats = torch.stack([pg, vf, ent, kl, cf])
+        ctx.mark_non_differentiable(stats)
+        return loss, stats
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_stats):
+        d_mean, d_v, d_logstd = ctx.saved_tensors
+        return d_mean.mul_(g_loss), d_v.mul_(g_loss), d_logstd * g_loss, None, None, None, None, None, None, None, None
+
+
+def fused_ppo_loss_supported(policy, obs):
+    return bool(obs.is_cuda and hasattr(policy, "evaluate_raw") and getattr(policy, "act_dim", 0) == 12)
+
+
 class Runner(object):
     """ppo2.py:479-582 with every buffer a device tensor of shape [T, N, ...]."""
 
@@ -275,6 +313,7 @@ class PPO2(object):
         except Exception:
             self.optimizer = torch.optim.Adam(self.policy.parameters(), **adam_kw)
         self.loss_names = ['policy_loss', 'value_loss', 'policy_entropy', 'approxkl', 'clipfrac']
+        self.fused_loss = True   # single-launch loss forward + backward on the GPU (tests flip it to compare with the eager graph)
         self.log = []
 
     # -- one optimizer step on one minibatch (ppo2.py:243-298) --
@@ -286,10 +325,18 @@ class PPO2(object):
             torch.distributed.all_reduce(moments)                     # C2: 3 floats
         mean = moments[0] / moments[2]
         var = torch.clamp(moments[1] / moments[2] - mean * mean, min=0.0)
-        advs = (advs - mean.to(advs.dtype)) / (torch.sqrt(var).to(advs.dtype) + 1e-8)
-        neglogpac, vpred, entropy = self.policy.evaluate(obs, states, masks, actions)
-        loss, pg, vf, ent, kl, cf = ppo_loss(neglogpac, vpred, entropy, actions, advs, returns, neglogpacs, values, cliprange_now,
-                                             self.ent_coef, self.vf_coef)
+        stats = None
+        if self.fused_loss and fused_ppo_loss_supported(self.policy, obs):
+            # forward + backward of the whole loss in one launch; advantages are normalised inside the kernel
+            adv_stats = torch.stack([mean, torch.sqrt(var)]).to(torch.float32)
+            pmean, vpred = self.policy.evaluate_raw(obs, states, masks)
+            loss, stats = _FusedPPOLoss.apply(pmean, vpred, self.policy.logstd, actions, returns, values, neglogpacs, adv_stats,
+                                              cliprange_now, self.ent_coef, self.vf_coef)
+        else:
+            advs = (advs - mean.to(advs.dtype)) / (torch.sqrt(var).to(advs.dtype) + 1e-8)
+            neglogpac, vpred, entropy = self.policy.evaluate(obs, states, masks, actions)
+            loss, pg, vf, ent, kl, cf = ppo_loss(neglogpac, vpred, entropy, actions, advs, returns, neglogpacs, values, cliprange_now,
+                                                 self.ent_coef, self.vf_coef)
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
         params = [p for p in self.policy.parameters() if p.grad is not None]
@@ -306,6 +353,8 @@ class PPO2(object):
         for g in self.optimizer.param_groups:
             g['lr'] = lr_now
         self.optimizer.step()
+        if stats is not None:
+            return stats.detach()
         return torch.stack([pg.detach(), vf.detach(), ent.detach(), kl.detach(), cf.detach()])
 
     def update(self, batch, lr_now, cliprange_now):

@@ -127,6 +127,15 @@ double irrl_env_cfg_value(const irrl_env *h, const char *key);
 int irrl_gae(int T, int N, const float *rewards, const float *values, const uint8_t *dones, const float *last_values,
              const uint8_t *last_dones, float gamma, float lam, float *adv, float *returns, void *hip_stream);
 
+/* PPO2 clipped-surrogate loss of a diagonal-Gaussian policy, forward and backward in one pass (ppo2.py:152-175): M samples,
+ * mean / actions [M, act], logstd [act], vpred / returns / old_values / old_neglogp [M], adv_stats = (mean, std) of the raw
+ * advantages returns - old_values (device; all-reduced first when there are several ranks).  Writes d loss / d mean [M, act] and
+ * d loss / d vpred [M] (loss = pg - ent_coef * entropy + vf_coef * vf; the constant entropy term is the caller's) and per-block
+ * partial sums [n_blocks, 4 + act] = pg loss, vf loss, approx KL, clip fraction, d loss / d logstd (pg part); act = 12. */
+int irrl_ppo_loss(size_t M, int act_dim, const float *mean, const float *logstd, const float *vpred, const float *actions,
+                  const float *returns, const float *old_values, const float *old_neglogp, const float *adv_stats, float cliprange,
+                  float vf_coef, float *d_mean, float *d_vpred, float *partials, int n_blocks, void *hip_stream);
+
 /* PMC calibration helper: copies n floats with one dword per lane (the env kernels' access width) so that
  * FETCH_SIZE / WRITE_SIZE can be calibrated on a known byte count (MI355X_MICROARCH.md, HBM section). */
 int irrl_calib_copy_dword(const float *src, float *dst, size_t n, void *hip_stream);

@@ -268,3 +268,32 @@ def test_run_bp_v5_test_branch_headless(tmp_path):
     assert np.allclose(rec["cmd"][:, 0], 0.8)
     # Manual start pose: origin, nominal height, then the robot moves
     assert abs(rec["oss"][0, 0]) < 1e-6 and abs(rec["oss"][0, 2] - 0.35) < 0.02
+
+
+@pytest.mark.parametrize("kind", ["lstm", "mlp"])
+def test_fused_ppo_loss_matches_eager_graph(kind):
+    """`irrl_ppo_loss` (loss forward + backward in one launch, advantages normalised in the kernel) against the eager
+    ppo_loss / DiagGaussian graph: same statistics and the same parameters after two optimizer steps."""
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import CustomLSTMPolicy, MlpPolicy
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.ppo2 import PPO2, Runner
+    res = {}
+    for fused in (True, False):
+        env = _env(64)
+        model = PPO2(policy=CustomLSTMPolicy if kind == "lstm" else MlpPolicy, env=env, n_steps=48, nminibatches=1 if kind == "lstm" else 2,
+                     noptepochs=2, gamma=0.99, lam=0.95, ent_coef=0.01, learning_rate=1e-3, cliprange=0.2, seed=11)
+        with torch.no_grad():
+            model.policy.logstd.add_(torch.linspace(-0.3, 0.2, 12, device=model.device).reshape(1, 12))
+        model.fused_loss = fused
+        runner = Runner(env, model, 48, 0.99, 0.95)
+        runner.noise_source = "torch"
+        batch = runner.run()
+        # make the clipped branches matter: perturb the stored old values / neglogps
+        g = torch.Generator(device=model.device); g.manual_seed(1)
+        batch["values"] = batch["values"] + 0.5 * torch.randn(batch["values"].shape, device=model.device, generator=g)
+        batch["neglogpacs"] = batch["neglogpacs"] + 0.3 * torch.randn(batch["neglogpacs"].shape, device=model.device, generator=g)
+        stats = model.update(batch, 1e-3, 0.2)
+        res[fused] = (stats.detach().cpu().numpy(), np.concatenate([p.reshape(-1) for p in model.get_parameter_list()]))
+    sa, sb = res[True][0], res[False][0]
+    assert np.allclose(sa, sb, rtol=2e-4, atol=2e-5), (sa, sb)
+    pa, pb = res[True][1], res[False][1]
+    assert np.abs(pa - pb).max() < 2e-5, np.abs(pa - pb).max()
