@@ -317,7 +317,8 @@ class PPO2(object):
         self.log = []
 
     # -- one optimizer step on one minibatch (ppo2.py:243-298) --
-    def _train_step(self, lr_now, cliprange_now, obs, returns, masks, actions, values, neglogpacs, states=None):
+    def _adv_moments(self, returns, values):
+        """(mean, var) of the raw advantages over ALL ranks' samples (ppo2.py:263 `advs.mean()/std()`), float64 device scalars."""
         advs = returns - values
         n_local = torch.tensor([float(advs.numel())], device=advs.device, dtype=torch.float64)
         moments = torch.stack([advs.double().sum(), (advs.double() ** 2).sum(), n_local[0]])
@@ -325,6 +326,11 @@ class PPO2(object):
             torch.distributed.all_reduce(moments)                     # C2: 3 floats
         mean = moments[0] / moments[2]
         var = torch.clamp(moments[1] / moments[2] - mean * mean, min=0.0)
+        return mean, var
+
+    def _train_step(self, lr_now, cliprange_now, obs, returns, masks, actions, values, neglogpacs, states=None, adv_moments=None):
+        mean, var = adv_moments if adv_moments is not None else self._adv_moments(returns, values)
+        advs = None if (self.fused_loss and fused_ppo_loss_supported(self.policy, obs)) else returns - values
         stats = None
         if self.fused_loss and fused_ppo_loss_supported(self.policy, obs):
             # forward + backward of the whole loss in one launch; advantages are normalised inside the kernel
@@ -366,6 +372,8 @@ class PPO2(object):
             assert N % self.nminibatches == 0, "For recurrent policies, the number of environments run in parallel " \
                                                "should be a multiple of nminibatches."
             envs_per_batch = N // self.nminibatches
+            # one minibatch = the whole rollout: the advantage moments are the same in every epoch
+            whole = self._adv_moments(batch["returns"], batch["values"]) if self.nminibatches == 1 else None
             for _ in range(self.noptepochs):
                 perm = torch.randperm(N, device=self.device, generator=self.generator)
                 for start in range(0, N, envs_per_batch):
@@ -377,7 +385,8 @@ class PPO2(object):
                         sl = lambda x: x[:, idx]
                         st = batch["states"][idx]
                     losses.append(self._train_step(lr_now, cliprange_now, sl(batch["obs"]), sl(batch["returns"]), sl(batch["masks"]),
-                                                   sl(batch["actions"]), sl(batch["values"]), sl(batch["neglogpacs"]), states=st))
+                                                   sl(batch["actions"]), sl(batch["values"]), sl(batch["neglogpacs"]), states=st,
+                                                   adv_moments=whole))
         else:
             n_batch = T * N
             assert n_batch % self.nminibatches == 0
