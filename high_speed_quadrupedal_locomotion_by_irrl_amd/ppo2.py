@@ -409,6 +409,21 @@ class PPO2(object):
         n_batch = self.n_envs * self.n_steps
         nupdates = int(total_timesteps) // (n_batch * self.world)       # total_timesteps counts all ranks' samples
         t_first = time.time()
+        csv_path = None
+        if self.tensorboard_log and self.rank == 0:
+            # the reference logs through tensorboard / the SB logger; headless here: the same table as progress.csv
+            os.makedirs(self.tensorboard_log, exist_ok=True)
+            csv_path = os.path.join(self.tensorboard_log, "progress.csv")
+        try:
+            self._learn_loop(nupdates, n_batch, runner, lr_fn, clip_fn, callback, log_interval, eval_every_n, log_dir, t_first, csv_path)
+        except KeyboardInterrupt:
+            # ppo2.py:443-448: keep what has been learned, then leave
+            if self.rank == 0 and log_dir:
+                print("[PPO2] interrupted: checkpoint", self.save(log_dir + "_interrupted"))
+            raise SystemExit(0)
+        return self
+
+    def _learn_loop(self, nupdates, n_batch, runner, lr_fn, clip_fn, callback, log_interval, eval_every_n, log_dir, t_first, csv_path):
         for update in range(1, nupdates + 1):
             if eval_every_n and update % eval_every_n == 1 and self.rank == 0 and log_dir:
                 # ppo2.py:331-341: visual test rollout (headless here: skipped) + checkpoint
@@ -435,9 +450,14 @@ class PPO2(object):
                 self.log.append(row)
                 if self.rank == 0:
                     print(" | ".join("%s %s" % (k, ("%.4g" % v) if isinstance(v, float) else v) for k, v in row.items()), flush=True)
+                    if csv_path:
+                        new_file = not os.path.exists(csv_path)
+                        with open(csv_path, "a") as f:
+                            if new_file:
+                                f.write(",".join(row.keys()) + "\n")
+                            f.write(",".join(repr(v) for v in row.values()) + "\n")
             if callback is not None and callback(locals(), globals()) is False:
                 break
-        return self
 
     # -- checkpoints (ppo2.py:452-476): (data dict, parameter list in stable-baselines order) --
     def _data(self):
