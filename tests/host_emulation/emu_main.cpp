@@ -11,6 +11,7 @@
 #include "irrl_config.hpp"
 #include "irrl_state_pool.hpp"
 #include "irrl_terrain.hpp"
+#include "irrl_csv.hpp"
 
 #include <string>
 #include <vector>
@@ -52,6 +53,14 @@ void *emu_create(const char *cfg_yaml) {
   return h;
 }
 void emu_destroy(void *hv) { delete (Emu *)hv; }
+// the product's host CSV reader (csrc/irrl_csv.hpp), reachable without a GPU: out == NULL queries the shape
+int emu_read_csv(const char *path, float *out, int *rows, int *cols) {
+  std::vector<float> data;
+  std::string e;
+  if (!irrl_host::read_csv_f32(path, data, *rows, *cols, e)) { g_err = e; return 1; }
+  if (out) std::memcpy(out, data.data(), data.size() * sizeof(float));
+  return 0;
+}
 int emu_set_ref(void *hv, const float *table, int rows, int cols) {
   Emu *h = (Emu *)hv;
   if (!h->P.ref_traj || rows < 2 || cols < 30) return 1;

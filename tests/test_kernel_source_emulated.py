@@ -170,3 +170,25 @@ def test_raisim_trained_policy_trots_at_the_commanded_speed(make):
     vx, falls = PL.closed_loop_reference_policy(make(cfg), cfg, 1.5, 700)
     assert falls == 0
     assert abs(vx[350:].mean() - 1.5) < 0.15, vx[350:].mean()
+
+
+def test_reference_trajectory_csv_reader(tmp_path):
+    """csrc/irrl_csv.hpp restates VectorizedEnvironment.hpp:33-76 `readCSV_m`: comma separated, no header, one row per line;
+    CRLF line ends, blank lines and short rows (zero padded) are tolerated, a missing file is an error."""
+    import ctypes as C
+    l = E.lib(16)
+    l.emu_read_csv.restype = C.c_int
+    l.emu_read_csv.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    tab = PL.ref_table(rows=7)
+    path = tmp_path / "a b ref.csv"
+    lines = [",".join("%.9g" % v for v in r) for r in tab]
+    lines[2] = ",".join(lines[2].split(",")[:25])                    # short row
+    path.write_bytes(("\r\n".join(lines[:4]) + "\r\n\r\n" + "\n".join(lines[4:]) + "\n").encode())
+    r, c = C.c_int(0), C.c_int(0)
+    assert l.emu_read_csv(str(path).encode(), None, C.byref(r), C.byref(c)) == 0 and (r.value, c.value) == (7, 30)
+    out = np.zeros((7, 30), np.float32)
+    assert l.emu_read_csv(str(path).encode(), out.ctypes.data_as(C.POINTER(C.c_float)), C.byref(r), C.byref(c)) == 0
+    want = tab.copy()
+    want[2, 25:] = 0.0
+    assert np.allclose(out, want, rtol=1e-6, atol=1e-7)
+    assert l.emu_read_csv(b"/nonexistent/ref.csv", None, C.byref(r), C.byref(c)) != 0
