@@ -39,15 +39,17 @@ def _ptr(t):
 _WCACHE = {}
 
 
-def _permuted_weights(wx, wh, b, perm):
-    """[unit][gate]-ordered copies of the layer's weights, rebuilt only when a parameter changed (optimizer steps
-    bump `_version`): the 750 policy steps of a rollout and the 4 sequence passes of an epoch reuse them."""
+def _permuted_weights(wx, wh, b, perm, force=False):
+    """[unit][gate]-ordered copies of the layer's weights.  They are refreshed (in place: captured graphs keep reading the
+    same buffers) when `force` is set -- `SBLstm.prepare()`, which the learner calls after EVERY optimizer step and the
+    runner before every rollout -- or when a parameter's `_version` changed.  The version alone is NOT enough: the fused
+    Adam kernel updates the parameters without bumping it."""
     key = (wx.data_ptr(), wh.data_ptr(), b.data_ptr())
     ver = (wx._version, wh._version, b._version)
     hit = _WCACHE.get(key)
     if hit is not None and hit[2]() is None:
         hit = None   # the parameter these copies were made from is gone: another tensor now lives at its address
-    if hit is not None and hit[0] == ver:
+    if hit is not None and hit[0] == ver and not force:
         return hit[1]
     with torch.no_grad():
         if hit is not None:
@@ -63,9 +65,9 @@ def _permuted_weights(wx, wh, b, perm):
 
 
 def refresh_weights(wx, wh, b):
-    """Bring the cached [unit][gate] copies up to date (call before replaying a captured rollout step)."""
+    """Rebuild the cached [unit][gate] copies from the parameters, unconditionally (after an optimizer step, before a rollout)."""
     if wx.is_cuda:
-        _permuted_weights(wx, wh, b, _perm(wh.shape[0], wx.device)[0])
+        _permuted_weights(wx, wh, b, _perm(wh.shape[0], wx.device)[0], force=True)
 
 
 def _tall_gemm_t(a, b, chunks=256):

@@ -40,8 +40,8 @@ class SBLstm(nn.Module):
         self.b = nn.Parameter(torch.zeros(4 * n_hidden))
 
     def prepare(self):
-        """Refresh the fused kernels' permuted weight copies after an optimizer step (needed before replaying a
-        captured rollout graph, which cannot call back into Python)."""
+        """Refresh the fused kernels' permuted weight copies from the parameters, unconditionally: the learner calls this
+        after every optimizer step, the runner before every rollout (a captured graph cannot call back into Python)."""
         if self.wx.is_cuda and self.use_fused:
             from . import lstm_fused
             lstm_fused.refresh_weights(self.wx, self.wh, self.b)

@@ -359,6 +359,8 @@ class PPO2(object):
         for g in self.optimizer.param_groups:
             g['lr'] = lr_now
         self.optimizer.step()
+        if hasattr(self.policy, "prepare"):
+            self.policy.prepare()   # the kernels' permuted weight copies follow the parameters (fused Adam does not bump `_version`)
         if stats is not None:
             return stats.detach()
         return torch.stack([pg.detach(), vf.detach(), ent.detach(), kl.detach(), cf.detach()])

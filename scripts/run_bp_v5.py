@@ -55,6 +55,7 @@ def parse_args(argv):
     p.add_argument("--delay", type=int, default=0, help="observation delay in control steps (DelayTool)")
     p.add_argument("--vel_filter_freq", type=float, default=1.0e6, help="low-pass on the joint-rate / omega observations [Hz]")
     p.add_argument("--act_filter_freq", type=float, default=1.0e6, help="low-pass on the action [Hz]")
+    p.add_argument("--cmd_filter_freq", type=float, default=1.0, help="low-pass on the command [Hz] (GaitGenerator command_filter_freq)")
     p.add_argument("--out", type=str, default=None, help="--test: .npz with the per-step records")
     return p.parse_args(argv)
 
@@ -86,9 +87,12 @@ def run_test(args, cfg):
     vel_his, act_his = np.zeros(35), np.zeros(12)
     action_total = np.zeros([env.num_envs, env.num_acts], dtype=np.float32)
     rec = {k: [] for k in ("joint", "joint_dot", "posture", "omega", "phase", "act", "oss", "contact", "joint_effort", "cmd", "reward")}
-    cmd = np.array([args.flag_fix_cmd, 0.0, 0.0])
+    cmd_target = np.array([args.flag_fix_cmd, 0.0, 0.0])
+    a_cmd = alpha(args.cmd_filter_freq)          # the reference's GaitGenerator low-passes the gamepad / fixed command at 1 Hz
+    cmd = np.zeros(3)
     n_done = 0
     for t in range(args.steps):
+        cmd = (1 - a_cmd) * cmd + a_cmd * cmd_target
         o = np.array(d_tool.input_output(obs[0, :].copy()), dtype=np.float64)
         o[32:35] = (1 - a_vel) * vel_his[32:35] + a_vel * o[32:35]
         o[17:29] = (1 - a_vel) * vel_his[17:29] + a_vel * o[17:29]
@@ -109,6 +113,7 @@ def run_test(args, cfg):
         if done[0]:
             n_done += 1
             ctrl.reset()
+            cmd = np.zeros(3)                   # the env restarted from rest
     out = {k: np.asarray(v) for k, v in rec.items()}
     vx = out["oss"][:, 19]
     print("test: %d steps (%.2f s), command %.2f m/s, mean forward velocity %.3f m/s (last half %.3f), falls %d, mean reward %.4f"
@@ -160,7 +165,7 @@ def main(argv=None):
                      nminibatches=1 if args.policy == "lstm" else 4, noptepochs=10, cliprange=0.2, verbose=1,
                      seed=int(cfg.get("seed", 1)))
     else:
-        model = PPO2.load(args.pre_trained_model, env=env)      # run_bp_v5.py:244-248
+        model = PPO2.load(args.pre_trained_model, env=env, verbose=1)      # run_bp_v5.py:244-248
         model.tensorboard_log = log_path
         model.learning_rate = args.learn_rate
     if saver:
