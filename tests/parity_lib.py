@@ -198,14 +198,14 @@ def ref_table(rows=900, seed=5):
     return tab
 
 
-def closed_loop_reference_policy(env, cfg, cmd_vx, steps):
+def closed_loop_reference_policy(env, cfg, cmd_vx, steps, fixture="actor_bp5_155.npz"):
     """Drive `env` (1 Manual-mode env with reset/step of the test adapters) with the reference's RaiSim-trained bp5_155 actor
     (tests/golden/actor_bp5_155.npz, decoded from IRRL/script/pkl/bp5_155.pkl by tools/gen_golden.py) exactly like the
     evaluation script does (run_bp_v5.py:397-409: the command is written into obs[0:3]).  -> (vx per step, falls)."""
     import os
     from high_speed_quadrupedal_locomotion_by_irrl_amd.checkpoint import NumpyLstmActor
     from high_speed_quadrupedal_locomotion_by_irrl_amd.helper import obs_normalisation
-    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "actor_bp5_155.npz"))
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fixture))
     ctrl = NumpyLstmActor([z["wx0"].astype(np.float64), z["wx1"].astype(np.float64)], [z["wh0"].astype(np.float64), z["wh1"].astype(np.float64)],
                           [z["b0"].astype(np.float64), z["b1"].astype(np.float64)], z["pi_w"].astype(np.float64), z["pi_b"].astype(np.float64))
     mean, std, _, _ = obs_normalisation(cfg)

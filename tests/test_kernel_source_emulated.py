@@ -192,3 +192,15 @@ def test_reference_trajectory_csv_reader(tmp_path):
     want[2, 25:] = 0.0
     assert np.allclose(out, want, rtol=1e-6, atol=1e-7)
     assert l.emu_read_csv(b"/nonexistent/ref.csv", None, C.byref(r), C.byref(c)) != 0
+
+
+@pytest.mark.parametrize("make", [O.OracleVecEnv, E.EmuVecEnv16])
+def test_policy_trained_on_the_hip_engine_trots_in_the_oracle(make):
+    """Policy-level parity of engine and oracle: an actor trained for 2000 PPO updates ON THE MI355X ENGINE (f32 HIP kernels,
+    `scripts/run_bp_v5.py --train`, 200 envs; tests/golden/actor_trained_on_hip_engine.npz via tools/export_actor_fixture.py)
+    drives the f64 oracle and the emulated kernel source closed loop in Manual mode with its own training config: no fall,
+    commanded 1.5 m/s tracked (the training config has WILDCAT: True -> the robot runs in -x)."""
+    cfg = load_env_cfg("default_cfg.yaml", num_envs=1, Manual=True, ObsNoise=0.0, ActionNoise=0.0, StochasticDynamics=False)
+    vx, falls = PL.closed_loop_reference_policy(make(cfg), cfg, 1.5, 900, fixture="actor_trained_on_hip_engine.npz")
+    assert falls == 0
+    assert -1.75 < vx[450:].mean() < -1.2, vx[450:].mean()
