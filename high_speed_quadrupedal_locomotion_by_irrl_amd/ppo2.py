@@ -461,6 +461,30 @@ class PPO2(object):
             if callback is not None and callback(locals(), globals()) is False:
                 break
 
+    # -- stable-baselines BaseRLModel surface used around PPO2 (base_class.py: predict / get_env / set_env) --
+    @torch.no_grad()
+    def predict(self, observation, state=None, mask=None, deterministic=False):
+        """-> (actions clipped to the action space, next LSTM states).  numpy or torch observations [n_env, ob_dim]."""
+        is_np = isinstance(observation, np.ndarray)
+        obs = torch.as_tensor(observation, dtype=torch.float32, device=self.device)
+        if obs.dim() == 1:
+            obs = obs.unsqueeze(0)
+        n = obs.shape[0]
+        st = self.policy.initial_state(n, self.device) if state is None else torch.as_tensor(state, dtype=torch.float32, device=self.device)
+        mk = torch.zeros(n, dtype=torch.bool, device=self.device) if mask is None else torch.as_tensor(mask, device=self.device).to(torch.bool)
+        actions, _, new_state, _ = self.policy.step(obs, st, mk, deterministic=deterministic, generator=self.generator)
+        actions = actions.clamp(-1.0, 1.0)
+        if is_np:
+            return actions.cpu().numpy(), (new_state.cpu().numpy() if new_state is not None else None)
+        return actions, new_state
+
+    def get_env(self):
+        return self.env
+
+    def set_env(self, env):
+        self.env = env
+        self.n_envs = env.num_envs if env is not None else None
+
     # -- checkpoints (ppo2.py:452-476): (data dict, parameter list in stable-baselines order) --
     def _data(self):
         return {"gamma": self.gamma, "n_steps": self.n_steps, "vf_coef": self.vf_coef, "ent_coef": self.ent_coef,
