@@ -312,6 +312,10 @@ class PPO2(object):
             self.optimizer = torch.optim.Adam(self.policy.parameters(), fused=(self.device.type == "cuda"), **adam_kw)
         except Exception:
             self.optimizer = torch.optim.Adam(self.policy.parameters(), **adam_kw)
+        # the LSTM kernels read [unit][gate]-permuted COPIES of the weights; fused Adam updates the parameters without bumping
+        # their `_version`, so the copies are refreshed explicitly after every step of this optimizer, whoever calls it
+        if hasattr(self.policy, "prepare") and hasattr(self.optimizer, "register_step_post_hook"):
+            self.optimizer.register_step_post_hook(lambda *_a, **_k: self.policy.prepare())
         self.loss_names = ['policy_loss', 'value_loss', 'policy_entropy', 'approxkl', 'clipfrac']
         self.fused_loss = True   # single-launch loss forward + backward on the GPU (tests flip it to compare with the eager graph)
         self.log = []
@@ -358,9 +362,7 @@ class PPO2(object):
             torch.nn.utils.clip_grad_norm_(params, self.max_grad_norm)  # clip_by_global_norm AFTER averaging
         for g in self.optimizer.param_groups:
             g['lr'] = lr_now
-        self.optimizer.step()
-        if hasattr(self.policy, "prepare"):
-            self.policy.prepare()   # the kernels' permuted weight copies follow the parameters (fused Adam does not bump `_version`)
+        self.optimizer.step()       # (its post-step hook refreshes the kernels' permuted weight copies)
         if stats is not None:
             return stats.detach()
         return torch.stack([pg.detach(), vf.detach(), ent.detach(), kl.detach(), cf.detach()])
