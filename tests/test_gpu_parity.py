@@ -227,8 +227,8 @@ def test_manual_eval_mode_with_state_disturbance():
 
 def test_raisim_trained_policy_trots_in_the_hip_kernels():
     """Sim-to-sim through the C-ABI: the reference's RaiSim-trained bp5_155 actor drives one Manual-mode env of the HIP engine
-    (evaluation config rsc/bp5_test.yaml): no fall in 4 s, commanded speed tracked (1 and 3 m/s)."""
-    cfg = load_env_cfg("bp5_test.yaml")
+    (evaluation config rsc/bp5_manual_eval.yaml): no fall in 4 s, commanded speed tracked (1 and 3 m/s)."""
+    cfg = load_env_cfg("bp5_manual_eval.yaml")
     for cmd, lo, hi in ((1.0, 0.9, 1.15), (3.0, 2.5, 3.2)):
         vx, falls = PL.closed_loop_reference_policy(_hip(cfg), cfg, cmd, 2000)
         assert falls == 0

@@ -164,9 +164,9 @@ def test_manual_eval_mode_with_state_disturbance(cand):
 @pytest.mark.parametrize("make", [O.OracleVecEnv, E.EmuVecEnv16])
 def test_raisim_trained_policy_trots_at_the_commanded_speed(make):
     """Sim-to-sim: the controller the reference authors trained in RaiSim (bp5_155) runs this build's physics closed loop in
-    the reference's evaluation configuration (rsc/bp5_test.yaml) -- no fall, and the commanded 1.5 m/s is tracked within
+    the reference's evaluation configuration (rsc/bp5_manual_eval.yaml) -- no fall, and the commanded 1.5 m/s is tracked within
     10 % (f64 oracle and the f32 kernel source)."""
-    cfg = load_env_cfg("bp5_test.yaml")
+    cfg = load_env_cfg("bp5_manual_eval.yaml")
     vx, falls = PL.closed_loop_reference_policy(make(cfg), cfg, 1.5, 700)
     assert falls == 0
     assert abs(vx[350:].mean() - 1.5) < 0.15, vx[350:].mean()
