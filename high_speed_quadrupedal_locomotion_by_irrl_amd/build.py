@@ -11,8 +11,8 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libirrl_env.so")
-SOURCES = ["irrl_env_abi.hip", "env_kernels.hip", "lstm_kernels.hip", "env_core.hpp", "lanes_hip.hpp", "env_params.h", "irrl_config.hpp",
-           "irrl_state_pool.hpp", "irrl_terrain.hpp"]
+# every source / header under csrc/ is a dependency of the library (three translation units include most of them)
+SOURCES = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".h")))
 
 
 def hipcc():
