@@ -15,7 +15,7 @@ STATE_DIM = 288
 def build(width=4):
     out = os.path.join(_HERE, "_build", "libirrl_emu%d.so" % width)
     srcs = [os.path.join(_HERE, f) for f in ("emu_main.cpp", "lanes_cpu.hpp")] + \
-           [os.path.join(_CSRC, f) for f in ("env_core.hpp", "env_params.h", "irrl_config.hpp", "irrl_state_pool.hpp", "irrl_terrain.hpp")]
+           [os.path.join(_CSRC, f) for f in ("env_core.hpp", "env_params.h", "irrl_config.hpp", "irrl_state_pool.hpp", "irrl_terrain.hpp", "irrl_csv.hpp")]
     if (not os.path.exists(out)) or os.path.getmtime(out) < max(os.path.getmtime(s) for s in srcs):
         os.makedirs(os.path.dirname(out), exist_ok=True)
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-DIRRL_EMU_W=%d" % width,
