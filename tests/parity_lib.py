@@ -222,3 +222,44 @@ def closed_loop_reference_policy(env, cfg, cmd_vx, steps, fixture="actor_bp5_155
             falls += 1
             ctrl.reset()
     return np.array(vx), falls
+
+
+class BatchedNumpyActor(object):
+    """The two-layer LSTM actor of a fixture (tests/golden/actor_*.npz) for a batch of envs, float64 numpy."""
+
+    def __init__(self, fixture, n):
+        import os
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fixture))
+        self.w = {k: z[k].astype(np.float64) for k in z.files}
+        self.c = [np.zeros((n, 48)), np.zeros((n, 48))]
+        self.h = [np.zeros((n, 48)), np.zeros((n, 48))]
+
+    def act(self, ob, done):
+        sig = lambda v: 1.0 / (1.0 + np.exp(-v))
+        x = np.asarray(ob, np.float64)
+        keep = (~np.asarray(done, bool)).astype(np.float64)[:, None]
+        for i in range(2):
+            self.c[i] *= keep
+            self.h[i] *= keep
+            z = x @ self.w["wx%d" % i] + self.h[i] @ self.w["wh%d" % i] + self.w["b%d" % i]
+            ig, fg, og, g = sig(z[:, :48]), sig(z[:, 48:96]), sig(z[:, 96:144]), np.tanh(z[:, 144:])
+            self.c[i] = fg * self.c[i] + ig * g
+            self.h[i] = og * np.tanh(self.c[i])
+            x = self.h[i]
+        return np.clip(x @ self.w["pi_w"] + self.w["pi_b"], -1.0, 1.0).astype(np.float32)
+
+
+def closed_loop_training_mode(env, fixture, steps):
+    """Training-mode envs (command process, resets, noise as configured) driven by the fixture's actor.
+    -> dict(mean reward per step, mean |v_x|, terminations)."""
+    n = env.n
+    actor = BatchedNumpyActor(fixture, n)
+    ob = env.observe()
+    done = np.zeros(n, bool)
+    rew, vx, n_done = [], [], 0
+    for _ in range(steps):
+        ob, r, done, _ = env.step(actor.act(ob, done))
+        rew.append(r.mean())
+        vx.append(np.abs(env.get_state()[:, S["GV"]]).mean())
+        n_done += int(done.sum())
+    return dict(reward=float(np.mean(rew)), speed=float(np.mean(vx)), terminations=n_done)

@@ -233,3 +233,16 @@ def test_raisim_trained_policy_trots_in_the_hip_kernels():
         vx, falls = PL.closed_loop_reference_policy(_hip(cfg), cfg, cmd, 2000)
         assert falls == 0
         assert lo < vx[1000:].mean() < hi, (cmd, vx[1000:].mean())
+
+
+def test_trained_policy_closed_loop_statistics_match_the_oracle():
+    """Closed loop, training mode (commands up to 5 m/s, observation / action noise, randomised dynamics), 64 envs x 400 steps:
+    the actor trained on this engine gives the same mean reward and speed, and no more terminations, in the HIP kernels
+    (through the C-ABI) as in the f64 oracle.  Trajectories diverge (chaos), the statistics must not."""
+    cfg = load_env_cfg("default_cfg.yaml", num_envs=64)
+    so = PL.closed_loop_training_mode(O.OracleVecEnv(cfg), "actor_trained_on_hip_engine.npz", 400)
+    sc = PL.closed_loop_training_mode(_hip(cfg), "actor_trained_on_hip_engine.npz", 400)
+    print("closed-loop statistics oracle", so, "hip", sc)
+    assert abs(sc["reward"] - so["reward"]) < 0.01 * abs(so["reward"])       # measured: 0.733741 vs 0.733722
+    assert abs(sc["speed"] - so["speed"]) < 0.01 * so["speed"]               # measured: 1.282898 vs 1.282887 m/s
+    assert so["terminations"] <= 2 and sc["terminations"] <= 2
