@@ -165,11 +165,14 @@ def main():
     if rank == 0:
         # HBM bytes per launch from the PMC passes (FETCH_SIZE x calibrated correction + WRITE_SIZE), collected with
         # rocprofv3 in separate runs (tools/gpu_pmc.sh) and committed under profiles/ -- not measurable in-process
-        traffic = None
+        traffic, issue = None, None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary_latest.json")))
             if int(pmc.get("envs", 4096)) == n and env.lanes_per_robot == 16:
                 traffic = float(pmc["hbm_bytes_per_launch"]["total"])
+                # how close the single resident wave per SIMD runs to its issue limit of one VALU instruction per 4 cycles
+                issue = {"valu_insts_per_wave": pmc["derived"]["valu_insts_per_wave"], "cycles_per_valu_inst": pmc["derived"]["cycles_per_valu_inst"],
+                         "frac_of_single_wave_issue_peak": 4.0 / pmc["derived"]["cycles_per_valu_inst"], "source": "profiles/pmc_summary_latest.json"}
         except Exception:
             pass
         total_env_steps = float(n) * world * args.steps
@@ -191,7 +194,7 @@ def main():
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n},
             "roofline_fp32": {"bound": "valu_fp32 (latency/issue bound: 1 wave per SIMD at 4096 envs)", "achieved": ach_tf,
                               "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP32_PEAK_TFLOPS,
-                              "algorithmic_flops_per_launch": ALG_FLOPS_PER_ENV_STEP * n},
+                              "algorithmic_flops_per_launch": ALG_FLOPS_PER_ENV_STEP * n, "valu_issue": issue},
             "resets_in_50_steps": float(n_done.item()),
         }
         if world == 1 and args.cpu_seconds > 0:
