@@ -1,21 +1,36 @@
 #!/usr/bin/env python3
-"""bench.py -- env-steps/sec of the env.step() hot path on MI355X (BASELINE.json metric).
+"""bench.py -- env-steps/sec of the env.step() hot path on MI355X, and PPO iterations/sec (BASELINE.json metric).
 
 A "step" is one FlexibleGymEnv.step() over one batch of 4096 robots per GPU (8 physics substeps at 4 kHz +
 observation + 8 reward terms + termination + masked in-step reset), with the action batch already resident
 in HBM.  Workload at N=1: BASELINE config 2 ("4096 envs on 1xMI355X, imitation reward, pure env-step
-kernel"), synthetic actions a = clip(0.3*N(0,1), -1, 1).  Multi-GPU: one process per GPU
-(launched by torch.distributed.run), 4096 envs per rank, no data-path collective (envs never interact,
-RaisimGymEnv.hpp:56) -> weak scaling; the only collectives are the timing barrier and the max-over-ranks.
+kernel"), synthetic actions a = clip(0.3*N(0,1), -1, 1) from Philox(seed=1, stream=env, counter=step)
+(device generator `irrl_bench_actions`, numpy twin tools/bench_actions.py).
 
-Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel = irrl_step_kernel, HIP-event
-timed inside this run), `roofline_fp32` (the VALU-FP32 view: this path is latency/issue bound, not HBM
-bound), `cpu_baseline` (the f64 oracle with the reference's OpenMP-over-envs threading on the
-GPU box's host cores, bounded sample, rank 0 / N=1 only).
+STEADY STATE: robots are reset 4 cm above their standing height, i.e. the first ~46 control steps after a reset
+are free flight with the contact solve skipped.  Before --warmup the bench therefore ALWAYS runs an untimed
+pre-roll (--preroll, default 300, at least 200 steps) so that the timed region sees landed robots; it reads the
+kernels' own counters (toe-substeps in the contact list, episodes started) around the timed region, reports
+`contact_fraction_in_timed_region` / `resets_in_timed_region`, and FAILS when the region was free flight.
+
+Multi-GPU: `python bench.py --gpus N` with N > 1 starts N ranks by itself (python -m torch.distributed.run, one
+rank per GPU, rendezvous on 127.0.0.1) unless it already runs under a launcher (WORLD_SIZE set).  4096 envs per
+rank, no data-path collective in the env benchmark (envs never interact, RaisimGymEnv.hpp:56) -> weak scaling;
+collectives there are only the timing barrier and the max-over-ranks.  The PPO leg runs on every rank with the
+north_star's collectives in the loop (flat 283 KB gradient all-reduce + 3-float advantage moments per optimizer
+step, ppo2.py) and reports whole-job iterations/s and samples/s.
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel = irrl_step_kernel, HIP-event timed
+over the timed region on the stream it is launched on), `roofline_fp32` (the VALU-FP32 view: this path is
+latency/issue bound, not HBM bound), `cpu_baseline` (the f64 oracle with the reference's
+OpenMP-over-envs threading on the GPU box's host cores + its single-thread rate, bounded sample, rank 0 / N=1 only),
+`ppo` (second half of the metric).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,6 +42,39 @@ ALG_BYTES_PER_ENV_STEP = 1521.0
 ALG_FLOPS_PER_ENV_STEP = 1.15e5  # instrumented oracle (tools/flopcount): 114 823 flop/env-step on this workload, 1.6 contact sweeps
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 FP32_PEAK_TFLOPS = 157.3
+ACTION_SEED = 1
+MIN_PREROLL = 200
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--preroll", type=int, default=300, help="untimed env steps before --warmup (never fewer than %d): robots land" % MIN_PREROLL)
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--cfg", default="bp5_imitation.yaml")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget (0 disables)")
+    ap.add_argument("--ppo-iters", type=int, default=2, help="timed PPO iterations of the LSTM policy (0 disables)")
+    ap.add_argument("--ppo-steps", type=int, default=750, help="rollout length of the PPO leg (the metric's is 750)")
+    ap.add_argument("--ppo-epochs", type=int, default=10, help="optimisation epochs of the PPO leg (the metric's is 10)")
+    ap.add_argument("--check-steps", type=int, default=2000, help="extra untimed-for-`value` window after the timed region that "
+                    "re-measures us/step over a longer run (0 disables); reported as `steady_state_check`")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args):
+    """`--gpus N` outside a launcher: start N fresh rank processes and relay their output.  This parent has not imported
+    torch and never touches the GPU (a process that has initialised the GPU must not be replaced / must not fork ranks)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def usable_cores():
@@ -49,47 +97,71 @@ def usable_cores():
     return max(1, n)
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(env_cfg, target_seconds):
     """Oracle (kind "port": the build's own CPU restatement; the RaiSim reference is closed source and absent)
-    timed with `#pragma omp parallel for schedule(dynamic)` over envs like VectorizedEnvironment.hpp:273."""
+    timed with `#pragma omp parallel for schedule(dynamic)` over envs like VectorizedEnvironment.hpp:273, on the same
+    Philox action stream as the GPU (after the same kind of pre-roll: landed robots), then once more on ONE thread."""
+    import ctypes
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
     import oracle as O
+    from bench_actions import bench_actions
     cores = usable_cores()
     os.environ["OMP_NUM_THREADS"] = str(cores)
     cfg = dict(env_cfg)
     n = int(cfg["num_envs"])
     env = O.OracleVecEnv(cfg)
-    rng = np.random.RandomState(1)
-    acts = [np.clip(0.3 * rng.normal(size=(n, 12)), -1, 1).astype(np.float32) for _ in range(8)]
+    gomp = ctypes.CDLL("libgomp.so.1")
+    gomp.omp_set_num_threads(cores)
+    acts = bench_actions(ACTION_SEED, 0, n, 0, 64, 0.3)
     t0 = time.perf_counter()
-    for k in range(4):
-        env.step(acts[k])
-    per_step = (time.perf_counter() - t0) / 4
-    steps = int(max(8, min(750, target_seconds / max(per_step, 1e-6))))
+    for k in range(60):          # pre-roll: the robots land (46 steps of free flight after the reset)
+        env.step(acts[k % 64])
+    per_step = (time.perf_counter() - t0) / 60
+    steps = int(max(8, min(750, 0.75 * target_seconds / max(per_step, 1e-6))))
     t0 = time.perf_counter()
     for k in range(steps):
-        env.step(acts[k % 8])
+        env.step(acts[(60 + k) % 64])
     dt = time.perf_counter() - t0
-    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d envs x %d control steps (f64 oracle, OpenMP dynamic over envs, %d threads, %.1f s)" % (n, steps, cores, dt)}
+    multi = n * steps / dt
+    # single thread: a slice of the pool, so that it stays inside the budget
+    gomp.omp_set_num_threads(1)
+    n1 = max(16, min(n, 256))
+    cfg1 = dict(cfg)
+    cfg1["num_envs"] = n1
+    env1 = O.OracleVecEnv(cfg1)
+    a1 = np.ascontiguousarray(acts[:, :n1])
+    for k in range(60):
+        env1.step(a1[k % 64])
+    steps1 = int(max(8, min(750, 0.2 * target_seconds * multi / cores / n1)))
+    t0 = time.perf_counter()
+    for k in range(steps1):
+        env1.step(a1[(60 + k) % 64])
+    dt1 = time.perf_counter() - t0
+    gomp.omp_set_num_threads(cores)
+    return {"value": multi, "unit": "env-steps/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "single_thread_value": n1 * steps1 / dt1,
+            "sample": "%d envs x %d control steps after a 60-step pre-roll (f64 oracle, OpenMP dynamic over envs, %d threads, %.1f s); "
+                      "single thread: %d envs x %d steps (%.1f s)" % (n, steps, cores, dt, n1, steps1, dt1)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
-    ap.add_argument("--cfg", default="bp5_imitation.yaml")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget (0 disables)")
-    ap.add_argument("--ppo-iters", type=int, default=2, help="timed PPO iterations of the LSTM policy at N=1 (0 disables)")
-    args = ap.parse_args()
-
-    import numpy as np
+def worker(args):
+    import ctypes as C
     import torch
     import yaml
     import high_speed_quadrupedal_locomotion_by_irrl_amd as pkg
+    from high_speed_quadrupedal_locomotion_by_irrl_amd import _lib
     from high_speed_quadrupedal_locomotion_by_irrl_amd.flexible_robot import FlexibleGymEnv
 
     rank = int(os.environ.get("RANK", "0"))
@@ -98,13 +170,14 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the env kernels have no CPU path")
     # IRRL_BENCH_BACKEND=gloo + IRRL_BENCH_ONE_DEVICE=1 let the multi-rank control flow be exercised on a 1-GPU box
-    # (both ranks on cuda:0, barrier / max-reduce over gloo); the driver's runs use the defaults: one GPU per rank, RCCL
+    # (both ranks on cuda:0, barrier / reductions over gloo); the driver's runs use the defaults: one GPU per rank, RCCL
     backend = os.environ.get("IRRL_BENCH_BACKEND", "nccl")
     if os.environ.get("IRRL_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    ranks_seen = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -112,33 +185,44 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                      # proves every rank is in the communicator (RCCL over xGMI by default)
+        ranks_seen = int(ones.item())
 
     with open(os.path.join(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY__, args.cfg)) as f:
         env_cfg = yaml.safe_load(f)["environment"]
-    env_cfg["num_envs"] = args.envs
-    env_cfg["seedd"] = int(env_cfg.get("seedd", 1)) + 7919 * rank   # different robots on every rank
     n = args.envs
+    env_cfg["num_envs"] = n
+    env_cfg["seedd"] = int(env_cfg.get("seedd", 1)) + 7919 * rank   # different robots on every rank
     env = FlexibleGymEnv(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY__, yaml.safe_dump(env_cfg), device=local_rank)
     env.init()
+    loop_count = int(round(float(env_cfg["control_dt"]) / float(env_cfg["simulation_dt"])))
 
-    # synthetic action pool resident in HBM (Philox-free here: torch generator seeded per rank)
-    g = torch.Generator(device=dev)
-    g.manual_seed(1 + rank)
-    pool = [torch.clamp(0.3 * torch.randn(n, 12, device=dev, generator=g), -1, 1).contiguous() for _ in range(64)]
+    # synthetic action stream resident in HBM: row s = actions of global step s for this rank's envs (global env id =
+    # rank * n + e).  Beyond 16384 steps the stream wraps (it would be 3 GB otherwise); the default run uses 5.5 k rows.
+    preroll = max(MIN_PREROLL, args.preroll)
+    total = preroll + args.warmup + args.steps + 50 + args.check_steps
+    rows = min(total, 16384)
+    lib = _lib.load()
+    actions = torch.empty(rows, n, 12, device=dev)
+    _lib.check(lib.irrl_bench_actions(ACTION_SEED, rank * n, n, 0, rows, 0.3, C.c_void_p(actions.data_ptr()),
+                                      C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
     ob = torch.zeros(n, 35, device=dev)
     rew = torch.zeros(n, device=dev)
     done = torch.zeros(n, dtype=torch.bool, device=dev)
     extra = torch.zeros(n, 6, device=dev)
-    n_done = torch.zeros((), device=dev)
+    cursor = [0]
 
-    def run(k_steps, count_done=False):
+    def run(k_steps):
+        s0 = cursor[0]
         for k in range(k_steps):
-            env.step(pool[k % 64], ob, rew, done, extra)
-            if count_done:
-                n_done.add_(done.sum())
+            env.step(actions[(s0 + k) % rows], ob, rew, done, extra)
+        cursor[0] = s0 + k_steps
 
+    run(preroll)                 # untimed, unconditional: robots land and the contact set becomes stationary
     run(args.warmup)
     torch.cuda.synchronize()
+    c0 = env.counters()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -153,15 +237,36 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps   # events on the stream the kernel is launched on
+    c1 = env.counters()
+    resets = c1[0] - c0[0]
+    contact_fraction = (c1[1] - c0[1]) / float(4 * loop_count * n * args.steps)
     if dist is not None:
         t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    # sanity on the timed work: finite outputs, episodes really terminate and reset inside the step
-    run(50, count_done=True)
-    torch.cuda.synchronize()
+        agg = torch.tensor([float(resets), contact_fraction], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(agg)
+        resets, contact_fraction = int(agg[0].item()), float(agg[1].item()) / world
     assert torch.isfinite(ob).all() and torch.isfinite(rew).all(), "non-finite env outputs"
+    # the timed region must be the steady state (robots on the ground, episodes ending inside the step), not free flight
+    if contact_fraction <= 0.0:
+        raise SystemExit("bench.py: no toe was in contact during the timed region (free flight) -- not a valid measurement")
+    if resets == 0 and n * world * args.steps >= 50000:
+        raise SystemExit("bench.py: no episode ended inside the timed region of %d env-steps -- not the steady-state workload" % (n * world * args.steps))
+    check = None
+    if args.check_steps > 0:
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        cc0 = env.counters()
+        e0.record()
+        run(args.check_steps)
+        e1.record()
+        torch.cuda.synchronize()
+        cc1 = env.counters()
+        check = {"steps": args.check_steps, "us_per_step": 1e3 * e0.elapsed_time(e1) / args.check_steps,
+                 "contact_fraction": (cc1[1] - cc0[1]) / float(4 * loop_count * n * args.check_steps), "resets": cc1[0] - cc0[0]}
 
+    out = None
     if rank == 0:
         # HBM bytes per launch from the PMC passes (FETCH_SIZE x calibrated correction + WRITE_SIZE), collected with
         # rocprofv3 in separate runs (tools/gpu_pmc.sh) and committed under profiles/ -- not measurable in-process
@@ -185,9 +290,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE config 2: %d envs/GPU x 1 env.step (8 substeps @4 kHz + obs + reward + "
-                                   "termination + in-step reset), cfg %s, actions clip(0.3 N(0,1))" % (n, args.cfg),
+                                   "termination + in-step reset), cfg %s, actions clip(0.3 N(0,1)) from Philox(seed 1, stream env, counter step), "
+                                   "%d-step untimed pre-roll before the warm-up" % (n, args.cfg, preroll),
                        "envs_per_gpu": n, "global_envs": n * world, "parallelism": "env-sharded x%d" % world,
-                       "lanes_per_robot": env.lanes_per_robot},
+                       "lanes_per_robot": env.lanes_per_robot, "preroll": preroll},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "irrl_step_kernel_l%d" % env.lanes_per_robot, "avg_launch_us": kernel_ms * 1e3,
@@ -195,21 +301,43 @@ def main():
             "roofline_fp32": {"bound": "valu_fp32 (latency/issue bound: 1 wave per SIMD at 4096 envs)", "achieved": ach_tf,
                               "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP32_PEAK_TFLOPS,
                               "algorithmic_flops_per_launch": ALG_FLOPS_PER_ENV_STEP * n, "valu_issue": issue},
-            "resets_in_50_steps": float(n_done.item()),
+            "contact_fraction_in_timed_region": contact_fraction, "resets_in_timed_region": resets,
+            "steady_state_check": check, "rccl_ranks_seen": ranks_seen, "backend": backend if world > 1 else None,
+            "library": lib.irrl_version().decode(),
         }
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(env_cfg, args.cpu_seconds)
-        if world == 1 and args.ppo_iters > 0:
-            # second half of BASELINE.json's metric ("PPO iters/sec"): the reference's training iteration (750-step rollout of
-            # all envs with the 2x48 + 2x48 LSTM policy, GAE, 10 epochs of full-length BPTT, global reset) on this GPU;
-            # reported beside the headline value, never mixed into it
-            del env
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
-            import ppo_bench
-            out["ppo"] = ppo_bench.measure("lstm", n, 750, args.ppo_iters + 1, 10, "default_cfg.yaml", verbose=False)
-        print(json.dumps(out))
+    if args.ppo_iters > 0:
+        # second half of BASELINE.json's metric ("PPO iters/sec"): the reference's training iteration (750-step rollout of
+        # all envs with the 2x48 + 2x48 LSTM policy, GAE, 10 epochs of full-length BPTT, global reset) on every rank, gradients
+        # and advantage moments all-reduced per optimizer step; reported beside the headline value, never mixed into it
+        del env
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import ppo_bench
+        ppo = ppo_bench.measure("lstm", n, args.ppo_steps, args.ppo_iters + 1, args.ppo_epochs, "default_cfg.yaml", verbose=False, rank=rank)
+        if dist is not None:
+            t = torch.tensor([ppo["rollout_s"], ppo["update_s"], ppo["rollout_s"] + ppo["update_s"]], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ppo["rollout_s"], ppo["update_s"], it_s = (float(x) for x in t.tolist())
+        else:
+            it_s = ppo["rollout_s"] + ppo["update_s"]
+        if out is not None:
+            ppo.update({"world": world, "global_envs": n * world, "ppo_iters_per_sec": 1.0 / it_s, "samples_per_sec": n * world * args.ppo_steps / it_s,
+                        "env_steps_per_sec_in_rollout": n * world * args.ppo_steps / ppo["rollout_s"],
+                        "collectives_per_optimizer_step": None if world == 1 else "all-reduce of the flat gradient (283 KB) + 3-float advantage moments"})
+            out["ppo"] = ppo
+    if out is not None:
+        print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
+    worker(args)
 
 
 if __name__ == "__main__":

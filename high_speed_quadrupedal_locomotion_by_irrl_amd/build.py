@@ -1,18 +1,31 @@
 """Build the gfx950 shared library of the env kernels + C-ABI (in-tree, so it travels with gpurun).
 
-    python -m high_speed_quadrupedal_locomotion_by_irrl_amd.build
+    python -m high_speed_quadrupedal_locomotion_by_irrl_amd.build [--force]
 
-hipcc cross-compiles without a GPU; the only target is gfx950 (MI355X / CDNA4)."""
+hipcc cross-compiles without a GPU; the only target is gfx950 (MI355X / CDNA4).
+
+Staleness is decided by CONTENT, not by file times: a sha256 over every source under csrc/, include/irrl_env.h and
+the compiler flags is baked into the library (`irrl_version()` = "gfx950;irrl-env r2;irrl-src-hash:<hex>"); a
+prebuilt `.so` is reused only when the hash found inside it equals the hash of the sources next to it.  (File times
+do not survive a fresh checkout or an rsync, and the built `.so` travels to the GPU box although git ignores it.)"""
+import hashlib
 import os
+import re
 import shutil
 import subprocess
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
+HEADER = os.path.join(_HERE, "..", "include", "irrl_env.h")
 LIB = os.path.join(_HERE, "libirrl_env.so")
-# every source / header under csrc/ is a dependency of the library (three translation units include most of them)
-SOURCES = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".h")))
+_MARK = b"irrl-src-hash:"
+
+
+def sources(csrc=None):
+    """every source / header under csrc/ is a dependency of the library (three translation units include most of them)"""
+    csrc = csrc or CSRC
+    return sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".hpp", ".h")))
 
 
 def hipcc():
@@ -22,29 +35,59 @@ def hipcc():
     raise RuntimeError("hipcc not found (expected /opt/rocm/bin/hipcc)")
 
 
-def is_stale():
-    if not os.path.exists(LIB):
-        return True
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(_HERE, "..", "include", "irrl_env.h")]
-    return os.path.getmtime(LIB) < max(os.path.getmtime(d) for d in deps)
-
-
+COMMON_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-fno-signed-zeros"]
 # Env kernels only (measured on MI355X, 4096 envs, same box): the SLP vectorizer's packed-f32 pairs cost more v_mov than
 # they save in this scalar-per-lane code (56.6 -> 51.4 us per step without it), and the single resident wave per SIMD
 # wants ILP-first scheduling (-> 50.1 us).
 ENV_FLAGS = ["-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 
 
+def source_hash(extra_flags=(), csrc=None, header=None):
+    """sha256 over (file name, file bytes) of every dependency + the flag lists, first 16 hex digits"""
+    csrc = csrc or CSRC
+    h = hashlib.sha256()
+    for name in sources(csrc):
+        h.update(name.encode() + b"\0")
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    with open(header or HEADER, "rb") as f:
+        h.update(b"irrl_env.h\0" + f.read())
+    h.update(("\0".join(COMMON_FLAGS + ["|"] + ENV_FLAGS + ["|"] + list(extra_flags))).encode())
+    return h.hexdigest()[:16]
+
+
+def embedded_hash(lib=None):
+    """the hash baked into a built library, read from the file's bytes (no dlopen, no HIP runtime); None if absent"""
+    lib = lib or LIB
+    if not os.path.exists(lib):
+        return None
+    with open(lib, "rb") as f:
+        blob = f.read()
+    m = re.search(re.escape(_MARK) + rb"([0-9a-f]{16})", blob)
+    return m.group(1).decode() if m else None
+
+
+def is_stale(extra_flags=(), csrc=None, lib=None):
+    return embedded_hash(lib) != source_hash(extra_flags, csrc)
+
+
 def build(force=False, verbose=False, extra_flags=()):
-    if not force and not is_stale():
+    """-> path of the library.  Compiles unless the prebuilt one carries the hash of the current sources; prints which."""
+    want = source_hash(extra_flags)
+    if not force and embedded_hash() == want:
+        if verbose:
+            print("[build] reusing %s (source hash %s matches)" % (os.path.basename(LIB), want))
         return LIB
-    common = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-fno-signed-zeros"] + list(extra_flags)
+    if verbose:
+        print("[build] compiling %s (source hash %s, library has %s)" % (os.path.basename(LIB), want, embedded_hash()))
+    common = [hipcc()] + COMMON_FLAGS + list(extra_flags)
     objdir = os.path.join(_HERE, "csrc", "_obj")
     os.makedirs(objdir, exist_ok=True)
     # the env kernels in both lane layouts (same source, different lane-primitive header), then the C-ABI + LSTM kernels
     units = [("env_kernels.hip", ["-DIRRL_LANES_PER_ROBOT=16"] + ENV_FLAGS, "env_kernels_l16.o"),
              ("env_kernels.hip", ["-DIRRL_LANES_PER_ROBOT=4"] + ENV_FLAGS, "env_kernels_l4.o"),
-             ("irrl_env_abi.hip", [], "irrl_env_abi.o")]
+             ("irrl_env_abi.hip", ['-DIRRL_SRC_HASH="%s"' % want], "irrl_env_abi.o")]
     procs = []
     for src, flags, obj in units:
         cmd = common + flags + ["-c", os.path.join(CSRC, src), "-o", os.path.join(objdir, obj)]
@@ -58,6 +101,9 @@ def build(force=False, verbose=False, extra_flags=()):
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link)
+    got = embedded_hash()
+    if got != want:
+        raise RuntimeError("built library carries source hash %r, expected %r" % (got, want))
     return LIB
 
 

@@ -281,6 +281,7 @@ struct EnvLane {
   vf jr[3], jrl[3], jdr[3], eer[3];
   vf lamw[3];
   vi in_contact; vf contact;
+  vu ccount;              // toe-substeps in the contact list (diagnostic counter, EnvState::contact_count)
   // per-env (replicated in the 4 lanes of the quad)
   v3 pos; vf qw, qx, qy, qz; v3 vw, ww;
   vf cmd[3], cmdf[3];
@@ -913,6 +914,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
   }
   IRRL_MARK("integrate");
   L.in_contact = vsel_i(active, 1, 0);
+  L.ccount = L.ccount + to_u(L.in_contact);
   // back to world-frame gv, then positions (semi-implicit Euler); joint `sub` integrates in its own lane
   L.vw = rot_mul(R, mk3(ub[0], ub[1], ub[2]));
   L.ww = rot_mul(R, mk3(ub[3], ub[4], ub[5]));
@@ -1109,6 +1111,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     L.lamw[0] = 0.0f; L.lamw[1] = 0.0f; L.lamw[2] = 0.0f;
   }
   L.in_contact = vsel_i(active, 1, 0);
+  L.ccount = L.ccount + to_u(L.in_contact);
   // back to world-frame gv, then positions (semi-implicit Euler)
   L.vw = rot_mul(R, mk3(ub[0], ub[1], ub[2]));
   L.ww = rot_mul(R, mk3(ub[3], ub[4], ub[5]));
@@ -1462,6 +1465,8 @@ IRRL_DEV void load_lane(const EnvParams &P, const EnvState &S, vi env, vi leg, E
     L.cmd[k] = ld(S.command, env * 3 + k); L.cmdf[k] = ld(S.command_filtered, env * 3 + k);
   }
   L.in_contact = ld_i(S.in_contact, env * 4 + leg); L.contact = ld(S.contact, env * 4 + leg);
+  L.ccount = 0u;
+  if (S.contact_count) L.ccount = ld_u(S.contact_count, env * 4 + leg);
   L.pos = mk3(ld(S.gc, gcb), ld(S.gc, gcb + 1), ld(S.gc, gcb + 2));
   L.qw = ld(S.gc, gcb + 3); L.qx = ld(S.gc, gcb + 4); L.qy = ld(S.gc, gcb + 5); L.qz = ld(S.gc, gcb + 6);
   L.vw = mk3(ld(S.gv, gvb), ld(S.gv, gvb + 1), ld(S.gv, gvb + 2));
@@ -1516,6 +1521,7 @@ IRRL_DEV void store_lane(const EnvParams &P, const EnvState &S, vi env, vi leg, 
     st_if(lead, S.ob, ob + k, L.ob_cmd[k]); st_if(lead, S.ob, ob + 29 + k, L.ob_post[k]); st_if(lead, S.ob, ob + 32 + k, L.ob_omega[k]);
   }
   st_i_if(valid, S.in_contact, env * 4 + leg, L.in_contact); st_if(valid, S.contact, env * 4 + leg, L.contact);
+  if (S.contact_count) st_u_if(valid, S.contact_count, env * 4 + leg, L.ccount);
   st_if(lead, S.gc, gcb, L.pos.x); st_if(lead, S.gc, gcb + 1, L.pos.y); st_if(lead, S.gc, gcb + 2, L.pos.z);
   st_if(lead, S.gc, gcb + 3, L.qw); st_if(lead, S.gc, gcb + 4, L.qx); st_if(lead, S.gc, gcb + 5, L.qy); st_if(lead, S.gc, gcb + 6, L.qz);
   st_if(lead, S.gv, gvb, L.vw.x); st_if(lead, S.gv, gvb + 1, L.vw.y); st_if(lead, S.gv, gvb + 2, L.vw.z);
@@ -1671,7 +1677,7 @@ IRRL_DEV void init_body(const EnvParams &P, const EnvState &S, vi env, vi leg, v
 #pragma unroll
   for (int k = 0; k < 11; k++) L.obl_env[k] = 0.0f;
   L.ob_phase[0] = 0.0f; L.ob_phase[1] = 0.0f;
-  L.in_contact = 0; L.contact = 0.0f;
+  L.in_contact = 0; L.contact = 0.0f; L.ccount = 0u;
   L.pos = mk3(0.0f, 0.0f, 0.0f); L.qw = 1.0f; L.qx = 0.0f; L.qy = 0.0f; L.qz = 0.0f;
   L.vw = mk3(0.0f, 0.0f, 0.0f); L.ww = mk3(0.0f, 0.0f, 0.0f);
   L.t0 = 0.0f; L.frame = 0; L.episode = 0u; L.up_height = P.up_height_max;

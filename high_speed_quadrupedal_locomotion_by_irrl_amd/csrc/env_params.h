@@ -61,6 +61,9 @@ struct EnvState {
   float *thigh_dz;      // [N]
   float *ob;            // [N,35] unscaled observation (obDouble_)
   float *ob_last;       // [N,35]
+  // diagnostic counter, NOT part of the env state (own allocation, may be NULL): toe-substeps spent in the contact list
+  // since the pool was created, per (env, leg); bench.py reads it around the timed region to prove the region was not free flight
+  uint32_t *contact_count;  // [N,4]
 };
 
 // RNG purposes -- (purpose, slot) addresses every random draw; identical table in the oracle.

@@ -57,6 +57,7 @@ struct irrl_env {
   uint8_t *d_done = nullptr;
   float *d_height = nullptr;  // shared height field (Terrain: True)
   float *d_ref = nullptr;     // reference-trajectory table [rows, 30] (ManualTraj: False)
+  uint32_t *d_counters = nullptr;  // [N,4] toe-substeps in contact (EnvState::contact_count, diagnostic)
   std::vector<float> h_height;
   // pinned host staging
   char *h_pinned = nullptr;
@@ -96,7 +97,12 @@ static int pick_lanes(int n_envs) {
 extern "C" {
 
 const char *irrl_last_error(void) { return g_err.c_str(); }
-const char *irrl_version(void) { return "gfx950;irrl-env r1"; }
+#ifndef IRRL_SRC_HASH
+#define IRRL_SRC_HASH "unknown"
+#endif
+// the build recipe (build.py) bakes a content hash of csrc/ + include/ + the compiler flags into the library, so a
+// prebuilt .so that does not match the sources next to it is detected without relying on file times
+const char *irrl_version(void) { return "gfx950;irrl-env r2;irrl-src-hash:" IRRL_SRC_HASH; }
 
 irrl_env *irrl_env_create(const char *resource_dir, const char *cfg_yaml, int device) {
   g_err.clear();
@@ -123,7 +129,8 @@ irrl_env *irrl_env_create(const char *resource_dir, const char *cfg_yaml, int de
   bool ok = hipSetDevice(device) == hipSuccess && hipMalloc(&h->d_pool, h->pool.bytes) == hipSuccess &&
             hipMemset(h->d_pool, 0, h->pool.bytes) == hipSuccess && hipMalloc((void **)&h->d_action, n * 12 * 4) == hipSuccess &&
             hipMalloc((void **)&h->d_ob, n * (35 * 4 + 4 + 6 * 4 + 1)) == hipSuccess &&   // ob | reward | extra | done: ONE D2H copy per host step
-            hipMalloc((void **)&h->d_scratch, n * 342 * 4) == hipSuccess;
+            hipMalloc((void **)&h->d_scratch, n * 342 * 4) == hipSuccess &&
+            hipMalloc((void **)&h->d_counters, n * 4 * 4) == hipSuccess && hipMemset(h->d_counters, 0, n * 4 * 4) == hipSuccess;
   h->pinned_bytes = n * 342 * 4 + h->pool.bytes + 4096;
   ok = ok && hipHostMalloc((void **)&h->h_pinned, h->pinned_bytes, hipHostMallocDefault) == hipSuccess;
   if (ok && h->P.terrain) {
@@ -139,6 +146,7 @@ irrl_env *irrl_env_create(const char *resource_dir, const char *cfg_yaml, int de
   }
   if (!ok) { g_err = "device / pinned allocation failed"; irrl_env_destroy(h); return nullptr; }
   h->S = h->pool.view(h->d_pool);
+  h->S.contact_count = h->d_counters;
   if (h->P.ref_traj) {
     // VEC:158-169: the table named by cfg["RefTraj"]; a missing file is only a console message there (and a crash at the
     // first step) -- here the pool is created, and init() refuses to run until irrl_env_set_ref_host supplied a table
@@ -178,6 +186,7 @@ void irrl_env_destroy(irrl_env *h) {
   if (h->d_scratch) (void)hipFree(h->d_scratch);
   if (h->d_height) (void)hipFree(h->d_height);
   if (h->d_ref) (void)hipFree(h->d_ref);
+  if (h->d_counters) (void)hipFree(h->d_counters);
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
   delete h;
 }
@@ -203,6 +212,15 @@ int irrl_env_action_dim(const irrl_env *) { return IRRL_ACTION_DIM; }
 int irrl_env_extra_dim(const irrl_env *) { return IRRL_EXTRA_DIM; }
 const char *irrl_env_extra_name(const irrl_env *, int j) { return (j >= 0 && j < IRRL_EXTRA_DIM) ? kExtraNames[j] : ""; }
 
+// The device-pointer entry points launch on h->stream, which belongs to h->device: make that device current when the
+// caller's is another one (a process driving pools on several GPUs).  hipGetDevice is a thread-local read, so the common
+// single-device case costs no driver call.
+static int use_device(irrl_env *h) {
+  int cur = -1;
+  if (hipGetDevice(&cur) == hipSuccess && cur == h->device) return 0;
+  HIP_TRY(hipSetDevice(h->device));
+  return 0;
+}
 static int need_init(irrl_env *h) {
   if (!h->initialised) { g_err = "irrl_env_init has not been called"; return 1; }
   return 0;
@@ -210,6 +228,7 @@ static int need_init(irrl_env *h) {
 
 int irrl_env_step(irrl_env *h, const float *action, float *ob, float *reward, uint8_t *done, float *extra) {
   if (need_init(h)) return 1;
+  if (use_device(h)) return 1;
   IRRL_LAUNCH(h, irrl_step_kernel, lane_grid(h, h->P.n_envs), h->P, h->S, action, ob, reward, done, extra);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -263,18 +282,21 @@ int irrl_env_test_step_host(irrl_env *h, const float *action, float *ob, float *
 
 int irrl_env_reset(irrl_env *h, float *ob) {
   if (need_init(h)) return 1;
+  if (use_device(h)) return 1;
   IRRL_LAUNCH(h, irrl_reset_kernel, lane_grid(h, h->P.n_envs), h->P, h->S, ob);
   HIP_TRY(hipGetLastError());
   return 0;
 }
 int irrl_env_observe(irrl_env *h, float *ob) {
   if (need_init(h)) return 1;
+  if (use_device(h)) return 1;
   IRRL_LAUNCH(h, irrl_observe_kernel, lane_grid(h, h->P.n_envs), h->P, h->S, ob);
   HIP_TRY(hipGetLastError());
   return 0;
 }
 int irrl_env_is_terminal(irrl_env *h, uint8_t *done) {
   if (need_init(h)) return 1;
+  if (use_device(h)) return 1;
   hipLaunchKernelGGL(irrl_terminal_kernel, dim3((unsigned)((h->P.n_envs + 255) / 256)), dim3(256), 0, h->stream, h->P, h->S, done);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -415,6 +437,24 @@ int irrl_env_heightfield_host(irrl_env *h, float *out, int *nx, int *ny) {
   if (out) std::memcpy(out, h->h_height.data(), h->h_height.size() * sizeof(float));
   return 0;
 }
+// diagnostic counters summed over the pool: out[0] = episodes started (init + every reset), out[1] = toe-substeps spent in
+// the contact list, out[2] = control steps since the last reset summed over the envs (frame_idx)
+int irrl_env_counters_host(irrl_env *h, unsigned long long *out) {
+  if (need_init(h)) return 1;
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t n = (size_t)h->P.n_envs;
+  std::vector<uint32_t> ep(n), cc(n * 4);
+  std::vector<int32_t> fr(n);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(ep.data(), h->S.episode, n * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(cc.data(), h->d_counters, n * 16, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(fr.data(), h->S.frame_idx, n * 4, hipMemcpyDeviceToHost));
+  unsigned long long a = 0, b = 0, c = 0;
+  for (size_t i = 0; i < n; i++) { a += ep[i]; c += (unsigned long long)fr[i]; }
+  for (size_t i = 0; i < n * 4; i++) b += cc[i];
+  out[0] = a; out[1] = b; out[2] = c;
+  return 0;
+}
 double irrl_env_cfg_value(const irrl_env *h, const char *key) {
   double d = NAN;
   std::string e;
@@ -433,6 +473,45 @@ __global__ void irrl_calib_copy_kernel(const float *__restrict__ src, float *__r
 }
 int irrl_calib_copy_dword(const float *src, float *dst, size_t n, void *hip_stream) {
   hipLaunchKernelGGL(irrl_calib_copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, src, dst, n);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ---- synthetic action stream of the benchmark: a = clip(sigma * N(0,1), -1, 1) from Philox4x32-10 keyed
+// (seed, 'ACT1'), counter (env, step, block, 0): block j of (env, step) gives actions 4j .. 4j+3 by Box-Muller on the
+// uniform pairs (u0,u1) -> (cos, sin), (u2,u3) -> (cos, sin).  Rows are [step - step0][env - env0][12].
+__global__ void irrl_bench_actions_kernel(unsigned seed, int env0, int n_envs, long long step0, int n_steps, float sigma, float *__restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)n_steps * n_envs * 3;
+  if (i >= total) return;
+  const int j = (int)(i % 3);
+  const size_t se = i / 3;
+  const int e = (int)(se % (size_t)n_envs);
+  const long long s = step0 + (long long)(se / (size_t)n_envs);
+  unsigned c0 = (unsigned)(env0 + e), c1 = (unsigned)s, c2 = (unsigned)j, c3 = 0u;
+  unsigned k0 = seed, k1 = 0x41435431u;
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    const unsigned hi0 = __umulhi(c0, 0xD2511F53u), lo0 = c0 * 0xD2511F53u;
+    const unsigned hi1 = __umulhi(c2, 0xCD9E8D57u), lo1 = c2 * 0xCD9E8D57u;
+    const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  const float sc = 1.0f / 16777216.0f;
+  const float u0 = (float)(c0 >> 8) * sc, u1 = (float)(c1 >> 8) * sc, u2 = (float)(c2 >> 8) * sc, u3 = (float)(c3 >> 8) * sc;
+  const float ra = sqrtf(-2.0f * logf(1.0f - u0)), rb = sqrtf(-2.0f * logf(1.0f - u2));
+  const float aa = 6.283185307179586f * u1, ab = 6.283185307179586f * u3;
+  float z[4] = {ra * cosf(aa), ra * sinf(aa), rb * cosf(ab), rb * sinf(ab)};
+  float *o = out + se * 12 + 4 * j;
+#pragma unroll
+  for (int k = 0; k < 4; k++) o[k] = fminf(fmaxf(sigma * z[k], -1.0f), 1.0f);
+}
+int irrl_bench_actions(unsigned seed, int env0, int n_envs, long long step0, int n_steps, float sigma, float *out, void *hip_stream) {
+  if (n_envs <= 0 || n_steps <= 0 || !out) { g_err = "irrl_bench_actions: empty request"; return 1; }
+  const size_t total = (size_t)n_steps * n_envs * 3;
+  hipLaunchKernelGGL(irrl_bench_actions_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, seed, env0, n_envs, step0,
+                     n_steps, sigma, out);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -47,6 +47,7 @@ struct StatePool {
     S.frame_idx = (int32_t *)(b + off[15]); S.episode = (uint32_t *)(b + off[16]); S.up_height = (float *)(b + off[17]);
     S.material = (float *)(b + off[18]); S.mass = (float *)(b + off[19]); S.com = (float *)(b + off[20]);
     S.thigh_dz = (float *)(b + off[21]); S.ob = (float *)(b + off[22]); S.ob_last = (float *)(b + off[23]);
+    S.contact_count = nullptr;   // diagnostic, allocated separately by the C-ABI
     return S;
   }
   // host mirror -> flat [n, 288] doubles

@@ -239,5 +239,11 @@ class FlexibleGymEnv(object):
         _lib.check(self._lib.irrl_env_heightfield_host(self._h, out.ctypes.data_as(_fp), C.byref(nx), C.byref(ny)))
         return out
 
+    def counters(self):
+        """(episodes started, toe-substeps in contact, sum of frame_idx) summed over the pool -- diagnostic, synchronises."""
+        out = (C.c_ulonglong * 3)()
+        _lib.check(self._lib.irrl_env_counters_host(self._h, out))
+        return int(out[0]), int(out[1]), int(out[2])
+
     def cfg_value(self, key):
         return self._lib.irrl_env_cfg_value(self._h, key.encode())

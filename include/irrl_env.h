@@ -118,6 +118,11 @@ int irrl_env_set_ref_host(irrl_env *h, const float *table, int rows, int cols);
 /* the shared height field of a `Terrain: True` pool (Environment.hpp:254-264), [nx, ny] row-major f32; out may be NULL
  * to query the shape only; returns non-zero on flat ground */
 int irrl_env_heightfield_host(irrl_env *h, float *out, int *nx, int *ny);
+/* diagnostic counters summed over the pool (the role of the per-env members itera / contact list sizes a reference user would
+ * print, Environment.hpp:554, 1199-1243): out[0] = episodes started (init + every reset), out[1] = toe-substeps spent in the
+ * contact list since create(), out[2] = sum of frame_idx.  Synchronises the pool's stream.  bench.py differences them around
+ * its timed region to show the region was not free flight. */
+int irrl_env_counters_host(irrl_env *h, unsigned long long *out);
 /* value of a numeric/bool config key as parsed by the library (tests the YAML reader); NaN if absent */
 double irrl_env_cfg_value(const irrl_env *h, const char *key);
 
@@ -135,6 +140,11 @@ int irrl_gae(int T, int N, const float *rewards, const float *values, const uint
 int irrl_ppo_loss(size_t M, int act_dim, const float *mean, const float *logstd, const float *vpred, const float *actions,
                   const float *returns, const float *old_values, const float *old_neglogp, const float *adv_stats, float cliprange,
                   float vf_coef, float *d_mean, float *d_vpred, float *partials, int n_blocks, void *hip_stream);
+
+/* synthetic action stream of the benchmark (a = clip(sigma N(0,1), -1, 1) from Philox(seed, stream = env,
+ * counter = step)): fills out[n_steps][n_envs][12] (device) for envs env0 .. and steps step0 ..; values depend only on
+ * (seed, global env id, step), not on the shape of the request.  tests/ hold the numpy twin. */
+int irrl_bench_actions(unsigned seed, int env0, int n_envs, long long step0, int n_steps, float sigma, float *out, void *hip_stream);
 
 /* PMC calibration helper: copies n floats with one dword per lane (the env kernels' access width) so that
  * FETCH_SIZE / WRITE_SIZE can be calibrated on a known byte count (MI355X_MICROARCH.md, HBM section). */

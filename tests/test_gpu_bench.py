@@ -1,0 +1,83 @@
+"""Measurement harness on the MI355X: the device action generator against its numpy twin, the kernels' diagnostic counters,
+and `bench.py --gpus 2` launching two ranks by itself (both on cuda:0 over gloo: IRRL_BENCH_ONE_DEVICE / IRRL_BENCH_BACKEND),
+with the PPO leg's gradient all-reduce in the loop."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from conftest import ROOT, load_env_cfg
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def test_device_action_stream_matches_the_numpy_twin():
+    import torch
+    from bench_actions import bench_actions
+    from high_speed_quadrupedal_locomotion_by_irrl_amd import _lib
+    lib = _lib.load()
+    out = torch.empty(7, 300, 12, device="cuda")
+    _lib.check(lib.irrl_bench_actions(1, 4096, 300, 5, 7, 0.3, C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    want = bench_actions(1, 4096, 300, 5, 7, 0.3)
+    np.testing.assert_allclose(out.cpu().numpy(), want, atol=2e-6)
+
+
+def test_counters_see_landing_and_resets():
+    from hip_env import HipVecEnv
+    n = 64
+    env = HipVecEnv(load_env_cfg("bp5_imitation.yaml", num_envs=n))
+    ep0, cc0, fr0 = env.impl.counters()
+    assert (ep0, cc0, fr0) == (n, 0, n)                      # one episode per env, nothing has touched the ground, frame_idx = 1
+    a = np.zeros((n, 12), np.float32)
+    for _ in range(30):                                      # 4 cm of free fall take ~46 control steps
+        env.step(a)
+    assert env.impl.counters()[1] == 0
+    for _ in range(70):
+        env.step(a)
+    ep1, cc1, fr1 = env.impl.counters()
+    inc = env.get_state()[:, 147:151]
+    assert cc1 > 0 and cc1 <= 4 * 8 * n * 70 and inc.sum() > 0
+    # one more step: the counter grows by at least the feet that stay down for all 8 substeps and at most by 8 per toe
+    env.step(a)
+    cc2 = env.impl.counters()[1]
+    assert 0 < cc2 - cc1 <= 8 * 4 * n
+    st = env.get_state()
+    st[:5, 2] = 0.1                                           # below the termination height: five in-step resets
+    env.set_state(st)
+    env.step(a)
+    assert env.impl.counters()[0] == ep1 + 5
+
+
+def _run_bench(extra, env_over):
+    env = dict(os.environ)
+    env.update(env_over)
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_line_is_steady_state():
+    out = _run_bench(["--steps", "20", "--warmup", "5", "--ppo-iters", "0", "--cpu-seconds", "0", "--check-steps", "200"], {})
+    assert out["n_gpus"] == 1 and out["steps"] == 20 and out["warmup"] == 5
+    assert out["contact_fraction_in_timed_region"] > 0.3 and out["resets_in_timed_region"] > 0
+    assert out["config"]["preroll"] >= 200
+    # the 20-step timed region and the 200-step check window measure the same regime
+    assert abs(out["roofline"]["avg_launch_us"] - out["steady_state_check"]["us_per_step"]) < 0.25 * out["steady_state_check"]["us_per_step"]
+
+
+def test_bench_gpus_2_runs_two_ranks_with_the_ppo_collectives():
+    out = _run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--envs", "512", "--cpu-seconds", "0", "--check-steps", "0",
+                      "--ppo-iters", "1", "--ppo-steps", "32", "--ppo-epochs", "2"],
+                     {"IRRL_BENCH_BACKEND": "gloo", "IRRL_BENCH_ONE_DEVICE": "1"})
+    assert out["n_gpus"] == 2 and out["rccl_ranks_seen"] == 2 and out["config"]["global_envs"] == 1024
+    assert out["ppo"]["world"] == 2 and out["ppo"]["global_envs"] == 1024 and out["ppo"]["ppo_iters_per_sec"] > 0

@@ -246,3 +246,63 @@ def test_trained_policy_closed_loop_statistics_match_the_oracle():
     assert abs(sc["reward"] - so["reward"]) < 0.01 * abs(so["reward"])       # measured: 0.733741 vs 0.733722
     assert abs(sc["speed"] - so["speed"]) < 0.01 * so["speed"]               # measured: 1.282898 vs 1.282887 m/s
     assert so["terminations"] <= 2 and sc["terminations"] <= 2
+
+
+def test_diagnostic_getters_match_the_oracle_values():
+    """(f)3: OriginState [N,41] = gc | gv | contact flags (ENV:1317-1334), GetJointEffort / GetGeneralizedForce (ENV:1351-1371)
+    after teacher-forced steps from common states -- values, not shapes."""
+    n = 48
+    orc, cand = _pair(load_env_cfg("default_cfg.yaml", num_envs=n))
+    rng = np.random.RandomState(4)
+    for k in range(60):                      # land first (free flight until ~step 46), then compare with feet on the ground
+        orc.step(PL.random_actions(rng, n, 0.4))
+    for k in range(6):
+        st = PL.f32_round_state(orc.get_state())
+        orc.set_state(st)
+        cand.set_state(st)
+        a = PL.random_actions(rng, n, 0.4)
+        orc.step(a)
+        cand.step(a)
+        os_o = orc.origin_state()
+        os_c = np.zeros((n, 41), np.float32)
+        cand.impl.OriginState(os_c)
+        same = np.all(os_o[:, 37:] == os_c[:, 37:], axis=1)                  # contact flags: exact except for threshold envs
+        assert same.mean() > 0.95 and os_o[:, 37:].sum() > n                    # and the feet really are on the ground
+        np.testing.assert_allclose(os_c[same, 0:19], os_o[same, 0:19], atol=10 * PL.TOL_STEP["pos"])
+        np.testing.assert_allclose(os_c[same, 19:37], os_o[same, 19:37], atol=10 * PL.TOL_STEP["vel"])
+        je_c, gf_c = np.zeros((n, 12), np.float32), np.zeros((n, 18), np.float32)
+        cand.impl.GetJointEffort(je_c)
+        cand.impl.GetGeneralizedForce(gf_c)
+        je_o, gf_o = orc.joint_effort(), orc.generalized_force()
+        assert np.abs(je_o).max() > 1.0                                         # real torques (N m), not zeros
+        np.testing.assert_allclose(je_c[same], je_o[same], atol=2e-2)            # kp 40 x joint angle error 2e-5 + kd x 5e-3
+        np.testing.assert_allclose(gf_c[same], gf_o[same], atol=2e-2)
+        np.testing.assert_array_equal(gf_c[:, 6:], je_c)
+
+
+def test_set_contact_coefficient_changes_the_cone_and_follows_the_oracle():
+    """(f)3: SetContactCoefficient (ENV:1407-1418) installs (mu, restitution, threshold) per env: the same material in the
+    oracle gives the same trajectories, the stored impulses obey the NEW cone, and slippery robots slide further."""
+    n = 32
+    cfg = load_env_cfg("bp5_imitation.yaml", num_envs=n)
+    orc, cand = _pair(cfg)
+    coeff = np.zeros((n, 3), np.float32)
+    coeff[:, 0] = np.where(np.arange(n) % 2 == 0, 0.05, 0.9)   # ice under the even robots
+    coeff[:, 1] = 0.1
+    coeff[:, 2] = 0.5
+    orc.set_contact_coeff(coeff)
+    cand.impl.SetContactCoefficient(coeff)
+    np.testing.assert_allclose(cand.get_state()[:, PL.S["MATERIAL"]:PL.S["MATERIAL"] + 3], coeff, atol=0)
+    rng = np.random.RandomState(8)
+    for _ in range(70):
+        orc.step(PL.random_actions(rng, n, 0.5))
+    st = PL.f32_round_state(orc.get_state())
+    cand.set_state(st)
+    orc.set_state(st)
+    worst, _ = PL.check_teacher_forced(orc, cand, steps=30, seed=12)
+    st = cand.get_state()
+    lam = st[:, PL.S["LAMW"]:PL.S["LAMW"] + 12].reshape(n, 4, 3)
+    ft = np.linalg.norm(lam[:, :, :2], axis=2)
+    assert (lam[:, :, 2] > 0).sum() > n                                              # feet on the ground
+    assert np.all(ft <= coeff[:, 0:1] * lam[:, :, 2] * (1 + 1e-4) + 1e-6)            # the NEW Coulomb cone, per env
+    assert np.any(ft[1::2] > 0.05 * lam[1::2, :, 2] * 1.5)                           # grippy robots do use more than mu = 0.05

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def measure(policy="lstm", envs=4096, steps=750, iters=3, epochs=10, cfg_name="default_cfg.yaml", verbose=True):
+def measure(policy="lstm", envs=4096, steps=750, iters=3, epochs=10, cfg_name="default_cfg.yaml", verbose=True, rank=0):
     """Runs `iters` PPO iterations (the first one also captures the rollout graph and warms the allocator) and returns
     the mean rollout / update time of the others."""
     import torch
@@ -24,6 +24,7 @@ def measure(policy="lstm", envs=4096, steps=750, iters=3, epochs=10, cfg_name="d
     from high_speed_quadrupedal_locomotion_by_irrl_amd.vec_env import TorchVecEnv
     cfg = yaml.safe_load(open(os.path.join(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY__, cfg_name)))["environment"]
     cfg["num_envs"] = envs
+    cfg["seedd"] = int(cfg.get("seedd", 1)) + 7919 * rank   # different robots on every rank of a multi-GPU run
     env = TorchVecEnv(FlexibleGymEnv(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY__, yaml.safe_dump(cfg)))
     lstm = policy == "lstm"
     model = PPO2(policy=CustomLSTMPolicy if lstm else MlpPolicy, env=env, gamma=0.99, n_steps=steps, ent_coef=0.0, learning_rate=1e-3,
