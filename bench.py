@@ -58,6 +58,7 @@ def parse_args(argv=None):
     ap.add_argument("--ppo-iters", type=int, default=2, help="timed PPO iterations of the LSTM policy (0 disables)")
     ap.add_argument("--ppo-steps", type=int, default=750, help="rollout length of the PPO leg (the metric's is 750)")
     ap.add_argument("--ppo-epochs", type=int, default=10, help="optimisation epochs of the PPO leg (the metric's is 10)")
+    ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch the timed steps one by one from Python instead of as one hipGraph")
     ap.add_argument("--check-steps", type=int, default=2000, help="extra untimed-for-`value` window after the timed region that "
                     "re-measures us/step over a longer run (0 disables); reported as `steady_state_check`")
     return ap.parse_args(argv)
@@ -222,22 +223,42 @@ def worker(args):
     run(preroll)                 # untimed, unconditional: robots land and the contact set becomes stationary
     run(args.warmup)
     torch.cuda.synchronize()
-    c0 = env.counters()
+    # The K timed steps are ONE hipGraph of K step-kernel nodes (action row = launch argument), the way the PPO rollout runs
+    # them (ppo2.Runner): no per-step host launch latency inside the bracket, so a 20-step window measures the kernel and not
+    # the Python call path.  Capturing records the launches without executing them.
+    graph = None
+    if args.graph and args.steps <= 20000:
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        s_keep = cursor[0]
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            run(args.steps)
+        cursor[0] = s_keep
+        torch.cuda.synchronize()
+    # the kernels' counters are summed on the device, stream-ordered: no read-back (idle GPU) right before the timed region
+    cnt0, cnt1 = torch.zeros(3, dtype=torch.int64, device=dev), torch.zeros(3, dtype=torch.int64, device=dev)
+    env.counters_into(cnt0)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    run(args.steps)
+    if graph is not None:
+        graph.replay()
+        cursor[0] += args.steps
+    else:
+        run(args.steps)
     ev1.record()
+    env.counters_into(cnt1)      # one 256-thread launch behind the closing event: outside the HIP-event window, ~2 us of the wall-clock one
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps   # events on the stream the kernel is launched on
-    c1 = env.counters()
+    c0, c1 = cnt0.tolist(), cnt1.tolist()
     resets = c1[0] - c0[0]
     contact_fraction = (c1[1] - c0[1]) / float(4 * loop_count * n * args.steps)
     if dist is not None:
@@ -293,7 +314,8 @@ def worker(args):
                                    "termination + in-step reset), cfg %s, actions clip(0.3 N(0,1)) from Philox(seed 1, stream env, counter step), "
                                    "%d-step untimed pre-roll before the warm-up" % (n, args.cfg, preroll),
                        "envs_per_gpu": n, "global_envs": n * world, "parallelism": "env-sharded x%d" % world,
-                       "lanes_per_robot": env.lanes_per_robot, "preroll": preroll},
+                       "lanes_per_robot": env.lanes_per_robot, "preroll": preroll,
+                       "launch": "one hipGraph of %d step-kernel nodes" % args.steps if graph is not None else "one launch per step from the host"},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "irrl_step_kernel_l%d" % env.lanes_per_robot, "avg_launch_us": kernel_ms * 1e3,

@@ -579,6 +579,140 @@ IRRL_DEV void terrain_sample(const EnvParams &P, vf x, vf y, vf &h, v3 &n) {
   n = mk3(-dhdx * inv, -dhdy * inv, inv);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Trunk collision box (URDF:26: 0.3 x 0.2 x 0.1 centred on the base origin; collision body "body/0", ENV:242): its eight
+// corners are point contacts against the same ground and material as the toes.  Corner b: x = +-0.15 (bit 2 set: -),
+// y = +-0.1 (bit 1 set: -), z = -+0.05 (bit 0 set: +) -- the oracle's numbering.  A corner only reaches the ground while
+// the robot is falling over (the episode ends at z < 0.15 m or 60 degrees of tilt) or on rough terrain, so everything
+// here sits behind wave-uniform tests and is written for clarity, not speed.  Each corner is OWNED by one lane of the
+// robot (16 lanes: leg quad (b >> 1), sub-lane (b & 1); 4 lanes: lane (b >> 1), slot (b & 1)); the Gauss-Seidel order is
+// toes FR..HL, then corners 0..7; corner impulses are not warm-started.  Contacts couple through the base only:
+// Y_c = L^-1 Jb_c^T, and everything the corners exchange with the toes is the 6-vector z = sum Y^T lambda.
+// ---------------------------------------------------------------------------------------------
+#ifdef IRRL_L16
+#define IRRL_NCPL 1
+IRRL_DEV vf robot_sum(vf x) { return legs_sum(sub_sum(x)); }
+IRRL_DEV vi box_corner_id(int) { return leg_id() * 2 + (sub_id() & 1); }
+IRRL_DEV vm box_corner_owner() { return sub_id() < 2; }
+#else
+#define IRRL_NCPL 2
+IRRL_DEV vf robot_sum(vf x) { return legs_sum(x); }
+IRRL_DEV vi box_corner_id(int j) { return leg_id() * 2 + j; }
+IRRL_DEV vm box_corner_owner() { return vm(true); }
+#endif
+#define IRRL_BOX_HX 0.15f
+#define IRRL_BOX_HY 0.1f
+#define IRRL_BOX_HZ 0.05f
+
+struct BoxContacts {
+  vi id[IRRL_NCPL];
+  vm own[IRRL_NCPL];          // slot j of this lane holds an ACTIVE corner that this lane owns
+  vf Y[IRRL_NCPL][3][6];      // rows of K L^-T, K = [1 | -[x]x]
+  ContactBlock CB[IRRL_NCPL];
+  v3 n[IRRL_NCPL], cfree[IRRL_NCPL], lam[IRRL_NCPL];
+  vf vstar[IRRL_NCPL];
+  vf zc[6];                   // sum over the robot's corners of Y^T lambda (same value in all its lanes)
+};
+// cheap wave-level pre-test: can any corner of this robot be at or below the highest ground?
+IRRL_DEV vm box_near_ground(const EnvParams &P, vf pos_z, v3 r2) {
+  vf ext = IRRL_BOX_HX * v_abs(r2.x) + IRRL_BOX_HY * v_abs(r2.y) + IRRL_BOX_HZ * v_abs(r2.z);
+  return pos_z - ext <= P.hf_max;
+}
+// detection + per-corner operators.  ub: free base velocity (after dt M^-1 (tau - b)), vB / wB: base velocity before the substep.
+IRRL_DEV bool box_setup(const EnvParams &P, const EnvLane &L, const rot3 &R, const vf L6[21], const vf ub[6], v3 vB, v3 wB, BoxContacts &B) {
+  bool any = false;
+  const vm owner = box_corner_owner();
+#pragma unroll
+  for (int i = 0; i < 6; i++) B.zc[i] = 0.0f;
+#pragma unroll
+  for (int j = 0; j < IRRL_NCPL; j++) {
+    const vi b = box_corner_id(j);
+    B.id[j] = b;
+    v3 x = mk3(vsel((b & 4) != 0, -IRRL_BOX_HX, IRRL_BOX_HX), vsel((b & 2) != 0, -IRRL_BOX_HY, IRRL_BOX_HY), vsel((b & 1) != 0, IRRL_BOX_HZ, -IRRL_BOX_HZ));
+    v3 cw = rot_mul(R, x);
+    vf hgt = 0.0f;
+    v3 nw = mk3(0.0f, 0.0f, 1.0f);
+    if (P.terrain) terrain_sample(P, L.pos.x + cw.x, L.pos.y + cw.y, hgt, nw);
+    vf gap = (L.pos.z + cw.z - hgt) * nw.z;
+    B.own[j] = owner & (gap <= 0.0f);
+    B.n[j] = rot_tmul(R, nw);
+    B.lam[j] = mk3(0.0f, 0.0f, 0.0f);
+    if (!wave_any(B.own[j])) {
+      B.own[j] = vm(false);
+      B.vstar[j] = 0.0f; B.cfree[j] = mk3(0.0f, 0.0f, 0.0f);
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int i = 0; i < 6; i++) B.Y[j][r][i] = 0.0f;
+      sym3 I; I.xx = 1.0f; I.xy = 0.0f; I.xz = 0.0f; I.yy = 1.0f; I.yz = 0.0f; I.zz = 1.0f;
+      B.CB[j] = make_contact_block(I, B.n[j]);
+      continue;
+    }
+    any = true;
+    // rows of [1 | -[x]x], then Y row = L^-1 (row)^T
+    const vf z0 = 0.0f, o1 = 1.0f;
+    vf K[3][6] = {{o1, z0, z0, z0, x.z, -x.y}, {z0, o1, z0, -x.z, z0, x.x}, {z0, z0, o1, x.y, -x.x, z0}};
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) B.Y[j][r][i] = K[r][i];
+      l6_fwd(L6, B.Y[j][r]);
+    }
+    sym3 G;
+    vf g[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = r; c < 3; c++) {
+        vf acc = B.Y[j][r][0] * B.Y[j][c][0];
+#pragma unroll
+        for (int i = 1; i < 6; i++) acc += B.Y[j][r][i] * B.Y[j][c][i];
+        g[r][c] = acc;
+      }
+    G.xx = g[0][0]; G.xy = g[0][1]; G.xz = g[0][2]; G.yy = g[1][1]; G.yz = g[1][2]; G.zz = g[2][2];
+    B.CB[j] = make_contact_block(G, B.n[j]);
+    v3 vpre = vB + cross(wB, x);
+    B.cfree[j] = mk3(ub[0], ub[1], ub[2]) + cross(mk3(ub[3], ub[4], ub[5]), x);
+    vf vn = dot(vpre, B.n[j]);
+    B.vstar[j] = vsel(vn < -L.m.rest_thr, -L.m.rest * vn, 0.0f);
+  }
+  return any;
+}
+// One Gauss-Seidel pass over the corners in the order 0..7.  zt: sum over the toes of Y^T lambda (replicated).  Adds this
+// pass's |dlambda|^2 to d2 (replicated over the robot's lanes); updates B.lam and B.zc.
+IRRL_DEV void box_sweep(BoxContacts &B, const vf zt[6], vf mu, vf &d2) {
+  vf dd = 0.0f;
+#pragma unroll
+  for (int b = 0; b < 8; b++) {
+    const int j = (IRRL_NCPL == 2) ? (b & 1) : 0;
+    const vm mine = B.own[j] & (B.id[j] == b);
+    if (!wave_any(mine)) continue;
+    // velocity at the corner without its own impulse: cfree + Y (zt + zc) - G lam_own
+    vf zs[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) zs[i] = zt[i] + B.zc[i];
+    v3 own = mul(B.CB[j].G, B.lam[j]);
+    v3 c = B.cfree[j] - own;
+#pragma unroll
+    for (int i = 0; i < 6; i++) { c.x += B.Y[j][0][i] * zs[i]; c.y += B.Y[j][1][i] * zs[i]; c.z += B.Y[j][2][i] * zs[i]; }
+    v3 ln = solve_contact(B.CB[j], c, B.n[j], B.vstar[j], mu, mine);
+    v3 dl = mk3(vsel(mine, ln.x - B.lam[j].x, 0.0f), vsel(mine, ln.y - B.lam[j].y, 0.0f), vsel(mine, ln.z - B.lam[j].z, 0.0f));
+    B.lam[j] = B.lam[j] + dl;
+    dd += dot(dl, dl);
+    // only the owner holds a non-zero dl, so the sum over the robot's lanes is a broadcast of Y^T dl
+#pragma unroll
+    for (int i = 0; i < 6; i++) B.zc[i] += robot_sum(B.Y[j][0][i] * dl.x + B.Y[j][1][i] * dl.y + B.Y[j][2][i] * dl.z);
+  }
+  d2 += robot_sum(dd);
+}
+IRRL_DEV vf box_lam2(const BoxContacts &B) {
+  vf s = 0.0f;
+#pragma unroll
+  for (int j = 0; j < IRRL_NCPL; j++) s += vsel(B.own[j], dot(B.lam[j], B.lam[j]), 0.0f);
+  return robot_sum(s);
+}
+
 // ---------------------------------------------------------------------------------------------
 // one physics substep (ENV:761-768): PD + clamp, then the build's integrate()
 // ---------------------------------------------------------------------------------------------
@@ -790,7 +924,8 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
   // ---- contact: toe sphere against the ground ----
   vf gap = (L.pos.z + dot(R.r2, k.ptoe) - hgt) * nwz - IRRL_TOE_RADIUS;
   vm active = gap <= 0.0f;
-  if (wave_any(active)) {
+  const bool box_near = wave_any(box_near_ground(P, L.pos.z, R.r2));
+  if (wave_any(active) || box_near) {
     v3 x = k.ptoe - IRRL_TOE_RADIUS * nB;
     // (D) column `sub` of the leg Jacobian, then all of it (R)
     v3 jc = live * cross(ax, x - p_s);
@@ -861,10 +996,15 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     vi rank = vsel_i(leg == 0, 0, vsel_i(leg == 1, a0i, vsel_i(leg == 2, a0i + a1i, a0i + a1i + a2i)));
     int nrank = wave_max_small(a0i + a1i + a2i + a3i);
     const float tol2 = P.contact_tol * P.contact_tol;
+    // trunk-box corners (rare: falling robots, rough terrain)
+    BoxContacts BX;
+    bool has_box = false;
+    if (box_near) has_box = box_setup(P, L, R, D.L6, ub, vB, wB, BX);
+    vf cz_r = 0.0f;   // row r of Y_toe . zc: what the corner impulses add to this toe's velocity
     for (int it = 0; it < P.contact_iters; it++) {
       vf d2 = 0.0f;
       for (int rk = 0; rk < nrank; rk++) {
-        vf cvr = cfree_r;
+        vf cvr = cfree_r + cz_r;
         {
           vf bx = legs_rot<1>(lam.x), by = legs_rot<1>(lam.y), bz = legs_rot<1>(lam.z);
           cvr += gx1[0] * bx + gx1[1] * by + gx1[2] * bz;
@@ -884,9 +1024,21 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
         lam = lam + dl;
         d2 += dot(dl, dl);
       }
+      vf d2b = 0.0f, l2b = 0.0f;
+      if (has_box) {
+        const vf lam_t = live * PICK3(vsel(active, lam.x, 0.0f), vsel(active, lam.y, 0.0f), vsel(active, lam.z, 0.0f));
+        vf zt[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) zt[i] = robot_sum(Yr[i] * lam_t);
+        box_sweep(BX, zt, L.m.mu, d2b);
+        l2b = box_lam2(BX);
+        cz_r = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 6; i++) cz_r += Yr[i] * BX.zc[i];
+      }
       if (tol2 > 0.0f) {
-        vf l2 = legs_sum(vsel(active, dot(lam, lam), 0.0f));
-        vm unconverged = legs_sum(d2) > tol2 * l2 + 1e-20f;
+        vf l2 = legs_sum(vsel(active, dot(lam, lam), 0.0f)) + l2b;
+        vm unconverged = legs_sum(d2) + d2b > tol2 * l2 + 1e-20f;
         if (!wave_any(unconverged)) break;
       }
     }
@@ -897,6 +1049,10 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     vf xbc[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) xbc[i] = legs_sum(sub_sum(Yr[i] * lam_r));
+    if (has_box) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) xbc[i] += BX.zc[i];
+    }
     l6_bwd(D.L6, xbc);
 #pragma unroll
     for (int i = 0; i < 6; i++) ub[i] += xbc[i];
@@ -982,7 +1138,8 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
   // sphere against the locally planar ground: centre-to-tangent-plane distance minus the radius
   vf gap = (L.pos.z + dot(R.r2, k.ptoe) - hgt) * nwz - IRRL_TOE_RADIUS;
   vm active = gap <= 0.0f;
-  if (wave_any(active)) {
+  const bool box_near = wave_any(box_near_ground(P, L.pos.z, R.r2));
+  if (wave_any(active) || box_near) {
     v3 x = k.ptoe - IRRL_TOE_RADIUS * nB;
     // leg columns of the contact Jacobian
     v3 jA = cross(mk3(1.0f, 0.0f, 0.0f), x - k.pA), jT = cross(k.h, x - k.pT), jS = cross(k.h, x - k.pS);
@@ -1059,11 +1216,16 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     vi rank = vsel_i(leg == 0, 0, vsel_i(leg == 1, a0i, vsel_i(leg == 2, a0i + a1i, a0i + a1i + a2i)));
     int nrank = wave_max_small(legs_sum_i(act_i));
     const float tol2 = P.contact_tol * P.contact_tol;
+    // trunk-box corners (rare: falling robots, rough terrain)
+    BoxContacts BX;
+    bool has_box = false;
+    if (box_near) has_box = box_setup(P, L, R, D.L6, ub, vB, wB, BX);
+    v3 cz = mk3(0.0f, 0.0f, 0.0f);   // Y_toe . zc: what the corner impulses add to this toe's velocity
     for (int it = 0; it < P.contact_iters; it++) {
       vf d2 = 0.0f;
       for (int rk = 0; rk < nrank; rk++) {
         // velocity at this contact without its own impulse: cfree + sum_{l' != l} G_ll' lam_l'
-        v3 cv = mk3(cfree[0], cfree[1], cfree[2]);
+        v3 cv = mk3(cfree[0], cfree[1], cfree[2]) + cz;
 #define IRRL_GX_APPLY(LP)                                                                       \
         {                                                                                       \
           vf bx = legs_bcast<LP>(lam.x), by = legs_bcast<LP>(lam.y), bz = legs_bcast<LP>(lam.z); \
@@ -1079,10 +1241,22 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
         lam = lam + dl;
         d2 += dot(dl, dl);
       }
+      vf d2b = 0.0f, l2b = 0.0f;
+      if (has_box) {
+        const v3 la = mk3(vsel(active, lam.x, 0.0f), vsel(active, lam.y, 0.0f), vsel(active, lam.z, 0.0f));
+        vf zt[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) zt[i] = robot_sum(Y[0][i] * la.x + Y[1][i] * la.y + Y[2][i] * la.z);
+        box_sweep(BX, zt, L.m.mu, d2b);
+        l2b = box_lam2(BX);
+        cz = mk3(0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (int i = 0; i < 6; i++) { cz.x += Y[0][i] * BX.zc[i]; cz.y += Y[1][i] * BX.zc[i]; cz.z += Y[2][i] * BX.zc[i]; }
+      }
       // build-defined early exit: every robot of the wave has sum |dlam|^2 <= tol^2 sum |lam|^2
       if (tol2 > 0.0f) {
-        vf l2 = legs_sum(vsel(active, dot(lam, lam), 0.0f));
-        vm unconverged = legs_sum(d2) > tol2 * l2 + 1e-20f;
+        vf l2 = legs_sum(vsel(active, dot(lam, lam), 0.0f)) + l2b;
+        vm unconverged = legs_sum(d2) + d2b > tol2 * l2 + 1e-20f;
         if (!wave_any(unconverged)) break;
       }
     }
@@ -1091,6 +1265,10 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     vf z[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) z[i] = legs_sum(Y[0][i] * lam.x + Y[1][i] * lam.y + Y[2][i] * lam.z);
+    if (has_box) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) z[i] += BX.zc[i];
+    }
     // velocity update: base part L^-T z, leg part C^-1 Jl^T lam - D xb
     vf xbc[6];
 #pragma unroll

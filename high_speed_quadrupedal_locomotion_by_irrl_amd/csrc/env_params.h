@@ -29,6 +29,7 @@ struct EnvParams {
   // height field (Terrain: True, Environment.hpp:254-264); height == nullptr / terrain == 0 means the plane z = 0
   int32_t terrain, hf_nx, hf_ny;
   float hf_x0, hf_y0, hf_inv_dx, hf_inv_dy;
+  float hf_max;            // highest sample of the height field (0 on the plane): pre-test of the trunk-box corner contacts
   const float *height;     // [hf_nx, hf_ny] row-major, shared by every robot of the pool
   // reference-trajectory mode (ManualTraj: False, Manual: False; Environment.hpp:17-21, 565-573, 972, 1100-1107, 1667-1671):
   // table [ref_rows, 30] f32 = theta 12 | theta_dot 12 | z | phase 2 | cmd 3, one row per control step

@@ -146,7 +146,7 @@ inline bool build_params(const Config &c, EnvParams &P, std::string &err) {
   if (crutial) { err = "Crutial: True (meteorite spheres, Environment.hpp:815-861) is not built in this engine"; return false; }
   P.terrain = terrain ? 1 : 0;  // the table itself is attached by the owner of the pool (irrl_terrain.hpp)
   P.hf_nx = 5000; P.hf_ny = 500;  // Environment.hpp:259-260
-  P.hf_x0 = -250.0f; P.hf_y0 = -10.0f;
+  P.hf_x0 = -250.0f; P.hf_y0 = -10.0f; P.hf_max = 0.0f;
   P.hf_inv_dx = (float)((5000 - 1) / 500.0); P.hf_inv_dy = (float)((500 - 1) / 20.0);
   P.height = nullptr;
   P.ref_traj = (!manual_traj && !P.manual) ? 1 : 0;   // table attached by the owner of the pool (RefTraj CSV or irrl_env_set_ref_host)

@@ -138,6 +138,9 @@ irrl_env *irrl_env_create(const char *resource_dir, const char *cfg_yaml, int de
     const size_t hb = h->h_height.size() * sizeof(float);
     ok = hipMalloc((void **)&h->d_height, hb) == hipSuccess && hipMemcpy(h->d_height, h->h_height.data(), hb, hipMemcpyHostToDevice) == hipSuccess;
     h->P.height = h->d_height;
+    float hmax = 0.0f;
+    for (float v : h->h_height) hmax = v > hmax ? v : hmax;
+    h->P.hf_max = hmax;
   }
   if (ok) {
     h->d_reward = h->d_ob + n * 35;
@@ -437,6 +440,28 @@ int irrl_env_heightfield_host(irrl_env *h, float *out, int *nx, int *ny) {
   if (out) std::memcpy(out, h->h_height.data(), h->h_height.size() * sizeof(float));
   return 0;
 }
+// stream-ordered variant: sums into d_out[3] (device, unsigned long long) on the pool's stream, no host synchronisation
+__global__ void irrl_counters_kernel(int n, const uint32_t *episode, const uint32_t *cc, const int32_t *frame, unsigned long long *out) {
+  __shared__ unsigned long long s[3][256];
+  unsigned long long a = 0, b = 0, c = 0;
+  for (int i = (int)threadIdx.x; i < n; i += 256) { a += episode[i]; c += (unsigned long long)frame[i]; }
+  for (int i = (int)threadIdx.x; i < 4 * n; i += 256) b += cc[i];
+  s[0][threadIdx.x] = a; s[1][threadIdx.x] = b; s[2][threadIdx.x] = c;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) { s[0][threadIdx.x] += s[0][threadIdx.x + w]; s[1][threadIdx.x] += s[1][threadIdx.x + w]; s[2][threadIdx.x] += s[2][threadIdx.x + w]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[0] = s[0][0]; out[1] = s[1][0]; out[2] = s[2][0]; }
+}
+int irrl_env_counters(irrl_env *h, unsigned long long *d_out) {
+  if (need_init(h)) return 1;
+  if (use_device(h)) return 1;
+  hipLaunchKernelGGL(irrl_counters_kernel, dim3(1), dim3(256), 0, h->stream, h->P.n_envs, (const uint32_t *)h->S.episode, (const uint32_t *)h->d_counters,
+                     (const int32_t *)h->S.frame_idx, d_out);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
 // diagnostic counters summed over the pool: out[0] = episodes started (init + every reset), out[1] = toe-substeps spent in
 // the contact list, out[2] = control steps since the last reset summed over the envs (frame_idx)
 int irrl_env_counters_host(irrl_env *h, unsigned long long *out) {
@@ -445,7 +470,7 @@ int irrl_env_counters_host(irrl_env *h, unsigned long long *out) {
   const size_t n = (size_t)h->P.n_envs;
   std::vector<uint32_t> ep(n), cc(n * 4);
   std::vector<int32_t> fr(n);
-  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipDeviceSynchronize());   // steps may have been replayed from a graph on another stream than h->stream
   HIP_TRY(hipMemcpy(ep.data(), h->S.episode, n * 4, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(cc.data(), h->d_counters, n * 16, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(fr.data(), h->S.frame_idx, n * 4, hipMemcpyDeviceToHost));

@@ -245,5 +245,11 @@ class FlexibleGymEnv(object):
         _lib.check(self._lib.irrl_env_counters_host(self._h, out))
         return int(out[0]), int(out[1]), int(out[2])
 
+    def counters_into(self, out):
+        """the same three sums written into `out` (CUDA int64 tensor of 3 elements), stream-ordered, no synchronisation"""
+        import torch
+        self._sync_stream()
+        _lib.check(self._lib.irrl_env_counters(self._h, _dev_ptr(out, (3,), (torch.int64,), "out")))
+
     def cfg_value(self, key):
         return self._lib.irrl_env_cfg_value(self._h, key.encode())

@@ -123,6 +123,8 @@ int irrl_env_heightfield_host(irrl_env *h, float *out, int *nx, int *ny);
  * contact list since create(), out[2] = sum of frame_idx.  Synchronises the pool's stream.  bench.py differences them around
  * its timed region to show the region was not free flight. */
 int irrl_env_counters_host(irrl_env *h, unsigned long long *out);
+/* the same three sums written to d_out[3] (device memory), stream-ordered on the pool's stream, no synchronisation */
+int irrl_env_counters(irrl_env *h, unsigned long long *d_out);
 /* value of a numeric/bool config key as parsed by the library (tests the YAML reader); NaN if absent */
 double irrl_env_cfg_value(const irrl_env *h, const char *key);
 

@@ -653,6 +653,7 @@ typedef struct {
   real extra[6];
   real gen_force[NV]; /* last generalized force handed to the integrator (world comps for the base) */
   long gs_sweeps, gs_substeps; /* statistics: contact sweeps executed / substeps */
+  long box_hits;               /* statistics: (trunk-box corner, substep) pairs in contact */
   robot_model model;
 } env_t;
 
@@ -962,52 +963,70 @@ static void physics_substep(orc_env *h, env_t *e, const real *pTarget) {
   real ufree[NV];
   for (int i = 0; i < NV; i++) ufree[i] = u[i] + dt * rhs[i];
 
-  /* contact detection + Jacobians */
-  int active[4];
-  real J[4][3][NV], MiJt[4][3][NV], G[4][4][9], cfree[4][3], vstar[4], lamB[4][3], nBl[4][3];
-  for (int l = 0; l < 4; l++) {
-    int s = 3 + 3 * l;
-    real off[3] = {RC(0), RC(0), RC(TOE_Z)}, xc[3], cw[3];
-    m3_mulv(xc, k.R[s], off);
-    v3_add(xc, xc, k.p[s]);
+  /* contact detection + Jacobians.  Contacts 0..3: the toe spheres; 4..11: the eight corners of the trunk's collision box
+   * (URDF:26 box 0.3 x 0.2 x 0.1 centred on the base origin, collision body "body/0" ENV:242) as points against the same
+   * ground with the same (default) material -- the ("steel","steel") pair of ENV:244 only concerns steel-steel pairs.
+   * Corner i: x = +-0.15 (bit 2 set: -), y = +-0.1 (bit 1 set: -), z = -+0.05 (bit 0 set: +).  Gauss-Seidel order: toes
+   * FR, FL, HR, HL, then corners 0..7.  Corner impulses are not warm-started (they are not part of the persisted state). */
+  enum { NC = 12 };
+  int active[NC];
+  real J[NC][3][NV], MiJt[NC][3][NV], cfree[NC][3], vstar[NC], lamB[NC][3], nBl[NC][3];
+  static const real box_half[3] = {RC(0.15), RC(0.1), RC(0.05)};
+  for (int ci = 0; ci < NC; ci++) {
+    real xc[3], cw[3], radius;
+    int l = ci, s = 3 + 3 * ci;
+    if (ci < 4) {
+      real off[3] = {RC(0), RC(0), RC(TOE_Z)};
+      m3_mulv(xc, k.R[s], off);
+      v3_add(xc, xc, k.p[s]);
+      radius = RC(TOE_RADIUS);
+    } else {
+      int b = ci - 4;
+      xc[0] = (b & 4) ? -box_half[0] : box_half[0];
+      xc[1] = (b & 2) ? -box_half[1] : box_half[1];
+      xc[2] = (b & 1) ? box_half[2] : -box_half[2];
+      radius = RC(0);
+    }
     m3_mulv(cw, R, xc);
-    /* sphere against the locally planar ground: distance of the centre to the tangent plane minus the radius */
+    /* sphere (or point) against the locally planar ground: distance of the centre to the tangent plane minus the radius */
     real hgt, nw[3];
     terrain_sample(h->height, e->gc[0] + cw[0], e->gc[1] + cw[1], &hgt, nw);
-    real gap = (e->gc[2] + cw[2] - hgt) * nw[2] - RC(TOE_RADIUS);
-    active[l] = (gap <= RC(0));
-    if (!active[l]) { v3_set(lamB[l], RC(0), RC(0), RC(0)); continue; }
-    real *nB = nBl[l];
+    real gap = (e->gc[2] + cw[2] - hgt) * nw[2] - radius;
+    active[ci] = (gap <= RC(0));
+    if (!active[ci]) { v3_set(lamB[ci], RC(0), RC(0), RC(0)); continue; }
+    real *nB = nBl[ci];
     m3_tmulv(nB, R, nw);
     real x[3];
-    for (int a = 0; a < 3; a++) x[a] = xc[a] - RC(TOE_RADIUS) * nB[a];
-    for (int r = 0; r < 3; r++) for (int cc = 0; cc < NV; cc++) J[l][r][cc] = RC(0);
-    for (int r = 0; r < 3; r++) J[l][r][r] = RC(1);
+    for (int a = 0; a < 3; a++) x[a] = xc[a] - radius * nB[a];
+    for (int r = 0; r < 3; r++) for (int cc = 0; cc < NV; cc++) J[ci][r][cc] = RC(0);
+    for (int r = 0; r < 3; r++) J[ci][r][r] = RC(1);
     /* -[x]x */
-    J[l][0][4] = x[2]; J[l][0][5] = -x[1];
-    J[l][1][3] = -x[2]; J[l][1][5] = x[0];
-    J[l][2][3] = x[1]; J[l][2][4] = -x[0];
-    for (int bdy = 1 + 3 * l; bdy <= s; bdy++) {
-      real d[3], col[3];
-      v3_sub(d, x, k.p[bdy]);
-      v3_cross(col, k.s[bdy], d);
-      for (int r = 0; r < 3; r++) J[l][r][6 + (bdy - 1)] = col[r];
-    }
+    J[ci][0][4] = x[2]; J[ci][0][5] = -x[1];
+    J[ci][1][3] = -x[2]; J[ci][1][5] = x[0];
+    J[ci][2][3] = x[1]; J[ci][2][4] = -x[0];
+    if (ci < 4)
+      for (int bdy = 1 + 3 * l; bdy <= s; bdy++) {
+        real d[3], col[3];
+        v3_sub(d, x, k.p[bdy]);
+        v3_cross(col, k.s[bdy], d);
+        for (int r = 0; r < 3; r++) J[ci][r][6 + (bdy - 1)] = col[r];
+      }
     real vpre[3];
     for (int r = 0; r < 3; r++) {
       real a1 = RC(0), a2 = RC(0);
-      for (int cc = 0; cc < NV; cc++) { a1 += J[l][r][cc] * u[cc]; a2 += J[l][r][cc] * ufree[cc]; }
-      vpre[r] = a1; cfree[l][r] = a2;
-      for (int cc = 0; cc < NV; cc++) MiJt[l][r][cc] = J[l][r][cc];
-      chol_solve(L, NV, MiJt[l][r]);
+      for (int cc = 0; cc < NV; cc++) { a1 += J[ci][r][cc] * u[cc]; a2 += J[ci][r][cc] * ufree[cc]; }
+      vpre[r] = a1; cfree[ci][r] = a2;
+      for (int cc = 0; cc < NV; cc++) MiJt[ci][r][cc] = J[ci][r][cc];
+      chol_solve(L, NV, MiJt[ci][r]);
     }
     real vn = v3_dot(vpre, nB);
-    vstar[l] = (vn < -m->rest_thr) ? (-m->rest * vn) : RC(0);
+    vstar[ci] = (vn < -m->rest_thr) ? (-m->rest * vn) : RC(0);
     /* warm start: previous impulse if the foot was already in the contact list */
-    if (e->in_contact[l]) m3_tmulv(lamB[l], R, e->lam_w[l]); else v3_set(lamB[l], RC(0), RC(0), RC(0));
+    if (ci < 4 && e->in_contact[ci]) m3_tmulv(lamB[ci], R, e->lam_w[ci]); else v3_set(lamB[ci], RC(0), RC(0), RC(0));
   }
-  for (int la = 0; la < 4; la++)
-    for (int lb = 0; lb < 4; lb++)
+  real G[NC][NC][9];
+  for (int la = 0; la < NC; la++)
+    for (int lb = 0; lb < NC; lb++)
       if (active[la] && active[lb])
         for (int r = 0; r < 3; r++)
           for (int r2 = 0; r2 < 3; r2++) {
@@ -1017,12 +1036,12 @@ static void physics_substep(orc_env *h, env_t *e, const real *pTarget) {
           }
   for (int it = 0; it < c->ContactIterations; it++) {
     real d2 = RC(0), l2 = RC(0);
-    for (int l = 0; l < 4; l++) {
+    for (int l = 0; l < NC; l++) {
       if (!active[l]) continue;
       real cv[3], old[3];
       v3_copy(cv, cfree[l]);
       v3_copy(old, lamB[l]);
-      for (int lb = 0; lb < 4; lb++) {
+      for (int lb = 0; lb < NC; lb++) {
         if (lb == l || !active[lb]) continue;
         real t[3];
         m3_mulv(t, G[l][lb], lamB[lb]);
@@ -1037,12 +1056,13 @@ static void physics_substep(orc_env *h, env_t *e, const real *pTarget) {
   e->gs_sweeps += c->ContactIterations;
 gs_done:
   e->gs_substeps += 1;
-  for (int l = 0; l < 4; l++) {
-    e->in_contact[l] = active[l];
-    if (!active[l]) { v3_set(e->lam_w[l], RC(0), RC(0), RC(0)); continue; }
+  for (int l = 0; l < NC; l++) {
+    if (l < 4) e->in_contact[l] = active[l];
+    if (!active[l]) { if (l < 4) v3_set(e->lam_w[l], RC(0), RC(0), RC(0)); continue; }
     for (int r = 0; r < 3; r++)
       for (int cc = 0; cc < NV; cc++) ufree[cc] += MiJt[l][r][cc] * lamB[l][r];
-    m3_mulv(e->lam_w[l], R, lamB[l]);
+    if (l < 4) m3_mulv(e->lam_w[l], R, lamB[l]);
+    else e->box_hits += 1;
   }
   /* back to world-frame gv, then positions (semi-implicit Euler) */
   m3_mulv(&e->gv[0], R, &ufree[0]);
@@ -1237,6 +1257,7 @@ int orc_set_ref(orc_env *h, const float *table, int rows, int cols) {
   return 0;
 }
 int orc_num_envs(const orc_env *h) { return h->n; }
+long orc_box_hits(const orc_env *h) { long t = 0; for (int i = 0; i < h->n; i++) t += h->envs[i].box_hits; return t; }
 int orc_real_bytes(void) { return (int)sizeof(real); }
 
 void orc_init(orc_env *h) {

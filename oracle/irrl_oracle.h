@@ -137,6 +137,8 @@ int orc_heightfield(const orc_env *h, float *out, int *nx, int *ny);
 void orc_terrain_sample(const orc_env *h, double x, double y, double out[4]);
 /* mean number of contact sweeps per substep since creation (statistics for DESIGN.md) */
 double orc_mean_contact_sweeps(const orc_env *h);
+/* (trunk-box corner, substep) pairs in contact since orc_init, summed over the envs (ENV:242 collision body "body/0") */
+long orc_box_hits(const orc_env *h);
 
 #ifdef __cplusplus
 }

@@ -183,6 +183,11 @@ class OracleVecEnv(object):
         self.lib.orc_terrain_sample(self.h, float(x), float(y), out)
         return np.array(out[:])
 
+    def box_hits(self):
+        self.lib.orc_box_hits.restype = C.c_long
+        self.lib.orc_box_hits.argtypes = [C.c_void_p]
+        return int(self.lib.orc_box_hits(self.h))
+
     def mean_contact_sweeps(self):
         return self.lib.orc_mean_contact_sweeps(self.h)
 

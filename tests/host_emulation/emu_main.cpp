@@ -49,6 +49,9 @@ void *emu_create(const char *cfg_yaml) {
   if (h->P.terrain) {
     irrl_host::generate_heightfield(irrl_host::TerrainSpec(), h->P.seed, h->height);
     h->P.height = h->height.data();
+    float hmax = 0.0f;
+    for (float v : h->height) hmax = v > hmax ? v : hmax;
+    h->P.hf_max = hmax;
   }
   return h;
 }

@@ -62,7 +62,7 @@ def check_probe(orc, cand):
     assert np.abs(nl_c - nl_o).max() < 5e-3  # entries up to ~90 N
 
 
-def check_teacher_forced(orc, cand, steps, seed=0, action_scale=0.5, force_terminal_every=0, max_factor=10.0):
+def check_teacher_forced(orc, cand, steps, seed=0, action_scale=0.5, force_terminal_every=0, max_factor=10.0, perturb=None):
     """Every step starts from the oracle's state (rounded to f32) in BOTH implementations."""
     rng = np.random.RandomState(seed)
     n = orc.n
@@ -73,6 +73,8 @@ def check_teacher_forced(orc, cand, steps, seed=0, action_scale=0.5, force_termi
         st = f32_round_state(orc.get_state())
         if force_terminal_every and k % force_terminal_every == force_terminal_every - 1:
             st[k % n, S["GC"] + 2] = 0.14  # below the 0.15 m termination height (ENV:1560)
+        if perturb is not None:
+            st = f32_round_state(perturb(st, k, rng))
         orc.set_state(st)
         cand.set_state(st)
         a = random_actions(rng, n, action_scale)
@@ -114,6 +116,26 @@ def check_teacher_forced(orc, cand, steps, seed=0, action_scale=0.5, force_termi
     worst["threshold_events"] = n_events
     assert n_events <= max(1, int(0.005 * steps * n)), "too many threshold events: %d of %d env-steps (%s)" % (n_events, steps * n, worst)
     return worst, n_done
+
+
+def tilt_onto_box_corner(st, k, rng, z_lo=0.152, z_hi=0.172, tilt_lo=52.0, tilt_hi=58.0):
+    """State perturbation for the trunk-box contact tests: every env is put low and tilted 52-58 degrees (inside the 60 degree
+    termination bound) about a horizontal axis chosen so that one bottom corner of the 0.3 x 0.2 x 0.1 box points at the
+    ground -- at base heights of 0.152-0.172 m that corner (and often its neighbour) is in the ground, the episode goes on."""
+    n = st.shape[0]
+    out = st.copy()
+    for e in range(n):
+        sx, sy = rng.choice([-1.0, 1.0]), rng.choice([-1.0, 1.0])
+        d = np.array([0.15 * sx, 0.1 * sy, 0.0]) + 0.02 * rng.normal(size=3) * np.array([1, 1, 0])   # horizontal direction of the corner
+        d /= np.linalg.norm(d)
+        axis = np.cross(np.array([0.0, 0.0, 1.0]), d)               # rotating about it lowers the corner in direction d
+        ang = np.radians(rng.uniform(tilt_lo, tilt_hi))
+        q = np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * axis])
+        out[e, S["GC"] + 2] = rng.uniform(z_lo, z_hi)
+        out[e, S["GC"] + 3:S["GC"] + 7] = q
+        out[e, S["GV"]:S["GV"] + 3] = [0.3 * rng.normal(), 0.3 * rng.normal(), -0.5 * rng.uniform()]
+        out[e, S["GV"] + 3:S["GV"] + 6] = 1.0 * rng.normal(size=3)
+    return out
 
 
 def check_free_running(make_orc, make_cand, cfg, preroll=90):

@@ -69,10 +69,10 @@ def _run_bench(extra, env_over):
 def test_bench_single_gpu_line_is_steady_state():
     out = _run_bench(["--steps", "20", "--warmup", "5", "--ppo-iters", "0", "--cpu-seconds", "0", "--check-steps", "200"], {})
     assert out["n_gpus"] == 1 and out["steps"] == 20 and out["warmup"] == 5
-    assert out["contact_fraction_in_timed_region"] > 0.3 and out["resets_in_timed_region"] > 0
+    assert out["contact_fraction_in_timed_region"] > 0.1 and out["resets_in_timed_region"] > 0
     assert out["config"]["preroll"] >= 200
     # the 20-step timed region and the 200-step check window measure the same regime
-    assert abs(out["roofline"]["avg_launch_us"] - out["steady_state_check"]["us_per_step"]) < 0.25 * out["steady_state_check"]["us_per_step"]
+    assert abs(out["roofline"]["avg_launch_us"] - out["steady_state_check"]["us_per_step"]) < 0.10 * out["steady_state_check"]["us_per_step"]
 
 
 def test_bench_gpus_2_runs_two_ranks_with_the_ppo_collectives():

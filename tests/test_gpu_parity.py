@@ -300,9 +300,36 @@ def test_set_contact_coefficient_changes_the_cone_and_follows_the_oracle():
     cand.set_state(st)
     orc.set_state(st)
     worst, _ = PL.check_teacher_forced(orc, cand, steps=30, seed=12)
-    st = cand.get_state()
-    lam = st[:, PL.S["LAMW"]:PL.S["LAMW"] + 12].reshape(n, 4, 3)
-    ft = np.linalg.norm(lam[:, :, :2], axis=2)
-    assert (lam[:, :, 2] > 0).sum() > n                                              # feet on the ground
-    assert np.all(ft <= coeff[:, 0:1] * lam[:, :, 2] * (1 + 1e-4) + 1e-6)            # the NEW Coulomb cone, per env
-    assert np.any(ft[1::2] > 0.05 * lam[1::2, :, 2] * 1.5)                           # grippy robots do use more than mu = 0.05
+    # the stored impulses obey the NEW cone, per env, over 40 more steps of the candidate alone
+    touching, grippy_ratio = 0, 0.0
+    for _ in range(40):
+        cand.step(PL.random_actions(rng, n, 0.5))
+        st = cand.get_state()
+        lam = st[:, PL.S["LAMW"]:PL.S["LAMW"] + 12].reshape(n, 4, 3)
+        ft = np.linalg.norm(lam[:, :, :2], axis=2)
+        touching += int((lam[:, :, 2] > 0).sum())
+        assert np.all(ft <= coeff[:, 0:1] * lam[:, :, 2] * (1 + 1e-4) + 1e-6)
+        on = lam[1::2, :, 2] > 1e-4
+        if on.any():
+            grippy_ratio = max(grippy_ratio, float((ft[1::2][on] / lam[1::2, :, 2][on]).max()))
+    assert touching > 4 * n                       # feet were on the ground
+    assert grippy_ratio > 0.05 * 1.5              # the grippy robots do use more friction than the icy ones may
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_trunk_box_corner_contacts_match_the_oracle_on_gpu(lanes, monkeypatch):
+    """ENV:242 / URDF:26: robots tilted 52-58 degrees onto a bottom corner of the trunk's collision box at base heights of
+    0.15-0.17 m (still inside the episode), teacher-forced through the C-ABI in both lane layouts; then the same on rough ground."""
+    monkeypatch.setenv("IRRL_LANES_PER_ROBOT", str(lanes))
+    n = 64
+    orc, cand = _pair(load_env_cfg("bp5_imitation.yaml", num_envs=n))
+    assert cand.impl.lanes_per_robot == lanes
+    h0 = orc.box_hits()
+    worst, n_done = PL.check_teacher_forced(orc, cand, steps=40, seed=3, perturb=PL.tilt_onto_box_corner, max_factor=40.0)
+    assert orc.box_hits() - h0 > n * 40 * 4 and n_done < n * 40 // 4
+    print("box-corner teacher-forced worst errors (lanes %d):" % lanes, worst)
+    orc, cand = _pair(load_env_cfg("bp5_terrain.yaml", num_envs=32))
+    h0 = orc.box_hits()
+    PL.check_teacher_forced(orc, cand, steps=30, seed=5, perturb=lambda st, k, rng: PL.tilt_onto_box_corner(st, k, rng, 0.16, 0.30, 20.0, 55.0),
+                            max_factor=1e4)
+    assert orc.box_hits() > h0

@@ -29,6 +29,21 @@ def test_both_lane_layouts_match_oracle(emu):
     PL.check_teacher_forced(orc, cand, steps=40, force_terminal_every=9, max_factor=1e4)
 
 
+@pytest.mark.parametrize("emu", [E.EmuVecEnv, E.EmuVecEnv16])
+def test_trunk_box_corners_collide_like_the_oracle(emu):
+    """ENV:242 / URDF:26: the trunk's collision box.  Robots tilted onto a bottom corner at 0.15-0.17 m: the corner contacts of
+    the kernel source (both lane layouts) against the oracle's, teacher-forced; the oracle's statistic proves corners did touch."""
+    orc, cand = _pair(load_env_cfg("bp5_imitation.yaml", num_envs=8), emu)
+    h0 = orc.box_hits()
+    worst, n_done = PL.check_teacher_forced(orc, cand, steps=40, seed=3, perturb=PL.tilt_onto_box_corner, max_factor=40.0)
+    assert orc.box_hits() - h0 > 8 * 40 * 4          # on average more than half a corner-substep pair per env-substep
+    assert n_done < 8 * 40 // 4                      # most steps stay inside the episode: the physics is what is compared
+    # rough ground brings corners down at small tilts too
+    orc, cand = _pair(load_env_cfg("bp5_terrain.yaml", num_envs=4), emu)
+    PL.check_teacher_forced(orc, cand, steps=30, seed=5, perturb=lambda st, k, rng: PL.tilt_onto_box_corner(st, k, rng, 0.16, 0.30, 20.0, 55.0),
+                            max_factor=1e4)
+
+
 def test_init_matches_oracle_train_cfg():
     PL.check_init(*_pair(load_env_cfg("default_cfg.yaml", num_envs=24)))
 

@@ -208,3 +208,61 @@ def test_contact_impulses_obey_momentum_balance_cone_and_stick_slip():
                 assert abs(lt[f] - mu * ln[f]) < 1e-6 * ln[f] + 1e-12
                 assert np.dot(lam[f, :2], vt) < 0 and np.dot(lam[f, :2], vt) < -0.9 * lt[f] * np.linalg.norm(vt)
                 assert abs(vel[f, 2]) < 1e-6
+
+
+def test_trunk_box_corner_contact_first_principles():
+    """ENV:242 / URDF:26: the trunk's 0.3 x 0.2 x 0.1 collision box against the ground.  A robot with its legs folded up is put
+    low, tilted 55 degrees onto one bottom corner and moving down: after ONE substep (a) the oracle reports corner contacts and
+    no toe contact, (b) the touching corner no longer approaches the ground (hard contact at velocity level, restitution above
+    the threshold), (c) the total momentum changed by exactly gravity plus an impulse that pushes up and lies inside the
+    friction cone about the ground normal, (d) a robot hovering 5 cm higher in the same pose feels nothing."""
+    dt = 0.00025
+    cfg = load_env_cfg("bp5_imitation.yaml", num_envs=2, control_dt=dt, simulation_dt=dt, Stiffness=0.0, Damping=0.0,
+                       ContactIterations=40, ContactTolerance=0.0)
+    env = O.OracleVecEnv(cfg)
+    st = env.get_state()
+    d = np.array([0.15, 0.1, 0.0]) / np.hypot(0.15, 0.1)
+    axis = np.cross([0.0, 0.0, 1.0], d)
+    ang = np.radians(55.0)
+    q = np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * axis])
+    for i, z in enumerate((0.165, 0.215)):
+        st[i, S["GC"]:S["GC"] + 19] = 0
+        st[i, S["GC"] + 2] = z
+        st[i, S["GC"] + 3:S["GC"] + 7] = q
+        st[i, S["GC"] + 7:S["GC"] + 19] = [-0.6, -2.25, 0.225, 0.6, -2.25, 0.225] * 2   # legs swung up over the back: toes 0.2 m above the ground
+        st[i, S["GV"]:S["GV"] + 18] = 0
+        st[i, S["GV"] + 2] = -0.8                                       # falling
+        st[i, S["LAMW"]:S["LAMW"] + 12] = 0
+        st[i, S["INCONTACT"]:S["INCONTACT"] + 4] = 0
+        st[i, S["TQL"]:S["TQL"] + 12] = 0
+    env.set_state(st)
+    s0 = env.get_state()
+    h0 = env.box_hits()
+    env.step(np.zeros((2, 12), np.float32))
+    s1 = env.get_state()
+    hits = env.box_hits() - h0
+    assert 1 <= hits <= 4                                               # only the low robot's lowest corner(s)
+    assert np.all(s1[:, S["INCONTACT"]:S["INCONTACT"] + 4] == 0)        # no toe is involved
+    Rm = R.quat_to_rot(s0[0, 3:7]) if hasattr(R, "quat_to_rot") else None
+    if Rm is None:
+        w, x, y, z = s0[0, 3:7]
+        Rm = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                       [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                       [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    corners = np.array([[sx * 0.15, sy * 0.1, sz * 0.05] for sx in (1, -1) for sy in (1, -1) for sz in (-1, 1)])
+    cw = corners @ Rm.T
+    low = int(np.argmin(cw[:, 2]))
+    assert s0[0, 2] + cw[low, 2] < 0 and np.all(np.delete(s0[0, 2] + cw[:, 2], low) > -0.02)
+    v1 = s1[0, 19:22] + np.cross(s1[0, 22:25], cw[low])
+    v0 = s0[0, 19:22] + np.cross(s0[0, 22:25], cw[low])
+    assert v0[2] < -0.5 and v1[2] >= -1e-9                              # (b) the corner stopped approaching (restitution 0.2 x 0.8 upwards)
+    assert abs(v1[2] - 0.2 * 0.8) < 0.02
+    for i in range(2):
+        p0, _, _ = _momenta(s0[i, :19], s0[i, 19:37])
+        p1, _, _ = _momenta(s1[i, :19], s1[i, 19:37])
+        imp = p1 - p0 - np.array([0, 0, -8.88 * 9.81 * dt])              # what the ground gave
+        if i == 0:
+            mu = s1[i, S["MATERIAL"]]
+            assert imp[2] > 0.5 and np.hypot(imp[0], imp[1]) <= mu * imp[2] * (1 + 1e-6) + 1e-4   # (c)
+        else:
+            assert np.abs(imp).max() < 1e-6                              # (d) free flight
