@@ -32,6 +32,9 @@ using namespace lanes;
 // ---------------------------------------------------------------------------------------------
 // small vector helpers
 // ---------------------------------------------------------------------------------------------
+#define IRRL_UNLIKELY(x) __builtin_expect(!!(x), 0)   /* rare wave-uniform branches: laid out off the hot path */
+struct irrl_yes { static constexpr bool value = true; };
+struct irrl_no { static constexpr bool value = false; };
 struct v3 { vf x, y, z; };
 struct sym3 { vf xx, xy, xz, yy, yz, zz; };
 
@@ -225,40 +228,48 @@ IRRL_DEV vf bezier_w(vf s) { return s * s * s + 3.0f * (s * s * (1.0f - s)); }
 IRRL_DEV vf gauss_bump(vf x, vf width, vf height) {
   return height * v_exp(-(x - width / 2.0f) * (x - width / 2.0f) / (2.0f * (width / 6.0f) * (width / 6.0f)));
 }
-IRRL_DEV vf smooth_raw(vf phase, vf slope, vf lam) {
-  vf f = v_fmod(phase, 1.0f);
-  vf a = (v_sin(f / lam * 2.0f * IRRL_PI_REF) * slope) + 0.5f;
-  vf b = (-v_sin((f - lam) / (1.0f - lam) * 2.0f * IRRL_PI_REF) * slope) + 0.5f;
-  return vsel(f < lam, a, b);
+// the same bump for width 1 (the only width the gait generator uses, ENV:1835): exponent -18 (x - 1/2)^2
+IRRL_DEV vf gauss_bump_w1(vf x, vf height) { return height * v_exp_fast(-18.0f * ((x - 0.5f) * (x - 0.5f))); }
+IRRL_DEV void sincos_fast(vf x, vf &s, vf &c);
+// phase >= 0: fmod(phase, 1) = phase - floor(phase) exactly; ONE sine of the branch's argument (Cody-Waite, 1e-7 absolute)
+IRRL_DEV vf smooth_raw(vf phase, vf slope, vf lam, vf inv_lam, vf inv_one_minus_lam) {
+  vf f = phase - v_floor(phase);
+  vm first = f < lam;
+  vf arg = vsel(first, f * inv_lam, (f - lam) * inv_one_minus_lam) * (2.0f * IRRL_PI_REF);
+  vf sn, cs;
+  sincos_fast(arg, sn, cs);
+  return vsel(first, sn, -sn) * slope + 0.5f;
 }
-IRRL_DEV vf smooth_function(vf phase, vf slope, vf lam) {
-  vf t = smooth_raw(phase, slope, lam);
+IRRL_DEV vf smooth_function(vf phase, vf slope, vf lam, vf inv_lam, vf inv_one_minus_lam) {
+  vf t = smooth_raw(phase, slope, lam, inv_lam, inv_one_minus_lam);
   return vsel(t > 1.0f, 1.0f, vsel(t < 0.0f, 0.0f, t));
 }
-IRRL_DEV vf smooth_function2(vf phase, vf slope, vf lam) {
-  vf t = smooth_raw(phase, slope, lam);
+IRRL_DEV vf smooth_function2(vf phase, vf slope, vf lam, vf inv_lam, vf inv_one_minus_lam) {
+  vf t = smooth_raw(phase, slope, lam, inv_lam, inv_one_minus_lam);
   return vsel(t > 1.0f, 0.0f, vsel(t < 0.0f, 1.0f, 1.0f - t));
 }
 // ENV:1687-1751.  th0/th1/th2 hold the previous ("stale") values on entry; `valid*` report which
 // slots were overwritten so the caller can reproduce the shared temp[3] chaining across legs.
 IRRL_DEV void inverse_kinematics(vf x, vf y, vf z, vf max_len, vm is_right, vf &th0, vf &th1, vf &th2, vm &ok0, vm &ok1, vm &ok2) {
   const float l_hip = IRRL_L_HIP, l_thigh = IRRL_L_THIGH, l_calf = IRRL_L_CALF;
-  vf ll = v_sqrt(x * x + y * y + z * z);
+  vf ll2 = x * x + y * y + z * z;
+  vf ll = v_sqrt(ll2);
   vm too_long = ll > max_len;
-  vf sc = (max_len - 1e-5f) / ll;
+  vf sc = (max_len - 1e-5f) * v_rsqrt(ll2);
   x = vsel(too_long, x * sc, x); y = vsel(too_long, y * sc, y); z = vsel(too_long, z * sc, z);
   vf root = v_sqrt(y * y * (z * z + y * y - l_hip * l_hip));
-  vf den = z * z + y * y;
-  vf temp = vsel(is_right, (-z * l_hip - root) / den, (z * l_hip + root) / den);
+  vf iden = v_rcp(z * z + y * y);
+  vf temp = vsel(is_right, -z * l_hip - root, z * l_hip + root) * iden;
   ok0 = v_abs(temp) <= 1.0f;
   th0 = vsel(ok0, v_asin(temp), th0);
   vf lr = v_sqrt(x * x + y * y + z * z - l_hip * l_hip);
   lr = vsel(lr > (l_thigh + l_calf), (l_thigh + l_calf - 1e-4f), lr);
-  vf t2 = (l_thigh * l_thigh + l_calf * l_calf - lr * lr) / 2.0f / l_thigh / l_calf + 1e-5f;
+  vf t2 = (l_thigh * l_thigh + l_calf * l_calf - lr * lr) * (0.5f / (l_thigh * l_calf)) + 1e-5f;
   ok2 = v_abs(t2) <= 1.0f;
   th2 = vsel(ok2, -(IRRL_PI_REF - v_acos(t2)), th2);
-  vf a1 = x / lr;
-  vf a2 = (lr * lr + l_thigh * l_thigh - l_calf * l_calf) / 2.0f / lr / l_thigh - 1e-5f;
+  vf ilr = v_rcp(lr);
+  vf a1 = x * ilr;
+  vf a2 = (lr * lr + l_thigh * l_thigh - l_calf * l_calf) * ((0.5f / l_thigh) * ilr) - 1e-5f;
   ok1 = (v_abs(a1) <= 1.0f) & (v_abs(a2) <= 1.0f);
   th1 = vsel(ok1, v_acos(a2) - v_asin(a1), th1);
 }
@@ -593,11 +604,13 @@ IRRL_DEV void terrain_sample(const EnvParams &P, vf x, vf y, vf &h, v3 &n) {
 #ifdef IRRL_L16
 #define IRRL_NCPL 1
 IRRL_DEV vf robot_sum(vf x) { return legs_sum(sub_sum(x)); }
+template <int LANE> IRRL_DEV vf robot_bcast(vf x) { return row_bcast<LANE>(x); }   // lane LANE of the robot's 16
 IRRL_DEV vi box_corner_id(int) { return leg_id() * 2 + (sub_id() & 1); }
 IRRL_DEV vm box_corner_owner() { return sub_id() < 2; }
 #else
 #define IRRL_NCPL 2
 IRRL_DEV vf robot_sum(vf x) { return legs_sum(x); }
+template <int LANE> IRRL_DEV vf robot_bcast(vf x) { return legs_bcast<LANE>(x); }
 IRRL_DEV vi box_corner_id(int j) { return leg_id() * 2 + j; }
 IRRL_DEV vm box_corner_owner() { return vm(true); }
 #endif
@@ -679,31 +692,39 @@ IRRL_DEV bool box_setup(const EnvParams &P, const EnvLane &L, const rot3 &R, con
   }
   return any;
 }
-// One Gauss-Seidel pass over the corners in the order 0..7.  zt: sum over the toes of Y^T lambda (replicated).  Adds this
-// pass's |dlambda|^2 to d2 (replicated over the robot's lanes); updates B.lam and B.zc.
+// Gauss-Seidel step of corner B (compile-time: its owner lane is a DPP broadcast source).  zt: sum over the toes of
+// Y^T lambda (replicated).  Adds |dlambda|^2 to dd in the owner lane; updates B.lam and the replicated B.zc.
+template <int CB>
+IRRL_DEV void box_corner_step(BoxContacts &B, const vf zt[6], vf mu, vf &dd) {
+  constexpr int j = (IRRL_NCPL == 2) ? (CB & 1) : 0;
+  const vm mine = B.own[j] & (B.id[j] == CB);
+  if (!wave_any(mine)) return;
+  // velocity at the corner without its own impulse: cfree + Y (zt + zc) - G lam_own
+  vf zs[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) zs[i] = zt[i] + B.zc[i];
+  v3 own = mul(B.CB[j].G, B.lam[j]);
+  v3 c = B.cfree[j] - own;
+#pragma unroll
+  for (int i = 0; i < 6; i++) { c.x += B.Y[j][0][i] * zs[i]; c.y += B.Y[j][1][i] * zs[i]; c.z += B.Y[j][2][i] * zs[i]; }
+  v3 ln = solve_contact(B.CB[j], c, B.n[j], B.vstar[j], mu, mine);
+  v3 dl = mk3(vsel(mine, ln.x - B.lam[j].x, 0.0f), vsel(mine, ln.y - B.lam[j].y, 0.0f), vsel(mine, ln.z - B.lam[j].z, 0.0f));
+  B.lam[j] = B.lam[j] + dl;
+  dd += dot(dl, dl);
+  // zc += Y^T dl of the owner lane, broadcast to the robot's lanes
+#ifdef IRRL_L16
+  constexpr int OWNER = (CB >> 1) * 4 + (CB & 1);
+#else
+  constexpr int OWNER = CB >> 1;
+#endif
+#pragma unroll
+  for (int i = 0; i < 6; i++) B.zc[i] += robot_bcast<OWNER>(B.Y[j][0][i] * dl.x + B.Y[j][1][i] * dl.y + B.Y[j][2][i] * dl.z);
+}
+// One Gauss-Seidel pass over the corners in the order 0..7; adds this pass's |dlambda|^2 to d2 (replicated over the robot's lanes).
 IRRL_DEV void box_sweep(BoxContacts &B, const vf zt[6], vf mu, vf &d2) {
   vf dd = 0.0f;
-#pragma unroll
-  for (int b = 0; b < 8; b++) {
-    const int j = (IRRL_NCPL == 2) ? (b & 1) : 0;
-    const vm mine = B.own[j] & (B.id[j] == b);
-    if (!wave_any(mine)) continue;
-    // velocity at the corner without its own impulse: cfree + Y (zt + zc) - G lam_own
-    vf zs[6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) zs[i] = zt[i] + B.zc[i];
-    v3 own = mul(B.CB[j].G, B.lam[j]);
-    v3 c = B.cfree[j] - own;
-#pragma unroll
-    for (int i = 0; i < 6; i++) { c.x += B.Y[j][0][i] * zs[i]; c.y += B.Y[j][1][i] * zs[i]; c.z += B.Y[j][2][i] * zs[i]; }
-    v3 ln = solve_contact(B.CB[j], c, B.n[j], B.vstar[j], mu, mine);
-    v3 dl = mk3(vsel(mine, ln.x - B.lam[j].x, 0.0f), vsel(mine, ln.y - B.lam[j].y, 0.0f), vsel(mine, ln.z - B.lam[j].z, 0.0f));
-    B.lam[j] = B.lam[j] + dl;
-    dd += dot(dl, dl);
-    // only the owner holds a non-zero dl, so the sum over the robot's lanes is a broadcast of Y^T dl
-#pragma unroll
-    for (int i = 0; i < 6; i++) B.zc[i] += robot_sum(B.Y[j][0][i] * dl.x + B.Y[j][1][i] * dl.y + B.Y[j][2][i] * dl.z);
-  }
+  box_corner_step<0>(B, zt, mu, dd); box_corner_step<1>(B, zt, mu, dd); box_corner_step<2>(B, zt, mu, dd); box_corner_step<3>(B, zt, mu, dd);
+  box_corner_step<4>(B, zt, mu, dd); box_corner_step<5>(B, zt, mu, dd); box_corner_step<6>(B, zt, mu, dd); box_corner_step<7>(B, zt, mu, dd);
   d2 += robot_sum(dd);
 }
 IRRL_DEV vf box_lam2(const BoxContacts &B) {
@@ -924,8 +945,15 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
   // ---- contact: toe sphere against the ground ----
   vf gap = (L.pos.z + dot(R.r2, k.ptoe) - hgt) * nwz - IRRL_TOE_RADIUS;
   vm active = gap <= 0.0f;
+#ifdef IRRL_NO_BOX   /* A/B switch of tools/build_variants.py: the build without the trunk-box collider */
+  const bool box_near = false;
+#else
   const bool box_near = wave_any(box_near_ground(P, L.pos.z, R.r2));
-  if (wave_any(active) || box_near) {
+#endif
+  // The contact block exists twice: the hot instantiation without the trunk-box corners, and a rare one with them (robots
+  // falling over, rough terrain) that is laid out off the hot path -- the corner code costs the common case nothing.
+  auto contact_block = [&](auto with_box_tag) {
+    constexpr bool WITH_BOX = decltype(with_box_tag)::value;
     v3 x = k.ptoe - IRRL_TOE_RADIUS * nB;
     // (D) column `sub` of the leg Jacobian, then all of it (R)
     v3 jc = live * cross(ax, x - p_s);
@@ -999,7 +1027,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     // trunk-box corners (rare: falling robots, rough terrain)
     BoxContacts BX;
     bool has_box = false;
-    if (box_near) has_box = box_setup(P, L, R, D.L6, ub, vB, wB, BX);
+    if constexpr (WITH_BOX) has_box = box_setup(P, L, R, D.L6, ub, vB, wB, BX);
     vf cz_r = 0.0f;   // row r of Y_toe . zc: what the corner impulses add to this toe's velocity
     for (int it = 0; it < P.contact_iters; it++) {
       vf d2 = 0.0f;
@@ -1025,7 +1053,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
         d2 += dot(dl, dl);
       }
       vf d2b = 0.0f, l2b = 0.0f;
-      if (has_box) {
+      if constexpr (WITH_BOX) if (has_box) {
         const vf lam_t = live * PICK3(vsel(active, lam.x, 0.0f), vsel(active, lam.y, 0.0f), vsel(active, lam.z, 0.0f));
         vf zt[6];
 #pragma unroll
@@ -1049,7 +1077,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     vf xbc[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) xbc[i] = legs_sum(sub_sum(Yr[i] * lam_r));
-    if (has_box) {
+    if constexpr (WITH_BOX) if (has_box) {
 #pragma unroll
       for (int i = 0; i < 6; i++) xbc[i] += BX.zc[i];
     }
@@ -1065,9 +1093,10 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     }
     v3 lw = rot_mul(R, lam);
     L.lamw[0] = lw.x; L.lamw[1] = lw.y; L.lamw[2] = lw.z;
-  } else {
-    L.lamw[0] = 0.0f; L.lamw[1] = 0.0f; L.lamw[2] = 0.0f;
-  }
+  };
+  if (IRRL_UNLIKELY(box_near)) contact_block(irrl_yes());
+  else if (wave_any(active)) contact_block(irrl_no());
+  else { L.lamw[0] = 0.0f; L.lamw[1] = 0.0f; L.lamw[2] = 0.0f; }
   IRRL_MARK("integrate");
   L.in_contact = vsel_i(active, 1, 0);
   L.ccount = L.ccount + to_u(L.in_contact);
@@ -1138,8 +1167,15 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
   // sphere against the locally planar ground: centre-to-tangent-plane distance minus the radius
   vf gap = (L.pos.z + dot(R.r2, k.ptoe) - hgt) * nwz - IRRL_TOE_RADIUS;
   vm active = gap <= 0.0f;
+#ifdef IRRL_NO_BOX   /* A/B switch of tools/build_variants.py: the build without the trunk-box collider */
+  const bool box_near = false;
+#else
   const bool box_near = wave_any(box_near_ground(P, L.pos.z, R.r2));
-  if (wave_any(active) || box_near) {
+#endif
+  // The contact block exists twice: the hot instantiation without the trunk-box corners, and a rare one with them (robots
+  // falling over, rough terrain) that is laid out off the hot path -- the corner code costs the common case nothing.
+  auto contact_block = [&](auto with_box_tag) {
+    constexpr bool WITH_BOX = decltype(with_box_tag)::value;
     v3 x = k.ptoe - IRRL_TOE_RADIUS * nB;
     // leg columns of the contact Jacobian
     v3 jA = cross(mk3(1.0f, 0.0f, 0.0f), x - k.pA), jT = cross(k.h, x - k.pT), jS = cross(k.h, x - k.pS);
@@ -1219,7 +1255,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     // trunk-box corners (rare: falling robots, rough terrain)
     BoxContacts BX;
     bool has_box = false;
-    if (box_near) has_box = box_setup(P, L, R, D.L6, ub, vB, wB, BX);
+    if constexpr (WITH_BOX) has_box = box_setup(P, L, R, D.L6, ub, vB, wB, BX);
     v3 cz = mk3(0.0f, 0.0f, 0.0f);   // Y_toe . zc: what the corner impulses add to this toe's velocity
     for (int it = 0; it < P.contact_iters; it++) {
       vf d2 = 0.0f;
@@ -1242,7 +1278,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
         d2 += dot(dl, dl);
       }
       vf d2b = 0.0f, l2b = 0.0f;
-      if (has_box) {
+      if constexpr (WITH_BOX) if (has_box) {
         const v3 la = mk3(vsel(active, lam.x, 0.0f), vsel(active, lam.y, 0.0f), vsel(active, lam.z, 0.0f));
         vf zt[6];
 #pragma unroll
@@ -1265,7 +1301,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     vf z[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) z[i] = legs_sum(Y[0][i] * lam.x + Y[1][i] * lam.y + Y[2][i] * lam.z);
-    if (has_box) {
+    if constexpr (WITH_BOX) if (has_box) {
 #pragma unroll
       for (int i = 0; i < 6; i++) z[i] += BX.zc[i];
     }
@@ -1285,9 +1321,10 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     }
     v3 lw = rot_mul(R, lam);
     L.lamw[0] = lw.x; L.lamw[1] = lw.y; L.lamw[2] = lw.z;
-  } else {
-    L.lamw[0] = 0.0f; L.lamw[1] = 0.0f; L.lamw[2] = 0.0f;
-  }
+  };
+  if (IRRL_UNLIKELY(box_near)) contact_block(irrl_yes());
+  else if (wave_any(active)) contact_block(irrl_no());
+  else { L.lamw[0] = 0.0f; L.lamw[1] = 0.0f; L.lamw[2] = 0.0f; }
   L.in_contact = vsel_i(active, 1, 0);
   L.ccount = L.ccount + to_u(L.in_contact);
   // back to world-frame gv, then positions (semi-implicit Euler)
@@ -1321,12 +1358,12 @@ IRRL_DEV void gait_leg_pass(const EnvParams &P, const EnvLane &L, vf t_eval, vf 
                             vf prev[3] /* temp[] entering leg 0 */, vf th_out[3], v3 &toe_out) {
   vi leg = leg_id();
   vf phase_l = pick4(P.phase[0], P.phase[1], P.phase[2], P.phase[3], leg);
-  vf rp = v_fmod(t_eval + phase_l * P.period, P.period) / P.period;
+  vf rp = v_fmod_pos(t_eval + phase_l * P.period, P.period, P.inv_period) * P.inv_period;
   vf anti = vsel(leg < 2, 1.0f, -1.0f);
   vf hx = gait_step / 2.0f, hy = side_step / 2.0f + anti * rot_step / 2.0f, hy2 = -side_step / 2.0f + -anti * rot_step / 2.0f;
   // stance: bezier from (+hx, hy) to (-hx, hy2); swing: from (-hx, hy2) to (+hx, hy) with a gaussian lift
   vm stance = rp < P.lam;
-  vf s = vsel(stance, rp / P.lam, (rp - P.lam) / (1.0f - P.lam));
+  vf s = vsel(stance, rp * P.inv_lam, (rp - P.lam) * P.inv_one_minus_lam);
   vf bw = bezier_w(s);
   vf p0x = vsel(stance, hx, -hx), pfx = vsel(stance, -hx, hx);
   vf p0y = vsel(stance, hy, hy2), pfy = vsel(stance, hy2, hy);
@@ -1334,7 +1371,7 @@ IRRL_DEV void gait_leg_pass(const EnvParams &P, const EnvLane &L, vf t_eval, vf 
   toe.x = p0x + bw * (pfx - p0x);
   toe.y = p0y + bw * (pfy - p0y);
   vf zst = -P.stand_height + bw * (-P.stand_height - -P.stand_height);
-  toe.z = vsel(stance, zst, -P.stand_height + gauss_bump(s, 1.0f, up_height));
+  toe.z = vsel(stance, zst, -P.stand_height + gauss_bump_w1(s, up_height));
   vf toff = pick4(-IRRL_L_HIP + P.lean_front, IRRL_L_HIP - P.lean_front, -IRRL_L_HIP + P.lean_hind, IRRL_L_HIP - P.lean_hind, leg);
   vf th0 = 0.0f, th1 = 0.0f, th2 = 0.0f;
   vm ok0, ok1, ok2;
@@ -1383,7 +1420,7 @@ IRRL_DEV void gait_generator_manual(const EnvParams &P, EnvLane &L, bool is_firs
   gait_leg_pass(P, L, t, gait_step, side_step, rot_step, L.up_height, prev, th, toe);
   L.jr[0] = th[0]; L.jr[1] = -th[1]; L.jr[2] = -th[2];
 #pragma unroll
-  for (int j = 0; j < 3; j++) { L.jdr[j] = (L.jr[j] - L.jrl[j]) / P.control_dt; L.jrl[j] = L.jr[j]; }
+  for (int j = 0; j < 3; j++) { L.jdr[j] = (L.jr[j] - L.jrl[j]) * P.inv_control_dt; L.jrl[j] = L.jr[j]; }
   // EndEffectorRef = toe + hip offset (ENV:331-334)
   L.eer[0] = toe.x + L.m.sf * 0.19f; L.eer[1] = toe.y + L.m.sy * 0.058f; L.eer[2] = toe.z + 0.0f;
 }
@@ -1408,7 +1445,7 @@ IRRL_DEV void command_obs_update(const EnvParams &P, EnvLane &L, vu env, bool fl
     return;
   }
   rng4 r = philox_u01(P.seed, env, L.episode, to_u(L.frame), flag_reset ? IRRL_P_RESET_CMD : IRRL_P_CMD);
-  vm resample = r.u0 < 0.5f / (P.max_time / P.control_dt);
+  vm resample = r.u0 < P.cmd_resample_p;
   if (flag_reset) resample = resample | vm(true);
   vf t = r.u1, v = r.u2;
   vm bx = (0.2f < t) & (t <= 0.7f);
@@ -1431,7 +1468,7 @@ IRRL_DEV void contact_obs_update(const EnvParams &P, EnvLane &L) {
     L.contact = vsel(L.in_contact != 0, 1.0f, 0.0f);
   } else {
     vf phase_l = pick4(P.phase[0], P.phase[1], P.phase[2], P.phase[3], leg_id());
-    vf rp = v_fmod(env_time(P, L) + phase_l * P.period, P.period) / P.period;
+    vf rp = v_fmod_pos(env_time(P, L) + phase_l * P.period, P.period, P.inv_period) * P.inv_period;
     L.contact = vsel(rp < P.lam, 1.0f, 0.0f);
   }
 }
@@ -1446,8 +1483,7 @@ IRRL_DEV void update_observation(const EnvParams &P, EnvLane &L, vu env) {
     L.ob_phase[0] = ld(P.ref, b + 25);
     L.ob_phase[1] = ld(P.ref, b + 26);
   } else {
-    L.ob_phase[0] = v_sin(2.0f * IRRL_PI_REF * t / P.period);
-    L.ob_phase[1] = v_cos(2.0f * IRRL_PI_REF * t / P.period);
+    sincos_fast(P.two_pi_over_period * t, L.ob_phase[0], L.ob_phase[1]);   // t stays below a few seconds: |x| < 2^8 pi/2
   }
   vf nj[3] = {0.0f, 0.0f, 0.0f}, nv[3] = {0.0f, 0.0f, 0.0f}, nn[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
   if (P.obs_noise != 0.0f) {
@@ -1494,7 +1530,7 @@ IRRL_DEV vf reward_update(const EnvParams &P, EnvLane &L, vf extra[6]) {
   vi leg = leg_id();
   v3 xB; vf vel_norm;
   toe_state(L, xB, vel_norm);
-  vf force_norm = vsel(L.in_contact != 0, v_sqrt(L.lamw[0] * L.lamw[0] + L.lamw[1] * L.lamw[1] + L.lamw[2] * L.lamw[2]) / P.control_dt, 0.0f);
+  vf force_norm = vsel(L.in_contact != 0, v_sqrt(L.lamw[0] * L.lamw[0] + L.lamw[1] * L.lamw[1] + L.lamw[2] * L.lamw[2]) * P.inv_control_dt, 0.0f);
   // per-leg partial sums, summed FR,FL,HR,HL by the quad reduction
   vf d0 = xB.x - L.eer[0], d1 = xB.y - L.eer[1], d2 = xB.z - L.eer[2];
   vf ee2 = legs_sum(d0 * d0 + d1 * d1 + d2 * d2);
@@ -1503,29 +1539,33 @@ IRRL_DEV vf reward_update(const EnvParams &P, EnvLane &L, vf extra[6]) {
   for (int k = 0; k < 3; k++) {
     vf a = L.jr[k] - L.q[k]; j2 += a * a;
     vf b = L.jdr[k] - L.qd[k]; jd2 += b * b;
-    tn[k] = L.tq[k] / ((k == 2) ? 27.0f : 18.0f);  // ENV:354
+    tn[k] = L.tq[k] * ((k == 2) ? (1.0f / 27.0f) : (1.0f / 18.0f));  // ENV:354
     tn2 += tn[k] * tn[k];
     vf c = tn[k] - L.tql[k]; td2 += c * c;
   }
   j2 = legs_sum(j2); jd2 = legs_sum(jd2); tn2 = legs_sum(tn2); td2 = legs_sum(td2);
 #pragma unroll
   for (int k = 0; k < 3; k++) L.tql[k] = tn[k];  // ENV:1515 keeps the NORMALISED torque
-  vf EE = P.c_ee * v_exp(-40.0f * ee2);
+  vf EE = P.c_ee * v_exp_fast(-40.0f * ee2);
   vf dz = L.pos.z - P.stand_height;
-  vf BC = P.c_pos * v_exp(-80.0f * (dz * dz));
-  vf BA = P.c_att * v_exp(-80.0f * (L.ob_post[0] * L.ob_post[0] + L.ob_post[1] * L.ob_post[1]));
-  vf JR = P.c_joint * 0.25f * v_exp(-2.0f * j2);
-  vf JD = P.c_joint * 0.75f * v_exp(-P.control_dt * jd2);
+  vf BC = P.c_pos * v_exp_fast(-80.0f * (dz * dz));
+  vf BA = P.c_att * v_exp_fast(-80.0f * (L.ob_post[0] * L.ob_post[0] + L.ob_post[1] * L.ob_post[1]));
+  vf JR = P.c_joint * 0.25f * v_exp_fast(-2.0f * j2);
+  vf JD = P.c_joint * 0.75f * v_exp_fast(-P.control_dt * jd2);
   vf lx = P.wildcat ? -L.cmdf[0] : L.cmdf[0];
   vf e0 = L.bodyLinVel.x - lx, e1 = L.bodyLinVel.y - L.cmdf[1], e2 = L.bodyLinVel.z;
   vf g0 = L.bodyAngVel.x, g1 = L.bodyAngVel.y, g2 = L.bodyAngVel.z - L.cmdf[2];
-  vf VR = P.c_vel / 2.0f * v_exp(-2.0f * (e0 * e0 + e1 * e1 + e2 * e2)) + P.c_vel / 2.0f * v_exp(-2.0f * (g0 * g0 + g1 * g1 + g2 * g2));
-  vf TR = P.c_torque / 2.0f * v_exp(-0.1f * tn2) + P.c_torque / 2.0f * v_exp(-0.1f / P.control_dt * td2);
+  vf VR = P.c_vel / 2.0f * v_exp_fast(-2.0f * (e0 * e0 + e1 * e1 + e2 * e2)) + P.c_vel / 2.0f * v_exp_fast(-2.0f * (g0 * g0 + g1 * g1 + g2 * g2));
+  vf TR = P.c_torque / 2.0f * v_exp_fast(-0.1f * tn2) + P.c_torque / 2.0f * v_exp_fast((-0.1f * P.inv_control_dt) * td2);
   vf phase_l = pick4(P.phase[0], P.phase[1], P.phase[2], P.phase[3], leg);
-  vf rp = v_fmod(env_time(P, L) + phase_l * P.period, P.period) / P.period;
-  vf cr = 4.0f * vel_norm * vel_norm * smooth_function(rp, 2.0f, P.lam) +
-          2.0f * (force_norm / 12.5f) * (force_norm / 12.5f) * smooth_function2(rp, 2.0f, P.lam);
-  vf CR = P.c_contact * v_exp(-2.0f * legs_sum(cr));
+  vf rp = v_fmod_pos(env_time(P, L) + phase_l * P.period, P.period, P.inv_period) * P.inv_period;
+  // smooth_function and smooth_function2 share the raw curve: s1 = clamp(t, 0, 1), s2 = 1 - s1
+  vf sraw = smooth_raw(rp, 2.0f, P.lam, P.inv_lam, P.inv_one_minus_lam);
+  vf s1 = vsel(sraw > 1.0f, 1.0f, vsel(sraw < 0.0f, 0.0f, sraw));
+  vf s2 = vsel(sraw > 1.0f, 0.0f, vsel(sraw < 0.0f, 1.0f, 1.0f - sraw));
+  vf fn = force_norm * (1.0f / 12.5f);
+  vf cr = 4.0f * vel_norm * vel_norm * s1 + 2.0f * fn * fn * s2;
+  vf CR = P.c_contact * v_exp_fast(-2.0f * legs_sum(cr));
   extra[0] = EE; extra[1] = BC; extra[2] = L.pos.z; extra[3] = BA; extra[4] = JR; extra[5] = VR;
   return EE + BC + JR + JD + VR + BA + TR + CR;  // ENV:1546-1547 order
 }
@@ -1687,45 +1727,57 @@ IRRL_DEV void load_lane(const EnvParams &P, const EnvState &S, vi env, vi leg, E
 IRRL_DEV void store_lane(const EnvParams &P, const EnvState &S, vi env, vi leg, vm valid, const EnvLane &L, bool store_model) {
   vi j12 = env * 12 + leg * 3, gcb = env * 19, gvb = env * 18, ob = env * 35;
   vm lead = valid & (leg == 0);
+  // two exec-mask regions (per-leg words, per-env words) instead of one per store
+  IRRL_MASKED_BEGIN(valid)
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    st_if(valid, S.gc, gcb + 7 + leg * 3 + k, L.q[k]); st_if(valid, S.gv, gvb + 6 + leg * 3 + k, L.qd[k]);
-    st_if(valid, S.ptarget_last, j12 + k, L.ptl[k]); st_if(valid, S.torque_last, j12 + k, L.tql[k]); st_if(valid, S.torque, j12 + k, L.tq[k]);
-    st_if(valid, S.joint_ref, j12 + k, L.jr[k]); st_if(valid, S.joint_ref_last, j12 + k, L.jrl[k]); st_if(valid, S.joint_dot_ref, j12 + k, L.jdr[k]);
-    st_if(valid, S.ee_ref, j12 + k, L.eer[k]); st_if(valid, S.lam_w, j12 + k, L.lamw[k]);
-    st_if(lead, S.command, env * 3 + k, L.cmd[k]); st_if(lead, S.command_filtered, env * 3 + k, L.cmdf[k]);
-    st_if(valid, S.ob, ob + 5 + leg * 3 + k, L.ob_q[k]); st_if(valid, S.ob, ob + 17 + leg * 3 + k, L.ob_qd[k]);
-    if (P.obs_filter) { st_if(valid, S.ob_last, ob + 5 + leg * 3 + k, L.obl_q[k]); st_if(valid, S.ob_last, ob + 17 + leg * 3 + k, L.obl_qd[k]); }
-    st_if(lead, S.ob, ob + k, L.ob_cmd[k]); st_if(lead, S.ob, ob + 29 + k, L.ob_post[k]); st_if(lead, S.ob, ob + 32 + k, L.ob_omega[k]);
+    stm(S.gc, gcb + 7 + leg * 3 + k, L.q[k]); stm(S.gv, gvb + 6 + leg * 3 + k, L.qd[k]);
+    stm(S.ptarget_last, j12 + k, L.ptl[k]); stm(S.torque_last, j12 + k, L.tql[k]); stm(S.torque, j12 + k, L.tq[k]);
+    stm(S.joint_ref, j12 + k, L.jr[k]); stm(S.joint_ref_last, j12 + k, L.jrl[k]); stm(S.joint_dot_ref, j12 + k, L.jdr[k]);
+    stm(S.ee_ref, j12 + k, L.eer[k]); stm(S.lam_w, j12 + k, L.lamw[k]);
+    stm(S.ob, ob + 5 + leg * 3 + k, L.ob_q[k]); stm(S.ob, ob + 17 + leg * 3 + k, L.ob_qd[k]);
+    if (P.obs_filter) { stm(S.ob_last, ob + 5 + leg * 3 + k, L.obl_q[k]); stm(S.ob_last, ob + 17 + leg * 3 + k, L.obl_qd[k]); }
   }
-  st_i_if(valid, S.in_contact, env * 4 + leg, L.in_contact); st_if(valid, S.contact, env * 4 + leg, L.contact);
-  if (S.contact_count) st_u_if(valid, S.contact_count, env * 4 + leg, L.ccount);
-  st_if(lead, S.gc, gcb, L.pos.x); st_if(lead, S.gc, gcb + 1, L.pos.y); st_if(lead, S.gc, gcb + 2, L.pos.z);
-  st_if(lead, S.gc, gcb + 3, L.qw); st_if(lead, S.gc, gcb + 4, L.qx); st_if(lead, S.gc, gcb + 5, L.qy); st_if(lead, S.gc, gcb + 6, L.qz);
-  st_if(lead, S.gv, gvb, L.vw.x); st_if(lead, S.gv, gvb + 1, L.vw.y); st_if(lead, S.gv, gvb + 2, L.vw.z);
-  st_if(lead, S.gv, gvb + 3, L.ww.x); st_if(lead, S.gv, gvb + 4, L.ww.y); st_if(lead, S.gv, gvb + 5, L.ww.z);
-  st_if(lead, S.t0, env, L.t0); st_i_if(lead, S.frame_idx, env, L.frame); st_u_if(lead, S.episode, env, L.episode); st_if(lead, S.up_height, env, L.up_height);
-  st_if(lead, S.ob, ob + 3, L.ob_phase[0]); st_if(lead, S.ob, ob + 4, L.ob_phase[1]);
+  stm_i(S.in_contact, env * 4 + leg, L.in_contact); stm(S.contact, env * 4 + leg, L.contact);
+  if (S.contact_count) stm_u(S.contact_count, env * 4 + leg, L.ccount);
+  if (store_model) {
+    stm(S.mass, env * 13 + 1 + leg * 3, L.m.mA); stm(S.mass, env * 13 + 2 + leg * 3, L.m.mT); stm(S.mass, env * 13 + 3 + leg * 3, L.m.mS);
+    vi cb = env * 39;
+    stm(S.com, cb + 3 + leg * 9, L.m.comA.x); stm(S.com, cb + 4 + leg * 9, L.m.comA.y); stm(S.com, cb + 5 + leg * 9, L.m.comA.z);
+    stm(S.com, cb + 6 + leg * 9, L.m.comT.x); stm(S.com, cb + 7 + leg * 9, L.m.comT.y); stm(S.com, cb + 8 + leg * 9, L.m.comT.z);
+    stm(S.com, cb + 9 + leg * 9, L.m.comS.x); stm(S.com, cb + 10 + leg * 9, L.m.comS.y); stm(S.com, cb + 11 + leg * 9, L.m.comS.z);
+  }
+  IRRL_MASKED_END
+  IRRL_MASKED_BEGIN(lead)
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    stm(S.command, env * 3 + k, L.cmd[k]); stm(S.command_filtered, env * 3 + k, L.cmdf[k]);
+    stm(S.ob, ob + k, L.ob_cmd[k]); stm(S.ob, ob + 29 + k, L.ob_post[k]); stm(S.ob, ob + 32 + k, L.ob_omega[k]);
+  }
+  stm(S.gc, gcb, L.pos.x); stm(S.gc, gcb + 1, L.pos.y); stm(S.gc, gcb + 2, L.pos.z);
+  stm(S.gc, gcb + 3, L.qw); stm(S.gc, gcb + 4, L.qx); stm(S.gc, gcb + 5, L.qy); stm(S.gc, gcb + 6, L.qz);
+  stm(S.gv, gvb, L.vw.x); stm(S.gv, gvb + 1, L.vw.y); stm(S.gv, gvb + 2, L.vw.z);
+  stm(S.gv, gvb + 3, L.ww.x); stm(S.gv, gvb + 4, L.ww.y); stm(S.gv, gvb + 5, L.ww.z);
+  stm(S.t0, env, L.t0); stm_i(S.frame_idx, env, L.frame); stm_u(S.episode, env, L.episode); stm(S.up_height, env, L.up_height);
+  stm(S.ob, ob + 3, L.ob_phase[0]); stm(S.ob, ob + 4, L.ob_phase[1]);
   if (P.obs_filter) {
 #pragma unroll
-    for (int k = 0; k < 5; k++) st_if(lead, S.ob_last, ob + k, L.obl_env[k]);
+    for (int k = 0; k < 5; k++) stm(S.ob_last, ob + k, L.obl_env[k]);
 #pragma unroll
-    for (int k = 0; k < 6; k++) st_if(lead, S.ob_last, ob + 29 + k, L.obl_env[5 + k]);
+    for (int k = 0; k < 6; k++) stm(S.ob_last, ob + 29 + k, L.obl_env[5 + k]);
   }
   if (store_model) {
-    st_if(lead, S.material, env * 3, L.m.mu); st_if(lead, S.material, env * 3 + 1, L.m.rest); st_if(lead, S.material, env * 3 + 2, L.m.rest_thr);
-    st_if(lead, S.mass, env * 13, L.m.m0);
-    st_if(valid, S.mass, env * 13 + 1 + leg * 3, L.m.mA); st_if(valid, S.mass, env * 13 + 2 + leg * 3, L.m.mT); st_if(valid, S.mass, env * 13 + 3 + leg * 3, L.m.mS);
+    stm(S.material, env * 3, L.m.mu); stm(S.material, env * 3 + 1, L.m.rest); stm(S.material, env * 3 + 2, L.m.rest_thr);
+    stm(S.mass, env * 13, L.m.m0);
     vi cb = env * 39;
-    st_if(lead, S.com, cb, L.m.com0.x); st_if(lead, S.com, cb + 1, L.m.com0.y); st_if(lead, S.com, cb + 2, L.m.com0.z);
-    st_if(valid, S.com, cb + 3 + leg * 9, L.m.comA.x); st_if(valid, S.com, cb + 4 + leg * 9, L.m.comA.y); st_if(valid, S.com, cb + 5 + leg * 9, L.m.comA.z);
-    st_if(valid, S.com, cb + 6 + leg * 9, L.m.comT.x); st_if(valid, S.com, cb + 7 + leg * 9, L.m.comT.y); st_if(valid, S.com, cb + 8 + leg * 9, L.m.comT.z);
-    st_if(valid, S.com, cb + 9 + leg * 9, L.m.comS.x); st_if(valid, S.com, cb + 10 + leg * 9, L.m.comS.y); st_if(valid, S.com, cb + 11 + leg * 9, L.m.comS.z);
-    st_if(lead, S.thigh_dz, env, L.m.dz);
+    stm(S.com, cb, L.m.com0.x); stm(S.com, cb + 1, L.m.com0.y); stm(S.com, cb + 2, L.m.com0.z);
+    stm(S.thigh_dz, env, L.m.dz);
   }
+  IRRL_MASKED_END
 }
 
-// ENV:1248-1268 + obs scaling ENV:375-393: writes this lane's share of the scaled [N,35] row
+// ENV:1248-1268 + obs scaling ENV:375-393: writes this lane's share of the scaled [N,35] row.  The scaling divides by
+// constants (1, 5 / 35 / 40, 0.7, 3): multiplications by their reciprocals here, one rounding away from the quotient.
 IRRL_DEV void observe_lane(const EnvParams &P, vi env, vi leg, vm valid, EnvLane &L, float *ob_out) {
   vm lead = valid & (leg == 0);
   if (P.obs_filter) {  // filter touches obs[5:35]
@@ -1742,20 +1794,27 @@ IRRL_DEV void observe_lane(const EnvParams &P, vi env, vi leg, vm valid, EnvLane
     L.obl_env[3] = L.ob_phase[0]; L.obl_env[4] = L.ob_phase[1];
   }
   vi ob = env * 35;
-  const float jstd[3] = {5.0f, 35.0f, 40.0f};
+  const float ijstd[3] = {1.0f / 5.0f, 1.0f / 35.0f, 1.0f / 40.0f};
   vf nominal[3] = {L.m.sy * P.abad, -0.78f, 1.57f};
+  IRRL_MASKED_BEGIN(valid)
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    st_if(valid, ob_out, ob + 5 + leg * 3 + k, (L.ob_q[k] - nominal[k]) / 1.0f);
-    st_if(valid, ob_out, ob + 17 + leg * 3 + k, (L.ob_qd[k] - 0.0f) / jstd[k]);
-    st_if(lead, ob_out, ob + 29 + k, (L.ob_post[k] - ((k == 2) ? 1.0f : 0.0f)) / 0.7f);
-    st_if(lead, ob_out, ob + 32 + k, (L.ob_omega[k] - 0.0f) / 3.0f);
+    stm(ob_out, ob + 5 + leg * 3 + k, L.ob_q[k] - nominal[k]);
+    stm(ob_out, ob + 17 + leg * 3 + k, L.ob_qd[k] * ijstd[k]);
   }
-  st_if(lead, ob_out, ob + 0, (L.ob_cmd[0] - (P.Vx + 0.0f) / 2.0f) / 1.0f);
-  st_if(lead, ob_out, ob + 1, (L.ob_cmd[1] - (P.Vy + -P.Vy) / 2.0f) / 1.0f);
-  st_if(lead, ob_out, ob + 2, (L.ob_cmd[2] - (P.Omega + -P.Omega) / 2.0f) / 1.0f);
-  st_if(lead, ob_out, ob + 3, L.ob_phase[0]);
-  st_if(lead, ob_out, ob + 4, L.ob_phase[1]);
+  IRRL_MASKED_END
+  IRRL_MASKED_BEGIN(lead)
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    stm(ob_out, ob + 29 + k, (L.ob_post[k] - ((k == 2) ? 1.0f : 0.0f)) * (1.0f / 0.7f));
+    stm(ob_out, ob + 32 + k, L.ob_omega[k] * (1.0f / 3.0f));
+  }
+  stm(ob_out, ob + 0, L.ob_cmd[0] - (P.Vx + 0.0f) / 2.0f);
+  stm(ob_out, ob + 1, L.ob_cmd[1] - (P.Vy + -P.Vy) / 2.0f);
+  stm(ob_out, ob + 2, L.ob_cmd[2] - (P.Omega + -P.Omega) / 2.0f);
+  stm(ob_out, ob + 3, L.ob_phase[0]);
+  stm(ob_out, ob + 4, L.ob_phase[1]);
+  IRRL_MASKED_END
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1818,14 +1877,26 @@ IRRL_DEV void step_body(const EnvParams &P, const EnvState &S, vi env, vi leg, v
   // (the lane that owns the stores) runs it -- same issue time, a quarter of the active lanes, which is what the
   // power-limited clock of a fully occupied chip responds to.  All cross-leg DPP traffic below is between sub-lanes 0.
   IRRL_SUB0_ONLY_BEGIN
+#ifndef IRRL_AB_NO_OBS
   update_observation(P, L, envu);
+#endif
   vf extra[6];
+#ifndef IRRL_AB_NO_REWARD
   vf rew = reward_update(P, L, extra);
+#else
+  vf rew = L.pos.z;
+  for (int j = 0; j < 6; j++) extra[j] = L.pos.z;
+#endif
+#ifndef IRRL_AB_NO_CMD
   command_obs_update(P, L, envu, false);
+#endif
   contact_obs_update(P, L);
   L.frame = L.frame + 1;
   // VEC:358-371
   vm done = (L.pos.z < 0.15f) | (L.pos.z > 0.65f) | (L.ob_post[2] < 0.5f);
+#ifdef IRRL_AB_NO_RESET
+  done = done & vm(false);
+#endif
   if (wave_any(done & valid)) {
     EnvLane Rn = L;
     reset_lane(P, Rn, envu);
@@ -1834,10 +1905,12 @@ IRRL_DEV void step_body(const EnvParams &P, const EnvState &S, vi env, vi leg, v
   }
   observe_lane(P, env, leg, valid, L, ob_out);
   vm lead = valid & (leg == 0);
-  st_if(lead, reward_out, env, rew);
-  st_u8_if(lead, done_out, env, vsel_i(done, 1, 0));
+  IRRL_MASKED_BEGIN(lead)
+  stm(reward_out, env, rew);
+  stm_u8(done_out, env, vsel_i(done, 1, 0));
 #pragma unroll
-  for (int j = 0; j < 6; j++) st_if(lead, extra_out, env * 6 + j, extra[j]);
+  for (int j = 0; j < 6; j++) stm(extra_out, env * 6 + j, extra[j]);
+  IRRL_MASKED_END
   store_lane(P, S, env, leg, valid, L, P.randomize_per_episode != 0);
   IRRL_SUB0_ONLY_END
 }

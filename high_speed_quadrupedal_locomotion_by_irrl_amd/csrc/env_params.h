@@ -37,6 +37,11 @@ struct EnvParams {
   int32_t state_disturbance;   // Manual + ForceDisturbance: periodic kick of the base state (Environment.hpp:912-940)
   int32_t disturb_every;       // int(period / control_dt * 10) evaluated in double like ENV:747 (in f32, 0.02 / 0.002 * 10 truncates to 99)
   const float *ref;
+  // derived scalars (irrl_host::derive_params): reciprocals and products of the configuration that the per-step epilogue would
+  // otherwise divide by in every lane (an IEEE f32 division is ~10 VALU instructions on gfx950)
+  float inv_control_dt, inv_period, inv_lam, inv_one_minus_lam;
+  float cmd_resample_p;    // 0.5 / (max_time / control_dt), Environment.hpp:1031
+  float two_pi_over_period;
 };
 
 // Device-resident state pool, structure of arrays in the reference's natural row-major shapes so the

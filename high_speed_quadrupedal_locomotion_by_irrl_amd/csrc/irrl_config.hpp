@@ -94,6 +94,16 @@ static const char *const kMandatoryKeys[] = {
     "max_time", "CubeNum", "FPS", "ActionNoise", "ObsNoise", "GaitType", "MotorMaxTorque", "MotorCriticalSpeed",
     "MotorMaxSpeed", "num_envs", "num_threads", "simulation_dt", "control_dt", "seedd"};
 
+// scalars derived from the configuration; call again whenever control_dt / period / lam / max_time change
+inline void derive_params(EnvParams &P) {
+  P.inv_control_dt = 1.0f / P.control_dt;
+  P.inv_period = 1.0f / P.period;
+  P.inv_lam = 1.0f / P.lam;
+  P.inv_one_minus_lam = 1.0f / (1.0f - P.lam);
+  P.cmd_resample_p = 0.5f / (P.max_time / P.control_dt);
+  P.two_pi_over_period = 2.0f * 3.1415926f / P.period;
+}
+
 inline bool build_params(const Config &c, EnvParams &P, std::string &err) {
   for (const char *k : kMandatoryKeys)
     if (!c.has(k)) { err = std::string("Node cfg[\"") + k + "\"] doesn't exist"; return false; }
@@ -161,6 +171,7 @@ inline bool build_params(const Config &c, EnvParams &P, std::string &err) {
     P.disturb_every = cdt > 0.0 ? (int32_t)(period / cdt * 10.0) : 0;
     if (P.disturb_every <= 0) P.state_disturbance = 0;
   }
+  derive_params(P);
   return true;
 }
 

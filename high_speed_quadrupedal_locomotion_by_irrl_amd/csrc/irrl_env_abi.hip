@@ -339,6 +339,7 @@ int irrl_env_set_control_dt(irrl_env *h, double dt) {
   h->P.control_dt = (float)dt;
   h->P.loop_count = (int32_t)(dt / (double)h->P.sim_dt + 1e-6);
   if (h->P.loop_count < 1) h->P.loop_count = 1;
+  irrl_host::derive_params(h->P);
   return 0;
 }
 int irrl_env_close(irrl_env *) { return 0; }
@@ -581,6 +582,20 @@ int irrl_ppo_loss(size_t M, int act_dim, const float *mean, const float *logstd,
   hipStream_t s = (hipStream_t)hip_stream;
   if (act_dim == 12) hipLaunchKernelGGL(irrl_ppo_loss_kernel<12>, dim3((unsigned)n_blocks), dim3(256), 0, s, M, mean, logstd, vpred, actions, returns, old_values, old_neglogp, adv_stats, cliprange, vf_coef, inv_m, d_mean, d_vpred, partials);
   else { g_err = "irrl_ppo_loss: act_dim must be 12"; return 1; }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ---- heads + PPO2 loss in one launch (kernel: csrc/lstm_kernels.hip, irrl_ppo_heads_loss_kernel) ----
+int irrl_ppo_heads_loss(size_t M, int act_dim, int hid, const float *h_pi, const float *h_v, const float *pi_w, const float *pi_b, const float *vf_w,
+                        const float *vf_b, const float *logstd, const float *actions, const float *returns, const float *old_values,
+                        const float *old_neglogp, const float *adv_stats, float cliprange, float vf_coef, float *d_hpi, float *d_hv, float *mean_out,
+                        float *value_out, float *partials, int n_blocks, void *hip_stream) {
+  if (M == 0 || n_blocks <= 0) { g_err = "irrl_ppo_heads_loss: empty batch"; return 1; }
+  if (act_dim != 12 || hid != 48) { g_err = "irrl_ppo_heads_loss: built for 48-unit latents and 12 actions"; return 1; }
+  const float inv_m = 1.0f / (float)M;
+  hipLaunchKernelGGL((irrl_ppo_heads_loss_kernel<12, 48>), dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)hip_stream, M, h_pi, h_v, pi_w, pi_b, vf_w, vf_b,
+                     logstd, actions, returns, old_values, old_neglogp, adv_stats, cliprange, vf_coef, inv_m, d_hpi, d_hv, mean_out, value_out, partials);
   HIP_TRY(hipGetLastError());
   return 0;
 }

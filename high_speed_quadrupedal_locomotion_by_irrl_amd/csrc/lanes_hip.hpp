@@ -90,6 +90,17 @@ IRRL_DEV vf v_acos(vf x) { return acosf(x); }
 IRRL_DEV vf v_exp(vf x) { return expf(x); }
 IRRL_DEV vf v_log(vf x) { return logf(x); }
 IRRL_DEV vf v_fmod(vf x, vf y) { return fmodf(x, y); }
+// exp for the reward terms (arguments <= 0, results compared at 2e-4): v_exp_f32 on x log2(e), ~1e-6 relative
+IRRL_DEV vf v_exp_fast(vf x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+// fmod(x, y) for 0 <= x < 2^10 y, y > 0 with inv_y ~ 1 / y: EXACT like fmodf (x - q y is representable, so the fma does not
+// round; the guessed quotient is corrected by at most one), without fmodf's generic loop
+IRRL_DEV vf v_fmod_pos(vf x, vf y, vf inv_y) {
+  vf q = __builtin_floorf(x * inv_y);
+  vf r = __builtin_fmaf(-q, y, x);
+  r = (r < 0.0f) ? r + y : r;
+  r = (r >= y) ? r - y : r;
+  return r;
+}
 IRRL_DEV vf v_abs(vf x) { return fabsf(x); }
 IRRL_DEV vf v_min(vf a, vf b) { return a < b ? a : b; }   // fmin(a,b) for non-NaN operands
 IRRL_DEV vf v_max(vf a, vf b) { return a > b ? a : b; }
@@ -106,6 +117,13 @@ IRRL_DEV void st(float *p, vi idx, vf v) { p[idx] = v; }
 IRRL_DEV void st_i(int32_t *p, vi idx, vi v) { p[idx] = v; }
 IRRL_DEV void st_u(uint32_t *p, vi idx, vu v) { p[idx] = v; }
 IRRL_DEV void st_u8(uint8_t *p, vi idx, vi v) { p[idx] = (uint8_t)v; }
+// a block executed by the lanes of mask m only (ONE exec-mask region for many stores); stm*: plain stores inside such a block
+#define IRRL_MASKED_BEGIN(m) if (m) {
+#define IRRL_MASKED_END }
+IRRL_DEV void stm(float *p, vi idx, vf v) { p[idx] = v; }
+IRRL_DEV void stm_i(int32_t *p, vi idx, vi v) { p[idx] = v; }
+IRRL_DEV void stm_u(uint32_t *p, vi idx, vu v) { p[idx] = v; }
+IRRL_DEV void stm_u8(uint8_t *p, vi idx, vi v) { p[idx] = (uint8_t)v; }
 // store only from the lanes whose mask is set
 IRRL_DEV void st_if(vm m, float *p, vi idx, vf v) { if (m) p[idx] = v; }
 IRRL_DEV void st_i_if(vm m, int32_t *p, vi idx, vi v) { if (m) p[idx] = v; }

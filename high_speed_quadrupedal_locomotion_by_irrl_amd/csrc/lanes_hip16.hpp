@@ -45,6 +45,7 @@ IRRL_DEV vf legs_sum(vf x) { x += dpp_f<0x124>(x); x += dpp_f<0x128>(x); return 
 IRRL_DEV vi legs_sum_i(vi x) { x += dpp_i<0x124>(x); x += dpp_i<0x128>(x); return x; }
 template <int K> IRRL_DEV vf legs_bcast(vf x) { return dpp_f<0x150 + 4 * K>(x); }          // row_newbcast:4K (sub-lane 0 of leg K)
 template <int K> IRRL_DEV vi legs_bcast_i(vi x) { return dpp_i<0x150 + 4 * K>(x); }
+template <int N> IRRL_DEV vf row_bcast(vf x) { return dpp_f<0x150 + N>(x); }               // row_newbcast:N (lane N of the robot's row)
 template <int D> IRRL_DEV vf legs_rot(vf x) { return dpp_f<0x120 + 4 * D>(x); }            // the leg D quads away (direction immaterial)
 // ---- inside a leg (the four sub-lanes of the quad) ----
 IRRL_DEV vf sub_sum(vf x) { x += dpp_f<0xB1>(x); x += dpp_f<0x4E>(x); return x; }          // quad_perm [1,0,3,2], [2,3,0,1]
@@ -93,6 +94,17 @@ IRRL_DEV vf v_acos(vf x) { return acosf(x); }
 IRRL_DEV vf v_exp(vf x) { return expf(x); }
 IRRL_DEV vf v_log(vf x) { return logf(x); }
 IRRL_DEV vf v_fmod(vf x, vf y) { return fmodf(x, y); }
+// exp for the reward terms (arguments <= 0, results compared at 2e-4): v_exp_f32 on x log2(e), ~1e-6 relative
+IRRL_DEV vf v_exp_fast(vf x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+// fmod(x, y) for 0 <= x < 2^10 y, y > 0 with inv_y ~ 1 / y: EXACT like fmodf (x - q y is representable, so the fma does not
+// round; the guessed quotient is corrected by at most one), without fmodf's generic loop
+IRRL_DEV vf v_fmod_pos(vf x, vf y, vf inv_y) {
+  vf q = __builtin_floorf(x * inv_y);
+  vf r = __builtin_fmaf(-q, y, x);
+  r = (r < 0.0f) ? r + y : r;
+  r = (r >= y) ? r - y : r;
+  return r;
+}
 IRRL_DEV vf v_abs(vf x) { return fabsf(x); }
 IRRL_DEV vf v_min(vf a, vf b) { return a < b ? a : b; }   // fmin(a,b) for non-NaN operands
 IRRL_DEV vf v_max(vf a, vf b) { return a > b ? a : b; }
@@ -109,6 +121,13 @@ IRRL_DEV void st(float *p, vi idx, vf v) { p[idx] = v; }
 IRRL_DEV void st_i(int32_t *p, vi idx, vi v) { p[idx] = v; }
 IRRL_DEV void st_u(uint32_t *p, vi idx, vu v) { p[idx] = v; }
 IRRL_DEV void st_u8(uint8_t *p, vi idx, vi v) { p[idx] = (uint8_t)v; }
+// a block executed by the lanes of mask m only (ONE exec-mask region for many stores); stm*: plain stores inside such a block
+#define IRRL_MASKED_BEGIN(m) if (m) {
+#define IRRL_MASKED_END }
+IRRL_DEV void stm(float *p, vi idx, vf v) { p[idx] = v; }
+IRRL_DEV void stm_i(int32_t *p, vi idx, vi v) { p[idx] = v; }
+IRRL_DEV void stm_u(uint32_t *p, vi idx, vu v) { p[idx] = v; }
+IRRL_DEV void stm_u8(uint8_t *p, vi idx, vi v) { p[idx] = (uint8_t)v; }
 // store only from the lanes whose mask is set
 IRRL_DEV void st_if(vm m, float *p, vi idx, vf v) { if (m) p[idx] = v; }
 IRRL_DEV void st_i_if(vm m, int32_t *p, vi idx, vi v) { if (m) p[idx] = v; }

@@ -160,7 +160,7 @@ class CustomLSTMPolicy(ActorCriticPolicy):
             new.append(s)
         return x, new
 
-    def _run(self, obs_seq, states, masks_seq):
+    def _run(self, obs_seq, states, masks_seq, latents_only=False):
         parts = self._split(states)
         k = len(self.n_lstm)
         if obs_seq.is_cuda and self.two_streams and obs_seq.shape[0] > 1 and not torch.cuda.is_current_stream_capturing():
@@ -179,6 +179,8 @@ class CustomLSTMPolicy(ActorCriticPolicy):
             latent_pi, new_pi = self._stack(self.lstm_pi, obs_seq, parts[:k], masks_seq)
             latent_v, new_v = self._stack(self.lstm_v, obs_seq, parts[k:], masks_seq)
         new = new_pi + new_v
+        if latents_only:
+            return latent_pi, latent_v, torch.cat(new, 1)
         mean = self.pi(latent_pi)
         value = self.vf(latent_v).squeeze(-1)
         return mean, value, torch.cat(new, 1)
@@ -228,6 +230,15 @@ class CustomLSTMPolicy(ActorCriticPolicy):
         computes neglogp / entropy / the clipped objectives and their gradients from these)."""
         mean, value, _ = self._run(obs_seq, states, masks_seq.to(obs_seq.dtype))
         return mean, value
+
+    def latents(self, obs_seq, states, masks_seq):
+        """Train-graph forward up to the heads' inputs: -> (latent_pi, latent_v) [T,N,H]; the heads, the loss and their gradients
+        then run in one launch (ppo2._FusedHeadsLoss, csrc `irrl_ppo_heads_loss`)."""
+        lp, lv, _ = self._run(obs_seq, states, masks_seq.to(obs_seq.dtype), latents_only=True)
+        return lp, lv
+
+    def fused_heads_supported(self, obs):
+        return bool(obs.is_cuda and SBLstm.use_fused and self.n_lstm[-1] == 48 and self.act_dim == 12)
 
     def evaluate(self, obs_seq, states, masks_seq, actions_seq):
         """Train-graph forward: obs [T,N,35], states [N,384] at the rollout start, masks [T,N], actions [T,N,12]

@@ -143,6 +143,16 @@ int irrl_ppo_loss(size_t M, int act_dim, const float *mean, const float *logstd,
                   const float *returns, const float *old_values, const float *old_neglogp, const float *adv_stats, float cliprange,
                   float vf_coef, float *d_mean, float *d_vpred, float *partials, int n_blocks, void *hip_stream);
 
+/* the policy / value heads of CustomLSTMPolicy (run_bp_v5.py:169-176: mean = h_pi W_pi + b_pi, v = h_v w_v + b_v) TOGETHER with the
+ * loss above, forward and backward in one pass: h_pi / h_v [M, hid] are the two stacks' last-layer outputs over the rollout.
+ * Writes d loss / d h_pi, d loss / d h_v [M, hid] (and, if not NULL, mean [M, act] / value [M]) and per-block partial sums
+ * [n_blocks, 4 + act + act + 1 + hid + hid * act] = (pg, vf, kl, clipfrac) | d logstd | d b_pi | d b_v | d w_v | d W_pi [hid][act].
+ * hid = 48, act = 12. */
+int irrl_ppo_heads_loss(size_t M, int act_dim, int hid, const float *h_pi, const float *h_v, const float *pi_w, const float *pi_b, const float *vf_w,
+                        const float *vf_b, const float *logstd, const float *actions, const float *returns, const float *old_values,
+                        const float *old_neglogp, const float *adv_stats, float cliprange, float vf_coef, float *d_hpi, float *d_hv, float *mean_out,
+                        float *value_out, float *partials, int n_blocks, void *hip_stream);
+
 /* synthetic action stream of the benchmark (a = clip(sigma N(0,1), -1, 1) from Philox(seed, stream = env,
  * counter = step)): fills out[n_steps][n_envs][12] (device) for envs env0 .. and steps step0 ..; values depend only on
  * (seed, global env id, step), not on the shape of the request.  tests/ hold the numpy twin. */

@@ -654,6 +654,9 @@ typedef struct {
   real gen_force[NV]; /* last generalized force handed to the integrator (world comps for the base) */
   long gs_sweeps, gs_substeps; /* statistics: contact sweeps executed / substeps */
   long box_hits;               /* statistics: (trunk-box corner, substep) pairs in contact */
+  long box_substeps, box_sweeps; /* substeps with at least one corner in contact, and the sweeps they took */
+  real box_lam[8][3];          /* corner impulses of the previous substep of THIS control step (warm start; base components) */
+  int box_was_active[8];
   robot_model model;
 } env_t;
 
@@ -1034,6 +1037,7 @@ static void physics_substep(orc_env *h, env_t *e, const real *pTarget) {
             for (int cc = 0; cc < NV; cc++) acc += J[la][r][cc] * MiJt[lb][r2][cc];
             G[la][lb][3 * r + r2] = acc;
           }
+  int sweeps_done = 0;
   for (int it = 0; it < c->ContactIterations; it++) {
     real d2 = RC(0), l2 = RC(0);
     for (int l = 0; l < NC; l++) {
@@ -1051,11 +1055,13 @@ static void physics_substep(orc_env *h, env_t *e, const real *pTarget) {
       for (int a = 0; a < 3; a++) { real dd = lamB[l][a] - old[a]; d2 += dd * dd; l2 += lamB[l][a] * lamB[l][a]; }
     }
     /* build-defined early exit (same rule in the kernels, evaluated per wave there) */
-    if (c->ContactTolerance > 0 && d2 <= RC(c->ContactTolerance * c->ContactTolerance) * l2 + RC(1e-20)) { it++; e->gs_sweeps += it; goto gs_done; }
+    if (c->ContactTolerance > 0 && d2 <= RC(c->ContactTolerance * c->ContactTolerance) * l2 + RC(1e-20)) { it++; sweeps_done = it; goto gs_done; }
   }
-  e->gs_sweeps += c->ContactIterations;
+  sweeps_done = c->ContactIterations;
 gs_done:
+  e->gs_sweeps += sweeps_done;
   e->gs_substeps += 1;
+  { int anyb = 0; for (int l = 4; l < NC; l++) anyb |= active[l]; if (anyb) { e->box_substeps += 1; e->box_sweeps += sweeps_done; } }
   for (int l = 0; l < NC; l++) {
     if (l < 4) e->in_contact[l] = active[l];
     if (!active[l]) { if (l < 4) v3_set(e->lam_w[l], RC(0), RC(0), RC(0)); continue; }
@@ -1257,6 +1263,7 @@ int orc_set_ref(orc_env *h, const float *table, int rows, int cols) {
   return 0;
 }
 int orc_num_envs(const orc_env *h) { return h->n; }
+void orc_box_stats(const orc_env *h, long out[3]) { out[0] = out[1] = out[2] = 0; for (int i = 0; i < h->n; i++) { out[0] += h->envs[i].box_hits; out[1] += h->envs[i].box_substeps; out[2] += h->envs[i].box_sweeps; } }
 long orc_box_hits(const orc_env *h) { long t = 0; for (int i = 0; i < h->n; i++) t += h->envs[i].box_hits; return t; }
 int orc_real_bytes(void) { return (int)sizeof(real); }
 

@@ -13,6 +13,8 @@
 // on the GPU this region runs on sub-lane 0 of every leg only; the emulation lets every lane compute (same values)
 #define IRRL_SUB0_ONLY_BEGIN {
 #define IRRL_SUB0_ONLY_END }
+#define IRRL_MASKED_BEGIN(m) { lanes::mask_scope irrl_scope_(m);
+#define IRRL_MASKED_END }
 
 // W lanes emulate ONE robot: W = 4 (one DPP quad per robot, one leg per lane) or W = 16 (one DPP row per robot: the quad
 // (i >> 2) is the leg, the lane inside the quad (i & 3) a sub-lane that splits the leg's work)
@@ -84,6 +86,7 @@ inline vi legs_sum_i(vi x) {
 template <int K> inline vf legs_bcast(vf x) { return vf(x.v[4 * K]); }      // row_newbcast:4K (sub-lane 0 of leg K)
 template <int K> inline vi legs_bcast_i(vi x) { return vi(x.v[4 * K]); }
 // same sub-lane of the leg D quads away (the rotation direction is immaterial to the algorithms built on it)
+template <int N> inline vf row_bcast(vf x) { return vf(x.v[N]); }            // row_newbcast:N
 template <int D> inline vf legs_rot(vf x) { vf r; for (int i = 0; i < 16; i++) r.v[i] = x.v[(i + 4 * D) & 15]; return r; }
 inline vf sub_sum(vf x) {
   vf a, r;
@@ -121,6 +124,18 @@ LANEWISE_FN(v_abs, std::fabs(a)) LANEWISE_FN(v_rsqrt, 1.0f / std::sqrt(a)) LANEW
 inline vi f2i(vf x) { vi r; for (int i = 0; i < W; i++) r.v[i] = (int32_t)x.v[i]; return r; }
 inline void v_sincos(vf x, vf &s, vf &c) { s = v_sin(x); c = v_cos(x); }
 inline vf v_fmod(vf x, vf y) { vf r; for (int i = 0; i < W; i++) r.v[i] = std::fmod(x.v[i], y.v[i]); return r; }
+inline vf v_exp_fast(vf x) { vf r; for (int i = 0; i < W; i++) r.v[i] = std::exp2(x.v[i] * 1.4426950408889634f); return r; }
+inline vf v_fmod_pos(vf x, vf y, vf inv_y) {
+  vf r;
+  for (int i = 0; i < W; i++) {
+    float q = std::floor(x.v[i] * inv_y.v[i]);
+    float t = std::fma(-q, y.v[i], x.v[i]);
+    if (t < 0.0f) t += y.v[i];
+    if (t >= y.v[i]) t -= y.v[i];
+    r.v[i] = t;
+  }
+  return r;
+}
 inline vf v_min(vf a, vf b) { return vsel(a < b, a, b); }
 inline vf v_max(vf a, vf b) { return vsel(a > b, a, b); }
 inline vu to_u(vi x) { vu r; for (int i = 0; i < W; i++) r.v[i] = (uint32_t)x.v[i]; return r; }
@@ -131,6 +146,14 @@ inline vu mulhi_u32(vu a, uint32_t b) { return mulhi_u32(a, vu(b)); }
 inline vf ld(const float *p, vi idx) { vf r; for (int i = 0; i < W; i++) r.v[i] = p[idx.v[i]]; return r; }
 inline vi ld_i(const int32_t *p, vi idx) { vi r; for (int i = 0; i < W; i++) r.v[i] = p[idx.v[i]]; return r; }
 inline vu ld_u(const uint32_t *p, vi idx) { vu r; for (int i = 0; i < W; i++) r.v[i] = p[idx.v[i]]; return r; }
+// masked blocks: the emulation keeps a current lane mask, stm* store under it
+// (internal linkage: the 4- and 16-lane emulation libraries live in one test process and must not share this object)
+static vm &cur_mask() { static thread_local vm m(true); return m; }
+struct mask_scope { vm saved; explicit mask_scope(vm m) : saved(cur_mask()) { cur_mask() = saved & m; } ~mask_scope() { cur_mask() = saved; } };
+inline void stm(float *p, vi idx, vf v) { for (int i = 0; i < W; i++) if (cur_mask().v[i]) p[idx.v[i]] = v.v[i]; }
+inline void stm_i(int32_t *p, vi idx, vi v) { for (int i = 0; i < W; i++) if (cur_mask().v[i]) p[idx.v[i]] = v.v[i]; }
+inline void stm_u(uint32_t *p, vi idx, vu v) { for (int i = 0; i < W; i++) if (cur_mask().v[i]) p[idx.v[i]] = v.v[i]; }
+inline void stm_u8(uint8_t *p, vi idx, vi v) { for (int i = 0; i < W; i++) if (cur_mask().v[i]) p[idx.v[i]] = (uint8_t)v.v[i]; }
 inline void st_if(vm m, float *p, vi idx, vf v) { for (int i = 0; i < W; i++) if (m.v[i]) p[idx.v[i]] = v.v[i]; }
 inline void st_i_if(vm m, int32_t *p, vi idx, vi v) { for (int i = 0; i < W; i++) if (m.v[i]) p[idx.v[i]] = v.v[i]; }
 inline void st_u_if(vm m, uint32_t *p, vi idx, vu v) { for (int i = 0; i < W; i++) if (m.v[i]) p[idx.v[i]] = v.v[i]; }

@@ -350,3 +350,39 @@ def test_kernels_follow_the_optimizer_and_checkpoints_reproduce_the_live_policy(
     model2 = PPO2.load(ck, env=env)
     a_loaded = model2.policy.step(obs, st, dones, deterministic=True)[0]
     assert float((a_loaded - a_fused).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("M", [64 * 5 + 37, 4096 * 8])
+def test_fused_heads_and_loss_gradients_match_autograd(M):
+    """`irrl_ppo_heads_loss` (heads forward, loss, and every gradient in one launch) against torch autograd of the eager heads +
+    ppo_loss on random latents: loss, statistics, d h_pi / d h_v rows, the head weight / bias gradients and d logstd; M not a
+    multiple of the 64-row tile exercises the ragged last tile."""
+    import math
+    from high_speed_quadrupedal_locomotion_by_irrl_amd import ppo2 as P2
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import diag_gaussian_neglogp, diag_gaussian_entropy
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    rn = lambda *s: torch.randn(*s, device=dev, generator=g)
+    h_pi, h_v = rn(M, 48).requires_grad_(), rn(M, 48).requires_grad_()
+    pi_w, pi_b = (0.2 * rn(48, 12)).requires_grad_(), (0.1 * rn(12)).requires_grad_()
+    vf_w, vf_b = (0.2 * rn(48, 1)).requires_grad_(), (0.1 * rn(1)).requires_grad_()
+    logstd = (0.2 * rn(1, 12)).requires_grad_()
+    actions, returns, old_v = rn(M, 12), rn(M), rn(M)
+    with torch.no_grad():
+        old_nlp = diag_gaussian_neglogp(actions, h_pi @ pi_w + pi_b, logstd) + 0.3 * rn(M)
+    advs = returns - old_v
+    stats_t = torch.stack([advs.mean(), advs.std(unbiased=False)]).to(torch.float32)
+    # eager reference
+    mean = h_pi @ pi_w + pi_b
+    v = (h_v @ vf_w + vf_b).squeeze(-1)
+    nadv = (advs - stats_t[0]) / (stats_t[1] + 1e-8)
+    loss_e, pg, vf, ent, kl, cf = P2.ppo_loss(diag_gaussian_neglogp(actions, mean, logstd), v, diag_gaussian_entropy(logstd, mean), actions, nadv,
+                                              returns, old_nlp, old_v, 0.2, 0.01, 0.5)
+    ge = torch.autograd.grad(loss_e, [h_pi, h_v, pi_w, pi_b, vf_w, vf_b, logstd])
+    loss_f, st = P2._FusedHeadsLoss.apply(h_pi, h_v, pi_w, pi_b, vf_w, vf_b, logstd, actions, returns, old_v, old_nlp, stats_t, 0.2, 0.01, 0.5)
+    gf = torch.autograd.grad(loss_f, [h_pi, h_v, pi_w, pi_b, vf_w, vf_b, logstd])
+    assert abs(float(loss_f) - float(loss_e)) < 2e-5 * max(1.0, abs(float(loss_e)))
+    np.testing.assert_allclose(st.cpu().numpy(), torch.stack([pg, vf, ent, kl, cf]).detach().cpu().numpy(), rtol=2e-4, atol=2e-5)
+    for name, a, b in zip(("d_hpi", "d_hv", "d_wpi", "d_bpi", "d_wv", "d_bv", "d_logstd"), gf, ge):
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) < 2e-4 * scale, (name, float((a - b).abs().max()), scale)

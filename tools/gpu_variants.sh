@@ -11,4 +11,9 @@ for f in $V/libirrl_env_*.so; do
   done
 done
 done
+for f in $V/libirrl_env_*.so; do
+  n=$(basename $f .so)
+  IRRL_ENV_LIB=$PWD/$f timeout 300 python tools/ppo_bench.py --policy lstm --envs 4096 --iters 3 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$n ppo rollout', round(d['rollout_s']*1e3,2), 'ms update', round(d['update_s']*1e3,2), 'ms')" >> gpurun_out/variants.log
+  IRRL_ENV_LIB=$PWD/$f timeout 300 python tools/step_cost_split.py 2>/dev/null | tail -1 >> gpurun_out/variants.log
+done
 echo done
