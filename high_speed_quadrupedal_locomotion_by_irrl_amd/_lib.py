@@ -54,6 +54,8 @@ SIGNATURES = {
     "irrl_env_cfg_value": (C.c_double, [vp, C.c_char_p]),
     "irrl_env_counters_host": (C.c_int, [vp, C.POINTER(C.c_ulonglong)]),
     "irrl_env_counters": (C.c_int, [vp, vp]),
+    "irrl_env_snapshot": (C.c_int, [vp]),
+    "irrl_env_restore": (C.c_int, [vp]),
     "irrl_bench_actions": (C.c_int, [C.c_uint, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_float, vp, vp]),
     "irrl_gae": (C.c_int, [C.c_int, C.c_int, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp]),
     "irrl_calib_copy_dword": (C.c_int, [vp, vp, C.c_size_t, vp]),

@@ -36,14 +36,26 @@ def _stub_fn(*a, **k):
 
 
 class _StubUnpickler(pickle.Unpickler):
-    _ROOTS = ("cloudpickle", "gym", "tensorflow", "stable_baselines", "raisim_gym", "flex_gym", "types")
+    """ALLOW-LIST unpickler: a checkpoint only ever needs numpy arrays, plain containers and scalars.  Exactly the globals
+    below resolve to the real thing; every other global a pickle names -- the tensorflow / gym / cloudpickle / stable_baselines
+    objects of a reference checkpoint, but also `os.system`, `builtins.eval` or anything else a crafted file could ask for --
+    becomes an inert stub that ignores its arguments.  Loading a checkpoint can therefore not run foreign code."""
+    _ALLOWED = {
+        ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"),
+        ("numpy._core.multiarray", "scalar"), ("numpy", "ndarray"), ("numpy", "dtype"), ("numpy.core.numeric", "_frombuffer"),
+        ("numpy._core.numeric", "_frombuffer"), ("numpy", "float32"), ("numpy", "float64"), ("numpy", "int32"), ("numpy", "int64"), ("numpy", "bool_"),
+        ("collections", "OrderedDict"), ("_codecs", "encode"),
+        ("builtins", "list"), ("builtins", "dict"), ("builtins", "tuple"), ("builtins", "set"), ("builtins", "frozenset"), ("builtins", "int"),
+        ("builtins", "float"), ("builtins", "bool"), ("builtins", "str"), ("builtins", "bytes"), ("builtins", "bytearray"), ("builtins", "complex"),
+        ("builtins", "slice"), ("builtins", "range"), ("__builtin__", "list"), ("__builtin__", "dict"), ("__builtin__", "tuple"), ("__builtin__", "set"),
+    }
     _FNS = ("CodeType", "code", "_make_skel_func", "_fill_function", "_builtin_type", "_make_cell", "_make_empty_cell",
             "_rehydrate_skeleton_class", "_make_skeleton_class", "subimport")
 
     def find_class(self, module, name):
-        if module.split(".")[0] in self._ROOTS:
-            return _stub_fn if name in self._FNS else _Stub
-        return super().find_class(module, name)
+        if (module, name) in self._ALLOWED:
+            return super().find_class(module, name)
+        return _stub_fn if name in self._FNS else _Stub
 
 
 def read_checkpoint(path):

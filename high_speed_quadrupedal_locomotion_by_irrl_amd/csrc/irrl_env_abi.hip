@@ -58,6 +58,7 @@ struct irrl_env {
   float *d_height = nullptr;  // shared height field (Terrain: True)
   float *d_ref = nullptr;     // reference-trajectory table [rows, 30] (ManualTraj: False)
   uint32_t *d_counters = nullptr;  // [N,4] toe-substeps in contact (EnvState::contact_count, diagnostic)
+  void *d_snapshot = nullptr;      // shadow copy of the pool (irrl_env_snapshot / irrl_env_restore), allocated on first use
   std::vector<float> h_height;
   // pinned host staging
   char *h_pinned = nullptr;
@@ -190,6 +191,7 @@ void irrl_env_destroy(irrl_env *h) {
   if (h->d_height) (void)hipFree(h->d_height);
   if (h->d_ref) (void)hipFree(h->d_ref);
   if (h->d_counters) (void)hipFree(h->d_counters);
+  if (h->d_snapshot) (void)hipFree(h->d_snapshot);
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
   delete h;
 }
@@ -439,6 +441,24 @@ int irrl_env_heightfield_host(irrl_env *h, float *out, int *nx, int *ny) {
   if (ny) *ny = h->P.hf_ny;
   if (!h->P.terrain) { g_err = "this pool runs on the plane z = 0 (Terrain: False)"; return 1; }
   if (out) std::memcpy(out, h->h_height.data(), h->h_height.size() * sizeof(float));
+  return 0;
+}
+// device-side snapshot of the whole state pool and its restoration, stream-ordered on the pool's stream (no host copy): lets a
+// caller run throw-away steps (e.g. the warm-up before a hipGraph capture) and continue from where it was
+int irrl_env_snapshot(irrl_env *h) {
+  if (need_init(h)) return 1;
+  if (use_device(h)) return 1;
+  if (!h->d_snapshot) HIP_TRY(hipMalloc(&h->d_snapshot, h->pool.bytes + (size_t)h->P.n_envs * 16));
+  HIP_TRY(hipMemcpyAsync(h->d_snapshot, h->d_pool, h->pool.bytes, hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync((char *)h->d_snapshot + h->pool.bytes, h->d_counters, (size_t)h->P.n_envs * 16, hipMemcpyDeviceToDevice, h->stream));
+  return 0;
+}
+int irrl_env_restore(irrl_env *h) {
+  if (need_init(h)) return 1;
+  if (use_device(h)) return 1;
+  if (!h->d_snapshot) { g_err = "irrl_env_restore: no snapshot has been taken"; return 1; }
+  HIP_TRY(hipMemcpyAsync(h->d_pool, h->d_snapshot, h->pool.bytes, hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->d_counters, (char *)h->d_snapshot + h->pool.bytes, (size_t)h->P.n_envs * 16, hipMemcpyDeviceToDevice, h->stream));
   return 0;
 }
 // stream-ordered variant: sums into d_out[3] (device, unsigned long long) on the pool's stream, no host synchronisation

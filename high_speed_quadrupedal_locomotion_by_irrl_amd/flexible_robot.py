@@ -60,6 +60,9 @@ class FlexibleGymEnv(object):
         if not self._h:
             raise RuntimeError("FlexibleGymEnv: " + _lib.last_error())
         self._n = self._lib.irrl_env_num_envs(self._h)
+        # bumped by every setter whose value is a BY-VALUE kernel argument (seed, time steps, reference table): a captured
+        # hipGraph of step launches has those arguments frozen, its owner compares epochs and re-captures (ppo2.Runner)
+        self.params_epoch = 0
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -125,6 +128,7 @@ class FlexibleGymEnv(object):
 
     def setSeed(self, seed):
         _lib.check(self._lib.irrl_env_set_seed(self._h, int(seed)))
+        self.params_epoch += 1
 
     def close(self):
         _lib.check(self._lib.irrl_env_close(self._h))
@@ -139,9 +143,11 @@ class FlexibleGymEnv(object):
 
     def setSimulationTimeStep(self, dt):
         _lib.check(self._lib.irrl_env_set_simulation_dt(self._h, float(dt)))
+        self.params_epoch += 1
 
     def setControlTimeStep(self, dt):
         _lib.check(self._lib.irrl_env_set_control_dt(self._h, float(dt)))
+        self.params_epoch += 1
 
     def getObDim(self):
         return self._lib.irrl_env_ob_dim(self._h)
@@ -229,6 +235,7 @@ class FlexibleGymEnv(object):
         table = np.ascontiguousarray(table, dtype=np.float32)
         assert table.ndim == 2
         _lib.check(self._lib.irrl_env_set_ref_host(self._h, table.ctypes.data_as(_fp), table.shape[0], table.shape[1]))
+        self.params_epoch += 1
 
     def heightfield(self):
         """[5000, 500] float32 height field of a Terrain: True pool (None on flat ground)."""
@@ -238,6 +245,15 @@ class FlexibleGymEnv(object):
         out = np.zeros((nx.value, ny.value), np.float32)
         _lib.check(self._lib.irrl_env_heightfield_host(self._h, out.ctypes.data_as(_fp), C.byref(nx), C.byref(ny)))
         return out
+
+    def snapshot(self):
+        """device copy of the whole state pool (stream-ordered on torch's current stream); `restore()` puts it back"""
+        self._sync_stream()
+        _lib.check(self._lib.irrl_env_snapshot(self._h))
+
+    def restore(self):
+        self._sync_stream()
+        _lib.check(self._lib.irrl_env_restore(self._h))
 
     def counters(self):
         """(episodes started, toe-substeps in contact, sum of frame_idx) summed over the pool -- diagnostic, synchronises."""

@@ -262,6 +262,15 @@ class MlpPolicy(ActorCriticPolicy):
         self.q = SBLinear(dims[-1], act_dim, init_scale=0.01)
         self.act_dim = act_dim
 
+    def sb_parameters(self):
+        """stable-baselines variable order of a FeedForwardPolicy with net_arch [dict(vf=[64,64], pi=[64,64])] (archi/policies.py:79-88:
+        pi_fc{i} then vf_fc{i} per layer; then vf, pi, logstd, q): lets reference MLP pickles load and this build's load there."""
+        out = []
+        for lp, lv in zip(self.pi_fc, self.vf_fc):
+            out += [lp.w, lp.b, lv.w, lv.b]
+        out += [self.vf.w, self.vf.b, self.pi.w, self.pi.b, self.logstd, self.q.w, self.q.b]
+        return out
+
     def _run(self, obs):
         p = obs
         for l in self.pi_fc:

@@ -192,6 +192,7 @@ class Runner(object):
         self.t_idx = torch.zeros(1, dtype=torch.long, device=dev)     # device row counter of the generic (per-step graph) path
         self.use_graph = (dev.type == "cuda") if use_graph is None else bool(use_graph)
         self._graph = None
+        self._graph_epoch = 0
         # sampling noise: the model's seeded generator; under graph capture it is registered with the graph
         self._gen = model.generator
         # single-launch policy step + raw env step when the policy / env pair supports it (LSTM policy on the GPU)
@@ -248,9 +249,16 @@ class Runner(object):
     def _maybe_capture(self):
         """Capture `_one_step` into a hipGraph (torch.cuda.CUDAGraph) after a short warm-up on a side stream.  The env
         kernel is launched through the C-ABI on torch's current stream, so it is recorded like any torch op."""
+        raw = getattr(self.env, "wrapper", None)
+        epoch = getattr(raw, "params_epoch", 0)
+        if self._graph is not None and epoch != self._graph_epoch:
+            # a setter changed a by-value kernel argument (seed, time steps, reference table) after the capture: the recorded
+            # launches still carry the old values -> drop the graph and record the rollout again
+            self._graph = None
         if self._graph is not None or not self.use_graph:
             return
         dev = self.model.device
+        self._graph_epoch = epoch
         try:
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
@@ -259,8 +267,19 @@ class Runner(object):
             stat_names = ("ep_ret", "ep_len", "finished_ret_sum", "finished_len_sum", "finished_count")
             stats = [(getattr(self.env, k), getattr(self.env, k).clone()) for k in stat_names if hasattr(self.env, k)]
             with torch.cuda.stream(side):
+                # the warm-up steps must leave no trace: the first rollout starts from env.reset() like the reference Runner and
+                # like the eager (use_graph=False) path.  The env pool is snapshotted on the device and put back, so are the
+                # runner's own tensors; the buffer rows the warm-up wrote are overwritten by the rollout.
+                can_restore = hasattr(raw, "snapshot")
+                if can_restore:
+                    raw.snapshot()
+                keep = [(t, t.clone()) for t in (self.obs, self.states, self.dones, self.rew)]
                 for i in range(3):
                     self._fused_step(min(i, self.n_steps - 1)) if self._fused else self._one_step()
+                if can_restore:
+                    raw.restore()
+                    for live, saved in keep:
+                        live.copy_(saved)
                 for live, saved in stats:
                     live.copy_(saved)
             torch.cuda.current_stream(dev).wait_stream(side)
@@ -583,12 +602,14 @@ class PPO2(object):
         pk = data.get("policy_kwargs") or {}
         n_lstm = pk.get("n_lstm", [48, 48])
         is_lstm = len(params) == 19 or data.get("policy") in ("CustomLSTMPolicy",)
+        if is_lstm and len(params) == 19:
+            n_lstm = [int(np.asarray(params[1]).shape[0]), int(np.asarray(params[4]).shape[0])]   # wh of the two actor layers: [h, 4h]
         policy = CustomLSTMPolicy(n_lstm=n_lstm) if is_lstm else MlpPolicy()
         hp = {k: data[k] for k in ("gamma", "n_steps", "ent_coef", "vf_coef", "max_grad_norm", "lam", "nminibatches", "noptepochs")
               if k in data and isinstance(data[k], (int, float))}
         for k in ("learning_rate", "cliprange"):
             hp[k] = data[k] if isinstance(data.get(k), float) else {"learning_rate": 1e-3, "cliprange": 0.2}[k]
         hp.update(kwargs)
-        model = cls(policy=policy, env=env, device=device, **hp)
+        model = cls(policy=policy, env=env, device=device, policy_kwargs={"n_lstm": list(n_lstm)} if is_lstm else None, **hp)
         model.load_parameters(params)
         return model

@@ -118,6 +118,10 @@ int irrl_env_set_ref_host(irrl_env *h, const float *table, int rows, int cols);
 /* the shared height field of a `Terrain: True` pool (Environment.hpp:254-264), [nx, ny] row-major f32; out may be NULL
  * to query the shape only; returns non-zero on flat ground */
 int irrl_env_heightfield_host(irrl_env *h, float *out, int *nx, int *ny);
+/* device-side snapshot of the whole state pool / its restoration, stream-ordered on the pool's stream: a caller can run
+ * throw-away steps (the warm-up in front of a hipGraph capture of the rollout) and continue from where it was */
+int irrl_env_snapshot(irrl_env *h);
+int irrl_env_restore(irrl_env *h);
 /* diagnostic counters summed over the pool (the role of the per-env members itera / contact list sizes a reference user would
  * print, Environment.hpp:554, 1199-1243): out[0] = episodes started (init + every reset), out[1] = toe-substeps spent in the
  * contact list since create(), out[2] = sum of frame_idx.  Synchronises the pool's stream.  bench.py differences them around

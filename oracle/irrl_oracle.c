@@ -673,6 +673,10 @@ struct orc_env {
   float *height; /* NULL = flat ground */
   float *ref;    /* reference-trajectory table [ref_rows, 30] (ManualTraj: False), NULL otherwise */
   int ref_rows;
+  /* contact-problem probe (tests): the last substep's toe contact problem of env `probe_env` (-1: off) */
+  int probe_env;
+  double probe_G[12 * 12], probe_cfree[12], probe_n[12], probe_vstar[4], probe_lam[12];
+  int probe_active[4];
 };
 
 static real env_time(const orc_env *h, const env_t *e) { return e->t0 + RC(e->frame_idx) * RC(h->cfg.control_dt); }
@@ -1062,6 +1066,19 @@ gs_done:
   e->gs_sweeps += sweeps_done;
   e->gs_substeps += 1;
   { int anyb = 0; for (int l = 4; l < NC; l++) anyb |= active[l]; if (anyb) { e->box_substeps += 1; e->box_sweeps += sweeps_done; } }
+  if (h->probe_env >= 0 && e == &h->envs[h->probe_env]) {   /* tests: hand out the toe contact problem and its solution */
+    for (int la = 0; la < 4; la++) {
+      h->probe_active[la] = active[la];
+      h->probe_vstar[la] = active[la] ? R_TO_DOUBLE(vstar[la]) : 0.0;
+      for (int r = 0; r < 3; r++) {
+        h->probe_cfree[3 * la + r] = active[la] ? R_TO_DOUBLE(cfree[la][r]) : 0.0;
+        h->probe_n[3 * la + r] = active[la] ? R_TO_DOUBLE(nBl[la][r]) : 0.0;
+        h->probe_lam[3 * la + r] = R_TO_DOUBLE(lamB[la][r]);
+        for (int lb = 0; lb < 4; lb++) for (int r2 = 0; r2 < 3; r2++)
+          h->probe_G[(3 * la + r) * 12 + 3 * lb + r2] = (active[la] && active[lb]) ? R_TO_DOUBLE(G[la][lb][3 * r + r2]) : 0.0;
+      }
+    }
+  }
   for (int l = 0; l < NC; l++) {
     if (l < 4) e->in_contact[l] = active[l];
     if (!active[l]) { if (l < 4) v3_set(e->lam_w[l], RC(0), RC(0), RC(0)); continue; }
@@ -1228,6 +1245,7 @@ orc_env *orc_create(const orc_cfg *cfg) {
   if (!cfg || cfg->num_envs <= 0) return NULL;
   if (cfg->Crutial) return NULL; /* row not built */
   orc_env *h = (orc_env *)calloc(1, sizeof(orc_env));
+  if (h) h->probe_env = -1;
   h->cfg = *cfg;
   if (h->cfg.ContactIterations <= 0) h->cfg.ContactIterations = 6;
   h->n = cfg->num_envs;
@@ -1264,6 +1282,11 @@ int orc_set_ref(orc_env *h, const float *table, int rows, int cols) {
 }
 int orc_num_envs(const orc_env *h) { return h->n; }
 void orc_box_stats(const orc_env *h, long out[3]) { out[0] = out[1] = out[2] = 0; for (int i = 0; i < h->n; i++) { out[0] += h->envs[i].box_hits; out[1] += h->envs[i].box_substeps; out[2] += h->envs[i].box_sweeps; } }
+void orc_set_probe(orc_env *h, int env_id) { h->probe_env = env_id; }
+void orc_get_probe(const orc_env *h, double *G, double *cfree, double *n, double *vstar, double *lam, int *active) {
+  memcpy(G, h->probe_G, sizeof(h->probe_G)); memcpy(cfree, h->probe_cfree, sizeof(h->probe_cfree)); memcpy(n, h->probe_n, sizeof(h->probe_n));
+  memcpy(vstar, h->probe_vstar, sizeof(h->probe_vstar)); memcpy(lam, h->probe_lam, sizeof(h->probe_lam)); memcpy(active, h->probe_active, sizeof(h->probe_active));
+}
 long orc_box_hits(const orc_env *h) { long t = 0; for (int i = 0; i < h->n; i++) t += h->envs[i].box_hits; return t; }
 int orc_real_bytes(void) { return (int)sizeof(real); }
 

@@ -139,6 +139,11 @@ void orc_terrain_sample(const orc_env *h, double x, double y, double out[4]);
 double orc_mean_contact_sweeps(const orc_env *h);
 /* (trunk-box corner, substep) pairs in contact since orc_init, summed over the envs (ENV:242 collision body "body/0") */
 long orc_box_hits(const orc_env *h);
+/* tests: capture the toe contact problem of env `env_id` in every substep (-1: off) and read the last one back:
+ * G [12,12] Delassus blocks (base components), cfree [4,3], unit normals [4,3], target normal speeds [4], the solved impulses
+ * [4,3] and the active flags [4]; rows / columns of inactive toes are zero */
+void orc_set_probe(orc_env *h, int env_id);
+void orc_get_probe(const orc_env *h, double *G, double *cfree, double *n, double *vstar, double *lam, int *active);
 
 #ifdef __cplusplus
 }

@@ -183,6 +183,20 @@ class OracleVecEnv(object):
         self.lib.orc_terrain_sample(self.h, float(x), float(y), out)
         return np.array(out[:])
 
+    def contact_probe(self, env_id):
+        """switch the contact-problem capture to env `env_id` (None: read the last captured problem back)"""
+        self.lib.orc_set_probe.argtypes = [C.c_void_p, C.c_int]
+        self.lib.orc_set_probe.restype = None
+        self.lib.orc_set_probe(self.h, int(env_id))
+
+    def contact_problem(self):
+        G, cf, n, vs, lam = np.zeros((12, 12)), np.zeros((4, 3)), np.zeros((4, 3)), np.zeros(4), np.zeros((4, 3))
+        act = np.zeros(4, np.int32)
+        self.lib.orc_get_probe.argtypes = [C.c_void_p] + [C.POINTER(C.c_double)] * 5 + [C.POINTER(C.c_int)]
+        self.lib.orc_get_probe.restype = None
+        self.lib.orc_get_probe(self.h, _dp(G), _dp(cf), _dp(n), _dp(vs), _dp(lam), act.ctypes.data_as(C.POINTER(C.c_int)))
+        return dict(G=G, cfree=cf, n=n, vstar=vs, lam=lam, active=act.astype(bool))
+
     def box_hits(self):
         self.lib.orc_box_hits.restype = C.c_long
         self.lib.orc_box_hits.argtypes = [C.c_void_p]

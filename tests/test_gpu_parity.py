@@ -225,14 +225,26 @@ def test_manual_eval_mode_with_state_disturbance():
     assert np.array_equal(ob[1:], ob0[1:]) and not np.array_equal(ob[0], ob0[0])
 
 
+# sim-to-sim table of the RaiSim-trained bp5_155 controller in THIS physics (profiles/r01_sim2sim_reference_policy.log, oracle):
+# command -> measured mean v_x over the last 2 s, and the regression band.  4-5 m/s commands saturate at 3.6-3.8 m/s because the
+# joint torques sit on the motor clamp of the evaluation config (18 N m, knee x 1.55 = 27.9 N m: tools/sim2sim sweep, DESIGN
+# section 3): with MotorMaxTorque 30 the same controller reaches 4.0 / 4.8 m/s; friction (mu 0.6 -> 1.0) and the motor speed
+# limits do not move it.
+SIM2SIM_BANDS = ((0.5, 0.45, 0.58), (1.0, 0.9, 1.15), (2.0, 1.85, 2.2), (3.0, 2.5, 3.2), (4.0, 3.4, 4.1), (5.0, 3.2, 4.2), (-1.0, -0.9, -0.55))
+
+
 def test_raisim_trained_policy_trots_in_the_hip_kernels():
     """Sim-to-sim through the C-ABI: the reference's RaiSim-trained bp5_155 actor drives one Manual-mode env of the HIP engine
-    (evaluation config rsc/bp5_manual_eval.yaml): no fall in 4 s, commanded speed tracked (1 and 3 m/s)."""
+    (evaluation config rsc/bp5_manual_eval.yaml): no fall in 4 s at any command from -1 to 5 m/s, speed inside the regression
+    band of the table above; with the torque clamp raised to 30 N m the 5 m/s command is tracked to better than 10 %."""
     cfg = load_env_cfg("bp5_manual_eval.yaml")
-    for cmd, lo, hi in ((1.0, 0.9, 1.15), (3.0, 2.5, 3.2)):
+    for cmd, lo, hi in SIM2SIM_BANDS:
         vx, falls = PL.closed_loop_reference_policy(_hip(cfg), cfg, cmd, 2000)
-        assert falls == 0
+        assert falls == 0, cmd
         assert lo < vx[1000:].mean() < hi, (cmd, vx[1000:].mean())
+    strong = dict(cfg, MotorMaxTorque=30.0)
+    vx, falls = PL.closed_loop_reference_policy(_hip(strong), strong, 5.0, 2000)
+    assert falls == 0 and 4.5 < vx[1000:].mean() < 5.2, vx[1000:].mean()
 
 
 def test_trained_policy_closed_loop_statistics_match_the_oracle():

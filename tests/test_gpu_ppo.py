@@ -386,3 +386,27 @@ def test_fused_heads_and_loss_gradients_match_autograd(M):
     for name, a, b in zip(("d_hpi", "d_hv", "d_wpi", "d_bpi", "d_wv", "d_bv", "d_logstd"), gf, ge):
         scale = float(b.abs().max()) + 1e-12
         assert float((a - b).abs().max()) < 2e-4 * scale, (name, float((a - b).abs().max()), scale)
+
+
+def test_graph_capture_warmup_leaves_no_trace_and_setters_invalidate_the_graph():
+    """(a) The three warm-up steps in front of the hipGraph capture are undone (device snapshot of the env pool + the runner's
+    tensors): the FIRST rollout of a graph runner equals the eager runner's bit for bit, i.e. it starts from env.reset().
+    (b) A setter that changes a by-value kernel argument after the capture (setSeed) is not silently ignored: the runner
+    re-captures, and its next rollout again equals the eager runner's that saw the same setSeed."""
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import CustomLSTMPolicy
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.ppo2 import PPO2, Runner
+    out = {}
+    for graph in (True, False):
+        env = _env(64)
+        model = PPO2(policy=CustomLSTMPolicy, env=env, n_steps=20, nminibatches=1, noptepochs=1, seed=9)
+        runner = Runner(env, model, 20, 0.99, 0.998, use_graph=graph)
+        b1 = {k: v.clone() for k, v in runner.run().items() if torch.is_tensor(v)}
+        assert (runner._graph is not None) == graph
+        env.wrapper.setSeed(77)                       # new noise / command streams from the next reset on
+        b2 = {k: v.clone() for k, v in runner.run().items() if torch.is_tensor(v)}
+        b3 = {k: v.clone() for k, v in runner.run().items() if torch.is_tensor(v)}
+        out[graph] = (b1, b2, b3)
+    for i in range(3):
+        for k in ("obs", "actions", "values", "true_reward", "masks"):
+            assert torch.equal(out[True][i][k], out[False][i][k]), (i, k)
+    assert not torch.equal(out[True][1]["obs"], out[True][0]["obs"])
