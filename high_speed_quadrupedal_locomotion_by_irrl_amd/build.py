@@ -4,6 +4,11 @@
 
 hipcc cross-compiles without a GPU; the only target is gfx950 (MI355X / CDNA4).
 
+The env kernels do not go through the compiler driver in one piece: their device code is compiled to assembly, passed
+through isa_pass.py (wait states for the hand-placed v_fmac_f32_dpp instructions, which the compiler cannot see through
+inline assembly), assembled, linked and bundled by the same LLVM tools the driver would call, and the host half is compiled
+with that device binary embedded (`compile_env_unit`).  Kernel registration and launches are the ordinary HIP ones.
+
 Staleness is decided by CONTENT, not by file times: a sha256 over every source under csrc/, include/irrl_env.h and
 the compiler flags is baked into the library (`irrl_version()` = "gfx950;irrl-env r2;irrl-src-hash:<hex>"); a
 prebuilt `.so` is reused only when the hash found inside it equals the hash of the sources next to it.  (File times
@@ -42,10 +47,41 @@ COMMON_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unu
 ENV_FLAGS = ["-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 
 
+def llvm_bin():
+    for cand in (os.environ.get("ROCM_LLVM_BIN"), "/opt/rocm/lib/llvm/bin"):
+        if cand and os.path.exists(os.path.join(cand, "clang")):
+            return cand
+    raise RuntimeError("ROCm LLVM tools not found (expected /opt/rocm/lib/llvm/bin)")
+
+
+def compile_env_unit(src, flags, obj, workdir, verbose=False):
+    """env_kernels.hip -> host object with the gfx950 code embedded, through the ISA pass:
+    device assembly (hipcc -S) -> isa_pass -> assemble -> link -> offload bundle -> host compile with the bundle included."""
+    from . import isa_pass
+    tag = os.path.splitext(os.path.basename(obj))[0]
+    s_raw, s_fix = os.path.join(workdir, tag + ".raw.s"), os.path.join(workdir, tag + ".s")
+    dev_o, dev_out, fatbin = os.path.join(workdir, tag + ".dev.o"), os.path.join(workdir, tag + ".dev.out"), os.path.join(workdir, tag + ".hipfb")
+    ll = llvm_bin()
+    cmds = [[hipcc()] + flags + ["--cuda-device-only", "-S", src, "-o", s_raw]]
+    run = lambda c: (print(" ".join(c)) if verbose else None, subprocess.check_call(c, stderr=subprocess.DEVNULL if not verbose else None))
+    run(cmds[0])
+    stats = isa_pass.process_file(s_raw, s_fix)
+    if verbose:
+        print("[isa_pass] %s: %s" % (tag, stats))
+    run([os.path.join(ll, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", s_fix, "-o", dev_o])
+    run([os.path.join(ll, "lld"), "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-o", dev_out, dev_o])
+    run([os.path.join(ll, "clang-offload-bundler"), "-type=o", "-bundle-align=4096",
+         "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950", "-input=/dev/null", "-input=" + dev_out, "-output=" + fatbin])
+    run([hipcc()] + flags + ["--cuda-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", fatbin, "-c", src, "-o", obj])
+    return stats
+
+
 def source_hash(extra_flags=(), csrc=None, header=None):
     """sha256 over (file name, file bytes) of every dependency + the flag lists, first 16 hex digits"""
     csrc = csrc or CSRC
     h = hashlib.sha256()
+    with open(os.path.join(_HERE, "isa_pass.py"), "rb") as f:
+        h.update(b"isa_pass.py\0" + f.read())
     for name in sources(csrc):
         h.update(name.encode() + b"\0")
         with open(os.path.join(csrc, name), "rb") as f:
@@ -81,22 +117,26 @@ def build(force=False, verbose=False, extra_flags=()):
         return LIB
     if verbose:
         print("[build] compiling %s (source hash %s, library has %s)" % (os.path.basename(LIB), want, embedded_hash()))
-    common = [hipcc()] + COMMON_FLAGS + list(extra_flags)
+    common = COMMON_FLAGS + list(extra_flags)
     objdir = os.path.join(_HERE, "csrc", "_obj")
     os.makedirs(objdir, exist_ok=True)
-    # the env kernels in both lane layouts (same source, different lane-primitive header), then the C-ABI + LSTM kernels
+    # the env kernels in both lane layouts (same source, different lane-primitive header) through the ISA pass, then the
+    # C-ABI + LSTM kernels through the plain driver
     units = [("env_kernels.hip", ["-DIRRL_LANES_PER_ROBOT=16"] + ENV_FLAGS, "env_kernels_l16.o"),
              ("env_kernels.hip", ["-DIRRL_LANES_PER_ROBOT=4"] + ENV_FLAGS, "env_kernels_l4.o"),
              ("irrl_env_abi.hip", ['-DIRRL_SRC_HASH="%s"' % want], "irrl_env_abi.o")]
-    procs = []
-    for src, flags, obj in units:
-        cmd = common + flags + ["-c", os.path.join(CSRC, src), "-o", os.path.join(objdir, obj)]
-        if verbose:
-            print(" ".join(cmd))
-        procs.append(subprocess.Popen(cmd))
-    for p in procs:
-        if p.wait() != 0:
-            raise RuntimeError("hipcc failed")
+    from concurrent.futures import ThreadPoolExecutor
+    def one(u):
+        src, flags, obj = u
+        if src == "env_kernels.hip":
+            compile_env_unit(os.path.join(CSRC, src), common + flags, os.path.join(objdir, obj), objdir, verbose)
+        else:
+            cmd = [hipcc()] + common + flags + ["-c", os.path.join(CSRC, src), "-o", os.path.join(objdir, obj)]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+    with ThreadPoolExecutor(3) as ex:
+        list(ex.map(one, units))
     link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + [os.path.join(objdir, u[2]) for u in units] + ["-o", LIB]
     if verbose:
         print(" ".join(link))

@@ -837,7 +837,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
   const vf ci0 = live * PICK3(D.Ci.xx, D.Ci.xy, D.Ci.xz), ci1 = live * PICK3(D.Ci.xy, D.Ci.yy, D.Ci.yz), ci2 = live * PICK3(D.Ci.xz, D.Ci.yz, D.Ci.zz);
   vf Xs[6];
 #pragma unroll
-  for (int i = 0; i < 6; i++) Xs[i] = sub_bcast<0>(Bs[i]) * ci0 + sub_bcast<1>(Bs[i]) * ci1 + sub_bcast<2>(Bs[i]) * ci2;
+  for (int i = 0; i < 6; i++) Xs[i] = sub_bcast_fma<2>(Bs[i], ci2, sub_bcast_fma<1>(Bs[i], ci1, sub_bcast<0>(Bs[i]) * ci0));
   IRRL_MARK("schur");
   // whole-robot composite -> base block A; Schur complement S = A - sum_legs sum_sub X[:,s] B[:,s]^T
   vf mtot = L.m.m0 + sub_bcast<0>(legs_sum(mc));
@@ -933,7 +933,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
   for (int i = 0; i < 6; i++) xb[i] = -D.bias_b[i] - legs_sum(sub_sum(Xs[i] * rl_s));
   l6_fwd(D.L6, xb);
   l6_bwd(D.L6, xb);
-  vf xl_s = ci0 * sub_bcast<0>(rl_s) + ci1 * sub_bcast<1>(rl_s) + ci2 * sub_bcast<2>(rl_s);   // row `sub` of C^-1 (symmetric)
+  vf xl_s = sub_bcast_fma<2>(rl_s, ci2, sub_bcast_fma<1>(rl_s, ci1, ci0 * sub_bcast<0>(rl_s)));   // row `sub` of C^-1 (symmetric)
 #pragma unroll
   for (int i = 0; i < 6; i++) xl_s -= Xs[i] * xb[i];
   vf ub[6];
@@ -972,8 +972,9 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     jb[3] = PICK3(vf(0.0f), -x.z, x.y); jb[4] = PICK3(x.z, vf(0.0f), -x.x); jb[5] = PICK3(-x.y, x.x, vf(0.0f));
     // K row = Jb row - Jl row . D, Y row = L^-1 K row
     vf Yr[6];
+    const vf njl0 = -jl0, njl1 = -jl1, njl2 = -jl2;
 #pragma unroll
-    for (int i = 0; i < 6; i++) Yr[i] = jb[i] - (jl0 * sub_bcast<0>(Xs[i]) + jl1 * sub_bcast<1>(Xs[i]) + jl2 * sub_bcast<2>(Xs[i]));
+    for (int i = 0; i < 6; i++) Yr[i] = sub_bcast_fma<2>(Xs[i], njl2, sub_bcast_fma<1>(Xs[i], njl1, sub_bcast_fma<0>(Xs[i], njl0, jb[i])));
     l6_fwd(D.L6, Yr);
     // JC row = Jl row . C^-1
     vf jc0 = jl0 * D.Ci.xx + jl1 * D.Ci.xy + jl2 * D.Ci.xz, jc1 = jl0 * D.Ci.xy + jl1 * D.Ci.yy + jl2 * D.Ci.yz, jc2 = jl0 * D.Ci.xz + jl1 * D.Ci.yz + jl2 * D.Ci.zz;
@@ -997,7 +998,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     // contact-point velocity rows: before the step (restitution) and free
     vf ul0 = sub_bcast<0>(ul_s), ul1 = sub_bcast<1>(ul_s), ul2 = sub_bcast<2>(ul_s);
     vf vpre_r = jl0 * L.qd[0] + jl1 * L.qd[1] + jl2 * L.qd[2] + jb[0] * vB.x + jb[1] * vB.y + jb[2] * vB.z + jb[3] * wB.x + jb[4] * wB.y + jb[5] * wB.z;
-    vf cfree_r = jl0 * ul0 + jl1 * ul1 + jl2 * ul2;
+    vf cfree_r = sub_bcast_fma<2>(ul_s, jl2, sub_bcast_fma<1>(ul_s, jl1, jl0 * ul0));
 #pragma unroll
     for (int i = 0; i < 6; i++) cfree_r += jb[i] * ub[i];
     const vf nB_r = live * PICK3(nB.x, nB.y, nB.z);
@@ -1011,9 +1012,9 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     vf gx1[3], gx2[3], gx3[3];
 #pragma unroll
     for (int cc = 0; cc < 3; cc++) {
-      vf a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+      vf a1 = Yr[0] * legs_rot<1>(Ya[cc][0]), a2 = Yr[0] * legs_rot<2>(Ya[cc][0]), a3 = Yr[0] * legs_rot<3>(Ya[cc][0]);
 #pragma unroll
-      for (int i = 0; i < 6; i++) { a1 += Yr[i] * legs_rot<1>(Ya[cc][i]); a2 += Yr[i] * legs_rot<2>(Ya[cc][i]); a3 += Yr[i] * legs_rot<3>(Ya[cc][i]); }
+      for (int i = 1; i < 6; i++) { a1 = legs_rot_fma<1>(Ya[cc][i], Yr[i], a1); a2 = legs_rot_fma<2>(Ya[cc][i], Yr[i], a2); a3 = legs_rot_fma<3>(Ya[cc][i], Yr[i], a3); }
       gx1[cc] = a1; gx2[cc] = a2; gx3[cc] = a3;
     }
   IRRL_MARK("gs");
@@ -1033,18 +1034,9 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
       vf d2 = 0.0f;
       for (int rk = 0; rk < nrank; rk++) {
         vf cvr = cfree_r + cz_r;
-        {
-          vf bx = legs_rot<1>(lam.x), by = legs_rot<1>(lam.y), bz = legs_rot<1>(lam.z);
-          cvr += gx1[0] * bx + gx1[1] * by + gx1[2] * bz;
-        }
-        {
-          vf bx = legs_rot<2>(lam.x), by = legs_rot<2>(lam.y), bz = legs_rot<2>(lam.z);
-          cvr += gx2[0] * bx + gx2[1] * by + gx2[2] * bz;
-        }
-        {
-          vf bx = legs_rot<3>(lam.x), by = legs_rot<3>(lam.y), bz = legs_rot<3>(lam.z);
-          cvr += gx3[0] * bx + gx3[1] * by + gx3[2] * bz;
-        }
+        cvr = legs_rot_fma<1>(lam.z, gx1[2], legs_rot_fma<1>(lam.y, gx1[1], legs_rot_fma<1>(lam.x, gx1[0], cvr)));
+        cvr = legs_rot_fma<2>(lam.z, gx2[2], legs_rot_fma<2>(lam.y, gx2[1], legs_rot_fma<2>(lam.x, gx2[0], cvr)));
+        cvr = legs_rot_fma<3>(lam.z, gx3[2], legs_rot_fma<3>(lam.y, gx3[1], legs_rot_fma<3>(lam.x, gx3[0], cvr)));
         v3 cv = mk3(sub_bcast<0>(cvr), sub_bcast<1>(cvr), sub_bcast<2>(cvr));
         vm commit = active & (rank == rk);
         v3 ln = solve_contact(CB, cv, nB, vstar, L.m.mu, commit);

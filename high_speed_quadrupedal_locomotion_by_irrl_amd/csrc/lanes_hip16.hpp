@@ -53,13 +53,46 @@ template <int K> IRRL_DEV vf sub_bcast(vf x) { return dpp_f<K * 0x55>(x); }     
 template <int K> IRRL_DEV vi sub_bcast_i(vi x) { return dpp_i<K * 0x55>(x); }
 // inclusive suffix sum over the sub-lanes, x_s + ... + x_3; REQUIRES x_3 == 0: quad_perm [1,2,3,3] then [2,3,3,3]
 IRRL_DEV vf sub_suffix_sum(vf x) { x += dpp_f<0xF9>(x); x += dpp_f<0xFE>(x); return x; }
-// inclusive prefix sum over the sub-lanes, x_0 + ... + x_s (quad_perm shifts re-read lane 0, so lanes 0 / 0,1 mask the add)
+// ---- acc + exchange(x) * y in ONE instruction (v_fmac_f32_dpp) ----
+// LLVM folds a DPP move into v_add / v_mul / v_sub but never into an FMA (its DPP combine runs before register allocation, where
+// an FMA is the three-address V_FMA_F32_e64 without a DPP encoding), so `acc += exchange(x) * y` would cost v_mov_b32_dpp +
+// v_fmac: 5.4 ns against 2.3 ns for one resident wave per SIMD (tools/microbench/valu_issue.hip).  The instruction is therefore
+// written out; build.py runs isa_pass.py over the device assembly to supply the DPP read-after-write wait states that the
+// compiler's hazard recogniser cannot see through inline assembly (gfx950 does not interlock: measured).
+// -DIRRL_NO_FMA_DPP restores the plain expression (A/B builds).
+#ifdef IRRL_NO_FMA_DPP
+#define IRRL_FMAC_DPP(ctrl, acc, x, y, moved) acc = __builtin_fmaf(moved, y, acc)
+#else
+#define IRRL_FMAC_DPP(ctrl, acc, x, y, moved) \
+  asm("v_fmac_f32_dpp %0, %1, %2 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "v"(y))
+#endif
+// acc + sub_bcast<K>(x) * y
+template <int K> IRRL_DEV vf sub_bcast_fma(vf x, vf y, vf acc) {
+  static_assert(K >= 0 && K < 4, "sub-lane");
+  if constexpr (K == 0) IRRL_FMAC_DPP("quad_perm:[0,0,0,0]", acc, x, y, sub_bcast<0>(x));
+  if constexpr (K == 1) IRRL_FMAC_DPP("quad_perm:[1,1,1,1]", acc, x, y, sub_bcast<1>(x));
+  if constexpr (K == 2) IRRL_FMAC_DPP("quad_perm:[2,2,2,2]", acc, x, y, sub_bcast<2>(x));
+  if constexpr (K == 3) IRRL_FMAC_DPP("quad_perm:[3,3,3,3]", acc, x, y, sub_bcast<3>(x));
+  return acc;
+}
+// acc + legs_rot<D>(x) * y
+template <int D> IRRL_DEV vf legs_rot_fma(vf x, vf y, vf acc) {
+  static_assert(D >= 1 && D < 4, "leg distance");
+  if constexpr (D == 1) IRRL_FMAC_DPP("row_ror:4", acc, x, y, legs_rot<1>(x));
+  if constexpr (D == 2) IRRL_FMAC_DPP("row_ror:8", acc, x, y, legs_rot<2>(x));
+  if constexpr (D == 3) IRRL_FMAC_DPP("row_ror:12", acc, x, y, legs_rot<3>(x));
+  return acc;
+}
+// inclusive prefix sum over the sub-lanes, x_0 + ... + x_s (quad_perm shifts re-read lane 0, so lanes 0 / 0,1 mask the add:
+// as multipliers, one v_fmac_f32_dpp does move + mask + add)
 IRRL_DEV vf sub_prefix_sum(vf x) {
   const unsigned s = threadIdx.x & 3u;
-  const float m1 = (s >= 1u) ? 1.0f : 0.0f, m2 = (s >= 2u) ? 1.0f : 0.0f;   // as multipliers: v_fmac_f32_dpp does move+mask+add
-  x = __builtin_fmaf(dpp_f<0x90>(x), m1, x);   // quad_perm [0,0,1,2]: lane s reads lane s-1
-  x = __builtin_fmaf(dpp_f<0x40>(x), m2, x);   // quad_perm [0,0,0,1]: lane s reads lane s-2
-  return x;
+  const float m1 = (s >= 1u) ? 1.0f : 0.0f, m2 = (s >= 2u) ? 1.0f : 0.0f;
+  vf a = x;
+  IRRL_FMAC_DPP("quad_perm:[0,0,1,2]", a, x, m1, dpp_f<0x90>(x));   // lane s reads lane s-1
+  vf b = a;
+  IRRL_FMAC_DPP("quad_perm:[0,0,0,1]", b, a, m2, dpp_f<0x40>(a));   // lane s reads lane s-2
+  return b;
 }
 
 // ---- masks / selects ----

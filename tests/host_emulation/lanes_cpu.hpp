@@ -96,6 +96,8 @@ inline vf sub_sum(vf x) {
 }
 template <int K> inline vf sub_bcast(vf x) { vf r; for (int i = 0; i < 16; i++) r.v[i] = x.v[(i & ~3) | K]; return r; }
 template <int K> inline vi sub_bcast_i(vi x) { vi r; for (int i = 0; i < 16; i++) r.v[i] = x.v[(i & ~3) | K]; return r; }
+template <int K> inline vf sub_bcast_fma(vf x, vf y, vf acc) { return acc + sub_bcast<K>(x) * y; }
+template <int D> inline vf legs_rot_fma(vf x, vf y, vf acc) { return acc + legs_rot<D>(x) * y; }
 // inclusive suffix sum over the sub-lanes (sub-lane s gets x_s + .. + x_3); REQUIRES x_3 == 0 (quad_perm [1,2,3,3], [2,3,3,3])
 inline vf sub_suffix_sum(vf x) {
   vf a, r;

@@ -1,0 +1,73 @@
+"""The ISA pass of the env-kernel build (high_speed_quadrupedal_locomotion_by_irrl_amd/isa_pass.py) on hand-written snippets:
+it must add exactly the wait states the gfx950 ISA manual asks for around inline-assembly v_fmac_f32_dpp instructions, and
+leave compiler-generated code alone.  Also: the product build really contains the hand-placed instructions, every one of them
+hazard-free after the pass (re-running the pass on its own output adds nothing)."""
+import os
+
+from high_speed_quadrupedal_locomotion_by_irrl_amd import build, isa_pass
+
+DPP = " quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+ASM = lambda body: "\t;;#ASMSTART\n" + body + "\t;;#ASMEND\n"
+
+
+def _run(text):
+    out, stats = isa_pass.run(text.splitlines(keepends=True))
+    return "".join(out), stats
+
+
+def _pad(n):
+    return "".join("\tv_mul_f32_e32 v%d, v%d, v%d\n" % (200 + i, 201 + i, 202 + i) for i in range(n))
+
+
+def test_reader_hazard_two_wait_states():
+    # VALU writes v5, our DPP instruction reads v5 as its DPP operand right behind it: 2 wait states
+    text = _pad(3) + "\tv_add_f32_e32 v5, v1, v2\n" + ASM("\tv_fmac_f32_dpp v9, v5, v7" + DPP) + _pad(3)
+    out, st = _run(text)
+    assert "s_nop 1" in out and out.index("s_nop 1") < out.index(";;#ASMSTART") and st["wait_states_added"] == 2
+    # one unrelated instruction in between: 1 wait state is still missing
+    text = _pad(3) + "\tv_add_f32_e32 v5, v1, v2\n\tv_mul_f32_e32 v30, v31, v32\n" + ASM("\tv_fmac_f32_dpp v9, v5, v7" + DPP) + _pad(3)
+    out, st = _run(text)
+    assert "s_nop 0" in out and st["wait_states_added"] == 1
+    # two instructions in between, or a write to the NON-dpp operand / the accumulator: nothing to do
+    for body in (_pad(3) + "\tv_add_f32_e32 v5, v1, v2\n" + _pad(2) + ASM("\tv_fmac_f32_dpp v9, v5, v7" + DPP),
+                 _pad(3) + "\tv_add_f32_e32 v7, v1, v2\n" + ASM("\tv_fmac_f32_dpp v9, v5, v7" + DPP),
+                 _pad(3) + "\tv_add_f32_e32 v9, v1, v2\n" + ASM("\tv_fmac_f32_dpp v9, v5, v7" + DPP)):
+        out, st = _run(body + _pad(3))
+        assert st["wait_states_added"] == 0, out
+    # an s_nop the compiler already placed counts
+    text = _pad(3) + "\tv_add_f32_e32 v5, v1, v2\n\ts_nop 1\n" + ASM("\tv_fmac_f32_dpp v9, v5, v7" + DPP) + _pad(3)
+    assert _run(text)[1]["wait_states_added"] == 0
+
+
+def test_writer_hazard_and_compiler_pairs():
+    # our instruction writes v9, a compiler-generated DPP instruction reads it as DPP operand: the compiler could not know
+    text = _pad(3) + ASM("\tv_fmac_f32_dpp v9, v5, v7" + DPP) + "\tv_add_f32_dpp v11, v9, v12" + DPP + _pad(3)
+    out, st = _run(text)
+    assert st["nops_writer"] == 1 and st["wait_states_added"] == 2
+    # compiler writer + compiler DPP reader: the compiler's own business (it already placed what is needed)
+    text = _pad(3) + "\tv_add_f32_e32 v9, v1, v2\n\tv_add_f32_dpp v11, v9, v12" + DPP + _pad(3)
+    assert _run(text)[1]["wait_states_added"] == 0
+
+
+def test_transcendental_and_exec_and_block_boundaries():
+    text = _pad(3) + "\tv_rcp_f32_e32 v7, v3\n" + ASM("\tv_fmac_f32_dpp v9, v5, v7" + DPP) + _pad(3)          # trans result used at once
+    assert _run(text)[1]["nops_trans"] == 1
+    text = _pad(3) + "\tv_cmpx_lt_f32_e32 v1, v2\n" + _pad(2) + ASM("\tv_fmac_f32_dpp v9, v5, v7" + DPP) + _pad(3)   # VALU wrote EXEC: 5
+    out, st = _run(text)
+    assert st["wait_states_added"] == 3                                                                     # 5 minus the two in between
+    text = ".LBB0_7:\n" + ASM("\tv_fmac_f32_dpp v9, v5, v7" + DPP) + _pad(3)                                  # unknown predecessors
+    assert _run(text)[1]["wait_states_added"] == 2
+    text = _pad(3) + ASM("\tv_fmac_f32_dpp v9, v5, v7" + DPP) + "\ts_cbranch_vccnz .LBB0_9\n"                 # unknown successors
+    out, st = _run(text)
+    assert st["wait_states_added"] == 2 and out.index("s_nop 1") > out.index(";;#ASMEND")
+
+
+def test_product_build_contains_the_hand_placed_instructions_and_is_hazard_free():
+    build.build()
+    s = os.path.join(build.CSRC, "_obj", "env_kernels_l16.s")
+    if not os.path.exists(s):       # library reused from a previous build without its intermediates: rebuild the unit's assembly
+        build.build(force=True)
+    text = open(s).read()
+    assert text.count("v_fmac_f32_dpp") >= 100                       # the 16-lane step kernel's exchanges ride on the FMAs
+    out, st = isa_pass.run(text.splitlines(keepends=True))
+    assert st["asm_dpp"] == text.count("v_fmac_f32_dpp") and st["wait_states_added"] == 0   # idempotent: nothing left to fix

@@ -10,14 +10,15 @@ for spec in sys.argv[1:]:
     name, _, flags = spec.partition("=")
     flags = [f for f in flags.split(",") if f]
     objs = []
-    procs = []
-    common = [B.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-fno-signed-zeros"] + flags
+    common = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-fno-signed-zeros"] + flags
     for src, fl, obj in (("env_kernels.hip", ["-DIRRL_LANES_PER_ROBOT=16"] + B.ENV_FLAGS, "l16"), ("env_kernels.hip", ["-DIRRL_LANES_PER_ROBOT=4"] + B.ENV_FLAGS, "l4"),
                          ("irrl_env_abi.hip", [], "abi")):
         o = os.path.join(out, f"{name}_{obj}.o")
         objs.append(o)
-        procs.append(subprocess.Popen(common + fl + ["-c", os.path.join(B.CSRC, src), "-o", o]))
-    assert all(p.wait() == 0 for p in procs)
+        if src == "env_kernels.hip":   # same route as the product build: device assembly -> ISA pass -> assemble -> embed
+            B.compile_env_unit(os.path.join(B.CSRC, src), common + fl, o, out)
+        else:
+            subprocess.check_call([B.hipcc()] + common + fl + ["-c", os.path.join(B.CSRC, src), "-o", o])
     lib = os.path.join(out, f"libirrl_env_{name}.so")
     subprocess.check_call([B.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib])
     for o in objs:
