@@ -33,8 +33,6 @@ using namespace lanes;
 // small vector helpers
 // ---------------------------------------------------------------------------------------------
 #define IRRL_UNLIKELY(x) __builtin_expect(!!(x), 0)   /* rare wave-uniform branches: laid out off the hot path */
-struct irrl_yes { static constexpr bool value = true; };
-struct irrl_no { static constexpr bool value = false; };
 struct v3 { vf x, y, z; };
 struct sym3 { vf xx, xy, xz, yy, yz, zz; };
 
@@ -293,6 +291,9 @@ struct EnvLane {
   vf lamw[3];
   vi in_contact; vf contact;
   vu ccount;              // toe-substeps in the contact list (diagnostic counter, EnvState::contact_count)
+#ifdef IRRL_PROFILE_WAVES
+  int prof_ranksteps, prof_flags;   // wave-uniform: Gauss-Seidel rank steps executed, bit 0 reset path, bit 1 box path, bits 8.. sweeps
+#endif
   // per-env (replicated in the 4 lanes of the quad)
   v3 pos; vf qw, qx, qy, qz; v3 vw, ww;
   vf cmd[3], cmdf[3];
@@ -597,9 +598,10 @@ IRRL_DEV void terrain_sample(const EnvParams &P, vf x, vf y, vf &h, v3 &n) {
 // y = +-0.1 (bit 1 set: -), z = -+0.05 (bit 0 set: +) -- the oracle's numbering.  A corner only reaches the ground while
 // the robot is falling over (the episode ends at z < 0.15 m or 60 degrees of tilt) or on rough terrain, so everything
 // here sits behind wave-uniform tests and is written for clarity, not speed.  Each corner is OWNED by one lane of the
-// robot (16 lanes: leg quad (b >> 1), sub-lane (b & 1); 4 lanes: lane (b >> 1), slot (b & 1)); the Gauss-Seidel order is
-// toes FR..HL, then corners 0..7; corner impulses are not warm-started.  Contacts couple through the base only:
-// Y_c = L^-1 Jb_c^T, and everything the corners exchange with the toes is the 6-vector z = sum Y^T lambda.
+// robot (16 lanes: leg quad (b >> 1), sub-lane (b & 1); 4 lanes: lane (b >> 1), slot (b & 1)).  The toes iterate first; the
+// corners follow in ONE pass of sequential impulses (0..7, cold start): each touching corner sees the velocity produced so far,
+// solves its own contact exactly and is applied at once -- nothing is re-iterated (what a later corner does to an earlier one
+// and to the toes is left to the next 0.25 ms substep).  Corners act on the base only: Y_c = L^-1 Jb_c^T.
 // ---------------------------------------------------------------------------------------------
 #ifdef IRRL_L16
 #define IRRL_NCPL 1
@@ -623,7 +625,7 @@ struct BoxContacts {
   vm own[IRRL_NCPL];          // slot j of this lane holds an ACTIVE corner that this lane owns
   vf Y[IRRL_NCPL][3][6];      // rows of K L^-T, K = [1 | -[x]x]
   ContactBlock CB[IRRL_NCPL];
-  v3 n[IRRL_NCPL], cfree[IRRL_NCPL], lam[IRRL_NCPL];
+  v3 n[IRRL_NCPL], cfree[IRRL_NCPL];
   vf vstar[IRRL_NCPL];
   vf zc[6];                   // sum over the robot's corners of Y^T lambda (same value in all its lanes)
 };
@@ -650,7 +652,6 @@ IRRL_DEV bool box_setup(const EnvParams &P, const EnvLane &L, const rot3 &R, con
     vf gap = (L.pos.z + cw.z - hgt) * nw.z;
     B.own[j] = owner & (gap <= 0.0f);
     B.n[j] = rot_tmul(R, nw);
-    B.lam[j] = mk3(0.0f, 0.0f, 0.0f);
     if (!wave_any(B.own[j])) {
       B.own[j] = vm(false);
       B.vstar[j] = 0.0f; B.cfree[j] = mk3(0.0f, 0.0f, 0.0f);
@@ -694,23 +695,18 @@ IRRL_DEV bool box_setup(const EnvParams &P, const EnvLane &L, const rot3 &R, con
 }
 // Gauss-Seidel step of corner B (compile-time: its owner lane is a DPP broadcast source).  zt: sum over the toes of
 // Y^T lambda (replicated).  Adds |dlambda|^2 to dd in the owner lane; updates B.lam and the replicated B.zc.
+// One corner of the pass (compile-time CB: its owner lane is a DPP broadcast source): the corner sees the velocity the toes and
+// the corners before it have produced, solves its single-contact problem exactly and is applied at once (B.zc advances).
 template <int CB>
-IRRL_DEV void box_corner_step(BoxContacts &B, const vf zt[6], vf mu, vf &dd) {
+IRRL_DEV void box_corner_step(BoxContacts &B, vf mu) {
   constexpr int j = (IRRL_NCPL == 2) ? (CB & 1) : 0;
   const vm mine = B.own[j] & (B.id[j] == CB);
   if (!wave_any(mine)) return;
-  // velocity at the corner without its own impulse: cfree + Y (zt + zc) - G lam_own
-  vf zs[6];
+  v3 c = B.cfree[j];
 #pragma unroll
-  for (int i = 0; i < 6; i++) zs[i] = zt[i] + B.zc[i];
-  v3 own = mul(B.CB[j].G, B.lam[j]);
-  v3 c = B.cfree[j] - own;
-#pragma unroll
-  for (int i = 0; i < 6; i++) { c.x += B.Y[j][0][i] * zs[i]; c.y += B.Y[j][1][i] * zs[i]; c.z += B.Y[j][2][i] * zs[i]; }
+  for (int i = 0; i < 6; i++) { c.x += B.Y[j][0][i] * B.zc[i]; c.y += B.Y[j][1][i] * B.zc[i]; c.z += B.Y[j][2][i] * B.zc[i]; }
   v3 ln = solve_contact(B.CB[j], c, B.n[j], B.vstar[j], mu, mine);
-  v3 dl = mk3(vsel(mine, ln.x - B.lam[j].x, 0.0f), vsel(mine, ln.y - B.lam[j].y, 0.0f), vsel(mine, ln.z - B.lam[j].z, 0.0f));
-  B.lam[j] = B.lam[j] + dl;
-  dd += dot(dl, dl);
+  v3 dl = mk3(vsel(mine, ln.x, 0.0f), vsel(mine, ln.y, 0.0f), vsel(mine, ln.z, 0.0f));
   // zc += Y^T dl of the owner lane, broadcast to the robot's lanes
 #ifdef IRRL_L16
   constexpr int OWNER = (CB >> 1) * 4 + (CB & 1);
@@ -720,18 +716,18 @@ IRRL_DEV void box_corner_step(BoxContacts &B, const vf zt[6], vf mu, vf &dd) {
 #pragma unroll
   for (int i = 0; i < 6; i++) B.zc[i] += robot_bcast<OWNER>(B.Y[j][0][i] * dl.x + B.Y[j][1][i] * dl.y + B.Y[j][2][i] * dl.z);
 }
-// One Gauss-Seidel pass over the corners in the order 0..7; adds this pass's |dlambda|^2 to d2 (replicated over the robot's lanes).
-IRRL_DEV void box_sweep(BoxContacts &B, const vf zt[6], vf mu, vf &d2) {
-  vf dd = 0.0f;
-  box_corner_step<0>(B, zt, mu, dd); box_corner_step<1>(B, zt, mu, dd); box_corner_step<2>(B, zt, mu, dd); box_corner_step<3>(B, zt, mu, dd);
-  box_corner_step<4>(B, zt, mu, dd); box_corner_step<5>(B, zt, mu, dd); box_corner_step<6>(B, zt, mu, dd); box_corner_step<7>(B, zt, mu, dd);
-  d2 += robot_sum(dd);
-}
-IRRL_DEV vf box_lam2(const BoxContacts &B) {
-  vf s = 0.0f;
+// THE TRUNK-BOX PASS: one pass of sequential impulses over the touching corners (0..7, cold start) behind the toe iteration.
+// ub: base twist with the toe impulses already applied.  -> dxb: the change of the base twist the corner impulses cause (the
+// caller adds it to ub and takes D dxb off the joint rates); false when no corner of the wave's robots touches.
+IRRL_DEV bool box_pass(const EnvParams &P, const EnvLane &L, const rot3 &R, const vf L6[21], const vf ub[6], v3 vB, v3 wB, vf dxb[6]) {
+  BoxContacts B;
+  if (!box_setup(P, L, R, L6, ub, vB, wB, B)) return false;
+  box_corner_step<0>(B, L.m.mu); box_corner_step<1>(B, L.m.mu); box_corner_step<2>(B, L.m.mu); box_corner_step<3>(B, L.m.mu);
+  box_corner_step<4>(B, L.m.mu); box_corner_step<5>(B, L.m.mu); box_corner_step<6>(B, L.m.mu); box_corner_step<7>(B, L.m.mu);
 #pragma unroll
-  for (int j = 0; j < IRRL_NCPL; j++) s += vsel(B.own[j], dot(B.lam[j], B.lam[j]), 0.0f);
-  return robot_sum(s);
+  for (int i = 0; i < 6; i++) dxb[i] = B.zc[i];
+  l6_bwd(L6, dxb);
+  return true;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -950,10 +946,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
 #else
   const bool box_near = wave_any(box_near_ground(P, L.pos.z, R.r2));
 #endif
-  // The contact block exists twice: the hot instantiation without the trunk-box corners, and a rare one with them (robots
-  // falling over, rough terrain) that is laid out off the hot path -- the corner code costs the common case nothing.
-  auto contact_block = [&](auto with_box_tag) {
-    constexpr bool WITH_BOX = decltype(with_box_tag)::value;
+  if (wave_any(active)) {
     v3 x = k.ptoe - IRRL_TOE_RADIUS * nB;
     // (D) column `sub` of the leg Jacobian, then all of it (R)
     v3 jc = live * cross(ax, x - p_s);
@@ -1024,41 +1017,34 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     vi a0i = legs_bcast_i<0>(act_i), a1i = legs_bcast_i<1>(act_i), a2i = legs_bcast_i<2>(act_i), a3i = legs_bcast_i<3>(act_i);
     vi rank = vsel_i(leg == 0, 0, vsel_i(leg == 1, a0i, vsel_i(leg == 2, a0i + a1i, a0i + a1i + a2i)));
     int nrank = wave_max_small(a0i + a1i + a2i + a3i);
+    // ContactSolver 2 (default): the contacts of a robot update SIMULTANEOUSLY from the sweep's starting iterate -- one solve
+    // per sweep instead of one per contact.  The toes couple only through the heavy base (off-diagonal Delassus blocks are a
+    // fraction of the diagonal ones), so this converges almost as fast as Gauss-Seidel (measured on the oracle: 2.4 vs 2.2
+    // sweeps per substep, p99 5 vs 4, same fixed point), and the step no longer lasts as long as the wave whose robots
+    // happen to have the most feet on the ground (tools/wave_spread.py).
+    const bool jacobi = P.contact_jacobi != 0;
+    if (jacobi) nrank = nrank > 0 ? 1 : 0;
     const float tol2 = P.contact_tol * P.contact_tol;
-    // trunk-box corners (rare: falling robots, rough terrain)
-    BoxContacts BX;
-    bool has_box = false;
-    if constexpr (WITH_BOX) has_box = box_setup(P, L, R, D.L6, ub, vB, wB, BX);
-    vf cz_r = 0.0f;   // row r of Y_toe . zc: what the corner impulses add to this toe's velocity
     for (int it = 0; it < P.contact_iters; it++) {
       vf d2 = 0.0f;
+#ifdef IRRL_PROFILE_WAVES
+      L.prof_ranksteps += nrank; L.prof_flags += 256;
+#endif
       for (int rk = 0; rk < nrank; rk++) {
-        vf cvr = cfree_r + cz_r;
+        vf cvr = cfree_r;
         cvr = legs_rot_fma<1>(lam.z, gx1[2], legs_rot_fma<1>(lam.y, gx1[1], legs_rot_fma<1>(lam.x, gx1[0], cvr)));
         cvr = legs_rot_fma<2>(lam.z, gx2[2], legs_rot_fma<2>(lam.y, gx2[1], legs_rot_fma<2>(lam.x, gx2[0], cvr)));
         cvr = legs_rot_fma<3>(lam.z, gx3[2], legs_rot_fma<3>(lam.y, gx3[1], legs_rot_fma<3>(lam.x, gx3[0], cvr)));
         v3 cv = mk3(sub_bcast<0>(cvr), sub_bcast<1>(cvr), sub_bcast<2>(cvr));
-        vm commit = active & (rank == rk);
+        vm commit = jacobi ? active : (active & (rank == rk));
         v3 ln = solve_contact(CB, cv, nB, vstar, L.m.mu, commit);
         v3 dl = mk3(vsel(commit, ln.x - lam.x, 0.0f), vsel(commit, ln.y - lam.y, 0.0f), vsel(commit, ln.z - lam.z, 0.0f));
         lam = lam + dl;
         d2 += dot(dl, dl);
       }
-      vf d2b = 0.0f, l2b = 0.0f;
-      if constexpr (WITH_BOX) if (has_box) {
-        const vf lam_t = live * PICK3(vsel(active, lam.x, 0.0f), vsel(active, lam.y, 0.0f), vsel(active, lam.z, 0.0f));
-        vf zt[6];
-#pragma unroll
-        for (int i = 0; i < 6; i++) zt[i] = robot_sum(Yr[i] * lam_t);
-        box_sweep(BX, zt, L.m.mu, d2b);
-        l2b = box_lam2(BX);
-        cz_r = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 6; i++) cz_r += Yr[i] * BX.zc[i];
-      }
       if (tol2 > 0.0f) {
-        vf l2 = legs_sum(vsel(active, dot(lam, lam), 0.0f)) + l2b;
-        vm unconverged = legs_sum(d2) + d2b > tol2 * l2 + 1e-20f;
+        vf l2 = legs_sum(vsel(active, dot(lam, lam), 0.0f));
+        vm unconverged = legs_sum(d2) > tol2 * l2 + 1e-20f;
         if (!wave_any(unconverged)) break;
       }
     }
@@ -1069,10 +1055,6 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     vf xbc[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) xbc[i] = legs_sum(sub_sum(Yr[i] * lam_r));
-    if constexpr (WITH_BOX) if (has_box) {
-#pragma unroll
-      for (int i = 0; i < 6; i++) xbc[i] += BX.zc[i];
-    }
     l6_bwd(D.L6, xbc);
 #pragma unroll
     for (int i = 0; i < 6; i++) ub[i] += xbc[i];
@@ -1085,10 +1067,20 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     }
     v3 lw = rot_mul(R, lam);
     L.lamw[0] = lw.x; L.lamw[1] = lw.y; L.lamw[2] = lw.z;
-  };
-  if (IRRL_UNLIKELY(box_near)) contact_block(irrl_yes());
-  else if (wave_any(active)) contact_block(irrl_no());
-  else { L.lamw[0] = 0.0f; L.lamw[1] = 0.0f; L.lamw[2] = 0.0f; }
+  } else {
+    L.lamw[0] = 0.0f; L.lamw[1] = 0.0f; L.lamw[2] = 0.0f;
+  }
+  // trunk-box corners (rare: robots falling over, rough terrain): one pass of sequential impulses behind the toe iteration
+  if (IRRL_UNLIKELY(box_near)) {
+    vf dxb[6];
+    if (box_pass(P, L, R, D.L6, ub, vB, wB, dxb)) {
+#ifdef IRRL_PROFILE_WAVES
+      L.prof_flags |= 2;
+#endif
+#pragma unroll
+      for (int i = 0; i < 6; i++) { ub[i] += dxb[i]; ul_s -= Xs[i] * dxb[i]; }
+    }
+  }
   IRRL_MARK("integrate");
   L.in_contact = vsel_i(active, 1, 0);
   L.ccount = L.ccount + to_u(L.in_contact);
@@ -1164,10 +1156,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
 #else
   const bool box_near = wave_any(box_near_ground(P, L.pos.z, R.r2));
 #endif
-  // The contact block exists twice: the hot instantiation without the trunk-box corners, and a rare one with them (robots
-  // falling over, rough terrain) that is laid out off the hot path -- the corner code costs the common case nothing.
-  auto contact_block = [&](auto with_box_tag) {
-    constexpr bool WITH_BOX = decltype(with_box_tag)::value;
+  if (wave_any(active)) {
     v3 x = k.ptoe - IRRL_TOE_RADIUS * nB;
     // leg columns of the contact Jacobian
     v3 jA = cross(mk3(1.0f, 0.0f, 0.0f), x - k.pA), jT = cross(k.h, x - k.pT), jS = cross(k.h, x - k.pS);
@@ -1243,17 +1232,14 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     vi a0i = legs_bcast_i<0>(act_i), a1i = legs_bcast_i<1>(act_i), a2i = legs_bcast_i<2>(act_i);
     vi rank = vsel_i(leg == 0, 0, vsel_i(leg == 1, a0i, vsel_i(leg == 2, a0i + a1i, a0i + a1i + a2i)));
     int nrank = wave_max_small(legs_sum_i(act_i));
+    const bool jacobi = P.contact_jacobi != 0;   // ContactSolver 2: simultaneous updates (see the 16-lane instantiation)
+    if (jacobi) nrank = nrank > 0 ? 1 : 0;
     const float tol2 = P.contact_tol * P.contact_tol;
-    // trunk-box corners (rare: falling robots, rough terrain)
-    BoxContacts BX;
-    bool has_box = false;
-    if constexpr (WITH_BOX) has_box = box_setup(P, L, R, D.L6, ub, vB, wB, BX);
-    v3 cz = mk3(0.0f, 0.0f, 0.0f);   // Y_toe . zc: what the corner impulses add to this toe's velocity
     for (int it = 0; it < P.contact_iters; it++) {
       vf d2 = 0.0f;
       for (int rk = 0; rk < nrank; rk++) {
         // velocity at this contact without its own impulse: cfree + sum_{l' != l} G_ll' lam_l'
-        v3 cv = mk3(cfree[0], cfree[1], cfree[2]) + cz;
+        v3 cv = mk3(cfree[0], cfree[1], cfree[2]);
 #define IRRL_GX_APPLY(LP)                                                                       \
         {                                                                                       \
           vf bx = legs_bcast<LP>(lam.x), by = legs_bcast<LP>(lam.y), bz = legs_bcast<LP>(lam.z); \
@@ -1263,28 +1249,16 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
         }
         IRRL_GX_APPLY(0) IRRL_GX_APPLY(1) IRRL_GX_APPLY(2) IRRL_GX_APPLY(3)
 #undef IRRL_GX_APPLY
-        vm commit = active & (rank == rk);
+        vm commit = jacobi ? active : (active & (rank == rk));
         v3 ln = solve_contact(CB, cv, nB, vstar, L.m.mu, commit);
         v3 dl = mk3(vsel(commit, ln.x - lam.x, 0.0f), vsel(commit, ln.y - lam.y, 0.0f), vsel(commit, ln.z - lam.z, 0.0f));
         lam = lam + dl;
         d2 += dot(dl, dl);
       }
-      vf d2b = 0.0f, l2b = 0.0f;
-      if constexpr (WITH_BOX) if (has_box) {
-        const v3 la = mk3(vsel(active, lam.x, 0.0f), vsel(active, lam.y, 0.0f), vsel(active, lam.z, 0.0f));
-        vf zt[6];
-#pragma unroll
-        for (int i = 0; i < 6; i++) zt[i] = robot_sum(Y[0][i] * la.x + Y[1][i] * la.y + Y[2][i] * la.z);
-        box_sweep(BX, zt, L.m.mu, d2b);
-        l2b = box_lam2(BX);
-        cz = mk3(0.0f, 0.0f, 0.0f);
-#pragma unroll
-        for (int i = 0; i < 6; i++) { cz.x += Y[0][i] * BX.zc[i]; cz.y += Y[1][i] * BX.zc[i]; cz.z += Y[2][i] * BX.zc[i]; }
-      }
       // build-defined early exit: every robot of the wave has sum |dlam|^2 <= tol^2 sum |lam|^2
       if (tol2 > 0.0f) {
-        vf l2 = legs_sum(vsel(active, dot(lam, lam), 0.0f)) + l2b;
-        vm unconverged = legs_sum(d2) + d2b > tol2 * l2 + 1e-20f;
+        vf l2 = legs_sum(vsel(active, dot(lam, lam), 0.0f));
+        vm unconverged = legs_sum(d2) > tol2 * l2 + 1e-20f;
         if (!wave_any(unconverged)) break;
       }
     }
@@ -1293,10 +1267,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     vf z[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) z[i] = legs_sum(Y[0][i] * lam.x + Y[1][i] * lam.y + Y[2][i] * lam.z);
-    if constexpr (WITH_BOX) if (has_box) {
-#pragma unroll
-      for (int i = 0; i < 6; i++) z[i] += BX.zc[i];
-    }
+
     // velocity update: base part L^-T z, leg part C^-1 Jl^T lam - D xb
     vf xbc[6];
 #pragma unroll
@@ -1313,10 +1284,21 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     }
     v3 lw = rot_mul(R, lam);
     L.lamw[0] = lw.x; L.lamw[1] = lw.y; L.lamw[2] = lw.z;
-  };
-  if (IRRL_UNLIKELY(box_near)) contact_block(irrl_yes());
-  else if (wave_any(active)) contact_block(irrl_no());
-  else { L.lamw[0] = 0.0f; L.lamw[1] = 0.0f; L.lamw[2] = 0.0f; }
+  } else {
+    L.lamw[0] = 0.0f; L.lamw[1] = 0.0f; L.lamw[2] = 0.0f;
+  }
+  // trunk-box corners (rare: robots falling over, rough terrain): one pass of sequential impulses behind the toe iteration
+  if (IRRL_UNLIKELY(box_near)) {
+    vf dxb[6];
+    if (box_pass(P, L, R, D.L6, ub, vB, wB, dxb)) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        ub[i] += dxb[i];
+#pragma unroll
+        for (int j = 0; j < 3; j++) ul[j] -= D.X[i][j] * dxb[i];
+      }
+    }
+  }
   L.in_contact = vsel_i(active, 1, 0);
   L.ccount = L.ccount + to_u(L.in_contact);
   // back to world-frame gv, then positions (semi-implicit Euler)
@@ -1664,17 +1646,19 @@ IRRL_DEV void select_lane(vm m, const EnvLane &a, EnvLane &b) {
 // ---------------------------------------------------------------------------------------------
 // state pool <-> lane context
 // ---------------------------------------------------------------------------------------------
-IRRL_DEV void load_lane(const EnvParams &P, const EnvState &S, vi env, vi leg, EnvLane &L) {
+// for_step: the step overwrites the applied torque, the contact flags and the whole raw observation before it reads them
+// (physics_substep / contact_obs_update / update_observation), so their 51 words per robot are not fetched
+IRRL_DEV void load_lane(const EnvParams &P, const EnvState &S, vi env, vi leg, EnvLane &L, bool for_step = false) {
   vi j12 = env * 12 + leg * 3, gcb = env * 19, gvb = env * 18;
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     L.q[k] = ld(S.gc, gcb + 7 + leg * 3 + k); L.qd[k] = ld(S.gv, gvb + 6 + leg * 3 + k);
-    L.ptl[k] = ld(S.ptarget_last, j12 + k); L.tql[k] = ld(S.torque_last, j12 + k); L.tq[k] = ld(S.torque, j12 + k);
+    L.ptl[k] = ld(S.ptarget_last, j12 + k); L.tql[k] = ld(S.torque_last, j12 + k); L.tq[k] = for_step ? vf(0.0f) : ld(S.torque, j12 + k);
     L.jr[k] = ld(S.joint_ref, j12 + k); L.jrl[k] = ld(S.joint_ref_last, j12 + k); L.jdr[k] = ld(S.joint_dot_ref, j12 + k);
     L.eer[k] = ld(S.ee_ref, j12 + k); L.lamw[k] = ld(S.lam_w, j12 + k);
     L.cmd[k] = ld(S.command, env * 3 + k); L.cmdf[k] = ld(S.command_filtered, env * 3 + k);
   }
-  L.in_contact = ld_i(S.in_contact, env * 4 + leg); L.contact = ld(S.contact, env * 4 + leg);
+  L.in_contact = ld_i(S.in_contact, env * 4 + leg); L.contact = for_step ? vf(0.0f) : ld(S.contact, env * 4 + leg);
   L.ccount = 0u;
   if (S.contact_count) L.ccount = ld_u(S.contact_count, env * 4 + leg);
   L.pos = mk3(ld(S.gc, gcb), ld(S.gc, gcb + 1), ld(S.gc, gcb + 2));
@@ -1693,12 +1677,18 @@ IRRL_DEV void load_lane(const EnvParams &P, const EnvState &S, vi env, vi leg, E
   L.m.dz = ld(S.thigh_dz, env);
   // raw observation (needed by observe()/isTerminalState() between steps, and by the ObsFilter history)
   vi ob = env * 35;
+  if (for_step) {
 #pragma unroll
-  for (int k = 0; k < 3; k++) {
-    L.ob_cmd[k] = ld(S.ob, ob + k); L.ob_post[k] = ld(S.ob, ob + 29 + k); L.ob_omega[k] = ld(S.ob, ob + 32 + k);
-    L.ob_q[k] = ld(S.ob, ob + 5 + leg * 3 + k); L.ob_qd[k] = ld(S.ob, ob + 17 + leg * 3 + k);
+    for (int k = 0; k < 3; k++) { L.ob_cmd[k] = 0.0f; L.ob_post[k] = 0.0f; L.ob_omega[k] = 0.0f; L.ob_q[k] = 0.0f; L.ob_qd[k] = 0.0f; }
+    L.ob_phase[0] = 0.0f; L.ob_phase[1] = 0.0f;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      L.ob_cmd[k] = ld(S.ob, ob + k); L.ob_post[k] = ld(S.ob, ob + 29 + k); L.ob_omega[k] = ld(S.ob, ob + 32 + k);
+      L.ob_q[k] = ld(S.ob, ob + 5 + leg * 3 + k); L.ob_qd[k] = ld(S.ob, ob + 17 + leg * 3 + k);
+    }
+    L.ob_phase[0] = ld(S.ob, ob + 3); L.ob_phase[1] = ld(S.ob, ob + 4);
   }
-  L.ob_phase[0] = ld(S.ob, ob + 3); L.ob_phase[1] = ld(S.ob, ob + 4);
   // obDouble_last_ is only read by the observation filter (ENV:1251-1256): leave it in HBM otherwise
   if (P.obs_filter) {
 #pragma unroll
@@ -1816,7 +1806,10 @@ IRRL_DEV void observe_lane(const EnvParams &P, vi env, vi leg, vm valid, EnvLane
 IRRL_DEV void step_body(const EnvParams &P, const EnvState &S, vi env, vi leg, vm valid, const float *action, float *ob_out,
                         float *reward_out, uint8_t *done_out, float *extra_out) {
   EnvLane L;
-  load_lane(P, S, env, leg, L);
+  load_lane(P, S, env, leg, L, true);
+#ifdef IRRL_PROFILE_WAVES
+  L.prof_ranksteps = 0; L.prof_flags = 0;
+#endif
   vu envu = to_u(env);
   // ENV:700-708
   vf pT[3];
@@ -1890,6 +1883,9 @@ IRRL_DEV void step_body(const EnvParams &P, const EnvState &S, vi env, vi leg, v
   done = done & vm(false);
 #endif
   if (wave_any(done & valid)) {
+#ifdef IRRL_PROFILE_WAVES
+    L.prof_flags |= 1;
+#endif
     EnvLane Rn = L;
     reset_lane(P, Rn, envu);
     select_lane(done, Rn, L);
@@ -1902,6 +1898,9 @@ IRRL_DEV void step_body(const EnvParams &P, const EnvState &S, vi env, vi leg, v
   stm_u8(done_out, env, vsel_i(done, 1, 0));
 #pragma unroll
   for (int j = 0; j < 6; j++) stm(extra_out, env * 6 + j, extra[j]);
+#ifdef IRRL_PROFILE_WAVES
+  stm(extra_out, env * 6 + 3, (float)L.prof_ranksteps); stm(extra_out, env * 6 + 4, (float)L.prof_flags);
+#endif
   IRRL_MASKED_END
   store_lane(P, S, env, leg, valid, L, P.randomize_per_episode != 0);
   IRRL_SUB0_ONLY_END

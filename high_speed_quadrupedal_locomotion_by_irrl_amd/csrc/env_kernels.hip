@@ -46,7 +46,14 @@ extern "C" {
 __global__ void __launch_bounds__(256, 1)
 IRRL_K(irrl_step_kernel)(EnvParams P, EnvState S, const float *action, float *ob, float *reward, uint8_t *done, float *extra) {
   IRRL_LANE_PROLOGUE
+#ifdef IRRL_PROFILE_WAVES   /* diagnostic build (tools/wave_spread.py): extra[env][5] <- this wave's duration in 100 MHz ticks */
+  const unsigned long long t0_ = wall_clock64();
+#endif
   irrl::step_body(P, S, env_, leg_, valid_, action, ob, reward, done, extra);
+#ifdef IRRL_PROFILE_WAVES
+  const unsigned long long t1_ = wall_clock64();
+  if (valid_ && leg_ == 0) extra[env_ * 6 + 5] = (float)(t1_ - t0_);
+#endif
 }
 
 __global__ void __launch_bounds__(256, 1) IRRL_K(irrl_init_kernel)(EnvParams P, EnvState S) {

@@ -145,6 +145,11 @@ inline bool build_params(const Config &c, EnvParams &P, std::string &err) {
   P.contact_iters = c.has("ContactIterations") ? (int32_t)num("ContactIterations") : 6;
   if (P.contact_iters <= 0) P.contact_iters = 6;
   P.contact_tol = c.has("ContactTolerance") ? (float)num("ContactTolerance") : 0.0f;
+  {
+    const int solver = c.has("ContactSolver") ? (int)num("ContactSolver") : 2;
+    if (solver != 0 && solver != 2) { err = "ContactSolver must be 2 (simultaneous updates, default) or 0 (Gauss-Seidel)"; return false; }
+    P.contact_jacobi = solver == 2 ? 1 : 0;
+  }
   P.clamp_r = P.tau_max / (P.w_max - P.w_crit);
   P.clamp_inv_den = 1.0f / (-P.w_max + P.w_crit);
   P.shared_noise = c.has("SharedNoiseScalar") ? (int32_t)flag("SharedNoiseScalar") : 1;

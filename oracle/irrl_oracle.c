@@ -653,6 +653,7 @@ typedef struct {
   real extra[6];
   real gen_force[NV]; /* last generalized force handed to the integrator (world comps for the base) */
   long gs_sweeps, gs_substeps; /* statistics: contact sweeps executed / substeps */
+  long gs_hist[64];            /* statistics: substeps (with at least one contact) by sweeps taken (last bin: >= 63) */
   long box_hits;               /* statistics: (trunk-box corner, substep) pairs in contact */
   long box_substeps, box_sweeps; /* substeps with at least one corner in contact, and the sweeps they took */
   real box_lam[8][3];          /* corner impulses of the previous substep of THIS control step (warm start; base components) */
@@ -974,7 +975,7 @@ static void physics_substep(orc_env *h, env_t *e, const real *pTarget) {
    * (URDF:26 box 0.3 x 0.2 x 0.1 centred on the base origin, collision body "body/0" ENV:242) as points against the same
    * ground with the same (default) material -- the ("steel","steel") pair of ENV:244 only concerns steel-steel pairs.
    * Corner i: x = +-0.15 (bit 2 set: -), y = +-0.1 (bit 1 set: -), z = -+0.05 (bit 0 set: +).  Gauss-Seidel order: toes
-   * FR, FL, HR, HL, then corners 0..7.  Corner impulses are not warm-started (they are not part of the persisted state). */
+   * FR, FL, HR, HL iterate (below); the corners follow in ONE pass of sequential impulses, 0..7, cold start. */
   enum { NC = 12 };
   int active[NC];
   real J[NC][3][NV], MiJt[NC][3][NV], cfree[NC][3], vstar[NC], lamB[NC][3], nBl[NC][3];
@@ -1031,9 +1032,9 @@ static void physics_substep(orc_env *h, env_t *e, const real *pTarget) {
     /* warm start: previous impulse if the foot was already in the contact list */
     if (ci < 4 && e->in_contact[ci]) m3_tmulv(lamB[ci], R, e->lam_w[ci]); else v3_set(lamB[ci], RC(0), RC(0), RC(0));
   }
-  real G[NC][NC][9];
-  for (int la = 0; la < NC; la++)
-    for (int lb = 0; lb < NC; lb++)
+  real G[4][4][9];
+  for (int la = 0; la < 4; la++)
+    for (int lb = 0; lb < 4; lb++)
       if (active[la] && active[lb])
         for (int r = 0; r < 3; r++)
           for (int r2 = 0; r2 < 3; r2++) {
@@ -1042,21 +1043,41 @@ static void physics_substep(orc_env *h, env_t *e, const real *pTarget) {
             G[la][lb][3 * r + r2] = acc;
           }
   int sweeps_done = 0;
+  /* THE PER-CONTACT ITERATION OVER THE TOES.  Groups of contacts update simultaneously (from the same iterate) inside a sweep;
+   * groups run one after the other.  ContactSolver 2 (default): the four toes are one group -- they couple only through the
+   * heavy base, the off-diagonal Delassus blocks are a fraction of the diagonal ones, and the simultaneous update converges
+   * almost as fast as Gauss-Seidel (2.4 against 2.2 sweeps per substep, same fixed point: measured) while
+   * the lock-step kernels need ONE solve per sweep instead of one per contact.  0: every toe its own group (Gauss-Seidel,
+   * FR FL HR HL);  1: two colours {FR, HL}, {FL, HR}. */
+  int group_of[4], n_groups;
+  if (c->ContactSolver == 2) { for (int l = 0; l < 4; l++) group_of[l] = 0; n_groups = 1; }
+  else if (c->ContactSolver == 1) { group_of[0] = 0; group_of[3] = 0; group_of[1] = 1; group_of[2] = 1; n_groups = 2; }
+  else { for (int l = 0; l < 4; l++) group_of[l] = l; n_groups = 4; }
+  const real relax = (c->ContactSolver == 0) ? RC(1) : RC(c->ContactRelax);
   for (int it = 0; it < c->ContactIterations; it++) {
     real d2 = RC(0), l2 = RC(0);
-    for (int l = 0; l < NC; l++) {
-      if (!active[l]) continue;
-      real cv[3], old[3];
-      v3_copy(cv, cfree[l]);
-      v3_copy(old, lamB[l]);
-      for (int lb = 0; lb < NC; lb++) {
-        if (lb == l || !active[lb]) continue;
-        real t[3];
-        m3_mulv(t, G[l][lb], lamB[lb]);
-        v3_add(cv, cv, t);
+    for (int g = 0; g < n_groups; g++) {
+      real newl[4][3];
+      for (int l = 0; l < 4; l++) {
+        if (!active[l] || group_of[l] != g) continue;
+        real cv[3];
+        v3_copy(cv, cfree[l]);
+        for (int lb = 0; lb < 4; lb++) {
+          if (lb == l || !active[lb]) continue;
+          real t[3];
+          m3_mulv(t, G[l][lb], lamB[lb]);
+          v3_add(cv, cv, t);
+        }
+        solve_contact(G[l][l], cv, nBl[l], vstar[l], m->mu, newl[l]);
       }
-      solve_contact(G[l][l], cv, nBl[l], vstar[l], m->mu, lamB[l]);
-      for (int a = 0; a < 3; a++) { real dd = lamB[l][a] - old[a]; d2 += dd * dd; l2 += lamB[l][a] * lamB[l][a]; }
+      for (int l = 0; l < 4; l++) {
+        if (!active[l] || group_of[l] != g) continue;
+        for (int a = 0; a < 3; a++) {
+          real dd = relax * (newl[l][a] - lamB[l][a]);
+          lamB[l][a] += dd;
+          d2 += dd * dd; l2 += lamB[l][a] * lamB[l][a];
+        }
+      }
     }
     /* build-defined early exit (same rule in the kernels, evaluated per wave there) */
     if (c->ContactTolerance > 0 && d2 <= RC(c->ContactTolerance * c->ContactTolerance) * l2 + RC(1e-20)) { it++; sweeps_done = it; goto gs_done; }
@@ -1065,6 +1086,7 @@ static void physics_substep(orc_env *h, env_t *e, const real *pTarget) {
 gs_done:
   e->gs_sweeps += sweeps_done;
   e->gs_substeps += 1;
+  { int anyc = 0; for (int l = 0; l < 4; l++) anyc |= active[l]; if (anyc) e->gs_hist[sweeps_done < 63 ? sweeps_done : 63] += 1; }
   { int anyb = 0; for (int l = 4; l < NC; l++) anyb |= active[l]; if (anyb) { e->box_substeps += 1; e->box_sweeps += sweeps_done; } }
   if (h->probe_env >= 0 && e == &h->envs[h->probe_env]) {   /* tests: hand out the toe contact problem and its solution */
     for (int la = 0; la < 4; la++) {
@@ -1079,13 +1101,36 @@ gs_done:
       }
     }
   }
-  for (int l = 0; l < NC; l++) {
-    if (l < 4) e->in_contact[l] = active[l];
-    if (!active[l]) { if (l < 4) v3_set(e->lam_w[l], RC(0), RC(0), RC(0)); continue; }
+  for (int l = 0; l < 4; l++) {
+    e->in_contact[l] = active[l];
+    if (!active[l]) { v3_set(e->lam_w[l], RC(0), RC(0), RC(0)); continue; }
     for (int r = 0; r < 3; r++)
       for (int cc = 0; cc < NV; cc++) ufree[cc] += MiJt[l][r][cc] * lamB[l][r];
-    if (l < 4) m3_mulv(e->lam_w[l], R, lamB[l]);
-    else e->box_hits += 1;
+    m3_mulv(e->lam_w[l], R, lamB[l]);
+  }
+  /* THE TRUNK-BOX CORNERS: one pass of sequential impulses behind the toe iteration, corners 0..7 in order, cold start.  Each
+   * touching corner sees the velocity the toes (and the corners before it) have produced, solves its own single-contact problem
+   * exactly (same rule as a toe: restitution target, Coulomb cone) and is applied at once; nothing is re-iterated, so what a
+   * later corner does to an earlier one -- and to the toes -- is left to the next 0.25 ms substep.  A corner reaches the ground
+   * only on a robot that is falling over (it terminates at 60 degrees of tilt or 0.15 m of height) or on rough terrain: cheap
+   * and momentum-consistent matters more there than a converged coupled solve. */
+  for (int l = 4; l < NC; l++) {
+    if (!active[l]) continue;
+    real Gc[9], cv[3], lam[3];
+    for (int r = 0; r < 3; r++) {
+      real acc = RC(0);
+      for (int cc = 0; cc < NV; cc++) acc += J[l][r][cc] * ufree[cc];
+      cv[r] = acc;
+      for (int r2 = 0; r2 < 3; r2++) {
+        real g = RC(0);
+        for (int cc = 0; cc < NV; cc++) g += J[l][r][cc] * MiJt[l][r2][cc];
+        Gc[3 * r + r2] = g;
+      }
+    }
+    solve_contact(Gc, cv, nBl[l], vstar[l], m->mu, lam);
+    for (int r = 0; r < 3; r++)
+      for (int cc = 0; cc < NV; cc++) ufree[cc] += MiJt[l][r][cc] * lam[r];
+    e->box_hits += 1;
   }
   /* back to world-frame gv, then positions (semi-implicit Euler) */
   m3_mulv(&e->gv[0], R, &ufree[0]);
@@ -1248,6 +1293,7 @@ orc_env *orc_create(const orc_cfg *cfg) {
   if (h) h->probe_env = -1;
   h->cfg = *cfg;
   if (h->cfg.ContactIterations <= 0) h->cfg.ContactIterations = 6;
+  if (!(h->cfg.ContactRelax > 0)) h->cfg.ContactRelax = 1.0;
   h->n = cfg->num_envs;
   h->envs = (env_t *)calloc((size_t)h->n, sizeof(env_t));
   obs_scaling(cfg, h->obMean, h->obStd);
@@ -1282,6 +1328,7 @@ int orc_set_ref(orc_env *h, const float *table, int rows, int cols) {
 }
 int orc_num_envs(const orc_env *h) { return h->n; }
 void orc_box_stats(const orc_env *h, long out[3]) { out[0] = out[1] = out[2] = 0; for (int i = 0; i < h->n; i++) { out[0] += h->envs[i].box_hits; out[1] += h->envs[i].box_substeps; out[2] += h->envs[i].box_sweeps; } }
+void orc_sweep_histogram(const orc_env *h, long out[64]) { for (int k = 0; k < 64; k++) { out[k] = 0; for (int i = 0; i < h->n; i++) out[k] += h->envs[i].gs_hist[k]; } }
 void orc_set_probe(orc_env *h, int env_id) { h->probe_env = env_id; }
 void orc_get_probe(const orc_env *h, double *G, double *cfree, double *n, double *vstar, double *lam, int *active) {
   memcpy(G, h->probe_G, sizeof(h->probe_G)); memcpy(cfree, h->probe_cfree, sizeof(h->probe_cfree)); memcpy(n, h->probe_n, sizeof(h->probe_n));

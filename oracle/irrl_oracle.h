@@ -61,6 +61,10 @@ typedef struct orc_cfg {
   int32_t SharedNoiseScalar;    /* 1: Eigen 12x1*12x1 pitfall => one shared factor (ENV:584,586,705) */
   int32_t RandomizePerEpisode;  /* 1: redo the ctor domain randomisation at every reset (config 5) */
   double ContactTolerance;      /* stop the sweeps once sum|dlambda|^2 <= tol^2 sum|lambda|^2 (0: always ContactIterations sweeps) */
+  int32_t ContactSolver;        /* order of the toe updates inside one sweep: 2 = the four toes at once (default; the kernels' one-solve-per-sweep),
+                                 * 0 = Gauss-Seidel over FR, FL, HR, HL, 1 = two colours {FR, HL} then {FL, HR} (oracle only).
+                                 * Trunk-box corners: one pass of sequential impulses behind the toe iteration, in every mode. */
+  double ContactRelax;          /* relaxation of the simultaneous updates (solvers 1, 2): lam += relax (lam_new - lam); default 1 */
 } orc_cfg;
 
 typedef struct orc_env orc_env; /* opaque vector-env handle */

@@ -41,11 +41,11 @@ class OrcCfg(C.Structure):
         ("FPS", C.c_double), ("ActionNoise", C.c_double), ("ObsNoise", C.c_double), ("GaitType", C.c_int32),
         ("MotorMaxTorque", C.c_double), ("MotorCriticalSpeed", C.c_double), ("MotorMaxSpeed", C.c_double),
         ("ContactIterations", C.c_int32), ("SharedNoiseScalar", C.c_int32), ("RandomizePerEpisode", C.c_int32),
-        ("ContactTolerance", C.c_double),
+        ("ContactTolerance", C.c_double), ("ContactSolver", C.c_int32), ("ContactRelax", C.c_double),
     ]
 
 
-_EXT_DEFAULTS = {"ContactIterations": 6, "SharedNoiseScalar": 1, "RandomizePerEpisode": 0, "ContactTolerance": 0.0}
+_EXT_DEFAULTS = {"ContactIterations": 6, "SharedNoiseScalar": 1, "RandomizePerEpisode": 0, "ContactTolerance": 0.0, "ContactSolver": 2, "ContactRelax": 1.0}
 
 
 def cfg_from_dict(env_cfg):

@@ -44,6 +44,16 @@ def test_trunk_box_corners_collide_like_the_oracle(emu):
                             max_factor=1e4)
 
 
+@pytest.mark.parametrize("emu", [E.EmuVecEnv, E.EmuVecEnv16])
+def test_gauss_seidel_contact_order_is_still_available(emu):
+    """ContactSolver: 0 (sequential Gauss-Seidel over FR, FL, HR, HL, then the box corners) -- the default is 2 (simultaneous
+    updates); both orders exist in the oracle and in the kernel source and agree with each other pairwise."""
+    orc, cand = _pair(load_env_cfg("default_cfg.yaml", num_envs=8, ContactSolver=0), emu)
+    PL.check_teacher_forced(orc, cand, steps=60, force_terminal_every=7)
+    orc, cand = _pair(load_env_cfg("bp5_imitation.yaml", num_envs=8, ContactSolver=0), emu)
+    PL.check_teacher_forced(orc, cand, steps=30, seed=3, perturb=PL.tilt_onto_box_corner, max_factor=40.0)
+
+
 def test_init_matches_oracle_train_cfg():
     PL.check_init(*_pair(load_env_cfg("default_cfg.yaml", num_envs=24)))
 

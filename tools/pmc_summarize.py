@@ -32,7 +32,7 @@ rd = cnt["FETCH_SIZE"]["median_per_launch"] * 1024.0 * cal["fetch_correction"]
 wr = cnt["WRITE_SIZE"]["median_per_launch"] * 1024.0 * cal["write_correction"]
 m = lambda c: cnt[c]["median_per_launch"]
 out = {"envs": 4096, "kernel": step_name,
-       "source": "rocprofv3 --pmc <group> --kernel-trace, one pass per group (tools/gpu_pmc.sh), 4096 envs, 300 launches, bp5_imitation.yaml",
+       "source": "rocprofv3 --pmc <group> --kernel-trace, one pass per group (tools/gpu_pmc.sh), 4096 envs, 400 launches (100 landing pre-roll + 300), bp5_imitation.yaml, Philox action stream; per-launch medians",
        "calibration": cal, "counters": cnt,
        "hbm_bytes_per_launch": {"read": rd, "written": wr, "total": rd + wr, "algorithmic": 1521 * 4096},
        "derived": {"valu_insts_per_wave": m("SQ_INSTS_VALU") / m("SQ_WAVES"), "salu_insts_per_wave": m("SQ_INSTS_SALU") / m("SQ_WAVES"),

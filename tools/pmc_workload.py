@@ -28,14 +28,16 @@ cfg = yaml.safe_load(open(os.path.join(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY
 cfg["num_envs"] = envs
 env = FlexibleGymEnv(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY__, yaml.safe_dump(cfg))
 env.init()
-g = torch.Generator(device=dev)
-g.manual_seed(1)
-pool = [torch.clamp(0.3 * torch.randn(envs, 12, device=dev, generator=g), -1, 1).contiguous() for _ in range(16)]
+# bench.py's action stream (Philox, seed 1); the first 100 steps are the landing pre-roll: the per-launch MEDIANS that
+# tools/pmc_summarize.py takes over all launches are steady-state values
+rows = steps + 100
+actions = torch.empty(rows, envs, 12, device=dev)
+_lib.check(lib.irrl_bench_actions(1, 0, envs, 0, rows, 0.3, C.c_void_p(actions.data_ptr()), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
 ob = torch.zeros(envs, 35, device=dev)
 rew = torch.zeros(envs, device=dev)
 done = torch.zeros(envs, dtype=torch.bool, device=dev)
 extra = torch.zeros(envs, 6, device=dev)
-for k in range(steps):
-    env.step(pool[k % 16], ob, rew, done, extra)
+for k in range(rows):
+    env.step(actions[k], ob, rew, done, extra)
 torch.cuda.synchronize()
 print("ok", float(rew.mean()))

@@ -24,6 +24,9 @@ def measure(policy="lstm", envs=4096, steps=750, iters=3, epochs=10, cfg_name="d
     from high_speed_quadrupedal_locomotion_by_irrl_amd.vec_env import TorchVecEnv
     cfg = yaml.safe_load(open(os.path.join(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY__, cfg_name)))["environment"]
     cfg["num_envs"] = envs
+    for kv in filter(None, os.environ.get("IRRL_CFG_OVERRIDE", "").split(",")):      # A/B runs: e.g. IRRL_CFG_OVERRIDE=ContactSolver=0
+        k, v = kv.split("=")
+        cfg[k] = yaml.safe_load(v)
     cfg["seedd"] = int(cfg.get("seedd", 1)) + 7919 * rank   # different robots on every rank of a multi-GPU run
     env = TorchVecEnv(FlexibleGymEnv(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY__, yaml.safe_dump(cfg)))
     lstm = policy == "lstm"
