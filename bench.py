@@ -9,7 +9,8 @@ kernel"), synthetic actions a = clip(0.3*N(0,1), -1, 1) from Philox(seed=1, stre
 
 STEADY STATE: robots are reset 4 cm above their standing height, i.e. the first ~46 control steps after a reset
 are free flight with the contact solve skipped.  Before --warmup the bench therefore ALWAYS runs an untimed
-pre-roll (--preroll, default 300, at least 200 steps) so that the timed region sees landed robots; it reads the
+pre-roll (--preroll, default 1000, at least 200 steps: the robots land within ~60 steps, the first wave of falls and in-step
+resets that follows has passed by step ~500) so that the timed region sees the stationary workload; it reads the
 kernels' own counters (toe-substeps in the contact list, episodes started) around the timed region, reports
 `contact_fraction_in_timed_region` / `resets_in_timed_region`, and FAILS when the region was free flight.
 
@@ -51,7 +52,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--preroll", type=int, default=300, help="untimed env steps before --warmup (never fewer than %d): robots land" % MIN_PREROLL)
+    ap.add_argument("--preroll", type=int, default=1000, help="untimed env steps before --warmup (never fewer than %d): robots land" % MIN_PREROLL)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--cfg", default="bp5_imitation.yaml")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget (0 disables)")

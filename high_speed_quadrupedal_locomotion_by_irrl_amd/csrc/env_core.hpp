@@ -1012,18 +1012,21 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     }
   IRRL_MARK("gs");
     // rank of this contact among the robot's active contacts (leg order FR,FL,HR,HL)
-    vi leg = leg_id();
-    vi act_i = vsel_i(active, 1, 0);
-    vi a0i = legs_bcast_i<0>(act_i), a1i = legs_bcast_i<1>(act_i), a2i = legs_bcast_i<2>(act_i), a3i = legs_bcast_i<3>(act_i);
-    vi rank = vsel_i(leg == 0, 0, vsel_i(leg == 1, a0i, vsel_i(leg == 2, a0i + a1i, a0i + a1i + a2i)));
-    int nrank = wave_max_small(a0i + a1i + a2i + a3i);
+    vi rank = 0;
+    int nrank = 1;   // (this block only runs when some toe of the wave touches)
+    if (P.contact_jacobi == 0) {
+      vi leg = leg_id();
+      vi act_i = vsel_i(active, 1, 0);
+      vi a0i = legs_bcast_i<0>(act_i), a1i = legs_bcast_i<1>(act_i), a2i = legs_bcast_i<2>(act_i), a3i = legs_bcast_i<3>(act_i);
+      rank = vsel_i(leg == 0, 0, vsel_i(leg == 1, a0i, vsel_i(leg == 2, a0i + a1i, a0i + a1i + a2i)));
+      nrank = wave_max_small(a0i + a1i + a2i + a3i);
+    }
     // ContactSolver 2 (default): the contacts of a robot update SIMULTANEOUSLY from the sweep's starting iterate -- one solve
     // per sweep instead of one per contact.  The toes couple only through the heavy base (off-diagonal Delassus blocks are a
     // fraction of the diagonal ones), so this converges almost as fast as Gauss-Seidel (measured on the oracle: 2.4 vs 2.2
     // sweeps per substep, p99 5 vs 4, same fixed point), and the step no longer lasts as long as the wave whose robots
     // happen to have the most feet on the ground (tools/wave_spread.py).
     const bool jacobi = P.contact_jacobi != 0;
-    if (jacobi) nrank = nrank > 0 ? 1 : 0;
     const float tol2 = P.contact_tol * P.contact_tol;
     for (int it = 0; it < P.contact_iters; it++) {
       vf d2 = 0.0f;
@@ -1544,8 +1547,10 @@ IRRL_DEV vf reward_update(const EnvParams &P, EnvLane &L, vf extra[6]) {
   return EE + BC + JR + JD + VR + BA + TR + CR;  // ENV:1546-1547 order
 }
 
-// ENV:547-635 for every lane (callers mask the result)
-IRRL_DEV void reset_lane(const EnvParams &P, EnvLane &L, vu env) {
+// ENV:547-635 for every lane (callers mask the result) WITHOUT its last three statements -- contact_obs_update, command_obs_update
+// (false) and the frame increment (ENV:627-629): a control step ends with exactly the same three (ENV:784-785), so the step kernel
+// runs them ONCE for the whole wave after it has merged the freshly reset robots (reset_lane_tail).
+IRRL_DEV void reset_lane_head(const EnvParams &P, EnvLane &L, vu env) {
   vi leg = leg_id();
   L.episode = L.episode + 1u;
   L.frame = 0;
@@ -1604,9 +1609,15 @@ IRRL_DEV void reset_lane(const EnvParams &P, EnvLane &L, vu env) {
   L.obl_env[3] = L.ob_phase[0]; L.obl_env[4] = L.ob_phase[1];
 #pragma unroll
   for (int k = 0; k < 3; k++) { L.obl_env[5 + k] = L.ob_post[k]; L.obl_env[8 + k] = L.ob_omega[k]; L.obl_q[k] = L.ob_q[k]; L.obl_qd[k] = L.ob_qd[k]; }
+}
+IRRL_DEV void reset_lane_tail(const EnvParams &P, EnvLane &L, vu env) {
   contact_obs_update(P, L);
   command_obs_update(P, L, env, false);
   L.frame = L.frame + 1;
+}
+IRRL_DEV void reset_lane(const EnvParams &P, EnvLane &L, vu env) {
+  reset_lane_head(P, L, env);
+  reset_lane_tail(P, L, env);
 }
 
 // field-wise select of two lane contexts (done ? a : b)
@@ -1872,12 +1883,7 @@ IRRL_DEV void step_body(const EnvParams &P, const EnvState &S, vi env, vi leg, v
   vf rew = L.pos.z;
   for (int j = 0; j < 6; j++) extra[j] = L.pos.z;
 #endif
-#ifndef IRRL_AB_NO_CMD
-  command_obs_update(P, L, envu, false);
-#endif
-  contact_obs_update(P, L);
-  L.frame = L.frame + 1;
-  // VEC:358-371
+  // VEC:358-371: termination is decided on the post-physics state (the command / reference update below does not touch what it reads)
   vm done = (L.pos.z < 0.15f) | (L.pos.z > 0.65f) | (L.ob_post[2] < 0.5f);
 #ifdef IRRL_AB_NO_RESET
   done = done & vm(false);
@@ -1887,10 +1893,17 @@ IRRL_DEV void step_body(const EnvParams &P, const EnvState &S, vi env, vi leg, v
     L.prof_flags |= 1;
 #endif
     EnvLane Rn = L;
-    reset_lane(P, Rn, envu);
+    reset_lane_head(P, Rn, envu);
     select_lane(done, Rn, L);
     rew = vsel(done, rew + P.c_term, rew);
   }
+  // the end of a step (ENV:784-785) and the end of a reset (ENV:627-629) are the same three statements: once for everybody
+#ifndef IRRL_AB_NO_CMD
+  reset_lane_tail(P, L, envu);
+#else
+  contact_obs_update(P, L);
+  L.frame = L.frame + 1;
+#endif
   observe_lane(P, env, leg, valid, L, ob_out);
   vm lead = valid & (leg == 0);
   IRRL_MASKED_BEGIN(lead)

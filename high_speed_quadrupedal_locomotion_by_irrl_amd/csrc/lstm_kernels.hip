@@ -391,8 +391,11 @@ lstm_seq_bwd_kernel(const float *__restrict__ gates, const float *__restrict__ c
 // 144 MFMAs per step at HID = 48) from the double-buffered dz / h_prev tiles of the step the other waves just finished:
 // with HID = 48 that is a fourth wave for the CU's fourth SIMD (the kernel's register budget allows one workgroup per
 // CU), and the recurrence waves drop from 192 to 144 MFMAs per step.
+#ifndef IRRL_BWD_MIN_WAVES
+#define IRRL_BWD_MIN_WAVES 1   /* waves per SIMD the backward kernel is compiled for (2: two workgroups -- both stacks -- share a CU) */
+#endif
 template <int HID, bool NEED_DX, bool HELPER>
-__global__ void __launch_bounds__((HID / 16 + (HELPER ? 1 : 0)) * 64)
+__global__ void __launch_bounds__((HID / 16 + (HELPER ? 1 : 0)) * 64, IRRL_BWD_MIN_WAVES)
 lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__ cseq, const float *__restrict__ hseq,
                       const float *__restrict__ x, const float *__restrict__ masks, const float *__restrict__ state0,
                       const float *__restrict__ dh_in, const float *__restrict__ wh_p, const float *__restrict__ wx_p,

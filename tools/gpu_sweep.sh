@@ -2,7 +2,7 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 rm -f gpurun_out/sweep.log
 for n in 1024 4096 8192 16384 32768 131072; do
-  timeout 300 python bench.py --cpu-seconds 0 --ppo-iters 0 --steps 1000 --warmup 100 --envs $n 2>/dev/null | grep metric | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('envs=$n', round(d['value']/1e6,2), 'M env-steps/s', round(d['roofline']['avg_launch_us'],2), 'us', 'fp32_frac', round(d['roofline_fp32']['frac'],4))" >> gpurun_out/sweep.log
+  timeout 300 python bench.py --cpu-seconds 0 --ppo-iters 0 --steps 1000 --warmup 100 --check-steps 0 --envs $n 2>/dev/null | grep metric | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('envs=$n', round(d['value']/1e6,2), 'M env-steps/s', round(d['roofline']['avg_launch_us'],2), 'us', 'fp32_frac', round(d['roofline_fp32']['frac'],4))" >> gpurun_out/sweep.log
 done
 python - <<'PY' >> gpurun_out/sweep.log 2>&1
 # PCIe-inclusive rate of the numpy (reference-style) boundary

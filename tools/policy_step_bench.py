@@ -5,7 +5,7 @@ import torch
 from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import CustomLSTMPolicy
 
 dev = torch.device("cuda")
-N, T = 4096, 64
+N, T = int(sys.argv[1]) if len(sys.argv) > 1 else 4096, 64
 pol = CustomLSTMPolicy().to(dev)
 obs = torch.randn(N, 35, device=dev)
 st = torch.randn(N, 384, device=dev) * 0.3
@@ -36,4 +36,4 @@ for _ in range(3):
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
-print("graph of %d rollout launches: %.2f us / launch" % (T, e0.elapsed_time(e1) * 1e3 / T))
+print("N %d graph of %d rollout launches: %.2f us / launch" % (N, T, e0.elapsed_time(e1) * 1e3 / T))
