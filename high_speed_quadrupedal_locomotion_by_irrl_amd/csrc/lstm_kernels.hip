@@ -755,6 +755,14 @@ lstm_policy_step_kernel(PolicyStepArgs a) {
   const int col = l & 15, rq = l >> 4;
   const int stack = w / NW, ws = w - stack * NW;
   const int e0 = blockIdx.x * 16;
+#ifdef IRRL_PROFILE_POLICY   /* diagnostic build (tools/policy_phases.py): 100 MHz time stamps of the phases of one workgroup */
+  unsigned long long ts_[8];
+  int tsn_ = 0;
+#define IRRL_PS_STAMP() do { __builtin_amdgcn_sched_barrier(0); ts_[tsn_++] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define IRRL_PS_STAMP() do { } while (0)
+#endif
+  IRRL_PS_STAMP();   // 0: start
   // N need not be a multiple of 16: rows past the pool read the last env (clamped index) and store nothing
   const int eA = (e0 + col < a.N) ? e0 + col : a.N - 1;
   int eC[4];
@@ -768,8 +776,9 @@ lstm_policy_step_kernel(PolicyStepArgs a) {
   float keepC[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) keepC[j] = a.dones[eC[j]] ? 0.0f : 1.0f;
-  for (int i = tid; i < HID * a.act_dim; i += blockDim.x) head_w[i] = a.pi_w[i];
-  if (tid < HID) head_w[HID * a.act_dim + tid] = a.vf_w[tid];
+  // (the head weights are needed last: they are fetched into registers BEHIND the LSTM operands below and parked in LDS
+  // after the first MFMA block -- staging them here made every wave wait for a global load before it issued the ~60
+  // operand loads: 5 us from kernel start to "loads issued" and 3.4 us at the first barrier, tools/policy_phases.py)
   // Everything that does not depend on layer 0's output is requested up front, in program order, so that the L2 / HBM
   // latency of ~60 independent loads overlaps instead of being paid once per k-step: both layers' previous h and c,
   // the observation slice, wh of both layers and wx of layer 0.  The recurrent half of layer 1 is accumulated before
@@ -809,7 +818,14 @@ lstm_policy_step_kernel(PolicyStepArgs a) {
     cp1[j] = a.states_in[(size_t)eC[j] * SD + soff1 + u];
   }
   const f32x4 bias0 = *(const f32x4 *)&b0[u * 4], bias1 = *(const f32x4 *)&b1[u * 4];
+  // head weights: pi_w [HID][act] then vf_w [HID] = HID * (act + 1) floats over the workgroup's threads, two per thread at most
+  const int n_head = HID * (a.act_dim + 1), nthr = 2 * NW * 64;
+  const int hi0 = tid, hi1 = tid + nthr, hi2 = tid + 2 * nthr;   // HID * 17 <= 3 * (8 HID) for every supported shape
+  const float hw0 = hi0 < n_head ? (hi0 < HID * a.act_dim ? a.pi_w[hi0] : a.vf_w[hi0 - HID * a.act_dim]) : 0.0f;
+  const float hw1 = hi1 < n_head ? (hi1 < HID * a.act_dim ? a.pi_w[hi1] : a.vf_w[hi1 - HID * a.act_dim]) : 0.0f;
+  const float hw2 = hi2 < n_head ? (hi2 < HID * a.act_dim ? a.pi_w[hi2] : a.vf_w[hi2 - HID * a.act_dim]) : 0.0f;
   __builtin_amdgcn_sched_barrier(0);   // keep the loads above clustered: the scheduler must not sink them between the MFMAs
+  IRRL_PS_STAMP();   // 1: loads issued
   f32x4 acc0[4], acc1[4];
 #pragma unroll
   for (int g = 0; g < 4; g++) { acc0[g] = (f32x4){bias0[g], bias0[g], bias0[g], bias0[g]}; acc1[g] = (f32x4){bias1[g], bias1[g], bias1[g], bias1[g]}; }
@@ -847,8 +863,13 @@ lstm_policy_step_kernel(PolicyStepArgs a) {
 #pragma unroll
     for (int g = 0; g < 4; g++) acc1[g] = PS_MFMA(av, Wh1[kk][g], acc1[g]);
   }
+  if (hi0 < n_head) head_w[hi0] = hw0;
+  if (hi1 < n_head) head_w[hi1] = hw1;
+  if (hi2 < n_head) head_w[hi2] = hw2;
+  IRRL_PS_STAMP();   // 2: layer-0 and recurrent layer-1 MFMAs issued (the loads have landed)
   // every wave has read the previous h of both layers before anyone overwrites them: states_out may alias states_in
   __syncthreads();
+  IRRL_PS_STAMP();   // 3: barrier
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const float ig = fast_sigmoid(acc0[0][j]), fg = fast_sigmoid(acc0[1][j]), og = fast_sigmoid(acc0[2][j]), gg = fast_tanh(acc0[3][j]);
@@ -865,6 +886,7 @@ lstm_policy_step_kernel(PolicyStepArgs a) {
 #pragma unroll
     for (int g = 0; g < 4; g++) acc1[g] = PS_MFMA(av, Wx1[kk][g], acc1[g]);
   }
+  IRRL_PS_STAMP();   // 4: layer-0 cell + layer-1 input MFMAs
   __syncthreads();   // all reads of layer 0's h are done before hbuf is reused for layer 1's h
 #pragma unroll
   for (int j = 0; j < 4; j++) {
@@ -876,7 +898,13 @@ lstm_policy_step_kernel(PolicyStepArgs a) {
     hbuf[stack][(4 * rq + j) * LD + u] = hn;
   }
   __syncthreads();
+  IRRL_PS_STAMP();   // 5: layer-1 cell
   policy_heads<HID>(a, hbuf[0], hbuf[1], LD, head_w, terms, e0, tid, t, gstep);
+  IRRL_PS_STAMP();   // 6: heads, sample, buffer rows
+#ifdef IRRL_PROFILE_POLICY
+  if (blockIdx.x == gridDim.x / 2 && tid == 0)
+    for (int k = 0; k < 7; k++) a.neglogp[k] = (float)(ts_[k] - ts_[0]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
