@@ -55,6 +55,8 @@ def parse_args(argv=None):
     ap.add_argument("--preroll", type=int, default=1000, help="untimed env steps before --warmup (never fewer than %d): robots land" % MIN_PREROLL)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--cfg", default="bp5_imitation.yaml")
+    ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
+                    help="override one key of the env configuration (YAML scalar), e.g. --set Crutial=true; the bench line names it")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget (0 disables)")
     ap.add_argument("--ppo-iters", type=int, default=2, help="timed PPO iterations of the LSTM policy (0 disables)")
     ap.add_argument("--ppo-steps", type=int, default=750, help="rollout length of the PPO leg (the metric's is 750)")
@@ -193,6 +195,11 @@ def worker(args):
 
     with open(os.path.join(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY__, args.cfg)) as f:
         env_cfg = yaml.safe_load(f)["environment"]
+    for kv in args.set:
+        key, _, val = kv.partition("=")
+        if key not in env_cfg:
+            raise SystemExit("--set %s: no such key in %s" % (key, args.cfg))
+        env_cfg[key] = yaml.safe_load(val)
     n = args.envs
     env_cfg["num_envs"] = n
     env_cfg["seedd"] = int(env_cfg.get("seedd", 1)) + 7919 * rank   # different robots on every rank
@@ -312,8 +319,8 @@ def worker(args):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE config 2: %d envs/GPU x 1 env.step (8 substeps @4 kHz + obs + reward + "
-                                   "termination + in-step reset), cfg %s, actions clip(0.3 N(0,1)) from Philox(seed 1, stream env, counter step), "
-                                   "%d-step untimed pre-roll before the warm-up" % (n, args.cfg, preroll),
+                                   "termination + in-step reset), cfg %s%s, actions clip(0.3 N(0,1)) from Philox(seed 1, stream env, counter step), "
+                                   "%d-step untimed pre-roll before the warm-up" % (n, args.cfg, (" with " + ", ".join(args.set)) if args.set else "", preroll),
                        "envs_per_gpu": n, "global_envs": n * world, "parallelism": "env-sharded x%d" % world,
                        "lanes_per_robot": env.lanes_per_robot, "preroll": preroll,
                        "launch": "one hipGraph of %d step-kernel nodes" % args.steps if graph is not None else "one launch per step from the host"},

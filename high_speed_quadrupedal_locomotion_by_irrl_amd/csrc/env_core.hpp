@@ -302,6 +302,8 @@ struct EnvLane {
   vf ob_q[3], ob_qd[3];                                // leg-level part (joint angles / rates + noise)
   vf obl_env[11], obl_q[3], obl_qd[3];                 // obDouble_last_ (only meaningful with ObsFilter)
   LegModel m;
+  // Crutial: True -- the meteorite (replicated in the robot's lanes; untouched otherwise)
+  v3 sp, sv; vf srad, smass; vi sdyn;
   // scratch carried from the dynamics to the epilogue
   v3 bodyLinVel, bodyAngVel;
 };
@@ -731,6 +733,96 @@ IRRL_DEV bool box_pass(const EnvParams &P, const EnvLane &L, const rot3 &R, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// The meteorite of Crutial: True (Environment.hpp:273-284, 731-740, 815-861).  The reference creates CubeNum "steel" spheres
+// at the same point with the same radius, mass and velocity (cube_place_radius = 0, ENV:1976): one sphere of CubeNum times
+// the mass here.  Every lane of a robot carries the same copy and does the same arithmetic (no lane specialisation: the path
+// runs for ~0.2 s out of every 1 s of a Crutial pool and not at all otherwise).
+//   meteoriteAttack(true)  ENV:815-842: parked (STATIC) at gc_ + (0.05, 0, 1.0), radius (t/5 + 1) cube_len, mass t/5 + 0.2 each
+//   meteoriteAttack(false) ENV:845-858: a parked sphere becomes DYNAMIC with velocity (gv_[0], gv_[1], -5)
+// ---------------------------------------------------------------------------------------------
+#define IRRL_CUBE_LEN 0.08f   // ENV:1974
+IRRL_DEV void sphere_place(const EnvParams &P, EnvLane &L, v3 base, vf t, vm m) {
+  L.sp.x = vsel(m, base.x + 0.05f, L.sp.x); L.sp.y = vsel(m, base.y, L.sp.y); L.sp.z = vsel(m, base.z + 1.0f, L.sp.z);
+  L.sv.x = vsel(m, 0.0f, L.sv.x); L.sv.y = vsel(m, 0.0f, L.sv.y); L.sv.z = vsel(m, 0.0f, L.sv.z);
+  L.srad = vsel(m, (t * 0.2f + 1.0f) * IRRL_CUBE_LEN, L.srad);
+  L.smass = vsel(m, (t * 0.2f + 0.2f) * P.cube_num, L.smass);
+  L.sdyn = vsel_i(m, 0, L.sdyn);
+}
+IRRL_DEV void sphere_release(EnvLane &L, vm m) {
+  m = m & (L.sdyn == 0);
+  L.sv.x = vsel(m, L.vw.x, L.sv.x); L.sv.y = vsel(m, L.vw.y, L.sv.y); L.sv.z = vsel(m, -5.0f, L.sv.z);
+  L.sdyn = vsel_i(m, 1, L.sdyn);
+}
+// One pass of sequential impulses behind the toes and the corners, released spheres only:
+//   sphere - trunk box ("steel"-"steel": mu 0, e 0.95, threshold 0.001, ENV:244): closest point q of the box (URDF:26) to the
+//     centre, normal from the sphere into the box; Delassus block = K M^-1 K^T of q (base only, K = [1 | -[q]x]) + 1 / m_s;
+//   sphere - ground (this env's default material pair), block 1 / m_s;
+// then the sphere integrates (semi-implicit Euler).  ub: base twist so far; -> dxb: what the sphere does to it (false: nothing).
+IRRL_DEV bool sphere_pass(const EnvParams &P, EnvLane &L, const rot3 &R, const vf L6[21], const vf ub[6], v3 vB, v3 wB, vf dxb[6]) {
+  const float dt = P.sim_dt;
+  const vm dyn = L.sdyn != 0;
+  const v3 sv_pre = L.sv;
+  const vf ms_inv = v_rcp(v_max(L.smass, 1e-6f));
+  L.sv.z = vsel(dyn, L.sv.z - 9.81f * dt, L.sv.z);
+  v3 cB = rot_tmul(R, L.sp - L.pos);
+  v3 qB = mk3(v_min(v_max(cB.x, -IRRL_BOX_HX), IRRL_BOX_HX), v_min(v_max(cB.y, -IRRL_BOX_HY), IRRL_BOX_HY), v_min(v_max(cB.z, -IRRL_BOX_HZ), IRRL_BOX_HZ));
+  v3 dd = cB - qB;
+  vf dist2 = dot(dd, dd);
+  const vm hit = dyn & (dist2 < L.srad * L.srad);
+  const bool any = wave_any(hit);
+  if (any) {
+    vf inv = v_rsqrt(v_max(dist2, 1e-18f));
+    vm outside = dist2 > 1e-18f;   // centre inside the box: the sphere leaves through the top face
+    v3 n = mk3(vsel(outside, -dd.x * inv, 0.0f), vsel(outside, -dd.y * inv, 0.0f), vsel(outside, -dd.z * inv, -1.0f));
+    const vf z0 = 0.0f, o1 = 1.0f;
+    vf Y[3][6] = {{o1, z0, z0, z0, qB.z, -qB.y}, {z0, o1, z0, -qB.z, z0, qB.x}, {z0, z0, o1, qB.y, -qB.x, z0}};
+#pragma unroll
+    for (int r = 0; r < 3; r++) l6_fwd(L6, Y[r]);
+    vf g[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+      for (int c = r; c < 3; c++) {
+        vf acc = Y[r][0] * Y[c][0];
+#pragma unroll
+        for (int i = 1; i < 6; i++) acc += Y[r][i] * Y[c][i];
+        g[r][c] = acc;
+      }
+    sym3 G;
+    G.xx = g[0][0] + ms_inv; G.xy = g[0][1]; G.xz = g[0][2]; G.yy = g[1][1] + ms_inv; G.yz = g[1][2]; G.zz = g[2][2] + ms_inv;
+    ContactBlock CB = make_contact_block(G, n);
+    v3 svB = rot_tmul(R, L.sv), svB_pre = rot_tmul(R, sv_pre);
+    v3 c = mk3(ub[0], ub[1], ub[2]) + cross(mk3(ub[3], ub[4], ub[5]), qB) - svB;
+    v3 pre = vB + cross(wB, qB) - svB_pre;
+    vf vn = dot(pre, n);
+    vf vs = vsel(vn < -0.001f, -0.95f * vn, 0.0f);
+    v3 lam = solve_contact(CB, c, n, vs, 0.0f, hit);
+    lam = mk3(vsel(hit, lam.x, 0.0f), vsel(hit, lam.y, 0.0f), vsel(hit, lam.z, 0.0f));
+#pragma unroll
+    for (int i = 0; i < 6; i++) dxb[i] = Y[0][i] * lam.x + Y[1][i] * lam.y + Y[2][i] * lam.z;
+    l6_bwd(L6, dxb);
+    v3 sw = rot_mul(R, svB - ms_inv * lam);
+    L.sv.x = vsel(hit, sw.x, L.sv.x); L.sv.y = vsel(hit, sw.y, L.sv.y); L.sv.z = vsel(hit, sw.z, L.sv.z);
+  }
+  {
+    vf hgt = 0.0f;
+    v3 nw = mk3(0.0f, 0.0f, 1.0f);
+    if (P.terrain) terrain_sample(P, L.sp.x, L.sp.y, hgt, nw);
+    const vm gnd = dyn & ((L.sp.z - hgt) * nw.z - L.srad <= 0.0f);
+    if (wave_any(gnd)) {
+      sym3 G; G.xx = ms_inv; G.xy = 0.0f; G.xz = 0.0f; G.yy = ms_inv; G.yz = 0.0f; G.zz = ms_inv;
+      ContactBlock CB = make_contact_block(G, nw);
+      vf vn = dot(sv_pre, nw);
+      vf vs = vsel(vn < -L.m.rest_thr, -L.m.rest * vn, 0.0f);
+      v3 lam = solve_contact(CB, L.sv, nw, vs, L.m.mu, gnd);
+      L.sv.x = vsel(gnd, L.sv.x + ms_inv * lam.x, L.sv.x); L.sv.y = vsel(gnd, L.sv.y + ms_inv * lam.y, L.sv.y); L.sv.z = vsel(gnd, L.sv.z + ms_inv * lam.z, L.sv.z);
+    }
+  }
+  L.sp.x = vsel(dyn, L.sp.x + dt * L.sv.x, L.sp.x); L.sp.y = vsel(dyn, L.sp.y + dt * L.sv.y, L.sp.y); L.sp.z = vsel(dyn, L.sp.z + dt * L.sv.z, L.sp.z);
+  return any;
+}
+
+// ---------------------------------------------------------------------------------------------
 // one physics substep (ENV:761-768): PD + clamp, then the build's integrate()
 // ---------------------------------------------------------------------------------------------
 
@@ -1086,6 +1178,13 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
       for (int i = 0; i < 6; i++) { ub[i] += dxb[i]; ul_s -= Xs[i] * dxb[i]; }
     }
   }
+  if (IRRL_UNLIKELY(P.crutial != 0) && wave_any(L.sdyn != 0)) {
+    vf dxb[6];
+    if (sphere_pass(P, L, R, D.L6, ub, vB, wB, dxb)) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) { ub[i] += dxb[i]; ul_s -= Xs[i] * dxb[i]; }
+    }
+  }
   IRRL_MARK("integrate");
   L.in_contact = vsel_i(active, 1, 0);
   L.ccount = L.ccount + to_u(L.in_contact);
@@ -1277,6 +1376,17 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
   if (IRRL_UNLIKELY(box_near)) {
     vf dxb[6];
     if (box_pass(P, L, R, D.L6, ub, vB, wB, dxb)) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        ub[i] += dxb[i];
+#pragma unroll
+        for (int j = 0; j < 3; j++) ul[j] -= D.X[i][j] * dxb[i];
+      }
+    }
+  }
+  if (IRRL_UNLIKELY(P.crutial != 0) && wave_any(L.sdyn != 0)) {
+    vf dxb[6];
+    if (sphere_pass(P, L, R, D.L6, ub, vB, wB, dxb)) {
 #pragma unroll
       for (int i = 0; i < 6; i++) {
         ub[i] += dxb[i];
@@ -1540,6 +1650,9 @@ IRRL_DEV void reset_lane_head(const EnvParams &P, EnvLane &L, vu env) {
   if (P.randomize_per_episode && P.stochastic) model_randomize(L.m, leg, P.seed, env, L.episode);
   rng4 rt = philox_u01(P.seed, env, L.episode, 0u, IRRL_P_RESET_TIME);
   L.t0 = P.manual ? 0.0f : rt.u0;
+  // ENV:608-612: the meteorite is parked above gc_, which still holds the base position of the state BEFORE this reset (the new
+  // state is set further down, ENV:617-623), sized by the new episode's start time
+  if (P.crutial) sphere_place(P, L, L.pos, L.t0, vm(true));
   if (P.ref_traj) {
     // ENV:538-539, 571: random start frame in the first half of the table, frame_len + 10 rows before its end
     const int span = P.ref_rows / 2 - (int)(P.max_time / P.control_dt) - 10;
@@ -1626,6 +1739,9 @@ IRRL_DEV void select_lane(vm m, const EnvLane &a, EnvLane &b) {
   b.ww.x = vsel(m, a.ww.x, b.ww.x); b.ww.y = vsel(m, a.ww.y, b.ww.y); b.ww.z = vsel(m, a.ww.z, b.ww.z);
   b.t0 = vsel(m, a.t0, b.t0); b.frame = vsel_i(m, a.frame, b.frame); b.episode = vsel_u(m, a.episode, b.episode);
   b.up_height = vsel(m, a.up_height, b.up_height);
+  b.sp.x = vsel(m, a.sp.x, b.sp.x); b.sp.y = vsel(m, a.sp.y, b.sp.y); b.sp.z = vsel(m, a.sp.z, b.sp.z);
+  b.sv.x = vsel(m, a.sv.x, b.sv.x); b.sv.y = vsel(m, a.sv.y, b.sv.y); b.sv.z = vsel(m, a.sv.z, b.sv.z);
+  b.srad = vsel(m, a.srad, b.srad); b.smass = vsel(m, a.smass, b.smass); b.sdyn = vsel_i(m, a.sdyn, b.sdyn);
   b.bodyLinVel.x = vsel(m, a.bodyLinVel.x, b.bodyLinVel.x); b.bodyLinVel.y = vsel(m, a.bodyLinVel.y, b.bodyLinVel.y); b.bodyLinVel.z = vsel(m, a.bodyLinVel.z, b.bodyLinVel.z);
   b.bodyAngVel.x = vsel(m, a.bodyAngVel.x, b.bodyAngVel.x); b.bodyAngVel.y = vsel(m, a.bodyAngVel.y, b.bodyAngVel.y); b.bodyAngVel.z = vsel(m, a.bodyAngVel.z, b.bodyAngVel.z);
   // model (only changes with RandomizePerEpisode)
@@ -1669,6 +1785,14 @@ IRRL_DEV void load_lane(const EnvParams &P, const EnvState &S, vi env, vi leg, E
   L.m.comT = mk3(ld(S.com, cb + 6 + leg * 9), ld(S.com, cb + 7 + leg * 9), ld(S.com, cb + 8 + leg * 9));
   L.m.comS = mk3(ld(S.com, cb + 9 + leg * 9), ld(S.com, cb + 10 + leg * 9), ld(S.com, cb + 11 + leg * 9));
   L.m.dz = ld(S.thigh_dz, env);
+  if (P.crutial) {
+    vi sb = env * 9;
+    L.sp = mk3(ld(S.sphere, sb), ld(S.sphere, sb + 1), ld(S.sphere, sb + 2));
+    L.sv = mk3(ld(S.sphere, sb + 3), ld(S.sphere, sb + 4), ld(S.sphere, sb + 5));
+    L.srad = ld(S.sphere, sb + 6); L.smass = ld(S.sphere, sb + 7); L.sdyn = f2i(ld(S.sphere, sb + 8));
+  } else {
+    L.sp = mk3(0.0f, 0.0f, 0.0f); L.sv = mk3(0.0f, 0.0f, 0.0f); L.srad = 0.0f; L.smass = 0.0f; L.sdyn = 0;
+  }
   // raw observation (needed by observe()/isTerminalState() between steps, and by the ObsFilter history)
   vi ob = env * 35;
   if (for_step) {
@@ -1736,6 +1860,12 @@ IRRL_DEV void store_lane(const EnvParams &P, const EnvState &S, vi env, vi leg, 
   stm(S.gv, gvb + 3, L.ww.x); stm(S.gv, gvb + 4, L.ww.y); stm(S.gv, gvb + 5, L.ww.z);
   stm(S.t0, env, L.t0); stm_i(S.frame_idx, env, L.frame); stm_u(S.episode, env, L.episode); stm(S.up_height, env, L.up_height);
   stm(S.ob, ob + 3, L.ob_phase[0]); stm(S.ob, ob + 4, L.ob_phase[1]);
+  if (P.crutial) {
+    vi sb = env * 9;
+    stm(S.sphere, sb, L.sp.x); stm(S.sphere, sb + 1, L.sp.y); stm(S.sphere, sb + 2, L.sp.z);
+    stm(S.sphere, sb + 3, L.sv.x); stm(S.sphere, sb + 4, L.sv.y); stm(S.sphere, sb + 5, L.sv.z);
+    stm(S.sphere, sb + 6, L.srad); stm(S.sphere, sb + 7, L.smass); stm(S.sphere, sb + 8, i2f(L.sdyn));
+  }
   if (P.obs_filter) {
 #pragma unroll
     for (int k = 0; k < 5; k++) stm(S.ob_last, ob + k, L.obl_env[k]);
@@ -1829,6 +1959,15 @@ IRRL_DEV void step_body(const EnvParams &P, const EnvState &S, vi env, vi leg, v
       pT[k] = p; L.ptl[k] = p;
     }
   }
+  if (P.crutial) {
+    // ENV:731-740: every int(5 period / control_dt) frames the meteorite is parked above the robot; on every other frame a
+    // parked one is released
+    const float kf = (float)P.attack_every;
+    const vf fr = i2f(L.frame);
+    const vm park = (fr - v_floor(fr / kf) * kf) < 0.5f;   // frame % K == 0 (exact in f32)
+    sphere_place(P, L, L.pos, env_time(P, L), park);
+    sphere_release(L, !park);
+  }
   if (P.state_disturbance) {
     // ENV:743-748, 912-940 (Manual evaluation runs): every 10 gait periods the base state is kicked -- z, the four
     // quaternion components, v_z and the roll / pitch rates get uniform(-1, 1) noise scaled 0.03 | 0.1 | 0.1 | 0.3 times 0.5.
@@ -1919,6 +2058,7 @@ IRRL_DEV void init_body(const EnvParams &P, const EnvState &S, vi env, vi leg, v
   L.pos = mk3(0.0f, 0.0f, 0.0f); L.qw = 1.0f; L.qx = 0.0f; L.qy = 0.0f; L.qz = 0.0f;
   L.vw = mk3(0.0f, 0.0f, 0.0f); L.ww = mk3(0.0f, 0.0f, 0.0f);
   L.t0 = 0.0f; L.frame = 0; L.episode = 0u; L.up_height = P.up_height_max;
+  L.sp = mk3(0.0f, 0.0f, 0.0f); L.sv = mk3(0.0f, 0.0f, 0.0f); L.srad = 0.0f; L.smass = 0.0f; L.sdyn = 0;
   L.bodyLinVel = mk3(0.0f, 0.0f, 0.0f); L.bodyAngVel = mk3(0.0f, 0.0f, 0.0f);
   if (P.stochastic) model_randomize(L.m, leg, P.seed, to_u(env), 0u); else model_nominal(L.m, leg);
   L.jr[0] = L.m.sy * P.abad;  // ENV:415-418

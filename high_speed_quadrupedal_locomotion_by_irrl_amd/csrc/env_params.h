@@ -38,6 +38,10 @@ struct EnvParams {
   int32_t state_disturbance;   // Manual + ForceDisturbance: periodic kick of the base state (Environment.hpp:912-940)
   int32_t disturb_every;       // int(period / control_dt * 10) evaluated in double like ENV:747 (in f32, 0.02 / 0.002 * 10 truncates to 99)
   const float *ref;
+  // Crutial: True -- the meteorite (Environment.hpp:273-284, 731-740, 815-861)
+  int32_t crutial;
+  int32_t attack_every;        // int(5 * period / control_dt) evaluated in double like ENV:733
+  float cube_num;              // CubeNum coincident spheres (cube_place_radius = 0, ENV:1976) carried as one of CubeNum x the mass
   // derived scalars (irrl_host::derive_params): reciprocals and products of the configuration that the per-step epilogue would
   // otherwise divide by in every lane (an IEEE f32 division is ~10 VALU instructions on gfx950)
   float inv_control_dt, inv_period, inv_lam, inv_one_minus_lam;
@@ -68,6 +72,7 @@ struct EnvState {
   float *thigh_dz;      // [N]
   float *ob;            // [N,35] unscaled observation (obDouble_)
   float *ob_last;       // [N,35]
+  float *sphere;        // [N,9]  Crutial: True -- meteorite centre 3, velocity 3 (world), radius, mass, body type (0 STATIC / 1 DYNAMIC)
   // diagnostic counter, NOT part of the env state (own allocation, may be NULL): toe-substeps spent in the contact list
   // since the pool was created, per (env, leg); bench.py reads it around the timed region to prove the region was not free flight
   uint32_t *contact_count;  // [N,4]

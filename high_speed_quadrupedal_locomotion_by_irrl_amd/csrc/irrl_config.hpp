@@ -158,7 +158,13 @@ inline bool build_params(const Config &c, EnvParams &P, std::string &err) {
   if (P.n_envs <= 0) { err = "num_envs must be positive"; return false; }
   if (P.loop_count <= 0) { err = "control_dt / simulation_dt must be >= 1"; return false; }
   const bool crutial = flag("Crutial"), terrain = flag("Terrain"), manual_traj = flag("ManualTraj"), force = flag("ForceDisturbance");
-  if (crutial) { err = "Crutial: True (meteorite spheres, Environment.hpp:815-861) is not built in this engine"; return false; }
+  P.crutial = crutial ? 1 : 0;
+  {
+    const double cubes = num("CubeNum"), period = num("period");
+    P.cube_num = (float)(cubes > 0.0 ? (double)(int)cubes : 1.0);
+    P.attack_every = control_dt > 0.0 ? (int32_t)(5.0 * period / control_dt) : 0;   // Environment.hpp:733
+    if (P.attack_every <= 0) P.crutial = 0;
+  }
   P.terrain = terrain ? 1 : 0;  // the table itself is attached by the owner of the pool (irrl_terrain.hpp)
   P.hf_nx = 5000; P.hf_ny = 500;  // Environment.hpp:259-260
   P.hf_x0 = -250.0f; P.hf_y0 = -10.0f; P.hf_max = 0.0f;

@@ -416,9 +416,16 @@ int irrl_env_set_contact_coeff_host(irrl_env *h, const float *in) {
   HIP_TRY(hipStreamSynchronize(h->stream));
   return 0;
 }
-int irrl_env_sphere_info_host(irrl_env *, float *) {
-  g_err = "GetSphereInfo needs Crutial: True (Environment.hpp:1423-1436), which this engine does not build";
-  return 1;
+int irrl_env_sphere_info_host(irrl_env *h, float *out) {   // Environment.hpp:1423-1436: centre of cubes[0] and its radius
+  if (h && !h->P.crutial) { g_err = "GetSphereInfo: Please make sure the [Flag_Crucial] is True (Environment.hpp:1434)"; return 1; }
+  if (need_init(h)) return 1;
+  std::vector<float> sph((size_t)h->P.n_envs * 9);
+  if (d2h(h, sph.data(), h->S.sphere, sph.size() * 4)) return 1;
+  for (int e = 0; e < h->P.n_envs; e++) {
+    for (int k = 0; k < 3; k++) out[4 * e + k] = sph[9 * e + k];
+    out[4 * e + 3] = sph[9 * e + 6];
+  }
+  return 0;
 }
 
 int irrl_env_get_state_host(irrl_env *h, double *out) {

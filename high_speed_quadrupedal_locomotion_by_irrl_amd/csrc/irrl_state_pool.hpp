@@ -4,7 +4,7 @@
 //
 // The reference keeps this state scattered over N heap-allocated ENVIRONMENT objects (members at
 // Environment.hpp:1904-2086) plus one raisim::World each; here it is a structure of arrays sized for
-// HBM residency: 277 words (1.1 KB) per robot, 36 MB for 32 768 robots.
+// HBM residency: 286 words (1.1 KB) per robot, 36 MB for 32 768 robots.
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -20,20 +20,20 @@ enum {
   FS_GC = 0, FS_GV = 19, FS_PTL = 37, FS_TQL = 49, FS_TQ = 61, FS_JR = 73, FS_JRL = 85, FS_JDR = 97, FS_EER = 109,
   FS_CMD = 121, FS_CMDF = 124, FS_T0 = 127, FS_FRAME = 128, FS_EPISODE = 129, FS_UPH = 130, FS_CONTACT = 131,
   FS_LAMW = 135, FS_INCONTACT = 147, FS_MATERIAL = 151, FS_MASS = 154, FS_COM = 167, FS_THIGH = 206, FS_OB = 207,
-  FS_OBLAST = 242, FS_END = 277
+  FS_OBLAST = 242, FS_SPHERE = 277, FS_END = 286
 };
 
 struct StatePool {
   int n = 0;
   size_t bytes = 0;
-  size_t off[24] = {0};
+  size_t off[25] = {0};
 
   static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
   explicit StatePool(int n_envs = 0) : n(n_envs) {
-    const int words[24] = {19, 18, 12, 12, 12, 12, 12, 12, 12, 12, 4, 4, 3, 3, 1, 1, 1, 1, 3, 13, 39, 1, 35, 35};
+    const int words[25] = {19, 18, 12, 12, 12, 12, 12, 12, 12, 12, 4, 4, 3, 3, 1, 1, 1, 1, 3, 13, 39, 1, 35, 35, 9};
     size_t o = 0;
-    for (int i = 0; i < 24; i++) { off[i] = o; o = align256(o + (size_t)words[i] * 4u * (size_t)(n > 0 ? n : 0)); }
+    for (int i = 0; i < 25; i++) { off[i] = o; o = align256(o + (size_t)words[i] * 4u * (size_t)(n > 0 ? n : 0)); }
     bytes = o;
   }
   EnvState view(void *base) const {
@@ -47,6 +47,7 @@ struct StatePool {
     S.frame_idx = (int32_t *)(b + off[15]); S.episode = (uint32_t *)(b + off[16]); S.up_height = (float *)(b + off[17]);
     S.material = (float *)(b + off[18]); S.mass = (float *)(b + off[19]); S.com = (float *)(b + off[20]);
     S.thigh_dz = (float *)(b + off[21]); S.ob = (float *)(b + off[22]); S.ob_last = (float *)(b + off[23]);
+    S.sphere = (float *)(b + off[24]);
     S.contact_count = nullptr;   // diagnostic, allocated separately by the C-ABI
     return S;
   }
@@ -70,6 +71,7 @@ struct StatePool {
       for (int k = 0; k < 39; k++) o[FS_COM + k] = S.com[e * 39 + k];
       o[FS_THIGH] = S.thigh_dz[e];
       for (int k = 0; k < 35; k++) { o[FS_OB + k] = S.ob[e * 35 + k]; o[FS_OBLAST + k] = S.ob_last[e * 35 + k]; }
+      for (int k = 0; k < 9; k++) o[FS_SPHERE + k] = S.sphere[e * 9 + k];
     }
   }
   void unpack(const double *in, void *host_base) const {
@@ -90,6 +92,7 @@ struct StatePool {
       for (int k = 0; k < 39; k++) S.com[e * 39 + k] = (float)o[FS_COM + k];
       S.thigh_dz[e] = (float)o[FS_THIGH];
       for (int k = 0; k < 35; k++) { S.ob[e * 35 + k] = (float)o[FS_OB + k]; S.ob_last[e * 35 + k] = (float)o[FS_OBLAST + k]; }
+      for (int k = 0; k < 9; k++) S.sphere[e * 9 + k] = (float)o[FS_SPHERE + k];
     }
   }
 };

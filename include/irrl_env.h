@@ -95,7 +95,8 @@ int irrl_env_generalized_force_host(irrl_env *h, float *out /* [N,18] ENV:1363-1
 int irrl_env_inverse_mass_matrix_host(irrl_env *h, float *out /* [N,324] column-major, ENV:1375-1391 */);
 int irrl_env_nonlinear_host(irrl_env *h, float *out /* [N,18] ENV:1396-1402 */);
 int irrl_env_set_contact_coeff_host(irrl_env *h, const float *in /* [N,3] mu, e, thr; ENV:1407-1418 */);
-/* PYB:46 GetSphereInfo needs Crutial: True (ENV:1423-1436), which this engine does not build: returns an error */
+/* PYB:46 / VEC:253-256 GetSphereInfo (ENV:1423-1436): centre (world) and radius of the meteorite of a `Crutial: True` pool;
+ * an error on a pool without it (the reference prints "Please make sure the [Flag_Crucial] is True") */
 int irrl_env_sphere_info_host(irrl_env *h, float *out /* [N,4] */);
 
 /* Full state exchange (build-defined, for checkpoint/parity): flat [N, IRRL_STATE_DIM] doubles per env,
@@ -107,7 +108,8 @@ enum {
   IRRL_S_COMMAND = 121, IRRL_S_COMMAND_FILTERED = 124, IRRL_S_T0 = 127, IRRL_S_FRAME = 128, IRRL_S_EPISODE = 129,
   IRRL_S_UP_HEIGHT = 130, IRRL_S_CONTACT = 131, IRRL_S_LAMBDA_W = 135, IRRL_S_IN_CONTACT = 147,
   IRRL_S_MATERIAL = 151, IRRL_S_MASS = 154, IRRL_S_COM = 167, IRRL_S_THIGH_DZ = 206, IRRL_S_OB = 207,
-  IRRL_S_OB_LAST = 242, IRRL_S_END = 277
+  IRRL_S_OB_LAST = 242,
+  IRRL_S_SPHERE = 277 /* Crutial: meteorite centre 3, velocity 3, radius, mass, body type (0 static / 1 dynamic) */, IRRL_S_END = 286
 };
 int irrl_env_get_state_host(irrl_env *h, double *out);
 int irrl_env_set_state_host(irrl_env *h, const double *in);

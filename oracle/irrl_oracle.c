@@ -656,6 +656,11 @@ typedef struct {
   long gs_hist[64];            /* statistics: substeps (with at least one contact) by sweeps taken (last bin: >= 63) */
   long box_hits;               /* statistics: (trunk-box corner, substep) pairs in contact */
   long box_substeps, box_sweeps; /* substeps with at least one corner in contact, and the sweeps they took */
+  /* the meteorite of Crutial: True (ENV:273-284, 815-861): the CubeNum spheres are created at the same point with the same
+   * radius, mass and velocity (cube_place_radius = 0, ENV:1976), so they are carried as ONE sphere of CubeNum times the mass */
+  real sph_p[3], sph_v[3], sph_rad, sph_mass;
+  int32_t sph_dyn;             /* raisim::BodyType: 0 STATIC (parked, no dynamics), 1 DYNAMIC (released) */
+  long sph_hits;               /* statistics: substeps in which the sphere touched the trunk box */
   real box_lam[8][3];          /* corner impulses of the previous substep of THIS control step (warm start; base components) */
   int box_was_active[8];
   robot_model model;
@@ -931,6 +936,25 @@ static real deep_mimic_reward(orc_env *h, env_t *e) {
 }
 
 /* ENV:1553-1578 */
+
+/* ---- the meteorite (Crutial: True) ----
+ * ENV:815-842 meteoriteAttack(true): the spheres are re-created STATIC at gc_ + (0.05, 0, 1.0) with radius
+ * (t/5 + 1) * cube_len and mass t/5 + 0.2 each ("steel"); ENV:845-858 meteoriteAttack(false) on a parked sphere: DYNAMIC with
+ * velocity (gv_[0], gv_[1], -5). */
+#define CUBE_LEN 0.08 /* ENV:1974 */
+static void sphere_place(const orc_cfg *c, env_t *e, const real *base_pos, real t) {
+  e->sph_p[0] = base_pos[0] + RC(0.05); e->sph_p[1] = base_pos[1]; e->sph_p[2] = base_pos[2] + RC(1.0);
+  v3_set(e->sph_v, RC(0), RC(0), RC(0));
+  e->sph_rad = (t / RC(5.0) + RC(1.0)) * RC(CUBE_LEN);
+  e->sph_mass = (t / RC(5.0) + RC(0.2)) * RC((double)(c->CubeNum > 0 ? c->CubeNum : 1));
+  e->sph_dyn = 0;
+}
+static void sphere_release(env_t *e) {
+  if (e->sph_dyn) return;
+  e->sph_dyn = 1;
+  v3_set(e->sph_v, e->gv[0], e->gv[1], RC(-5.0));
+}
+
 static int is_terminal(const env_t *e) { return (e->gc[2] < RC(0.15) || e->gc[2] > RC(0.65) || e->ob[31] < RC(0.5)); }
 
 /* one physics substep: PD + clamp (ENV:761-767) then the build's integrate() (stands in for ENV:768) */
@@ -1132,6 +1156,69 @@ gs_done:
       for (int cc = 0; cc < NV; cc++) ufree[cc] += MiJt[l][r][cc] * lam[r];
     e->box_hits += 1;
   }
+  /* THE METEORITE (Crutial: True), released spheres only (a parked one hangs 1 m above where the base was; nothing reaches it).
+   * One pass of sequential impulses behind the corners, same single-contact rule:
+   *   sphere - trunk box ("steel"-"steel": mu 0, e 0.95, threshold 0.001, ENV:244): closest point of the box (URDF:26) to the
+   *     sphere centre; the trunk side of the Delassus block is J M^-1 J^T of that point, the sphere side I / m_s;
+   *   sphere - ground (default material pair of this env);
+   * then the sphere integrates like everything else (semi-implicit Euler).  Sphere - leg contacts are not modelled. */
+  if (c->Crutial && e->sph_dyn) {
+    real sv_pre[3], ms_inv = RC(1) / e->sph_mass;
+    v3_copy(sv_pre, e->sph_v);
+    e->sph_v[2] -= RC(GRAV) * dt;
+    real dw[3], cB[3], qB[3], dd[3];
+    v3_sub(dw, e->sph_p, &e->gc[0]);
+    m3_tmulv(cB, R, dw);
+    for (int a = 0; a < 3; a++) { qB[a] = cB[a] > box_half[a] ? box_half[a] : (cB[a] < -box_half[a] ? -box_half[a] : cB[a]); dd[a] = cB[a] - qB[a]; }
+    real dist2 = v3_dot(dd, dd);
+    if (dist2 < e->sph_rad * e->sph_rad) {
+      real nB[3], Js[3][NV], MiJs[3][NV], Gc[9], cv[3], lam[3], svB[3], pre[3], tmp[3], svB_pre[3];
+      if (dist2 > RC(1e-18)) { real inv = RC(1) / R_SQRT(dist2); for (int a = 0; a < 3; a++) nB[a] = -dd[a] * inv; }
+      else v3_set(nB, RC(0), RC(0), RC(-1)); /* centre inside the box: the sphere leaves through the top face */
+      for (int r = 0; r < 3; r++) for (int cc = 0; cc < NV; cc++) Js[r][cc] = RC(0);
+      /* point velocity v + w x q: rows [ I | -[q]x ] */
+      Js[0][0] = Js[1][1] = Js[2][2] = RC(1);
+      Js[0][4] = qB[2];  Js[0][5] = -qB[1];
+      Js[1][3] = -qB[2]; Js[1][5] = qB[0];
+      Js[2][3] = qB[1];  Js[2][4] = -qB[0];
+      for (int r = 0; r < 3; r++) { memcpy(MiJs[r], Js[r], sizeof(Js[r])); chol_solve(L, NV, MiJs[r]); }
+      m3_tmulv(svB, R, e->sph_v);
+      m3_tmulv(svB_pre, R, sv_pre);
+      for (int r = 0; r < 3; r++) {
+        real acc = RC(0);
+        for (int cc = 0; cc < NV; cc++) acc += Js[r][cc] * ufree[cc];
+        cv[r] = acc - svB[r];
+        for (int r2 = 0; r2 < 3; r2++) {
+          real g = RC(0);
+          for (int cc = 0; cc < NV; cc++) g += Js[r][cc] * MiJs[r2][cc];
+          Gc[3 * r + r2] = g + (r == r2 ? ms_inv : RC(0));
+        }
+      }
+      v3_cross(tmp, wB, qB);
+      for (int a = 0; a < 3; a++) pre[a] = vB[a] + tmp[a] - svB_pre[a];
+      real vn = v3_dot(pre, nB);
+      real vs = vn < RC(-0.001) ? RC(-0.95) * vn : RC(0);
+      solve_contact(Gc, cv, nB, vs, RC(0), lam);
+      for (int r = 0; r < 3; r++)
+        for (int cc = 0; cc < NV; cc++) ufree[cc] += MiJs[r][cc] * lam[r];
+      for (int a = 0; a < 3; a++) svB[a] -= lam[a] * ms_inv;
+      m3_mulv(e->sph_v, R, svB);
+      e->sph_hits += 1;
+    }
+    {
+      real hgt, nw[3];
+      if (h->height) terrain_sample(h->height, e->sph_p[0], e->sph_p[1], &hgt, nw);
+      else { hgt = RC(0); v3_set(nw, RC(0), RC(0), RC(1)); }
+      if ((e->sph_p[2] - hgt) * nw[2] - e->sph_rad <= RC(0)) {
+        real Gc[9] = {ms_inv, RC(0), RC(0), RC(0), ms_inv, RC(0), RC(0), RC(0), ms_inv}, lam[3];
+        real vn = v3_dot(sv_pre, nw);
+        real vs = vn < -m->rest_thr ? -m->rest * vn : RC(0);
+        solve_contact(Gc, e->sph_v, nw, vs, m->mu, lam);
+        v3_axpy(e->sph_v, ms_inv, lam);
+      }
+    }
+    v3_axpy(e->sph_p, dt, e->sph_v);
+  }
   /* back to world-frame gv, then positions (semi-implicit Euler) */
   m3_mulv(&e->gv[0], R, &ufree[0]);
   m3_mulv(&e->gv[3], R, &ufree[3]);
@@ -1164,6 +1251,9 @@ static void env_reset(orc_env *h, env_t *e, int env_id) {
     int span = h->ref_rows / 2 - (int)(c->max_time / c->control_dt) - 10;
     e->frame_idx = span > 0 ? (int)R_TO_DOUBLE(R_FLOOR(RC((double)span) * sampling_reshape(u[1]))) : 0;
   }
+  /* ENV:608-612: the meteorite is parked above gc_ -- which still holds the base position of the state BEFORE this reset
+   * (the new state is set further down, ENV:617-623) -- sized by the new episode's start time */
+  if (c->Crutial) sphere_place(c, e, &e->gc[0], e->t0);
   for (int i = 0; i < 3; i++) e->command_filtered[i] = RC(0);
   for (int j = 0; j < 12; j++) e->torque_last[j] = RC(0);
   command_obs_update(h, e, env_id, 1);
@@ -1228,6 +1318,11 @@ static real env_step(orc_env *h, env_t *e, int env_id, const float *action) {
     pT[j] = p;
     e->pTargetLast[j] = p;
   }
+  if (c->Crutial) { /* ENV:731-740: every 5 gait periods the meteorite is parked above the robot, one control step later it is released */
+    int K = (int)(5.0 * c->period / c->control_dt);
+    if (K > 0 && e->frame_idx % K == 0) sphere_place(c, e, &e->gc[0], env_time(h, e));
+    else sphere_release(e);
+  }
   if (c->ForceDisturbance && c->Manual) { /* ENV:743-748 -> state_disturbance ENV:912-940 */
     int K = (int)(c->period / c->control_dt * 10.0);
     if (K > 0 && e->frame_idx % K == 0) {
@@ -1288,7 +1383,6 @@ static void obs_scaling(const orc_cfg *c, real *mean, real *std) {
 
 orc_env *orc_create(const orc_cfg *cfg) {
   if (!cfg || cfg->num_envs <= 0) return NULL;
-  if (cfg->Crutial) return NULL; /* row not built */
   orc_env *h = (orc_env *)calloc(1, sizeof(orc_env));
   if (h) h->probe_env = -1;
   h->cfg = *cfg;
@@ -1334,6 +1428,14 @@ void orc_get_probe(const orc_env *h, double *G, double *cfree, double *n, double
   memcpy(G, h->probe_G, sizeof(h->probe_G)); memcpy(cfree, h->probe_cfree, sizeof(h->probe_cfree)); memcpy(n, h->probe_n, sizeof(h->probe_n));
   memcpy(vstar, h->probe_vstar, sizeof(h->probe_vstar)); memcpy(lam, h->probe_lam, sizeof(h->probe_lam)); memcpy(active, h->probe_active, sizeof(h->probe_active));
 }
+void orc_sphere_info(orc_env *h, float *out) { /* ENV:1423-1436 GetSphereInfo: centre of cubes[0] and its radius */
+  for (int i = 0; i < h->n; i++) {
+    const env_t *e = &h->envs[i];
+    for (int k = 0; k < 3; k++) out[4 * i + k] = (float)R_TO_DOUBLE(e->sph_p[k]);
+    out[4 * i + 3] = (float)R_TO_DOUBLE(e->sph_rad);
+  }
+}
+long orc_sphere_hits(const orc_env *h) { long t = 0; for (int i = 0; i < h->n; i++) t += h->envs[i].sph_hits; return t; }
 long orc_box_hits(const orc_env *h) { long t = 0; for (int i = 0; i < h->n; i++) t += h->envs[i].box_hits; return t; }
 int orc_real_bytes(void) { return (int)sizeof(real); }
 
@@ -1451,7 +1553,7 @@ void orc_set_contact_coeff(orc_env *h, const float *in) { /* ENV:1407-1418 */
 enum { S_GC = 0, S_GV = 19, S_PTL = 37, S_TQL = 49, S_TQ = 61, S_JR = 73, S_JRL = 85, S_JDR = 97, S_EER = 109,
        S_CMD = 121, S_CMDF = 124, S_T0 = 127, S_FRAME = 128, S_EPISODE = 129, S_UPH = 130, S_CONTACT = 131,
        S_LAMW = 135, S_INCONTACT = 147, S_MATERIAL = 151, S_MASS = 154, S_COM = 167, S_THIGH = 206, S_OB = 207,
-       S_OBLAST = 242, S_END = 277 };
+       S_OBLAST = 242, S_SPHERE = 277 /* pos 3, vel 3, radius, mass, dynamic */, S_END = 286 };
 
 void orc_get_state(orc_env *h, double *out) {
   for (int i = 0; i < h->n; i++) {
@@ -1471,6 +1573,8 @@ void orc_get_state(orc_env *h, double *out) {
     for (int k = 0; k < NB; k++) { o[S_MASS + k] = R_TO_DOUBLE(e->model.mass[k]); for (int a = 0; a < 3; a++) o[S_COM + 3 * k + a] = R_TO_DOUBLE(e->model.com[k][a]); }
     o[S_THIGH] = R_TO_DOUBLE(e->model.thigh_dz);
     for (int k = 0; k < 35; k++) { o[S_OB + k] = R_TO_DOUBLE(e->ob[k]); o[S_OBLAST + k] = R_TO_DOUBLE(e->ob_last[k]); }
+    for (int k = 0; k < 3; k++) { o[S_SPHERE + k] = R_TO_DOUBLE(e->sph_p[k]); o[S_SPHERE + 3 + k] = R_TO_DOUBLE(e->sph_v[k]); }
+    o[S_SPHERE + 6] = R_TO_DOUBLE(e->sph_rad); o[S_SPHERE + 7] = R_TO_DOUBLE(e->sph_mass); o[S_SPHERE + 8] = (double)e->sph_dyn;
   }
 }
 void orc_set_state(orc_env *h, const double *in) {
@@ -1492,6 +1596,8 @@ void orc_set_state(orc_env *h, const double *in) {
     e->model.thigh_dz = RC(o[S_THIGH]);
     for (int l = 0; l < NLEG; l++) e->model.jpos[3 + 3 * l][2] += e->model.thigh_dz;
     for (int k = 0; k < 35; k++) { e->ob[k] = RC(o[S_OB + k]); e->ob_last[k] = RC(o[S_OBLAST + k]); }
+    for (int k = 0; k < 3; k++) { e->sph_p[k] = RC(o[S_SPHERE + k]); e->sph_v[k] = RC(o[S_SPHERE + 3 + k]); }
+    e->sph_rad = RC(o[S_SPHERE + 6]); e->sph_mass = RC(o[S_SPHERE + 7]); e->sph_dyn = (int32_t)o[S_SPHERE + 8];
     quat_to_rot(&e->gc[3], e->Rwb);
     m3_tmulv(e->bodyLinVel, e->Rwb, &e->gv[0]);
     m3_tmulv(e->bodyAngVel, e->Rwb, &e->gv[3]);

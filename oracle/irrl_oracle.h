@@ -143,6 +143,9 @@ void orc_terrain_sample(const orc_env *h, double x, double y, double out[4]);
 double orc_mean_contact_sweeps(const orc_env *h);
 /* (trunk-box corner, substep) pairs in contact since orc_init, summed over the envs (ENV:242 collision body "body/0") */
 long orc_box_hits(const orc_env *h);
+/* Crutial: True -- ENV:1423-1436 GetSphereInfo: [N,4] = centre of the meteorite (world) and its radius; substeps with sphere-trunk contact */
+void orc_sphere_info(orc_env *h, float *out /* [N,4] */);
+long orc_sphere_hits(const orc_env *h);
 /* tests: capture the toe contact problem of env `env_id` in every substep (-1: off) and read the last one back:
  * G [12,12] Delassus blocks (base components), cfree [4,3], unit normals [4,3], target normal speeds [4], the solved impulses
  * [4,3] and the active flags [4]; rows / columns of inactive toes are zero */

@@ -152,7 +152,7 @@ class OracleVecEnv(object):
         self.n = self.cfg.num_envs
         self.h = self.lib.orc_create(C.byref(self.cfg))
         if not self.h:
-            raise RuntimeError("orc_create refused this configuration (Crutial row not built)")
+            raise RuntimeError("orc_create refused this configuration")
         if ref is not None:
             ref = np.ascontiguousarray(ref, np.float32)
             self.lib.orc_set_ref.restype = C.c_int
@@ -196,6 +196,18 @@ class OracleVecEnv(object):
         self.lib.orc_get_probe.restype = None
         self.lib.orc_get_probe(self.h, _dp(G), _dp(cf), _dp(n), _dp(vs), _dp(lam), act.ctypes.data_as(C.POINTER(C.c_int)))
         return dict(G=G, cfree=cf, n=n, vstar=vs, lam=lam, active=act.astype(bool))
+
+    def sphere_info(self):
+        """GetSphereInfo (ENV:1423-1436) for every env: [N,4] = meteorite centre + radius"""
+        out = np.zeros((self.n, 4), np.float32)
+        self.lib.orc_sphere_info.argtypes = [C.c_void_p, C.c_void_p]
+        self.lib.orc_sphere_info(self.h, out.ctypes.data)
+        return out
+
+    def sphere_hits(self):
+        self.lib.orc_sphere_hits.restype = C.c_long
+        self.lib.orc_sphere_hits.argtypes = [C.c_void_p]
+        return int(self.lib.orc_sphere_hits(self.h))
 
     def box_hits(self):
         self.lib.orc_box_hits.restype = C.c_long
@@ -271,7 +283,7 @@ class OracleVecEnv(object):
 # ---- flat-state field offsets (irrl_oracle.c "S_*" enum == include/irrl_env.h) ----
 S = dict(GC=0, GV=19, PTL=37, TQL=49, TQ=61, JR=73, JRL=85, JDR=97, EER=109, CMD=121, CMDF=124, T0=127,
          FRAME=128, EPISODE=129, UPH=130, CONTACT=131, LAMW=135, INCONTACT=147, MATERIAL=151, MASS=154,
-         COM=167, THIGH=206, OB=207, OBLAST=242, END=277)
+         COM=167, THIGH=206, OB=207, OBLAST=242, SPHERE=277, END=286)
 
 
 # ---- unit probes ----

@@ -41,6 +41,11 @@ class HipVecEnv(object):
         self.impl.GetNonlinear(nl)
         return minv, nl
 
+    def sphere_info(self):
+        out = np.zeros((self.n, 4), np.float32)
+        self.impl.GetSphereInfo(out)
+        return out
+
     def get_state(self):
         return self.impl.get_state()
 

@@ -345,3 +345,47 @@ def test_trunk_box_corner_contacts_match_the_oracle_on_gpu(lanes, monkeypatch):
     PL.check_teacher_forced(orc, cand, steps=30, seed=5, perturb=lambda st, k, rng: PL.tilt_onto_box_corner(st, k, rng, 0.16, 0.30, 20.0, 55.0),
                             max_factor=1e4)
     assert orc.box_hits() > h0
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_crutial_meteorite_matches_the_oracle_on_gpu(lanes, monkeypatch):
+    """Crutial: True (ENV:273-284, 731-740, 815-861) through the C-ABI in both lane layouts: the park / release schedule,
+    teacher-forced steps with a sphere dropped onto the trunk or the ground before every step, GetSphereInfo (ENV:1423-1436),
+    and a free-running pool in which the scheduled spheres do reach robots."""
+    monkeypatch.setenv("IRRL_LANES_PER_ROBOT", str(lanes))
+    n = 48
+    cfg = load_env_cfg("bp5_imitation.yaml", num_envs=n, Crutial=True, CubeNum=6, period=0.05)   # parked every 125 control steps
+    orc, cand = _pair(cfg)
+    assert cand.impl.lanes_per_robot == lanes
+    k = PL.S["SPHERE"]
+    assert np.abs(orc.get_state()[:, k:k + 9] - cand.get_state()[:, k:k + 9]).max() < 1e-6
+    np.testing.assert_allclose(cand.sphere_info(), orc.sphere_info(), atol=1e-6)
+    st = orc.get_state()
+    st[:, PL.S["FRAME"]] = 110
+    orc.set_state(st)
+    PL.check_teacher_forced(orc, cand, steps=30, seed=2, force_terminal_every=11)       # crosses frame 125: park + release
+    assert (orc.get_state()[:, k + 8] == 1).any()
+    h0 = orc.sphere_hits()
+    worst, n_done = PL.check_teacher_forced(orc, cand, steps=40, seed=4, perturb=PL.drop_meteorite, max_factor=40.0)
+    assert orc.sphere_hits() - h0 > 5 * n
+    print("meteorite teacher-forced worst errors (lanes %d):" % lanes, worst)
+    np.testing.assert_allclose(cand.sphere_info(), orc.sphere_info(), atol=2e-4)
+    orc, cand = _pair(load_env_cfg("bp5_terrain.yaml", num_envs=24, Crutial=True, CubeNum=2))
+    PL.check_teacher_forced(orc, cand, steps=24, seed=6, perturb=PL.drop_meteorite, max_factor=1e4)
+    # free running with the default gait period: released at frame 1, 1 m above the base at -5 m/s -> it arrives ~0.16 s later;
+    # a standing robot (zero actions keep the nominal pose) is hit on the trunk and pushed down
+    cfg = load_env_cfg("bp5_imitation.yaml", num_envs=n, Crutial=True, CubeNum=6, Manual=True, Vx=0.0, max_time=10.0)
+    hip = _hip(cfg)
+    hip.reset()
+    a = np.zeros((n, 12), np.float32)
+    zmin, vzmin, bounced = 1e9, 0.0, False
+    for t in range(140):
+        hip.step(a)
+        s = hip.get_state()
+        vzmin = min(vzmin, s[:, 21].min())
+        bounced |= bool((s[:, k + 5] > 1.0).any())
+    assert vzmin < -0.6 and bounced          # (a free-standing robot never drops faster than ~0.45 m/s while it settles)
+    # without Crutial the getter refuses, like the reference's message
+    plain = _hip(load_env_cfg("bp5_imitation.yaml", num_envs=4))
+    with pytest.raises(RuntimeError, match="Flag_Crucial"):
+        plain.sphere_info()

@@ -45,6 +45,28 @@ def test_trunk_box_corners_collide_like_the_oracle(emu):
 
 
 @pytest.mark.parametrize("emu", [E.EmuVecEnv, E.EmuVecEnv16])
+def test_crutial_meteorite_matches_the_oracle(emu):
+    """Crutial: True (ENV:273-284, 731-740, 815-861): the schedule (parked at reset and every 5 periods, released a step later)
+    free-running from init, then teacher-forced steps with a sphere dropped onto the trunk / the ground before every step."""
+    cfg = load_env_cfg("bp5_imitation.yaml", num_envs=6, Crutial=True, CubeNum=6, period=0.05)   # K = 125 control steps
+    orc, cand = _pair(cfg, emu)
+    k = PL.S["SPHERE"]
+    assert np.abs(orc.get_state()[:, k:k + 9] - cand.get_state()[:, k:k + 9]).max() < 1e-6
+    st = orc.get_state()
+    st[:, PL.S["FRAME"]] = 110
+    orc.set_state(st)
+    PL.check_teacher_forced(orc, cand, steps=30, seed=2, force_terminal_every=11)       # crosses frame 125: park + release
+    s = orc.get_state()
+    assert (s[:, k + 8] == 1).any() and orc.sphere_hits() == 0
+    h0 = orc.sphere_hits()
+    worst, n_done = PL.check_teacher_forced(orc, cand, steps=40, seed=4, perturb=PL.drop_meteorite, max_factor=40.0)
+    assert orc.sphere_hits() - h0 > 30                                                  # the spheres did hit trunks (1-2 substeps of contact per impact)
+    # rough ground under the sphere
+    orc, cand = _pair(load_env_cfg("bp5_terrain.yaml", num_envs=3, Crutial=True, CubeNum=2), emu)
+    PL.check_teacher_forced(orc, cand, steps=24, seed=6, perturb=PL.drop_meteorite, max_factor=1e4)
+
+
+@pytest.mark.parametrize("emu", [E.EmuVecEnv, E.EmuVecEnv16])
 def test_gauss_seidel_contact_order_is_still_available(emu):
     """ContactSolver: 0 (sequential Gauss-Seidel over FR, FL, HR, HL, then the box corners) -- the default is 2 (simultaneous
     updates); both orders exist in the oracle and in the kernel source and agree with each other pairwise."""
@@ -108,8 +130,7 @@ def test_config_parser_matches_pyyaml():
     del bad["Stiffness"]
     with pytest.raises(RuntimeError, match="Stiffness"):
         E.EmuVecEnv(bad)
-    with pytest.raises(RuntimeError, match="Crutial"):
-        EMU(dict(cfg, Crutial=True))
+    assert EMU(dict(cfg, num_envs=2, Crutial=True)).n == 2         # the meteorite pool builds (test_crutial_meteorite_matches_the_oracle)
     assert "seedd" in text
 
 

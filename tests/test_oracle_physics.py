@@ -266,3 +266,142 @@ def test_trunk_box_corner_contact_first_principles():
             assert imp[2] > 0.5 and np.hypot(imp[0], imp[1]) <= mu * imp[2] * (1 + 1e-6) + 1e-4   # (c)
         else:
             assert np.abs(imp).max() < 1e-6                              # (d) free flight
+
+
+def _sphere_state(st, i, p, v, rad, mass, dyn=1):
+    k = S["SPHERE"]
+    st[i, k:k + 3] = p
+    st[i, k + 3:k + 6] = v
+    st[i, k + 6:k + 9] = (rad, mass, dyn)
+
+
+def test_meteorite_hits_the_trunk_first_principles():
+    """Crutial: True (ENV:273-284, 815-861).  A robot in free flight with a steel sphere dropping onto the top face of its trunk
+    box, ONE substep: (a) the oracle reports the sphere-trunk contact, (b) robot + sphere momentum (linear, and angular about
+    the world origin) changes by gravity only -- the contact impulse is internal, (c) the contact points separate at 0.95 of the
+    approach speed ("steel"-"steel": e 0.95, ENV:244), (d) nothing tangential is exchanged (mu 0), (e) a sphere passing 1 cm
+    beside the box exchanges nothing."""
+    dt = 0.00025
+    cfg = load_env_cfg("bp5_imitation.yaml", num_envs=2, control_dt=dt, simulation_dt=dt, Stiffness=0.0, Damping=0.0, Crutial=True, CubeNum=1)
+    env = O.OracleVecEnv(cfg)
+    st = env.get_state()
+    rad, mass = 0.09, 1.3
+    for i in range(2):
+        st[i, S["GC"]:S["GC"] + 19] = 0
+        st[i, S["GC"] + 2] = 0.5
+        st[i, S["GC"] + 3] = 1.0
+        st[i, S["GC"] + 7:S["GC"] + 19] = [-0.1, -0.78, 1.57, 0.1, -0.78, 1.57] * 2
+        st[i, S["GV"]:S["GV"] + 18] = 0
+        st[i, S["GV"]:S["GV"] + 6] = (0.4, -0.2, -0.3, 0.5, -0.4, 0.3)
+        st[i, S["LAMW"]:S["LAMW"] + 12] = 0
+        st[i, S["INCONTACT"]:S["INCONTACT"] + 4] = 0
+        st[i, S["TQL"]:S["TQL"] + 12] = 0
+    # env 0: centre above the top face at (0.08, -0.03), 1 cm of overlap; env 1: beside the +y face, 1 cm clear of it
+    _sphere_state(st, 0, (0.08, -0.03, 0.5 + 0.05 + rad - 0.01), (0.7, 0.3, -6.0), rad, mass)
+    _sphere_state(st, 1, (0.0, 0.1 + rad + 0.01, 0.5), (0.0, -0.05, -6.0), rad, mass)
+    env.set_state(st)
+    s0 = env.get_state()
+    env.step(np.zeros((2, 12), np.float32))
+    s1 = env.get_state()
+    assert env.sphere_hits() == 1                                       # (a), (e)
+    k = S["SPHERE"]
+    g = np.array([0, 0, -9.81])
+    # env 1 is the control: the same robot in the same state with the sphere passing beside it -- what differs between the two
+    # robots after the substep is the contact impulse alone (the integrator's own O(dt) momentum drift cancels)
+    assert np.abs(s0[0, :37] - s0[1, :37]).max() == 0
+    assert np.abs(mass * (s1[1, k + 3:k + 6] - s0[1, k + 3:k + 6]) - mass * g * dt).max() < 1e-12     # (e) free fall
+    # momenta of the new velocities in the configuration the impulse was applied in (velocity-level solve, positions follow)
+    dP_robot = _momenta(s0[0, :19], s1[0, 19:37])[0] - _momenta(s0[1, :19], s1[1, 19:37])[0]
+    dP_sphere = mass * (s1[0, k + 3:k + 6] - s0[0, k + 3:k + 6]) - mass * g * dt
+    assert np.abs(dP_robot + dP_sphere).max() < 1e-9 and dP_robot[2] < -1.0               # (b) equal and opposite, robot pushed down
+    assert np.abs(dP_sphere[:2]).max() < 1e-9                                             # (d) frictionless, normal to the top face (n = z)
+    # angular: the impulse acts at the closest box point q (start positions: the solve is at velocity level)
+    q_w = np.array([0.08, -0.03, 0.05])                                 # base axes = world axes here
+    M0 = O.mass_matrix_world(s0[0, :19])
+    dL = M0[3:6] @ (s1[0, 19:37] - s1[1, 19:37])                        # about the base origin
+    assert np.abs(dL - np.cross(q_w, dP_robot)).max() < 1e-9, (dL, np.cross(q_w, dP_robot))
+    # (c) restitution: normal relative speed of the contact points after = -0.95 x before
+    def rel_n(s):
+        vr = s[19:22] + np.cross(s[22:25], q_w) - s[k + 3:k + 6]
+        return vr[2]
+    before, after = rel_n(s0[0]), rel_n(s1[0])
+    assert before > 5.0                                                 # trunk point moves up relative to the sphere = approach
+    assert abs(after + 0.95 * before) < 1e-6 * before + 1e-9
+
+
+def test_meteorite_ground_bounce_and_free_fall():
+    """the sphere alone: free fall is semi-implicit Euler under g; on the ground it bounces with the env's default material
+    (restitution above the threshold speed) and Coulomb friction slows its slide"""
+    dt = 0.00025
+    cfg = load_env_cfg("bp5_imitation.yaml", num_envs=1, control_dt=dt, simulation_dt=dt, Crutial=True, CubeNum=2)
+    env = O.OracleVecEnv(cfg)
+    st = env.get_state()
+    mu, rest, thr = st[0, S["MATERIAL"]:S["MATERIAL"] + 3]
+    rad, mass = 0.1, 0.8
+    _sphere_state(st, 0, (3.0, 1.0, 0.5), (0.5, 0.0, -3.0), rad, mass)
+    env.set_state(st)
+    k = S["SPHERE"]
+    z, vz = 0.5, -3.0
+    bounced = False
+    for n in range(900):
+        env.step(np.zeros((1, 12), np.float32))
+        s = env.get_state()[0]
+        if not bounced and z - rad > 0:
+            vz -= 9.81 * dt
+            z += vz * dt
+            assert abs(s[k + 2] - z) < 1e-9 and abs(s[k + 5] - vz) < 1e-9 and abs(s[k + 3] - 0.5) < 1e-12
+            v_in = vz
+        elif not bounced:
+            bounced = True
+            assert abs(s[k + 5] - rest * abs(v_in)) < 1e-6 and rest > 0 and abs(v_in) > thr
+            # friction impulse mu * normal impulse against the slide
+            jn = mass * (s[k + 5] - (v_in - 9.81 * dt))
+            assert abs(mass * (0.5 - s[k + 3]) - min(mu * jn, mass * 0.5)) < 1e-6
+            break
+    assert bounced
+    info = env.sphere_info()[0]
+    assert np.allclose(info[:3], s[k:k + 3], atol=1e-6) and abs(info[3] - rad) < 1e-7
+
+
+def test_meteorite_schedule_follows_the_reference():
+    """ENV:608-612 (reset parks the sphere above the PREVIOUS base position, sized by the new start time), ENV:731-740 (parked
+    every int(5 period / control_dt) frames above the current base, released one control step later with (gv0, gv1, -5)),
+    ENV:1423-1436 GetSphereInfo."""
+    cfg = load_env_cfg("bp5_imitation.yaml", num_envs=3, Crutial=True, CubeNum=6, max_time=10.0)
+    env = O.OracleVecEnv(cfg)
+    k = S["SPHERE"]
+    K = int(5 * cfg["period"] / cfg["control_dt"])
+    first = env.get_state()
+    # the reset inside init(): the state before it was all zeros
+    assert np.allclose(first[:, k:k + 3], [0.05, 0.0, 1.0]) and np.all(first[:, k + 8] == 0)
+    env.reset()
+    st = env.get_state()
+    t0 = st[:, S["T0"]]
+    # a later reset: above where the base was BEFORE it, not above the new random start position
+    assert np.allclose(st[:, k:k + 3], first[:, 0:3] + [0.05, 0.0, 1.0]) and np.all(st[:, k + 8] == 0)
+    assert np.abs(st[:, 0:2] - first[:, 0:2]).min() > 1e-3
+    assert np.allclose(st[:, k + 6], (t0 / 5 + 1) * 0.08) and np.allclose(st[:, k + 7], 6 * (t0 / 5 + 0.2))
+    info = env.sphere_info()
+    assert np.allclose(info[:, :3], st[:, k:k + 3], atol=1e-6) and np.allclose(info[:, 3], st[:, k + 6], atol=1e-7)
+    a = np.zeros((3, 12), np.float32)
+    prev = st
+    env.step(a)                                                        # frame 1: released with the base's horizontal velocity
+    s = env.get_state()
+    assert np.all(s[:, k + 8] == 1)
+    sub = int(round(cfg["control_dt"] / cfg["simulation_dt"]))
+    assert np.allclose(s[:, k + 3:k + 5], prev[:, 19:21], atol=1e-12) and np.allclose(s[:, k + 5], -5 - 9.81 * cfg["simulation_dt"] * sub)
+    # walk one env to the next parking frame by hand (frames count control steps since the reset, resets restart them)
+    st = env.get_state()
+    st[:, S["FRAME"]] = K - 1
+    env.set_state(st)
+    env.step(a)                                                        # frame K-1: still flying
+    s1 = env.get_state()
+    assert np.all(s1[:, k + 8] == 1)
+    base_before = s1[:, 0:3].copy()
+    tnow = s1[:, S["T0"]] + K * cfg["control_dt"]
+    env.step(a)                                                        # frame K: parked above the base as it was at the start of this step
+    s2 = env.get_state()
+    live = s2[:, S["FRAME"]] == K + 1                                  # envs that did not terminate inside this step
+    assert live.any()
+    assert np.all(s2[live, k + 8] == 0) and np.allclose(s2[live, k:k + 3], base_before[live] + [0.05, 0, 1.0], atol=1e-12)
+    assert np.allclose(s2[live, k + 6], (tnow[live] / 5 + 1) * 0.08) and np.allclose(s2[live, k + 3:k + 6], 0)
