@@ -23,10 +23,19 @@
 //   and all solves with M are a 6x6 triangular solve plus lane-local 3x3 work.  The Delassus operator of
 //   the toe contacts is G_ll' = Y_l^T Y_l' + delta_ll' E_l with Y_l = L^-1 K_l^T (6x3, lane-local), so
 //   the Gauss-Seidel contact sweep only exchanges one 6-vector z = sum_l Y_l lambda_l inside the quad.
-#pragma once
+//
+// The file may be included more than once with different IRRL_CORE_NS / IRRL_CRUTIAL (env_kernels.hip does: the namespace
+// `irrl` decides the meteorite paths by the run-time flag, `irrl_plain` has them compiled out for pools without Crutial).
 #include "env_params.h"
 
-namespace irrl {
+#ifndef IRRL_CORE_NS
+#define IRRL_CORE_NS irrl
+#endif
+#ifndef IRRL_CRUTIAL
+#define IRRL_CRUTIAL(P) ((P).crutial != 0)   /* Crutial: True -- the meteorite (ENV:273-284, 731-740, 815-861) */
+#endif
+
+namespace IRRL_CORE_NS {
 using namespace lanes;
 
 // ---------------------------------------------------------------------------------------------
@@ -1178,7 +1187,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
       for (int i = 0; i < 6; i++) { ub[i] += dxb[i]; ul_s -= Xs[i] * dxb[i]; }
     }
   }
-  if (IRRL_UNLIKELY(P.crutial != 0) && wave_any(L.sdyn != 0)) {
+  if (IRRL_UNLIKELY(IRRL_CRUTIAL(P)) && wave_any(L.sdyn != 0)) {
     vf dxb[6];
     if (sphere_pass(P, L, R, D.L6, ub, vB, wB, dxb)) {
 #pragma unroll
@@ -1384,7 +1393,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
       }
     }
   }
-  if (IRRL_UNLIKELY(P.crutial != 0) && wave_any(L.sdyn != 0)) {
+  if (IRRL_UNLIKELY(IRRL_CRUTIAL(P)) && wave_any(L.sdyn != 0)) {
     vf dxb[6];
     if (sphere_pass(P, L, R, D.L6, ub, vB, wB, dxb)) {
 #pragma unroll
@@ -1652,7 +1661,7 @@ IRRL_DEV void reset_lane_head(const EnvParams &P, EnvLane &L, vu env) {
   L.t0 = P.manual ? 0.0f : rt.u0;
   // ENV:608-612: the meteorite is parked above gc_, which still holds the base position of the state BEFORE this reset (the new
   // state is set further down, ENV:617-623), sized by the new episode's start time
-  if (P.crutial) sphere_place(P, L, L.pos, L.t0, vm(true));
+  if (IRRL_CRUTIAL(P)) sphere_place(P, L, L.pos, L.t0, vm(true));
   if (P.ref_traj) {
     // ENV:538-539, 571: random start frame in the first half of the table, frame_len + 10 rows before its end
     const int span = P.ref_rows / 2 - (int)(P.max_time / P.control_dt) - 10;
@@ -1785,7 +1794,7 @@ IRRL_DEV void load_lane(const EnvParams &P, const EnvState &S, vi env, vi leg, E
   L.m.comT = mk3(ld(S.com, cb + 6 + leg * 9), ld(S.com, cb + 7 + leg * 9), ld(S.com, cb + 8 + leg * 9));
   L.m.comS = mk3(ld(S.com, cb + 9 + leg * 9), ld(S.com, cb + 10 + leg * 9), ld(S.com, cb + 11 + leg * 9));
   L.m.dz = ld(S.thigh_dz, env);
-  if (P.crutial) {
+  if (IRRL_CRUTIAL(P)) {
     vi sb = env * 9;
     L.sp = mk3(ld(S.sphere, sb), ld(S.sphere, sb + 1), ld(S.sphere, sb + 2));
     L.sv = mk3(ld(S.sphere, sb + 3), ld(S.sphere, sb + 4), ld(S.sphere, sb + 5));
@@ -1860,7 +1869,7 @@ IRRL_DEV void store_lane(const EnvParams &P, const EnvState &S, vi env, vi leg, 
   stm(S.gv, gvb + 3, L.ww.x); stm(S.gv, gvb + 4, L.ww.y); stm(S.gv, gvb + 5, L.ww.z);
   stm(S.t0, env, L.t0); stm_i(S.frame_idx, env, L.frame); stm_u(S.episode, env, L.episode); stm(S.up_height, env, L.up_height);
   stm(S.ob, ob + 3, L.ob_phase[0]); stm(S.ob, ob + 4, L.ob_phase[1]);
-  if (P.crutial) {
+  if (IRRL_CRUTIAL(P)) {
     vi sb = env * 9;
     stm(S.sphere, sb, L.sp.x); stm(S.sphere, sb + 1, L.sp.y); stm(S.sphere, sb + 2, L.sp.z);
     stm(S.sphere, sb + 3, L.sv.x); stm(S.sphere, sb + 4, L.sv.y); stm(S.sphere, sb + 5, L.sv.z);
@@ -1959,7 +1968,7 @@ IRRL_DEV void step_body(const EnvParams &P, const EnvState &S, vi env, vi leg, v
       pT[k] = p; L.ptl[k] = p;
     }
   }
-  if (P.crutial) {
+  if (IRRL_CRUTIAL(P)) {
     // ENV:731-740: every int(5 period / control_dt) frames the meteorite is parked above the robot; on every other frame a
     // parked one is released
     const float kf = (float)P.attack_every;
@@ -2130,4 +2139,4 @@ IRRL_DEV void dynamics_probe_body(const EnvParams &P, const EnvState &S, vi env,
   }
 }
 
-}  // namespace irrl
+}  // namespace IRRL_CORE_NS

@@ -14,6 +14,14 @@
 #define IRRL_ROBOTS_PER_WAVE 16
 #endif
 #include "env_core.hpp"
+// second instantiation of the lane bodies with the meteorite (Crutial: True) compiled out: pools without it -- every benchmark
+// and training configuration -- run the step kernel built from this one (measured: the run-time-flag version costs 0.5 us of
+// the 38 us step even with the flag off: 16 more VGPRs live across the substeps and the branches in the schedule)
+#undef IRRL_CORE_NS
+#undef IRRL_CRUTIAL
+#define IRRL_CORE_NS irrl_plain
+#define IRRL_CRUTIAL(P) false
+#include "env_core.hpp"
 
 // This file is compiled twice (build.py): once per lane layout, kernel names suffixed _l16 / _l4.
 #if IRRL_LANES_PER_ROBOT == 16
@@ -43,13 +51,20 @@
 
 extern "C" {
 
+// pools with Crutial: True (the launcher picks by EnvParams::crutial)
+__global__ void __launch_bounds__(256, 1)
+IRRL_K(irrl_step_kernel_crutial)(EnvParams P, EnvState S, const float *action, float *ob, float *reward, uint8_t *done, float *extra) {
+  IRRL_LANE_PROLOGUE
+  irrl::step_body(P, S, env_, leg_, valid_, action, ob, reward, done, extra);
+}
+
 __global__ void __launch_bounds__(256, 1)
 IRRL_K(irrl_step_kernel)(EnvParams P, EnvState S, const float *action, float *ob, float *reward, uint8_t *done, float *extra) {
   IRRL_LANE_PROLOGUE
 #ifdef IRRL_PROFILE_WAVES   /* diagnostic build (tools/wave_spread.py): extra[env][5] <- this wave's duration in 100 MHz ticks */
   const unsigned long long t0_ = wall_clock64();
 #endif
-  irrl::step_body(P, S, env_, leg_, valid_, action, ob, reward, done, extra);
+  irrl_plain::step_body(P, S, env_, leg_, valid_, action, ob, reward, done, extra);
 #ifdef IRRL_PROFILE_WAVES
   const unsigned long long t1_ = wall_clock64();
   if (valid_ && leg_ == 0) extra[env_ * 6 + 5] = (float)(t1_ - t0_);

@@ -15,6 +15,7 @@
 //          throughput once the pool is large enough to occupy the chip on its own
 #define IRRL_DECLARE_KERNELS(sfx)                                                                                            \
   extern "C" __global__ void irrl_step_kernel##sfx(EnvParams, EnvState, const float *, float *, float *, uint8_t *, float *);   \
+  extern "C" __global__ void irrl_step_kernel_crutial##sfx(EnvParams, EnvState, const float *, float *, float *, uint8_t *, float *); \
   extern "C" __global__ void irrl_init_kernel##sfx(EnvParams, EnvState);                                                       \
   extern "C" __global__ void irrl_reset_kernel##sfx(EnvParams, EnvState, float *);                                             \
   extern "C" __global__ void irrl_observe_kernel##sfx(EnvParams, EnvState, float *);                                           \
@@ -93,6 +94,13 @@ static int pick_lanes(int n_envs) {
   do {                                                                                                                    \
     if ((h)->lanes == 16) hipLaunchKernelGGL(name##_l16, grid, quad_block(), 0, (h)->stream, __VA_ARGS__);                 \
     else hipLaunchKernelGGL(name##_l4, grid, quad_block(), 0, (h)->stream, __VA_ARGS__);                                   \
+  } while (0)
+
+// the step kernel: pools with Crutial: True run the instantiation that carries the meteorite (env_kernels.hip)
+#define IRRL_LAUNCH_STEP(h, grid, ...)                                                                                      \
+  do {                                                                                                                    \
+    if ((h)->P.crutial) IRRL_LAUNCH(h, irrl_step_kernel_crutial, grid, __VA_ARGS__);                                         \
+    else IRRL_LAUNCH(h, irrl_step_kernel, grid, __VA_ARGS__);                                                                \
   } while (0)
 
 extern "C" {
@@ -234,7 +242,7 @@ static int need_init(irrl_env *h) {
 int irrl_env_step(irrl_env *h, const float *action, float *ob, float *reward, uint8_t *done, float *extra) {
   if (need_init(h)) return 1;
   if (use_device(h)) return 1;
-  IRRL_LAUNCH(h, irrl_step_kernel, lane_grid(h, h->P.n_envs), h->P, h->S, action, ob, reward, done, extra);
+  IRRL_LAUNCH_STEP(h, lane_grid(h, h->P.n_envs), h->P, h->S, action, ob, reward, done, extra);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -260,7 +268,7 @@ static int step_host_impl(irrl_env *h, int n_step, const float *action, float *o
   HIP_TRY(hipMemcpyAsync(h->d_action, pa, n * 12 * 4, hipMemcpyHostToDevice, h->stream));
   EnvParams P = h->P;
   P.n_envs = n_step;
-  IRRL_LAUNCH(h, irrl_step_kernel, lane_grid(h, n_step), P, h->S, (const float *)h->d_action, h->d_ob, h->d_reward, h->d_done, h->d_extra);
+  IRRL_LAUNCH_STEP(h, lane_grid(h, n_step), P, h->S, (const float *)h->d_action, h->d_ob, h->d_reward, h->d_done, h->d_extra);
   HIP_TRY(hipGetLastError());
   if (n_step == h->P.n_envs) {
     // device outputs and their pinned staging are laid out alike (ob | reward | extra | done): one copy

