@@ -61,7 +61,10 @@ def parse_args(argv=None):
     ap.add_argument("--ppo-iters", type=int, default=2, help="timed PPO iterations of the LSTM policy (0 disables)")
     ap.add_argument("--ppo-steps", type=int, default=750, help="rollout length of the PPO leg (the metric's is 750)")
     ap.add_argument("--ppo-epochs", type=int, default=10, help="optimisation epochs of the PPO leg (the metric's is 10)")
-    ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch the timed steps one by one from Python instead of as one hipGraph")
+    ap.add_argument("--launch", choices=("rows", "graph", "python"), default="rows",
+                    help="how the K timed steps are issued: 'rows' = one irrl_env_step_rows call (K back-to-back launches from C, default), "
+                         "'graph' = one hipGraph of K step-kernel nodes (what the PPO rollout is), 'python' = one ctypes call per step")
+    ap.add_argument("--no-graph", dest="launch", action="store_const", const="python", help="same as --launch python")
     ap.add_argument("--check-steps", type=int, default=2000, help="extra untimed-for-`value` window after the timed region that "
                     "re-measures us/step over a longer run (0 disables); reported as `steady_state_check`")
     return ap.parse_args(argv)
@@ -222,26 +225,30 @@ def worker(args):
     extra = torch.zeros(n, 6, device=dev)
     cursor = [0]
 
-    def run(k_steps):
+    def run(k_steps, mode="rows"):
         s0 = cursor[0]
-        for k in range(k_steps):
-            env.step(actions[(s0 + k) % rows], ob, rew, done, extra)
+        if mode == "rows":
+            env.step_rows(k_steps, actions, s0 % rows, ob, rew, done, extra)
+        else:
+            for k in range(k_steps):
+                env.step(actions[(s0 + k) % rows], ob, rew, done, extra)
         cursor[0] = s0 + k_steps
 
     run(preroll)                 # untimed, unconditional: robots land and the contact set becomes stationary
     run(args.warmup)
     torch.cuda.synchronize()
-    # The K timed steps are ONE hipGraph of K step-kernel nodes (action row = launch argument), the way the PPO rollout runs
-    # them (ppo2.Runner): no per-step host launch latency inside the bracket, so a 20-step window measures the kernel and not
-    # the Python call path.  Capturing records the launches without executing them.
+    # The K timed steps go out as K back-to-back launches from ONE C call (irrl_env_step_rows: action row = launch argument): no
+    # per-step Python / ctypes latency inside the bracket, and the first kernel starts a few microseconds after the call -- with
+    # the driver's --steps 20 the bracket is 0.8 ms long and a hipGraph launch (--launch graph: what the PPO rollout uses, 1500
+    # nodes there) costs ~40 us before its first node runs.  Capturing records the launches without executing them.
     graph = None
-    if args.graph and args.steps <= 20000:
+    if args.launch == "graph" and args.steps <= 20000:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         s_keep = cursor[0]
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=side):
-            run(args.steps)
+            run(args.steps, "python")
         cursor[0] = s_keep
         torch.cuda.synchronize()
     # the kernels' counters are summed on the device, stream-ordered: no read-back (idle GPU) right before the timed region
@@ -257,14 +264,15 @@ def worker(args):
         graph.replay()
         cursor[0] += args.steps
     else:
-        run(args.steps)
+        run(args.steps, args.launch)
     ev1.record()
-    env.counters_into(cnt1)      # one 256-thread launch behind the closing event: outside the HIP-event window, ~2 us of the wall-clock one
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    env.counters_into(cnt1)      # nothing has stepped the pool since the timed region ended
+    torch.cuda.synchronize()
     kernel_ms = ev0.elapsed_time(ev1) / args.steps   # events on the stream the kernel is launched on
     c0, c1 = cnt0.tolist(), cnt1.tolist()
     resets = c1[0] - c0[0]
@@ -323,7 +331,9 @@ def worker(args):
                                    "%d-step untimed pre-roll before the warm-up" % (n, args.cfg, (" with " + ", ".join(args.set)) if args.set else "", preroll),
                        "envs_per_gpu": n, "global_envs": n * world, "parallelism": "env-sharded x%d" % world,
                        "lanes_per_robot": env.lanes_per_robot, "preroll": preroll,
-                       "launch": "one hipGraph of %d step-kernel nodes" % args.steps if graph is not None else "one launch per step from the host"},
+                       "launch": {"rows": "%d back-to-back launches from one irrl_env_step_rows call" % args.steps,
+                                  "graph": "one hipGraph of %d step-kernel nodes" % args.steps,
+                                  "python": "one ctypes call per step"}[args.launch if (graph is not None or args.launch != "graph") else "python"]},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "irrl_step_kernel_l%d" % env.lanes_per_robot, "avg_launch_us": kernel_ms * 1e3,

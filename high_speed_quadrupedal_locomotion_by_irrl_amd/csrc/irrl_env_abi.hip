@@ -247,6 +247,20 @@ int irrl_env_step(irrl_env *h, const float *action, float *ob, float *reward, ui
   return 0;
 }
 
+int irrl_env_step_rows(irrl_env *h, int count, const float *action_rows, int n_rows, int first_row, float *ob, float *reward,
+                       uint8_t *done, float *extra) {
+  if (need_init(h)) return 1;
+  if (count < 0 || n_rows <= 0 || first_row < 0) { g_err = "irrl_env_step_rows: count >= 0, n_rows > 0, first_row >= 0"; return 1; }
+  if (use_device(h)) return 1;
+  const size_t row = (size_t)h->P.n_envs * 12;
+  for (int k = 0; k < count; k++) {
+    const float *action = action_rows + row * (size_t)((first_row + k) % n_rows);
+    IRRL_LAUNCH_STEP(h, lane_grid(h, h->P.n_envs), h->P, h->S, action, ob, reward, done, extra);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // pinned staging layout: action | ob | reward | extra | done
 static void staging(irrl_env *h, float **a, float **o, float **r, float **x, uint8_t **d) {
   const size_t n = (size_t)h->P.n_envs;

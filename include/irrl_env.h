@@ -65,6 +65,11 @@ const char *irrl_env_extra_name(const irrl_env *h, int j);
 /* PYB:21,23 step -> VEC:268-278 (+ perAgentStep VEC:352-372, ENVIRONMENT::step ENV:692-809) */
 int irrl_env_step(irrl_env *h, const float *action, float *ob, float *reward, uint8_t *done, float *extra);
 int irrl_env_step_host(irrl_env *h, const float *action, float *ob, float *reward, uint8_t *done, float *extra);
+/* build-defined: `count` consecutive steps from a device-resident action table [n_rows, N, 12] (step k takes row
+ * (first_row + k) % n_rows), launched back to back on the env's stream by one call -- open-loop playback / benchmarking without a
+ * host round trip per step.  Outputs as irrl_env_step (those of the last step survive). */
+int irrl_env_step_rows(irrl_env *h, int count, const float *action_rows, int n_rows, int first_row, float *ob, float *reward,
+                       uint8_t *done, float *extra);
 /* PYB:24 testStep -> VEC:280-290: env 0 only in the reference (visual eval); here it steps env 0 only and
  * leaves rows 1.. of the outputs untouched (headless: no rendering). */
 int irrl_env_test_step_host(irrl_env *h, const float *action, float *ob, float *reward, uint8_t *done, float *extra);

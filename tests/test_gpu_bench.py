@@ -29,6 +29,30 @@ def test_device_action_stream_matches_the_numpy_twin():
     np.testing.assert_allclose(out.cpu().numpy(), want, atol=2e-6)
 
 
+def test_step_rows_equals_the_same_steps_one_by_one():
+    """irrl_env_step_rows (K back-to-back launches from one C call, action row = launch argument, rows wrap around) leaves the
+    pool and the outputs bit-identical to K irrl_env_step calls -- for a plain pool and for a Crutial one (its own step kernel)"""
+    import torch
+    from hip_env import HipVecEnv
+    n, K, rows = 96, 37, 16
+    for over in ({}, {"Crutial": True}):
+        a, b = HipVecEnv(load_env_cfg("default_cfg.yaml", num_envs=n, **over)), HipVecEnv(load_env_cfg("default_cfg.yaml", num_envs=n, **over))
+        g = torch.Generator(device="cuda").manual_seed(5)
+        table = (0.3 * torch.randn(rows, n, 12, device="cuda", generator=g)).clamp(-1, 1)
+        outs = []
+        for env in (a, b):
+            outs.append((torch.zeros(n, 35, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(n, dtype=torch.bool, device="cuda"), torch.zeros(n, 6, device="cuda")))
+        a.impl.step_rows(K, table, 11, *outs[0])
+        for k in range(K):
+            b.impl.step(table[(11 + k) % rows], *outs[1])
+        torch.cuda.synchronize()
+        for x, y in zip(outs[0], outs[1]):
+            assert torch.equal(x, y)
+        np.testing.assert_array_equal(a.get_state(), b.get_state())
+        with pytest.raises(RuntimeError, match="step_rows"):
+            a.impl.step_rows(-1, table, 0, *outs[0])
+
+
 def test_counters_see_landing_and_resets():
     from hip_env import HipVecEnv
     n = 64
