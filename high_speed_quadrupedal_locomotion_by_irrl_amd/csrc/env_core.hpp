@@ -152,6 +152,19 @@ IRRL_DEV void legs_rng16(vu seed, vu env, vu episode, vu step, vu purpose, vf ou
   out[8] = legs_bcast<2>(r.u0); out[9] = legs_bcast<2>(r.u1); out[10] = legs_bcast<2>(r.u2); out[11] = legs_bcast<2>(r.u3);
   out[12] = legs_bcast<3>(r.u0); out[13] = legs_bcast<3>(r.u1); out[14] = legs_bcast<3>(r.u2); out[15] = legs_bcast<3>(r.u3);
 }
+// the same 16 values from a draw the lanes already hold (r = philox_u01(..., purpose + leg) of each leg's lane)
+IRRL_DEV void legs_gather16(const rng4 &r, vf out[16]) {
+  out[0] = legs_bcast<0>(r.u0); out[1] = legs_bcast<0>(r.u1); out[2] = legs_bcast<0>(r.u2); out[3] = legs_bcast<0>(r.u3);
+  out[4] = legs_bcast<1>(r.u0); out[5] = legs_bcast<1>(r.u1); out[6] = legs_bcast<1>(r.u2); out[7] = legs_bcast<1>(r.u3);
+  out[8] = legs_bcast<2>(r.u0); out[9] = legs_bcast<2>(r.u1); out[10] = legs_bcast<2>(r.u2); out[11] = legs_bcast<2>(r.u3);
+  out[12] = legs_bcast<3>(r.u0); out[13] = legs_bcast<3>(r.u1); out[14] = legs_bcast<3>(r.u2); out[15] = legs_bcast<3>(r.u3);
+}
+// One step's noise draws made up front.  A step of a noisy configuration consumes the action noise (1 draw per robot, or 4 with
+// independent factors) and the three observation-noise vectors (3 draws each, legs 0-2): with 16 lanes per robot that is ONE
+// Philox evaluation per lane -- sub-lane 0 of leg l draws OBS_JOINT + l, sub-lane 1 OBS_JVEL + l, sub-lane 2 OBS_NORMAL + l,
+// sub-lane 3 the action noise -- instead of four in a row (1 in every lane + 3 in the epilogue).  Same (purpose, slot) addresses,
+// same numbers.
+struct StepNoise { rng4 joint, jvel, normal; };
 // pick element (3*leg + k) of a 12-vector that every lane holds
 IRRL_DEV vf pick_leg(const vf v[12], vi leg, int k) {
   return vsel(leg == 0, v[k], vsel(leg == 1, v[3 + k], vsel(leg == 2, v[6 + k], v[9 + k])));
@@ -1553,7 +1566,7 @@ IRRL_DEV void contact_obs_update(const EnvParams &P, EnvLane &L) {
 }
 
 // ENV:956-1004
-IRRL_DEV void update_observation(const EnvParams &P, EnvLane &L, vu env) {
+IRRL_DEV void update_observation(const EnvParams &P, EnvLane &L, vu env, const StepNoise *pre = nullptr) {
   vi leg = leg_id();
   vf t = env_time(P, L);
   L.ob_cmd[0] = 0.0f; L.ob_cmd[1] = 0.0f; L.ob_cmd[2] = 0.0f;  // ENV:960 zeroes the buffer
@@ -1567,13 +1580,13 @@ IRRL_DEV void update_observation(const EnvParams &P, EnvLane &L, vu env) {
   vf nj[3] = {0.0f, 0.0f, 0.0f}, nv[3] = {0.0f, 0.0f, 0.0f}, nn[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
   if (P.obs_noise != 0.0f) {
     vf u[16];
-    legs_rng16(P.seed, env, L.episode, to_u(L.frame), IRRL_P_OBS_JOINT, u);
+    if (pre) legs_gather16(pre->joint, u); else legs_rng16(P.seed, env, L.episode, to_u(L.frame), IRRL_P_OBS_JOINT, u);
 #pragma unroll
     for (int k = 0; k < 3; k++) nj[k] = (2.0f * pick_leg(u, leg, k) - 1.0f) * 0.002f * P.obs_noise;
-    legs_rng16(P.seed, env, L.episode, to_u(L.frame), IRRL_P_OBS_JVEL, u);
+    if (pre) legs_gather16(pre->jvel, u); else legs_rng16(P.seed, env, L.episode, to_u(L.frame), IRRL_P_OBS_JVEL, u);
 #pragma unroll
     for (int k = 0; k < 3; k++) nv[k] = (2.0f * pick_leg(u, leg, k) - 1.0f) * 0.8f * P.obs_noise;
-    legs_rng16(P.seed, env, L.episode, to_u(L.frame), IRRL_P_OBS_NORMAL, u);
+    if (pre) legs_gather16(pre->normal, u); else legs_rng16(P.seed, env, L.episode, to_u(L.frame), IRRL_P_OBS_NORMAL, u);
     // Box-Muller: normal k from uniforms (2k, 2k+1); lane l evaluates normals l and 4 + (l & 1)
     vf ua = pick4(u[0], u[2], u[4], u[6], leg), ub = pick4(u[1], u[3], u[5], u[7], leg);
     vf uc = vsel((leg & 1) == 0, u[8], u[10]), ud = vsel((leg & 1) == 0, u[9], u[11]);
@@ -1936,8 +1949,12 @@ IRRL_DEV void observe_lane(const EnvParams &P, vi env, vi leg, vm valid, EnvLane
 // whole-step bodies (one call per lane); the __global__ wrappers live in env_kernels.hip
 // ---------------------------------------------------------------------------------------------
 // VEC:268-278 + 352-372 around ENV:692-809
+struct NoStepHook { IRRL_DEV void operator()() const {} };
+// `before_substeps` runs once between the step prologue (all of this step's global loads are behind it) and the substep loop:
+// the fused env + policy kernel starts its LDS prefetch of the policy weights there (env_kernels.hip)
+template <class Hook = NoStepHook>
 IRRL_DEV void step_body(const EnvParams &P, const EnvState &S, vi env, vi leg, vm valid, const float *action, float *ob_out,
-                        float *reward_out, uint8_t *done_out, float *extra_out) {
+                        float *reward_out, uint8_t *done_out, float *extra_out, Hook before_substeps = Hook()) {
   EnvLane L;
   load_lane(P, S, env, leg, L, true);
 #ifdef IRRL_PROFILE_WAVES
@@ -1946,9 +1963,38 @@ IRRL_DEV void step_body(const EnvParams &P, const EnvState &S, vi env, vi leg, v
   vu envu = to_u(env);
   // ENV:700-708
   vf pT[3];
+#ifdef IRRL_L16
+  // noisy configurations: all of this step's draws in one Philox evaluation per lane (StepNoise above)
+  const bool predraw = P.obs_noise != 0.0f;
+  rng4 draw;
+  draw.u0 = 0.0f; draw.u1 = 0.0f; draw.u2 = 0.0f; draw.u3 = 0.0f;
+  if (predraw) {
+    const vi sub = sub_id();
+    const vu lg = to_u(leg);
+    const vu purpose = vsel_u(sub == 0, IRRL_P_OBS_JOINT + lg, vsel_u(sub == 1, IRRL_P_OBS_JVEL + lg, vsel_u(sub == 2, IRRL_P_OBS_NORMAL + lg,
+                              P.shared_noise ? vu(IRRL_P_ACTION_NOISE) : IRRL_P_ACTION_NOISE + lg)));
+    draw = philox_u01(P.seed, envu, L.episode, to_u(L.frame), purpose);
+  }
+#else
+  const bool predraw = false;
+#endif
   {
     vf an[3] = {0.0f, 0.0f, 0.0f};
     if (P.action_noise != 0.0f) {
+#ifdef IRRL_L16
+      if (predraw) {
+        rng4 r;
+        r.u0 = sub_bcast<3>(draw.u0); r.u1 = sub_bcast<3>(draw.u1); r.u2 = sub_bcast<3>(draw.u2); r.u3 = sub_bcast<3>(draw.u3);
+        if (P.shared_noise) {
+          an[0] = an[1] = an[2] = 2.0f * r.u0 - 1.0f;
+        } else {
+          vf u[16];
+          legs_gather16(r, u);
+#pragma unroll
+          for (int k = 0; k < 3; k++) an[k] = 2.0f * pick_leg(u, leg, k) - 1.0f;
+        }
+      } else
+#endif
       if (P.shared_noise) {
         rng4 r = philox_u01(P.seed, envu, L.episode, to_u(L.frame), IRRL_P_ACTION_NOISE);
         an[0] = an[1] = an[2] = 2.0f * r.u0 - 1.0f;
@@ -1999,13 +2045,25 @@ IRRL_DEV void step_body(const EnvParams &P, const EnvState &S, vi env, vi leg, v
       L.ww.y = vsel(fire, L.ww.y + 0.3f * (2.0f * b.u3 - 1.0f) * r, L.ww.y);
     }
   }
+  before_substeps();
   for (int i = 0; i < P.loop_count; i++) physics_substep(P, L, pT);
   // The epilogue is per-leg work: with four sub-lanes per leg it would be executed four times over.  Only sub-lane 0
   // (the lane that owns the stores) runs it -- same issue time, a quarter of the active lanes, which is what the
   // power-limited clock of a fully occupied chip responds to.  All cross-leg DPP traffic below is between sub-lanes 0.
+#ifdef IRRL_L16
+  StepNoise sn;
+  if (predraw) {   // all lanes still active: sub-lane 0 collects what sub-lanes 1 and 2 drew
+    sn.joint = draw;
+    sn.jvel.u0 = sub_bcast<1>(draw.u0); sn.jvel.u1 = sub_bcast<1>(draw.u1); sn.jvel.u2 = sub_bcast<1>(draw.u2); sn.jvel.u3 = sub_bcast<1>(draw.u3);
+    sn.normal.u0 = sub_bcast<2>(draw.u0); sn.normal.u1 = sub_bcast<2>(draw.u1); sn.normal.u2 = sub_bcast<2>(draw.u2); sn.normal.u3 = sub_bcast<2>(draw.u3);
+  }
+  const StepNoise *pre = predraw ? &sn : nullptr;
+#else
+  const StepNoise *pre = nullptr;
+#endif
   IRRL_SUB0_ONLY_BEGIN
 #ifndef IRRL_AB_NO_OBS
-  update_observation(P, L, envu);
+  update_observation(P, L, envu, pre);
 #endif
   vf extra[6];
 #ifndef IRRL_AB_NO_REWARD

@@ -23,6 +23,10 @@
 #define IRRL_CRUTIAL(P) false
 #include "env_core.hpp"
 
+#if IRRL_LANES_PER_ROBOT == 16
+#include "policy_step.hpp"   // the LSTM policy's rollout step (device code shared with lstm_kernels.hip)
+#endif
+
 // This file is compiled twice (build.py): once per lane layout, kernel names suffixed _l16 / _l4.
 #if IRRL_LANES_PER_ROBOT == 16
 #define IRRL_K(name) name##_l16
@@ -70,6 +74,41 @@ IRRL_K(irrl_step_kernel)(EnvParams P, EnvState S, const float *action, float *ob
   if (valid_ && leg_ == 0) extra[env_ * 6 + 5] = (float)(t1_ - t0_);
 #endif
 }
+
+#if IRRL_LANES_PER_ROBOT == 16
+// ONE ROLLOUT STEP IN ONE LAUNCH: env.step of 16 robots (the workgroup's four waves, four robots each: the step kernel's body
+// unchanged) and, behind a workgroup barrier, the LSTM policy's step on the observations those 16 robots just produced (one
+// MFMA M-tile; policy_step.hpp with two virtual waves per wave).  `action` is what the previous launch's policy part wrote
+// for these robots (a.clipped), `ob` / `done` / `reward` are a.obs / a.dones / a.prev_reward: nothing a workgroup touches
+// belongs to another workgroup, so the only synchronisation is the barrier.  Against two launches per step this removes a
+// launch boundary and hides the layer-0 weight fetch -- and still MEASURES SLOWER (62.9 against 58.2 us per step at 4096 envs,
+// tools/rollout_phases.py): the launch ends with its slowest workgroup, which pays the whole policy part behind its slowest
+// robot, and four waves (three of them with two virtual waves of MFMA work each) take 18.5 us for what the stand-alone kernel's
+// six waves do in 14.1.  Bit-identical results; an OPTION of irrl_lstm_rollout (fuse = 1), not the default.  (HID 48, ob 35.)
+__global__ void __launch_bounds__(256, 1)
+irrl_step_policy_kernel_l16(EnvParams P, EnvState S, const float *action, float *ob, float *reward, uint8_t *done, float *extra, PolicyStepArgs a) {
+  __shared__ float hbuf[2][16 * 49];
+  __shared__ float terms[16][17];
+  __shared__ float head_w[48 * 17];
+  __shared__ __attribute__((aligned(1024))) float lds_w[PolicyLdsImage<48>::FLOATS];   // 126 KiB: wh0 | wx0 of the actor and the critic stack
+#ifdef IRRL_PROFILE_POLICY
+  const unsigned long long pt0_ = wall_clock64();
+#endif
+  {
+    IRRL_LANE_PROLOGUE
+    // the env part keeps no LDS and, between its prologue and its epilogue, issues no global load (flat ground): the layer-0
+    // policy weights travel L2 -> LDS underneath the eight substeps
+    irrl_plain::step_body(P, S, env_, leg_, valid_, action, ob, reward, done, extra, [&]() { policy_prefetch_lds<48, 256>(a, lds_w); });
+  }
+#ifdef IRRL_PROFILE_POLICY
+  const unsigned long long pt1_ = wall_clock64();
+#else
+  const unsigned long long pt0_ = 0, pt1_ = 0;
+#endif
+  __syncthreads();   // the workgroup's stores of obs / dones / reward are complete and visible to its own loads, the LDS image has landed
+  policy_step_body<48, 9, 2, 256, true>(a, (int)blockIdx.x * 16, hbuf, terms, head_w, lds_w, pt0_, pt1_);
+}
+#endif
 
 __global__ void __launch_bounds__(256, 1) IRRL_K(irrl_init_kernel)(EnvParams P, EnvState S) {
   IRRL_LANE_PROLOGUE

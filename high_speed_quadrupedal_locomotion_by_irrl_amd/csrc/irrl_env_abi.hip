@@ -23,6 +23,7 @@
 IRRL_DECLARE_KERNELS(_l16)
 IRRL_DECLARE_KERNELS(_l4)
 extern "C" __global__ void irrl_terminal_kernel(EnvParams, EnvState, uint8_t *);
+extern "C" __global__ void irrl_step_policy_kernel_l16(EnvParams, EnvState, const float *, float *, float *, uint8_t *, float *, PolicyStepArgs);
 
 #include "irrl_config.hpp"
 #include "irrl_state_pool.hpp"
@@ -256,6 +257,53 @@ int irrl_env_step_rows(irrl_env *h, int count, const float *action_rows, int n_r
   for (int k = 0; k < count; k++) {
     const float *action = action_rows + row * (size_t)((first_row + k) % n_rows);
     IRRL_LAUNCH_STEP(h, lane_grid(h, h->P.n_envs), h->P, h->S, action, ob, reward, done, extra);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int irrl_lstm_rollout(irrl_env *h, int steps, int hid, int ob_dim, int act_dim, float *obs, uint8_t *dones, const float *states_in,
+                      float *states_out, const float *const *lstm_w, const float *pi_w, const float *pi_b, const float *vf_w,
+                      const float *vf_b, const float *logstd, const float *noise, int rng_on, unsigned rng_seed, long long rng_step,
+                      const long long *rng_base, float *action, float *clipped, float *value, float *neglogp, long long row, float *mb_obs,
+                      float *mb_actions, float *mb_values, float *mb_neglogp, uint8_t *mb_dones, float *mb_rewards,
+                      float *env_reward, float *env_extra, int fuse, void *hip_stream) {
+  if (need_init(h)) return 1;
+  if (steps < 0 || row < 0 || act_dim != 12 || ob_dim != 35) { g_err = "irrl_lstm_rollout: steps >= 0, row >= 0, ob 35, act 12"; return 1; }
+  if (!(mb_obs && mb_actions && mb_values && mb_neglogp && mb_dones)) { g_err = "irrl_lstm_rollout: the rollout buffers are mandatory"; return 1; }
+  HIP_TRY(hipSetDevice(h->device));
+  h->stream = (hipStream_t)hip_stream;
+  const int n = h->P.n_envs;
+  auto noise_at = [&](int k) { return noise ? noise + (size_t)k * (size_t)n * (size_t)act_dim : nullptr; };
+  // step k's policy part alone (k == 0, and every step on the two-launch path)
+  auto policy = [&](int k) {
+    return irrl_lstm_policy_step(hid, ob_dim, act_dim, n, obs, dones, k == 0 ? states_in : states_out, states_out, lstm_w, pi_w, pi_b, vf_w, vf_b,
+                                 logstd, noise_at(k), rng_on, rng_seed, rng_step + k, rng_base, action, clipped, value, neglogp, row + k, mb_obs,
+                                 mb_actions, mb_values, mb_neglogp, mb_dones, mb_rewards, env_reward, hip_stream);
+  };
+  // fuse != 0: one launch per step, env.step k together with the policy step k + 1 (16-lane layout = one MFMA M-tile per four env
+  // waves, the reference's 48-unit network, pools without the meteorite).  Bit-identical to the two-launch sequence, and measured
+  // SLOWER on MI355X (62.9 against 58.2 us per step at 4096 envs): kept as an option, not the default.
+  const bool fused = fuse != 0 && h->lanes == 16 && !h->P.crutial && hid == 48 && steps > 1;
+  if (steps > 0 && policy(0) != 0) { g_err = "irrl_lstm_rollout: policy step refused its arguments"; return 1; }
+  for (int k = 0; k < steps; k++) {
+    if (fused && k + 1 < steps) {
+      PolicyStepArgs a;
+      a.obs = obs; a.dones = dones; a.states_in = states_out; a.states_out = states_out;
+      for (int i = 0; i < 12; i++) a.w[i] = lstm_w[i];
+      a.pi_w = pi_w; a.pi_b = pi_b; a.vf_w = vf_w; a.vf_b = vf_b; a.logstd = logstd; a.noise = noise_at(k + 1);
+      a.action = action; a.clipped = clipped; a.value = value; a.neglogp = neglogp;
+      a.row = row + k + 1; a.rng_base = rng_base;
+      a.mb_obs = mb_obs; a.mb_actions = mb_actions; a.mb_values = mb_values; a.mb_neglogp = mb_neglogp; a.mb_dones = mb_dones;
+      a.mb_rewards = mb_rewards; a.prev_reward = mb_rewards ? env_reward : nullptr;
+      a.rng_step = rng_step + k + 1; a.rng_seed = rng_seed; a.rng_on = rng_on;
+      a.N = n; a.ob_dim = ob_dim; a.act_dim = act_dim;
+      hipLaunchKernelGGL(irrl_step_policy_kernel_l16, dim3((n + 15) / 16), dim3(256), 0, h->stream, h->P, h->S, (const float *)clipped, obs,
+                         env_reward, dones, env_extra, a);
+    } else {
+      IRRL_LAUNCH_STEP(h, lane_grid(h, n), h->P, h->S, (const float *)clipped, obs, env_reward, dones, env_extra);
+      if (k + 1 < steps && policy(k + 1) != 0) { g_err = "irrl_lstm_rollout: policy step refused its arguments"; return 1; }
+    }
   }
   HIP_TRY(hipGetLastError());
   return 0;

@@ -22,12 +22,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define LSTM_DEV __device__ __forceinline__
-
-LSTM_DEV float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-LSTM_DEV float fast_tanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
+#include "policy_step.hpp"   // f32x4, LSTM_DEV, fast_sigmoid / fast_tanh, the rollout step of the LSTM policy
 
 template <int HID>
 __global__ void __launch_bounds__(HID / 16 * 64)
@@ -626,285 +621,15 @@ lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// One ROLLOUT step of the whole CustomLSTMPolicy in a single launch (run_bp_v5.py:178-185 `step`): actor stack and
-// critic stack (two LSTM layers each), the action / value heads, the Gaussian sample, its neglogp, the [-1, 1] clip the
-// runner applies (ppo2.py:533-535) and the rollout-buffer rows of step t (ppo2.py:521-531), including the reward row
-// of the PREVIOUS step, so that a rollout step is exactly two launches (this + env step); the row index is a launch
-// argument (the runner captures the whole rollout, one node pair per step, into a hipGraph).
-// A workgroup owns 16 envs; waves [0, NW) run the actor stack, waves [NW, 2 NW) the critic stack, each wave 16 hidden
-// units with their four gates (same MFMA mapping as the sequence kernels).  Weights are read once per workgroup from
-// L2 (all workgroups read the same ~260 KB), the LSTM state [N, 8 HID] is updated in place.
-struct PolicyStepArgs {
-  const float *obs;        // [N, ob_dim]
-  const uint8_t *dones;    // [N] episode ended before this step (mask of the state)
-  const float *states_in;  // [N, 8 HID]: pi0 [c|h], pi1 [c|h], v0 [c|h], v1 [c|h]  (run_bp_v5.py:136-140)
-  float *states_out;       // may alias states_in
-  const float *w[12];      // layer (pi0, pi1, v0, v1) x (wx_p [n_in][HID][4], wh_p [HID][HID][4], b_p [HID][4])
-  const float *pi_w, *pi_b, *vf_w, *vf_b, *logstd;
-  const float *noise;      // [N, act_dim] standard normal, or NULL
-  float *action, *clipped, *value, *neglogp;
-  long long row;           // rollout row t written in the mb_* buffers, or -1: none
-  const long long *rng_base;  // device scalar added to rng_step (e.g. steps of all earlier rollouts), or NULL
-  float *mb_obs, *mb_actions, *mb_values, *mb_neglogp, *mb_rewards;
-  uint8_t *mb_dones;
-  const float *prev_reward;  // [N] reward of the previous env step -> mb_rewards[t-1] (t > 0)
-  long long rng_step;
-  unsigned rng_seed;
-  int rng_on;              // noise == NULL: 1 = counter-RNG sample (Philox keyed like the env's), 0 = deterministic
-  int N, ob_dim, act_dim;
-};
-
-// Philox4x32-10, key (seed, 'IRR1') -- the env engine's generator (env_core.hpp philox_u01): 4 uniforms in [0, 1)
-LSTM_DEV void policy_philox(unsigned seed, unsigned c0, unsigned c1, unsigned c2, unsigned c3, float out[4]) {
-  unsigned k0 = seed, k1 = 0x49525231u;
-#pragma unroll
-  for (int r = 0; r < 10; r++) {
-    const unsigned hi0 = __umulhi(c0, 0xD2511F53u), lo0 = c0 * 0xD2511F53u;
-    const unsigned hi1 = __umulhi(c2, 0xCD9E8D57u), lo1 = c2 * 0xCD9E8D57u;
-    const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  const float s = 1.0f / 16777216.0f;
-  out[0] = (float)(c0 >> 8) * s; out[1] = (float)(c1 >> 8) * s; out[2] = (float)(c2 >> 8) * s; out[3] = (float)(c3 >> 8) * s;
-}
-#define IRRL_P_POLICY_NOISE 0x50u  /* purpose word of the sampling noise: block q = action index / 4 uses purpose 0x50 + q */
-
-// Heads, sample, neglogp, clip and rollout-buffer rows shared by the LSTM and MLP policy-step kernels: thread (env, action)
-// for the mean / sample, 16 more threads for the value and the neglogp sum.  hpi / hv: the two nets' last hidden
-// activations [16 envs][LD] in LDS; head_w: pi_w [HID][act] then vf_w [HID] staged in LDS.
-template <int HID>
-LSTM_DEV void policy_heads(const PolicyStepArgs &a, const float *hpi, const float *hv, int LD, const float *head_w, float (*terms)[17],
-                           int e0, int tid, long long t, long long gstep) {
-  // heads: thread (env, action) for the mean / sample, 16 more threads for the value and the neglogp sum
-  const int A = a.act_dim;
-  if (tid < 16 * A && e0 + tid / A < a.N) {
-    const int env = tid / A, ai = tid - env * A;
-    float mean = a.pi_b[ai];
-#pragma unroll
-    for (int k = 0; k < HID; k++) mean = __builtin_fmaf(hpi[env * LD + k], head_w[k * A + ai], mean);
-    const float ls = a.logstd[ai];
-    const float sd = __expf(ls);
-    const size_t o = (size_t)(e0 + env) * A + ai;
-    float z = 0.0f;
-    if (a.noise) {
-      z = a.noise[o];
-    } else if (a.rng_on) {
-      float r[4];
-      policy_philox(a.rng_seed, (unsigned)(e0 + env), (unsigned)((unsigned long long)gstep >> 32), (unsigned)gstep, IRRL_P_POLICY_NOISE + (unsigned)(ai >> 2), r);
-      // Box-Muller on the pair (r0, r1) for slots 0/1 and (r2, r3) for slots 2/3; 1 - u is in (0, 1]
-      const int pair = (ai >> 1) & 1;
-      const float ua = pair ? r[2] : r[0], ub = pair ? r[3] : r[1];
-      const float rad = __builtin_sqrtf(-2.0f * __logf(1.0f - ua));
-      const float ang = 6.283185307179586f * ub;
-      z = rad * ((ai & 1) ? __sinf(ang) : __cosf(ang));
-    }
-    const float act = mean + sd * z;
-    const float d = (act - mean) / sd;
-    terms[env][ai] = 0.5f * d * d + ls;
-    const float cl = fminf(fmaxf(act, -1.0f), 1.0f);
-    a.action[o] = act;
-    a.clipped[o] = cl;
-    if (a.mb_actions) a.mb_actions[(size_t)t * a.N * A + o] = act;
-  }
-  float val = 0.0f;
-  const int vt = tid - 16 * A;
-  const bool vok = vt >= 0 && vt < 16 && e0 + vt < a.N;
-  if (vok) {
-    val = a.vf_b[0];
-#pragma unroll
-    for (int k = 0; k < HID; k++) val = __builtin_fmaf(hv[vt * LD + k], head_w[HID * A + k], val);
-  }
-  __syncthreads();
-  if (vok) {
-    float nl = 0.0f;
-    for (int ai = 0; ai < A; ai++) nl += terms[vt][ai];
-    nl += 0.918938533204672742f * (float)A;   // 0.5 log(2 pi) per action dimension
-    const int e = e0 + vt;
-    a.value[e] = val;
-    a.neglogp[e] = nl;
-    if (a.mb_values) {
-      a.mb_values[(size_t)t * a.N + e] = val;
-      a.mb_neglogp[(size_t)t * a.N + e] = nl;
-      a.mb_dones[(size_t)t * a.N + e] = a.dones[e];
-      if (a.prev_reward && t > 0) a.mb_rewards[(size_t)(t - 1) * a.N + e] = a.prev_reward[e];
-    }
-  }
-  if (a.mb_obs) {
-    const int n = ((a.N - e0 < 16) ? a.N - e0 : 16) * a.ob_dim;
-    const float *src = a.obs + (size_t)e0 * a.ob_dim;
-    float *dst = a.mb_obs + ((size_t)t * a.N + e0) * a.ob_dim;
-    for (int i = tid; i < n; i += blockDim.x) dst[i] = src[i];
-  }
-}
-
-#define PS_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b_, c_, 0, 0, 0)
-// OBK = k-steps of the observation projection ((ob_dim + 3) / 4) when known at compile time, 0 = runtime loop
+// One ROLLOUT step of the whole CustomLSTMPolicy in a single launch: the device code lives in policy_step.hpp (shared with the
+// fused env + policy kernel of env_kernels.hip); this is the stand-alone kernel, a workgroup of 2 HID/16 waves per 16 envs.
 template <int HID, int OBK>
 __global__ void __launch_bounds__(2 * (HID / 16) * 64)
 lstm_policy_step_kernel(PolicyStepArgs a) {
-  constexpr int NW = HID / 16;
-  constexpr int KS = HID / 4;
-  constexpr int LD = HID + 1;
-  constexpr int SD = 8 * HID;
-  __shared__ float hbuf[2][16 * LD];   // per stack: the h of the layer just computed, [env][unit]
+  __shared__ float hbuf[2][16 * (HID + 1)];   // per stack: the h of the layer just computed, [env][unit]
   __shared__ float terms[16][17];
-  __shared__ float head_w[HID * 17];   // pi_w [HID][act] then vf_w [HID]: staged once, read by the head threads
-  const int tid = threadIdx.x;
-  const int w = tid >> 6, l = tid & 63;
-  const int col = l & 15, rq = l >> 4;
-  const int stack = w / NW, ws = w - stack * NW;
-  const int e0 = blockIdx.x * 16;
-#ifdef IRRL_PROFILE_POLICY   /* diagnostic build (tools/policy_phases.py): 100 MHz time stamps of the phases of one workgroup */
-  unsigned long long ts_[8];
-  int tsn_ = 0;
-#define IRRL_PS_STAMP() do { __builtin_amdgcn_sched_barrier(0); ts_[tsn_++] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define IRRL_PS_STAMP() do { } while (0)
-#endif
-  IRRL_PS_STAMP();   // 0: start
-  // N need not be a multiple of 16: rows past the pool read the last env (clamped index) and store nothing
-  const int eA = (e0 + col < a.N) ? e0 + col : a.N - 1;
-  int eC[4];
-  bool okC[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) { okC[j] = e0 + 4 * rq + j < a.N; eC[j] = okC[j] ? e0 + 4 * rq + j : a.N - 1; }
-  const int u = 16 * ws + col;
-  const long long t = a.row;
-  const long long gstep = a.rng_step + (a.rng_base ? *a.rng_base : 0ll);
-  const float keepA = a.dones[eA] ? 0.0f : 1.0f;
-  float keepC[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) keepC[j] = a.dones[eC[j]] ? 0.0f : 1.0f;
-  // (the head weights are needed last: they are fetched into registers BEHIND the LSTM operands below and parked in LDS
-  // after the first MFMA block -- staging them here made every wave wait for a global load before it issued the ~60
-  // operand loads: 5 us from kernel start to "loads issued" and 3.4 us at the first barrier, tools/policy_phases.py)
-  // Everything that does not depend on layer 0's output is requested up front, in program order, so that the L2 / HBM
-  // latency of ~60 independent loads overlaps instead of being paid once per k-step: both layers' previous h and c,
-  // the observation slice, wh of both layers and wx of layer 0.  The recurrent half of layer 1 is accumulated before
-  // layer 0's cell math; only h0 wx1 has to wait for it.
-  // selects between kernel arguments (scalar registers), not an indexed load of the argument block
-  const float *__restrict__ wx0 = stack ? a.w[6] : a.w[0], *__restrict__ wh0 = stack ? a.w[7] : a.w[1], *__restrict__ b0 = stack ? a.w[8] : a.w[2];
-  const float *__restrict__ wx1 = stack ? a.w[9] : a.w[3], *__restrict__ wh1 = stack ? a.w[10] : a.w[4], *__restrict__ b1 = stack ? a.w[11] : a.w[5];
-  const size_t soff0 = (size_t)(stack * 2 + 0) * 2 * HID, soff1 = (size_t)(stack * 2 + 1) * 2 * HID;
-  constexpr int OBKC = OBK > 0 ? OBK : 1;
-  float hp0[KS], hp1[KS], cp0[4], cp1[4], ob[OBKC];
-  f32x4 Wh0[KS], Wh1[KS], Wx0[OBKC];
-#pragma unroll
-  for (int kk = 0; kk < KS; kk++) hp0[kk] = a.states_in[(size_t)eA * SD + soff0 + HID + 4 * kk + rq];
-  if (OBK > 0) {
-#pragma unroll
-    for (int kk = 0; kk < OBKC; kk++) {
-      const int k = 4 * kk + rq, kc = k < a.ob_dim ? k : a.ob_dim - 1;   // clamped: the load is unconditional, the value masked
-      ob[kk] = a.obs[(size_t)eA * a.ob_dim + kc];
-    }
-  }
-#pragma unroll
-  for (int kk = 0; kk < KS; kk++) Wh0[kk] = *(const f32x4 *)&wh0[((size_t)(4 * kk + rq) * HID + u) * 4];
-  if (OBK > 0) {
-#pragma unroll
-    for (int kk = 0; kk < OBKC; kk++) {
-      const int k = 4 * kk + rq, kc = k < a.ob_dim ? k : a.ob_dim - 1;
-      Wx0[kk] = *(const f32x4 *)&wx0[((size_t)kc * HID + u) * 4];
-    }
-  }
-#pragma unroll
-  for (int kk = 0; kk < KS; kk++) hp1[kk] = a.states_in[(size_t)eA * SD + soff1 + HID + 4 * kk + rq];
-#pragma unroll
-  for (int kk = 0; kk < KS; kk++) Wh1[kk] = *(const f32x4 *)&wh1[((size_t)(4 * kk + rq) * HID + u) * 4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    cp0[j] = a.states_in[(size_t)eC[j] * SD + soff0 + u];
-    cp1[j] = a.states_in[(size_t)eC[j] * SD + soff1 + u];
-  }
-  const f32x4 bias0 = *(const f32x4 *)&b0[u * 4], bias1 = *(const f32x4 *)&b1[u * 4];
-  // head weights: pi_w [HID][act] then vf_w [HID] = HID * (act + 1) floats over the workgroup's threads, two per thread at most
-  const int n_head = HID * (a.act_dim + 1), nthr = 2 * NW * 64;
-  const int hi0 = tid, hi1 = tid + nthr, hi2 = tid + 2 * nthr;   // HID * 17 <= 3 * (8 HID) for every supported shape
-  const float hw0 = hi0 < n_head ? (hi0 < HID * a.act_dim ? a.pi_w[hi0] : a.vf_w[hi0 - HID * a.act_dim]) : 0.0f;
-  const float hw1 = hi1 < n_head ? (hi1 < HID * a.act_dim ? a.pi_w[hi1] : a.vf_w[hi1 - HID * a.act_dim]) : 0.0f;
-  const float hw2 = hi2 < n_head ? (hi2 < HID * a.act_dim ? a.pi_w[hi2] : a.vf_w[hi2 - HID * a.act_dim]) : 0.0f;
-  __builtin_amdgcn_sched_barrier(0);   // keep the loads above clustered: the scheduler must not sink them between the MFMAs
-  IRRL_PS_STAMP();   // 1: loads issued
-  f32x4 acc0[4], acc1[4];
-#pragma unroll
-  for (int g = 0; g < 4; g++) { acc0[g] = (f32x4){bias0[g], bias0[g], bias0[g], bias0[g]}; acc1[g] = (f32x4){bias1[g], bias1[g], bias1[g], bias1[g]}; }
-#pragma unroll
-  for (int kk = 0; kk < KS; kk++) {
-    const float av = hp0[kk] * keepA;
-#pragma unroll
-    for (int g = 0; g < 4; g++) acc0[g] = PS_MFMA(av, Wh0[kk][g], acc0[g]);
-  }
-  if (OBK > 0) {
-#pragma unroll
-    for (int kk = 0; kk < OBKC; kk++) {
-      const float av = (4 * kk + rq < a.ob_dim) ? ob[kk] : 0.0f;
-#pragma unroll
-      for (int g = 0; g < 4; g++) acc0[g] = PS_MFMA(av, Wx0[kk][g], acc0[g]);
-    }
-  } else {
-    const int ksx = (a.ob_dim + 3) >> 2;
-    for (int kk = 0; kk < ksx; kk++) {
-      const int k = 4 * kk + rq, kc = k < a.ob_dim ? k : a.ob_dim - 1;
-      const float av = (k < a.ob_dim) ? a.obs[(size_t)eA * a.ob_dim + kc] : 0.0f;
-      const f32x4 bw = *(const f32x4 *)&wx0[((size_t)kc * HID + u) * 4];
-#pragma unroll
-      for (int g = 0; g < 4; g++) acc0[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[g], acc0[g], 0, 0, 0);
-    }
-  }
-  // layer 1's input weights: requested now, consumed after layer 0's cell
-  f32x4 Wx1[KS];
-#pragma unroll
-  for (int kk = 0; kk < KS; kk++) Wx1[kk] = *(const f32x4 *)&wx1[((size_t)(4 * kk + rq) * HID + u) * 4];
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int kk = 0; kk < KS; kk++) {
-    const float av = hp1[kk] * keepA;
-#pragma unroll
-    for (int g = 0; g < 4; g++) acc1[g] = PS_MFMA(av, Wh1[kk][g], acc1[g]);
-  }
-  if (hi0 < n_head) head_w[hi0] = hw0;
-  if (hi1 < n_head) head_w[hi1] = hw1;
-  if (hi2 < n_head) head_w[hi2] = hw2;
-  IRRL_PS_STAMP();   // 2: layer-0 and recurrent layer-1 MFMAs issued (the loads have landed)
-  // every wave has read the previous h of both layers before anyone overwrites them: states_out may alias states_in
-  __syncthreads();
-  IRRL_PS_STAMP();   // 3: barrier
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const float ig = fast_sigmoid(acc0[0][j]), fg = fast_sigmoid(acc0[1][j]), og = fast_sigmoid(acc0[2][j]), gg = fast_tanh(acc0[3][j]);
-    const float cn = fg * (cp0[j] * keepC[j]) + ig * gg;
-    const float hn = og * fast_tanh(cn);
-    const size_t row = (size_t)eC[j] * SD + soff0;
-    if (okC[j]) { a.states_out[row + u] = cn; a.states_out[row + HID + u] = hn; }
-    hbuf[stack][(4 * rq + j) * LD + u] = hn;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int kk = 0; kk < KS; kk++) {
-    const float av = hbuf[stack][col * LD + 4 * kk + rq];
-#pragma unroll
-    for (int g = 0; g < 4; g++) acc1[g] = PS_MFMA(av, Wx1[kk][g], acc1[g]);
-  }
-  IRRL_PS_STAMP();   // 4: layer-0 cell + layer-1 input MFMAs
-  __syncthreads();   // all reads of layer 0's h are done before hbuf is reused for layer 1's h
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const float ig = fast_sigmoid(acc1[0][j]), fg = fast_sigmoid(acc1[1][j]), og = fast_sigmoid(acc1[2][j]), gg = fast_tanh(acc1[3][j]);
-    const float cn = fg * (cp1[j] * keepC[j]) + ig * gg;
-    const float hn = og * fast_tanh(cn);
-    const size_t row = (size_t)eC[j] * SD + soff1;
-    if (okC[j]) { a.states_out[row + u] = cn; a.states_out[row + HID + u] = hn; }
-    hbuf[stack][(4 * rq + j) * LD + u] = hn;
-  }
-  __syncthreads();
-  IRRL_PS_STAMP();   // 5: layer-1 cell
-  policy_heads<HID>(a, hbuf[0], hbuf[1], LD, head_w, terms, e0, tid, t, gstep);
-  IRRL_PS_STAMP();   // 6: heads, sample, buffer rows
-#ifdef IRRL_PROFILE_POLICY
-  if (blockIdx.x == gridDim.x / 2 && tid == 0)
-    for (int k = 0; k < 7; k++) a.neglogp[k] = (float)(ts_[k] - ts_[0]);
-#endif
+  __shared__ float head_w[HID * 17];          // pi_w [HID][act] then vf_w [HID]: staged once, read by the head threads
+  policy_step_body<HID, OBK, 1, 2 * (HID / 16) * 64>(a, blockIdx.x * 16, hbuf, terms, head_w);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -1,0 +1,423 @@
+// policy_step.hpp -- device code of the single-launch rollout step of the reference's CustomLSTMPolicy, shared by
+//   * lstm_policy_step_kernel (lstm_kernels.hip): the step alone, a workgroup of 2 HID/16 waves per 16 envs, and
+//   * irrl_step_policy_kernel (env_kernels.hip): env.step of 16 robots and, behind a barrier, the policy step on the
+//     observations those robots just produced -- one launch per rollout step instead of two.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#ifndef IRRL_LSTM_COMMON
+#define IRRL_LSTM_COMMON
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // a 16-byte vector at a 4-byte aligned address
+#define LSTM_DEV __device__ __forceinline__
+LSTM_DEV float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+LSTM_DEV float fast_tanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------
+// One ROLLOUT step of the whole CustomLSTMPolicy in a single launch (run_bp_v5.py:178-185 `step`): actor stack and
+// critic stack (two LSTM layers each), the action / value heads, the Gaussian sample, its neglogp, the [-1, 1] clip the
+// runner applies (ppo2.py:533-535) and the rollout-buffer rows of step t (ppo2.py:521-531), including the reward row
+// of the PREVIOUS step, so that a rollout step is exactly two launches (this + env step); the row index is a launch
+// argument (the runner captures the whole rollout, one node pair per step, into a hipGraph).
+// A workgroup owns 16 envs; waves [0, NW) run the actor stack, waves [NW, 2 NW) the critic stack, each wave 16 hidden
+// units with their four gates (same MFMA mapping as the sequence kernels).  Weights are read once per workgroup from
+// L2 (all workgroups read the same ~260 KB), the LSTM state [N, 8 HID] is updated in place.
+struct PolicyStepArgs {
+  const float *obs;        // [N, ob_dim]
+  const uint8_t *dones;    // [N] episode ended before this step (mask of the state)
+  const float *states_in;  // [N, 8 HID]: pi0 [c|h], pi1 [c|h], v0 [c|h], v1 [c|h]  (run_bp_v5.py:136-140)
+  float *states_out;       // may alias states_in
+  const float *w[12];      // layer (pi0, pi1, v0, v1) x (wx_p [n_in][HID][4], wh_p [HID][HID][4], b_p [HID][4])
+  const float *pi_w, *pi_b, *vf_w, *vf_b, *logstd;
+  const float *noise;      // [N, act_dim] standard normal, or NULL
+  float *action, *clipped, *value, *neglogp;
+  long long row;           // rollout row t written in the mb_* buffers, or -1: none
+  const long long *rng_base;  // device scalar added to rng_step (e.g. steps of all earlier rollouts), or NULL
+  float *mb_obs, *mb_actions, *mb_values, *mb_neglogp, *mb_rewards;
+  uint8_t *mb_dones;
+  const float *prev_reward;  // [N] reward of the previous env step -> mb_rewards[t-1] (t > 0)
+  long long rng_step;
+  unsigned rng_seed;
+  int rng_on;              // noise == NULL: 1 = counter-RNG sample (Philox keyed like the env's), 0 = deterministic
+  int N, ob_dim, act_dim;
+};
+
+// Philox4x32-10, key (seed, 'IRR1') -- the env engine's generator (env_core.hpp philox_u01): 4 uniforms in [0, 1)
+LSTM_DEV void policy_philox(unsigned seed, unsigned c0, unsigned c1, unsigned c2, unsigned c3, float out[4]) {
+  unsigned k0 = seed, k1 = 0x49525231u;
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    const unsigned hi0 = __umulhi(c0, 0xD2511F53u), lo0 = c0 * 0xD2511F53u;
+    const unsigned hi1 = __umulhi(c2, 0xCD9E8D57u), lo1 = c2 * 0xCD9E8D57u;
+    const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  const float s = 1.0f / 16777216.0f;
+  out[0] = (float)(c0 >> 8) * s; out[1] = (float)(c1 >> 8) * s; out[2] = (float)(c2 >> 8) * s; out[3] = (float)(c3 >> 8) * s;
+}
+#define IRRL_P_POLICY_NOISE 0x50u  /* purpose word of the sampling noise: block q = action index / 4 uses purpose 0x50 + q */
+
+// Heads, sample, neglogp, clip and rollout-buffer rows shared by the LSTM and MLP policy-step kernels: thread (env, action)
+// for the mean / sample, 16 more threads for the value and the neglogp sum.  hpi / hv: the two nets' last hidden
+// activations [16 envs][LD] in LDS; head_w: pi_w [HID][act] then vf_w [HID] staged in LDS.
+template <int HID>
+LSTM_DEV void policy_heads(const PolicyStepArgs &a, const float *hpi, const float *hv, int LD, const float *head_w, float (*terms)[17],
+                           int e0, int tid, long long t, long long gstep) {
+  // heads: thread (env, action) for the mean / sample, 16 more threads for the value and the neglogp sum
+  const int A = a.act_dim;
+  if (tid < 16 * A && e0 + tid / A < a.N) {
+    const int env = tid / A, ai = tid - env * A;
+    float mean = a.pi_b[ai];
+#pragma unroll
+    for (int k = 0; k < HID; k++) mean = __builtin_fmaf(hpi[env * LD + k], head_w[k * A + ai], mean);
+    const float ls = a.logstd[ai];
+    const float sd = __expf(ls);
+    const size_t o = (size_t)(e0 + env) * A + ai;
+    float z = 0.0f;
+    if (a.noise) {
+      z = a.noise[o];
+    } else if (a.rng_on) {
+      float r[4];
+      policy_philox(a.rng_seed, (unsigned)(e0 + env), (unsigned)((unsigned long long)gstep >> 32), (unsigned)gstep, IRRL_P_POLICY_NOISE + (unsigned)(ai >> 2), r);
+      // Box-Muller on the pair (r0, r1) for slots 0/1 and (r2, r3) for slots 2/3; 1 - u is in (0, 1]
+      const int pair = (ai >> 1) & 1;
+      const float ua = pair ? r[2] : r[0], ub = pair ? r[3] : r[1];
+      const float rad = __builtin_sqrtf(-2.0f * __logf(1.0f - ua));
+      const float ang = 6.283185307179586f * ub;
+      z = rad * ((ai & 1) ? __sinf(ang) : __cosf(ang));
+    }
+    const float act = mean + sd * z;
+    const float d = (act - mean) / sd;
+    terms[env][ai] = 0.5f * d * d + ls;
+    const float cl = fminf(fmaxf(act, -1.0f), 1.0f);
+    a.action[o] = act;
+    a.clipped[o] = cl;
+    if (a.mb_actions) a.mb_actions[(size_t)t * a.N * A + o] = act;
+  }
+  float val = 0.0f;
+  const int vt = tid - 16 * A;
+  const bool vok = vt >= 0 && vt < 16 && e0 + vt < a.N;
+  if (vok) {
+    val = a.vf_b[0];
+#pragma unroll
+    for (int k = 0; k < HID; k++) val = __builtin_fmaf(hv[vt * LD + k], head_w[HID * A + k], val);
+  }
+  __syncthreads();
+  if (vok) {
+    float nl = 0.0f;
+    for (int ai = 0; ai < A; ai++) nl += terms[vt][ai];
+    nl += 0.918938533204672742f * (float)A;   // 0.5 log(2 pi) per action dimension
+    const int e = e0 + vt;
+    a.value[e] = val;
+    a.neglogp[e] = nl;
+    if (a.mb_values) {
+      a.mb_values[(size_t)t * a.N + e] = val;
+      a.mb_neglogp[(size_t)t * a.N + e] = nl;
+      a.mb_dones[(size_t)t * a.N + e] = a.dones[e];
+      if (a.prev_reward && t > 0) a.mb_rewards[(size_t)(t - 1) * a.N + e] = a.prev_reward[e];
+    }
+  }
+  if (a.mb_obs) {
+    const int n = ((a.N - e0 < 16) ? a.N - e0 : 16) * a.ob_dim;
+    const float *src = a.obs + (size_t)e0 * a.ob_dim;
+    float *dst = a.mb_obs + ((size_t)t * a.N + e0) * a.ob_dim;
+    for (int i = tid; i < n; i += blockDim.x) dst[i] = src[i];
+  }
+}
+
+#define PS_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b_, c_, 0, 0, 0)
+#ifdef IRRL_PROFILE_POLICY   /* diagnostic build (tools/policy_phases.py): 100 MHz time stamps of the phases of one workgroup */
+#define IRRL_PS_STAMP() do { __builtin_amdgcn_sched_barrier(0); ts_[tsn_++] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define IRRL_PS_STAMP() do { } while (0)
+#endif
+// The step for the 16 envs e0 .. e0 + 15 by one workgroup of NTHR threads.  The work is cut into 2 NW "virtual waves" (stack
+// s = actor / critic, ws = 16 hidden units with their four gates: the MFMA mapping of the sequence kernels):
+//   VPW = 1: NTHR = 2 NW x 64, every wave is one virtual wave (the stand-alone kernel);
+//   VPW = 2: NTHR = 256, waves 0 .. NW-1 run (actor, ws = w) AND (critic, ws = w), two independent accumulation streams per
+//            wave; a wave beyond NW only takes part in the barriers, the head weights, the heads and the row copies (the
+//            fused env + policy kernel, whose workgroup is the four env waves of these 16 robots).
+// Per output element the arithmetic and its order are the same in both: the two kernels agree bit for bit.
+// OBK = k-steps of the observation projection ((ob_dim + 3) / 4) when known at compile time, 0 = runtime loop.
+//
+// LDSW: the layer-0 operands wh0 / wx0 of both stacks were copied to LDS (policy_prefetch_lds, same [k][unit][gate] image as in
+// global memory: a wave's 16-byte reads of one k-row are 256 contiguous bytes, conflict free) while the workgroup was busy with
+// something else -- the fused kernel's env part; the first MFMA block then starts without waiting for L2.
+template <int HID>
+struct PolicyLdsImage {
+  static constexpr int WH0 = HID * HID * 4;                       // floats, a multiple of 256 (1 KiB pieces) for HID % 8 == 0
+  static constexpr int WX0 = ((48 * HID * 4 + 255) / 256) * 256;  // room for ob_dim <= 48 rows, rounded up to whole 1 KiB pieces
+  static constexpr int STACK = WH0 + WX0;
+  static constexpr int FLOATS = 2 * STACK;
+};
+// all NTHR threads: one global_load_lds_dwordx4 per 1 KiB piece and wave (destination = wave-uniform base + lane x 16 bytes);
+// no registers, completion on the VM counter -- the caller's next __syncthreads() drains it
+template <int HID, int NTHR>
+LSTM_DEV void policy_prefetch_lds(const PolicyStepArgs &a, float *lds_w) {
+  typedef PolicyLdsImage<HID> IMG;
+  constexpr int NWAVES = NTHR / 64;
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int wx_floats = a.ob_dim * HID * 4;
+  const int wx_pieces = (wx_floats + 255) / 256;
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    const float *wh0 = s ? a.w[7] : a.w[1], *wx0 = s ? a.w[6] : a.w[0];
+    float *dst = lds_w + s * IMG::STACK;
+    for (int c = w; c < IMG::WH0 / 256; c += NWAVES)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wh0 + c * 256 + l * 4),
+                                       (__attribute__((address_space(3))) void *)(dst + c * 256), 16, 0, 0);
+    for (int c = w; c < wx_pieces; c += NWAVES) {
+      int idx = c * 256 + l * 4;
+      idx = idx < wx_floats - 4 ? idx : wx_floats - 4;            // the last piece is ragged: lanes past the end re-read the last 16 bytes
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wx0 + idx),
+                                       (__attribute__((address_space(3))) void *)(dst + IMG::WH0 + c * 256), 16, 0, 0);
+    }
+  }
+}
+
+template <int HID, int OBK, int VPW, int NTHR, bool LDSW = false>
+LSTM_DEV void policy_step_body(const PolicyStepArgs &a, const int e0, float (*hbuf)[16 * (HID + 1)], float (*terms)[17], float *head_w,
+                               const float *lds_w = nullptr, unsigned long long prof_t0 = 0, unsigned long long prof_t1 = 0) {
+  constexpr int NW = HID / 16;
+  constexpr int KS = HID / 4;
+  constexpr int LD = HID + 1;
+  constexpr int SD = 8 * HID;
+  static_assert(VPW == 1 ? NTHR == 2 * NW * 64 : (VPW == 2 && NTHR >= NW * 64), "workgroup shape");
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, l = tid & 63;
+  const int col = l & 15, rq = l >> 4;
+  const bool mine = VPW == 1 ? true : (w < NW);                 // wave-uniform: this wave owns virtual waves
+  const int ws = VPW == 1 ? w % NW : (w < NW ? w : 0);
+#ifdef IRRL_PROFILE_POLICY
+  unsigned long long ts_[8];
+  int tsn_ = 0;
+#endif
+  IRRL_PS_STAMP();   // 0: start
+  // N need not be a multiple of 16: rows past the pool read the last env (clamped index) and store nothing
+  const int eA = (e0 + col < a.N) ? e0 + col : a.N - 1;
+  int eC[4];
+  bool okC[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) { okC[j] = e0 + 4 * rq + j < a.N; eC[j] = okC[j] ? e0 + 4 * rq + j : a.N - 1; }
+  const int u = 16 * ws + col;
+  const long long t = a.row;
+  const long long gstep = a.rng_step + (a.rng_base ? *a.rng_base : 0ll);
+  const float keepA = a.dones[eA] ? 0.0f : 1.0f;
+  float keepC[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) keepC[j] = a.dones[eC[j]] ? 0.0f : 1.0f;
+  // (the head weights are needed last: they are fetched into registers BEHIND the LSTM operands below and parked in LDS
+  // after the first MFMA block -- staging them first made every wave wait for a global load before it issued the ~60
+  // operand loads: 5 us from kernel start to "loads issued" and 3.4 us at the first barrier, tools/policy_phases.py)
+  // Everything that does not depend on layer 0's output is requested up front, in program order, so that the L2 / HBM
+  // latency of the independent loads overlaps instead of being paid once per k-step: both layers' previous h and c,
+  // the observation slice, wh of both layers and wx of layer 0.  The recurrent half of layer 1 is accumulated before
+  // layer 0's cell math; only h0 wx1 has to wait for it.
+  constexpr int OBKC = OBK > 0 ? OBK : 1;
+  const float *wx0[VPW], *wh0[VPW], *b0[VPW], *wx1[VPW], *wh1[VPW], *b1[VPW];
+  size_t soff0[VPW], soff1[VPW];
+  int stk[VPW];
+#pragma unroll
+  for (int v = 0; v < VPW; v++) {
+    const int stack = VPW == 1 ? w / NW : v;
+    stk[v] = stack;
+    // selects between kernel arguments (scalar registers), not an indexed load of the argument block
+    wx0[v] = stack ? a.w[6] : a.w[0]; wh0[v] = stack ? a.w[7] : a.w[1]; b0[v] = stack ? a.w[8] : a.w[2];
+    wx1[v] = stack ? a.w[9] : a.w[3]; wh1[v] = stack ? a.w[10] : a.w[4]; b1[v] = stack ? a.w[11] : a.w[5];
+    soff0[v] = (size_t)(stack * 2 + 0) * 2 * HID; soff1[v] = (size_t)(stack * 2 + 1) * 2 * HID;
+  }
+  // previous h of both layers as 16-byte vectors: lane (env, rq) holds elements 16 m + 4 rq + j (m < KS / 4, j < 4), so the
+  // k-step (m, j) of the recurrent products pairs A = h[16 m + 4 rq + j] with the wh row of the same index -- the k order of the
+  // sum differs from 4 kk + rq (rounding only), and the 2 x KS scattered dword loads of a wave become 2 x KS / 4 vector loads
+  // that use every byte of the 64-byte lines they touch
+  constexpr int KV = KS / 4;
+  constexpr int OBV = OBK > 0 ? (OBK - 1) / 4 : 0;   // whole 16-element groups of the observation row that are valid for every ob_dim with this OBK
+  static_assert(KS % 4 == 0, "HID must be a multiple of 16");
+  f32x4 hp0[VPW][KV], hp1[VPW][KV];
+  float cp0[VPW][4], cp1[VPW][4], ob[OBKC];
+  f32x4 Wh0[VPW][KS], Wh1[VPW][KS], Wx0[VPW][OBKC], Wx1[VPW][KS], bias0[VPW], bias1[VPW];
+  f32x4 acc0[VPW][4], acc1[VPW][4];
+  if (mine) {
+#pragma unroll
+    for (int v = 0; v < VPW; v++)
+#pragma unroll
+      for (int m = 0; m < KV; m++) hp0[v][m] = *(const f32x4 *)&a.states_in[(size_t)eA * SD + soff0[v] + HID + 16 * m + 4 * rq];
+    if (OBK > 0) {
+      // the observation row the same way: OBV 16-byte vectors (elements 16 m + 4 rq + j, all below ob_dim > 4 OBK - 4; rows of
+      // 35 floats are only 4-byte aligned) and the k-steps behind them as single words in the plain 4 kk + rq order
+#pragma unroll
+      for (int m = 0; m < OBV; m++) {
+        const f32x4u v4 = *(const f32x4u *)&a.obs[(size_t)eA * a.ob_dim + 16 * m + 4 * rq];
+        ob[4 * m + 0] = v4[0]; ob[4 * m + 1] = v4[1]; ob[4 * m + 2] = v4[2]; ob[4 * m + 3] = v4[3];
+      }
+#pragma unroll
+      for (int kk = 4 * OBV; kk < OBKC; kk++) {
+        const int k = 4 * kk + rq, kc = k < a.ob_dim ? k : a.ob_dim - 1;   // clamped: the load is unconditional, the value masked
+        ob[kk] = a.obs[(size_t)eA * a.ob_dim + kc];
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < VPW; v++) {
+#pragma unroll
+      for (int kk = 0; kk < KS; kk++)
+        Wh0[v][kk] = LDSW ? *(const f32x4 *)&lds_w[stk[v] * PolicyLdsImage<HID>::STACK + ((16 * (kk / 4) + 4 * rq + (kk % 4)) * HID + u) * 4]
+                          : *(const f32x4 *)&wh0[v][((size_t)(16 * (kk / 4) + 4 * rq + (kk % 4)) * HID + u) * 4];
+      if (OBK > 0) {
+#pragma unroll
+        for (int kk = 0; kk < OBKC; kk++) {
+          const int k = kk < 4 * OBV ? 16 * (kk / 4) + 4 * rq + (kk % 4) : 4 * kk + rq, kc = k < a.ob_dim ? k : a.ob_dim - 1;
+          Wx0[v][kk] = LDSW ? *(const f32x4 *)&lds_w[stk[v] * PolicyLdsImage<HID>::STACK + PolicyLdsImage<HID>::WH0 + (kc * HID + u) * 4]
+                            : *(const f32x4 *)&wx0[v][((size_t)kc * HID + u) * 4];
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < VPW; v++) {
+#pragma unroll
+      for (int m = 0; m < KV; m++) hp1[v][m] = *(const f32x4 *)&a.states_in[(size_t)eA * SD + soff1[v] + HID + 16 * m + 4 * rq];
+#pragma unroll
+      for (int kk = 0; kk < KS; kk++) Wh1[v][kk] = *(const f32x4 *)&wh1[v][((size_t)(16 * (kk / 4) + 4 * rq + (kk % 4)) * HID + u) * 4];
+    }
+#pragma unroll
+    for (int v = 0; v < VPW; v++) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        cp0[v][j] = a.states_in[(size_t)eC[j] * SD + soff0[v] + u];
+        cp1[v][j] = a.states_in[(size_t)eC[j] * SD + soff1[v] + u];
+      }
+      bias0[v] = *(const f32x4 *)&b0[v][u * 4]; bias1[v] = *(const f32x4 *)&b1[v][u * 4];
+    }
+  }
+  // head weights: pi_w [HID][act] then vf_w [HID] = HID * (act + 1) <= HID * 17 floats over the workgroup's threads
+  constexpr int NHW = (HID * 17 + NTHR - 1) / NTHR;
+  const int n_head = HID * (a.act_dim + 1);
+  float hw[NHW];
+#pragma unroll
+  for (int i = 0; i < NHW; i++) {
+    const int hi = tid + i * NTHR;
+    hw[i] = hi < n_head ? (hi < HID * a.act_dim ? a.pi_w[hi] : a.vf_w[hi - HID * a.act_dim]) : 0.0f;
+  }
+  __builtin_amdgcn_sched_barrier(0);   // keep the loads above clustered: the scheduler must not sink them between the MFMAs
+  IRRL_PS_STAMP();   // 1: loads issued
+  if (mine) {
+#pragma unroll
+    for (int v = 0; v < VPW; v++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        acc0[v][g] = (f32x4){bias0[v][g], bias0[v][g], bias0[v][g], bias0[v][g]};
+        acc1[v][g] = (f32x4){bias1[v][g], bias1[v][g], bias1[v][g], bias1[v][g]};
+      }
+#pragma unroll
+    for (int kk = 0; kk < KS; kk++) {
+#pragma unroll
+      for (int v = 0; v < VPW; v++) {
+        const float av = hp0[v][kk / 4][kk % 4] * keepA;
+#pragma unroll
+        for (int g = 0; g < 4; g++) acc0[v][g] = PS_MFMA(av, Wh0[v][kk][g], acc0[v][g]);
+      }
+    }
+    if (OBK > 0) {
+#pragma unroll
+      for (int kk = 0; kk < OBKC; kk++) {
+        const float av = (kk < 4 * OBV || 4 * kk + rq < a.ob_dim) ? ob[kk] : 0.0f;
+#pragma unroll
+        for (int v = 0; v < VPW; v++)
+#pragma unroll
+          for (int g = 0; g < 4; g++) acc0[v][g] = PS_MFMA(av, Wx0[v][kk][g], acc0[v][g]);
+      }
+    } else {
+      const int ksx = (a.ob_dim + 3) >> 2;
+      for (int kk = 0; kk < ksx; kk++) {
+        const int k = 4 * kk + rq, kc = k < a.ob_dim ? k : a.ob_dim - 1;
+        const float av = (k < a.ob_dim) ? a.obs[(size_t)eA * a.ob_dim + kc] : 0.0f;
+#pragma unroll
+        for (int v = 0; v < VPW; v++) {
+          const f32x4 bw = *(const f32x4 *)&wx0[v][((size_t)kc * HID + u) * 4];
+#pragma unroll
+          for (int g = 0; g < 4; g++) acc0[v][g] = PS_MFMA(av, bw[g], acc0[v][g]);
+        }
+      }
+    }
+    // layer 1's input weights: requested now, consumed after layer 0's cell
+#pragma unroll
+    for (int v = 0; v < VPW; v++)
+#pragma unroll
+      for (int kk = 0; kk < KS; kk++) Wx1[v][kk] = *(const f32x4 *)&wx1[v][((size_t)(4 * kk + rq) * HID + u) * 4];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < KS; kk++) {
+#pragma unroll
+      for (int v = 0; v < VPW; v++) {
+        const float av = hp1[v][kk / 4][kk % 4] * keepA;
+#pragma unroll
+        for (int g = 0; g < 4; g++) acc1[v][g] = PS_MFMA(av, Wh1[v][kk][g], acc1[v][g]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NHW; i++) {
+    const int hi = tid + i * NTHR;
+    if (hi < n_head) head_w[hi] = hw[i];
+  }
+  IRRL_PS_STAMP();   // 2: layer-0 and recurrent layer-1 MFMAs issued (the loads have landed)
+  // every wave has read the previous h of both layers before anyone overwrites them: states_out may alias states_in
+  __syncthreads();
+  IRRL_PS_STAMP();   // 3: barrier
+  if (mine) {
+#pragma unroll
+    for (int v = 0; v < VPW; v++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float ig = fast_sigmoid(acc0[v][0][j]), fg = fast_sigmoid(acc0[v][1][j]), og = fast_sigmoid(acc0[v][2][j]), gg = fast_tanh(acc0[v][3][j]);
+        const float cn = fg * (cp0[v][j] * keepC[j]) + ig * gg;
+        const float hn = og * fast_tanh(cn);
+        const size_t row = (size_t)eC[j] * SD + soff0[v];
+        if (okC[j]) { a.states_out[row + u] = cn; a.states_out[row + HID + u] = hn; }
+        hbuf[stk[v]][(4 * rq + j) * LD + u] = hn;
+      }
+  }
+  __syncthreads();
+  if (mine) {
+#pragma unroll
+    for (int kk = 0; kk < KS; kk++) {
+#pragma unroll
+      for (int v = 0; v < VPW; v++) {
+        const float av = hbuf[stk[v]][col * LD + 4 * kk + rq];
+#pragma unroll
+        for (int g = 0; g < 4; g++) acc1[v][g] = PS_MFMA(av, Wx1[v][kk][g], acc1[v][g]);
+      }
+    }
+  }
+  IRRL_PS_STAMP();   // 4: layer-0 cell + layer-1 input MFMAs
+  __syncthreads();   // all reads of layer 0's h are done before hbuf is reused for layer 1's h
+  if (mine) {
+#pragma unroll
+    for (int v = 0; v < VPW; v++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float ig = fast_sigmoid(acc1[v][0][j]), fg = fast_sigmoid(acc1[v][1][j]), og = fast_sigmoid(acc1[v][2][j]), gg = fast_tanh(acc1[v][3][j]);
+        const float cn = fg * (cp1[v][j] * keepC[j]) + ig * gg;
+        const float hn = og * fast_tanh(cn);
+        const size_t row = (size_t)eC[j] * SD + soff1[v];
+        if (okC[j]) { a.states_out[row + u] = cn; a.states_out[row + HID + u] = hn; }
+        hbuf[stk[v]][(4 * rq + j) * LD + u] = hn;
+      }
+  }
+  __syncthreads();
+  IRRL_PS_STAMP();   // 5: layer-1 cell
+  policy_heads<HID>(a, hbuf[0], hbuf[1], LD, head_w, terms, e0, tid, t, gstep);
+  IRRL_PS_STAMP();   // 6: heads, sample, buffer rows
+#ifdef IRRL_PROFILE_POLICY
+  if (blockIdx.x == gridDim.x / 2 && tid == 0) {
+    for (int k = 0; k < 7; k++) a.neglogp[k] = (float)(ts_[k] - ts_[0]);
+    // fused kernel: kernel start -> this wave's env part done -> policy part entered (behind the workgroup barrier)
+    a.neglogp[7] = prof_t0 ? (float)(prof_t1 - prof_t0) : 0.0f;
+    a.neglogp[8] = prof_t0 ? (float)(ts_[0] - prof_t0) : 0.0f;
+  }
+#else
+  (void)prof_t0; (void)prof_t1;
+#endif
+}

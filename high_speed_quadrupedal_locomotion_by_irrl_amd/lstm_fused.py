@@ -255,6 +255,41 @@ def policy_step(policy, obs, states, dones, noise=None, rng=None, states_out=Non
     return action, clipped, value, neglogp, states_out
 
 
+def policy_rollout(policy, env_impl, steps, obs, states, dones, rng, rollout, out, env_reward, env_extra, noise_all=None, fused=False):
+    """`steps` rollout steps (policy_step + env.step on the clipped action) issued back to back by one C call
+    (irrl_lstm_rollout): obs / dones / states are updated in place, rows row .. row + steps - 1 of the rollout buffers are written
+    (rewards one row behind, the last one is left in `env_reward`).  `env_impl` is the FlexibleGymEnv that owns the pool.
+    fused=True: env.step k and policy step k + 1 as one launch (csrc/env_kernels.hip irrl_step_policy_kernel_l16; same bits,
+    measured slower than two launches -- an experiment)."""
+    lib = _lib.load()
+    N, ob_dim = obs.shape
+    hid, act = policy.n_lstm[0], policy.act_dim
+    dev = obs.device
+    perm = _perm(hid, dev)[0]
+    ptrs = []
+    for l in list(policy.lstm_pi) + list(policy.lstm_v):
+        wx_p, wh_p, b_p = _permuted_weights(l.wx, l.wh, l.b, perm)
+        ptrs += [wx_p.data_ptr(), wh_p.data_ptr(), b_p.data_ptr()]
+    warr = (C.c_void_p * 12)(*ptrs)
+    assert obs.is_contiguous() and states.is_contiguous() and dones.is_contiguous() and dones.element_size() == 1
+    assert env_reward.is_contiguous() and env_extra.is_contiguous() and tuple(env_extra.shape) == (N, 6)
+    action, clipped, value, neglogp = out
+    rng_on, seed, step, base = 0, 0, 0, None
+    if noise_all is not None:
+        assert noise_all.is_contiguous() and tuple(noise_all.shape[1:]) == (N, act) and noise_all.shape[0] >= steps
+    elif rng is not None:
+        rng_on, seed, step = 1, int(rng[0]) & 0xFFFFFFFF, int(rng[1])
+        base = _ptr(rng[2]) if len(rng) > 2 and rng[2] is not None else None
+    rc = lib.irrl_lstm_rollout(env_impl._h, int(steps), hid, ob_dim, act, _ptr(obs), _ptr(dones), _ptr(states), _ptr(states), warr,
+                               _ptr(policy.pi.w), _ptr(policy.pi.b), _ptr(policy.vf.w), _ptr(policy.vf.b), _ptr(policy.logstd),
+                               _ptr(noise_all) if noise_all is not None else None, rng_on, seed, step, base,
+                               _ptr(action), _ptr(clipped), _ptr(value), _ptr(neglogp), int(rollout["row"]),
+                               _ptr(rollout["mb_obs"]), _ptr(rollout["mb_actions"]), _ptr(rollout["mb_values"]), _ptr(rollout["mb_neglogpacs"]),
+                               _ptr(rollout["mb_dones"]), _ptr(rollout["mb_rewards"]), _ptr(env_reward), _ptr(env_extra), 1 if fused else 0,
+                               C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    _lib.check(rc)
+
+
 def mlp_policy_step_supported(policy, obs):
     return (obs.is_cuda and obs.dtype == torch.float32 and len(policy.pi_fc) == 2 and policy.pi_fc[0].w.shape[1] == 64
             and policy.pi_fc[1].w.shape == (64, 64) and policy.act_dim <= 15)

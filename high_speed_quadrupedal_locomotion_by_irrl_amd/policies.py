@@ -201,6 +201,12 @@ class CustomLSTMPolicy(ActorCriticPolicy):
         return lstm_fused.policy_step(self, obs, states, d.contiguous(), noise=noise, rng=rng, states_out=states_out, rollout=rollout, out=out)
 
     @torch.no_grad()
+    def fused_rollout(self, env_impl, steps, obs, states, dones, rng, rollout, out, env_reward, env_extra, noise_all=None, fused=False):
+        """`steps` fused_step + env.step pairs issued by one C call (lstm_fused.policy_rollout)"""
+        from . import lstm_fused
+        lstm_fused.policy_rollout(self, env_impl, steps, obs, states, dones, rng, rollout, out, env_reward, env_extra, noise_all=noise_all, fused=fused)
+
+    @torch.no_grad()
     def step(self, obs, states, masks, deterministic=False, generator=None, noise=None):
         """run_bp_v5.py:178-185: -> action (unclipped sample), value, new states, neglogp.  `noise` [N,act] overrides the
         generator draw (pre-drawn standard normals)."""

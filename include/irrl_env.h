@@ -216,6 +216,21 @@ int irrl_lstm_policy_step(int hid, int ob_dim, int act_dim, int N, const float *
                           float *mb_actions, float *mb_values, float *mb_neglogp, uint8_t *mb_dones, float *mb_rewards,
                           const float *prev_reward, void *hip_stream);
 
+/* `steps` consecutive rollout steps (policy step t, then env.step on its clipped action) launched back to back by ONE call on
+ * `hip_stream`: step k runs irrl_lstm_policy_step with rng_step + k, row + k and noise + k N act (if noise is given: a
+ * [steps, N, act] table), states updated in place (states_out may equal states_in), and then the env step of pool `env`
+ * (N = its num_envs) that writes obs / dones IN PLACE (the arrays the next policy step reads), the reward to `env_reward` [N]
+ * (= prev_reward of the next policy step) and the extras to `env_extra` [N,6].  What ppo2.Runner used to record as a hipGraph of
+ * 2 x steps kernel nodes (same speed, no capture).  fuse != 0: env.step k and the policy step k + 1 run as ONE launch (a workgroup =
+ * the four env waves of 16 robots = one MFMA M-tile; 16-lane layout, hid 48, no Crutial; otherwise ignored) -- bit-identical
+ * results, measured slower than the two-launch sequence on MI355X, so callers pass 0 unless they are measuring it. */
+int irrl_lstm_rollout(irrl_env *env, int steps, int hid, int ob_dim, int act_dim, float *obs, uint8_t *dones, const float *states_in,
+                      float *states_out, const float *const *lstm_w, const float *pi_w, const float *pi_b, const float *vf_w,
+                      const float *vf_b, const float *logstd, const float *noise, int rng_on, unsigned rng_seed, long long rng_step,
+                      const long long *rng_base, float *action, float *clipped, float *value, float *neglogp, long long row, float *mb_obs,
+                      float *mb_actions, float *mb_values, float *mb_neglogp, uint8_t *mb_dones, float *mb_rewards,
+                      float *env_reward, float *env_extra, int fuse, void *hip_stream);
+
 /* the same single-launch rollout step for MlpPolicy (flex_gym/archi/policies.py:430-446: separate pi / vf nets of two tanh
  * layers of `hid` = 64 units).  mlp_w: HOST array of 8 device pointers pi_w1 [ob][hid], pi_b1, pi_w2 [hid][hid], pi_b2,
  * vf_w1, vf_b1, vf_w2, vf_b2; heads, sampling, outputs and rollout rows as above; act <= 15. */

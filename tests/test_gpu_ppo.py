@@ -389,24 +389,30 @@ def test_fused_heads_and_loss_gradients_match_autograd(M):
 
 
 def test_graph_capture_warmup_leaves_no_trace_and_setters_invalidate_the_graph():
-    """(a) The three warm-up steps in front of the hipGraph capture are undone (device snapshot of the env pool + the runner's
-    tensors): the FIRST rollout of a graph runner equals the eager runner's bit for bit, i.e. it starts from env.reset().
-    (b) A setter that changes a by-value kernel argument after the capture (setSeed) is not silently ignored: the runner
-    re-captures, and its next rollout again equals the eager runner's that saw the same setSeed."""
+    """Three ways to issue the fused rollout -- "direct" (the default: 2 x T launches from one C call, irrl_lstm_rollout), "graph"
+    (one hipGraph of 2 x T kernel nodes) and "eager" (one Python call per launch) -- give the same rollouts bit for bit:
+    (a) the three warm-up steps in front of the hipGraph capture are undone (device snapshot of the env pool + the runner's
+    tensors), i.e. the FIRST rollout of a graph runner starts from env.reset();
+    (b) a setter that changes a by-value kernel argument after the capture (setSeed) is not silently ignored: the graph runner
+    re-captures; the direct runner reads the parameters at launch time anyway."""
     from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import CustomLSTMPolicy
     from high_speed_quadrupedal_locomotion_by_irrl_amd.ppo2 import PPO2, Runner
     out = {}
-    for graph in (True, False):
+    for mode in ("direct", "one_launch", "graph", "eager"):
         env = _env(64)
         model = PPO2(policy=CustomLSTMPolicy, env=env, n_steps=20, nminibatches=1, noptepochs=1, seed=9)
-        runner = Runner(env, model, 20, 0.99, 0.998, use_graph=graph)
+        runner = Runner(env, model, 20, 0.99, 0.998, use_graph=(mode != "eager"))
+        assert runner.rollout_launch == "direct"      # what a Runner picks by itself for the LSTM policy on the HIP engine
+        runner.rollout_launch = "direct" if mode in ("direct", "one_launch") else "graph"
+        runner.rollout_one_launch_per_step = mode == "one_launch"      # env.step k + policy step k + 1 in one kernel (an option)
         b1 = {k: v.clone() for k, v in runner.run().items() if torch.is_tensor(v)}
-        assert (runner._graph is not None) == graph
+        assert (runner._graph is not None) == (mode == "graph")
         env.wrapper.setSeed(77)                       # new noise / command streams from the next reset on
         b2 = {k: v.clone() for k, v in runner.run().items() if torch.is_tensor(v)}
         b3 = {k: v.clone() for k, v in runner.run().items() if torch.is_tensor(v)}
-        out[graph] = (b1, b2, b3)
-    for i in range(3):
-        for k in ("obs", "actions", "values", "true_reward", "masks"):
-            assert torch.equal(out[True][i][k], out[False][i][k]), (i, k)
-    assert not torch.equal(out[True][1]["obs"], out[True][0]["obs"])
+        out[mode] = (b1, b2, b3)
+    for mode in ("direct", "one_launch", "graph"):
+        for i in range(3):
+            for k in ("obs", "actions", "values", "true_reward", "masks", "neglogpacs", "returns"):
+                assert torch.equal(out[mode][i][k], out["eager"][i][k]), (mode, i, k)
+    assert not torch.equal(out["graph"][1]["obs"], out["graph"][0]["obs"])

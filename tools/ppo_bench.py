@@ -33,6 +33,8 @@ def measure(policy="lstm", envs=4096, steps=750, iters=3, epochs=10, cfg_name="d
     model = PPO2(policy=CustomLSTMPolicy if lstm else MlpPolicy, env=env, gamma=0.99, n_steps=steps, ent_coef=0.0, learning_rate=1e-3,
                  vf_coef=0.5, max_grad_norm=0.5, lam=0.998, nminibatches=1 if lstm else 4, noptepochs=epochs, cliprange=0.2, verbose=0, seed=1)
     runner = Runner(env, model, steps, 0.99, 0.998)
+    if os.environ.get("IRRL_ROLLOUT_LAUNCH"):          # A/B: "graph" = the hipGraph rollout instead of the direct launches
+        runner.rollout_launch = os.environ["IRRL_ROLLOUT_LAUNCH"]
     rows = []
     for it in range(iters):
         torch.cuda.synchronize()
