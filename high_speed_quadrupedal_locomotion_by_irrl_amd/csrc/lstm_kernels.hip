@@ -118,7 +118,13 @@ lstm_seq_fwd_kernel(const float *__restrict__ zx, const float *__restrict__ wh_p
 // HELPER adds one wave that computes the input projection b + x_{t+1} wx for ALL gate columns one step ahead (it does not
 // depend on h) and hands it over through a double-buffered LDS tile; the recurrence waves then start from that tile and issue
 // only the HID/4 x 4 recurrent MFMAs before their gate arithmetic.
-template <int HID, int KXS, bool HELPER>
+// SPLIT (with HELPER): the k range of the input projection is shared out so that the helper's SIMD is not the bottleneck -- two
+// forward kernels (actor and critic) share a CU, so both helpers sit on the same SIMD and at 12 column tiles x KXS MFMAs per step
+// each they alone set the step time (29-32 % MFMA busy overall).  The helper keeps all k-steps but one 16-element group; every
+// recurrence wave adds that group for its own columns (4 k-steps x 4 gates = 16 MFMAs, issued before the previous h is needed).
+// Whole 16-element groups of the input row travel as 16-byte vectors: lane (env, rq) holds elements 16 m + 4 rq + j and the
+// k-step (m, j) pairs them with the wx rows of the same index (a permutation of the k order inside the group: rounding only).
+template <int HID, int KXS, bool HELPER, bool SPLIT = false>
 __global__ void __launch_bounds__((HID / 16 + (HELPER ? 1 : 0)) * 64)
 lstm_seq_fwd_x_kernel(const float *__restrict__ x, const float *__restrict__ wx_p, const float *__restrict__ b_p,
                       const float *__restrict__ wh_p, const float *__restrict__ masks, const float *__restrict__ state0,
@@ -134,15 +140,21 @@ lstm_seq_fwd_x_kernel(const float *__restrict__ x, const float *__restrict__ wx_
   const int col = l & 15, rq = l >> 4;
   const int e0 = blockIdx.x * 16;
   const int u = 16 * w + col;
+  static_assert(!SPLIT || HELPER, "SPLIT shares the input projection between the helper and the recurrence waves");
+  constexpr int NG = SPLIT ? KXS / 4 : 0;      // whole 16-element groups of the input row, fetched as vectors (the host checks n_in >= 16 NG)
+  constexpr int GW = SPLIT ? NG - 1 : -1;      // the group the recurrence waves keep
+  // input element that k-step kk pairs with lane rq
+  auto elem = [&](int kk) { return kk < 4 * NG ? 16 * (kk / 4) + 4 * rq + (kk % 4) : 4 * kk + rq; };
   if (HELPER && w == NW) {
     // ---- helper wave: zx_t[env][c] = b[c] + sum_k x_t[env][k] wx[k][c] for every permuted gate column c, one step ahead ----
+    // (with SPLIT: over the k-steps outside group GW)
     float bxh[KXS][4 * NW], bias_h[4 * NW];
 #pragma unroll
     for (int ct = 0; ct < 4 * NW; ct++) {
       bias_h[ct] = b_p[16 * ct + col];
 #pragma unroll
       for (int kk = 0; kk < KXS; kk++) {
-        const int k = 4 * kk + rq;
+        const int k = elem(kk);
         bxh[kk][ct] = (k < n_in) ? wx_p[(size_t)k * HID * 4 + 16 * ct + col] : 0.0f;
       }
     }
@@ -150,7 +162,13 @@ lstm_seq_fwd_x_kernel(const float *__restrict__ x, const float *__restrict__ wx_
     auto fetch_h = [&](int t, float (&dst)[KXS]) {
       const float *row = x + ((size_t)t * N + e0 + col) * n_in;
 #pragma unroll
-      for (int kk = 0; kk < KXS; kk++) {
+      for (int m = 0; m < NG; m++) {
+        if (m == GW) continue;
+        const f32x4u v4 = *(const f32x4u *)&row[16 * m + 4 * rq];
+        dst[4 * m + 0] = v4[0]; dst[4 * m + 1] = v4[1]; dst[4 * m + 2] = v4[2]; dst[4 * m + 3] = v4[3];
+      }
+#pragma unroll
+      for (int kk = 4 * NG; kk < KXS; kk++) {
         const int k = 4 * kk + rq;
         dst[kk] = row[k < n_in ? k : n_in - 1];
       }
@@ -164,18 +182,20 @@ lstm_seq_fwd_x_kernel(const float *__restrict__ x, const float *__restrict__ wx_
         for (int ct = 0; ct < 4 * NW; ct++) {
           f32x4 acc = (f32x4){bias_h[ct], bias_h[ct], bias_h[ct], bias_h[ct]};
 #pragma unroll
-          for (int kk = 0; kk < KXS; kk++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xh[kk], bxh[kk][ct], acc, 0, 0, 0);
+          for (int kk = 0; kk < KXS; kk++)
+            if (kk / 4 != GW || kk >= 4 * NG) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xh[kk], bxh[kk][ct], acc, 0, 0, 0);
 #pragma unroll
           for (int j = 0; j < 4; j++) zb[(4 * rq + j) * LDZX + 16 * ct + col] = acc[j];
         }
 #pragma unroll
-        for (int kk = 0; kk < KXS; kk++) xh[kk] = xhn[kk];
+        for (int kk = 0; kk < KXS; kk++)
+          if (kk / 4 != GW || kk >= 4 * NG) xh[kk] = xhn[kk];
       }
       __syncthreads();
     }
     return;
   }
-  float bw[KS][4], bx[HELPER ? 1 : KXS][4];
+  float bw[KS][4], bx[HELPER ? (SPLIT ? 4 : 1) : KXS][4];
 #pragma unroll
   for (int kk = 0; kk < KS; kk++)
 #pragma unroll
@@ -188,6 +208,15 @@ lstm_seq_fwd_x_kernel(const float *__restrict__ x, const float *__restrict__ wx_
       for (int g = 0; g < 4; g++) bx[kk][g] = (k < n_in) ? wx_p[((size_t)k * HID + u) * 4 + g] : 0.0f;
     }
   }
+  if (SPLIT) {   // this wave's share of the input projection: group GW against its own 16 units x 4 gates
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) bx[j][g] = wx_p[((size_t)(16 * GW + 4 * rq + j) * HID + u) * 4 + g];
+  }
+  f32x4 xw = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}, xwn = xw;
+  auto fetch_w = [&](int t) -> f32x4 { return *(const f32x4u *)&x[((size_t)t * N + e0 + col) * n_in + 16 * (GW < 0 ? 0 : GW) + 4 * rq]; };
+  if (SPLIT) xw = fetch_w(0);
   const f32x4 bias = *(const f32x4 *)&b_p[u * 4];
   float c[4], hlast[4];
 #pragma unroll
@@ -216,6 +245,7 @@ lstm_seq_fwd_x_kernel(const float *__restrict__ x, const float *__restrict__ wx_
   for (int t = 0; t < T; t++) {
     const int tn = (t + 1 < T) ? t + 1 : t;
     if (!HELPER) fetch_x(tn, xn);
+    if (SPLIT) xwn = fetch_w(tn);
     const float keepA = 1.0f - mA_cur;
     float keepC[4];
 #pragma unroll
@@ -233,6 +263,12 @@ lstm_seq_fwd_x_kernel(const float *__restrict__ x, const float *__restrict__ wx_
       for (int j = 0; j < 4; j++) zr[j] = *(const f32x4 *)&zb[(4 * rq + j) * LDZX + 4 * u];
 #pragma unroll
       for (int g = 0; g < 4; g++) acc[g] = (f32x4){zr[0][g], zr[1][g], zr[2][g], zr[3][g]};
+      if (SPLIT) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xw[j], bx[j][g], acc[g], 0, 0, 0);
+      }
     } else {
 #pragma unroll
       for (int g = 0; g < 4; g++) acc[g] = (f32x4){bias[g], bias[g], bias[g], bias[g]};
@@ -265,6 +301,7 @@ lstm_seq_fwd_x_kernel(const float *__restrict__ x, const float *__restrict__ wx_
     }
 #pragma unroll
     for (int kk = 0; kk < KXS; kk++) xa[kk] = xn[kk];
+    xw = xwn;
 #pragma unroll
     for (int j = 0; j < 4; j++) mC_cur[j] = mC_next[j];
     mA_cur = mA_next;
@@ -960,9 +997,14 @@ int irrl_lstm_seq_forward_x(int hid, int T, int N, int n_in, const float *x, con
   const int kxs = (n_in + 3) / 4;
   // HID = 32 / 48: one extra wave computes the input projection one step ahead (IRRL_LSTM_FWD_HELPER=0: plain kernel, for A/B runs)
   static const bool fhelper = [] { const char *e = getenv("IRRL_LSTM_FWD_HELPER"); return !(e && e[0] == '0'); }();
+  // the input projection shared between the helper and the recurrence waves (IRRL_LSTM_FWD_SPLIT=0: helper alone, for A/B runs);
+  // needs every vectorised 16-element group inside the row
+  static const bool fsplit = [] { const char *e = getenv("IRRL_LSTM_FWD_SPLIT"); return !(e && e[0] == '0'); }();
+  const bool split = fsplit && n_in >= 16 * (kxs <= 9 ? 2 : 3);
 #define IRRL_FX(H, K) \
   do { \
-    if (fhelper && H <= 48) hipLaunchKernelGGL((lstm_seq_fwd_x_kernel<H, K, true>), dim3(N / 16), dim3((H / 16 + 1) * 64), 0, s, x, wx_p, b_p, wh_p, masks, state0, gates, cseq, hseq, state_out, T, N, n_in); \
+    if (fhelper && H <= 48 && split) hipLaunchKernelGGL((lstm_seq_fwd_x_kernel<H, K, true, true>), dim3(N / 16), dim3((H / 16 + 1) * 64), 0, s, x, wx_p, b_p, wh_p, masks, state0, gates, cseq, hseq, state_out, T, N, n_in); \
+    else if (fhelper && H <= 48) hipLaunchKernelGGL((lstm_seq_fwd_x_kernel<H, K, true>), dim3(N / 16), dim3((H / 16 + 1) * 64), 0, s, x, wx_p, b_p, wh_p, masks, state0, gates, cseq, hseq, state_out, T, N, n_in); \
     else hipLaunchKernelGGL((lstm_seq_fwd_x_kernel<H, K, false>), dim3(N / 16), dim3(H / 16 * 64), 0, s, x, wx_p, b_p, wh_p, masks, state0, gates, cseq, hseq, state_out, T, N, n_in); \
   } while (0)
   if (hid == 48 && kxs <= 9) IRRL_FX(48, 9);
