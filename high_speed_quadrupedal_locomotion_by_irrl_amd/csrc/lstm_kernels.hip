@@ -426,7 +426,10 @@ lstm_seq_bwd_kernel(const float *__restrict__ gates, const float *__restrict__ c
 #ifndef IRRL_BWD_MIN_WAVES
 #define IRRL_BWD_MIN_WAVES 1   /* waves per SIMD the backward kernel is compiled for (2: two workgroups -- both stacks -- share a CU) */
 #endif
-template <int HID, bool NEED_DX, bool HELPER>
+// HX (with HELPER): input M-tiles of the dwx accumulation that the helper takes over as well (the last HX of the MX = 3), 16 MFMAs
+// per tile and step off every recurrence wave -- they are the critical path (their MFMAs and their gate arithmetic do not
+// overlap), the helper's SIMD has room: 144 + 48 HX MFMAs per step against 144 - 16 HX (96 - 16 HX without dx) plus ~3 k cycles.
+template <int HID, bool NEED_DX, bool HELPER, int HX = 0>
 __global__ void __launch_bounds__((HID / 16 + (HELPER ? 1 : 0)) * 64, IRRL_BWD_MIN_WAVES)
 lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__ cseq, const float *__restrict__ hseq,
                       const float *__restrict__ x, const float *__restrict__ masks, const float *__restrict__ state0,
@@ -439,6 +442,8 @@ lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__
   // recurrence waves are the critical path)
   constexpr int HM = HELPER ? 0 : NW;
   constexpr int MX = 3;                       // input M-tiles (n_in <= 48)
+  static_assert(HX >= 0 && HX <= MX && (HX == 0 || HELPER), "HX: dwx M-tiles accumulated by the helper wave");
+  constexpr int MXW = MX - HX;                // dwx M-tiles the recurrence waves accumulate (for their own 64 gate columns)
   constexpr int XPW = (MX + NW - 1) / NW;     // input tiles staged / reduced per wave
   constexpr int LDZ = 64 + 4;
   constexpr int LDH = HID + 1;
@@ -454,20 +459,27 @@ lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__
   const int u = 16 * w + col;
   if (HELPER && w == NW) {
     // ---- helper wave: dwh[k][c] += sum_env hprev[env][k] dz[env][c] for every column c, one step behind the barrier ----
-    f32x4 accH[NW][4 * NW];
+    f32x4 accH[NW][4 * NW], accXh[HX > 0 ? HX : 1][4 * NW];
 #pragma unroll
     for (int mt = HM; mt < NW; mt++)
 #pragma unroll
       for (int ct = 0; ct < 4 * NW; ct++) accH[mt][ct] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int q = 0; q < HX; q++)
+#pragma unroll
+      for (int ct = 0; ct < 4 * NW; ct++) accXh[q][ct] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     int pbh = 0;
     for (int t = T - 1; t >= 0; t--) {
       __syncthreads();   // the recurrence waves have published dz_t and h_prev_t in buffers [pbh]
       const float *hpp = hpbuf[pbh];
+      const float *xbh = xbuf[pbh];
 #pragma unroll
       for (int sk = 0; sk < 4; sk++) {
-        float ah[NW];
+        float ah[NW], axh[HX > 0 ? HX : 1];
 #pragma unroll
         for (int mt = HM; mt < NW; mt++) ah[mt] = hpp[(4 * sk + rq) * LDH + 16 * mt + col];
+#pragma unroll
+        for (int q = 0; q < HX; q++) axh[q] = xbh[(4 * sk + rq) * LDX + 16 * (MXW + q) + col];
 #pragma unroll
         for (int ws = 0; ws < NW; ws++)
 #pragma unroll
@@ -475,6 +487,8 @@ lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__
             const float bz = dzbuf[HELPER ? pbh : 0][ws][(4 * sk + rq) * LDZ + 16 * nt + col];
 #pragma unroll
             for (int mt = HM; mt < NW; mt++) accH[mt][4 * ws + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[mt], bz, accH[mt][4 * ws + nt], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < HX; q++) accXh[q][4 * ws + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(axh[q], bz, accXh[q][4 * ws + nt], 0, 0, 0);
           }
       }
       pbh ^= 1;
@@ -486,6 +500,15 @@ lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__
       for (int r = 0; r < 4; r++)
 #pragma unroll
         for (int mt = HM; mt < NW; mt++) dwh_part[(blk * HID + 16 * mt + 4 * rq + r) * (4 * HID) + 16 * ct + col] = accH[mt][ct][r];
+#pragma unroll
+    for (int q = 0; q < HX; q++)
+#pragma unroll
+      for (int ct = 0; ct < 4 * NW; ct++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int i = 16 * (MXW + q) + 4 * rq + r;
+          if (i < n_in) dwx_part[(blk * n_in + i) * (4 * HID) + 16 * ct + col] = accXh[q][ct][r];
+        }
     return;
   }
   // B fragments (K = this wave's 64 permuted gate columns): dh_prev tiles over the hidden index, dx tiles over the input
@@ -504,13 +527,13 @@ lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__
         bX[kk][nx] = (i < n_in) ? wx_p[(size_t)i * HID * 4 + 64 * w + 4 * kk + rq] : 0.0f;
       }
   }
-  f32x4 accWh[NW][4], accWx[MX][4];
+  f32x4 accWh[NW][4], accWx[MXW > 0 ? MXW : 1][4];
 #pragma unroll
   for (int nt = 0; nt < 4; nt++) {
 #pragma unroll
     for (int mt = 0; mt < NW; mt++) accWh[mt][nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int mx = 0; mx < MX; mx++) accWx[mx][nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    for (int mx = 0; mx < MXW; mx++) accWx[mx][nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
   }
   float dbacc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   float dc[4] = {0.0f, 0.0f, 0.0f, 0.0f}, dhrec[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -626,13 +649,13 @@ lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__
 #pragma unroll
       for (int mt = 0; mt < HM; mt++) ah[mt] = hp[(4 * sk + rq) * LDH + 16 * mt + col];
 #pragma unroll
-      for (int mx = 0; mx < MX; mx++) ax[mx] = xb[(4 * sk + rq) * LDX + 16 * mx + col];
+      for (int mx = 0; mx < MXW; mx++) ax[mx] = xb[(4 * sk + rq) * LDX + 16 * mx + col];
 #pragma unroll
       for (int nt = 0; nt < 4; nt++) {
 #pragma unroll
         for (int mt = 0; mt < HM; mt++) accWh[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[mt], bz[nt], accWh[mt][nt], 0, 0, 0);
 #pragma unroll
-        for (int mx = 0; mx < MX; mx++) accWx[mx][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[mx], bz[nt], accWx[mx][nt], 0, 0, 0);
+        for (int mx = 0; mx < MXW; mx++) accWx[mx][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[mx], bz[nt], accWx[mx][nt], 0, 0, 0);
       }
     }
     pb ^= 1;
@@ -647,7 +670,7 @@ lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__
 #pragma unroll
       for (int mt = 0; mt < HM; mt++) dwh_part[(blk * HID + 16 * mt + 4 * rq + r) * (4 * HID) + c] = accWh[mt][nt][r];
 #pragma unroll
-      for (int mx = 0; mx < MX; mx++) {
+      for (int mx = 0; mx < MXW; mx++) {
         const int i = 16 * mx + 4 * rq + r;
         if (i < n_in) dwx_part[(blk * n_in + i) * (4 * HID) + c] = accWx[mx][nt][r];
       }
@@ -1078,9 +1101,17 @@ int irrl_lstm_seq_backward_x(int hid, int T, int N, int n_in, const float *gates
   hipStream_t s = (hipStream_t)hip_stream;
   // HID = 32 / 48: one extra wave for the dwh accumulation (IRRL_LSTM_BWD_HELPER=0 selects the plain kernel for A/B runs)
   static const bool helper = [] { const char *e = getenv("IRRL_LSTM_BWD_HELPER"); return !(e && e[0] == '0'); }();
+  // the helper can also accumulate dwx M-tiles (template HX).  IRRL_LSTM_BWD_SHARE = "<with dx><without dx>" tiles, e.g. 21, 10, 01.
+  // default 10 (one tile, in the kernel that also carries dx): PPO update 166.5 -> 163.6 ms; 20: 165.2, 01: 172.3, 11: 170.7, 02: 183.2
+  // (profiles/r02_ab_bwd_helper_share.log) -- without dx the helper's SIMD is already the longer one
+  static const int share = [] { const char *e = getenv("IRRL_LSTM_BWD_SHARE"); return (e && e[0] && e[1]) ? (e[0] - '0') * 10 + (e[1] - '0') : 10; }();
+  const int hx = dx ? share / 10 : share % 10;
+#define IRRL_BXH(H, D, X) hipLaunchKernelGGL((lstm_seq_bwd_x_kernel<H, D, true, X>), dim3(N / 16), dim3((H / 16 + 1) * 64), 0, s, gates, cseq, hseq, x, masks, state0, dh_in, wh_p, wx_p, dx, dwx_part, dwh_part, db_part, T, N, n_in)
 #define IRRL_BX(H, D) \
   do { \
-    if (helper && H <= 48) hipLaunchKernelGGL((lstm_seq_bwd_x_kernel<H, D, true>), dim3(N / 16), dim3((H / 16 + 1) * 64), 0, s, gates, cseq, hseq, x, masks, state0, dh_in, wh_p, wx_p, dx, dwx_part, dwh_part, db_part, T, N, n_in); \
+    if (helper && H <= 48 && hx == 1) IRRL_BXH(H, D, 1); \
+    else if (helper && H <= 48 && hx == 2) IRRL_BXH(H, D, 2); \
+    else if (helper && H <= 48) hipLaunchKernelGGL((lstm_seq_bwd_x_kernel<H, D, true>), dim3(N / 16), dim3((H / 16 + 1) * 64), 0, s, gates, cseq, hseq, x, masks, state0, dh_in, wh_p, wx_p, dx, dwx_part, dwh_part, db_part, T, N, n_in); \
     else hipLaunchKernelGGL((lstm_seq_bwd_x_kernel<H, D, false>), dim3(N / 16), dim3(H / 16 * 64), 0, s, gates, cseq, hseq, x, masks, state0, dh_in, wh_p, wx_p, dx, dwx_part, dwh_part, db_part, T, N, n_in); \
   } while (0)
   if (hid == 48 && dx) IRRL_BX(48, true);
