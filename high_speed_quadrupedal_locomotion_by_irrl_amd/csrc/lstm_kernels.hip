@@ -469,8 +469,17 @@ lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__
 #pragma unroll
       for (int ct = 0; ct < 4 * NW; ct++) accXh[q][ct] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     int pbh = 0;
+#ifdef IRRL_PROFILE_BWD   /* diagnostic build (tools/lstm_bwd_phases.py): where a step goes, summed over the T steps */
+    unsigned long long hw_wait = 0, hw_work = 0, hts = wall_clock64();
+#endif
     for (int t = T - 1; t >= 0; t--) {
+#ifdef IRRL_PROFILE_BWD
+      { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = wall_clock64(); hw_work += n_ - hts; hts = n_; __builtin_amdgcn_sched_barrier(0); }
+#endif
       __syncthreads();   // the recurrence waves have published dz_t and h_prev_t in buffers [pbh]
+#ifdef IRRL_PROFILE_BWD
+      { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = wall_clock64(); hw_wait += n_ - hts; hts = n_; __builtin_amdgcn_sched_barrier(0); }
+#endif
       const float *hpp = hpbuf[pbh];
       const float *xbh = xbuf[pbh];
 #pragma unroll
@@ -509,6 +518,9 @@ lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__
           const int i = 16 * (MXW + q) + 4 * rq + r;
           if (i < n_in) dwx_part[(blk * n_in + i) * (4 * HID) + 16 * ct + col] = accXh[q][ct][r];
         }
+#ifdef IRRL_PROFILE_BWD
+    if (blockIdx.x == gridDim.x / 2 && l == 0) { float *o_ = db_part + (size_t)gridDim.x * 16 * HID; o_[8] = (float)hw_wait; o_[9] = (float)hw_work; }   // one row behind the partials: the profiling caller allocates it
+#endif
     return;
   }
   // B fragments (K = this wave's 64 permuted gate columns): dh_prev tiles over the hidden index, dx tiles over the input
@@ -559,6 +571,12 @@ lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__
     }
   };
   fetch(T - 1);
+#ifdef IRRL_PROFILE_BWD
+  unsigned long long ph_[6] = {0, 0, 0, 0, 0, 0}, pts_ = wall_clock64();
+#define IRRL_BW_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = wall_clock64(); ph_[i] += n_ - pts_; pts_ = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define IRRL_BW_STAMP(i) do { } while (0)
+#endif
   for (int t = T - 1; t >= 0; t--) {
     float keepC[4];
     f32x4 dz4[4], g4[4];
@@ -590,6 +608,7 @@ lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    IRRL_BW_STAMP(0);   // staging of h_prev / x, prefetch issue, gate arithmetic, dz tile
     f32x4 acc[NW], accx[NEED_DX ? MX : 1];
 #pragma unroll
     for (int nt = 0; nt < NW; nt++) acc[nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
@@ -616,7 +635,9 @@ lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__
         for (int nx = 0; nx < MX; nx++) part[pb][w][(4 * rq + j) * LDP + HID + 16 * nx + col] = accx[nx][j];
       }
     }
+    IRRL_BW_STAMP(1);   // recurrence (+ dx) MFMAs, partials to LDS
     __syncthreads();   // partials of all waves, and this step's h_prev / x tiles, are now visible
+    IRRL_BW_STAMP(2);   // barrier
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       float sacc = 0.0f;
@@ -640,6 +661,7 @@ lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__
         }
       }
     }
+    IRRL_BW_STAMP(3);   // partial sums -> dh_prev, dx rows
     // weight-gradient accumulation: D[m][c] += sum_env A[m][env] B[env][c], env = 4s + rq
 #pragma unroll
     for (int sk = 0; sk < 4; sk++) {
@@ -658,8 +680,13 @@ lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__
         for (int mx = 0; mx < MXW; mx++) accWx[mx][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[mx], bz[nt], accWx[mx][nt], 0, 0, 0);
       }
     }
+    IRRL_BW_STAMP(4);   // weight-gradient MFMAs
     pb ^= 1;
   }
+#ifdef IRRL_PROFILE_BWD
+  if (blockIdx.x == gridDim.x / 2 && w == 0 && l == 0)
+    for (int i = 0; i < 5; i++) (db_part + (size_t)gridDim.x * 16 * HID)[i] = (float)ph_[i];
+#endif
   // per-workgroup partial gradients; C/D slot (row 4 rq + r, column col) of tile (m, nt) = (input / hidden index, gate column)
   const size_t blk = blockIdx.x;
 #pragma unroll
