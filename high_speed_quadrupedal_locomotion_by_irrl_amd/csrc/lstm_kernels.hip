@@ -174,6 +174,9 @@ lstm_seq_fwd_x_kernel(const float *__restrict__ x, const float *__restrict__ wx_
       }
     };
     fetch_h(0, xh);
+#ifdef IRRL_PROFILE_FWD   /* diagnostic build (tools/lstm_fwd_phases.py) */
+    unsigned long long hw_wait = 0, hw_work = 0, hts = wall_clock64();
+#endif
     for (int t = 0; t <= T; t++) {          // iteration t produces zx_t; the barrier at its end pairs with the recurrence waves'
       if (t < T) {
         if (t + 1 < T) fetch_h(t + 1, xhn);
@@ -191,8 +194,17 @@ lstm_seq_fwd_x_kernel(const float *__restrict__ x, const float *__restrict__ wx_
         for (int kk = 0; kk < KXS; kk++)
           if (kk / 4 != GW || kk >= 4 * NG) xh[kk] = xhn[kk];
       }
+#ifdef IRRL_PROFILE_FWD
+      { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = wall_clock64(); hw_work += n_ - hts; hts = n_; __builtin_amdgcn_sched_barrier(0); }
+#endif
       __syncthreads();
+#ifdef IRRL_PROFILE_FWD
+      { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = wall_clock64(); hw_wait += n_ - hts; hts = n_; __builtin_amdgcn_sched_barrier(0); }
+#endif
     }
+#ifdef IRRL_PROFILE_FWD
+    if (blockIdx.x == gridDim.x / 2 && l == 0) { float *o_ = state_out + (size_t)N * 2 * HID; o_[8] = (float)hw_wait; o_[9] = (float)hw_work; }   // one row behind the states: the profiling caller allocates it
+#endif
     return;
   }
   float bw[KS][4], bx[HELPER ? (SPLIT ? 4 : 1) : KXS][4];
@@ -242,6 +254,12 @@ lstm_seq_fwd_x_kernel(const float *__restrict__ x, const float *__restrict__ wx_
   for (int j = 0; j < 4; j++) mC_cur[j] = masks[e0 + 4 * rq + j];
   __syncthreads();
   int cur = 0;
+#ifdef IRRL_PROFILE_FWD
+  unsigned long long ph_[4] = {0, 0, 0, 0}, pts_ = wall_clock64();
+#define IRRL_FW_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = wall_clock64(); ph_[i] += n_ - pts_; pts_ = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define IRRL_FW_STAMP(i) do { } while (0)
+#endif
   for (int t = 0; t < T; t++) {
     const int tn = (t + 1 < T) ? t + 1 : t;
     if (!HELPER) fetch_x(tn, xn);
@@ -278,6 +296,7 @@ lstm_seq_fwd_x_kernel(const float *__restrict__ x, const float *__restrict__ wx_
 #pragma unroll
         for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kk], bx[kk][g], acc[g], 0, 0, 0);
     }
+    IRRL_FW_STAMP(0);   // prefetch issue, the helper's tile, this wave's share of the input projection
     const float *hb = hbuf[cur];
 #pragma unroll
     for (int kk = 0; kk < KS; kk++) {
@@ -285,6 +304,7 @@ lstm_seq_fwd_x_kernel(const float *__restrict__ x, const float *__restrict__ wx_
 #pragma unroll
       for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[kk][g], acc[g], 0, 0, 0);
     }
+    IRRL_FW_STAMP(1);   // recurrent MFMAs
     float *hn = hbuf[cur ^ 1];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -305,9 +325,15 @@ lstm_seq_fwd_x_kernel(const float *__restrict__ x, const float *__restrict__ wx_
 #pragma unroll
     for (int j = 0; j < 4; j++) mC_cur[j] = mC_next[j];
     mA_cur = mA_next;
+    IRRL_FW_STAMP(2);   // cell, stores, h to LDS
     __syncthreads();
+    IRRL_FW_STAMP(3);   // barrier
     cur ^= 1;
   }
+#ifdef IRRL_PROFILE_FWD
+  if (blockIdx.x == gridDim.x / 2 && w == 0 && l == 0)
+    for (int i = 0; i < 4; i++) (state_out + (size_t)N * 2 * HID)[i] = (float)ph_[i];
+#endif
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int e = e0 + 4 * rq + j;
