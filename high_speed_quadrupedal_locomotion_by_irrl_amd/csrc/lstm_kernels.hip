@@ -508,22 +508,32 @@ lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__
 #endif
       const float *hpp = hpbuf[pbh];
       const float *xbh = xbuf[pbh];
+      // all LDS operands of the step first, then the MFMAs back to back: an MFMA behind its own ds_read waits out the LDS latency,
+      // and a wave's VALU / LDS work never overlaps its MFMAs (tools/microbench/mfma_rate.hip), so every exposed read is lost time
+      float ah[4][NW], axh[4][HX > 0 ? HX : 1], bzv[4][NW][4];
 #pragma unroll
       for (int sk = 0; sk < 4; sk++) {
-        float ah[NW], axh[HX > 0 ? HX : 1];
 #pragma unroll
-        for (int mt = HM; mt < NW; mt++) ah[mt] = hpp[(4 * sk + rq) * LDH + 16 * mt + col];
+        for (int mt = HM; mt < NW; mt++) ah[sk][mt] = hpp[(4 * sk + rq) * LDH + 16 * mt + col];
 #pragma unroll
-        for (int q = 0; q < HX; q++) axh[q] = xbh[(4 * sk + rq) * LDX + 16 * (MXW + q) + col];
+        for (int q = 0; q < HX; q++) axh[sk][q] = xbh[(4 * sk + rq) * LDX + 16 * (MXW + q) + col];
+#pragma unroll
+        for (int ws = 0; ws < NW; ws++)
+#pragma unroll
+          for (int nt = 0; nt < 4; nt++) bzv[sk][ws][nt] = dzbuf[HELPER ? pbh : 0][ws][(4 * sk + rq) * LDZ + 16 * nt + col];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int sk = 0; sk < 4; sk++) {
 #pragma unroll
         for (int ws = 0; ws < NW; ws++)
 #pragma unroll
           for (int nt = 0; nt < 4; nt++) {
-            const float bz = dzbuf[HELPER ? pbh : 0][ws][(4 * sk + rq) * LDZ + 16 * nt + col];
+            const float bz = bzv[sk][ws][nt];
 #pragma unroll
-            for (int mt = HM; mt < NW; mt++) accH[mt][4 * ws + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[mt], bz, accH[mt][4 * ws + nt], 0, 0, 0);
+            for (int mt = HM; mt < NW; mt++) accH[mt][4 * ws + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[sk][mt], bz, accH[mt][4 * ws + nt], 0, 0, 0);
 #pragma unroll
-            for (int q = 0; q < HX; q++) accXh[q][4 * ws + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(axh[q], bz, accXh[q][4 * ws + nt], 0, 0, 0);
+            for (int q = 0; q < HX; q++) accXh[q][4 * ws + nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(axh[sk][q], bz, accXh[q][4 * ws + nt], 0, 0, 0);
           }
       }
       pbh ^= 1;
@@ -642,9 +652,13 @@ lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__
 #pragma unroll
       for (int nx = 0; nx < MX; nx++) accx[nx] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     }
+    float av[16];
+#pragma unroll
+    for (int kk = 0; kk < 16; kk++) av[kk] = dzbuf[HELPER ? pb : 0][w][col * LDZ + 4 * kk + rq];  // A[i = env col][k = 4kk + rq]
+    __builtin_amdgcn_sched_barrier(0);   // the 16 reads stay in front of the MFMAs (see the helper)
 #pragma unroll
     for (int kk = 0; kk < 16; kk++) {
-      const float a = dzbuf[HELPER ? pb : 0][w][col * LDZ + 4 * kk + rq];  // A[i = env col][k = 4kk + rq]
+      const float a = av[kk];
 #pragma unroll
       for (int nt = 0; nt < NW; nt++) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bT[kk][nt], acc[nt], 0, 0, 0);
       if (NEED_DX) {
@@ -689,21 +703,25 @@ lstm_seq_bwd_x_kernel(const float *__restrict__ gates, const float *__restrict__
     }
     IRRL_BW_STAMP(3);   // partial sums -> dh_prev, dx rows
     // weight-gradient accumulation: D[m][c] += sum_env A[m][env] B[env][c], env = 4s + rq
+    float bz[4][4], ah[4][NW], ax[4][MX];
 #pragma unroll
     for (int sk = 0; sk < 4; sk++) {
-      float bz[4], ah[NW], ax[MX];
 #pragma unroll
-      for (int nt = 0; nt < 4; nt++) bz[nt] = dzbuf[HELPER ? pb : 0][w][(4 * sk + rq) * LDZ + 16 * nt + col];
+      for (int nt = 0; nt < 4; nt++) bz[sk][nt] = dzbuf[HELPER ? pb : 0][w][(4 * sk + rq) * LDZ + 16 * nt + col];
 #pragma unroll
-      for (int mt = 0; mt < HM; mt++) ah[mt] = hp[(4 * sk + rq) * LDH + 16 * mt + col];
+      for (int mt = 0; mt < HM; mt++) ah[sk][mt] = hp[(4 * sk + rq) * LDH + 16 * mt + col];
 #pragma unroll
-      for (int mx = 0; mx < MXW; mx++) ax[mx] = xb[(4 * sk + rq) * LDX + 16 * mx + col];
+      for (int mx = 0; mx < MXW; mx++) ax[sk][mx] = xb[(4 * sk + rq) * LDX + 16 * mx + col];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int sk = 0; sk < 4; sk++) {
 #pragma unroll
       for (int nt = 0; nt < 4; nt++) {
 #pragma unroll
-        for (int mt = 0; mt < HM; mt++) accWh[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[mt], bz[nt], accWh[mt][nt], 0, 0, 0);
+        for (int mt = 0; mt < HM; mt++) accWh[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[sk][mt], bz[sk][nt], accWh[mt][nt], 0, 0, 0);
 #pragma unroll
-        for (int mx = 0; mx < MXW; mx++) accWx[mx][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[mx], bz[nt], accWx[mx][nt], 0, 0, 0);
+        for (int mx = 0; mx < MXW; mx++) accWx[mx][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[sk][mx], bz[sk][nt], accWx[mx][nt], 0, 0, 0);
       }
     }
     IRRL_BW_STAMP(4);   // weight-gradient MFMAs
