@@ -177,22 +177,22 @@ lstm_seq_fwd_x_kernel(const float *__restrict__ x, const float *__restrict__ wx_
 #ifdef IRRL_PROFILE_FWD   /* diagnostic build (tools/lstm_fwd_phases.py) */
     unsigned long long hw_wait = 0, hw_work = 0, hts = wall_clock64();
 #endif
-    for (int t = 0; t <= T; t++) {          // iteration t produces zx_t; the barrier at its end pairs with the recurrence waves'
+    // two steps per trip, the x registers used alternately: copying xhn to xh at the end of a step would make the helper wait, in
+    // the SAME step, for the load it issued at its start (~1 us of exposed HBM latency per step: it was at work for 2.1 us with 0.8 us
+    // of MFMAs); now the load of step t + 1 is first touched one whole step after it was issued
+    auto helper_step = [&](int t, float (&xc)[KXS], float (&xn_)[KXS]) {   // iteration t produces zx_t; its barrier pairs with the recurrence waves'
       if (t < T) {
-        if (t + 1 < T) fetch_h(t + 1, xhn);
+        if (t + 1 < T) fetch_h(t + 1, xn_);
         float *zb = zxbuf[t & 1];
 #pragma unroll
         for (int ct = 0; ct < 4 * NW; ct++) {
           f32x4 acc = (f32x4){bias_h[ct], bias_h[ct], bias_h[ct], bias_h[ct]};
 #pragma unroll
           for (int kk = 0; kk < KXS; kk++)
-            if (kk / 4 != GW || kk >= 4 * NG) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xh[kk], bxh[kk][ct], acc, 0, 0, 0);
+            if (kk / 4 != GW || kk >= 4 * NG) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[kk], bxh[kk][ct], acc, 0, 0, 0);
 #pragma unroll
           for (int j = 0; j < 4; j++) zb[(4 * rq + j) * LDZX + 16 * ct + col] = acc[j];
         }
-#pragma unroll
-        for (int kk = 0; kk < KXS; kk++)
-          if (kk / 4 != GW || kk >= 4 * NG) xh[kk] = xhn[kk];
       }
 #ifdef IRRL_PROFILE_FWD
       { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = wall_clock64(); hw_work += n_ - hts; hts = n_; __builtin_amdgcn_sched_barrier(0); }
@@ -201,6 +201,10 @@ lstm_seq_fwd_x_kernel(const float *__restrict__ x, const float *__restrict__ wx_
 #ifdef IRRL_PROFILE_FWD
       { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = wall_clock64(); hw_wait += n_ - hts; hts = n_; __builtin_amdgcn_sched_barrier(0); }
 #endif
+    };
+    for (int t = 0; t <= T; t += 2) {
+      helper_step(t, xh, xhn);
+      if (t + 1 <= T) helper_step(t + 1, xhn, xh);
     }
 #ifdef IRRL_PROFILE_FWD
     if (blockIdx.x == gridDim.x / 2 && l == 0) { float *o_ = state_out + (size_t)N * 2 * HID; o_[8] = (float)hw_wait; o_[9] = (float)hw_work; }   // one row behind the states: the profiling caller allocates it
@@ -226,7 +230,7 @@ lstm_seq_fwd_x_kernel(const float *__restrict__ x, const float *__restrict__ wx_
 #pragma unroll
       for (int g = 0; g < 4; g++) bx[j][g] = wx_p[((size_t)(16 * GW + 4 * rq + j) * HID + u) * 4 + g];
   }
-  f32x4 xw = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}, xwn = xw;
+  f32x4 xw = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
   auto fetch_w = [&](int t) -> f32x4 { return *(const f32x4u *)&x[((size_t)t * N + e0 + col) * n_in + 16 * (GW < 0 ? 0 : GW) + 4 * rq]; };
   if (SPLIT) xw = fetch_w(0);
   const f32x4 bias = *(const f32x4 *)&b_p[u * 4];
@@ -239,7 +243,6 @@ lstm_seq_fwd_x_kernel(const float *__restrict__ x, const float *__restrict__ wx_
     hbuf[0][(4 * rq + j) * LD + u] = hlast[j];
   }
   // A fragments of x_t: A[i = env col][k = 4kk + rq]; columns >= n_in are clamped (their B rows are zero)
-  float xa[KXS], xn[KXS];   // (unused with the helper wave)
   auto fetch_x = [&](int t, float (&dst)[KXS]) {
     const float *row = x + ((size_t)t * N + e0 + col) * n_in;
 #pragma unroll
@@ -248,30 +251,32 @@ lstm_seq_fwd_x_kernel(const float *__restrict__ x, const float *__restrict__ wx_
       dst[kk] = row[k < n_in ? k : n_in - 1];
     }
   };
-  if (!HELPER) fetch_x(0, xa);
-  float mA_cur = masks[e0 + col], mC_cur[4];
+  // per-step inputs fetched one step ahead; two sets used alternately (no register copy of a load that is still in flight, see the helper)
+  struct StepIn { float xa[KXS]; f32x4 xw; float mA, mC[4]; };
+  StepIn in0, in1;
+  if (!HELPER) fetch_x(0, in0.xa);
+  in0.xw = xw;
+  in0.mA = masks[e0 + col];
 #pragma unroll
-  for (int j = 0; j < 4; j++) mC_cur[j] = masks[e0 + 4 * rq + j];
+  for (int j = 0; j < 4; j++) in0.mC[j] = masks[e0 + 4 * rq + j];
   __syncthreads();
-  int cur = 0;
 #ifdef IRRL_PROFILE_FWD
   unsigned long long ph_[4] = {0, 0, 0, 0}, pts_ = wall_clock64();
 #define IRRL_FW_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = wall_clock64(); ph_[i] += n_ - pts_; pts_ = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define IRRL_FW_STAMP(i) do { } while (0)
 #endif
-  for (int t = 0; t < T; t++) {
+  auto rec_step = [&](int t, int cur, StepIn &ic, StepIn &inx) {
     const int tn = (t + 1 < T) ? t + 1 : t;
-    if (!HELPER) fetch_x(tn, xn);
-    if (SPLIT) xwn = fetch_w(tn);
-    const float keepA = 1.0f - mA_cur;
+    if (!HELPER) fetch_x(tn, inx.xa);
+    if (SPLIT) inx.xw = fetch_w(tn);
+    const float keepA = 1.0f - ic.mA;
     float keepC[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) keepC[j] = 1.0f - mC_cur[j];
-    const float mA_next = masks[(size_t)tn * N + e0 + col];
-    float mC_next[4];
+    for (int j = 0; j < 4; j++) keepC[j] = 1.0f - ic.mC[j];
+    inx.mA = masks[(size_t)tn * N + e0 + col];
 #pragma unroll
-    for (int j = 0; j < 4; j++) mC_next[j] = masks[(size_t)tn * N + e0 + 4 * rq + j];
+    for (int j = 0; j < 4; j++) inx.mC[j] = masks[(size_t)tn * N + e0 + 4 * rq + j];
     f32x4 acc[4];
     if (HELPER) {
       // b + x_t wx from the helper wave's tile (published before the barrier that ended the previous step)
@@ -285,7 +290,7 @@ lstm_seq_fwd_x_kernel(const float *__restrict__ x, const float *__restrict__ wx_
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
-          for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xw[j], bx[j][g], acc[g], 0, 0, 0);
+          for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ic.xw[j], bx[j][g], acc[g], 0, 0, 0);
       }
     } else {
 #pragma unroll
@@ -294,7 +299,7 @@ lstm_seq_fwd_x_kernel(const float *__restrict__ x, const float *__restrict__ wx_
 #pragma unroll
       for (int kk = 0; kk < KXS; kk++)
 #pragma unroll
-        for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[kk], bx[kk][g], acc[g], 0, 0, 0);
+        for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ic.xa[kk], bx[kk][g], acc[g], 0, 0, 0);
     }
     IRRL_FW_STAMP(0);   // prefetch issue, the helper's tile, this wave's share of the input projection
     const float *hb = hbuf[cur];
@@ -319,16 +324,13 @@ lstm_seq_fwd_x_kernel(const float *__restrict__ x, const float *__restrict__ wx_
       hseq[row * HID + u] = hn_;
       hn[(4 * rq + j) * LD + u] = hn_;
     }
-#pragma unroll
-    for (int kk = 0; kk < KXS; kk++) xa[kk] = xn[kk];
-    xw = xwn;
-#pragma unroll
-    for (int j = 0; j < 4; j++) mC_cur[j] = mC_next[j];
-    mA_cur = mA_next;
     IRRL_FW_STAMP(2);   // cell, stores, h to LDS
     __syncthreads();
     IRRL_FW_STAMP(3);   // barrier
-    cur ^= 1;
+  };
+  for (int t = 0; t < T; t += 2) {
+    rec_step(t, 0, in0, in1);
+    if (t + 1 < T) rec_step(t + 1, 1, in1, in0);
   }
 #ifdef IRRL_PROFILE_FWD
   if (blockIdx.x == gridDim.x / 2 && w == 0 && l == 0)
