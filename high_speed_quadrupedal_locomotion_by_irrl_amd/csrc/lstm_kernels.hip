@@ -303,11 +303,14 @@ lstm_seq_fwd_x_kernel(const float *__restrict__ x, const float *__restrict__ wx_
     }
     IRRL_FW_STAMP(0);   // prefetch issue, the helper's tile, this wave's share of the input projection
     const float *hb = hbuf[cur];
+    float hv[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; kk++) hv[kk] = hb[col * LD + 4 * kk + rq] * keepA;
+    __builtin_amdgcn_sched_barrier(0);   // all LDS reads of h in front of the MFMAs (a read behind an MFMA is exposed latency)
 #pragma unroll
     for (int kk = 0; kk < KS; kk++) {
-      const float a = hb[col * LD + 4 * kk + rq] * keepA;
 #pragma unroll
-      for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[kk][g], acc[g], 0, 0, 0);
+      for (int g = 0; g < 4; g++) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[kk], bw[kk][g], acc[g], 0, 0, 0);
     }
     IRRL_FW_STAMP(1);   // recurrent MFMAs
     float *hn = hbuf[cur ^ 1];
