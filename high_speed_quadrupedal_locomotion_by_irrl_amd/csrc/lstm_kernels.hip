@@ -916,7 +916,14 @@ irrl_ppo_heads_loss_kernel(size_t M, const float *__restrict__ h_pi, const float
   __shared__ f32x4 Wl[H][A / 4];      // pi head weights, [unit][action]
   __shared__ float wv[H];
   __shared__ float dm[4][64][17];     // per wave: rows (d_mean[0..11], d_v, 0, 0, 0) of the current 64-sample tile (+1 pad)
-  __shared__ float red[4][P];
+  // per wave: the current 64-row tile of ONE latent matrix (h_v, then h_pi), filled by coalesced 16-byte loads (a tile is 12 KiB of
+  // contiguous memory), read back row-per-lane for the head and as the MFMA A operand, overwritten with the row gradients and
+  // written out in whole lines.  (Row-per-lane global accesses touch 64 cache lines per instruction and use 16 bytes of each; with
+  // 8 waves per CU the 24 KiB a wave works on did not survive in L1 between its visits, and the MFMA operands were read a third time.)
+  constexpr int TLD = H + 4;          // 52: 16-byte aligned rows; 13 l + q is a bijection mod 16 for the row-per-lane 16-byte accesses
+  __shared__ __attribute__((aligned(16))) float tile[4][64 * TLD];
+  static_assert(P <= 64 * TLD, "the reduction scratch reuses the tiles");
+  float (*red)[64 * TLD] = tile;      // [wave][P] partial sums, written after the last tile (behind a barrier)
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, col = l & 15, rq = l >> 4;
   for (int i = tid; i < H * A; i += 256) ((float *)Wl)[i] = pi_w[i];
   if (tid < H) wv[tid] = vf_w[tid];
@@ -935,19 +942,86 @@ irrl_ppo_heads_loss_kernel(size_t M, const float *__restrict__ h_pi, const float
   for (int a = A + 1; a < 17; a++) dm[w][l][a] = 0.0f;   // padding columns stay zero
   __syncthreads();
   const size_t n_tiles = (M + 63) / 64;
-  for (size_t tile = (size_t)blockIdx.x * 4 + w; tile < n_tiles; tile += (size_t)gridDim.x * 4) {
-    const size_t r0 = tile * 64;
+  float *tl = tile[w];
+  for (size_t tile_i = (size_t)blockIdx.x * 4 + w; tile_i < n_tiles; tile_i += (size_t)gridDim.x * 4) {
+    const size_t r0 = tile_i * 64;
     const size_t r = r0 + l;
     const bool ok = r < M;
     const size_t rc = ok ? r : M - 1;
-    // ---- this lane's sample: heads forward, four latent units per iteration (weights broadcast from LDS) ----
-    const f32x4 *php = (const f32x4 *)(h_pi + rc * H), *phv = (const f32x4 *)(h_v + rc * H);
-    float mean[A], v = bv;
+    const float live = ok ? 1.0f : 0.0f;
+    // coalesced fill of the wave's tile from matrix `src` (rows r0 .. r0 + 63, clamped at the end of the batch), and the reverse
+    auto fill = [&](const float *__restrict__ src) {
+#pragma unroll 4
+      for (int i = 0; i < H * 64 / 256; i++) {
+        const int c = l + 64 * i;                     // 16-byte piece of the tile: row c / (H / 4), columns 4 (c % (H / 4)) ..
+        const int row = c / (H / 4), cq = c - row * (H / 4);
+        const size_t rr = r0 + row < M ? r0 + row : M - 1;
+        *(f32x4 *)&tl[row * TLD + 4 * cq] = *(const f32x4 *)&src[rr * H + 4 * cq];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto drain = [&](float *__restrict__ dst) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 4
+      for (int i = 0; i < H * 64 / 256; i++) {
+        const int c = l + 64 * i;
+        const int row = c / (H / 4), cq = c - row * (H / 4);
+        if (r0 + row < M) *(f32x4 *)&dst[(r0 + row) * H + 4 * cq] = *(const f32x4 *)&tl[row * TLD + 4 * cq];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    };
+    // one of the two weight-gradient products for the wave's 64 rows on the matrix cores: A[i = unit][k = row] from the staged tile,
+    // B[k = row][j] = the dm tile (columns 0 .. 11 = d_mean, column 12 = d_v)
+    auto grad_mfma = [&](f32x4 (&acc)[NT]) {
+#pragma unroll 2
+      for (int s4 = 0; s4 < 16; s4++) {
+        const float bb = dm[w][4 * s4 + rq][col];
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(tl[(4 * s4 + rq) * TLD + 16 * t + col], bb, acc[t], 0, 0, 0);
+      }
+    };
+    const float R = returns[rc], ov = old_values[rc], onlp = old_neglogp[rc];
+    // ================= value stack: v, d_v, d loss / d h_v = d_v w_v, d w_v += h_v^T d_v =================
+    fill(h_v);
+    float v = bv;
+#pragma unroll
+    for (int q = 0; q < H / 4; q++) {
+      const f32x4 y = *(const f32x4 *)&tl[l * TLD + 4 * q];
+#pragma unroll
+      for (int j = 0; j < 4; j++) v = __builtin_fmaf(y[j], wv[4 * q + j], v);
+    }
+    const float dv = v - ov;
+    const float vc = ov + fminf(fmaxf(dv, -cliprange), cliprange);
+    const float l1 = (v - R) * (v - R), l2 = (vc - R) * (vc - R);
+    const float g_clamp = (dv >= -cliprange && dv <= cliprange) ? 1.0f : 0.0f;
+    const float dvf = (l1 > l2) ? (v - R) : ((l1 < l2) ? (vc - R) * g_clamp : 0.5f * (v - R) + 0.5f * (vc - R) * g_clamp);
+    const float d_v = live * inv_m * vf_coef * dvf;
+    dm[w][l][A] = d_v;
+    sc[1] += live * 0.5f * fmaxf(l1, l2);
+    dbv += d_v;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    grad_mfma(dWv);                                   // (its columns other than 12 multiply the previous tile's d_mean: never read)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < H / 4; q++)
+      *(f32x4 *)&tl[l * TLD + 4 * q] = (f32x4){d_v * wv[4 * q], d_v * wv[4 * q + 1], d_v * wv[4 * q + 2], d_v * wv[4 * q + 3]};
+    drain(d_hv);
+    // ================= policy stack: mean, loss terms, d_mean, d loss / d h_pi = d_mean W_pi^T, dW_pi += h_pi^T d_mean =================
+    fill(h_pi);
+    float mean[A];
 #pragma unroll
     for (int a = 0; a < A; a++) mean[a] = pi_b[a];
 #pragma unroll 3
     for (int q = 0; q < H / 4; q++) {
-      const f32x4 x = php[q], y = phv[q];
+      const f32x4 x = *(const f32x4 *)&tl[l * TLD + 4 * q];
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const int k = 4 * q + j;
@@ -957,20 +1031,19 @@ irrl_ppo_heads_loss_kernel(size_t M, const float *__restrict__ h_pi, const float
           mean[4 * a4] = __builtin_fmaf(x[j], wk[0], mean[4 * a4]); mean[4 * a4 + 1] = __builtin_fmaf(x[j], wk[1], mean[4 * a4 + 1]);
           mean[4 * a4 + 2] = __builtin_fmaf(x[j], wk[2], mean[4 * a4 + 2]); mean[4 * a4 + 3] = __builtin_fmaf(x[j], wk[3], mean[4 * a4 + 3]);
         }
-        v = __builtin_fmaf(y[j], wv[k], v);
       }
     }
-    float act[A];
+    // ---- loss terms and row gradients (same arithmetic as irrl_ppo_loss_kernel) ----
+    float diff[A], q2 = 0.0f;
     {
       const f32x4 *pa = (const f32x4 *)(actions + rc * A);
 #pragma unroll
-      for (int q = 0; q < A / 4; q++) { const f32x4 x = pa[q]; act[4 * q] = x[0]; act[4 * q + 1] = x[1]; act[4 * q + 2] = x[2]; act[4 * q + 3] = x[3]; }
-    }
-    const float R = returns[rc], ov = old_values[rc], onlp = old_neglogp[rc];
-    // ---- loss terms and row gradients (same arithmetic as irrl_ppo_loss_kernel) ----
-    float diff[A], q2 = 0.0f;
+      for (int q = 0; q < A / 4; q++) {
+        const f32x4 x = pa[q];
 #pragma unroll
-    for (int a = 0; a < A; a++) { diff[a] = (act[a] - mean[a]) * sd_inv[a]; q2 += diff[a] * diff[a]; }
+        for (int j = 0; j < 4; j++) { const int a = 4 * q + j; diff[a] = (x[j] - mean[a]) * sd_inv[a]; q2 += diff[a] * diff[a]; }
+      }
+    }
     const float nlp = 0.5f * q2 + 0.918938533204672742f * (float)A + ls_sum;
     const float adv = (R - ov - a_mean) * a_istd;
     const float ratio = __expf(onlp - nlp);
@@ -978,14 +1051,7 @@ irrl_ppo_heads_loss_kernel(size_t M, const float *__restrict__ h_pi, const float
     const float pg1 = -adv * ratio, pg2 = -adv * rcl;
     const bool inside = (ratio >= 1.0f - cliprange) && (ratio <= 1.0f + cliprange);
     const float dpg_dratio = inside ? -adv : ((pg1 > pg2) ? -adv : ((pg1 == pg2) ? -0.5f * adv : 0.0f));
-    const float live = ok ? 1.0f : 0.0f;
     const float dl_dnlp = live * inv_m * dpg_dratio * (-ratio);
-    const float dv = v - ov;
-    const float vc = ov + fminf(fmaxf(dv, -cliprange), cliprange);
-    const float l1 = (v - R) * (v - R), l2 = (vc - R) * (vc - R);
-    const float g_clamp = (dv >= -cliprange && dv <= cliprange) ? 1.0f : 0.0f;
-    const float dvf = (l1 > l2) ? (v - R) : ((l1 < l2) ? (vc - R) * g_clamp : 0.5f * (v - R) + 0.5f * (vc - R) * g_clamp);
-    const float d_v = live * inv_m * vf_coef * dvf;
     float dmean[A];
 #pragma unroll
     for (int a = 0; a < A; a++) {
@@ -994,58 +1060,42 @@ irrl_ppo_heads_loss_kernel(size_t M, const float *__restrict__ h_pi, const float
       dbp[a] += dmean[a];
       dm[w][l][a] = dmean[a];
     }
-    dm[w][l][A] = d_v;
     sc[0] += live * fmaxf(pg1, pg2);
-    sc[1] += live * 0.5f * fmaxf(l1, l2);
     sc[2] += live * 0.5f * (nlp - onlp) * (nlp - onlp);
     sc[3] += (ok && fabsf(ratio - 1.0f) > cliprange) ? 1.0f : 0.0f;
-    dbv += d_v;
-    if (ok) {
-      if (mean_out) {
-        f32x4 *pm = (f32x4 *)(mean_out + r * A);
+    if (ok && mean_out) {
+      f32x4 *pm = (f32x4 *)(mean_out + r * A);
 #pragma unroll
-        for (int q = 0; q < A / 4; q++) pm[q] = (f32x4){mean[4 * q], mean[4 * q + 1], mean[4 * q + 2], mean[4 * q + 3]};
-        value_out[r] = v;
-      }
-      // d loss / d h_pi = d_mean W_pi^T, d loss / d h_v = d_v w_v
-      f32x4 *px = (f32x4 *)(d_hpi + r * H), *pv = (f32x4 *)(d_hv + r * H);
-#pragma unroll 3
-      for (int q = 0; q < H / 4; q++) {
-        f32x4 o, ovv;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int k = 4 * q + j;
-          float acc = 0.0f;
-#pragma unroll
-          for (int a4 = 0; a4 < A / 4; a4++) {
-            const f32x4 wk = Wl[k][a4];
-            acc = __builtin_fmaf(dmean[4 * a4], wk[0], acc); acc = __builtin_fmaf(dmean[4 * a4 + 1], wk[1], acc);
-            acc = __builtin_fmaf(dmean[4 * a4 + 2], wk[2], acc); acc = __builtin_fmaf(dmean[4 * a4 + 3], wk[3], acc);
-          }
-          o[j] = acc;
-          ovv[j] = d_v * wv[k];
-        }
-        px[q] = o;
-        pv[q] = ovv;
-      }
+      for (int q = 0; q < A / 4; q++) pm[q] = (f32x4){mean[4 * q], mean[4 * q + 1], mean[4 * q + 2], mean[4 * q + 3]};
+      value_out[r] = v;
     }
-    // ---- dW_pi += h_pi^T d_mean and d w_v += h_v^T d_v for the wave's 64 rows on the matrix cores ----
-    // A[i = unit][k = row] re-read from the (L1-resident) latent rows, B[k = row][j] = the LDS tile (column 12 = d_v).
-    // (the tile is private to the wave, whose lanes run in lockstep: no barrier between the writes above and these reads)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-#pragma unroll 2
-    for (int s4 = 0; s4 < 16; s4++) {
-      const size_t rr = r0 + 4 * s4 + rq;
-      const size_t rrc = rr < M ? rr : M - 1;
-      const float b = dm[w][4 * s4 + rq][col];
-#pragma unroll
-      for (int t = 0; t < NT; t++) {
-        dW[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(h_pi[rrc * H + 16 * t + col], b, dW[t], 0, 0, 0);
-        dWv[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(h_v[rrc * H + 16 * t + col], b, dWv[t], 0, 0, 0);
-      }
-    }
+    __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    grad_mfma(dW);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // d loss / d h_pi = d_mean W_pi^T: this lane's row into the tile, then out in whole lines
+#pragma unroll 3
+    for (int q = 0; q < H / 4; q++) {
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int k = 4 * q + j;
+        float acc = 0.0f;
+#pragma unroll
+        for (int a4 = 0; a4 < A / 4; a4++) {
+          const f32x4 wk = Wl[k][a4];
+          acc = __builtin_fmaf(dmean[4 * a4], wk[0], acc); acc = __builtin_fmaf(dmean[4 * a4 + 1], wk[1], acc);
+          acc = __builtin_fmaf(dmean[4 * a4 + 2], wk[2], acc); acc = __builtin_fmaf(dmean[4 * a4 + 3], wk[3], acc);
+        }
+        o[j] = acc;
+      }
+      *(f32x4 *)&tl[l * TLD + 4 * q] = o;
+    }
+    drain(d_hpi);
   }
+  __syncthreads();   // every wave is done with its tile: the tiles now hold the reduction scratch
   // ---- workgroup reduction: per-lane sums over the wave, then the four waves through LDS ----
   auto wave_sum = [](float x) {
 #pragma unroll
