@@ -598,6 +598,100 @@ IRRL_DEV v3 solve_contact(const ContactBlock &B, v3 c, v3 n, vf vstar, vf mu, vm
   return r;
 }
 
+// ---------------------------------------------------------------------------------------------
+// THE PUBLISHED PER-CONTACT RULE (ContactSolver bit 0; EnvParams::contact_rule): RaiSim -- world_->integrate(), ENV:768 -- resolves
+// contacts with the per-contact iteration of Hwangbo, Lee & Hutter (RA-L 2018): each single-contact problem solved EXACTLY under
+// Signorini, Coulomb and maximum dissipation --
+//   opening  (c.n >= v*): lam = 0;   sticking (lam_s = -G^-1 (c - v* n) pushes, inside the cone): lam = lam_s;
+//   slipping: the point of {cone boundary} x {v_n+ = v*} that minimises the post-impact kinetic energy
+//             h(lam) = 1/2 lam^T G lam + lam^T (c - v* n).
+// The paper bisects on the polar angle of that conic; here the same point comes from a 2x2 trust-region problem with ONE scalar
+// unknown:  contact frame (t1, t2, n); the normal condition eliminates lam_n = alpha + beta . x (alpha = -(c.n - v*) / G_nn,
+// beta = -G_tn / G_nn, x = tangential impulse), so h = 1/2 x^T A x + b^T x with A = G_tt - G_tn G_tn^T / G_nn, b = c_t + alpha G_tn,
+// free minimiser x* = -A^-1 b = the sticking impulse.  The cone section |x| <= mu (alpha + beta . x) is, in xi = x / alpha, the
+// FIXED ellipse (xi - xi_c)^T P (xi - xi_c) <= 1, P = (1 - mu^2 beta beta^T) s / mu^2, xi_c = mu^2 beta / s, s = 1 - mu^2 |beta|^2
+// (focus at the origin, eccentricity mu |beta|).  The A-metric projection of xi* onto it: (A + gamma P)(xi - xi_c) = A (xi* - xi_c),
+// gamma >= 0 from (xi - xi_c)^T P (xi - xi_c) = 1, i.e. p(gamma) / sqrt(r(gamma)) = sigma with p = det(A + gamma P), r a quadratic,
+// sigma = |xi* - xi_c| -- concave and increasing, so IRRL_MD_NEWTON Newton steps from gamma = 0 are monotone (3-4 reach f32).
+// Caps (not reached on the shipped configurations, mu |beta| <= 0.86 there): eccentricity above sqrt(1 - SMIN) (the conic turns
+// into a parabola / hyperbola at the jamming corner) -> beta shortened in the cone section; sigma > SIGMAX (a barely pressing
+// contact sliding fast, impulse ~1e-4 of a pressing one) -> far point pulled in; mu < MUMIN -> frictionless, lam = alpha n.
+// Everything that depends only on (G, n, mu) is per-substep (ContactBlockMD); the CPU restatement the parity tests compare with
+// runs the same steps with the same constants.
+// ---------------------------------------------------------------------------------------------
+#define IRRL_MD_NEWTON 4
+#define IRRL_MD_SMIN 0.04f
+#define IRRL_MD_SIGMAX 1.0e4f
+#define IRRL_MD_MUMIN 1.0e-6f
+struct ContactBlockMD { v3 t1, t2; vf mu, g1, g2, ignn, A11, A12, A22, be1, be2, detA, idetA, P11, P12, P22, detP, mix, zc1, zc2; };
+IRRL_DEV ContactBlockMD make_contact_block_md(sym3 G, v3 n, vf mu_in) {
+  ContactBlockMD B;
+  const vf mu = v_max(mu_in, IRRL_MD_MUMIN);
+  B.mu = mu;
+  // branch-free orthonormal frame around n (Duff et al. 2017)
+  const vf sg = vsel(n.z >= 0.0f, 1.0f, -1.0f);
+  const vf fa = -v_rcp(sg + n.z), fb = n.x * n.y * fa;
+  B.t1 = mk3(1.0f + sg * n.x * n.x * fa, sg * fb, -sg * n.x);
+  B.t2 = mk3(fb, sg + n.y * n.y * fa, -n.y);
+  const v3 Gt1 = mul(G, B.t1), Gt2 = mul(G, B.t2), Gn = mul(G, n);
+  B.g1 = dot(B.t1, Gn); B.g2 = dot(B.t2, Gn);
+  B.ignn = v_rcp(dot(n, Gn));
+  B.A11 = dot(B.t1, Gt1) - B.g1 * B.g1 * B.ignn; B.A12 = dot(B.t1, Gt2) - B.g1 * B.g2 * B.ignn; B.A22 = dot(B.t2, Gt2) - B.g2 * B.g2 * B.ignn;
+  B.be1 = -B.g1 * B.ignn; B.be2 = -B.g2 * B.ignn;
+  B.detA = B.A11 * B.A22 - B.A12 * B.A12;
+  B.idetA = v_rcp(B.detA);
+  const vf mb2 = mu * mu * (B.be1 * B.be1 + B.be2 * B.be2);
+  const vf shrink = vsel(mb2 <= 1.0f - IRRL_MD_SMIN, 1.0f, v_sqrt((1.0f - IRRL_MD_SMIN) * v_rcp(v_max(mb2, 1e-30f))));
+  const vf e1 = shrink * mu * B.be1, e2 = shrink * mu * B.be2;
+  const vf s = 1.0f - (e1 * e1 + e2 * e2), is = v_rcp(s), ims = s * v_rcp(mu * mu);
+  B.P11 = (1.0f - e1 * e1) * ims; B.P12 = -e1 * e2 * ims; B.P22 = (1.0f - e2 * e2) * ims;
+  B.detP = B.P11 * B.P22 - B.P12 * B.P12;
+  B.mix = B.A22 * B.P11 - 2.0f * B.A12 * B.P12 + B.A11 * B.P22;
+  B.zc1 = mu * e1 * is; B.zc2 = mu * e2 * is;
+  return B;
+}
+IRRL_DEV v3 solve_contact_md(const ContactBlockMD &B, v3 c, v3 n, vf vstar, vf mu_in) {
+  const vf cn = dot(c, n) - vstar;
+  const vm sep = cn >= 0.0f;
+  const vf alpha = -cn * B.ignn;
+  const vf b1 = dot(c, B.t1) + alpha * B.g1, b2 = dot(c, B.t2) + alpha * B.g2;
+  const vf x1 = -(B.A22 * b1 - B.A12 * b2) * B.idetA, x2 = -(B.A11 * b2 - B.A12 * b1) * B.idetA;
+  const vf ln = alpha + B.be1 * x1 + B.be2 * x2;
+  const vm sticking = (x1 * x1 + x2 * x2 <= B.mu * B.mu * ln * ln) & (ln > 0.0f);
+  // slipping
+  const vf ia = v_rcp(v_max(alpha, 1e-30f));
+  vf d1 = x1 * ia - B.zc1, d2 = x2 * ia - B.zc2;
+  const vf s2 = d1 * d1 + d2 * d2;
+  const vf isg = v_rsqrt(v_max(s2, 1e-30f));
+  const vf sig = v_min(s2 * isg, IRRL_MD_SIGMAX);
+  d1 = d1 * isg; d2 = d2 * isg;
+  const vf w1 = B.A11 * d1 + B.A12 * d2, w2 = B.A12 * d1 + B.A22 * d2;
+  const vf u1 = B.detA * d1, u2 = B.detA * d2;
+  const vf q1 = B.P22 * w1 - B.P12 * w2, q2 = B.P11 * w2 - B.P12 * w1;
+  const vf Pu1 = B.P11 * u1 + B.P12 * u2, Pu2 = B.P12 * u1 + B.P22 * u2, Pq1 = B.P11 * q1 + B.P12 * q2, Pq2 = B.P12 * q1 + B.P22 * q2;
+  const vf c0 = u1 * Pu1 + u2 * Pu2, c1 = 2.0f * (q1 * Pu1 + q2 * Pu2), c2 = q1 * Pq1 + q2 * Pq2;
+  vf gam = 0.0f;
+#pragma unroll
+  for (int it = 0; it < IRRL_MD_NEWTON; it++) {
+    const vf p = (B.detP * gam + B.mix) * gam + B.detA, r = (c2 * gam + c1) * gam + c0;
+    const vf dp = 2.0f * B.detP * gam + B.mix, dr = 2.0f * c2 * gam + c1;
+    gam += r * (sig * v_sqrt(r) - p) * v_rcp(dp * r - 0.5f * p * dr);
+  }
+  const vf kk = sig * v_rcp((B.detP * gam + B.mix) * gam + B.detA);
+  vf X1 = alpha * ((u1 + gam * q1) * kk + B.zc1), X2 = alpha * ((u2 + gam * q2) * kk + B.zc2);
+  const vm frictionless = mu_in <= IRRL_MD_MUMIN;
+  X1 = vsel(sticking, x1, vsel(frictionless, 0.0f, X1));
+  X2 = vsel(sticking, x2, vsel(frictionless, 0.0f, X2));
+  const vf lnn = vsel(sep, 0.0f, alpha + B.be1 * X1 + B.be2 * X2);   // normal velocity condition exact
+  X1 = vsel(sep, 0.0f, X1); X2 = vsel(sep, 0.0f, X2);
+  return mk3(X1 * B.t1.x + X2 * B.t2.x + lnn * n.x, X1 * B.t1.y + X2 * B.t2.y + lnn * n.y, X1 * B.t1.z + X2 * B.t2.z + lnn * n.z);
+}
+// a contact that is solved once (trunk-box corners, meteorite): block + solve in one go, by the pool's rule (wave-uniform)
+IRRL_DEV v3 solve_contact_once(const EnvParams &P, sym3 G, v3 c, v3 n, vf vstar, vf mu, vm relevant) {
+  if (P.contact_rule) return solve_contact_md(make_contact_block_md(G, n, mu), c, n, vstar, mu);
+  return solve_contact(make_contact_block(G, n), c, n, vstar, mu, relevant);
+}
+
 // height and unit normal of the ground below world point (x, y): bilinear cell of the shared height field
 IRRL_DEV void terrain_sample(const EnvParams &P, vf x, vf y, vf &h, v3 &n) {
   vf fx = (x - P.hf_x0) * P.hf_inv_dx, fy = (y - P.hf_y0) * P.hf_inv_dy;
@@ -648,7 +742,7 @@ struct BoxContacts {
   vi id[IRRL_NCPL];
   vm own[IRRL_NCPL];          // slot j of this lane holds an ACTIVE corner that this lane owns
   vf Y[IRRL_NCPL][3][6];      // rows of K L^-T, K = [1 | -[x]x]
-  ContactBlock CB[IRRL_NCPL];
+  sym3 G[IRRL_NCPL];          // the corner's own Delassus block
   v3 n[IRRL_NCPL], cfree[IRRL_NCPL];
   vf vstar[IRRL_NCPL];
   vf zc[6];                   // sum over the robot's corners of Y^T lambda (same value in all its lanes)
@@ -684,7 +778,7 @@ IRRL_DEV bool box_setup(const EnvParams &P, const EnvLane &L, const rot3 &R, con
 #pragma unroll
         for (int i = 0; i < 6; i++) B.Y[j][r][i] = 0.0f;
       sym3 I; I.xx = 1.0f; I.xy = 0.0f; I.xz = 0.0f; I.yy = 1.0f; I.yz = 0.0f; I.zz = 1.0f;
-      B.CB[j] = make_contact_block(I, B.n[j]);
+      B.G[j] = I;
       continue;
     }
     any = true;
@@ -709,7 +803,7 @@ IRRL_DEV bool box_setup(const EnvParams &P, const EnvLane &L, const rot3 &R, con
         g[r][c] = acc;
       }
     G.xx = g[0][0]; G.xy = g[0][1]; G.xz = g[0][2]; G.yy = g[1][1]; G.yz = g[1][2]; G.zz = g[2][2];
-    B.CB[j] = make_contact_block(G, B.n[j]);
+    B.G[j] = G;
     v3 vpre = vB + cross(wB, x);
     B.cfree[j] = mk3(ub[0], ub[1], ub[2]) + cross(mk3(ub[3], ub[4], ub[5]), x);
     vf vn = dot(vpre, B.n[j]);
@@ -722,14 +816,14 @@ IRRL_DEV bool box_setup(const EnvParams &P, const EnvLane &L, const rot3 &R, con
 // One corner of the pass (compile-time CB: its owner lane is a DPP broadcast source): the corner sees the velocity the toes and
 // the corners before it have produced, solves its single-contact problem exactly and is applied at once (B.zc advances).
 template <int CB>
-IRRL_DEV void box_corner_step(BoxContacts &B, vf mu) {
+IRRL_DEV void box_corner_step(const EnvParams &P, BoxContacts &B, vf mu) {
   constexpr int j = (IRRL_NCPL == 2) ? (CB & 1) : 0;
   const vm mine = B.own[j] & (B.id[j] == CB);
   if (!wave_any(mine)) return;
   v3 c = B.cfree[j];
 #pragma unroll
   for (int i = 0; i < 6; i++) { c.x += B.Y[j][0][i] * B.zc[i]; c.y += B.Y[j][1][i] * B.zc[i]; c.z += B.Y[j][2][i] * B.zc[i]; }
-  v3 ln = solve_contact(B.CB[j], c, B.n[j], B.vstar[j], mu, mine);
+  v3 ln = solve_contact_once(P, B.G[j], c, B.n[j], B.vstar[j], mu, mine);
   v3 dl = mk3(vsel(mine, ln.x, 0.0f), vsel(mine, ln.y, 0.0f), vsel(mine, ln.z, 0.0f));
   // zc += Y^T dl of the owner lane, broadcast to the robot's lanes
 #ifdef IRRL_L16
@@ -746,8 +840,8 @@ IRRL_DEV void box_corner_step(BoxContacts &B, vf mu) {
 IRRL_DEV bool box_pass(const EnvParams &P, const EnvLane &L, const rot3 &R, const vf L6[21], const vf ub[6], v3 vB, v3 wB, vf dxb[6]) {
   BoxContacts B;
   if (!box_setup(P, L, R, L6, ub, vB, wB, B)) return false;
-  box_corner_step<0>(B, L.m.mu); box_corner_step<1>(B, L.m.mu); box_corner_step<2>(B, L.m.mu); box_corner_step<3>(B, L.m.mu);
-  box_corner_step<4>(B, L.m.mu); box_corner_step<5>(B, L.m.mu); box_corner_step<6>(B, L.m.mu); box_corner_step<7>(B, L.m.mu);
+  box_corner_step<0>(P, B, L.m.mu); box_corner_step<1>(P, B, L.m.mu); box_corner_step<2>(P, B, L.m.mu); box_corner_step<3>(P, B, L.m.mu);
+  box_corner_step<4>(P, B, L.m.mu); box_corner_step<5>(P, B, L.m.mu); box_corner_step<6>(P, B, L.m.mu); box_corner_step<7>(P, B, L.m.mu);
 #pragma unroll
   for (int i = 0; i < 6; i++) dxb[i] = B.zc[i];
   l6_bwd(L6, dxb);
@@ -812,13 +906,12 @@ IRRL_DEV bool sphere_pass(const EnvParams &P, EnvLane &L, const rot3 &R, const v
       }
     sym3 G;
     G.xx = g[0][0] + ms_inv; G.xy = g[0][1]; G.xz = g[0][2]; G.yy = g[1][1] + ms_inv; G.yz = g[1][2]; G.zz = g[2][2] + ms_inv;
-    ContactBlock CB = make_contact_block(G, n);
     v3 svB = rot_tmul(R, L.sv), svB_pre = rot_tmul(R, sv_pre);
     v3 c = mk3(ub[0], ub[1], ub[2]) + cross(mk3(ub[3], ub[4], ub[5]), qB) - svB;
     v3 pre = vB + cross(wB, qB) - svB_pre;
     vf vn = dot(pre, n);
     vf vs = vsel(vn < -0.001f, -0.95f * vn, 0.0f);
-    v3 lam = solve_contact(CB, c, n, vs, 0.0f, hit);
+    v3 lam = solve_contact_once(P, G, c, n, vs, 0.0f, hit);
     lam = mk3(vsel(hit, lam.x, 0.0f), vsel(hit, lam.y, 0.0f), vsel(hit, lam.z, 0.0f));
 #pragma unroll
     for (int i = 0; i < 6; i++) dxb[i] = Y[0][i] * lam.x + Y[1][i] * lam.y + Y[2][i] * lam.z;
@@ -833,10 +926,9 @@ IRRL_DEV bool sphere_pass(const EnvParams &P, EnvLane &L, const rot3 &R, const v
     const vm gnd = dyn & ((L.sp.z - hgt) * nw.z - L.srad <= 0.0f);
     if (wave_any(gnd)) {
       sym3 G; G.xx = ms_inv; G.xy = 0.0f; G.xz = 0.0f; G.yy = ms_inv; G.yz = 0.0f; G.zz = ms_inv;
-      ContactBlock CB = make_contact_block(G, nw);
       vf vn = dot(sv_pre, nw);
       vf vs = vsel(vn < -L.m.rest_thr, -L.m.rest * vn, 0.0f);
-      v3 lam = solve_contact(CB, L.sv, nw, vs, L.m.mu, gnd);
+      v3 lam = solve_contact_once(P, G, L.sv, nw, vs, L.m.mu, gnd);
       L.sv.x = vsel(gnd, L.sv.x + ms_inv * lam.x, L.sv.x); L.sv.y = vsel(gnd, L.sv.y + ms_inv * lam.y, L.sv.y); L.sv.z = vsel(gnd, L.sv.z + ms_inv * lam.z, L.sv.z);
     }
   }
@@ -1101,7 +1193,9 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     sym3 G;
     G.xx = sub_bcast<0>(gr[0]); G.xy = sub_bcast<0>(gr[1]); G.xz = sub_bcast<0>(gr[2]);
     G.yy = sub_bcast<1>(gr[1]); G.yz = sub_bcast<1>(gr[2]); G.zz = sub_bcast<2>(gr[2]);
-    ContactBlock CB = make_contact_block(G, nB);
+    // per-substep constants of the single-contact solve, by the pool's rule (wave-uniform; the other block is never read)
+    ContactBlock CB; ContactBlockMD CM;
+    if (P.contact_rule) CM = make_contact_block_md(G, nB, L.m.mu); else CB = make_contact_block(G, nB);
     // contact-point velocity rows: before the step (restitution) and free
     vf ul0 = sub_bcast<0>(ul_s), ul1 = sub_bcast<1>(ul_s), ul2 = sub_bcast<2>(ul_s);
     vf vpre_r = jl0 * L.qd[0] + jl1 * L.qd[1] + jl2 * L.qd[2] + jb[0] * vB.x + jb[1] * vB.y + jb[2] * vB.z + jb[3] * wB.x + jb[4] * wB.y + jb[5] * wB.z;
@@ -1156,7 +1250,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
         cvr = legs_rot_fma<3>(lam.z, gx3[2], legs_rot_fma<3>(lam.y, gx3[1], legs_rot_fma<3>(lam.x, gx3[0], cvr)));
         v3 cv = mk3(sub_bcast<0>(cvr), sub_bcast<1>(cvr), sub_bcast<2>(cvr));
         vm commit = jacobi ? active : (active & (rank == rk));
-        v3 ln = solve_contact(CB, cv, nB, vstar, L.m.mu, commit);
+        v3 ln = P.contact_rule ? solve_contact_md(CM, cv, nB, vstar, L.m.mu) : solve_contact(CB, cv, nB, vstar, L.m.mu, commit);
         v3 dl = mk3(vsel(commit, ln.x - lam.x, 0.0f), vsel(commit, ln.y - lam.y, 0.0f), vsel(commit, ln.z - lam.z, 0.0f));
         lam = lam + dl;
         d2 += dot(dl, dl);
@@ -1316,7 +1410,8 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
         Gm[r][c] = acc;
       }
     sym3 G; G.xx = Gm[0][0]; G.xy = Gm[0][1]; G.xz = Gm[0][2]; G.yy = Gm[1][1]; G.yz = Gm[1][2]; G.zz = Gm[2][2];
-    ContactBlock CB = make_contact_block(G, nB);
+    ContactBlock CB; ContactBlockMD CM;
+    if (P.contact_rule) CM = make_contact_block_md(G, nB, L.m.mu); else CB = make_contact_block(G, nB);
     // contact-point velocities: before the step (restitution) and free
     vf vpre[3], cfree[3];
     const vf upre[6] = {vB.x, vB.y, vB.z, wB.x, wB.y, wB.z};
@@ -1357,7 +1452,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
           cv.x += Y[0][i] * o; cv.y += Y[1][i] * o; cv.z += Y[2][i] * o;
         }
         vm commit = jacobi ? active : (active & (rank == rk));
-        v3 ln = solve_contact(CB, cv, nB, vstar, L.m.mu, commit);
+        v3 ln = P.contact_rule ? solve_contact_md(CM, cv, nB, vstar, L.m.mu) : solve_contact(CB, cv, nB, vstar, L.m.mu, commit);
         v3 dl = mk3(vsel(commit, ln.x - lam.x, 0.0f), vsel(commit, ln.y - lam.y, 0.0f), vsel(commit, ln.z - lam.z, 0.0f));
         lam = lam + dl;
         d2 += dot(dl, dl);

@@ -24,7 +24,9 @@ struct EnvParams {
   float phase[4];          // Environment.hpp:398-409
   float max_len;           // Environment.hpp:395
   float contact_tol;       // [ext] ContactTolerance: early exit of the contact sweeps (0 = fixed sweep count)
-  int32_t contact_jacobi;  // [ext] ContactSolver: 2 (default) = all contacts of a robot update simultaneously in a sweep, 0 = Gauss-Seidel
+  int32_t contact_jacobi;  // [ext] ContactSolver bit 1: set = all contacts of a robot update simultaneously in a sweep, clear = Gauss-Seidel FR, FL, HR, HL
+  int32_t contact_rule;    // [ext] ContactSolver bit 0: set = the published per-contact rule of RaiSim's solver (maximum dissipation on the cone
+                           //       boundary, Hwangbo et al. 2018), clear = the build's first sliding rule (along the sticking impulse)
   float clamp_r;           // tau_max / (w_max - w_crit)            (Environment.hpp:1279)
   float clamp_inv_den;     // 1 / (-w_max + w_crit)                 (Environment.hpp:1296-1297)
   // height field (Terrain: True, Environment.hpp:254-264); height == nullptr / terrain == 0 means the plane z = 0

@@ -146,10 +146,18 @@ inline bool build_params(const Config &c, EnvParams &P, std::string &err) {
   if (P.contact_iters <= 0) P.contact_iters = 6;
   P.contact_tol = c.has("ContactTolerance") ? (float)num("ContactTolerance") : 0.0f;
   {
-    const int solver = c.has("ContactSolver") ? (int)num("ContactSolver") : 2;
-    if (solver != 0 && solver != 2) { err = "ContactSolver must be 2 (simultaneous updates, default) or 0 (Gauss-Seidel)"; return false; }
-    P.contact_jacobi = solver == 2 ? 1 : 0;
+    // bit 1: order inside a sweep (set = the toes of a robot update simultaneously, clear = Gauss-Seidel FR, FL, HR, HL);
+    // bit 0: per-contact rule (set = the published maximum-dissipation rule of RaiSim's solver, clear = the build's first rule)
+    const int solver = c.has("ContactSolver") ? (int)num("ContactSolver") : 3;
+    if (solver < 0 || solver > 3) { err = "ContactSolver must be 0..3 (bit 1: simultaneous sweeps, bit 0: published per-contact rule)"; return false; }
+    P.contact_jacobi = (solver & 2) ? 1 : 0;
+    P.contact_rule = (solver & 1) ? 1 : 0;
   }
+  // the build-defined contact keys are a closed set: a misspelt or unsupported one (e.g. a relaxation factor only some other
+  // implementation knows) must not be ignored silently -- two engines would then solve different iterations
+  for (const auto &it : c.kv)
+    if (it.first.compare(0, 7, "Contact") == 0 && it.first != "ContactCoeff" && it.first != "ContactIterations" &&
+        it.first != "ContactTolerance" && it.first != "ContactSolver") { err = "unsupported build-defined key cfg[\"" + it.first + "\"]"; return false; }
   P.clamp_r = P.tau_max / (P.w_max - P.w_crit);
   P.clamp_inv_den = 1.0f / (-P.w_max + P.w_crit);
   P.shared_noise = c.has("SharedNoiseScalar") ? (int32_t)flag("SharedNoiseScalar") : 1;

@@ -530,8 +530,8 @@ static void chol_solve(const real *L, int n, real *x) {
 }
 
 /* one-contact solve: velocity without own impulse c, local Delassus G (3x3), unit normal n,
- * target normal speed vstar, friction mu. */
-static void solve_contact(const real *G, const real *c, const real *n, real vstar, real mu, real *lam) {
+ * target normal speed vstar, friction mu.  The build's first rule (ContactSolver bit 0 clear). */
+static void solve_contact_dir(const real *G, const real *c, const real *n, real vstar, real mu, real *lam) {
   real cn = v3_dot(c, n) - vstar;
   if (cn >= RC(0)) { v3_set(lam, RC(0), RC(0), RC(0)); return; }
   real rhs[3], l[3], Gn[3];
@@ -557,6 +557,93 @@ static void solve_contact(const real *G, const real *c, const real *n, real vsta
   real den = nGw > RC(0.2) * nGn ? nGw : RC(0.2) * nGn;
   v3_scale(lam, w, -cn / den);
 }
+
+/* one-contact solve, the PUBLISHED rule of the reference's physics engine (ContactSolver bit 0 set).  RaiSim (ENV:768 world_->integrate(),
+ * closed source) resolves contacts with the per-contact iteration of Hwangbo, Lee & Hutter, "Per-Contact Iteration Method for
+ * Solving Contact Dynamics", RA-L 2018: every single-contact problem is solved EXACTLY under Signorini's
+ * condition, the Coulomb cone and the maximum-dissipation principle --
+ *   opening  (c.n >= v*):                                    lam = 0
+ *   sticking (lam_s = -G^-1 (c - v* n) pushes, inside cone): lam = lam_s
+ *   slipping: the point of {cone boundary} x {v_n+ = v*} that minimises the post-impact kinetic energy
+ *             h(lam) = 1/2 lam^T G lam + lam^T (c - v* n).
+ * The paper finds that point by bisection on the polar angle of the conic; here it is found in closed form up to a scalar
+ * root (same point; tests/test_contact_model_gap.py compares against a brute-force scan + bisection in numpy):
+ *   contact frame (t1, t2, n); eliminate lam_n with the normal condition, lam_n = alpha + beta . x, alpha = -(c.n - v*) / G_nn,
+ *   beta = -G_tn / G_nn, x = tangential impulse  =>  h = 1/2 x^T A x + b^T x with A = G_tt - G_tn G_tn^T / G_nn (Schur complement),
+ *   b = c_t + alpha G_tn; its free minimiser x* = -A^-1 b is the sticking impulse.  The cone section |x| <= mu (alpha + beta . x)
+ *   is, in xi = x / alpha, the FIXED ellipse (xi - xi_c)^T P (xi - xi_c) <= 1 with P = (1 - mu^2 beta beta^T) s / mu^2,
+ *   xi_c = mu^2 beta / s, s = 1 - mu^2 |beta|^2 (focus at the origin, eccentricity mu |beta|).  Minimising the A-metric distance
+ *   to xi* over the ellipse is a 2x2 trust-region problem: (A + gamma P)(xi - xi_c) = A (xi* - xi_c) with gamma >= 0 from the
+ *   scalar equation  (xi - xi_c)^T P (xi - xi_c) = 1,  solved by MD_NEWTON Newton steps on  p(gamma) / sqrt(r(gamma)) = sigma
+ *   (the reciprocal form: concave and increasing, Newton from gamma = 0 is monotone and converges in 3-4 steps;
+ *   p = det(A + gamma P), r = quadratic in gamma, sigma = |xi* - xi_c|).
+ * Caps (never active on the shipped configurations, where mu |beta| <= 0.86 over 1.2e5 captured contact problems):
+ *   mu |beta| > sqrt(1 - MD_SMIN): the conic is a parabola / hyperbola (jamming corner); beta is shortened in the cone section to
+ *   the ellipse of eccentricity sqrt(1 - MD_SMIN);  sigma > MD_SIGMAX (a barely pressing contact sliding fast: alpha -> 0, the
+ *   impulse is ~1e-4 of a pressing one): the far point is pulled in to MD_SIGMAX;  mu < MD_MUMIN: frictionless, lam = alpha n.
+ * The HIP kernels run this same algorithm (csrc/env_core.hpp solve_contact_md), step for step. */
+#define MD_NEWTON 4
+#define MD_SMIN 0.04
+#define MD_SIGMAX 1.0e4
+#define MD_MUMIN 1.0e-6
+static void solve_contact_md(const real *G, const real *c, const real *n, real vstar, real mu_in, real *lam) {
+  const real cn = v3_dot(c, n) - vstar;
+  if (cn >= RC(0)) { v3_set(lam, RC(0), RC(0), RC(0)); return; }
+  const real mu = mu_in > RC(MD_MUMIN) ? mu_in : RC(MD_MUMIN);
+  /* branch-free orthonormal frame around n (Duff et al. 2017) */
+  const real sg = n[2] >= RC(0) ? RC(1) : RC(-1);
+  const real fa = RC(-1) / (sg + n[2]), fb = n[0] * n[1] * fa;
+  const real t1[3] = {RC(1) + sg * n[0] * n[0] * fa, sg * fb, -sg * n[0]};
+  const real t2[3] = {fb, sg + n[1] * n[1] * fa, -n[1]};
+  real Gt1[3], Gt2[3], Gn[3];
+  m3_mulv(Gt1, G, t1); m3_mulv(Gt2, G, t2); m3_mulv(Gn, G, n);
+  const real g1 = v3_dot(t1, Gn), g2 = v3_dot(t2, Gn), ignn = RC(1) / v3_dot(n, Gn);
+  const real A11 = v3_dot(t1, Gt1) - g1 * g1 * ignn, A12 = v3_dot(t1, Gt2) - g1 * g2 * ignn, A22 = v3_dot(t2, Gt2) - g2 * g2 * ignn;
+  const real be1 = -g1 * ignn, be2 = -g2 * ignn;
+  const real detA = A11 * A22 - A12 * A12, idetA = RC(1) / detA;
+  /* sticking impulse */
+  const real alpha = -cn * ignn;
+  const real b1 = v3_dot(c, t1) + alpha * g1, b2 = v3_dot(c, t2) + alpha * g2;
+  const real x1 = -(A22 * b1 - A12 * b2) * idetA, x2 = -(A11 * b2 - A12 * b1) * idetA;
+  const real ln = alpha + be1 * x1 + be2 * x2;
+  if (ln > RC(0) && x1 * x1 + x2 * x2 <= mu * mu * ln * ln) {
+    for (int i = 0; i < 3; i++) lam[i] = x1 * t1[i] + x2 * t2[i] + ln * n[i];
+    return;
+  }
+  if (mu_in <= RC(MD_MUMIN)) { v3_scale(lam, n, alpha); return; }
+  /* slipping: the fixed ellipse of the cone section in xi = x / alpha */
+  const real mb2 = mu * mu * (be1 * be1 + be2 * be2);
+  const real shrink = mb2 <= RC(1.0 - MD_SMIN) ? RC(1) : R_SQRT(RC(1.0 - MD_SMIN) / mb2);
+  const real e1 = shrink * mu * be1, e2 = shrink * mu * be2;       /* mu beta (capped) */
+  const real s = RC(1) - (e1 * e1 + e2 * e2), is = RC(1) / s, ims = s / (mu * mu);
+  const real P11 = (RC(1) - e1 * e1) * ims, P12 = -e1 * e2 * ims, P22 = (RC(1) - e2 * e2) * ims;
+  const real detP = P11 * P22 - P12 * P12, mix = A22 * P11 - RC(2) * A12 * P12 + A11 * P22;
+  const real zc1 = mu * e1 * is, zc2 = mu * e2 * is;
+  /* the far point relative to the centre, as direction d and distance sigma */
+  const real ia = RC(1) / alpha;
+  real d1 = x1 * ia - zc1, d2 = x2 * ia - zc2;
+  const real s2 = d1 * d1 + d2 * d2;
+  const real isg = RC(1) / R_SQRT(s2 > RC(1e-30) ? s2 : RC(1e-30));
+  const real sig = s2 * isg < RC(MD_SIGMAX) ? s2 * isg : RC(MD_SIGMAX);
+  d1 *= isg; d2 *= isg;
+  /* (A + gamma P)^-1 A d = (u + gamma q) / p(gamma):  u = adj(A) A d = detA d,  q = adj(P) A d */
+  const real w1 = A11 * d1 + A12 * d2, w2 = A12 * d1 + A22 * d2;
+  const real u1 = detA * d1, u2 = detA * d2;
+  const real q1 = P22 * w1 - P12 * w2, q2 = P11 * w2 - P12 * w1;
+  const real Pu1 = P11 * u1 + P12 * u2, Pu2 = P12 * u1 + P22 * u2, Pq1 = P11 * q1 + P12 * q2, Pq2 = P12 * q1 + P22 * q2;
+  const real c0 = u1 * Pu1 + u2 * Pu2, c1 = RC(2) * (q1 * Pu1 + q2 * Pu2), c2 = q1 * Pq1 + q2 * Pq2;
+  real gam = RC(0);
+  for (int it = 0; it < MD_NEWTON; it++) {
+    const real p = (detP * gam + mix) * gam + detA, r = (c2 * gam + c1) * gam + c0;
+    const real dp = RC(2) * detP * gam + mix, dr = RC(2) * c2 * gam + c1;
+    gam += r * (sig * R_SQRT(r) - p) / (dp * r - RC(0.5) * p * dr);
+  }
+  const real kk = sig / ((detP * gam + mix) * gam + detA);
+  const real X1 = alpha * ((u1 + gam * q1) * kk + zc1), X2 = alpha * ((u2 + gam * q2) * kk + zc2);
+  const real lnn = alpha + be1 * X1 + be2 * X2;                      /* normal velocity condition exact */
+  for (int i = 0; i < 3; i++) lam[i] = X1 * t1[i] + X2 * t2[i] + lnn * n[i];
+}
+#define solve_contact(RULE, G, c, n, vstar, mu, lam) ((RULE) ? solve_contact_md(G, c, n, vstar, mu, lam) : solve_contact_dir(G, c, n, vstar, mu, lam))
 
 /* ---- height field (Terrain: True).  RaiSim's Perlin terrain (ENV:254-264) is closed source; the spec is the
  * build's own: improved Perlin noise, LCG-shuffled permutation seeded by seedd,
@@ -963,6 +1050,7 @@ static void physics_substep(orc_env *h, env_t *e, const real *pTarget) {
   const robot_model *m = &e->model;
   real dt = RC(c->simulation_dt);
   real *q = &e->gc[7], *qd = &e->gv[6];
+  const int rule_md = c->ContactSolver & 1;
   /* PD law + 1 % blend with torque_last + clamp */
   real tau[12];
   for (int j = 0; j < 12; j++) {
@@ -1067,17 +1155,14 @@ static void physics_substep(orc_env *h, env_t *e, const real *pTarget) {
             G[la][lb][3 * r + r2] = acc;
           }
   int sweeps_done = 0;
-  /* THE PER-CONTACT ITERATION OVER THE TOES.  Groups of contacts update simultaneously (from the same iterate) inside a sweep;
-   * groups run one after the other.  ContactSolver 2 (default): the four toes are one group -- they couple only through the
-   * heavy base, the off-diagonal Delassus blocks are a fraction of the diagonal ones, and the simultaneous update converges
-   * almost as fast as Gauss-Seidel (2.4 against 2.2 sweeps per substep, same fixed point: measured) while
-   * the lock-step kernels need ONE solve per sweep instead of one per contact.  0: every toe its own group (Gauss-Seidel,
-   * FR FL HR HL);  1: two colours {FR, HL}, {FL, HR}. */
+  /* THE PER-CONTACT ITERATION OVER THE TOES.  ContactSolver bit 1 is the ORDER inside a sweep: clear = Gauss-Seidel FR, FL, HR, HL
+   * (the published method); set = the four toes update simultaneously from the sweep's starting iterate -- they couple only
+   * through the heavy base, the off-diagonal Delassus blocks are a fraction of the diagonal ones, and this converges almost as
+   * fast as Gauss-Seidel (2.4 against 2.2 sweeps per substep, same fixed point: measured) while the lock-step
+   * kernels need ONE solve per sweep instead of one per contact.  Bit 0 is the per-contact RULE (solve_contact_md / _dir). */
   int group_of[4], n_groups;
-  if (c->ContactSolver == 2) { for (int l = 0; l < 4; l++) group_of[l] = 0; n_groups = 1; }
-  else if (c->ContactSolver == 1) { group_of[0] = 0; group_of[3] = 0; group_of[1] = 1; group_of[2] = 1; n_groups = 2; }
+  if (c->ContactSolver & 2) { for (int l = 0; l < 4; l++) group_of[l] = 0; n_groups = 1; }
   else { for (int l = 0; l < 4; l++) group_of[l] = l; n_groups = 4; }
-  const real relax = (c->ContactSolver == 0) ? RC(1) : RC(c->ContactRelax);
   for (int it = 0; it < c->ContactIterations; it++) {
     real d2 = RC(0), l2 = RC(0);
     for (int g = 0; g < n_groups; g++) {
@@ -1092,12 +1177,12 @@ static void physics_substep(orc_env *h, env_t *e, const real *pTarget) {
           m3_mulv(t, G[l][lb], lamB[lb]);
           v3_add(cv, cv, t);
         }
-        solve_contact(G[l][l], cv, nBl[l], vstar[l], m->mu, newl[l]);
+        solve_contact(rule_md, G[l][l], cv, nBl[l], vstar[l], m->mu, newl[l]);
       }
       for (int l = 0; l < 4; l++) {
         if (!active[l] || group_of[l] != g) continue;
         for (int a = 0; a < 3; a++) {
-          real dd = relax * (newl[l][a] - lamB[l][a]);
+          real dd = newl[l][a] - lamB[l][a];
           lamB[l][a] += dd;
           d2 += dd * dd; l2 += lamB[l][a] * lamB[l][a];
         }
@@ -1151,7 +1236,7 @@ gs_done:
         Gc[3 * r + r2] = g;
       }
     }
-    solve_contact(Gc, cv, nBl[l], vstar[l], m->mu, lam);
+    solve_contact(rule_md, Gc, cv, nBl[l], vstar[l], m->mu, lam);
     for (int r = 0; r < 3; r++)
       for (int cc = 0; cc < NV; cc++) ufree[cc] += MiJt[l][r][cc] * lam[r];
     e->box_hits += 1;
@@ -1198,7 +1283,7 @@ gs_done:
       for (int a = 0; a < 3; a++) pre[a] = vB[a] + tmp[a] - svB_pre[a];
       real vn = v3_dot(pre, nB);
       real vs = vn < RC(-0.001) ? RC(-0.95) * vn : RC(0);
-      solve_contact(Gc, cv, nB, vs, RC(0), lam);
+      solve_contact(rule_md, Gc, cv, nB, vs, RC(0), lam);
       for (int r = 0; r < 3; r++)
         for (int cc = 0; cc < NV; cc++) ufree[cc] += MiJs[r][cc] * lam[r];
       for (int a = 0; a < 3; a++) svB[a] -= lam[a] * ms_inv;
@@ -1213,7 +1298,7 @@ gs_done:
         real Gc[9] = {ms_inv, RC(0), RC(0), RC(0), ms_inv, RC(0), RC(0), RC(0), ms_inv}, lam[3];
         real vn = v3_dot(sv_pre, nw);
         real vs = vn < -m->rest_thr ? -m->rest * vn : RC(0);
-        solve_contact(Gc, e->sph_v, nw, vs, m->mu, lam);
+        solve_contact(rule_md, Gc, e->sph_v, nw, vs, m->mu, lam);
         v3_axpy(e->sph_v, ms_inv, lam);
       }
     }
@@ -1387,7 +1472,6 @@ orc_env *orc_create(const orc_cfg *cfg) {
   if (h) h->probe_env = -1;
   h->cfg = *cfg;
   if (h->cfg.ContactIterations <= 0) h->cfg.ContactIterations = 6;
-  if (!(h->cfg.ContactRelax > 0)) h->cfg.ContactRelax = 1.0;
   h->n = cfg->num_envs;
   h->envs = (env_t *)calloc((size_t)h->n, sizeof(env_t));
   obs_scaling(cfg, h->obMean, h->obStd);
@@ -1605,6 +1689,14 @@ void orc_set_state(orc_env *h, const double *in) {
 }
 
 /* ---- unit probes (double in/out) ---- */
+/* the single-contact solves for the tests: G row-major 3x3, c, n, out lam; rule 1 = published (solve_contact_md), 0 = the build's first rule */
+void orc_solve_contact(int rule, const double G[9], const double c[3], const double n[3], double vstar, double mu, double lam[3]) {
+  real g[9], cc[3], nn[3], l[3];
+  for (int i = 0; i < 9; i++) g[i] = RC(G[i]);
+  for (int i = 0; i < 3; i++) { cc[i] = RC(c[i]); nn[i] = RC(n[i]); }
+  solve_contact(rule, g, cc, nn, RC(vstar), RC(mu), l);
+  for (int i = 0; i < 3; i++) lam[i] = R_TO_DOUBLE(l[i]);
+}
 void orc_cubic_bezier(const double p0[3], const double pf[3], double s, double out[3]) {
   real a[3] = {RC(p0[0]), RC(p0[1]), RC(p0[2])}, b[3] = {RC(pf[0]), RC(pf[1]), RC(pf[2])}, o[3];
   cubic_bezier(a, b, RC(s), o);

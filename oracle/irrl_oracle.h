@@ -61,10 +61,13 @@ typedef struct orc_cfg {
   int32_t SharedNoiseScalar;    /* 1: Eigen 12x1*12x1 pitfall => one shared factor (ENV:584,586,705) */
   int32_t RandomizePerEpisode;  /* 1: redo the ctor domain randomisation at every reset (config 5) */
   double ContactTolerance;      /* stop the sweeps once sum|dlambda|^2 <= tol^2 sum|lambda|^2 (0: always ContactIterations sweeps) */
-  int32_t ContactSolver;        /* order of the toe updates inside one sweep: 2 = the four toes at once (default; the kernels' one-solve-per-sweep),
-                                 * 0 = Gauss-Seidel over FR, FL, HR, HL, 1 = two colours {FR, HL} then {FL, HR} (oracle only).
-                                 * Trunk-box corners: one pass of sequential impulses behind the toe iteration, in every mode. */
-  double ContactRelax;          /* relaxation of the simultaneous updates (solvers 1, 2): lam += relax (lam_new - lam); default 1 */
+  int32_t ContactSolver;        /* bit 1 = ORDER of the toe updates inside one sweep: set = the four toes at once (the kernels' one-solve-per-sweep),
+                                 * clear = Gauss-Seidel over FR, FL, HR, HL;  bit 0 = per-contact RULE for a sliding contact: set = the published
+                                 * rule of RaiSim's solver (Hwangbo, Lee, Hutter, RA-L 2018: the minimiser of the post-impact kinetic energy on
+                                 * {cone boundary} x {v_n = target}, solve_contact_md below), clear = the build's first rule (slide along the sticking
+                                 * impulse's tangential direction).  So 0 = GS + build rule, 1 = GS + published rule (the published method),
+                                 * 2 = simultaneous + build rule, 3 = simultaneous + published rule (default of the shipped configs).
+                                 * Trunk-box corners / meteorite: one pass of sequential impulses behind the toe iteration with the same rule. */
 } orc_cfg;
 
 typedef struct orc_env orc_env; /* opaque vector-env handle */
@@ -102,6 +105,7 @@ void orc_get_state(orc_env *h, double *out /* [N,ORC_STATE_DIM] */);
 void orc_set_state(orc_env *h, const double *in /* [N,ORC_STATE_DIM] */);
 
 /* --- unit-level entry points (always double in/out) used by the golden-vector tests --- */
+void orc_solve_contact(int rule, const double G[9], const double c[3], const double n[3], double vstar, double mu, double lam[3]);
 void orc_cubic_bezier(const double p0[3], const double pf[3], double s, double out[3]);
 double orc_gauss(double x, double width, double height);
 void orc_bezier2(const double p0[3], const double pf[3], double s, double h, double out[3]);

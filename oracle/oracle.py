@@ -41,17 +41,20 @@ class OrcCfg(C.Structure):
         ("FPS", C.c_double), ("ActionNoise", C.c_double), ("ObsNoise", C.c_double), ("GaitType", C.c_int32),
         ("MotorMaxTorque", C.c_double), ("MotorCriticalSpeed", C.c_double), ("MotorMaxSpeed", C.c_double),
         ("ContactIterations", C.c_int32), ("SharedNoiseScalar", C.c_int32), ("RandomizePerEpisode", C.c_int32),
-        ("ContactTolerance", C.c_double), ("ContactSolver", C.c_int32), ("ContactRelax", C.c_double),
+        ("ContactTolerance", C.c_double), ("ContactSolver", C.c_int32),
     ]
 
 
-_EXT_DEFAULTS = {"ContactIterations": 6, "SharedNoiseScalar": 1, "RandomizePerEpisode": 0, "ContactTolerance": 0.0, "ContactSolver": 2, "ContactRelax": 1.0}
+_EXT_DEFAULTS = {"ContactIterations": 6, "SharedNoiseScalar": 1, "RandomizePerEpisode": 0, "ContactTolerance": 0.0, "ContactSolver": 3}
 
 
 def cfg_from_dict(env_cfg):
     """Fill an OrcCfg from the ``environment:`` mapping of a config (every reference key mandatory,
     ENV:1594-1659 / BASE:41-42)."""
     c = OrcCfg()
+    for k in env_cfg:   # the build-defined contact keys are a closed set (same check as csrc/irrl_config.hpp)
+        if str(k).startswith("Contact") and k not in ("ContactCoeff", "ContactIterations", "ContactTolerance", "ContactSolver"):
+            raise KeyError("unsupported build-defined key cfg[%r]" % k)
     for name, ctype in OrcCfg._fields_:
         if name in env_cfg:
             v = env_cfg[name]
@@ -103,6 +106,7 @@ def _lib(precision="f64"):
     lib.orc_mean_contact_sweeps.argtypes = [vp]
     d3 = C.c_double * 3
     lib.orc_cubic_bezier.argtypes = [d3, d3, C.c_double, d3]
+    lib.orc_solve_contact.argtypes = [C.c_int, C.c_double * 9, d3, d3, C.c_double, C.c_double, d3]
     lib.orc_bezier2.argtypes = [d3, d3, C.c_double, C.c_double, d3]
     lib.orc_gauss.restype = C.c_double
     lib.orc_gauss.argtypes = [C.c_double] * 3
@@ -287,6 +291,14 @@ S = dict(GC=0, GV=19, PTL=37, TQL=49, TQ=61, JR=73, JRL=85, JDR=97, EER=109, CMD
 
 
 # ---- unit probes ----
+def solve_contact_md(G, c, n, vstar, mu, precision="f64", rule=1):
+    """the single-contact solve of the oracle (rule 1: the published maximum-dissipation rule; 0: the build's first rule)"""
+    out = (C.c_double * 3)()
+    _lib(precision).orc_solve_contact(int(rule), (C.c_double * 9)(*np.asarray(G, float).ravel()), (C.c_double * 3)(*c), (C.c_double * 3)(*n),
+                                      float(vstar), float(mu), out)
+    return np.array(out[:])
+
+
 def cubic_bezier(p0, pf, s, precision="f64"):
     out = (C.c_double * 3)()
     _lib(precision).orc_cubic_bezier((C.c_double * 3)(*p0), (C.c_double * 3)(*pf), s, out)

@@ -17,6 +17,12 @@ import oracle as O
 
 S = O.S
 TOL_STEP = dict(ob=5e-4, rew=2e-4, extra=2e-4, pos=2e-5, vel=5e-3)
+# Rough ground (Terrain: True) and robots lying on a trunk-box corner add hard thresholds of their own -- the height-field cell
+# a toe / corner samples, a corner entering the contact list -- so an env-step may carry a threshold event of a larger size
+# there: events are counted from 40x the tolerance (default 10x) and NOTHING may exceed 400x (observation 0.2, positions 8 mm,
+# velocities 2 m/s: a different contact set for most of a step).  Measured worst on 16 envs x 100 terrain steps with forced
+# resets: observation 10x, positions 63x, velocities 17x the tolerance, 3-6 events in 1600 env-steps.
+TERRAIN_MAX_FACTOR = 40.0
 
 
 def random_actions(rng, n, scale=0.3):
@@ -211,7 +217,7 @@ def check_free_running(make_orc, make_cand, cfg, preroll=90):
     return out
 
 
-def check_invariants(cand, steps=40, seed=3):
+def check_invariants(cand, steps=40, seed=3, flat_ground=True):
     """Size-independent physical properties, usable at the full 4096-env configuration."""
     rng = np.random.RandomState(seed)
     n = cand.n
@@ -224,9 +230,10 @@ def check_invariants(cand, steps=40, seed=3):
     lam = st[:, S["LAMW"]:S["LAMW"] + 12].reshape(n, 4, 3)
     mu = st[:, S["MATERIAL"]]
     inc = st[:, S["INCONTACT"]:S["INCONTACT"] + 4]
-    assert np.all(lam[:, :, 2] >= -1e-7)
-    ft = np.linalg.norm(lam[:, :, :2], axis=2)
-    assert np.all(ft <= mu[:, None] * lam[:, :, 2] * (1 + 1e-4) + 1e-6)     # Coulomb cone
+    if flat_ground:                                                            # (on a height field the cone axis is the local normal)
+        assert np.all(lam[:, :, 2] >= -1e-7)
+        ft = np.linalg.norm(lam[:, :, :2], axis=2)
+        assert np.all(ft <= mu[:, None] * lam[:, :, 2] * (1 + 1e-4) + 1e-6)     # Coulomb cone
     assert np.all(np.abs(lam[inc == 0]) == 0)                                  # no impulse without contact
     assert np.all((st[:, 2] > 0.1) & (st[:, 2] < 0.7))                          # base height inside the episode band
     return st

@@ -76,11 +76,12 @@ def _hwangbo_per_contact_iteration(prob, mu, sweeps=200):
     return lam
 
 
-def _oracle_problem(case):
+def _oracle_problem(case, solver=2, precision="f64"):
     """one 0.25 ms substep of the oracle from a prepared state; returns the captured contact problem and friction"""
     dt = 0.00025
-    cfg = load_env_cfg("bp5_imitation.yaml", num_envs=1, control_dt=dt, simulation_dt=dt, ContactIterations=200, ContactTolerance=0.0)
-    env = O.OracleVecEnv(cfg)
+    cfg = load_env_cfg("bp5_imitation.yaml", num_envs=1, control_dt=dt, simulation_dt=dt, ContactIterations=200, ContactTolerance=0.0,
+                       ContactSolver=solver)
+    env = O.OracleVecEnv(cfg, precision)
     st = env.get_state()
     st[0, S["GC"]:S["GC"] + 19] = 0
     st[0, S["GC"] + 2] = case.get("z", 0.2890)                 # nominal stance: toes ~1 mm into the ground
@@ -114,8 +115,52 @@ CASES = {
 }
 
 
+@pytest.mark.parametrize("solver", [1, 3])
+@pytest.mark.parametrize("name", list(CASES))
+def test_published_rule_in_the_oracle_equals_the_numpy_per_contact_iteration(name, solver):
+    """ContactSolver 1 (Gauss-Seidel) and 3 (simultaneous sweeps) with the published per-contact rule (oracle solve_contact_md: closed
+    form up to a scalar Newton root) against the brute-force numpy implementation of the same published method (scan + bisection on
+    the polar angle of the conic), on the robot's own contact problems: 1 / 2 / 4 feet, sticking, sliding, landing -- identical
+    impulses (1e-6 of the largest one)."""
+    case = CASES[name]
+    prob, mu, rest, thr = _oracle_problem(case, solver=solver)
+    lam_h = _hwangbo_per_contact_iteration(prob, mu)
+    scale = np.abs(lam_h).max()
+    assert scale > 0
+    assert np.abs(prob["lam"] - lam_h).max() <= 1e-6 * scale, (name, prob["lam"], lam_h)
+
+
+def test_published_rule_single_contact_random_problems_f64_and_f32():
+    """the single-contact solve alone, on randomised problems around the captured ones (friction 0.2 .. 1.0, perturbed velocities,
+    tilted normals): f64 oracle vs numpy brute force to 2e-6, f32 build of the same C source to 5e-4 (f32 cancellation in c.n)"""
+    rng = np.random.default_rng(5)
+    prob, mu, _, _ = _oracle_problem(CASES["4 feet sliding diagonally + yaw"], solver=1)
+    worst64 = worst32 = 0.0
+    n_slide = 0
+    for trial in range(300):
+        i = int(rng.integers(4))
+        G = prob["G"][3 * i:3 * i + 3, 3 * i:3 * i + 3] * rng.uniform(0.7, 1.4)
+        n = np.array([rng.normal(0, 0.2), rng.normal(0, 0.2), 1.0])
+        n /= np.linalg.norm(n)
+        c = rng.standard_normal(3) * np.array([1.0, 1.0, 0.3]) - 0.05 * n
+        m = float(rng.uniform(0.2, 1.0))
+        vs = float(rng.choice([0.0, 0.05]))
+        ref = _single_contact_hwangbo(G, c, n, m, vs)
+        sc = np.abs(ref).max()
+        if sc == 0.0:
+            assert np.all(O.solve_contact_md(G, c, n, vs, m) == 0.0)
+            continue
+        ln = ref @ n
+        n_slide += np.linalg.norm(ref - ln * n) > (1 - 1e-7) * m * ln
+        worst64 = max(worst64, np.abs(O.solve_contact_md(G, c, n, vs, m) - ref).max() / sc)
+        worst32 = max(worst32, np.abs(O.solve_contact_md(G, c, n, vs, m, "f32") - ref).max() / sc)
+    assert n_slide > 100, n_slide
+    assert worst64 < 2e-6 and worst32 < 5e-4, (worst64, worst32)
+
+
 @pytest.mark.parametrize("name", list(CASES))
 def test_block_gs_rule_against_the_published_per_contact_iteration(name):
+    """ContactSolver 0 / 2 -- the build's FIRST sliding rule, kept as an option -- against the published method: the stated gap."""
     case = CASES[name]
     prob, mu, rest, thr = _oracle_problem(case)
     act = prob["active"]

@@ -105,6 +105,47 @@ def test_fused_lstm_policy_full_size_agrees_with_eager():
         assert float((a - b).abs().max()) / (float(a.abs().max()) + 1e-6) < 1e-4
 
 
+@pytest.mark.parametrize("N", [1, 37])
+def test_hip_lstm_kernels_reproduce_the_reference_actor_known_answers(N):
+    """The reference's own known answers on the MI355X kernels (CustomerLstmNN.py:112-175 `predict` on the trained bp5_155 weights,
+    tests/golden/lstm_bp5_155.json from tools/gen_golden.py): the eight actor tensors (tests/golden/actor_bp5_155.npz -- the weights
+    must travel: /root/reference does not exist on the GPU box) are loaded into the policy, then
+      (a) `lstm_policy_step_kernel` (one launch per control step, state carried from step to step) and
+      (b) `lstm_seq_fwd_x_kernel` (the train-graph forward over the whole sequence, one launch per layer)
+    must give the pickle's action means to 2e-5 and the CSV twin's clipped actions to 5e-5 (its '%.6f' rounding)."""
+    import json, os
+    from conftest import GOLDEN
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import CustomLSTMPolicy, SBLstm
+    g = json.load(open(os.path.join(GOLDEN, "lstm_bp5_155.json")))
+    z = np.load(os.path.join(GOLDEN, "actor_bp5_155.npz"))
+    dev = torch.device("cuda")
+    torch.manual_seed(3)
+    pol = CustomLSTMPolicy().to(dev)
+    with torch.no_grad():
+        for i, l in enumerate(pol.lstm_pi):
+            l.wx.copy_(torch.from_numpy(z["wx%d" % i])); l.wh.copy_(torch.from_numpy(z["wh%d" % i])); l.b.copy_(torch.from_numpy(z["b%d" % i]))
+        pol.pi.w.copy_(torch.from_numpy(z["pi_w"])); pol.pi.b.copy_(torch.from_numpy(z["pi_b"]))
+    pol.prepare()
+    assert SBLstm.use_fused
+    obs_seq = torch.tensor(g["obs_seq"], dtype=torch.float32, device=dev)                      # [6, 35]
+    want = np.asarray(g["actor_mean_pkl"], np.float64)
+    want_csv = np.asarray(g["actor_clipped_csv"], np.float64)
+    T = obs_seq.shape[0]
+    # (a) the rollout's single-launch policy step
+    st = pol.initial_state(N, dev)
+    dones = torch.zeros(N, dtype=torch.bool, device=dev)
+    assert pol.fused_step_supported(obs_seq[0].expand(N, 35).contiguous())
+    for t in range(T):
+        act, clipped, _, _, st = pol.fused_step(obs_seq[t].expand(N, 35).contiguous(), st, dones, noise=None)
+        a = act.double().cpu().numpy()
+        assert np.abs(a - want[t]).max() < 2e-5, (t, np.abs(a - want[t]).max())
+        assert np.abs(clipped.double().cpu().numpy() - want_csv[t]).max() < 5e-5
+    # (b) the persistent sequence kernel of the train graph
+    mean, _ = pol.evaluate_raw(obs_seq.unsqueeze(1).expand(T, N, 35).contiguous(), pol.initial_state(N, dev), torch.zeros(T, N, device=dev))
+    m = mean.detach().double().cpu().numpy()                                                    # [T, N, 12]
+    assert np.abs(m - want[:, None, :]).max() < 2e-5, np.abs(m - want[:, None, :]).max()
+
+
 @pytest.mark.parametrize("N,hid,deterministic", [(4096, 48, False), (48, 48, True), (16, 32, False), (160, 64, False), (200, 48, False), (7, 48, False)])
 def test_fused_policy_step_matches_eager_step(N, hid, deterministic):
     """The single-launch rollout step (both LSTM stacks, heads, sample, neglogp, clip, buffer rows) against the eager

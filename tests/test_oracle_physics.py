@@ -163,13 +163,18 @@ def test_more_contact_sweeps_change_little():
     assert np.abs(outs[0] - outs[1])[:, :19].max() < 5e-3
 
 
-def test_contact_impulses_obey_momentum_balance_cone_and_stick_slip():
+@pytest.mark.parametrize("solver", [3, 1, 2])
+def test_contact_impulses_obey_momentum_balance_cone_and_stick_slip(solver):
     """One 0.25 ms substep with the feet on the ground, from sticking (robot at rest) and sliding (1.5 m/s sideways /
     forwards) starts: the stored world-frame contact impulses must (a) account for the change of the total linear
     momentum, p1 - p0 = sum(lambda) - m g dt z, up to the O(dt^2) change of configuration, (b) lie in the Coulomb cone,
-    on its boundary and dissipative for sliding feet, (c) leave sticking feet without velocity."""
+    on its boundary and dissipative for sliding feet, (c) leave sticking feet without velocity.  Both per-contact rules: the
+    published one (ContactSolver 3 / 1: maximum dissipation on the cone boundary -- its friction is tilted off the anti-slip
+    direction through the normal-tangential coupling of the Delassus block, up to ~30 degrees on this robot) and the build's
+    first rule (2: within 26 degrees)."""
     dt = 0.00025
-    cfg = load_env_cfg("bp5_imitation.yaml", num_envs=6, control_dt=dt, simulation_dt=dt, ContactIterations=30, ContactTolerance=0.0)
+    cfg = load_env_cfg("bp5_imitation.yaml", num_envs=6, control_dt=dt, simulation_dt=dt, ContactIterations=30, ContactTolerance=0.0,
+                       ContactSolver=solver)
     env = O.OracleVecEnv(cfg)
     st = env.get_state()
     slide = [np.zeros(3), np.zeros(3), np.array([1.5, 0, 0]), np.array([0, 1.5, 0]), np.array([-1.0, 1.0, 0]), np.array([2.0, 0.3, 0])]
@@ -206,7 +211,7 @@ def test_contact_impulses_obey_momentum_balance_cone_and_stick_slip():
                 assert np.linalg.norm(vt) < 5e-4 and abs(vel[f, 2]) < 1e-6 and lt[f] < 0.9 * mu * ln[f]
             else:          # sliding: on the cone boundary, opposing the slip, normal velocity removed
                 assert abs(lt[f] - mu * ln[f]) < 1e-6 * ln[f] + 1e-12
-                assert np.dot(lam[f, :2], vt) < 0 and np.dot(lam[f, :2], vt) < -0.9 * lt[f] * np.linalg.norm(vt)
+                assert np.dot(lam[f, :2], vt) < 0 and np.dot(lam[f, :2], vt) < -(0.9 if solver == 2 else 0.85) * lt[f] * np.linalg.norm(vt)
                 assert abs(vel[f, 2]) < 1e-6
 
 
