@@ -309,20 +309,36 @@ def worker(args):
         check = {"steps": args.check_steps, "us_per_step": 1e3 * e0.elapsed_time(e1) / args.check_steps,
                  "contact_fraction": (cc1[1] - cc0[1]) / float(4 * loop_count * n * args.check_steps), "resets": cc1[0] - cc0[0]}
 
+    # the same K steps issued the way the reference's runner issues them: ONE FlexibleGymEnv.step() call (ctypes -> C-ABI) per
+    # control step (RaisimGymVecEnv.py:31), wall clock around the loop -- reported beside `value`, never as `value`
+    per_call = None
+    if args.launch == "rows" and world == 1:
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        run(args.steps, "python")
+        torch.cuda.synchronize()
+        per_call_s = time.perf_counter() - tc
+        per_call = {"value": float(n) * args.steps / per_call_s, "unit": "env-steps/s", "us_per_step": 1e6 * per_call_s / args.steps,
+                    "what": "%d steps, one FlexibleGymEnv.step() call per step on device tensors (the reference-shaped call surface)" % args.steps}
+
     out = None
     if rank == 0:
         # HBM bytes per launch from the PMC passes (FETCH_SIZE x calibrated correction + WRITE_SIZE), collected with
-        # rocprofv3 in separate runs (tools/gpu_pmc.sh) and committed under profiles/ -- not measurable in-process
-        traffic, issue = None, None
+        # rocprofv3 in separate runs (tools/gpu.sh pmc) and committed under profiles/ -- not measurable in-process
+        traffic, issue, pmc_note = None, None, None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary_latest.json")))
-            if int(pmc.get("envs", 4096)) == n and env.lanes_per_robot == 16:
+            # the counters describe ONE binary: they are reported only when the summary carries the version string of the
+            # library this process loaded (tools/pmc_workload.py records it on the GPU box), never for a later kernel
+            if pmc.get("library") != _lib.version():
+                pmc_note = "profiles/pmc_summary_latest.json was measured on %s, this run is %s: counters withheld" % (pmc.get("library"), _lib.version())
+            elif int(pmc.get("envs", 4096)) == n and env.lanes_per_robot == 16 and not args.set and args.cfg == "bp5_imitation.yaml":
                 traffic = float(pmc["hbm_bytes_per_launch"]["total"])
                 # how close the single resident wave per SIMD runs to its issue limit of one VALU instruction per 4 cycles
                 issue = {"valu_insts_per_wave": pmc["derived"]["valu_insts_per_wave"], "cycles_per_valu_inst": pmc["derived"]["cycles_per_valu_inst"],
                          "frac_of_single_wave_issue_peak": 4.0 / pmc["derived"]["cycles_per_valu_inst"], "source": "profiles/pmc_summary_latest.json"}
-        except Exception:
-            pass
+        except Exception as e:
+            pmc_note = "no usable profiles/pmc_summary_latest.json (%s)" % e
         total_env_steps = float(n) * world * args.steps
         value = total_env_steps / elapsed
         launch_s = kernel_ms * 1e-3
@@ -349,7 +365,8 @@ def worker(args):
                               "algorithmic_flops_per_launch": ALG_FLOPS_PER_ENV_STEP * n, "valu_issue": issue},
             "contact_fraction_in_timed_region": contact_fraction, "resets_in_timed_region": resets,
             "steady_state_check": check, "rccl_ranks_seen": ranks_seen, "backend": backend if world > 1 else None,
-            "library": lib.irrl_version().decode(),
+            "library": lib.irrl_version().decode(), "pmc_note": pmc_note, "per_step_call": per_call,
+            "contact_solver": int(env_cfg.get("ContactSolver", 3)),
         }
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(env_cfg, args.cpu_seconds)

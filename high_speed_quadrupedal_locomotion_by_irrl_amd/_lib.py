@@ -95,6 +95,11 @@ def load():
     return lib
 
 
+def version():
+    """"gfx950;irrl-env rN;irrl-src-hash:<hex>" of the loaded library (the hash covers every source under csrc/ + the flags)"""
+    return load().irrl_version().decode()
+
+
 def last_error():
     return load().irrl_last_error().decode("utf-8", "replace")
 

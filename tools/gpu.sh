@@ -1,0 +1,108 @@
+#!/bin/bash
+# ONE parameterised GPU-box script (replaces the tools/gpu_*.sh pile of rounds 1-2).  Run through gpurun, e.g.
+#   gpurun --timeout 2400 -- 'bash tools/gpu.sh box smoke tests bench'
+# Every stage writes under gpurun_out/ (merged back by gpurun); copy what is to be judged into profiles/ by hand.
+# Stages:
+#   box            GPU / host identification
+#   smoke          __graft_entry__.smoke()
+#   tests [expr]   pytest -m gpu (optionally -k expr via TESTS_K=...)
+#   bench          bench.py default line + driver-style 20-step line
+#   bench3         the three shipped configs, env leg only
+#   solvers        env leg of the benchmark config under ContactSolver 0 1 2 3
+#   sweep          envs-per-GPU sweep + PCIe-inclusive numpy boundary
+#   prof           rocprofv3 --kernel-trace --stats of the bench command
+#   profppo        rocprofv3 --kernel-trace --stats of 2 PPO iterations x 2 epochs (LSTM)
+#   pmc            PMC passes of the env step kernel (separate --pmc runs, no trace domains besides kernel-trace)
+#   pmclstm        PMC passes of the LSTM sequence kernels
+#   ppo            tools/ppo_bench.py lstm + mlp, 3 iterations each
+#   irrl2          the IRRL recipe at the benchmark scale: stage 1 imitation + stage 2 relaxation, 4096 envs, 300 updates each
+#   train200       the reference's command line (200 envs, 2e8 samples), headless evaluation of the result
+#   variants       A/B of every csrc/_variants/libirrl_env_*.so (tools/build_variants.py) on this one box, interleaved
+#   spread         per-wave durations of the step kernel (needs the `prof` variant library)
+#   ab <cmd...>    run the rest of the line verbatim (one-off A/B)
+cd "$GRAFT_REPO_ROOT" || exit 1
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out
+mkdir -p "$O"
+line() { python3 -c "import sys,json
+for l in sys.stdin:
+    if l.startswith('{') and 'metric' in l:
+        d=json.loads(l); print('$1', round(d['value']/1e6,2), 'M env-steps/s', round(d['roofline']['avg_launch_us'],2), 'us per launch', 'fp32_frac', round(d['roofline_fp32']['frac'],4))"; }
+while [ $# -gt 0 ]; do
+  stage=$1; shift
+  case $stage in
+    box) (rocminfo | grep -E "Marketing|gfx" | head -4; nproc; lscpu | grep "Model name"; python3 -c "import os;print('cgroup cpus', len(os.sched_getaffinity(0)))") > $O/box.log 2>&1 ;;
+    smoke) timeout 600 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; echo "smoke rc=$?" >> $O/smoke.log ;;
+    tests) timeout 2400 python -m pytest tests -m gpu -q -s ${TESTS_K:+-k "$TESTS_K"} > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log ;;
+    bench)
+      timeout 900 python bench.py > $O/bench.log 2>&1; echo "bench rc=$?" >> $O/bench.log
+      timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_driver_style.log 2>&1 ;;
+    bench3)
+      for c in bp5_imitation default_cfg bp5_terrain; do
+        timeout 600 python bench.py --cfg $c.yaml --cpu-seconds 0 --ppo-iters 0 --steps 2000 > $O/bench_$c.log 2>&1
+      done ;;
+    solvers)
+      rm -f $O/solvers.log
+      for s in 3 2 1 0 3 2; do
+        timeout 600 python bench.py --set ContactSolver=$s --cpu-seconds 0 --ppo-iters 0 --steps 2000 2>/dev/null | line "ContactSolver=$s" >> $O/solvers.log
+      done ;;
+    sweep)
+      rm -f $O/sweep.log
+      for n in 1024 4096 8192 16384 32768 131072; do
+        timeout 300 python bench.py --cpu-seconds 0 --ppo-iters 0 --steps 1000 --warmup 100 --check-steps 0 --envs $n 2>/dev/null | line "envs=$n" >> $O/sweep.log
+      done
+      timeout 300 python tools/host_boundary_rate.py >> $O/sweep.log 2>&1 ;;
+    prof)
+      (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python3 $R/bench.py --steps 20 --warmup 5 --cpu-seconds 0 --ppo-iters 0 --check-steps 500 > $O/rocprof_bench.log 2>&1) ;;
+    profppo)
+      (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ppo -- python3 $R/tools/ppo_bench.py --policy lstm --envs 4096 --iters 2 --epochs 2 > $O/rocprof_ppo.log 2>&1) ;;
+    pmc)
+      rm -rf $O/pmc_env_*
+      (cd /tmp && export TMPDIR=/tmp
+       for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAIT_ANY SQ_INSTS_VALU_TRANS GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
+         tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
+         timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/pmc_env_$tag -- python3 $R/tools/pmc_workload.py 300 4096 > $O/pmc_env_$tag.log 2>&1
+       done)
+      python tools/pmc_summarize.py $O > $O/pmc_summary.json 2> $O/pmc_summarize.log ;;
+    pmclstm)
+      rm -rf $O/pmc_lstm_*
+      (cd /tmp && export TMPDIR=/tmp
+       for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
+         tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
+         timeout 900 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/pmc_lstm_$tag -- python3 $R/tools/ppo_bench.py --policy lstm --envs 4096 --iters 1 --epochs 1 --serial-stacks > $O/pmc_lstm_$tag.log 2>&1
+       done) ;;
+    ppo)
+      timeout 300 python tools/ppo_bench.py --policy mlp --envs 4096 --iters 3 > $O/ppo_mlp.log 2>&1
+      timeout 300 python tools/ppo_bench.py --policy lstm --envs 4096 --iters 3 > $O/ppo_lstm.log 2>&1 ;;
+    irrl2)
+      RS=high_speed_quadrupedal_locomotion_by_irrl_amd/rsc; mkdir -p $O/irrl2; rm -f $O/irrl2/*
+      timeout 900 python scripts/run_bp_v5.py --train --cfg $RS/bp5_imitation.yaml --num_envs 4096 --l 0.001 --max_iter $((4096*750*300)) --eval_every_n 0 2>&1 | grep -E "nupdates|final checkpoint" | awk 'NR%10==1 || /final/' | cut -c1-330 > $O/irrl2/stage1_imitation.log
+      cp "$(grep "final checkpoint" $O/irrl2/stage1_imitation.log | awk '{print $3}')" $O/irrl2/stage1.pkl
+      timeout 900 python scripts/run_bp_v5.py --train --cfg $RS/default_cfg.yaml --num_envs 4096 --l 0.0005 --max_iter $((4096*750*300)) --eval_every_n 0 --load $O/irrl2/stage1.pkl 2>&1 | grep -E "nupdates|final checkpoint" | awk 'NR%10==1 || /final/' | cut -c1-330 > $O/irrl2/stage2_relaxation.log
+      cp "$(grep "final checkpoint" $O/irrl2/stage2_relaxation.log | awk '{print $3}')" $O/irrl2/stage2.pkl
+      timeout 300 python tools/eval_checkpoint_gpu.py $O/irrl2/stage2.pkl 256 2>&1 | grep -E "rollout|deterministic" > $O/irrl2/eval_stage2.log ;;
+    train200)
+      mkdir -p $O/irrl; rm -f $O/irrl/*.log
+      timeout 1500 python scripts/run_bp_v5.py --train --l 0.001 --max_iter ${MAX_ITER:-200000000} --eval_every_n 0 2>&1 | grep -E "nupdates|final checkpoint" | awk 'NR%25==1 || /final/' | cut -c1-330 > $O/irrl/stage1.log
+      cp "$(grep "final checkpoint" $O/irrl/stage1.log | awk '{print $3}')" $O/irrl/stage1_final.pkl
+      timeout 300 python tools/eval_checkpoint_gpu.py $O/irrl/stage1_final.pkl 256 2>&1 | grep -E "rollout|deterministic" >> $O/irrl/eval.log
+      for c in 1.0 2.0 3.0; do
+        timeout 300 python scripts/run_bp_v5.py --test --model $O/irrl/stage1_final.pkl --cmd $c --steps 2000 2>&1 | grep "^test:" >> $O/irrl/eval.log
+      done ;;
+    variants)
+      V=high_speed_quadrupedal_locomotion_by_irrl_amd/csrc/_variants; rm -f $O/variants.log
+      for r in 1 2; do for f in $V/libirrl_env_*.so; do
+        IRRL_ENV_LIB=$PWD/$f timeout 300 python bench.py ${VARIANT_ARGS} --cpu-seconds 0 --ppo-iters 0 --steps 2000 2>/dev/null | line "$(basename $f .so)" >> $O/variants.log
+      done; done
+      if [ -n "$VARIANTS_PPO" ]; then for f in $V/libirrl_env_*.so; do
+        IRRL_ENV_LIB=$PWD/$f timeout 300 python tools/ppo_bench.py --policy lstm --envs 4096 --iters 3 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$(basename $f .so) ppo rollout', round(d['rollout_s']*1e3,2), 'ms update', round(d['update_s']*1e3,2), 'ms')" >> $O/variants.log
+      done; fi ;;
+    spread)
+      V=high_speed_quadrupedal_locomotion_by_irrl_amd/csrc/_variants; rm -f $O/wave_spread.log
+      IRRL_ENV_LIB=$PWD/$V/libirrl_env_prof.so timeout 300 python tools/wave_spread.py 2>/dev/null | tail -1 >> $O/wave_spread.log
+      IRRL_ENV_LIB=$PWD/$V/libirrl_env_prof.so timeout 300 python tools/wave_spread.py --cfg default_cfg.yaml --sigma 1.0 2>/dev/null | tail -1 >> $O/wave_spread.log ;;
+    ab) "$@" > $O/ab.log 2>&1; echo "rc=$?" >> $O/ab.log; break ;;
+    *) echo "unknown stage $stage" >&2 ;;
+  esac
+done
+echo done

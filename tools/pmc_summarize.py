@@ -1,14 +1,16 @@
-"""Summarise the rocprofv3 --pmc passes of tools/gpu_pmc.sh (gpurun_out/pmc_*/<host>/<pid>_counter_collection.csv, newest
+"""Summarise the rocprofv3 --pmc passes of `tools/gpu.sh pmc` (gpurun_out/pmc_env_*/<host>/<pid>_counter_collection.csv, newest
 file per counter group) into profiles/<name>.json and profiles/pmc_summary_latest.json (read by bench.py for `traffic`).
 FETCH_SIZE / WRITE_SIZE are in KB; the fetch correction is calibrated on the dword-per-lane copy kernel of the same pass
-(MI355X_MICROARCH.md, HBM section).   usage: python tools/pmc_summarize.py r01_pmc_summary_step5"""
+(MI355X_MICROARCH.md, HBM section).  The summary carries the irrl_version() of the library the counters were measured on
+(gpurun_out/pmc_env_version.txt, written by tools/pmc_workload.py on the GPU box): bench.py reports `traffic` / `valu_issue` only
+when that equals the library it is running.   usage: python tools/pmc_summarize.py r01_pmc_summary_step5"""
 import csv, glob, json, os, statistics, sys
 
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 name = sys.argv[1] if len(sys.argv) > 1 else "pmc_summary"
 per = {}
 calib = {}
-for d in sorted(glob.glob(os.path.join(root, "gpurun_out", "pmc_*"))):
+for d in sorted(glob.glob(os.path.join(root, "gpurun_out", "pmc_env_*"))):
     if not os.path.isdir(d):
         continue
     files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
@@ -31,8 +33,9 @@ cal["write_correction"] = copy_bytes / (cal["WRITE_SIZE_KB"] * 1024.0)
 rd = cnt["FETCH_SIZE"]["median_per_launch"] * 1024.0 * cal["fetch_correction"]
 wr = cnt["WRITE_SIZE"]["median_per_launch"] * 1024.0 * cal["write_correction"]
 m = lambda c: cnt[c]["median_per_launch"]
-out = {"envs": 4096, "kernel": step_name,
-       "source": "rocprofv3 --pmc <group> --kernel-trace, one pass per group (tools/gpu_pmc.sh), 4096 envs, 400 launches (100 landing pre-roll + 300), bp5_imitation.yaml, Philox action stream; per-launch medians",
+ver_file = os.path.join(root, "gpurun_out", "pmc_env_version.txt")
+out = {"envs": 4096, "kernel": step_name, "library": open(ver_file).read().strip() if os.path.exists(ver_file) else None,
+       "source": "rocprofv3 --pmc <group> --kernel-trace, one pass per group (tools/gpu.sh pmc), 4096 envs, 400 launches (100 landing pre-roll + 300), bp5_imitation.yaml, Philox action stream; per-launch medians",
        "calibration": cal, "counters": cnt,
        "hbm_bytes_per_launch": {"read": rd, "written": wr, "total": rd + wr, "algorithmic": 1521 * 4096},
        "derived": {"valu_insts_per_wave": m("SQ_INSTS_VALU") / m("SQ_WAVES"), "salu_insts_per_wave": m("SQ_INSTS_SALU") / m("SQ_WAVES"),

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Workload for the rocprofv3 --pmc passes: 1 calibration copy of 256 MiB with dword-per-lane accesses (known byte
+"""Workload for the rocprofv3 --pmc passes (tools/gpu.sh pmc): 1 calibration copy of 256 MiB with dword-per-lane accesses (known byte
 count) followed by N env steps at 4096 envs.  Run once per counter group (TCC slots do not fit FETCH_SIZE and
-WRITE_SIZE in one pass), see tools/gpu_pmc.sh."""
+WRITE_SIZE in one pass).  Writes the measured library's irrl_version() to gpurun_out/pmc_env_version.txt so that
+the summary (tools/pmc_summarize.py) can be tied to the binary it was measured on."""
 import ctypes as C
 import os
 import sys
@@ -18,6 +19,9 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 envs = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 dev = torch.device("cuda", 0)
 lib = _lib.load()
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+with open(os.path.join(ROOT, "gpurun_out", "pmc_env_version.txt"), "w") as f:
+    f.write(_lib.version() + "\n")
 n = 64 * 1024 * 1024  # 256 MiB of floats
 src = torch.ones(n, device=dev)
 dst = torch.empty(n, device=dev)
