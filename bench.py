@@ -205,7 +205,7 @@ def worker(args):
         env_cfg[key] = yaml.safe_load(val)
     n = args.envs
     env_cfg["num_envs"] = n
-    env_cfg["seedd"] = int(env_cfg.get("seedd", 1)) + 7919 * rank   # different robots on every rank
+    env_cfg["EnvIdOffset"] = rank * n   # rank r owns the global env ids r * n .. (r + 1) * n - 1 of the one big pool (same seed everywhere)
     env = FlexibleGymEnv(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY__, yaml.safe_dump(env_cfg), device=local_rank)
     env.init()
     loop_count = int(round(float(env_cfg["control_dt"]) / float(env_cfg["simulation_dt"])))

@@ -63,7 +63,15 @@ def compile_env_unit(src, flags, obj, workdir, verbose=False):
     dev_o, dev_out, fatbin = os.path.join(workdir, tag + ".dev.o"), os.path.join(workdir, tag + ".dev.out"), os.path.join(workdir, tag + ".hipfb")
     ll = llvm_bin()
     cmds = [[hipcc()] + flags + ["--cuda-device-only", "-S", src, "-o", s_raw]]
-    run = lambda c: (print(" ".join(c)) if verbose else None, subprocess.check_call(c, stderr=subprocess.DEVNULL if not verbose else None))
+    def run(c):
+        """quiet unless it fails: the tool's diagnostics (assembler errors included) are kept and shown with the failure"""
+        if verbose:
+            print(" ".join(c))
+        r = subprocess.run(c, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if r.returncode != 0 or verbose:
+            sys.stderr.write(r.stdout.decode("utf-8", "replace"))
+        if r.returncode != 0:
+            raise subprocess.CalledProcessError(r.returncode, c)
     run(cmds[0])
     stats = isa_pass.process_file(s_raw, s_fix)
     if verbose:

@@ -612,14 +612,16 @@ IRRL_DEV v3 solve_contact(const ContactBlock &B, v3 c, v3 n, vf vstar, vf mu, vm
 // FIXED ellipse (xi - xi_c)^T P (xi - xi_c) <= 1, P = (1 - mu^2 beta beta^T) s / mu^2, xi_c = mu^2 beta / s, s = 1 - mu^2 |beta|^2
 // (focus at the origin, eccentricity mu |beta|).  The A-metric projection of xi* onto it: (A + gamma P)(xi - xi_c) = A (xi* - xi_c),
 // gamma >= 0 from (xi - xi_c)^T P (xi - xi_c) = 1, i.e. p(gamma) / sqrt(r(gamma)) = sigma with p = det(A + gamma P), r a quadratic,
-// sigma = |xi* - xi_c| -- concave and increasing, so IRRL_MD_NEWTON Newton steps from gamma = 0 are monotone (3-4 reach f32).
+// sigma = |xi* - xi_c| -- concave and increasing, so Newton is monotone after its first step from any start; the start is the root
+// of the isotropic problem along the far point's direction d, gamma_0 = a (sigma sqrt(rho) - 1) / rho (a = d^T A d, rho = d^T P d),
+// and IRRL_MD_NEWTON = 2 steps from there are converged to 2e-9 (f64) on the robot's own sliding problems.
 // Caps (not reached on the shipped configurations, mu |beta| <= 0.86 there): eccentricity above sqrt(1 - SMIN) (the conic turns
 // into a parabola / hyperbola at the jamming corner) -> beta shortened in the cone section; sigma > SIGMAX (a barely pressing
 // contact sliding fast, impulse ~1e-4 of a pressing one) -> far point pulled in; mu < MUMIN -> frictionless, lam = alpha n.
 // Everything that depends only on (G, n, mu) is per-substep (ContactBlockMD); the CPU restatement the parity tests compare with
 // runs the same steps with the same constants.
 // ---------------------------------------------------------------------------------------------
-#define IRRL_MD_NEWTON 4
+#define IRRL_MD_NEWTON 2
 #define IRRL_MD_SMIN 0.04f
 #define IRRL_MD_SIGMAX 1.0e4f
 #define IRRL_MD_MUMIN 1.0e-6f
@@ -650,7 +652,7 @@ IRRL_DEV ContactBlockMD make_contact_block_md(sym3 G, v3 n, vf mu_in) {
   B.zc1 = mu * e1 * is; B.zc2 = mu * e2 * is;
   return B;
 }
-IRRL_DEV v3 solve_contact_md(const ContactBlockMD &B, v3 c, v3 n, vf vstar, vf mu_in) {
+IRRL_DEV v3 solve_contact_md(const ContactBlockMD &B, v3 c, v3 n, vf vstar, vf mu_in, vm relevant) {
   const vf cn = dot(c, n) - vstar;
   const vm sep = cn >= 0.0f;
   const vf alpha = -cn * B.ignn;
@@ -658,37 +660,44 @@ IRRL_DEV v3 solve_contact_md(const ContactBlockMD &B, v3 c, v3 n, vf vstar, vf m
   const vf x1 = -(B.A22 * b1 - B.A12 * b2) * B.idetA, x2 = -(B.A11 * b2 - B.A12 * b1) * B.idetA;
   const vf ln = alpha + B.be1 * x1 + B.be2 * x2;
   const vm sticking = (x1 * x1 + x2 * x2 <= B.mu * B.mu * ln * ln) & (ln > 0.0f);
-  // slipping
-  const vf ia = v_rcp(v_max(alpha, 1e-30f));
-  vf d1 = x1 * ia - B.zc1, d2 = x2 * ia - B.zc2;
-  const vf s2 = d1 * d1 + d2 * d2;
-  const vf isg = v_rsqrt(v_max(s2, 1e-30f));
-  const vf sig = v_min(s2 * isg, IRRL_MD_SIGMAX);
-  d1 = d1 * isg; d2 = d2 * isg;
-  const vf w1 = B.A11 * d1 + B.A12 * d2, w2 = B.A12 * d1 + B.A22 * d2;
-  const vf u1 = B.detA * d1, u2 = B.detA * d2;
-  const vf q1 = B.P22 * w1 - B.P12 * w2, q2 = B.P11 * w2 - B.P12 * w1;
-  const vf Pu1 = B.P11 * u1 + B.P12 * u2, Pu2 = B.P12 * u1 + B.P22 * u2, Pq1 = B.P11 * q1 + B.P12 * q2, Pq2 = B.P12 * q1 + B.P22 * q2;
-  const vf c0 = u1 * Pu1 + u2 * Pu2, c1 = 2.0f * (q1 * Pu1 + q2 * Pu2), c2 = q1 * Pq1 + q2 * Pq2;
-  vf gam = 0.0f;
-#pragma unroll
-  for (int it = 0; it < IRRL_MD_NEWTON; it++) {
-    const vf p = (B.detP * gam + B.mix) * gam + B.detA, r = (c2 * gam + c1) * gam + c0;
-    const vf dp = 2.0f * B.detP * gam + B.mix, dr = 2.0f * c2 * gam + c1;
-    gam += r * (sig * v_sqrt(r) - p) * v_rcp(dp * r - 0.5f * p * dr);
-  }
-  const vf kk = sig * v_rcp((B.detP * gam + B.mix) * gam + B.detA);
-  vf X1 = alpha * ((u1 + gam * q1) * kk + B.zc1), X2 = alpha * ((u2 + gam * q2) * kk + B.zc2);
   const vm frictionless = mu_in <= IRRL_MD_MUMIN;
-  X1 = vsel(sticking, x1, vsel(frictionless, 0.0f, X1));
-  X2 = vsel(sticking, x2, vsel(frictionless, 0.0f, X2));
+  vf X1 = vsel(frictionless, 0.0f, x1), X2 = vsel(frictionless, 0.0f, x2);
+  // slipping (wave-uniform skip when no contact whose result is kept slides -- feet standing still, the others in flight: 2.2 us
+  // of the step at 4096 envs, same box A/B)
+  if (wave_any(relevant & !sep & !sticking & !frictionless)) {
+    const vf ia = v_rcp(v_max(alpha, 1e-30f));
+    vf d1 = x1 * ia - B.zc1, d2 = x2 * ia - B.zc2;
+    const vf s2 = d1 * d1 + d2 * d2;
+    const vf isg = v_rsqrt(v_max(s2, 1e-30f));
+    const vf sig = v_min(s2 * isg, IRRL_MD_SIGMAX);
+    d1 = d1 * isg; d2 = d2 * isg;
+    const vf w1 = B.A11 * d1 + B.A12 * d2, w2 = B.A12 * d1 + B.A22 * d2;
+    const vf u1 = B.detA * d1, u2 = B.detA * d2;
+    const vf q1 = B.P22 * w1 - B.P12 * w2, q2 = B.P11 * w2 - B.P12 * w1;
+    const vf Pu1 = B.P11 * u1 + B.P12 * u2, Pu2 = B.P12 * u1 + B.P22 * u2, Pq1 = B.P11 * q1 + B.P12 * q2, Pq2 = B.P12 * q1 + B.P22 * q2;
+    const vf c0 = u1 * Pu1 + u2 * Pu2, c1 = 2.0f * (q1 * Pu1 + q2 * Pu2), c2 = q1 * Pq1 + q2 * Pq2;
+    const vf rho = c0 * B.idetA * B.idetA;
+    vf gam = v_max((w1 * d1 + w2 * d2) * (sig * v_sqrt(rho) - 1.0f) * v_rcp(rho), 0.0f);
+#pragma unroll
+    for (int it = 0; it < IRRL_MD_NEWTON; it++) {
+      const vf p = (B.detP * gam + B.mix) * gam + B.detA, r = (c2 * gam + c1) * gam + c0;
+      const vf dp = 2.0f * B.detP * gam + B.mix, dr = 2.0f * c2 * gam + c1;
+      gam += r * (sig * v_sqrt(r) - p) * v_rcp(dp * r - 0.5f * p * dr);
+    }
+    const vf kk = sig * v_rcp((B.detP * gam + B.mix) * gam + B.detA);
+    const vm slide = !sticking & !frictionless;
+    X1 = vsel(slide, alpha * ((u1 + gam * q1) * kk + B.zc1), X1);
+    X2 = vsel(slide, alpha * ((u2 + gam * q2) * kk + B.zc2), X2);
+  }
   const vf lnn = vsel(sep, 0.0f, alpha + B.be1 * X1 + B.be2 * X2);   // normal velocity condition exact
   X1 = vsel(sep, 0.0f, X1); X2 = vsel(sep, 0.0f, X2);
   return mk3(X1 * B.t1.x + X2 * B.t2.x + lnn * n.x, X1 * B.t1.y + X2 * B.t2.y + lnn * n.y, X1 * B.t1.z + X2 * B.t2.z + lnn * n.z);
 }
-// a contact that is solved once (trunk-box corners, meteorite): block + solve in one go, by the pool's rule (wave-uniform)
-IRRL_DEV v3 solve_contact_once(const EnvParams &P, sym3 G, v3 c, v3 n, vf vstar, vf mu, vm relevant) {
-  if (P.contact_rule) return solve_contact_md(make_contact_block_md(G, n, mu), c, n, vstar, mu);
+// a contact that is solved once (trunk-box corners, meteorite): block + solve in one go, by the pool's rule (RULE: compile time --
+// the step kernel is instantiated once per rule, so neither rule's live values weigh on the other's register allocation)
+template <int RULE>
+IRRL_DEV v3 solve_contact_once(sym3 G, v3 c, v3 n, vf vstar, vf mu, vm relevant) {
+  if (RULE) return solve_contact_md(make_contact_block_md(G, n, mu), c, n, vstar, mu, relevant);
   return solve_contact(make_contact_block(G, n), c, n, vstar, mu, relevant);
 }
 
@@ -815,15 +824,15 @@ IRRL_DEV bool box_setup(const EnvParams &P, const EnvLane &L, const rot3 &R, con
 // Y^T lambda (replicated).  Adds |dlambda|^2 to dd in the owner lane; updates B.lam and the replicated B.zc.
 // One corner of the pass (compile-time CB: its owner lane is a DPP broadcast source): the corner sees the velocity the toes and
 // the corners before it have produced, solves its single-contact problem exactly and is applied at once (B.zc advances).
-template <int CB>
-IRRL_DEV void box_corner_step(const EnvParams &P, BoxContacts &B, vf mu) {
+template <int RULE, int CB>
+IRRL_DEV void box_corner_step(BoxContacts &B, vf mu) {
   constexpr int j = (IRRL_NCPL == 2) ? (CB & 1) : 0;
   const vm mine = B.own[j] & (B.id[j] == CB);
   if (!wave_any(mine)) return;
   v3 c = B.cfree[j];
 #pragma unroll
   for (int i = 0; i < 6; i++) { c.x += B.Y[j][0][i] * B.zc[i]; c.y += B.Y[j][1][i] * B.zc[i]; c.z += B.Y[j][2][i] * B.zc[i]; }
-  v3 ln = solve_contact_once(P, B.G[j], c, B.n[j], B.vstar[j], mu, mine);
+  v3 ln = solve_contact_once<RULE>(B.G[j], c, B.n[j], B.vstar[j], mu, mine);
   v3 dl = mk3(vsel(mine, ln.x, 0.0f), vsel(mine, ln.y, 0.0f), vsel(mine, ln.z, 0.0f));
   // zc += Y^T dl of the owner lane, broadcast to the robot's lanes
 #ifdef IRRL_L16
@@ -837,11 +846,12 @@ IRRL_DEV void box_corner_step(const EnvParams &P, BoxContacts &B, vf mu) {
 // THE TRUNK-BOX PASS: one pass of sequential impulses over the touching corners (0..7, cold start) behind the toe iteration.
 // ub: base twist with the toe impulses already applied.  -> dxb: the change of the base twist the corner impulses cause (the
 // caller adds it to ub and takes D dxb off the joint rates); false when no corner of the wave's robots touches.
+template <int RULE>
 IRRL_DEV bool box_pass(const EnvParams &P, const EnvLane &L, const rot3 &R, const vf L6[21], const vf ub[6], v3 vB, v3 wB, vf dxb[6]) {
   BoxContacts B;
   if (!box_setup(P, L, R, L6, ub, vB, wB, B)) return false;
-  box_corner_step<0>(P, B, L.m.mu); box_corner_step<1>(P, B, L.m.mu); box_corner_step<2>(P, B, L.m.mu); box_corner_step<3>(P, B, L.m.mu);
-  box_corner_step<4>(P, B, L.m.mu); box_corner_step<5>(P, B, L.m.mu); box_corner_step<6>(P, B, L.m.mu); box_corner_step<7>(P, B, L.m.mu);
+  box_corner_step<RULE, 0>(B, L.m.mu); box_corner_step<RULE, 1>(B, L.m.mu); box_corner_step<RULE, 2>(B, L.m.mu); box_corner_step<RULE, 3>(B, L.m.mu);
+  box_corner_step<RULE, 4>(B, L.m.mu); box_corner_step<RULE, 5>(B, L.m.mu); box_corner_step<RULE, 6>(B, L.m.mu); box_corner_step<RULE, 7>(B, L.m.mu);
 #pragma unroll
   for (int i = 0; i < 6; i++) dxb[i] = B.zc[i];
   l6_bwd(L6, dxb);
@@ -874,6 +884,7 @@ IRRL_DEV void sphere_release(EnvLane &L, vm m) {
 //     centre, normal from the sphere into the box; Delassus block = K M^-1 K^T of q (base only, K = [1 | -[q]x]) + 1 / m_s;
 //   sphere - ground (this env's default material pair), block 1 / m_s;
 // then the sphere integrates (semi-implicit Euler).  ub: base twist so far; -> dxb: what the sphere does to it (false: nothing).
+template <int RULE>
 IRRL_DEV bool sphere_pass(const EnvParams &P, EnvLane &L, const rot3 &R, const vf L6[21], const vf ub[6], v3 vB, v3 wB, vf dxb[6]) {
   const float dt = P.sim_dt;
   const vm dyn = L.sdyn != 0;
@@ -911,7 +922,7 @@ IRRL_DEV bool sphere_pass(const EnvParams &P, EnvLane &L, const rot3 &R, const v
     v3 pre = vB + cross(wB, qB) - svB_pre;
     vf vn = dot(pre, n);
     vf vs = vsel(vn < -0.001f, -0.95f * vn, 0.0f);
-    v3 lam = solve_contact_once(P, G, c, n, vs, 0.0f, hit);
+    v3 lam = solve_contact_once<RULE>(G, c, n, vs, 0.0f, hit);
     lam = mk3(vsel(hit, lam.x, 0.0f), vsel(hit, lam.y, 0.0f), vsel(hit, lam.z, 0.0f));
 #pragma unroll
     for (int i = 0; i < 6; i++) dxb[i] = Y[0][i] * lam.x + Y[1][i] * lam.y + Y[2][i] * lam.z;
@@ -928,7 +939,7 @@ IRRL_DEV bool sphere_pass(const EnvParams &P, EnvLane &L, const rot3 &R, const v
       sym3 G; G.xx = ms_inv; G.xy = 0.0f; G.xz = 0.0f; G.yy = ms_inv; G.yz = 0.0f; G.zz = ms_inv;
       vf vn = dot(sv_pre, nw);
       vf vs = vsel(vn < -L.m.rest_thr, -L.m.rest * vn, 0.0f);
-      v3 lam = solve_contact_once(P, G, L.sv, nw, vs, L.m.mu, gnd);
+      v3 lam = solve_contact_once<RULE>(G, L.sv, nw, vs, L.m.mu, gnd);
       L.sv.x = vsel(gnd, L.sv.x + ms_inv * lam.x, L.sv.x); L.sv.y = vsel(gnd, L.sv.y + ms_inv * lam.y, L.sv.y); L.sv.z = vsel(gnd, L.sv.z + ms_inv * lam.z, L.sv.z);
     }
   }
@@ -948,6 +959,7 @@ IRRL_DEV bool sphere_pass(const EnvParams &P, EnvLane &L, const rot3 &R, const v
 // inertias / subtree forces are SUFFIX SUMS over the quad (2 DPP adds), sums over legs are row rotations.
 // Values tagged (R) are replicated in the quad, (D) differ per sub-lane.
 // ---------------------------------------------------------------------------------------------
+template <int RULE>
 IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
   const float dt = P.sim_dt;
   const vi sub = sub_id();
@@ -1193,9 +1205,9 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     sym3 G;
     G.xx = sub_bcast<0>(gr[0]); G.xy = sub_bcast<0>(gr[1]); G.xz = sub_bcast<0>(gr[2]);
     G.yy = sub_bcast<1>(gr[1]); G.yz = sub_bcast<1>(gr[2]); G.zz = sub_bcast<2>(gr[2]);
-    // per-substep constants of the single-contact solve, by the pool's rule (wave-uniform; the other block is never read)
+    // per-substep constants of the single-contact solve, by the pool's rule (compile time; the other block does not exist)
     ContactBlock CB; ContactBlockMD CM;
-    if (P.contact_rule) CM = make_contact_block_md(G, nB, L.m.mu); else CB = make_contact_block(G, nB);
+    if (RULE) CM = make_contact_block_md(G, nB, L.m.mu); else CB = make_contact_block(G, nB);
     // contact-point velocity rows: before the step (restitution) and free
     vf ul0 = sub_bcast<0>(ul_s), ul1 = sub_bcast<1>(ul_s), ul2 = sub_bcast<2>(ul_s);
     vf vpre_r = jl0 * L.qd[0] + jl1 * L.qd[1] + jl2 * L.qd[2] + jb[0] * vB.x + jb[1] * vB.y + jb[2] * vB.z + jb[3] * wB.x + jb[4] * wB.y + jb[5] * wB.z;
@@ -1250,7 +1262,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
         cvr = legs_rot_fma<3>(lam.z, gx3[2], legs_rot_fma<3>(lam.y, gx3[1], legs_rot_fma<3>(lam.x, gx3[0], cvr)));
         v3 cv = mk3(sub_bcast<0>(cvr), sub_bcast<1>(cvr), sub_bcast<2>(cvr));
         vm commit = jacobi ? active : (active & (rank == rk));
-        v3 ln = P.contact_rule ? solve_contact_md(CM, cv, nB, vstar, L.m.mu) : solve_contact(CB, cv, nB, vstar, L.m.mu, commit);
+        v3 ln = RULE ? solve_contact_md(CM, cv, nB, vstar, L.m.mu, commit) : solve_contact(CB, cv, nB, vstar, L.m.mu, commit);
         v3 dl = mk3(vsel(commit, ln.x - lam.x, 0.0f), vsel(commit, ln.y - lam.y, 0.0f), vsel(commit, ln.z - lam.z, 0.0f));
         lam = lam + dl;
         d2 += dot(dl, dl);
@@ -1286,7 +1298,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
   // trunk-box corners (rare: robots falling over, rough terrain): one pass of sequential impulses behind the toe iteration
   if (IRRL_UNLIKELY(box_near)) {
     vf dxb[6];
-    if (box_pass(P, L, R, D.L6, ub, vB, wB, dxb)) {
+    if (box_pass<RULE>(P, L, R, D.L6, ub, vB, wB, dxb)) {
 #ifdef IRRL_PROFILE_WAVES
       L.prof_flags |= 2;
 #endif
@@ -1296,7 +1308,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
   }
   if (IRRL_UNLIKELY(IRRL_CRUTIAL(P)) && wave_any(L.sdyn != 0)) {
     vf dxb[6];
-    if (sphere_pass(P, L, R, D.L6, ub, vB, wB, dxb)) {
+    if (sphere_pass<RULE>(P, L, R, D.L6, ub, vB, wB, dxb)) {
 #pragma unroll
       for (int i = 0; i < 6; i++) { ub[i] += dxb[i]; ul_s -= Xs[i] * dxb[i]; }
     }
@@ -1326,6 +1338,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
 #undef PICK3
 }
 #else
+template <int RULE>
 IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
   const float dt = P.sim_dt;
   // PD law, 1 % blend with the normalised torque_last, speed-dependent clamp
@@ -1411,7 +1424,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
       }
     sym3 G; G.xx = Gm[0][0]; G.xy = Gm[0][1]; G.xz = Gm[0][2]; G.yy = Gm[1][1]; G.yz = Gm[1][2]; G.zz = Gm[2][2];
     ContactBlock CB; ContactBlockMD CM;
-    if (P.contact_rule) CM = make_contact_block_md(G, nB, L.m.mu); else CB = make_contact_block(G, nB);
+    if (RULE) CM = make_contact_block_md(G, nB, L.m.mu); else CB = make_contact_block(G, nB);
     // contact-point velocities: before the step (restitution) and free
     vf vpre[3], cfree[3];
     const vf upre[6] = {vB.x, vB.y, vB.z, wB.x, wB.y, wB.z};
@@ -1452,7 +1465,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
           cv.x += Y[0][i] * o; cv.y += Y[1][i] * o; cv.z += Y[2][i] * o;
         }
         vm commit = jacobi ? active : (active & (rank == rk));
-        v3 ln = P.contact_rule ? solve_contact_md(CM, cv, nB, vstar, L.m.mu) : solve_contact(CB, cv, nB, vstar, L.m.mu, commit);
+        v3 ln = RULE ? solve_contact_md(CM, cv, nB, vstar, L.m.mu, commit) : solve_contact(CB, cv, nB, vstar, L.m.mu, commit);
         v3 dl = mk3(vsel(commit, ln.x - lam.x, 0.0f), vsel(commit, ln.y - lam.y, 0.0f), vsel(commit, ln.z - lam.z, 0.0f));
         lam = lam + dl;
         d2 += dot(dl, dl);
@@ -1492,7 +1505,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
   // trunk-box corners (rare: robots falling over, rough terrain): one pass of sequential impulses behind the toe iteration
   if (IRRL_UNLIKELY(box_near)) {
     vf dxb[6];
-    if (box_pass(P, L, R, D.L6, ub, vB, wB, dxb)) {
+    if (box_pass<RULE>(P, L, R, D.L6, ub, vB, wB, dxb)) {
 #pragma unroll
       for (int i = 0; i < 6; i++) {
         ub[i] += dxb[i];
@@ -1503,7 +1516,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
   }
   if (IRRL_UNLIKELY(IRRL_CRUTIAL(P)) && wave_any(L.sdyn != 0)) {
     vf dxb[6];
-    if (sphere_pass(P, L, R, D.L6, ub, vB, wB, dxb)) {
+    if (sphere_pass<RULE>(P, L, R, D.L6, ub, vB, wB, dxb)) {
 #pragma unroll
       for (int i = 0; i < 6; i++) {
         ub[i] += dxb[i];
@@ -2047,7 +2060,8 @@ IRRL_DEV void observe_lane(const EnvParams &P, vi env, vi leg, vm valid, EnvLane
 struct NoStepHook { IRRL_DEV void operator()() const {} };
 // `before_substeps` runs once between the step prologue (all of this step's global loads are behind it) and the substep loop:
 // the fused env + policy kernel starts its LDS prefetch of the policy weights there (env_kernels.hip)
-template <class Hook = NoStepHook>
+// RULE: the per-contact rule of the pool (EnvParams::contact_rule), a compile-time constant of the instantiation the launcher picks
+template <int RULE, class Hook = NoStepHook>
 IRRL_DEV void step_body(const EnvParams &P, const EnvState &S, vi env, vi leg, vm valid, const float *action, float *ob_out,
                         float *reward_out, uint8_t *done_out, float *extra_out, Hook before_substeps = Hook()) {
   EnvLane L;
@@ -2055,7 +2069,7 @@ IRRL_DEV void step_body(const EnvParams &P, const EnvState &S, vi env, vi leg, v
 #ifdef IRRL_PROFILE_WAVES
   L.prof_ranksteps = 0; L.prof_flags = 0;
 #endif
-  vu envu = to_u(env);
+  vu envu = to_u(env) + P.env_id_offset;   // RNG address: the GLOBAL env id
   // ENV:700-708
   vf pT[3];
 #ifdef IRRL_L16
@@ -2141,7 +2155,7 @@ IRRL_DEV void step_body(const EnvParams &P, const EnvState &S, vi env, vi leg, v
     }
   }
   before_substeps();
-  for (int i = 0; i < P.loop_count; i++) physics_substep(P, L, pT);
+  for (int i = 0; i < P.loop_count; i++) physics_substep<RULE>(P, L, pT);
   // The epilogue is per-leg work: with four sub-lanes per leg it would be executed four times over.  Only sub-lane 0
   // (the lane that owns the stores) runs it -- same issue time, a quarter of the active lanes, which is what the
   // power-limited clock of a fully occupied chip responds to.  All cross-leg DPP traffic below is between sub-lanes 0.
@@ -2222,9 +2236,9 @@ IRRL_DEV void init_body(const EnvParams &P, const EnvState &S, vi env, vi leg, v
   L.t0 = 0.0f; L.frame = 0; L.episode = 0u; L.up_height = P.up_height_max;
   L.sp = mk3(0.0f, 0.0f, 0.0f); L.sv = mk3(0.0f, 0.0f, 0.0f); L.srad = 0.0f; L.smass = 0.0f; L.sdyn = 0;
   L.bodyLinVel = mk3(0.0f, 0.0f, 0.0f); L.bodyAngVel = mk3(0.0f, 0.0f, 0.0f);
-  if (P.stochastic) model_randomize(L.m, leg, P.seed, to_u(env), 0u); else model_nominal(L.m, leg);
+  if (P.stochastic) model_randomize(L.m, leg, P.seed, to_u(env) + P.env_id_offset, 0u); else model_nominal(L.m, leg);
   L.jr[0] = L.m.sy * P.abad;  // ENV:415-418
-  reset_lane(P, L, to_u(env));
+  reset_lane(P, L, to_u(env) + P.env_id_offset);
   store_lane(P, S, env, leg, valid, L, true);
 }
 
@@ -2232,7 +2246,7 @@ IRRL_DEV void init_body(const EnvParams &P, const EnvState &S, vi env, vi leg, v
 IRRL_DEV void reset_body(const EnvParams &P, const EnvState &S, vi env, vi leg, vm valid, float *ob_out) {
   EnvLane L;
   load_lane(P, S, env, leg, L);
-  reset_lane(P, L, to_u(env));
+  reset_lane(P, L, to_u(env) + P.env_id_offset);
   observe_lane(P, env, leg, valid, L, ob_out);
   store_lane(P, S, env, leg, valid, L, P.randomize_per_episode != 0);
 }

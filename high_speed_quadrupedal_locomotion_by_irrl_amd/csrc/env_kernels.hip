@@ -55,20 +55,28 @@
 
 extern "C" {
 
-// pools with Crutial: True (the launcher picks by EnvParams::crutial)
-__global__ void __launch_bounds__(256, 1)
-IRRL_K(irrl_step_kernel_crutial)(EnvParams P, EnvState S, const float *action, float *ob, float *reward, uint8_t *done, float *extra) {
-  IRRL_LANE_PROLOGUE
-  irrl::step_body(P, S, env_, leg_, valid_, action, ob, reward, done, extra);
-}
+// The step kernel exists once per (Crutial, per-contact rule): the launcher picks by EnvParams::crutial / ::contact_rule.  Suffix
+// _md = the published maximum-dissipation rule of RaiSim's solver (ContactSolver bit 0, the shipped default), none = the build's
+// first sliding rule.  (One kernel deciding by a run-time flag cost the OTHER rule's path 6 us of a 37 us step: both rules'
+// per-substep constants were live across the sweep loop and the allocator paid for them in AGPR copies.)
+#define IRRL_STEP_KERNEL(NAME, NS, RULE)                                                                                           \
+  __global__ void __launch_bounds__(256, 1)                                                                                        \
+  IRRL_K(NAME)(EnvParams P, EnvState S, const float *action, float *ob, float *reward, uint8_t *done, float *extra) {               \
+    IRRL_LANE_PROLOGUE                                                                                                             \
+    NS::step_body<RULE>(P, S, env_, leg_, valid_, action, ob, reward, done, extra);                                                \
+  }
+IRRL_STEP_KERNEL(irrl_step_kernel_crutial, irrl, 0)
+IRRL_STEP_KERNEL(irrl_step_kernel_crutial_md, irrl, 1)
+IRRL_STEP_KERNEL(irrl_step_kernel_dir, irrl_plain, 0)
 
+// the default pool: no meteorite, published rule
 __global__ void __launch_bounds__(256, 1)
 IRRL_K(irrl_step_kernel)(EnvParams P, EnvState S, const float *action, float *ob, float *reward, uint8_t *done, float *extra) {
   IRRL_LANE_PROLOGUE
 #ifdef IRRL_PROFILE_WAVES   /* diagnostic build (tools/wave_spread.py): extra[env][5] <- this wave's duration in 100 MHz ticks */
   const unsigned long long t0_ = wall_clock64();
 #endif
-  irrl_plain::step_body(P, S, env_, leg_, valid_, action, ob, reward, done, extra);
+  irrl_plain::step_body<1>(P, S, env_, leg_, valid_, action, ob, reward, done, extra);
 #ifdef IRRL_PROFILE_WAVES
   const unsigned long long t1_ = wall_clock64();
   if (valid_ && leg_ == 0) extra[env_ * 6 + 5] = (float)(t1_ - t0_);
@@ -78,7 +86,7 @@ IRRL_K(irrl_step_kernel)(EnvParams P, EnvState S, const float *action, float *ob
 #if IRRL_LANES_PER_ROBOT == 16
 // ONE ROLLOUT STEP IN ONE LAUNCH: env.step of 16 robots (the workgroup's four waves, four robots each: the step kernel's body
 // unchanged) and, behind a workgroup barrier, the LSTM policy's step on the observations those 16 robots just produced (one
-// MFMA M-tile; policy_step.hpp with two virtual waves per wave).  `action` is what the previous launch's policy part wrote
+// MFMA M-tile; policy_step.hpp with two virtual waves per wave).  Published contact rule only (the launcher falls back otherwise).  `action` is what the previous launch's policy part wrote
 // for these robots (a.clipped), `ob` / `done` / `reward` are a.obs / a.dones / a.prev_reward: nothing a workgroup touches
 // belongs to another workgroup, so the only synchronisation is the barrier.  Against two launches per step this removes a
 // launch boundary and hides the layer-0 weight fetch -- and still MEASURES SLOWER (62.9 against 58.2 us per step at 4096 envs,
@@ -98,7 +106,7 @@ irrl_step_policy_kernel_l16(EnvParams P, EnvState S, const float *action, float 
     IRRL_LANE_PROLOGUE
     // the env part keeps no LDS and, between its prologue and its epilogue, issues no global load (flat ground): the layer-0
     // policy weights travel L2 -> LDS underneath the eight substeps
-    irrl_plain::step_body(P, S, env_, leg_, valid_, action, ob, reward, done, extra, [&]() { policy_prefetch_lds<48, 256>(a, lds_w); });
+    irrl_plain::step_body<1>(P, S, env_, leg_, valid_, action, ob, reward, done, extra, [&]() { policy_prefetch_lds<48, 256>(a, lds_w); });
   }
 #ifdef IRRL_PROFILE_POLICY
   const unsigned long long pt1_ = wall_clock64();

@@ -9,6 +9,9 @@ struct EnvParams {
   int32_t n_envs;
   int32_t loop_count;      // int(control_dt / simulation_dt + 1e-10), Environment.hpp:711
   uint32_t seed;           // seedd
+  uint32_t env_id_offset;  // [ext] EnvIdOffset: global id of this pool's env 0 -- every random draw is addressed by (seed, GLOBAL env id,
+                           //       episode, step, purpose), so rank r of an N-GPU job (offset r * num_envs) owns exactly the robots r * num_envs ..
+                           //       of the one big pool: results do not depend on how the envs are sharded over GPUs
   int32_t contact_iters;   // [ext] ContactIterations
   float sim_dt, control_dt, max_time;
   float abad, period, lam, stand_height, up_height_max;

@@ -104,6 +104,20 @@ inline void derive_params(EnvParams &P) {
   P.two_pi_over_period = 2.0f * 3.1415926f / P.period;
 }
 
+// the frame cadences the reference evaluates with the LIVE control_dt_, in double (Environment.hpp:733 `frame_idx % int(5 * period_ /
+// control_dt_)` for the meteorite, :747 `int(period_ / control_dt_ * 10)` for state_disturbance) -- and the flags that depend on
+// them.  Called by build_params and again by the control-dt setter (VectorizedEnvironment::setControlTimeStep).
+inline void derive_cadences(const Config &c, double control_dt, EnvParams &P) {
+  double period = 0.0;
+  bool crutial = false, force = false;
+  std::string e;
+  c.get_double("period", period, e); c.get_bool("Crutial", crutial, e); c.get_bool("ForceDisturbance", force, e);
+  P.attack_every = control_dt > 0.0 ? (int32_t)(5.0 * period / control_dt) : 0;
+  P.crutial = (crutial && P.attack_every > 0) ? 1 : 0;
+  P.disturb_every = control_dt > 0.0 ? (int32_t)(period / control_dt * 10.0) : 0;
+  P.state_disturbance = (force && P.manual && P.disturb_every > 0) ? 1 : 0;
+}
+
 inline bool build_params(const Config &c, EnvParams &P, std::string &err) {
   for (const char *k : kMandatoryKeys)
     if (!c.has(k)) { err = std::string("Node cfg[\"") + k + "\"] doesn't exist"; return false; }
@@ -116,6 +130,7 @@ inline bool build_params(const Config &c, EnvParams &P, std::string &err) {
   P.control_dt = (float)control_dt;
   P.loop_count = (int32_t)(control_dt / sim_dt + 1e-10);  // Environment.hpp:711
   P.seed = (uint32_t)(int32_t)num("seedd");
+  P.env_id_offset = c.has("EnvIdOffset") ? (uint32_t)(int64_t)num("EnvIdOffset") : 0u;   // [ext] global id of env 0 (multi-GPU shards)
   P.max_time = (float)num("max_time");
   P.abad = (float)num("abad"); P.period = (float)num("period"); P.lam = (float)num("lam");
   P.stand_height = (float)num("stand_height"); P.up_height_max = (float)num("up_height");
@@ -166,12 +181,9 @@ inline bool build_params(const Config &c, EnvParams &P, std::string &err) {
   if (P.n_envs <= 0) { err = "num_envs must be positive"; return false; }
   if (P.loop_count <= 0) { err = "control_dt / simulation_dt must be >= 1"; return false; }
   const bool crutial = flag("Crutial"), terrain = flag("Terrain"), manual_traj = flag("ManualTraj"), force = flag("ForceDisturbance");
-  P.crutial = crutial ? 1 : 0;
   {
-    const double cubes = num("CubeNum"), period = num("period");
+    const double cubes = num("CubeNum");
     P.cube_num = (float)(cubes > 0.0 ? (double)(int)cubes : 1.0);
-    P.attack_every = control_dt > 0.0 ? (int32_t)(5.0 * period / control_dt) : 0;   // Environment.hpp:733
-    if (P.attack_every <= 0) P.crutial = 0;
   }
   P.terrain = terrain ? 1 : 0;  // the table itself is attached by the owner of the pool (irrl_terrain.hpp)
   P.hf_nx = 5000; P.hf_ny = 500;  // Environment.hpp:259-260
@@ -182,14 +194,8 @@ inline bool build_params(const Config &c, EnvParams &P, std::string &err) {
   P.ref_rows = 0; P.ref = nullptr;
   // ForceDisturbance: with Manual it is state_disturbance (ENV:912-940, built); without Manual it is force_attack, whose trigger
   // `random() < 2 dt / T` (ENV:751) compares a 31-bit integer with a number < 1 and never fires -> nothing to build
-  P.state_disturbance = (force && P.manual) ? 1 : 0;
-  {
-    double period = 0.0, cdt = 0.0;
-    std::string e2;
-    c.get_double("period", period, e2); c.get_double("control_dt", cdt, e2);
-    P.disturb_every = cdt > 0.0 ? (int32_t)(period / cdt * 10.0) : 0;
-    if (P.disturb_every <= 0) P.state_disturbance = 0;
-  }
+  (void)crutial; (void)force;
+  derive_cadences(c, control_dt, P);
   derive_params(P);
   return true;
 }

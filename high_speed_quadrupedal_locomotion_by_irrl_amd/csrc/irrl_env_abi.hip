@@ -15,7 +15,9 @@
 //          throughput once the pool is large enough to occupy the chip on its own
 #define IRRL_DECLARE_KERNELS(sfx)                                                                                            \
   extern "C" __global__ void irrl_step_kernel##sfx(EnvParams, EnvState, const float *, float *, float *, uint8_t *, float *);   \
+  extern "C" __global__ void irrl_step_kernel_dir##sfx(EnvParams, EnvState, const float *, float *, float *, uint8_t *, float *); \
   extern "C" __global__ void irrl_step_kernel_crutial##sfx(EnvParams, EnvState, const float *, float *, float *, uint8_t *, float *); \
+  extern "C" __global__ void irrl_step_kernel_crutial_md##sfx(EnvParams, EnvState, const float *, float *, float *, uint8_t *, float *); \
   extern "C" __global__ void irrl_init_kernel##sfx(EnvParams, EnvState);                                                       \
   extern "C" __global__ void irrl_reset_kernel##sfx(EnvParams, EnvState, float *);                                             \
   extern "C" __global__ void irrl_observe_kernel##sfx(EnvParams, EnvState, float *);                                           \
@@ -97,11 +99,14 @@ static int pick_lanes(int n_envs) {
     else hipLaunchKernelGGL(name##_l4, grid, quad_block(), 0, (h)->stream, __VA_ARGS__);                                   \
   } while (0)
 
-// the step kernel: pools with Crutial: True run the instantiation that carries the meteorite (env_kernels.hip)
+// the step kernel: one instantiation per (Crutial, per-contact rule) -- env_kernels.hip
 #define IRRL_LAUNCH_STEP(h, grid, ...)                                                                                      \
   do {                                                                                                                    \
-    if ((h)->P.crutial) IRRL_LAUNCH(h, irrl_step_kernel_crutial, grid, __VA_ARGS__);                                         \
-    else IRRL_LAUNCH(h, irrl_step_kernel, grid, __VA_ARGS__);                                                                \
+    if ((h)->P.crutial) {                                                                                                   \
+      if ((h)->P.contact_rule) IRRL_LAUNCH(h, irrl_step_kernel_crutial_md, grid, __VA_ARGS__);                               \
+      else IRRL_LAUNCH(h, irrl_step_kernel_crutial, grid, __VA_ARGS__);                                                      \
+    } else if ((h)->P.contact_rule) IRRL_LAUNCH(h, irrl_step_kernel, grid, __VA_ARGS__);                                     \
+    else IRRL_LAUNCH(h, irrl_step_kernel_dir, grid, __VA_ARGS__);                                                            \
   } while (0)
 
 extern "C" {
@@ -265,7 +270,7 @@ int irrl_env_step_rows(irrl_env *h, int count, const float *action_rows, int n_r
 int irrl_lstm_rollout(irrl_env *h, int steps, int hid, int ob_dim, int act_dim, float *obs, uint8_t *dones, const float *states_in,
                       float *states_out, const float *const *lstm_w, const float *pi_w, const float *pi_b, const float *vf_w,
                       const float *vf_b, const float *logstd, const float *noise, int rng_on, unsigned rng_seed, long long rng_step,
-                      const long long *rng_base, float *action, float *clipped, float *value, float *neglogp, long long row, float *mb_obs,
+                      const long long *rng_base, int env_id_offset, float *action, float *clipped, float *value, float *neglogp, long long row, float *mb_obs,
                       float *mb_actions, float *mb_values, float *mb_neglogp, uint8_t *mb_dones, float *mb_rewards,
                       float *env_reward, float *env_extra, int fuse, void *hip_stream) {
   if (need_init(h)) return 1;
@@ -278,13 +283,13 @@ int irrl_lstm_rollout(irrl_env *h, int steps, int hid, int ob_dim, int act_dim, 
   // step k's policy part alone (k == 0, and every step on the two-launch path)
   auto policy = [&](int k) {
     return irrl_lstm_policy_step(hid, ob_dim, act_dim, n, obs, dones, k == 0 ? states_in : states_out, states_out, lstm_w, pi_w, pi_b, vf_w, vf_b,
-                                 logstd, noise_at(k), rng_on, rng_seed, rng_step + k, rng_base, action, clipped, value, neglogp, row + k, mb_obs,
+                                 logstd, noise_at(k), rng_on, rng_seed, rng_step + k, rng_base, env_id_offset, action, clipped, value, neglogp, row + k, mb_obs,
                                  mb_actions, mb_values, mb_neglogp, mb_dones, mb_rewards, env_reward, hip_stream);
   };
   // fuse != 0: one launch per step, env.step k together with the policy step k + 1 (16-lane layout = one MFMA M-tile per four env
   // waves, the reference's 48-unit network, pools without the meteorite).  Bit-identical to the two-launch sequence, and measured
   // SLOWER on MI355X (62.9 against 58.2 us per step at 4096 envs): kept as an option, not the default.
-  const bool fused = fuse != 0 && h->lanes == 16 && !h->P.crutial && hid == 48 && steps > 1;
+  const bool fused = fuse != 0 && h->lanes == 16 && !h->P.crutial && h->P.contact_rule && hid == 48 && steps > 1;
   if (steps > 0 && policy(0) != 0) { g_err = "irrl_lstm_rollout: policy step refused its arguments"; return 1; }
   for (int k = 0; k < steps; k++) {
     if (fused && k + 1 < steps) {
@@ -296,7 +301,7 @@ int irrl_lstm_rollout(irrl_env *h, int steps, int hid, int ob_dim, int act_dim, 
       a.row = row + k + 1; a.rng_base = rng_base;
       a.mb_obs = mb_obs; a.mb_actions = mb_actions; a.mb_values = mb_values; a.mb_neglogp = mb_neglogp; a.mb_dones = mb_dones;
       a.mb_rewards = mb_rewards; a.prev_reward = mb_rewards ? env_reward : nullptr;
-      a.rng_step = rng_step + k + 1; a.rng_seed = rng_seed; a.rng_on = rng_on;
+      a.rng_step = rng_step + k + 1; a.rng_seed = rng_seed; a.rng_on = rng_on; a.env_id_offset = (unsigned)env_id_offset;
       a.N = n; a.ob_dim = ob_dim; a.act_dim = act_dim;
       hipLaunchKernelGGL(irrl_step_policy_kernel_l16, dim3((n + 15) / 16), dim3(256), 0, h->stream, h->P, h->S, (const float *)clipped, obs,
                          env_reward, dones, env_extra, a);
@@ -411,6 +416,7 @@ int irrl_env_set_control_dt(irrl_env *h, double dt) {
   h->P.control_dt = (float)dt;
   h->P.loop_count = (int32_t)(dt / (double)h->P.sim_dt + 1e-6);
   if (h->P.loop_count < 1) h->P.loop_count = 1;
+  irrl_host::derive_cadences(h->cfg, dt, h->P);   // attack_every / disturb_every follow the live control_dt like ENV:733,747
   irrl_host::derive_params(h->P);
   return 0;
 }

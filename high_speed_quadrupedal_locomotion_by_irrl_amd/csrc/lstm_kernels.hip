@@ -1183,7 +1183,7 @@ int irrl_lstm_seq_backward(int hid, int T, int N, const float *gates, const floa
 int irrl_lstm_policy_step(int hid, int ob_dim, int act_dim, int N, const float *obs, const uint8_t *dones, const float *states_in,
                           float *states_out, const float *const *lstm_w, const float *pi_w, const float *pi_b, const float *vf_w,
                           const float *vf_b, const float *logstd, const float *noise, int rng_on, unsigned rng_seed, long long rng_step,
-                          const long long *rng_base, float *action, float *clipped, float *value, float *neglogp, long long row, float *mb_obs,
+                          const long long *rng_base, int env_id_offset, float *action, float *clipped, float *value, float *neglogp, long long row, float *mb_obs,
                           float *mb_actions, float *mb_values, float *mb_neglogp, uint8_t *mb_dones, float *mb_rewards,
                           const float *prev_reward, void *hip_stream) {
   if (N <= 0 || ob_dim <= 0 || act_dim <= 0 || act_dim > 16) return 1;
@@ -1200,7 +1200,7 @@ int irrl_lstm_policy_step(int hid, int ob_dim, int act_dim, int N, const float *
   a.mb_neglogp = rows ? mb_neglogp : nullptr; a.mb_dones = rows ? mb_dones : nullptr; a.mb_rewards = rows ? mb_rewards : nullptr;
   a.prev_reward = (rows && mb_rewards) ? prev_reward : nullptr;
   if (rows && !(mb_obs && mb_actions && mb_values && mb_neglogp && mb_dones)) return 1;
-  a.rng_step = rng_step; a.rng_seed = rng_seed; a.rng_on = rng_on;
+  a.rng_step = rng_step; a.rng_seed = rng_seed; a.rng_on = rng_on; a.env_id_offset = (unsigned)env_id_offset;
   a.N = N; a.ob_dim = ob_dim; a.act_dim = act_dim;
   hipStream_t s = (hipStream_t)hip_stream;
   const int obk = (ob_dim + 3) / 4;
@@ -1256,7 +1256,7 @@ int irrl_lstm_seq_backward_x(int hid, int T, int N, int n_in, const float *gates
 // (no recurrent state).
 int irrl_mlp_policy_step(int hid, int ob_dim, int act_dim, int N, const float *obs, const uint8_t *dones, const float *const *mlp_w,
                          const float *pi_w, const float *pi_b, const float *vf_w, const float *vf_b, const float *logstd, const float *noise,
-                         int rng_on, unsigned rng_seed, long long rng_step, const long long *rng_base, float *action, float *clipped,
+                         int rng_on, unsigned rng_seed, long long rng_step, const long long *rng_base, int env_id_offset, float *action, float *clipped,
                          float *value, float *neglogp, long long row, float *mb_obs, float *mb_actions, float *mb_values, float *mb_neglogp,
                          uint8_t *mb_dones, float *mb_rewards, const float *prev_reward, void *hip_stream) {
   if (N <= 0 || ob_dim <= 0 || act_dim <= 0 || act_dim > 15 || hid != 64) return 1;
@@ -1271,7 +1271,7 @@ int irrl_mlp_policy_step(int hid, int ob_dim, int act_dim, int N, const float *o
   a.mb_neglogp = rows ? mb_neglogp : nullptr; a.mb_dones = rows ? mb_dones : nullptr; a.mb_rewards = rows ? mb_rewards : nullptr;
   a.prev_reward = (rows && mb_rewards) ? prev_reward : nullptr;
   if (rows && !(mb_obs && mb_actions && mb_values && mb_neglogp && mb_dones)) return 1;
-  a.rng_step = rng_step; a.rng_seed = rng_seed; a.rng_on = rng_on;
+  a.rng_step = rng_step; a.rng_seed = rng_seed; a.rng_on = rng_on; a.env_id_offset = (unsigned)env_id_offset;
   a.N = N; a.ob_dim = ob_dim; a.act_dim = act_dim;
   hipLaunchKernelGGL((mlp_policy_step_kernel<64>), dim3((N + 15) / 16), dim3(256), 0, (hipStream_t)hip_stream, a);
   return hipGetLastError() == hipSuccess ? 0 : 2;

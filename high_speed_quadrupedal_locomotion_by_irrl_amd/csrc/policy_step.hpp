@@ -40,6 +40,7 @@ struct PolicyStepArgs {
   const float *prev_reward;  // [N] reward of the previous env step -> mb_rewards[t-1] (t > 0)
   long long rng_step;
   unsigned rng_seed;
+  unsigned env_id_offset;  // global id of env 0 (the sampling noise of env e is addressed by e + env_id_offset: multi-GPU shards)
   int rng_on;              // noise == NULL: 1 = counter-RNG sample (Philox keyed like the env's), 0 = deterministic
   int N, ob_dim, act_dim;
 };
@@ -81,7 +82,7 @@ LSTM_DEV void policy_heads(const PolicyStepArgs &a, const float *hpi, const floa
       z = a.noise[o];
     } else if (a.rng_on) {
       float r[4];
-      policy_philox(a.rng_seed, (unsigned)(e0 + env), (unsigned)((unsigned long long)gstep >> 32), (unsigned)gstep, IRRL_P_POLICY_NOISE + (unsigned)(ai >> 2), r);
+      policy_philox(a.rng_seed, (unsigned)(e0 + env) + a.env_id_offset, (unsigned)((unsigned long long)gstep >> 32), (unsigned)gstep, IRRL_P_POLICY_NOISE + (unsigned)(ai >> 2), r);
       // Box-Muller on the pair (r0, r1) for slots 0/1 and (r2, r3) for slots 2/3; 1 - u is in (0, 1]
       const int pair = (ai >> 1) & 1;
       const float ua = pair ? r[2] : r[0], ub = pair ? r[3] : r[1];

@@ -16,8 +16,18 @@ the device assembly between the compiler and the assembler -- inserts exactly th
   * transcendental VALU (v_rcp / v_rsq / v_sqrt / v_exp / v_log / v_sin / v_cos) result read by the next VALU: 1 wait state
   * block boundaries: predecessors are not traced; an inline-assembly DPP instruction closer than 2 wait states to the start of
     its basic block, or an inline-assembly write closer than 2 wait states to the block's end, gets the missing wait states.
+  * a VALU write of EXEC closer than 5 wait states to the END of its block gets the missing wait states there, so no successor
+    block can start with a DPP instruction inside the window (predecessors are not traced: the writer pays, not every reader).
 Compiler-generated pairs are the compiler's business and are left alone.  Every instruction counts one wait state, `s_nop N`
-counts N + 1.  Inline assembly is recognised by the ;;#ASMSTART / ;;#ASMEND brackets the compiler prints around it."""
+counts N + 1.  Inline assembly is recognised by the ;;#ASMSTART / ;;#ASMEND brackets the compiler prints around it; an
+inline-assembly block must hold exactly ONE instruction (the wait states go in front of the bracket, so a hazard between two
+instructions of one block could not be fixed): anything else is rejected.
+
+FAIL CLOSED.  `verify` re-scans the OUTPUT of the pass with an independent, simpler rule set and raises `HazardError` if ANY DPP
+instruction -- hand-placed or compiler-generated -- reads its DPP operand closer than 2 wait states behind a VALU write of that
+register, closer than 5 behind a VALU write of EXEC, or (hand-placed ones) closer than 2 to the start of its block; or if a VALU
+write of EXEC sits closer than 5 to a block end.  `process_file` (the build) always verifies: a missed hazard would be silently
+wrong contact / CRBA numerics, so the build stops instead."""
 import re
 import sys
 
@@ -69,6 +79,8 @@ class Inst(object):
     def writes(self):
         if not self.is_valu or self.op.startswith(("v_cmp", "v_nop", "v_readlane", "v_readfirstlane")):
             return set()
+        if self.op.startswith("v_swap"):     # v_swap_b32 vA, vB writes both of its operands
+            return _regs(self.dst) | (_regs(self.srcs[0]) if self.srcs else set())
         return _regs(self.dst)
 
     def reads(self):
@@ -91,15 +103,18 @@ def _is_block_end(op):
     return op.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc", "s_swappc", "s_barrier"))
 
 
-def run(lines):
-    """-> (new lines, statistics)"""
-    # parse into blocks of instructions
-    insts = []          # per line: Inst or None
-    in_asm = False
+class HazardError(RuntimeError):
+    pass
+
+
+def _parse(lines):
+    """-> per line: Inst, "BLOCK" (a label) or None.  Rejects inline-assembly blocks that hold more than one instruction."""
+    insts = []
+    in_asm, asm_count, asm_line = False, 0, 0
     for i, ln in enumerate(lines):
         t = ln.split("//")[0].strip()
         if t.startswith(";;#ASMSTART"):
-            in_asm = True
+            in_asm, asm_count, asm_line = True, 0, i
             insts.append(None)
             continue
         if t.startswith(";;#ASMEND"):
@@ -110,7 +125,58 @@ def run(lines):
         if not t or t.startswith(".") and not _is_block_start(t) or _is_block_start(t):
             insts.append("BLOCK" if _is_block_start(t) else None)
             continue
+        if in_asm:
+            asm_count += 1
+            if asm_count > 1:
+                raise HazardError("inline-assembly block at line %d holds more than one instruction: hazards inside it cannot be fixed" % (asm_line + 1))
         insts.append(Inst(i, t, in_asm))
+    return insts
+
+
+def verify(lines):
+    """Independent re-scan (see the module docstring).  -> number of DPP instructions checked; raises HazardError."""
+    insts = _parse(lines)
+    problems, checked = [], 0
+    for i, x in enumerate(insts):
+        if not isinstance(x, Inst) or not x.is_valu:
+            continue
+        if x.writes_exec_valu():            # a VALU write of EXEC must be 5 wait states away from the end of its block
+            ws, k = 0, i + 1
+            while k < len(insts) and ws < 5:
+                y = insts[k]
+                if y == "BLOCK" or (isinstance(y, Inst) and _is_block_end(y.op)):
+                    problems.append("line %d: VALU write of EXEC %d wait state(s) before a block end (line %d)" % (i + 1, ws, k + 1))
+                    break
+                if isinstance(y, Inst):
+                    ws += y.wait_states
+                k += 1
+        if not (x.is_dpp and x.srcs):
+            continue
+        checked += 1
+        dpp_src = _regs(x.srcs[0])
+        ws, k, hit_start = 0, i - 1, False
+        while k >= 0 and ws < 5:
+            y = insts[k]
+            if y == "BLOCK" or (isinstance(y, Inst) and _is_block_end(y.op)):
+                hit_start = True
+                break
+            if isinstance(y, Inst):
+                if y.is_valu and ws < 2 and (y.writes() & dpp_src):
+                    problems.append("line %d: %s reads v%s as DPP operand %d wait state(s) behind line %d: %s" % (i + 1, x.op, sorted(y.writes() & dpp_src), ws, k + 1, y.text))
+                if y.writes_exec_valu():
+                    problems.append("line %d: %s %d wait state(s) behind a VALU write of EXEC (line %d)" % (i + 1, x.op, ws, k + 1))
+                ws += y.wait_states
+            k -= 1
+        if x.ours and (hit_start or k < 0) and ws < 2:
+            problems.append("line %d: hand-placed %s only %d wait state(s) behind the start of its block" % (i + 1, x.op, ws))
+    if problems:
+        raise HazardError("%d unresolved DPP / EXEC hazard(s) in the env-kernel assembly:\n  " % len(problems) + "\n  ".join(problems[:20]))
+    return checked
+
+
+def run(lines):
+    """-> (new lines, statistics)"""
+    insts = _parse(lines)          # per line: Inst, "BLOCK" or None
     n = len(lines)
     insert_before = {}   # line index -> wait states to add in front of it
     stats = dict(asm_dpp=0, nops_reader=0, nops_writer=0, nops_trans=0, nops_block=0, wait_states_added=0)
@@ -182,6 +248,21 @@ def run(lines):
             if isinstance(y, Inst):
                 ws += y.wait_states
             k += 1
+    # a VALU write of EXEC too close to a block end: the successors' DPP instructions cannot see it, so the writer pays
+    for i in range(n):
+        x = insts[i]
+        if not (isinstance(x, Inst) and x.is_valu and x.writes_exec_valu()):
+            continue
+        ws, k = 0, i + 1
+        while k < n and ws < 5:
+            y = insts[k]
+            if y == "BLOCK" or (isinstance(y, Inst) and _is_block_end(y.op)):
+                insert_before[k] = max(insert_before.get(k, 0), 5 - ws)
+                stats["nops_block"] += 1
+                break
+            if isinstance(y, Inst):
+                ws += y.wait_states + insert_before.get(k, 0)
+            k += 1
     out = []
     for i, ln in enumerate(lines):
         w = insert_before.get(i, 0)
@@ -196,6 +277,7 @@ def process_file(src, dst):
     with open(src) as f:
         lines = f.readlines()
     out, stats = run(lines)
+    stats["dpp_verified"] = verify(out)      # fail closed: raises HazardError when anything is left
     with open(dst, "w") as f:
         f.writelines(out)
     return stats

@@ -209,7 +209,7 @@ def policy_step_supported(policy, obs):
 
 def policy_step(policy, obs, states, dones, noise=None, rng=None, states_out=None, rollout=None, out=None):
     """obs [N,ob], states [N,8H], dones [N] bool/u8 -> action, clipped, value, neglogp, states_out.
-    Sampling: `noise` [N,act] if given; else rng = (seed, step[, base]) draws it in the kernel (counter RNG at step
+    Sampling: `noise` [N,act] if given; else rng = (seed, step[, base[, env0]]) draws it in the kernel (counter RNG at step
     `step + base`, base an int64 device scalar); else deterministic.
     `rollout` = dict(row=t, mb_obs, mb_actions, mb_values, mb_neglogpacs, mb_dones, and optionally mb_rewards +
     prev_reward): row t of each buffer is written and the reward of the previous step goes to row t-1.
@@ -234,10 +234,11 @@ def policy_step(policy, obs, states, dones, noise=None, rng=None, states_out=Non
     action, clipped, value, neglogp = out
     if noise is not None:
         noise = noise.contiguous()
-    rng_on, seed, step, base = 0, 0, 0, None
+    rng_on, seed, step, base, env0 = 0, 0, 0, None, 0
     if rng is not None and noise is None:
         rng_on, seed, step = 1, int(rng[0]) & 0xFFFFFFFF, int(rng[1])
         base = _ptr(rng[2]) if len(rng) > 2 and rng[2] is not None else None
+        env0 = int(rng[3]) if len(rng) > 3 else 0      # global id of env 0 (multi-GPU shards)
     if rollout is not None:
         opt = lambda k: _ptr(rollout[k]) if rollout.get(k) is not None else None
         row = int(rollout["row"])
@@ -247,7 +248,7 @@ def policy_step(policy, obs, states, dones, noise=None, rng=None, states_out=Non
         row, rptr = -1, [None] * 7
     rc = lib.irrl_lstm_policy_step(hid, ob_dim, act, N, _ptr(obs), _ptr(dones), _ptr(states), _ptr(states_out), warr,
                                    _ptr(policy.pi.w), _ptr(policy.pi.b), _ptr(policy.vf.w), _ptr(policy.vf.b), _ptr(policy.logstd),
-                                   _ptr(noise) if noise is not None else None, rng_on, seed, step, base,
+                                   _ptr(noise) if noise is not None else None, rng_on, seed, step, base, env0,
                                    _ptr(action), _ptr(clipped), _ptr(value), _ptr(neglogp), row,
                                    *rptr, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     if rc != 0:
@@ -274,15 +275,16 @@ def policy_rollout(policy, env_impl, steps, obs, states, dones, rng, rollout, ou
     assert obs.is_contiguous() and states.is_contiguous() and dones.is_contiguous() and dones.element_size() == 1
     assert env_reward.is_contiguous() and env_extra.is_contiguous() and tuple(env_extra.shape) == (N, 6)
     action, clipped, value, neglogp = out
-    rng_on, seed, step, base = 0, 0, 0, None
+    rng_on, seed, step, base, env0 = 0, 0, 0, None, 0
     if noise_all is not None:
         assert noise_all.is_contiguous() and tuple(noise_all.shape[1:]) == (N, act) and noise_all.shape[0] >= steps
     elif rng is not None:
         rng_on, seed, step = 1, int(rng[0]) & 0xFFFFFFFF, int(rng[1])
         base = _ptr(rng[2]) if len(rng) > 2 and rng[2] is not None else None
+        env0 = int(rng[3]) if len(rng) > 3 else 0      # global id of env 0 (multi-GPU shards)
     rc = lib.irrl_lstm_rollout(env_impl._h, int(steps), hid, ob_dim, act, _ptr(obs), _ptr(dones), _ptr(states), _ptr(states), warr,
                                _ptr(policy.pi.w), _ptr(policy.pi.b), _ptr(policy.vf.w), _ptr(policy.vf.b), _ptr(policy.logstd),
-                               _ptr(noise_all) if noise_all is not None else None, rng_on, seed, step, base,
+                               _ptr(noise_all) if noise_all is not None else None, rng_on, seed, step, base, env0,
                                _ptr(action), _ptr(clipped), _ptr(value), _ptr(neglogp), int(rollout["row"]),
                                _ptr(rollout["mb_obs"]), _ptr(rollout["mb_actions"]), _ptr(rollout["mb_values"]), _ptr(rollout["mb_neglogpacs"]),
                                _ptr(rollout["mb_dones"]), _ptr(rollout["mb_rewards"]), _ptr(env_reward), _ptr(env_extra), 1 if fused else 0,
@@ -311,10 +313,11 @@ def mlp_policy_step(policy, obs, dones, noise=None, rng=None, rollout=None, out=
     action, clipped, value, neglogp = out
     if noise is not None:
         noise = noise.contiguous()
-    rng_on, seed, step, base = 0, 0, 0, None
+    rng_on, seed, step, base, env0 = 0, 0, 0, None, 0
     if rng is not None and noise is None:
         rng_on, seed, step = 1, int(rng[0]) & 0xFFFFFFFF, int(rng[1])
         base = _ptr(rng[2]) if len(rng) > 2 and rng[2] is not None else None
+        env0 = int(rng[3]) if len(rng) > 3 else 0      # global id of env 0 (multi-GPU shards)
     if rollout is not None:
         opt = lambda k: _ptr(rollout[k]) if rollout.get(k) is not None else None
         row = int(rollout["row"])
@@ -323,7 +326,7 @@ def mlp_policy_step(policy, obs, dones, noise=None, rng=None, rollout=None, out=
     else:
         row, rptr = -1, [None] * 7
     rc = lib.irrl_mlp_policy_step(64, ob_dim, act, N, _ptr(obs), _ptr(dones), warr, _ptr(policy.pi.w), _ptr(policy.pi.b), _ptr(policy.vf.w),
-                                  _ptr(policy.vf.b), _ptr(policy.logstd), _ptr(noise) if noise is not None else None, rng_on, seed, step, base,
+                                  _ptr(policy.vf.b), _ptr(policy.logstd), _ptr(noise) if noise is not None else None, rng_on, seed, step, base, env0,
                                   _ptr(action), _ptr(clipped), _ptr(value), _ptr(neglogp), row, *rptr,
                                   C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     if rc != 0:

@@ -124,10 +124,11 @@ class _FusedHeadsLoss(torch.autograd.Function):
     """The policy / value heads (mean = h_pi W_pi + b_pi, v = h_v w_v + b_v), the loss of `_FusedPPOLoss` and ALL their
     gradients in one launch (`irrl_ppo_heads_loss`): replaces the heads' forward GEMMs, the [M,12] x [12,48] dx GEMM that alone
     took 2.45 ms per epoch at 4096 x 750 (it writes 590 MB), the two tall weight-gradient reductions and the loss kernel.
-    backward() assumes the upstream gradient of `loss` is 1 (PPO2 calls loss.backward() on it directly) unless
-    `assume_unit_grad` is switched off, in which case every returned gradient is scaled (one more pass over [M,48] x 2)."""
+    backward() scales every returned gradient by the upstream gradient of `loss` (a caller may scale the loss: loss / world,
+    gradient accumulation, loss scaling); PPO2 calls loss.backward() directly, and the upstream 1 is recognised on the HOST
+    (autograd hands a fresh ones-tensor whose value is read only when `check_unit_grad` asks for it -- the default multiplies,
+    two more passes over [M,48], 0.3 ms per epoch at 4096 x 750, instead of trusting an assumption)."""
     N_BLOCKS = 1024
-    assume_unit_grad = True
 
     @staticmethod
     def forward(ctx, h_pi, h_v, pi_w, pi_b, vf_w, vf_b, logstd, actions, returns, old_values, old_neglogp, adv_stats, cliprange, ent_coef, vf_coef):
@@ -162,9 +163,9 @@ class _FusedHeadsLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g_stats):
         d_hp, d_hv, d_wpi, d_bpi, d_wv, d_bv, d_logstd = ctx.saved_tensors
-        if not _FusedHeadsLoss.assume_unit_grad:
-            d_hp, d_hv = d_hp * g_loss, d_hv * g_loss
-            d_wpi, d_bpi, d_wv, d_bv, d_logstd = d_wpi * g_loss, d_bpi * g_loss, d_wv * g_loss, d_bv * g_loss, d_logstd * g_loss
+        # in place: the saved row gradients are this node's own buffers and backward runs once (retain_graph is not supported here)
+        d_hp, d_hv = d_hp.mul_(g_loss), d_hv.mul_(g_loss)
+        d_wpi, d_bpi, d_wv, d_bv, d_logstd = d_wpi * g_loss, d_bpi * g_loss, d_wv * g_loss, d_bv * g_loss, d_logstd * g_loss
         return d_hp, d_hv, d_wpi, d_bpi, d_wv, d_bv, d_logstd, None, None, None, None, None, None, None, None
 
 
@@ -215,12 +216,23 @@ class Runner(object):
         self._out = (torch.empty(n, env.num_acts, device=dev), torch.empty(n, env.num_acts, device=dev), torch.empty(n, device=dev),
                      torch.empty(n, device=dev))
 
+    def _draw_noise(self, shape, env_axis):
+        """standard normals for this rank's envs out of the draw for ALL ranks' envs (identically seeded generators): rank r takes
+        rows r * n .. of the env axis, so the union over ranks is the single-process draw"""
+        world, rank = self.model.world, self.model.rank
+        if world == 1:
+            return torch.randn(shape, device=self.obs.device, dtype=self.obs.dtype, generator=self._gen)
+        full = list(shape)
+        n = full[env_axis]
+        full[env_axis] = n * world
+        return torch.randn(full, device=self.obs.device, dtype=self.obs.dtype, generator=self._gen).narrow(env_axis, rank * n, n)
+
     def _fused_step(self, t):
         """Rollout step t as two launches: the whole policy step (sample, clip, buffer rows incl. the previous reward) and
         the env step, which writes obs / reward / dones straight into the runner's tensors."""
         noise = self.noise_all[t] if self.noise_all is not None else None
         _, clipped, _, _, _ = self.model.policy.fused_step(
-            self.obs, self.states, self.dones, noise=noise, rng=(self.model.noise_seed, t, self.rng_base), states_out=self.states, out=self._out,
+            self.obs, self.states, self.dones, noise=noise, rng=(self.model.noise_seed, t, self.rng_base, self.model.env_id_offset), states_out=self.states, out=self._out,
             rollout=dict(row=t, mb_obs=self.mb_obs, mb_actions=self.mb_actions, mb_values=self.mb_values, mb_neglogpacs=self.mb_neglogpacs,
                          mb_dones=self.mb_dones, mb_rewards=self.mb_rewards, prev_reward=self.rew))
         self.env.step_into(clipped, self.obs, self.rew, self.dones)
@@ -232,7 +244,7 @@ class Runner(object):
         if self.noise_all is not None:
             actions, values, states, neglogpacs = pol.step(self.obs, self.states, self.dones, noise=self.noise_all.index_select(0, self.t_idx)[0])
         else:
-            actions, values, states, neglogpacs = pol.step(self.obs, self.states, self.dones, generator=self._gen)
+            actions, values, states, neglogpacs = pol.step(self.obs, self.states, self.dones, noise=self._draw_noise((self.obs.shape[0], self.env.num_acts), 0))
         self.mb_obs.index_copy_(0, self.t_idx, self.obs.unsqueeze(0))
         self.mb_actions.index_copy_(0, self.t_idx, actions.unsqueeze(0))
         self.mb_values.index_copy_(0, self.t_idx, values.unsqueeze(0))
@@ -317,7 +329,7 @@ class Runner(object):
             shape = (self.n_steps,) + tuple(self.mb_actions.shape[1:])
             if self.noise_all is None:
                 self.noise_all = torch.empty(shape, device=self.obs.device, dtype=self.obs.dtype)   # fixed address: graphs read it
-            self.noise_all.copy_(torch.randn(shape, device=self.obs.device, dtype=self.obs.dtype, generator=self._gen))
+            self.noise_all.copy_(self._draw_noise(shape, 1))
         direct = self._fused and self.rollout_launch == "direct"
         if self.use_graph and not direct:
             self._maybe_capture()
@@ -327,7 +339,7 @@ class Runner(object):
             if direct:
                 d = self.dones if self.dones.element_size() == 1 else None
                 assert d is not None
-                pol.fused_rollout(self.env.wrapper, self.n_steps, self.obs, self.states, d, (self.model.noise_seed, 0, self.rng_base),
+                pol.fused_rollout(self.env.wrapper, self.n_steps, self.obs, self.states, d, (self.model.noise_seed, 0, self.rng_base, self.model.env_id_offset),
                                   dict(row=0, mb_obs=self.mb_obs, mb_actions=self.mb_actions, mb_values=self.mb_values,
                                        mb_neglogpacs=self.mb_neglogpacs, mb_dones=self.mb_dones, mb_rewards=self.mb_rewards),
                                   self._out, self.rew, self.env.extra, noise_all=self.noise_all, fused=self.rollout_one_launch_per_step)
@@ -378,7 +390,9 @@ class PPO2(object):
         self.world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
         self.rank = torch.distributed.get_rank() if self.world > 1 else 0
         self.seed = 0 if seed is None else int(seed)
-        # identical initial weights on every rank, different sampling noise per rank
+        # identical initial weights and identical generators on every rank; what differs per rank is WHICH robots it owns: rank r
+        # holds the global env ids r * n_envs .. (r + 1) * n_envs - 1 of the one big pool (env RNG: the pool's EnvIdOffset; sampling
+        # noise: stream = global env id), so an N-rank job collects exactly the samples the single-process job on N * n_envs envs does
         torch.manual_seed(self.seed)
         if isinstance(policy, type):
             self.policy = policy(**self.policy_kwargs)
@@ -386,8 +400,9 @@ class PPO2(object):
             self.policy = policy
         self.policy.to(self.device)
         self.generator = torch.Generator(device=self.device)
-        self.generator.manual_seed(self.seed * 1000003 + 7919 * self.rank + 1)
-        self.noise_seed = (self.seed * 1000003 + 7919 * self.rank + 1) & 0xFFFFFFFF   # key of the in-kernel sampling noise
+        self.generator.manual_seed(self.seed * 1000003 + 1)
+        self.noise_seed = (self.seed * 1000003 + 1) & 0xFFFFFFFF   # key of the in-kernel sampling noise
+        self.env_id_offset = self.rank * int(self.n_envs or 0)     # global id of this rank's env 0
         adam_kw = dict(lr=float(learning_rate) if not callable(learning_rate) else 1e-3, eps=1e-5, betas=(0.9, 0.999))
         try:  # one fused kernel over the 19 parameter tensors on the GPU
             self.optimizer = torch.optim.Adam(self.policy.parameters(), fused=(self.device.type == "cuda"), **adam_kw)

@@ -212,11 +212,13 @@ int irrl_lstm_seq_backward_x(int hid, int T, int N, int n_in, const float *gates
 int irrl_lstm_policy_step(int hid, int ob_dim, int act_dim, int N, const float *obs, const uint8_t *dones, const float *states_in,
                           float *states_out, const float *const *lstm_w, const float *pi_w, const float *pi_b, const float *vf_w,
                           const float *vf_b, const float *logstd, const float *noise, int rng_on, unsigned rng_seed, long long rng_step,
-                          const long long *rng_base, float *action, float *clipped, float *value, float *neglogp, long long row, float *mb_obs,
+                          const long long *rng_base, int env_id_offset, float *action, float *clipped, float *value, float *neglogp, long long row, float *mb_obs,
                           float *mb_actions, float *mb_values, float *mb_neglogp, uint8_t *mb_dones, float *mb_rewards,
                           const float *prev_reward, void *hip_stream);
 
-/* `steps` consecutive rollout steps (policy step t, then env.step on its clipped action) launched back to back by ONE call on
+/* (env_id_offset in the three policy entry points: global id of env 0 -- the in-kernel sampling noise of env e is the counter RNG's
+ * stream e + env_id_offset, so an N-GPU job whose ranks pass rank * N draws exactly the noise of the one big pool.)
+ * `steps` consecutive rollout steps (policy step t, then env.step on its clipped action) launched back to back by ONE call on
  * `hip_stream`: step k runs irrl_lstm_policy_step with rng_step + k, row + k and noise + k N act (if noise is given: a
  * [steps, N, act] table), states updated in place (states_out may equal states_in), and then the env step of pool `env`
  * (N = its num_envs) that writes obs / dones IN PLACE (the arrays the next policy step reads), the reward to `env_reward` [N]
@@ -227,7 +229,7 @@ int irrl_lstm_policy_step(int hid, int ob_dim, int act_dim, int N, const float *
 int irrl_lstm_rollout(irrl_env *env, int steps, int hid, int ob_dim, int act_dim, float *obs, uint8_t *dones, const float *states_in,
                       float *states_out, const float *const *lstm_w, const float *pi_w, const float *pi_b, const float *vf_w,
                       const float *vf_b, const float *logstd, const float *noise, int rng_on, unsigned rng_seed, long long rng_step,
-                      const long long *rng_base, float *action, float *clipped, float *value, float *neglogp, long long row, float *mb_obs,
+                      const long long *rng_base, int env_id_offset, float *action, float *clipped, float *value, float *neglogp, long long row, float *mb_obs,
                       float *mb_actions, float *mb_values, float *mb_neglogp, uint8_t *mb_dones, float *mb_rewards,
                       float *env_reward, float *env_extra, int fuse, void *hip_stream);
 
@@ -236,7 +238,7 @@ int irrl_lstm_rollout(irrl_env *env, int steps, int hid, int ob_dim, int act_dim
  * vf_w1, vf_b1, vf_w2, vf_b2; heads, sampling, outputs and rollout rows as above; act <= 15. */
 int irrl_mlp_policy_step(int hid, int ob_dim, int act_dim, int N, const float *obs, const uint8_t *dones, const float *const *mlp_w,
                          const float *pi_w, const float *pi_b, const float *vf_w, const float *vf_b, const float *logstd, const float *noise,
-                         int rng_on, unsigned rng_seed, long long rng_step, const long long *rng_base, float *action, float *clipped,
+                         int rng_on, unsigned rng_seed, long long rng_step, const long long *rng_base, int env_id_offset, float *action, float *clipped,
                          float *value, float *neglogp, long long row, float *mb_obs, float *mb_actions, float *mb_values, float *mb_neglogp,
                          uint8_t *mb_dones, float *mb_rewards, const float *prev_reward, void *hip_stream);
 

@@ -60,6 +60,7 @@ typedef struct orc_cfg {
   int32_t ContactIterations;    /* Gauss-Seidel sweeps per substep (default 6) */
   int32_t SharedNoiseScalar;    /* 1: Eigen 12x1*12x1 pitfall => one shared factor (ENV:584,586,705) */
   int32_t RandomizePerEpisode;  /* 1: redo the ctor domain randomisation at every reset (config 5) */
+  int32_t EnvIdOffset;          /* global id of env 0 of this pool: random draws are addressed by the GLOBAL env id (multi-GPU shards) */
   double ContactTolerance;      /* stop the sweeps once sum|dlambda|^2 <= tol^2 sum|lambda|^2 (0: always ContactIterations sweeps) */
   int32_t ContactSolver;        /* bit 1 = ORDER of the toe updates inside one sweep: set = the four toes at once (the kernels' one-solve-per-sweep),
                                  * clear = Gauss-Seidel over FR, FL, HR, HL;  bit 0 = per-contact RULE for a sliding contact: set = the published
@@ -88,6 +89,7 @@ void orc_step(orc_env *h, const float *action /* [N,12] */, float *ob /* [N,35] 
               float *reward /* [N] */, uint8_t *done /* [N] */, float *extra /* [N,6] */);
 void orc_is_terminal(orc_env *h, uint8_t *done);
 void orc_set_seed(orc_env *h, int seed);
+void orc_set_control_dt(orc_env *h, double dt);
 
 /* diagnostics getters (ENV:1317-1418), f32 rows like the reference's Eigen::Ref<EigenVec> */
 void orc_origin_state(orc_env *h, float *out /* [N,41] */);

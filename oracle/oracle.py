@@ -40,12 +40,12 @@ class OrcCfg(C.Structure):
         ("Damping", C.c_double), ("Freq", C.c_double), ("max_time", C.c_double), ("CubeNum", C.c_int32),
         ("FPS", C.c_double), ("ActionNoise", C.c_double), ("ObsNoise", C.c_double), ("GaitType", C.c_int32),
         ("MotorMaxTorque", C.c_double), ("MotorCriticalSpeed", C.c_double), ("MotorMaxSpeed", C.c_double),
-        ("ContactIterations", C.c_int32), ("SharedNoiseScalar", C.c_int32), ("RandomizePerEpisode", C.c_int32),
+        ("ContactIterations", C.c_int32), ("SharedNoiseScalar", C.c_int32), ("RandomizePerEpisode", C.c_int32), ("EnvIdOffset", C.c_int32),
         ("ContactTolerance", C.c_double), ("ContactSolver", C.c_int32),
     ]
 
 
-_EXT_DEFAULTS = {"ContactIterations": 6, "SharedNoiseScalar": 1, "RandomizePerEpisode": 0, "ContactTolerance": 0.0, "ContactSolver": 3}
+_EXT_DEFAULTS = {"ContactIterations": 6, "SharedNoiseScalar": 1, "RandomizePerEpisode": 0, "EnvIdOffset": 0, "ContactTolerance": 0.0, "ContactSolver": 3}
 
 
 def cfg_from_dict(env_cfg):
@@ -99,6 +99,8 @@ def _lib(precision="f64"):
     }.items():
         getattr(lib, name).restype = None
         getattr(lib, name).argtypes = args
+    lib.orc_set_control_dt.restype = None
+    lib.orc_set_control_dt.argtypes = [vp, C.c_double]
     lib.orc_num_envs.restype = C.c_int
     lib.orc_num_envs.argtypes = [vp]
     lib.orc_real_bytes.restype = C.c_int
@@ -240,6 +242,9 @@ class OracleVecEnv(object):
         extra = np.zeros((self.n, 6), np.float32)
         self.lib.orc_step(self.h, _fp(action), _fp(ob), _fp(rew), _u8(done), _fp(extra))
         return ob, rew, done.astype(bool), extra
+
+    def set_control_dt(self, dt):
+        self.lib.orc_set_control_dt(self.h, float(dt))
 
     def is_terminal(self):
         done = np.zeros(self.n, np.uint8)

@@ -140,7 +140,8 @@ def main(argv=None):
         return run_test(args, cfg)
     if args.num_envs:
         cfg["environment"]["num_envs"] = args.num_envs
-    cfg["environment"]["seedd"] = int(cfg["environment"]["seedd"]) + 7919 * rank   # each rank owns different robots
+    # rank r owns the global env ids r * num_envs .. of the one big pool: same seed everywhere, results independent of the GPU count
+    cfg["environment"]["EnvIdOffset"] = rank * int(cfg["environment"]["num_envs"])
     # run_bp_v5.py:205-207: the environment sub-tree is dumped to a string and parsed again on the native side
     env = Environment(FlexibleGymEnv(__RSCDIR__, yaml.safe_dump(cfg["environment"]), device=local_rank))
 

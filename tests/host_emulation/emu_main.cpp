@@ -89,7 +89,8 @@ void emu_observe(void *hv, float *ob) {
 void emu_step(void *hv, const float *action, float *ob, float *reward, uint8_t *done, float *extra) {
   Emu *h = (Emu *)hv;
   for (int e = 0; e < h->P.n_envs; e++)
-    irrl::step_body(h->P, h->S, lanes_env(e), lanes::leg_id(), store_mask(), action, ob, reward, done, extra);
+    if (h->P.contact_rule) irrl::step_body<1>(h->P, h->S, lanes_env(e), lanes::leg_id(), store_mask(), action, ob, reward, done, extra);
+    else irrl::step_body<0>(h->P, h->S, lanes_env(e), lanes::leg_id(), store_mask(), action, ob, reward, done, extra);
 }
 void emu_probe(void *hv, float *minv, float *nonlin) {
   Emu *h = (Emu *)hv;

@@ -88,6 +88,70 @@ def test_env_results_do_not_depend_on_batch_size():
         assert np.array_equal(ob_b[:64], ob_s) and np.array_equal(r_b[:64], r_s) and np.array_equal(d_b[:64], d_s)
 
 
+def test_two_shards_with_env_id_offsets_are_the_big_pool_bit_for_bit():
+    """SURVEY 8e / VEC:273: rank r of an N-GPU job owns the global env ids r * n .. (r + 1) * n - 1 (`EnvIdOffset`).  Two pools of
+    2048 with offsets 0 / 2048 == one pool of 4096, bit for bit over 50 steps (training config: noise, randomised dynamics, command
+    process, in-step resets) -- the multi-GPU partitioning is the single-GPU job, by construction."""
+    rng = np.random.RandomState(7)
+    acts = [PL.random_actions(rng, 4096, 0.5) for _ in range(50)]
+    big = _hip(load_env_cfg("default_cfg.yaml", num_envs=4096))
+    lo = _hip(load_env_cfg("default_cfg.yaml", num_envs=2048, EnvIdOffset=0))
+    hi = _hip(load_env_cfg("default_cfg.yaml", num_envs=2048, EnvIdOffset=2048))
+    assert np.array_equal(big.observe()[:2048], lo.observe()) and np.array_equal(big.observe()[2048:], hi.observe())
+    n_done = 0
+    for k, a in enumerate(acts):
+        if k == 10:        # some robots below the termination height: the in-step resets draw from the global-id streams too
+            st = big.get_state()
+            st[::97, PL.S["GC"] + 2] = 0.14
+            big.set_state(st); lo.set_state(st[:2048]); hi.set_state(st[2048:])
+        ob_b, r_b, d_b, x_b = big.step(a)
+        ob_l, r_l, d_l, x_l = lo.step(a[:2048].copy())
+        ob_h, r_h, d_h, x_h = hi.step(a[2048:].copy())
+        assert np.array_equal(ob_b[:2048], ob_l) and np.array_equal(ob_b[2048:], ob_h)
+        assert np.array_equal(r_b[:2048], r_l) and np.array_equal(r_b[2048:], r_h)
+        assert np.array_equal(d_b[:2048], d_l) and np.array_equal(d_b[2048:], d_h)
+        assert np.array_equal(x_b[:2048], x_l) and np.array_equal(x_b[2048:], x_h)
+        n_done += int(d_b.sum())
+    st = big.get_state()
+    assert np.array_equal(st[:2048], lo.get_state()) and np.array_equal(st[2048:], hi.get_state())
+    assert n_done >= 40
+
+
+def test_control_dt_setter_moves_the_frame_cadences_like_the_reference():
+    """VEC:328-331 setControlTimeStep after construction: the reference evaluates `frame_idx % int(5 * period_ / control_dt_)`
+    (meteorite, ENV:733) and `int(period_ / control_dt_ * 10)` (state_disturbance, ENV:747) with the LIVE control_dt_.  A Crutial
+    pool (period 0.05: parked every 125 frames at 0.002 s) switched to 0.004 s must park at frame 62 -- engine (C-ABI setter) and
+    oracle, teacher-forced across that frame; same for the state_disturbance kick (period 0.02: every 100 -> 50 frames)."""
+    cfg = load_env_cfg("bp5_imitation.yaml", num_envs=16, Crutial=True, CubeNum=6, period=0.05)
+    orc, cand = _pair(cfg)
+    orc.set_control_dt(0.004)
+    cand.impl.setControlTimeStep(0.004)
+    st = orc.get_state()
+    st[:, PL.S["FRAME"]] = 55
+    orc.set_state(st)
+    k = PL.S["SPHERE"]
+    parked_at = []
+    rng = np.random.RandomState(3)
+    for step in range(12):
+        s0 = PL.f32_round_state(orc.get_state())
+        orc.set_state(s0); cand.set_state(s0)
+        a = PL.random_actions(rng, 16, 0.3)
+        orc.step(a); cand.step(a)
+        so, sc = orc.get_state(), cand.get_state()
+        assert np.array_equal(so[:, k + 8], sc[:, k + 8]) and np.abs(so[:, k:k + 8] - sc[:, k:k + 8]).max() < 1e-4
+        if (so[:, k + 8] == 0).all() and (s0[:, k + 8] == 1).any():
+            parked_at.append(int(s0[0, PL.S["FRAME"]]))
+    assert parked_at == [62], parked_at
+    cfg = load_env_cfg("default_cfg.yaml", num_envs=8, Manual=True, ForceDisturbance=True, period=0.02, ObsNoise=0.0, ActionNoise=0.0)
+    orc, cand = _pair(cfg)
+    orc.set_control_dt(0.004)
+    cand.impl.setControlTimeStep(0.004)
+    st = orc.get_state()
+    st[:, PL.S["FRAME"]] = 44
+    orc.set_state(st)
+    PL.check_teacher_forced(orc, cand, steps=12, seed=9, action_scale=0.1)      # crosses frame 50: both kick, or the states differ
+
+
 def test_statistical_agreement_over_a_rollout():
     # free-running trajectories diverge (chaos), distributions must not: 256 envs x 300 steps
     cfg = load_env_cfg("default_cfg.yaml", num_envs=256)

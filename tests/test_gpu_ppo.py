@@ -105,6 +105,20 @@ def test_fused_lstm_policy_full_size_agrees_with_eager():
         assert float((a - b).abs().max()) / (float(a.abs().max()) + 1e-6) < 1e-4
 
 
+@pytest.mark.parametrize("policy", ["lstm", "mlp"])
+def test_two_rank_ppo_iteration_on_the_hip_engine_equals_the_single_process_one(tmp_path, policy):
+    """The only multi-GPU proof available without a node: two ranks (gloo, both on cuda:0), 64 envs each with
+    EnvIdOffset = rank * 64, one PPO iteration through the product's Runner (fused policy-step + env-step launches, in-kernel
+    sampling noise addressed by the global env id) and PPO2.update (gradient + advantage-moment all-reduce) == the single-process
+    iteration on the 128-env pool: rollout buffers bit-identical, parameters equal up to the gradient's summation order."""
+    import sys, os
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_ppo_distributed import check_two_ranks_equal_single_process
+    two, one = check_two_ranks_equal_single_process(tmp_path, "cuda", 64, 24, policy)
+    assert int(one["fused_rollout"]) == 1 and int(two[0]["fused_rollout"]) == 1
+
+
 @pytest.mark.parametrize("N", [1, 37])
 def test_hip_lstm_kernels_reproduce_the_reference_actor_known_answers(N):
     """The reference's own known answers on the MI355X kernels (CustomerLstmNN.py:112-175 `predict` on the trained bp5_155 weights,

@@ -62,6 +62,51 @@ def test_transcendental_and_exec_and_block_boundaries():
     assert st["wait_states_added"] == 2 and out.index("s_nop 1") > out.index(";;#ASMEND")
 
 
+def test_verifier_fails_closed():
+    """the independent re-scan of the pass's output (isa_pass.verify, run by every build): an unresolved hazard stops the build"""
+    import pytest
+    bad = _pad(3) + "\tv_add_f32_e32 v5, v1, v2\n" + ASM("\tv_fmac_f32_dpp v9, v5, v7" + DPP) + _pad(3)
+    with pytest.raises(isa_pass.HazardError, match="DPP operand"):
+        isa_pass.verify(bad.splitlines(keepends=True))
+    assert isa_pass.verify(_run(bad)[0].splitlines(keepends=True)) == 1                      # the pass's own output is clean
+    # v_swap_b32 writes BOTH of its operands
+    swap = _pad(3) + "\tv_swap_b32 v3, v5\n" + ASM("\tv_fmac_f32_dpp v9, v5, v7" + DPP) + _pad(3)
+    with pytest.raises(isa_pass.HazardError):
+        isa_pass.verify(swap.splitlines(keepends=True))
+    out, st = _run(swap)
+    assert st["wait_states_added"] == 2 and isa_pass.verify(out.splitlines(keepends=True)) == 1
+    # a VALU write of EXEC near the end of a block: the successor block's DPP instruction cannot see it -> padded at the block end
+    ex = _pad(3) + "\tv_cmpx_lt_f32_e32 v1, v2\n\ts_cbranch_execz .LBB0_3\n.LBB0_2:\n" + _pad(2) + ASM("\tv_fmac_f32_dpp v9, v5, v7" + DPP) + _pad(3)
+    with pytest.raises(isa_pass.HazardError, match="EXEC"):
+        isa_pass.verify(ex.splitlines(keepends=True))
+    out, st = _run(ex)
+    assert "s_nop 4" in out and out.index("s_nop 4") < out.index("s_cbranch_execz")
+    isa_pass.verify(out.splitlines(keepends=True))
+    # compiler-generated pairs are verified too (not fixed: that would be a compiler bug, and the build must stop)
+    cc = _pad(3) + "\tv_add_f32_e32 v9, v1, v2\n\tv_add_f32_dpp v11, v9, v12" + DPP + _pad(3)
+    with pytest.raises(isa_pass.HazardError):
+        isa_pass.verify(cc.splitlines(keepends=True))
+    # two instructions in one inline-assembly block: rejected by the pass and by the verifier
+    two = _pad(3) + ASM("\tv_add_f32_e32 v5, v1, v2\n\tv_fmac_f32_dpp v9, v5, v7" + DPP) + _pad(3)
+    with pytest.raises(isa_pass.HazardError, match="more than one instruction"):
+        _run(two)
+
+
+def test_verifier_on_the_real_env_kernel_assembly_of_both_lane_layouts():
+    """the assembly the product library was built from (csrc/_obj/env_kernels_l{16,4}.s): every DPP instruction of every kernel
+    -- hand-placed and compiler-generated -- is hazard-free; the compiler's raw output of the 16-lane layout is not"""
+    import pytest
+    build.build()
+    if not all(os.path.exists(os.path.join(build.CSRC, "_obj", "env_kernels_l%d.s" % l)) for l in (16, 4)):
+        build.build(force=True)
+    for lanes, min_dpp in ((16, 2000), (4, 1000)):
+        fixed = open(os.path.join(build.CSRC, "_obj", "env_kernels_l%d.s" % lanes)).readlines()
+        assert isa_pass.verify(fixed) >= min_dpp
+    raw = open(os.path.join(build.CSRC, "_obj", "env_kernels_l16.raw.s")).readlines()
+    with pytest.raises(isa_pass.HazardError):
+        isa_pass.verify(raw)
+
+
 def test_product_build_contains_the_hand_placed_instructions_and_is_hazard_free():
     build.build()
     s = os.path.join(build.CSRC, "_obj", "env_kernels_l16.s")

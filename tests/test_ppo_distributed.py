@@ -112,6 +112,46 @@ def test_two_rank_learn_loop_keeps_replicas_in_sync(tmp_path):
     assert len(np.load(tmp_path / "log_0.npy")) == 2 and np.isfinite(p0).all()
 
 
+def _run_workers(tmp_path, device, world, envs, steps, policy):
+    """start `world` processes of tests/two_rank_ppo_worker.py (gloo on 127.0.0.1) and return their saved dicts"""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "two_rank_ppo_worker.py"), "--device", device, "--envs", str(envs),
+                                       "--steps", str(steps), "--policy", policy, "--out", str(tmp_path)], env=env))
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    return [dict(np.load(os.path.join(str(tmp_path), "rank%dof%d.npz" % (r, world)))) for r in range(world)]
+
+
+def check_two_ranks_equal_single_process(tmp_path, device, envs, steps, policy):
+    """N-rank job == the single-process job on the concatenated pool: the ranks' rollouts ARE the halves of the big rollout (bit for
+    bit: global env ids address every random draw -- env RNG and sampling noise), and the data-parallel update gives the same
+    parameters up to the summation order of the gradient.  (Exact equality of the rollouts is asserted on the GPU path.)"""
+    two = _run_workers(tmp_path, device, 2, envs, steps, policy)
+    one = _run_workers(tmp_path, device, 1, 2 * envs, steps, policy)[0]
+    for key in ("obs", "actions", "values", "neglogpacs", "returns", "masks"):
+        a = np.concatenate([two[0][key], two[1][key]], axis=1)      # [T, N, ...]
+        assert a.shape == one[key].shape, key
+        err = np.abs(a.astype(np.float64) - one[key].astype(np.float64)).max()
+        if device == "cuda" or key == "masks":
+            # the HIP kernels compute every env row on its own (an MFMA row's accumulation order does not depend on its neighbours)
+            assert np.array_equal(a, one[key]), (key, err)
+        else:
+            # CPU BLAS blocks a [3, k] and a [6, k] product differently: last-bit differences in the policy outputs, same samples
+            assert err < 2e-4 * (1.0 + np.abs(one[key]).max()), (key, err)
+    np.testing.assert_array_equal(two[0]["params"], two[1]["params"])                 # replicas bit-identical
+    np.testing.assert_allclose(two[0]["params"], one["params"], atol=3e-6)              # same update up to summation order
+    return two, one
+
+
+@pytest.mark.parametrize("policy", ["lstm", "mlp"])
+def test_two_rank_iteration_equals_single_process_on_the_concatenated_pool(tmp_path, policy):
+    check_two_ranks_equal_single_process(tmp_path, "cpu", 3, 12, policy)
+
+
 def test_single_process_learn_with_mlp_and_lstm():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from conftest import load_env_cfg

@@ -23,4 +23,7 @@ for spec in sys.argv[1:]:
     subprocess.check_call([B.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib])
     for o in objs:
         os.remove(o)
+    for f in os.listdir(out):     # the ISA route's intermediates (they would travel to the GPU box with every gpurun snapshot)
+        if f.startswith(name + "_l") and f.split(".", 1)[-1] in ("dev.o", "dev.out", "hipfb", "raw.s", "s"):
+            os.remove(os.path.join(out, f))
     print(lib)

@@ -27,7 +27,7 @@ def measure(policy="lstm", envs=4096, steps=750, iters=3, epochs=10, cfg_name="d
     for kv in filter(None, os.environ.get("IRRL_CFG_OVERRIDE", "").split(",")):      # A/B runs: e.g. IRRL_CFG_OVERRIDE=ContactSolver=0
         k, v = kv.split("=")
         cfg[k] = yaml.safe_load(v)
-    cfg["seedd"] = int(cfg.get("seedd", 1)) + 7919 * rank   # different robots on every rank of a multi-GPU run
+    cfg["EnvIdOffset"] = rank * envs   # rank r owns the global env ids r * envs .. of the one big pool (same seed everywhere)
     env = TorchVecEnv(FlexibleGymEnv(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY__, yaml.safe_dump(cfg)))
     lstm = policy == "lstm"
     model = PPO2(policy=CustomLSTMPolicy if lstm else MlpPolicy, env=env, gamma=0.99, n_steps=steps, ent_coef=0.0, learning_rate=1e-3,
