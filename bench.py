@@ -40,7 +40,7 @@ sys.path.insert(0, ROOT)
 
 # algorithmic cost of one env-step (SURVEY 8d / BASELINE.md section 4)
 ALG_BYTES_PER_ENV_STEP = 1521.0
-ALG_FLOPS_PER_ENV_STEP = 1.15e5  # instrumented oracle (tools/flopcount): 114 823 flop/env-step on this workload, 1.6 contact sweeps
+ALG_FLOPS_PER_ENV_STEP = 1.18e5  # instrumented oracle (tools/flopcount), the published method (Gauss-Seidel + published per-contact rule): 118 364 flop/env-step on this workload, 1.6 contact sweeps (round 2, first rule: 114 823)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 FP32_PEAK_TFLOPS = 157.3
 ACTION_SEED = 1

@@ -10,7 +10,7 @@ inline assembly), assembled, linked and bundled by the same LLVM tools the drive
 with that device binary embedded (`compile_env_unit`).  Kernel registration and launches are the ordinary HIP ones.
 
 Staleness is decided by CONTENT, not by file times: a sha256 over every source under csrc/, include/irrl_env.h and
-the compiler flags is baked into the library (`irrl_version()` = "gfx950;irrl-env r2;irrl-src-hash:<hex>"); a
+the compiler flags is baked into the library (`irrl_version()` = "gfx950;irrl-env r3;irrl-src-hash:<hex>"); a
 prebuilt `.so` is reused only when the hash found inside it equals the hash of the sources next to it.  (File times
 do not survive a fresh checkout or an rsync, and the built `.so` travels to the GPU box although git ignores it.)"""
 import hashlib
@@ -31,6 +31,43 @@ def sources(csrc=None):
     """every source / header under csrc/ is a dependency of the library (three translation units include most of them)"""
     csrc = csrc or CSRC
     return sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".hpp", ".h")))
+
+
+# the reference's own operator boundary, compiled: pybind11 module `_flexible_robot` (csrc/flexible_robot_pybind.cpp) over the
+# C-ABI -- a host-only g++ translation unit that links libirrl_env.so, built into <repo>/native/
+PYBIND_SRC = os.path.join(CSRC, "flexible_robot_pybind.cpp")
+NATIVE_DIR = os.path.join(_HERE, "..", "native")
+
+
+def pybind_module_path():
+    import sysconfig
+    return os.path.join(NATIVE_DIR, "_flexible_robot" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_pybind(force=False, verbose=False):
+    """-> path of native/_flexible_robot<EXT_SUFFIX>; rebuilt when its source or the C-ABI header is newer (content hash kept next
+    to it, like the library's)."""
+    import sysconfig
+    import pybind11
+    out = pybind_module_path()
+    h = hashlib.sha256()
+    for f in (PYBIND_SRC, HEADER):
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    want = h.hexdigest()[:16]
+    stamp = out + ".srchash"
+    if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+        return out
+    os.makedirs(NATIVE_DIR, exist_ok=True)
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"],
+           "-I" + os.path.dirname(os.path.abspath(HEADER)), PYBIND_SRC, "-o", out, "-L" + _HERE, "-lirrl_env",
+           "-Wl,-rpath,$ORIGIN/../" + os.path.basename(_HERE)]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(want + "\n")
+    return out
 
 
 def hipcc():
@@ -157,3 +194,4 @@ def build(force=False, verbose=False, extra_flags=()):
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_pybind(force="--force" in sys.argv, verbose=True))

@@ -117,7 +117,7 @@ const char *irrl_last_error(void) { return g_err.c_str(); }
 #endif
 // the build recipe (build.py) bakes a content hash of csrc/ + include/ + the compiler flags into the library, so a
 // prebuilt .so that does not match the sources next to it is detected without relying on file times
-const char *irrl_version(void) { return "gfx950;irrl-env r2;irrl-src-hash:" IRRL_SRC_HASH; }
+const char *irrl_version(void) { return "gfx950;irrl-env r3;irrl-src-hash:" IRRL_SRC_HASH; }
 
 irrl_env *irrl_env_create(const char *resource_dir, const char *cfg_yaml, int device) {
   g_err.clear();

@@ -53,6 +53,38 @@ def test_shims_mirror_the_reference_surface():
         importlib.import_module(mod)
 
 
+def load_native_module():
+    """the compiled pybind11 module native/_flexible_robot<EXT_SUFFIX> (built by build.build_pybind), imported from its file so
+    that the root-level ctypes module of the same name stays what `import _flexible_robot` gives"""
+    import importlib.util
+    import torch  # noqa: F401  (one HIP runtime per process: PyTorch's, loaded before the kernels' library)
+    from high_speed_quadrupedal_locomotion_by_irrl_amd import build
+    build.build()
+    path = build.build_pybind()
+    spec = importlib.util.spec_from_file_location("_flexible_robot", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_compiled_pybind_module_has_the_reference_surface():
+    """raisim_gym.cpp:14-46 compiled over the C-ABI: module `_flexible_robot`, class `FlexibleGymEnv`, ctor (resourceDir, cfg) and
+    the 29 method names; without a GPU the constructor fails loudly with the engine's message"""
+    import yaml
+    import high_speed_quadrupedal_locomotion_by_irrl_amd as pkg
+    from high_speed_quadrupedal_locomotion_by_irrl_amd import _lib
+    mod = load_native_module()
+    assert mod.__name__ == "_flexible_robot" and mod.engine_version() == _lib.version()
+    cls = mod.FlexibleGymEnv
+    for m in REF_METHODS:
+        assert callable(getattr(cls, m)), m
+    assert "resourceDir: str, cfg: str" in cls.__init__.__doc__
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no HIP device|gfx950"):
+            cls(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY__, yaml.safe_dump(load_env_cfg("default_cfg.yaml")))
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     import torch
     if torch.cuda.is_available():

@@ -204,6 +204,67 @@ def test_reference_call_surface():
     assert len(info2) == 32 and "episode" in info2[0]
 
 
+def test_compiled_pybind_boundary_matches_the_ctypes_shim():
+    """The reference's own boundary, compiled (native/_flexible_robot: pybind11 over the C-ABI, raisim_gym.cpp:14-46): numpy
+    arrays by reference and filled in place, TypeError on a wrong dtype / layout (no silent copy), ValueError on a wrong shape,
+    bit-identical results to the ctypes class over 30 steps with resets, usable as the `impl` of RaisimGymVecEnv."""
+    import yaml
+    import high_speed_quadrupedal_locomotion_by_irrl_amd as pkg
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.vec_env import RaisimGymVecEnv
+    from test_abi_surface import REF_METHODS, load_native_module
+    mod = load_native_module()
+    n = 48
+    cfg = load_env_cfg("default_cfg.yaml", num_envs=n)
+    text = yaml.safe_dump(cfg)
+    nat = mod.FlexibleGymEnv(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY__, text)
+    nat.init()
+    ref = _hip(cfg)
+    assert all(callable(getattr(nat, m)) for m in REF_METHODS)
+    assert (nat.getNumOfEnvs(), nat.getObDim(), nat.getActionDim(), nat.getExtraInfoDim(), nat.GetOriginStateDim()) == (n, 35, 12, 6, 41)
+    assert nat.getExtraInfoNames() == ref.impl.getExtraInfoNames()
+    ob, rew, done, extra = np.zeros((n, 35), np.float32), np.zeros(n, np.float32), np.zeros(n, np.bool_), np.zeros((n, 6), np.float32)
+    nat.observe(ob)
+    assert np.array_equal(ob, ref.observe()) and ob.any()                       # filled in place
+    rng = np.random.RandomState(11)
+    n_done = 0
+    for k in range(30):
+        a = PL.random_actions(rng, n, 0.5)
+        if k == 5:
+            st = nat.get_state()
+            st[::7, PL.S["GC"] + 2] = 0.14
+            nat.set_state(st); ref.set_state(st)
+        nat.step(a, ob, rew, done, extra)
+        ob_r, rew_r, done_r, extra_r = ref.step(a)
+        assert np.array_equal(ob, ob_r) and np.array_equal(rew, rew_r) and np.array_equal(done, done_r) and np.array_equal(extra, extra_r)
+        n_done += int(done.sum())
+    assert n_done >= 6
+    out_n, out_r = np.zeros((n, 41), np.float32), np.zeros((n, 41), np.float32)
+    nat.OriginState(out_n); ref.impl.OriginState(out_r)
+    assert np.array_equal(out_n, out_r)
+    r24, r24r = np.zeros((n, 24), np.float32), np.zeros((n, 24), np.float32)
+    nat.ReferenceState(r24); ref.impl.ReferenceState(r24r)
+    assert np.array_equal(r24, r24r)                                              # the VEC:223-226 dispatch quirk, both
+    minv, minv_r = np.zeros((n, 324), np.float32), np.zeros((n, 324), np.float32)
+    nat.GetInverseMassMatrix(minv); ref.impl.GetInverseMassMatrix(minv_r)
+    assert np.array_equal(minv, minv_r)
+    # the Eigen::Ref contract: no conversion, no copy
+    with pytest.raises(TypeError):
+        nat.observe(np.zeros((n, 35), np.float64))
+    with pytest.raises(TypeError):
+        nat.observe(np.zeros((35, n), np.float32).T)                              # not C-contiguous
+    with pytest.raises(TypeError):
+        nat.step(a, ob, rew, np.zeros(n, np.float32), extra)                      # done must be bool
+    with pytest.raises(ValueError):
+        nat.observe(np.zeros((n, 34), np.float32))
+    with pytest.raises(RuntimeError, match="Flag_Crucial"):
+        nat.GetSphereInfo(np.zeros((n, 4), np.float32))
+    # the reference's Python adapter on top of the compiled class
+    venv = RaisimGymVecEnv(mod.FlexibleGymEnv(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY__, text))
+    o0 = venv.reset()
+    o1, r1, d1, info = venv.step(PL.random_actions(rng, n, 0.3))
+    assert o0.shape == (n, 35) and o1.dtype == np.float32 and r1.shape == (n,) and d1.dtype == np.bool_ and len(info) == n
+
+
 def test_terrain_and_per_episode_randomisation_config5():
     """BASELINE config 5 ingredients: Perlin height field shared by the pool + friction/mass/COM/thigh randomisation
     redrawn at every reset."""

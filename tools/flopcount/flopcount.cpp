@@ -23,6 +23,7 @@ int main(int argc, char **argv) {
   c.Stiffness = 40; c.Stiffness_Low = 40; c.AbadRatio = 1; c.Damping = 1; c.Freq = 30; c.max_time = 1.5; c.CubeNum = 1; c.FPS = 60;
   c.ObsNoise = (argc > 1) ? 2.0 : 0.0; c.GaitType = 1; c.MotorMaxTorque = 18; c.MotorCriticalSpeed = 100; c.MotorMaxSpeed = 200;
   c.ContactIterations = 6; c.SharedNoiseScalar = 1; c.ContactTolerance = 1e-4;
+  c.ContactSolver = getenv("IRRL_FLOPCOUNT_SOLVER") ? atoi(getenv("IRRL_FLOPCOUNT_SOLVER")) : 1;   /* 1 = the published method: Gauss-Seidel + the published per-contact rule */
   orc_env *h = orc_create(&c);
   orc_init(h);
   const int n = c.num_envs;
@@ -36,7 +37,7 @@ int main(int argc, char **argv) {
   const int K = 100;
   for (int k = 0; k < K; k++) { for (auto &a : act) a = rnd(); orc_step(h, act.data(), ob.data(), rew.data(), done.data(), extra.data()); }
   double per = (double)CountReal::n / ((double)K * n);
-  printf("{\"flops_per_env_step\": %.1f, \"envs\": %d, \"steps\": %d, \"mean_contact_sweeps\": %.3f, \"convention\": \"add/sub/mul/div/sqrt/transcendental = 1\"}\n",
-         per, n, K, orc_mean_contact_sweeps(h));
+  printf("{\"contact_solver\": %d, \"flops_per_env_step\": %.1f, \"envs\": %d, \"steps\": %d, \"mean_contact_sweeps\": %.3f, \"convention\": \"add/sub/mul/div/sqrt/transcendental = 1\"}\n",
+         c.ContactSolver, per, n, K, orc_mean_contact_sweeps(h));
   return 0;
 }

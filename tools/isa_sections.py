@@ -1,18 +1,31 @@
 """Instruction-count breakdown of one physics substep of the step kernel (16-lane layout) by source section.
 Builds csrc/env_kernels.hip to assembly with -DIRRL_MARKS (section markers + scheduling barriers at the section borders, so
 the total is a few percent above the production build) and counts VALU / SALU / other instructions between markers.
-usage: python tools/isa_sections.py [extra -D flags]"""
+usage: python tools/isa_sections.py [--kernel NAME] [extra -D flags]   (default kernel: irrl_step_kernel_l16 = the published contact rule;
+irrl_step_kernel_dir_l16 = the build's first rule)"""
 import os, re, subprocess, sys, tempfile, collections
 
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 src = os.path.join(root, "high_speed_quadrupedal_locomotion_by_irrl_amd", "csrc", "env_kernels.hip")
 out = os.path.join(tempfile.mkdtemp(), "marks.s")
+kernel = "irrl_step_kernel_l16"
+if "--kernel" in sys.argv:
+    i = sys.argv.index("--kernel")
+    kernel = sys.argv[i + 1]
+    del sys.argv[i:i + 2]
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-fno-signed-zeros",
        "-DIRRL_LANES_PER_ROBOT=16", "-DIRRL_MARKS", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-S", "--cuda-device-only", "-o", out, src] + sys.argv[1:]
 subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
 sec, counts, order = None, collections.OrderedDict(), []
+inside = False
 for line in open(out):
     t = line.strip()
+    if t.split(";")[0].strip() == kernel + ":":
+        inside = True
+    elif inside and t.startswith(".Lfunc_end"):
+        inside = False
+    if not inside:
+        continue
     m = re.match(r"; IRRL_MARK (\w+)", t)
     if m:
         sec = m.group(1)
