@@ -625,73 +625,99 @@ IRRL_DEV v3 solve_contact(const ContactBlock &B, v3 c, v3 n, vf vstar, vf mu, vm
 #define IRRL_MD_SMIN 0.04f
 #define IRRL_MD_SIGMAX 1.0e4f
 #define IRRL_MD_MUMIN 1.0e-6f
-struct ContactBlockMD { v3 t1, t2; vf mu, g1, g2, ignn, A11, A12, A22, be1, be2, detA, idetA, P11, P12, P22, detP, mix, zc1, zc2; };
+// The tangential plane's algebra is written on PAIRS (vf2: one v_pk_*_f32 per pair operation on the GPU): column pairs of the 2x2
+// matrices, so that M v = M_col1 v.x + M_col2 v.y is two packed instructions with the halves of v broadcast by op_sel.
+struct ContactBlockMD {
+  vf2 Tx, Ty, Tz;          // (t1.k, t2.k), k = x, y, z: the frame's tangents, packed by component
+  vf2 g, be, zc;           // G_tn, beta = -G_tn / G_nn, centre of the cone section's ellipse
+  vf2 AC1, AC2;            // columns of A = G_tt - G_tn G_tn^T / G_nn (symmetric)
+  vf2 NI1, NI2;            // columns of -A^-1
+  vf2 PC1, PC2, QC1, QC2;  // columns of P and of adj(P)
+  vf mu2, ignn, detA, idetA2, detP, detP2, mix;
+};
 IRRL_DEV ContactBlockMD make_contact_block_md(sym3 G, v3 n, vf mu_in) {
   ContactBlockMD B;
   const vf mu = v_max(mu_in, IRRL_MD_MUMIN);
-  B.mu = mu;
+  B.mu2 = mu * mu;
   // branch-free orthonormal frame around n (Duff et al. 2017)
   const vf sg = vsel(n.z >= 0.0f, 1.0f, -1.0f);
   const vf fa = -v_rcp(sg + n.z), fb = n.x * n.y * fa;
-  B.t1 = mk3(1.0f + sg * n.x * n.x * fa, sg * fb, -sg * n.x);
-  B.t2 = mk3(fb, sg + n.y * n.y * fa, -n.y);
-  const v3 Gt1 = mul(G, B.t1), Gt2 = mul(G, B.t2), Gn = mul(G, n);
-  B.g1 = dot(B.t1, Gn); B.g2 = dot(B.t2, Gn);
+  B.Tx = pk2(1.0f + sg * n.x * n.x * fa, fb);
+  B.Ty = pk2(sg * fb, sg + n.y * n.y * fa);
+  B.Tz = pk2(-sg * n.x, -n.y);
+  // G (t1 | t2) by rows, G n
+  const vf2 GTx = G.xx * B.Tx + G.xy * B.Ty + G.xz * B.Tz, GTy = G.xy * B.Tx + G.yy * B.Ty + G.yz * B.Tz, GTz = G.xz * B.Tx + G.yz * B.Ty + G.zz * B.Tz;
+  const v3 Gn = mul(G, n);
+  const vf2 a1 = pk_lo(B.Tx) * GTx + pk_lo(B.Ty) * GTy + pk_lo(B.Tz) * GTz;     // (t1.G t1, t1.G t2)
+  const vf2 a2 = pk_hi(B.Tx) * GTx + pk_hi(B.Ty) * GTy + pk_hi(B.Tz) * GTz;     // (t2.G t1, t2.G t2)
+  B.g = Gn.x * B.Tx + Gn.y * B.Ty + Gn.z * B.Tz;
   B.ignn = v_rcp(dot(n, Gn));
-  B.A11 = dot(B.t1, Gt1) - B.g1 * B.g1 * B.ignn; B.A12 = dot(B.t1, Gt2) - B.g1 * B.g2 * B.ignn; B.A22 = dot(B.t2, Gt2) - B.g2 * B.g2 * B.ignn;
-  B.be1 = -B.g1 * B.ignn; B.be2 = -B.g2 * B.ignn;
-  B.detA = B.A11 * B.A22 - B.A12 * B.A12;
-  B.idetA = v_rcp(B.detA);
-  const vf mb2 = mu * mu * (B.be1 * B.be1 + B.be2 * B.be2);
-  const vf shrink = vsel(mb2 <= 1.0f - IRRL_MD_SMIN, 1.0f, v_sqrt((1.0f - IRRL_MD_SMIN) * v_rcp(v_max(mb2, 1e-30f))));
-  const vf e1 = shrink * mu * B.be1, e2 = shrink * mu * B.be2;
-  const vf s = 1.0f - (e1 * e1 + e2 * e2), is = v_rcp(s), ims = s * v_rcp(mu * mu);
-  B.P11 = (1.0f - e1 * e1) * ims; B.P12 = -e1 * e2 * ims; B.P22 = (1.0f - e2 * e2) * ims;
-  B.detP = B.P11 * B.P22 - B.P12 * B.P12;
-  B.mix = B.A22 * B.P11 - 2.0f * B.A12 * B.P12 + B.A11 * B.P22;
-  B.zc1 = mu * e1 * is; B.zc2 = mu * e2 * is;
+  const vf2 gs = B.ignn * B.g;
+  B.AC1 = a1 - pk_lo(gs) * B.g;
+  B.AC2 = a2 - pk_hi(gs) * B.g;
+  B.be = -gs;
+  const vf A11 = pk_lo(B.AC1), A12 = pk_hi(B.AC1), A22 = pk_hi(B.AC2);
+  B.detA = A11 * A22 - A12 * A12;
+  const vf idetA = v_rcp(B.detA);
+  B.idetA2 = idetA * idetA;
+  B.NI1 = (-idetA) * pk2(A22, -A12);
+  B.NI2 = (-idetA) * pk2(-A12, A11);
+  const vf mb2 = B.mu2 * pk_hsum(B.be * B.be);
+  vf shrink = mu;
+  if (IRRL_UNLIKELY(wave_any(mb2 > 1.0f - IRRL_MD_SMIN)))      // the jamming corner: not reached on the shipped configurations
+    shrink = vsel(mb2 <= 1.0f - IRRL_MD_SMIN, mu, mu * v_sqrt((1.0f - IRRL_MD_SMIN) * v_rcp(v_max(mb2, 1e-30f))));
+  const vf2 e = shrink * B.be;                                   // mu beta (capped)
+  const vf e1 = pk_lo(e), e2 = pk_hi(e);
+  const vf s = 1.0f - pk_hsum(e * e), is = v_rcp(s), ims = s * v_rcp(B.mu2);
+  const vf P11 = (1.0f - e1 * e1) * ims, P12 = -e1 * e2 * ims, P22 = (1.0f - e2 * e2) * ims;
+  B.PC1 = pk2(P11, P12); B.PC2 = pk2(P12, P22);
+  B.QC1 = pk2(P22, -P12); B.QC2 = pk2(-P12, P11);
+  B.detP = P11 * P22 - P12 * P12;
+  B.detP2 = 2.0f * B.detP;
+  B.mix = A22 * P11 - 2.0f * A12 * P12 + A11 * P22;
+  B.zc = (mu * is) * e;
   return B;
 }
 IRRL_DEV v3 solve_contact_md(const ContactBlockMD &B, v3 c, v3 n, vf vstar, vf mu_in, vm relevant) {
   const vf cn = dot(c, n) - vstar;
   const vm sep = cn >= 0.0f;
   const vf alpha = -cn * B.ignn;
-  const vf b1 = dot(c, B.t1) + alpha * B.g1, b2 = dot(c, B.t2) + alpha * B.g2;
-  const vf x1 = -(B.A22 * b1 - B.A12 * b2) * B.idetA, x2 = -(B.A11 * b2 - B.A12 * b1) * B.idetA;
-  const vf ln = alpha + B.be1 * x1 + B.be2 * x2;
-  const vm sticking = (x1 * x1 + x2 * x2 <= B.mu * B.mu * ln * ln) & (ln > 0.0f);
+  const vf2 b = c.x * B.Tx + c.y * B.Ty + c.z * B.Tz + alpha * B.g;
+  const vf2 x = pk_lo(b) * B.NI1 + pk_hi(b) * B.NI2;              // the sticking impulse's tangential part
+  const vf ln = alpha + pk_hsum(B.be * x);
+  const vm sticking = (pk_hsum(x * x) <= B.mu2 * ln * ln) & (ln > 0.0f);
   const vm frictionless = mu_in <= IRRL_MD_MUMIN;
-  vf X1 = vsel(frictionless, 0.0f, x1), X2 = vsel(frictionless, 0.0f, x2);
+  const vf zero = 0.0f;
+  vf2 X = pk_sel(frictionless, pk2(zero, zero), x);
   // slipping (wave-uniform skip when no contact whose result is kept slides -- feet standing still, the others in flight: 2.2 us
   // of the step at 4096 envs, same box A/B)
   if (wave_any(relevant & !sep & !sticking & !frictionless)) {
     const vf ia = v_rcp(v_max(alpha, 1e-30f));
-    vf d1 = x1 * ia - B.zc1, d2 = x2 * ia - B.zc2;
-    const vf s2 = d1 * d1 + d2 * d2;
+    vf2 d = ia * x - B.zc;
+    const vf s2 = pk_hsum(d * d);
     const vf isg = v_rsqrt(v_max(s2, 1e-30f));
     const vf sig = v_min(s2 * isg, IRRL_MD_SIGMAX);
-    d1 = d1 * isg; d2 = d2 * isg;
-    const vf w1 = B.A11 * d1 + B.A12 * d2, w2 = B.A12 * d1 + B.A22 * d2;
-    const vf u1 = B.detA * d1, u2 = B.detA * d2;
-    const vf q1 = B.P22 * w1 - B.P12 * w2, q2 = B.P11 * w2 - B.P12 * w1;
-    const vf Pu1 = B.P11 * u1 + B.P12 * u2, Pu2 = B.P12 * u1 + B.P22 * u2, Pq1 = B.P11 * q1 + B.P12 * q2, Pq2 = B.P12 * q1 + B.P22 * q2;
-    const vf c0 = u1 * Pu1 + u2 * Pu2, c1 = 2.0f * (q1 * Pu1 + q2 * Pu2), c2 = q1 * Pq1 + q2 * Pq2;
-    const vf rho = c0 * B.idetA * B.idetA;
-    vf gam = v_max((w1 * d1 + w2 * d2) * (sig * v_sqrt(rho) - 1.0f) * v_rcp(rho), 0.0f);
+    d = isg * d;
+    const vf2 w = pk_lo(d) * B.AC1 + pk_hi(d) * B.AC2;            // A d
+    const vf2 u = B.detA * d;                                      // adj(A) A d
+    const vf2 q = pk_lo(w) * B.QC1 + pk_hi(w) * B.QC2;            // adj(P) A d
+    const vf2 Pu = pk_lo(u) * B.PC1 + pk_hi(u) * B.PC2, Pq = pk_lo(q) * B.PC1 + pk_hi(q) * B.PC2;
+    const vf c0 = pk_hsum(u * Pu), c1 = 2.0f * pk_hsum(q * Pu), c2 = pk_hsum(q * Pq), c22 = 2.0f * c2;
+    const vf rho = c0 * B.idetA2;
+    vf gam = v_max(pk_hsum(w * d) * (sig * v_sqrt(rho) - 1.0f) * v_rcp(rho), 0.0f);
 #pragma unroll
     for (int it = 0; it < IRRL_MD_NEWTON; it++) {
       const vf p = (B.detP * gam + B.mix) * gam + B.detA, r = (c2 * gam + c1) * gam + c0;
-      const vf dp = 2.0f * B.detP * gam + B.mix, dr = 2.0f * c2 * gam + c1;
+      const vf dp = B.detP2 * gam + B.mix, dr = c22 * gam + c1;
       gam += r * (sig * v_sqrt(r) - p) * v_rcp(dp * r - 0.5f * p * dr);
     }
     const vf kk = sig * v_rcp((B.detP * gam + B.mix) * gam + B.detA);
-    const vm slide = !sticking & !frictionless;
-    X1 = vsel(slide, alpha * ((u1 + gam * q1) * kk + B.zc1), X1);
-    X2 = vsel(slide, alpha * ((u2 + gam * q2) * kk + B.zc2), X2);
+    const vf2 Xs = alpha * (kk * (u + gam * q) + B.zc);
+    X = pk_sel(!sticking & !frictionless, Xs, X);
   }
-  const vf lnn = vsel(sep, 0.0f, alpha + B.be1 * X1 + B.be2 * X2);   // normal velocity condition exact
-  X1 = vsel(sep, 0.0f, X1); X2 = vsel(sep, 0.0f, X2);
-  return mk3(X1 * B.t1.x + X2 * B.t2.x + lnn * n.x, X1 * B.t1.y + X2 * B.t2.y + lnn * n.y, X1 * B.t1.z + X2 * B.t2.z + lnn * n.z);
+  const vf lnn = vsel(sep, 0.0f, alpha + pk_hsum(B.be * X));   // normal velocity condition exact
+  const vf X1 = vsel(sep, 0.0f, pk_lo(X)), X2 = vsel(sep, 0.0f, pk_hi(X));
+  return mk3(X1 * pk_lo(B.Tx) + X2 * pk_hi(B.Tx) + lnn * n.x, X1 * pk_lo(B.Ty) + X2 * pk_hi(B.Ty) + lnn * n.y, X1 * pk_lo(B.Tz) + X2 * pk_hi(B.Tz) + lnn * n.z);
 }
 // a contact that is solved once (trunk-box corners, meteorite): block + solve in one go, by the pool's rule (RULE: compile time --
 // the step kernel is instantiated once per rule, so neither rule's live values weigh on the other's register allocation)
@@ -1256,10 +1282,12 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
       L.prof_ranksteps += nrank; L.prof_flags += 256;
 #endif
       for (int rk = 0; rk < nrank; rk++) {
-        vf cvr = cfree_r;
-        cvr = legs_rot_fma<1>(lam.z, gx1[2], legs_rot_fma<1>(lam.y, gx1[1], legs_rot_fma<1>(lam.x, gx1[0], cvr)));
-        cvr = legs_rot_fma<2>(lam.z, gx2[2], legs_rot_fma<2>(lam.y, gx2[1], legs_rot_fma<2>(lam.x, gx2[0], cvr)));
-        cvr = legs_rot_fma<3>(lam.z, gx3[2], legs_rot_fma<3>(lam.y, gx3[1], legs_rot_fma<3>(lam.x, gx3[0], cvr)));
+        // three independent accumulation chains (one per partner leg), then two adds: the single resident wave issues a DEPENDENT
+        // VALU instruction every ~3.7 ns against 2.3 ns for independent ones, and this chain heads every sweep's critical path
+        const vf c1 = legs_rot_fma<1>(lam.z, gx1[2], legs_rot_fma<1>(lam.y, gx1[1], legs_rot_fma<1>(lam.x, gx1[0], cfree_r)));
+        const vf c2 = legs_rot_fma<2>(lam.z, gx2[2], legs_rot_fma<2>(lam.y, gx2[1], legs_rot<2>(lam.x) * gx2[0]));
+        const vf c3 = legs_rot_fma<3>(lam.z, gx3[2], legs_rot_fma<3>(lam.y, gx3[1], legs_rot<3>(lam.x) * gx3[0]));
+        const vf cvr = c1 + (c2 + c3);
         v3 cv = mk3(sub_bcast<0>(cvr), sub_bcast<1>(cvr), sub_bcast<2>(cvr));
         vm commit = jacobi ? active : (active & (rank == rk));
         v3 ln = RULE ? solve_contact_md(CM, cv, nB, vstar, L.m.mu, commit) : solve_contact(CB, cv, nB, vstar, L.m.mu, commit);

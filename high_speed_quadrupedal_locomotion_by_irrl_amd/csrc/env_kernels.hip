@@ -118,6 +118,50 @@ irrl_step_policy_kernel_l16(EnvParams P, EnvState S, const float *action, float 
 }
 #endif
 
+#if IRRL_LANES_PER_ROBOT == 16
+// THE WHOLE ROLLOUT IN ONE LAUNCH (persistent): a workgroup owns 16 robots -- its four env waves, one MFMA M-tile of the policy --
+// for all `steps` control steps: policy step k -> barrier -> env.step k -> barrier -> policy step k + 1 ...  Robots never interact
+// (VEC:273) and the policy is per-robot, so NOTHING crosses workgroups: there is no grid-wide boundary between steps, a step costs
+// its workgroup's own time instead of the slowest of 1024 waves (mean 35.8 us against 43.4 us for the step kernel at 4096 envs,
+// tools/wave_spread.py), the 2 x steps launch boundaries are gone, and the layer-0 weights are fetched into LDS ONCE.  The code of a
+// step is the fused kernel's above (same device functions, same order): obs / dones / states / clipped actions / rollout rows are
+// bit-identical to the two-launch sequence.  Within a workgroup every global array is written and re-read by the same CU: the
+// vector L1 is coherent at workgroup scope (non-tgsplit), the barriers' waits on the memory counters order the accesses.
+__global__ void __launch_bounds__(256, 1)
+irrl_rollout_persistent_kernel_l16(EnvParams P, EnvState S, float *ob, float *reward, uint8_t *done, float *extra, PolicyStepArgs a, int steps) {
+  __shared__ float hbuf[2][16 * 49];
+  __shared__ float terms[16][17];
+  __shared__ float head_w[48 * 17];
+  __shared__ __attribute__((aligned(1024))) float lds_w[PolicyLdsImage<48>::FLOATS];   // 126 KiB: wh0 | wx0 of the actor and the critic stack
+  policy_prefetch_lds<48, 256>(a, lds_w);
+  const float *states_first = a.states_in, *noise0 = a.noise;
+  const long long row0 = a.row, rng0 = a.rng_step;
+  const size_t noise_stride = (size_t)a.N * (size_t)a.act_dim;
+  __syncthreads();   // the LDS image has landed
+  for (int k = 0; k < steps; k++) {
+    // threadIdx.x made opaque once per iteration: every per-lane address below is then computed inside the loop (left to the
+    // optimizer, the loop-invariant addresses of both parts -- hundreds of 64-bit values -- are hoisted and spilled)
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    a.row = row0 + k; a.rng_step = rng0 + k;
+    a.noise = noise0 ? noise0 + (size_t)k * noise_stride : nullptr;
+    a.states_in = k == 0 ? states_first : a.states_out;
+    policy_step_body<48, 9, 2, 256, true>(a, (int)blockIdx.x * 16, hbuf, terms, head_w, lds_w, 0, 0, tid);
+    __syncthreads();   // this workgroup's clipped actions (and the rollout rows) are stored and visible to its own loads
+    {
+      const int lane_ = tid & 63;
+      const int wave_ = (int)blockIdx.x * 4 + (tid >> 6);
+      int env_ = wave_ * 4 + (lane_ >> 4);
+      const int leg_ = (lane_ >> 2) & 3;
+      const bool valid_ = (env_ < P.n_envs) && ((lane_ & 3) == 0);
+      if (env_ >= P.n_envs) env_ = P.n_envs - 1;
+      irrl_plain::step_body<1>(P, S, env_, leg_, valid_, (const float *)a.clipped, ob, reward, done, extra);
+    }
+    __syncthreads();   // obs / dones / reward of step k are stored and visible: the next policy step reads them
+  }
+}
+#endif
+
 __global__ void __launch_bounds__(256, 1) IRRL_K(irrl_init_kernel)(EnvParams P, EnvState S) {
   IRRL_LANE_PROLOGUE
   irrl::init_body(P, S, env_, leg_, valid_);

@@ -26,6 +26,7 @@ IRRL_DECLARE_KERNELS(_l16)
 IRRL_DECLARE_KERNELS(_l4)
 extern "C" __global__ void irrl_terminal_kernel(EnvParams, EnvState, uint8_t *);
 extern "C" __global__ void irrl_step_policy_kernel_l16(EnvParams, EnvState, const float *, float *, float *, uint8_t *, float *, PolicyStepArgs);
+extern "C" __global__ void irrl_rollout_persistent_kernel_l16(EnvParams, EnvState, float *, float *, uint8_t *, float *, PolicyStepArgs, int);
 
 #include "irrl_config.hpp"
 #include "irrl_state_pool.hpp"
@@ -289,7 +290,26 @@ int irrl_lstm_rollout(irrl_env *h, int steps, int hid, int ob_dim, int act_dim, 
   // fuse != 0: one launch per step, env.step k together with the policy step k + 1 (16-lane layout = one MFMA M-tile per four env
   // waves, the reference's 48-unit network, pools without the meteorite).  Bit-identical to the two-launch sequence, and measured
   // SLOWER on MI355X (62.9 against 58.2 us per step at 4096 envs): kept as an option, not the default.
-  const bool fused = fuse != 0 && h->lanes == 16 && !h->P.crutial && h->P.contact_rule && hid == 48 && steps > 1;
+  const bool one_tile = h->lanes == 16 && !h->P.crutial && h->P.contact_rule && hid == 48;   // what the combined kernels are instantiated for
+  // fuse == 2: THE WHOLE ROLLOUT AS ONE PERSISTENT LAUNCH (irrl_rollout_persistent_kernel_l16): a workgroup loops over all steps for its
+  // 16 robots -- no grid-wide boundary between steps, layer-0 weights fetched into LDS once.  Same device code per step as the
+  // other two paths, bit-identical buffers.
+  if (fuse == 2 && one_tile && steps > 0) {
+    PolicyStepArgs a;
+    a.obs = obs; a.dones = dones; a.states_in = states_in; a.states_out = states_out;
+    for (int i = 0; i < 12; i++) a.w[i] = lstm_w[i];
+    a.pi_w = pi_w; a.pi_b = pi_b; a.vf_w = vf_w; a.vf_b = vf_b; a.logstd = logstd; a.noise = noise;
+    a.action = action; a.clipped = clipped; a.value = value; a.neglogp = neglogp;
+    a.row = row; a.rng_base = rng_base;
+    a.mb_obs = mb_obs; a.mb_actions = mb_actions; a.mb_values = mb_values; a.mb_neglogp = mb_neglogp; a.mb_dones = mb_dones;
+    a.mb_rewards = mb_rewards; a.prev_reward = mb_rewards ? env_reward : nullptr;
+    a.rng_step = rng_step; a.rng_seed = rng_seed; a.rng_on = rng_on; a.env_id_offset = (unsigned)env_id_offset;
+    a.N = n; a.ob_dim = ob_dim; a.act_dim = act_dim;
+    hipLaunchKernelGGL(irrl_rollout_persistent_kernel_l16, dim3((n + 15) / 16), dim3(256), 0, h->stream, h->P, h->S, obs, env_reward, dones, env_extra, a, steps);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
+  const bool fused = fuse == 1 && one_tile && steps > 1;
   if (steps > 0 && policy(0) != 0) { g_err = "irrl_lstm_rollout: policy step refused its arguments"; return 1; }
   for (int k = 0; k < steps; k++) {
     if (fused && k + 1 < steps) {

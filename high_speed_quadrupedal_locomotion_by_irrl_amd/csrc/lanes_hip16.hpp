@@ -20,11 +20,23 @@ typedef int32_t vi;
 typedef uint32_t vu;
 typedef bool vm;
 
+// a PAIR of f32 per lane in an even-aligned register pair: +, -, * and a * b + c on pairs are ONE v_pk_{add,mul,fma}_f32 each
+// (2.55 ns against 2.28 ns for a scalar FMA with one resident wave per SIMD, i.e. 1.3 ns per useful FMA), and op_sel broadcasts
+// either half of an operand for free (the compiler emits it for the .xx / .yy swizzles and for pk2(s, s)).  Used where the
+// algebra IS 2-vectors from the start -- the tangential plane of the published per-contact solve -- not as a vectorizer target.
+typedef float vf2 __attribute__((ext_vector_type(2)));
+
 // region executed by sub-lane 0 of every leg only (a real branch: the other lanes idle through it)
 #define IRRL_SUB0_ONLY_BEGIN if ((threadIdx.x & 3u) == 0u) {
 #define IRRL_SUB0_ONLY_END }
 
 namespace lanes {
+
+IRRL_DEV vf2 pk2(vf a, vf b) { vf2 r; r.x = a; r.y = b; return r; }
+IRRL_DEV vf pk_lo(vf2 a) { return a.x; }
+IRRL_DEV vf pk_hi(vf2 a) { return a.y; }
+IRRL_DEV vf pk_hsum(vf2 a) { return a.x + a.y; }
+IRRL_DEV vf2 pk_sel(vm m, vf2 a, vf2 b) { vf2 r; r.x = m ? a.x : b.x; r.y = m ? a.y : b.y; return r; }
 
 IRRL_DEV vi leg_id() { return (vi)((threadIdx.x >> 2) & 3u); }
 IRRL_DEV vi sub_id() { return (vi)(threadIdx.x & 3u); }

@@ -181,13 +181,15 @@ LSTM_DEV void policy_prefetch_lds(const PolicyStepArgs &a, float *lds_w) {
 
 template <int HID, int OBK, int VPW, int NTHR, bool LDSW = false>
 LSTM_DEV void policy_step_body(const PolicyStepArgs &a, const int e0, float (*hbuf)[16 * (HID + 1)], float (*terms)[17], float *head_w,
-                               const float *lds_w = nullptr, unsigned long long prof_t0 = 0, unsigned long long prof_t1 = 0) {
+                               const float *lds_w = nullptr, unsigned long long prof_t0 = 0, unsigned long long prof_t1 = 0, const int tid_opaque = -1) {
   constexpr int NW = HID / 16;
   constexpr int KS = HID / 4;
   constexpr int LD = HID + 1;
   constexpr int SD = 8 * HID;
   static_assert(VPW == 1 ? NTHR == 2 * NW * 64 : (VPW == 2 && NTHR >= NW * 64), "workgroup shape");
-  const int tid = threadIdx.x;
+  // tid_opaque: the persistent rollout kernel hands in threadIdx.x through an empty asm every iteration, so that the per-lane
+  // address arithmetic below stays INSIDE its step loop (hoisted, it is hundreds of live 64-bit registers: 2 KB of scratch)
+  const int tid = tid_opaque >= 0 ? tid_opaque : (int)threadIdx.x;
   const int w = tid >> 6, l = tid & 63;
   const int col = l & 15, rq = l >> 4;
   const bool mine = VPW == 1 ? true : (w < NW);                 // wave-uniform: this wave owns virtual waves

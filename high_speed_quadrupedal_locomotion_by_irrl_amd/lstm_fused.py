@@ -260,7 +260,8 @@ def policy_rollout(policy, env_impl, steps, obs, states, dones, rng, rollout, ou
     """`steps` rollout steps (policy_step + env.step on the clipped action) issued back to back by one C call
     (irrl_lstm_rollout): obs / dones / states are updated in place, rows row .. row + steps - 1 of the rollout buffers are written
     (rewards one row behind, the last one is left in `env_reward`).  `env_impl` is the FlexibleGymEnv that owns the pool.
-    fused=True: env.step k and policy step k + 1 as one launch (csrc/env_kernels.hip irrl_step_policy_kernel_l16; same bits,
+    fused=2: the whole rollout as ONE persistent launch (irrl_rollout_persistent_kernel_l16: a workgroup loops over all steps for its
+    16 robots); fused=1 / True: env.step k and policy step k + 1 as one launch (csrc/env_kernels.hip irrl_step_policy_kernel_l16; same bits,
     measured slower than two launches -- an experiment)."""
     lib = _lib.load()
     N, ob_dim = obs.shape
@@ -287,7 +288,7 @@ def policy_rollout(policy, env_impl, steps, obs, states, dones, rng, rollout, ou
                                _ptr(noise_all) if noise_all is not None else None, rng_on, seed, step, base, env0,
                                _ptr(action), _ptr(clipped), _ptr(value), _ptr(neglogp), int(rollout["row"]),
                                _ptr(rollout["mb_obs"]), _ptr(rollout["mb_actions"]), _ptr(rollout["mb_values"]), _ptr(rollout["mb_neglogpacs"]),
-                               _ptr(rollout["mb_dones"]), _ptr(rollout["mb_rewards"]), _ptr(env_reward), _ptr(env_extra), 1 if fused else 0,
+                               _ptr(rollout["mb_dones"]), _ptr(rollout["mb_rewards"]), _ptr(env_reward), _ptr(env_extra), int(fused),
                                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     _lib.check(rc)
 

@@ -125,15 +125,17 @@ class _FusedHeadsLoss(torch.autograd.Function):
     gradients in one launch (`irrl_ppo_heads_loss`): replaces the heads' forward GEMMs, the [M,12] x [12,48] dx GEMM that alone
     took 2.45 ms per epoch at 4096 x 750 (it writes 590 MB), the two tall weight-gradient reductions and the loss kernel.
     backward() scales every returned gradient by the upstream gradient of `loss` (a caller may scale the loss: loss / world,
-    gradient accumulation, loss scaling); PPO2 calls loss.backward() directly, and the upstream 1 is recognised on the HOST
-    (autograd hands a fresh ones-tensor whose value is read only when `check_unit_grad` asks for it -- the default multiplies,
-    two more passes over [M,48], 0.3 ms per epoch at 4096 x 750, instead of trusting an assumption)."""
+    gradient accumulation, loss scaling) -- two more passes over [M,48], 0.3-0.5 ms per epoch at 4096 x 750.  A caller that
+    backpropagates the loss ITSELF, unscaled, says so per call (`unit_grad=True`, the last argument: PPO2._train_step calls
+    loss.backward() on it directly) and the row gradients are returned as they are; nothing is assumed by default."""
     N_BLOCKS = 1024
 
     @staticmethod
-    def forward(ctx, h_pi, h_v, pi_w, pi_b, vf_w, vf_b, logstd, actions, returns, old_values, old_neglogp, adv_stats, cliprange, ent_coef, vf_coef):
+    def forward(ctx, h_pi, h_v, pi_w, pi_b, vf_w, vf_b, logstd, actions, returns, old_values, old_neglogp, adv_stats, cliprange, ent_coef, vf_coef,
+                unit_grad=False):
         from . import _lib
         lib = _lib.load()
+        ctx.unit_grad = bool(unit_grad)
         H, A = h_pi.shape[-1], pi_w.shape[1]
         M = h_pi.numel() // H
         hp, hv = h_pi.contiguous(), h_v.contiguous()
@@ -163,10 +165,10 @@ class _FusedHeadsLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g_stats):
         d_hp, d_hv, d_wpi, d_bpi, d_wv, d_bv, d_logstd = ctx.saved_tensors
-        # in place: the saved row gradients are this node's own buffers and backward runs once (retain_graph is not supported here)
-        d_hp, d_hv = d_hp.mul_(g_loss), d_hv.mul_(g_loss)
-        d_wpi, d_bpi, d_wv, d_bv, d_logstd = d_wpi * g_loss, d_bpi * g_loss, d_wv * g_loss, d_bv * g_loss, d_logstd * g_loss
-        return d_hp, d_hv, d_wpi, d_bpi, d_wv, d_bv, d_logstd, None, None, None, None, None, None, None, None
+        if not ctx.unit_grad:
+            d_hp, d_hv = d_hp * g_loss, d_hv * g_loss
+            d_wpi, d_bpi, d_wv, d_bv, d_logstd = d_wpi * g_loss, d_bpi * g_loss, d_wv * g_loss, d_bv * g_loss, d_logstd * g_loss
+        return d_hp, d_hv, d_wpi, d_bpi, d_wv, d_bv, d_logstd, None, None, None, None, None, None, None, None, None
 
 
 def fused_ppo_loss_supported(policy, obs):
@@ -205,7 +207,9 @@ class Runner(object):
         # re-capture after a setter, start sooner and run ~0.5 us per kernel shorter than graph nodes (ROCm 7.2, MI355X)
         self.rollout_launch = "direct" if (self._fused and hasattr(model.policy, "fused_rollout") and hasattr(getattr(env, "wrapper", None), "_h")
                                            and hasattr(env, "extra")) else "graph"
-        self.rollout_one_launch_per_step = bool(int(os.environ.get("IRRL_ROLLOUT_FUSED", "0")))   # experiment: env.step + policy step in one kernel
+        # 0 = two launches per step, 1 = env.step k + policy step k + 1 in one kernel (an experiment, slower), 2 = the whole rollout as ONE
+        # persistent launch (a workgroup loops over all steps for its 16 robots; falls back to 0 where the kernel is not instantiated)
+        self.rollout_one_launch_per_step = int(os.environ.get("IRRL_ROLLOUT_FUSED", "0"))
         self._raw_env = hasattr(env, "step_into") and hasattr(env, "account_rollout") and dev.type == "cuda"
         # sampling noise: "kernel" = the engine's counter RNG inside the fused policy kernel (fused path only; the generic
         # path draws from the model's generator per step), "torch" = standard normals for the whole rollout drawn up front
@@ -441,7 +445,7 @@ class PPO2(object):
                 # ... and the two heads with it: the LSTM stacks hand their last-layer outputs straight to the kernel
                 h_pi, h_v = pol.latents(obs, states, masks)
                 loss, stats = _FusedHeadsLoss.apply(h_pi, h_v, pol.pi.w, pol.pi.b, pol.vf.w, pol.vf.b, pol.logstd, actions, returns, values,
-                                                    neglogpacs, adv_stats, cliprange_now, self.ent_coef, self.vf_coef)
+                                                    neglogpacs, adv_stats, cliprange_now, self.ent_coef, self.vf_coef, True)   # loss.backward() below, unscaled
             else:
                 pmean, vpred = pol.evaluate_raw(obs, states, masks)
                 loss, stats = _FusedPPOLoss.apply(pmean, vpred, pol.logstd, actions, returns, values, neglogpacs, adv_stats,

@@ -225,7 +225,9 @@ int irrl_lstm_policy_step(int hid, int ob_dim, int act_dim, int N, const float *
  * (= prev_reward of the next policy step) and the extras to `env_extra` [N,6].  What ppo2.Runner used to record as a hipGraph of
  * 2 x steps kernel nodes (same speed, no capture).  fuse != 0: env.step k and the policy step k + 1 run as ONE launch (a workgroup =
  * the four env waves of 16 robots = one MFMA M-tile; 16-lane layout, hid 48, no Crutial; otherwise ignored) -- bit-identical
- * results, measured slower than the two-launch sequence on MI355X, so callers pass 0 unless they are measuring it. */
+ * results, measured slower than the two-launch sequence on MI355X.  fuse == 2: the whole rollout as ONE persistent launch (a workgroup
+ * loops over all `steps` for its 16 robots: no grid-wide boundary between steps; same conditions, otherwise the two-launch sequence) --
+ * bit-identical results again. */
 int irrl_lstm_rollout(irrl_env *env, int steps, int hid, int ob_dim, int act_dim, float *obs, uint8_t *dones, const float *states_in,
                       float *states_out, const float *const *lstm_w, const float *pi_w, const float *pi_b, const float *vf_w,
                       const float *vf_b, const float *logstd, const float *noise, int rng_on, unsigned rng_seed, long long rng_step,

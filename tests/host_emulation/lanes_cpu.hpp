@@ -54,7 +54,21 @@ inline vu operator>>(vu a, int s) { vu r; for (int i = 0; i < W; i++) r.v[i] = a
 inline vf &operator+=(vf &a, vf b) { a = a + b; return a; }
 inline vf &operator-=(vf &a, vf b) { a = a - b; return a; }
 
+// the GPU's packed f32 pair (v_pk_*_f32): two lane vectors here
+struct vf2 { vf x, y; };
+inline vf2 operator+(vf2 a, vf2 b) { return vf2{a.x + b.x, a.y + b.y}; }
+inline vf2 operator-(vf2 a, vf2 b) { return vf2{a.x - b.x, a.y - b.y}; }
+inline vf2 operator*(vf2 a, vf2 b) { return vf2{a.x * b.x, a.y * b.y}; }
+inline vf2 operator*(vf a, vf2 b) { return vf2{a * b.x, a * b.y}; }
+inline vf2 operator*(vf2 a, vf b) { return vf2{a.x * b, a.y * b}; }
+inline vf2 operator*(float a, vf2 b) { return vf2{a * b.x, a * b.y}; }
+inline vf2 operator-(vf2 a) { return vf2{-a.x, -a.y}; }
+
 namespace lanes {
+inline vf2 pk2(vf a, vf b) { return vf2{a, b}; }
+inline vf pk_lo(vf2 a) { return a.x; }
+inline vf pk_hi(vf2 a) { return a.y; }
+inline vf pk_hsum(vf2 a) { return a.x + a.y; }
 #if IRRL_EMU_W == 4
 inline vi leg_id() { vi r; for (int i = 0; i < W; i++) r.v[i] = i; return r; }
 inline vf legs_sum(vf x) {
@@ -115,6 +129,7 @@ inline vf sub_prefix_sum(vf x) {
 }
 #endif
 inline vf vsel(vm m, vf a, vf b) { vf r; for (int i = 0; i < W; i++) r.v[i] = m.v[i] ? a.v[i] : b.v[i]; return r; }
+inline vf2 pk_sel(vm m, vf2 a, vf2 b) { return vf2{vsel(m, a.x, b.x), vsel(m, a.y, b.y)}; }
 inline vi vsel_i(vm m, vi a, vi b) { vi r; for (int i = 0; i < W; i++) r.v[i] = m.v[i] ? a.v[i] : b.v[i]; return r; }
 inline vu vsel_u(vm m, vu a, vu b) { vu r; for (int i = 0; i < W; i++) r.v[i] = m.v[i] ? a.v[i] : b.v[i]; return r; }
 inline bool wave_any(vm m) { bool r = false; for (int i = 0; i < W; i++) r = r || m.v[i]; return r; }

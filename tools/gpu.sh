@@ -62,14 +62,13 @@ while [ $# -gt 0 ]; do
        for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAIT_ANY SQ_INSTS_VALU_TRANS GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
          tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
          timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/pmc_env_$tag -- python3 $R/tools/pmc_workload.py 300 4096 > $O/pmc_env_$tag.log 2>&1
-       done)
-      python tools/pmc_summarize.py $O > $O/pmc_summary.json 2> $O/pmc_summarize.log ;;
+       done) ;;      # then, back in the build container: python tools/pmc_summarize.py r03_pmc_summary
     pmclstm)
       rm -rf $O/pmc_lstm_*
       (cd /tmp && export TMPDIR=/tmp
        for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
          tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
-         timeout 900 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/pmc_lstm_$tag -- python3 $R/tools/ppo_bench.py --policy lstm --envs 4096 --iters 1 --epochs 1 --serial-stacks > $O/pmc_lstm_$tag.log 2>&1
+         timeout 900 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/pmc_lstm_$tag -- python3 $R/tools/ppo_bench.py --policy lstm --envs 4096 --iters 1 --epochs 1 > $O/pmc_lstm_$tag.log 2>&1
        done) ;;
     ppo)
       timeout 300 python tools/ppo_bench.py --policy mlp --envs 4096 --iters 3 > $O/ppo_mlp.log 2>&1

@@ -12,7 +12,7 @@ def main():
     ap.add_argument("--cfg", default="bp5_imitation.yaml")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--sigma", type=float, default=0.3, help="action scale (1.0 ~ an untrained policy: robots fall all the time)")
-    ap.add_argument("--solver", type=int, default=2)
+    ap.add_argument("--solver", type=int, default=3)
     a = ap.parse_args()
     import ctypes as C
     import numpy as np
