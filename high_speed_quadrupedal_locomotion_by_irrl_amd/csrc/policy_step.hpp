@@ -90,9 +90,11 @@ LSTM_DEV void policy_heads(const PolicyStepArgs &a, const float *hpi, const floa
       const float ang = 6.283185307179586f * ub;
       z = rad * ((ai & 1) ? __sinf(ang) : __cosf(ang));
     }
-    const float act = mean + sd * z;
+    // explicit FMAs: the contraction of these three statements must not depend on the kernel this function is inlined into (the
+    // stand-alone, the one-launch-per-step and the persistent rollout kernels promise bit-identical buffers)
+    const float act = __builtin_fmaf(sd, z, mean);
     const float d = (act - mean) / sd;
-    terms[env][ai] = 0.5f * d * d + ls;
+    terms[env][ai] = __builtin_fmaf(0.5f * d, d, ls);
     const float cl = fminf(fmaxf(act, -1.0f), 1.0f);
     a.action[o] = act;
     a.clipped[o] = cl;
@@ -110,7 +112,8 @@ LSTM_DEV void policy_heads(const PolicyStepArgs &a, const float *hpi, const floa
   if (vok) {
     float nl = 0.0f;
     for (int ai = 0; ai < A; ai++) nl += terms[vt][ai];
-    nl += 0.918938533204672742f * (float)A;   // 0.5 log(2 pi) per action dimension
+    nl = __builtin_fmaf((float)A, 0.918938533204672742f, nl);   // 0.5 log(2 pi) per action dimension (an explicit FMA: inside a step loop the
+                                                                  // product is loop-invariant and would otherwise be rounded on its own)
     const int e = e0 + vt;
     a.value[e] = val;
     a.neglogp[e] = nl;
