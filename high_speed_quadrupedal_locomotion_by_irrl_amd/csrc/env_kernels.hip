@@ -138,6 +138,12 @@ irrl_rollout_persistent_kernel_l16(EnvParams P, EnvState S, float *ob, float *re
   const long long row0 = a.row, rng0 = a.rng_step;
   const size_t noise_stride = (size_t)a.N * (size_t)a.act_dim;
   __syncthreads();   // the LDS image has landed
+#ifdef IRRL_PROFILE_PERSIST   /* diagnostic build (tools/persistent_phases.py): where a step goes, per wave, summed over the steps */
+  unsigned long long ph_[4] = {0, 0, 0, 0}, pts_ = wall_clock64();
+#define IRRL_PP_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = wall_clock64(); ph_[i] += n_ - pts_; pts_ = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define IRRL_PP_STAMP(i) do { } while (0)
+#endif
   for (int k = 0; k < steps; k++) {
     // threadIdx.x made opaque once per iteration: every per-lane address below is then computed inside the loop (left to the
     // optimizer, the loop-invariant addresses of both parts -- hundreds of 64-bit values -- are hoisted and spilled)
@@ -147,7 +153,9 @@ irrl_rollout_persistent_kernel_l16(EnvParams P, EnvState S, float *ob, float *re
     a.noise = noise0 ? noise0 + (size_t)k * noise_stride : nullptr;
     a.states_in = k == 0 ? states_first : a.states_out;
     policy_step_body<48, 9, 2, 256, true>(a, (int)blockIdx.x * 16, hbuf, terms, head_w, lds_w, 0, 0, tid);
+    IRRL_PP_STAMP(0);   // policy step
     __syncthreads();   // this workgroup's clipped actions (and the rollout rows) are stored and visible to its own loads
+    IRRL_PP_STAMP(1);   // barrier behind the policy step
     {
       const int lane_ = tid & 63;
       const int wave_ = (int)blockIdx.x * 4 + (tid >> 6);
@@ -157,8 +165,16 @@ irrl_rollout_persistent_kernel_l16(EnvParams P, EnvState S, float *ob, float *re
       if (env_ >= P.n_envs) env_ = P.n_envs - 1;
       irrl_plain::step_body<1>(P, S, env_, leg_, valid_, (const float *)a.clipped, ob, reward, done, extra);
     }
+    IRRL_PP_STAMP(2);   // env step of this wave's four robots
     __syncthreads();   // obs / dones / reward of step k are stored and visible: the next policy step reads them
+    IRRL_PP_STAMP(3);   // barrier behind the env step: waiting for the workgroup's slowest wave
   }
+#ifdef IRRL_PROFILE_PERSIST
+  if ((threadIdx.x & 63u) == 0u) {
+    const int wv = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (wv * 4 < P.n_envs) for (int i = 0; i < 4; i++) extra[(size_t)wv * 4 * 6 + i] = (float)ph_[i];
+  }
+#endif
 }
 #endif
 
