@@ -80,3 +80,20 @@ def test_bench_gpus_n_launches_n_ranks_by_itself(monkeypatch):
     monkeypatch.setattr(bench, "worker", lambda args: ran.append(args.gpus))
     bench.main()
     assert ran == [4] and not calls
+
+
+def test_baseline_config1_plumbing_runs_through_the_training_script_on_cpu():
+    """BASELINE config 1 ("64 parallel envs, CPU reference path via run_bp_v5.py --train ... plumbing"): the training script's whole
+    control flow -- argument parsing, config dump / re-parse, VecEnv construction, PPO2(CustomLSTMPolicy) with the reference's
+    hyper-parameters, rollouts, GAE, 10 epochs of BPTT, logging -- with 64 envs on CPU, the env class bound to the oracle-backed test
+    double (the RaiSim path is closed source and absent; the product package itself has no CPU path).  A 10-step rollout instead of
+    750 keeps it to seconds; tools/cpu_config1.py times the full-size version (profiles/r02_config1_cpu_*.json)."""
+    import os, sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import cpu_config1
+    out = cpu_config1.plumbing(2, 2, max_time=0.02)
+    assert out["iterations"] == 2 and out["n_steps"] == 10 and len(out["log"]) == 2
+    assert [r["nupdates"] for r in out["log"]] == [1, 2]
+    import math
+    assert all(math.isfinite(r["value_loss"]) for r in out["log"]) and out["samples_per_sec"] > 0

@@ -105,17 +105,19 @@ def test_fused_lstm_policy_full_size_agrees_with_eager():
         assert float((a - b).abs().max()) / (float(a.abs().max()) + 1e-6) < 1e-4
 
 
-@pytest.mark.parametrize("policy", ["lstm", "mlp"])
-def test_two_rank_ppo_iteration_on_the_hip_engine_equals_the_single_process_one(tmp_path, policy):
+@pytest.mark.parametrize("policy,cfg", [("lstm", "default_cfg.yaml"), ("mlp", "default_cfg.yaml"), ("lstm", "bp5_terrain.yaml")])
+def test_two_rank_ppo_iteration_on_the_hip_engine_equals_the_single_process_one(tmp_path, policy, cfg):
     """The only multi-GPU proof available without a node: two ranks (gloo, both on cuda:0), 64 envs each with
     EnvIdOffset = rank * 64, one PPO iteration through the product's Runner (fused policy-step + env-step launches, in-kernel
     sampling noise addressed by the global env id) and PPO2.update (gradient + advantage-moment all-reduce) == the single-process
-    iteration on the 128-env pool: rollout buffers bit-identical, parameters equal up to the gradient's summation order."""
+    iteration on the 128-env pool: rollout buffers bit-identical, parameters equal up to the gradient's summation order.  With
+    `bp5_terrain.yaml` this is BASELINE config 4 / 5 in miniature (LSTM policy, env shards, gradient all-reduce; shared height field,
+    per-episode friction / mass / COM randomisation, command process) on the one GPU a test box has."""
     import sys, os
     from conftest import ROOT
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_ppo_distributed import check_two_ranks_equal_single_process
-    two, one = check_two_ranks_equal_single_process(tmp_path, "cuda", 64, 24, policy)
+    two, one = check_two_ranks_equal_single_process(tmp_path, "cuda", 64, 24, policy, cfg)
     assert int(one["fused_rollout"]) == 1 and int(two[0]["fused_rollout"]) == 1
 
 

@@ -112,7 +112,7 @@ def test_two_rank_learn_loop_keeps_replicas_in_sync(tmp_path):
     assert len(np.load(tmp_path / "log_0.npy")) == 2 and np.isfinite(p0).all()
 
 
-def _run_workers(tmp_path, device, world, envs, steps, policy):
+def _run_workers(tmp_path, device, world, envs, steps, policy, cfg="default_cfg.yaml"):
     """start `world` processes of tests/two_rank_ppo_worker.py (gloo on 127.0.0.1) and return their saved dicts"""
     import subprocess
     port = _free_port()
@@ -120,18 +120,18 @@ def _run_workers(tmp_path, device, world, envs, steps, policy):
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "two_rank_ppo_worker.py"), "--device", device, "--envs", str(envs),
-                                       "--steps", str(steps), "--policy", policy, "--out", str(tmp_path)], env=env))
+                                       "--steps", str(steps), "--policy", policy, "--cfg", cfg, "--out", str(tmp_path)], env=env))
     for p in procs:
         assert p.wait(timeout=900) == 0
     return [dict(np.load(os.path.join(str(tmp_path), "rank%dof%d.npz" % (r, world)))) for r in range(world)]
 
 
-def check_two_ranks_equal_single_process(tmp_path, device, envs, steps, policy):
+def check_two_ranks_equal_single_process(tmp_path, device, envs, steps, policy, cfg="default_cfg.yaml"):
     """N-rank job == the single-process job on the concatenated pool: the ranks' rollouts ARE the halves of the big rollout (bit for
     bit: global env ids address every random draw -- env RNG and sampling noise), and the data-parallel update gives the same
     parameters up to the summation order of the gradient.  (Exact equality of the rollouts is asserted on the GPU path.)"""
-    two = _run_workers(tmp_path, device, 2, envs, steps, policy)
-    one = _run_workers(tmp_path, device, 1, 2 * envs, steps, policy)[0]
+    two = _run_workers(tmp_path, device, 2, envs, steps, policy, cfg)
+    one = _run_workers(tmp_path, device, 1, 2 * envs, steps, policy, cfg)[0]
     for key in ("obs", "actions", "values", "neglogpacs", "returns", "masks"):
         a = np.concatenate([two[0][key], two[1][key]], axis=1)      # [T, N, ...]
         assert a.shape == one[key].shape, key

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--envs", type=int, default=64)        # per rank
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--policy", default="lstm")
+    ap.add_argument("--cfg", default="default_cfg.yaml")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     import torch
@@ -28,7 +29,7 @@ def main():
     if world > 1:
         torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
-    cfg = load_env_cfg("default_cfg.yaml", num_envs=a.envs, EnvIdOffset=rank * a.envs)
+    cfg = load_env_cfg(a.cfg, num_envs=a.envs, EnvIdOffset=rank * a.envs)
     from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import CustomLSTMPolicy, MlpPolicy
     from high_speed_quadrupedal_locomotion_by_irrl_amd.ppo2 import PPO2, Runner
     if a.device == "cuda":

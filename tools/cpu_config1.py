@@ -53,7 +53,7 @@ def env_rate(n, precision, threads, seconds, cfg):
     return {"envs": n, "precision": precision, "threads": threads, "steps": steps, "env_steps_per_sec": n * steps / dt}
 
 
-def plumbing(iters, cores):
+def plumbing(iters, cores, max_time=None):
     """scripts/run_bp_v5.py --train on CPU: the script's env classes are replaced by oracle-backed doubles"""
     import tempfile
     import torch
@@ -63,6 +63,9 @@ def plumbing(iters, cores):
     import high_speed_quadrupedal_locomotion_by_irrl_amd as pkg
     cfg = yaml.safe_load(open(os.path.join(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY__, "default_cfg.yaml")))
     cfg["environment"].update(num_envs=64, render=False, num_threads=cores)
+    if max_time is not None:     # tests: a short rollout (n_steps = max_time / control_dt) through the same plumbing
+        cfg["environment"]["max_time"] = float(max_time)
+    n_steps = int(round(float(cfg["environment"]["max_time"]) / float(cfg["environment"]["control_dt"])))
     tmp = tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False)
     yaml.safe_dump(cfg, tmp)
     tmp.close()
@@ -77,11 +80,12 @@ def plumbing(iters, cores):
         rows.extend(self.log)
     script.PPO2._learn_loop = learn_loop
     t0 = time.perf_counter()
-    script.main(["--train", "--cfg", tmp.name, "--max_iter", str(64 * 750 * iters), "--save", "0"])
+    script.main(["--train", "--cfg", tmp.name, "--max_iter", str(64 * n_steps * iters), "--save", "0"])
     dt = time.perf_counter() - t0
     os.unlink(tmp.name)
-    return {"command": "scripts/run_bp_v5.py --train --cfg <default_cfg.yaml with num_envs 64> --max_iter %d" % (64 * 750 * iters),
-            "iterations": iters, "wall_s": dt, "ppo_iters_per_sec": iters / dt, "samples_per_sec": 64 * 750 * iters / dt,
+    script.PPO2._learn_loop = orig_learn
+    return {"command": "scripts/run_bp_v5.py --train --cfg <default_cfg.yaml with num_envs 64> --max_iter %d" % (64 * n_steps * iters),
+            "iterations": iters, "n_steps": n_steps, "wall_s": dt, "ppo_iters_per_sec": iters / dt, "samples_per_sec": 64 * n_steps * iters / dt,
             "log": [{k: r[k] for k in ("nupdates", "fps", "ep_reward_mean", "ep_len_mean", "explained_variance", "value_loss") if k in r} for r in rows]}
 
 
