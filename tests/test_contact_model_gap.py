@@ -159,6 +159,17 @@ def test_published_rule_single_contact_random_problems_f64_and_f32():
 
 
 @pytest.mark.parametrize("name", list(CASES))
+def test_simultaneous_sweeps_and_gauss_seidel_reach_the_same_impulses(name):
+    """the order inside a sweep (ContactSolver bit 1) changes the path, not the fixed point: converged impulses of the simultaneous
+    iteration equal the Gauss-Seidel ones, for the build's first rule (2 vs 0) and for the published one (3 vs 1)"""
+    for a, b in ((2, 0), (3, 1)):
+        pa, _, _, _ = _oracle_problem(CASES[name], solver=a)
+        pb, _, _, _ = _oracle_problem(CASES[name], solver=b)
+        scale = np.abs(pb["lam"]).max()
+        assert scale > 0 and np.abs(pa["lam"] - pb["lam"]).max() <= 1e-7 * scale, (name, a, b)
+
+
+@pytest.mark.parametrize("name", list(CASES))
 def test_block_gs_rule_against_the_published_per_contact_iteration(name):
     """ContactSolver 0 / 2 -- the build's FIRST sliding rule, kept as an option -- against the published method: the stated gap."""
     case = CASES[name]
