@@ -34,24 +34,41 @@
 #define IRRL_K(name) name##_l4
 #endif
 
+// XCD-aware block -> robots mapping.  The hardware hands consecutive workgroups to the 8 XCDs round-robin (workgroup b runs on XCD
+// b % 8), and every XCD has its own L2.  With the identity mapping the four robots of workgroup b and those of b + 1 -- neighbours
+// in every array of the pool, 16 B apart in a per-env scalar array -- sit on different XCDs, so one 128-byte line is fetched from
+// HBM by up to eight L2s.  irrl_xcd_block() renumbers the blocks so that XCD x owns ONE contiguous range of robots (a bijection of
+// [0, gridDim.x) for any grid size): a line is then fetched by one L2 (two at a range boundary).  Results do not change -- only
+// which wave computes which robot.
+__device__ __forceinline__ int irrl_xcd_block() {
+#ifdef IRRL_NO_XCD_SWIZZLE   /* A/B switch of tools/build_variants.py */
+  return (int)blockIdx.x;
+#endif
+  const int nb = (int)gridDim.x, b = (int)blockIdx.x;
+  const int x = b & 7, j = b >> 3;                  // XCD of this workgroup, its rank among that XCD's workgroups
+  const int q = nb >> 3, r = nb & 7;                // XCD x gets q workgroups, + 1 if x < r
+  return x * q + (x < r ? x : r) + j;
+}
 // env_: robot of this lane; leg_: its leg; valid_: this lane owns the stores of (robot, leg) -- with 16 lanes per robot
-// that is sub-lane 0 of each quad.  Idle rows shadow the last robot with their stores masked.
+// that is sub-lane 0 of each quad.  Idle rows shadow the last robot with their stores masked.  BLK: the (renumbered) block index.
 #if IRRL_LANES_PER_ROBOT == 16
-#define IRRL_LANE_PROLOGUE                                                                   \
+#define IRRL_LANE_PROLOGUE_B(BLK)                                                            \
   const int lane_ = (int)(threadIdx.x & 63u);                                                \
-  const int wave_ = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));               \
+  const int wave_ = (int)((BLK) * (blockDim.x >> 6) + (threadIdx.x >> 6));                    \
   int env_ = wave_ * 4 + (lane_ >> 4);                                                       \
   const int leg_ = (lane_ >> 2) & 3;                                                         \
   const bool valid_ = (env_ < P.n_envs) && ((lane_ & 3) == 0);                               \
   if (env_ >= P.n_envs) env_ = P.n_envs - 1;
 #else
-#define IRRL_LANE_PROLOGUE                                     \
+#define IRRL_LANE_PROLOGUE_B(BLK)                              \
   const int lane_ = (int)(threadIdx.x & 63u);                  \
-  int env_ = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (lane_ >> 2); \
+  int env_ = (int)((BLK) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 16 + (lane_ >> 2); \
   const int leg_ = lane_ & 3;                                  \
   const bool valid_ = env_ < P.n_envs;                         \
   if (!valid_) env_ = P.n_envs - 1; /* idle quads shadow the last robot; their stores are masked */
 #endif
+#define IRRL_LANE_PROLOGUE IRRL_LANE_PROLOGUE_B(irrl_xcd_block())          /* the stand-alone lane kernels */
+#define IRRL_LANE_PROLOGUE_IDENTITY IRRL_LANE_PROLOGUE_B((int)blockIdx.x)  /* kernels whose policy part addresses robots by blockIdx */
 
 extern "C" {
 
@@ -103,7 +120,7 @@ irrl_step_policy_kernel_l16(EnvParams P, EnvState S, const float *action, float 
   const unsigned long long pt0_ = wall_clock64();
 #endif
   {
-    IRRL_LANE_PROLOGUE
+    IRRL_LANE_PROLOGUE_IDENTITY
     // the env part keeps no LDS and, between its prologue and its epilogue, issues no global load (flat ground): the layer-0
     // policy weights travel L2 -> LDS underneath the eight substeps
     irrl_plain::step_body<1>(P, S, env_, leg_, valid_, action, ob, reward, done, extra, [&]() { policy_prefetch_lds<48, 256>(a, lds_w); });
