@@ -1,5 +1,5 @@
 """Evaluate a checkpoint in TRAINING-mode envs on the GPU (same path as the rollout: fused policy step + env step), report
-episode statistics with sampled and with deterministic actions.   usage: python tools/eval_checkpoint_gpu.py ckpt.pkl [envs]"""
+episode statistics with sampled and with deterministic actions.   usage: python tools/eval_checkpoint_gpu.py ckpt.pkl [envs] [cfg.yaml]"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch, yaml
@@ -10,7 +10,8 @@ from high_speed_quadrupedal_locomotion_by_irrl_amd.ppo2 import PPO2, Runner
 
 ck = sys.argv[1]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-cfg = yaml.safe_load(open(os.path.join(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY__, "default_cfg.yaml")))["environment"]
+cfg_path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY__, "default_cfg.yaml")
+cfg = yaml.safe_load(open(cfg_path))["environment"]
 cfg["num_envs"] = n
 env = TorchVecEnv(FlexibleGymEnv(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY__, yaml.safe_dump(cfg)))
 model = PPO2.load(ck, env=env)

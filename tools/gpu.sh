@@ -16,6 +16,8 @@
 #   pmclstm        PMC passes of the LSTM sequence kernels
 #   ppo            tools/ppo_bench.py lstm + mlp, 3 iterations each
 #   irrl2          the IRRL recipe at the benchmark scale: stage 1 imitation + stage 2 relaxation, 4096 envs, 300 updates each
+#   terrain        BASELINE config 5 on one GPU: 4096 envs on the Perlin height field with per-episode friction / mass / COM randomisation and the
+#                  command process, LSTM policy, 200 updates from scratch + evaluation of the result
 #   train200       the reference's command line (200 envs, 2e8 samples), headless evaluation of the result
 #   variants       A/B of every csrc/_variants/libirrl_env_*.so (tools/build_variants.py) on this one box, interleaved
 #   spread         per-wave durations of the step kernel (needs the `prof` variant library)
@@ -80,6 +82,11 @@ while [ $# -gt 0 ]; do
       timeout 900 python scripts/run_bp_v5.py --train --cfg $RS/default_cfg.yaml --num_envs 4096 --l 0.0005 --max_iter $((4096*750*300)) --eval_every_n 0 --load $O/irrl2/stage1.pkl 2>&1 | grep -E "nupdates|final checkpoint" | awk 'NR%10==1 || /final/' | cut -c1-330 > $O/irrl2/stage2_relaxation.log
       cp "$(grep "final checkpoint" $O/irrl2/stage2_relaxation.log | awk '{print $3}')" $O/irrl2/stage2.pkl
       timeout 300 python tools/eval_checkpoint_gpu.py $O/irrl2/stage2.pkl 256 2>&1 | grep -E "rollout|deterministic" > $O/irrl2/eval_stage2.log ;;
+    terrain)
+      RS=high_speed_quadrupedal_locomotion_by_irrl_amd/rsc; mkdir -p $O/terrain; rm -f $O/terrain/*
+      timeout 900 python scripts/run_bp_v5.py --train --cfg $RS/bp5_terrain.yaml --num_envs 4096 --l 0.001 --max_iter $((4096*750*200)) --eval_every_n 0 2>&1 | grep -E "nupdates|final checkpoint" | awk 'NR%10==1 || /final/' | cut -c1-330 > $O/terrain/train.log
+      cp "$(grep "final checkpoint" $O/terrain/train.log | awk '{print $3}')" $O/terrain/final.pkl
+      timeout 300 python tools/eval_checkpoint_gpu.py $O/terrain/final.pkl 256 $RS/bp5_terrain.yaml 2>&1 | grep -E "rollout|deterministic" > $O/terrain/eval.log ;;
     train200)
       mkdir -p $O/irrl; rm -f $O/irrl/*.log
       timeout 1500 python scripts/run_bp_v5.py --train --l 0.001 --max_iter ${MAX_ITER:-200000000} --eval_every_n 0 2>&1 | grep -E "nupdates|final checkpoint" | awk 'NR%25==1 || /final/' | cut -c1-330 > $O/irrl/stage1.log
