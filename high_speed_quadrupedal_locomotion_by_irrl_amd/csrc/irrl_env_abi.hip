@@ -8,6 +8,7 @@
 #include <stdint.h>
 #include "env_params.h"
 #include "lstm_kernels.hip"
+#include "mlp_update.hpp"
 
 // The env kernels are compiled in two lane layouts from the same source (csrc/env_kernels.hip, see build.py):
 //   _l16  16 lanes per robot (lanes_hip16.hpp): 4 robots per wave -- fills all 1024 SIMDs at 4096 robots, shortest step
@@ -722,5 +723,24 @@ int irrl_ppo_heads_loss(size_t M, int act_dim, int hid, const float *h_pi, const
   HIP_TRY(hipGetLastError());
   return 0;
 }
+
+// ---- MlpPolicy: gradients of one PPO2 minibatch, one launch per network (kernel: csrc/mlp_update.hpp) ----
+int irrl_mlp_ppo_grads(int kind, size_t n, const int64_t *idx, int ob_dim, int hid, int act_dim, const float *obs, const float *actions,
+                       const float *returns, const float *old_values, const float *old_neglogp, const float *w1, const float *b1, const float *w2,
+                       const float *b2, const float *w3, const float *b3, const float *logstd, const float *adv_stats, float cliprange, float vf_coef,
+                       float *partials, int n_blocks, void *hip_stream) {
+  if (n == 0 || n_blocks <= 0) { g_err = "irrl_mlp_ppo_grads: empty batch"; return 1; }
+  if (ob_dim != IRRL_MLP_OB || hid != IRRL_MLP_H || act_dim != 12) { g_err = "irrl_mlp_ppo_grads: built for 35 observations, [64, 64] hidden units and 12 actions"; return 1; }
+  if (kind != 0 && kind != 1) { g_err = "irrl_mlp_ppo_grads: kind is 0 (policy network) or 1 (value network)"; return 1; }
+  MlpUpdateArgs a;
+  a.n = n; a.idx = idx; a.obs = obs; a.actions = actions; a.returns = returns; a.old_values = old_values; a.old_neglogp = old_neglogp;
+  a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.logstd = logstd; a.adv_stats = adv_stats;
+  a.cliprange = cliprange; a.vf_coef = vf_coef; a.inv_n = 1.0f / (float)n; a.partials = partials;
+  if (kind == 0) hipLaunchKernelGGL(irrl_mlp_ppo_kernel<0>, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)hip_stream, a);
+  else hipLaunchKernelGGL(irrl_mlp_ppo_kernel<1>, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)hip_stream, a);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int irrl_mlp_ppo_partial_len(void) { return IRRL_MLP_P; }
 
 }  // extern "C"

@@ -171,6 +171,55 @@ class _FusedHeadsLoss(torch.autograd.Function):
         return d_hp, d_hv, d_wpi, d_bpi, d_wv, d_bv, d_logstd, None, None, None, None, None, None, None, None, None
 
 
+def mlp_ppo_grads_supported(policy, obs):
+    """The single-launch-per-network gradient kernels (`irrl_mlp_ppo_grads`) cover the reference's MlpPolicy as configured:
+    35 observations, [64, 64] tanh stacks, 12 actions."""
+    fc = getattr(policy, "pi_fc", None)
+    return bool(obs.is_cuda and fc is not None and len(fc) == 2 and tuple(fc[0].w.shape) == (35, 64) and tuple(fc[1].w.shape) == (64, 64)
+                and tuple(policy.pi.w.shape) == (64, 12) and tuple(policy.vf.w.shape) == (64, 1) and obs.dtype == torch.float32)
+
+
+def mlp_ppo_grads(policy, obs, actions, returns, old_values, old_neglogp, adv_stats, cliprange, ent_coef, vf_coef, index=None, n_blocks=256):
+    """loss = pg - ent_coef * entropy + vf_coef * vf of MlpPolicy on one minibatch, and its gradient with respect to every parameter,
+    in two launches (policy network, value network; csrc/mlp_update.hpp) -- the whole of ppo2.py:243-298's graph evaluation.
+    obs / actions / returns / old_values / old_neglogp are the FLAT rollout arrays; index (int64 device vector) picks the
+    minibatch's rows in place (None: all rows).  -> (loss, stats[pg, vf, entropy, approxkl, clipfrac], {parameter: gradient})."""
+    from . import _lib
+    lib = _lib.load()
+    dev = obs.device
+    n = int(index.numel()) if index is not None else int(returns.numel())
+    P = lib.irrl_mlp_ppo_partial_len()
+    partials = torch.empty(2, n_blocks, P, device=dev, dtype=torch.float32)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    c = lambda t: t if t.is_contiguous() else t.contiguous()
+    obs, actions, returns, old_values, old_neglogp = c(obs), c(actions), c(returns), c(old_values), c(old_neglogp)
+    ip = p(index) if index is not None else None
+    if index is not None:
+        assert index.dtype == torch.int64 and index.is_contiguous()
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    nets = ((0, policy.pi_fc, policy.pi), (1, policy.vf_fc, policy.vf))
+    for kind, fc, head in nets:
+        _lib.check(lib.irrl_mlp_ppo_grads(kind, n, ip, obs.shape[-1], fc[0].w.shape[1], actions.shape[-1], p(obs), p(actions), p(returns),
+                                          p(old_values), p(old_neglogp), p(c(fc[0].w)), p(c(fc[0].b)), p(c(fc[1].w)), p(c(fc[1].b)),
+                                          p(c(head.w)), p(c(head.b)), p(c(policy.logstd)), p(adv_stats), float(cliprange), float(vf_coef),
+                                          p(partials[kind]), n_blocks, stream))
+    sums = partials.sum(1)                                   # [2, P]: workgroups added in one fixed order
+    A = actions.shape[-1]
+    pg, kl, cf, vf = sums[0, 0] / n, sums[0, 1] / n, sums[0, 2] / n, sums[1, 0] / n
+    ent = (policy.logstd + 0.5 * (math.log(2.0 * math.pi) + 1.0)).sum()
+    loss = pg - ent * ent_coef + vf * vf_coef
+    grads = {policy.logstd: (sums[0, 4:4 + A] - ent_coef).reshape(policy.logstd.shape)}
+    o1, o2, o3, w1, w2, w3 = 20, 84, 148, 164, 164 + 48 * 64, 164 + 48 * 64 + 64 * 64
+    for kind, fc, head in nets:
+        r = sums[kind]
+        out = head.w.shape[1]
+        grads[fc[0].b], grads[fc[1].b], grads[head.b] = r[o1:o1 + 64], r[o2:o2 + 64], r[o3:o3 + out]
+        grads[fc[0].w] = r[w1:w1 + 48 * 64].view(48, 64)[:35]
+        grads[fc[1].w] = r[w2:w2 + 64 * 64].view(64, 64)
+        grads[head.w] = r[w3:w3 + 64 * 16].view(64, 16)[:, :out]
+    return loss, torch.stack([pg, vf, ent.detach(), kl, cf]), grads
+
+
 def fused_ppo_loss_supported(policy, obs):
     return bool(obs.is_cuda and hasattr(policy, "evaluate_raw") and getattr(policy, "act_dim", 0) == 12)
 
@@ -418,6 +467,7 @@ class PPO2(object):
             self.optimizer.register_step_post_hook(lambda *_a, **_k: self.policy.prepare())
         self.loss_names = ['policy_loss', 'value_loss', 'policy_entropy', 'approxkl', 'clipfrac']
         self.fused_loss = True   # single-launch loss forward + backward on the GPU (tests flip it to compare with the eager graph)
+        self.fused_mlp = True    # MlpPolicy: forward + loss + every gradient in one launch per network (tests flip it likewise)
         self.fused_heads = True  # ... including the policy / value heads and their gradients (LSTM policy, 48-unit latents)
         self.log = []
 
@@ -433,7 +483,19 @@ class PPO2(object):
         var = torch.clamp(moments[1] / moments[2] - mean * mean, min=0.0)
         return mean, var
 
-    def _train_step(self, lr_now, cliprange_now, obs, returns, masks, actions, values, neglogpacs, states=None, adv_moments=None):
+    def _train_step(self, lr_now, cliprange_now, obs, returns, masks, actions, values, neglogpacs, states=None, adv_moments=None, index=None):
+        """index: the arrays are the FLAT rollout and `index` picks this minibatch's rows (MlpPolicy's gradient kernels read them
+        in place); otherwise the arrays are the minibatch."""
+        if index is not None:
+            mean, var = adv_moments if adv_moments is not None else self._adv_moments(returns[index], values[index])
+            adv_stats = torch.stack([mean, torch.sqrt(var)]).to(torch.float32)
+            _loss, stats, grads = mlp_ppo_grads(self.policy, obs, actions, returns, values, neglogpacs, adv_stats, cliprange_now, self.ent_coef,
+                                                self.vf_coef, index=index)
+            self.optimizer.zero_grad(set_to_none=True)
+            for prm, grd in grads.items():
+                prm.grad = grd.contiguous()
+            self._apply_gradients(lr_now)
+            return stats
         mean, var = adv_moments if adv_moments is not None else self._adv_moments(returns, values)
         advs = None if (self.fused_loss and fused_ppo_loss_supported(self.policy, obs)) else returns - values
         stats = None
@@ -457,6 +519,13 @@ class PPO2(object):
                                                  self.ent_coef, self.vf_coef)
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
+        self._apply_gradients(lr_now)
+        if stats is not None:
+            return stats.detach()
+        return torch.stack([pg.detach(), vf.detach(), ent.detach(), kl.detach(), cf.detach()])
+
+    def _apply_gradients(self, lr_now):
+        """Average over ranks, clip by the global norm, Adam (ppo2.py:182-189, 283-298)."""
         params = [p for p in self.policy.parameters() if p.grad is not None]
         if self.world > 1:
             flat = torch.cat([p.grad.reshape(-1) for p in params])    # C1: one flat bucket (283 KB for the LSTM policy)
@@ -471,9 +540,6 @@ class PPO2(object):
         for g in self.optimizer.param_groups:
             g['lr'] = lr_now
         self.optimizer.step()       # (its post-step hook refreshes the kernels' permuted weight copies)
-        if stats is not None:
-            return stats.detach()
-        return torch.stack([pg.detach(), vf.detach(), ent.detach(), kl.detach(), cf.detach()])
 
     def update(self, batch, lr_now, cliprange_now):
         """All epochs / minibatches of one PPO iteration (ppo2.py:362-404)."""
@@ -505,10 +571,15 @@ class PPO2(object):
             bs = n_batch // self.nminibatches
             flat = {k: batch[k].transpose(0, 1).reshape(n_batch, *batch[k].shape[2:]) for k in
                     ("obs", "returns", "masks", "actions", "values", "neglogpacs")}   # swap_and_flatten: env-major
+            in_place = self.fused_mlp and mlp_ppo_grads_supported(self.policy, flat["obs"])
             for _ in range(self.noptepochs):
                 inds = torch.randperm(n_batch, device=self.device, generator=self.generator)
                 for start in range(0, n_batch, bs):
                     mb = inds[start:start + bs]
+                    if in_place:     # the gradient kernels read the minibatch's rows through the index: nothing is gathered
+                        losses.append(self._train_step(lr_now, cliprange_now, flat["obs"], flat["returns"], flat["masks"], flat["actions"],
+                                                       flat["values"], flat["neglogpacs"], index=mb.contiguous()))
+                        continue
                     losses.append(self._train_step(lr_now, cliprange_now, flat["obs"][mb], flat["returns"][mb], flat["masks"][mb],
                                                    flat["actions"][mb], flat["values"][mb], flat["neglogpacs"][mb]))
         return torch.stack(losses).mean(0)

@@ -164,6 +164,21 @@ int irrl_ppo_heads_loss(size_t M, int act_dim, int hid, const float *h_pi, const
                         const float *old_neglogp, const float *adv_stats, float cliprange, float vf_coef, float *d_hpi, float *d_hv, float *mean_out,
                         float *value_out, float *partials, int n_blocks, void *hip_stream);
 
+/* MlpPolicy (archi/policies.py:430-446: [64, 64] tanh stacks for policy and value over the 35 observations; the learner of BASELINE
+ * config 2) under the PPO2 loss above: forward AND backward of one network over one minibatch in one launch -- what ppo2.py:243-298
+ * (`_train_step`) evaluates through the TensorFlow graph.  kind 0 = policy network (w3 [64, 12]; uses actions, old_neglogp, logstd and
+ * the normalised advantages), kind 1 = value network (w3 [64, 1]; clipped value loss times vf_coef).  idx [n] (int64, device) selects
+ * the minibatch's rows of the flat rollout arrays (NULL: rows 0..n-1); nothing is gathered.  Weights are [in, out] row-major.
+ * Writes per-workgroup partial sums [n_blocks, irrl_mlp_ppo_partial_len()], to be added up by the caller (fixed order); a row is
+ * scalars[4] (kind 0: pg loss, approx KL, clip fraction; kind 1: value loss -- sums over samples, divide by n) | d logstd[16] (pg part) |
+ * d b1[64] | d b2[64] | d b3[16] | d W1[48][64] (rows >= 35 are zero) | d W2[64][64] | d W3[64][16] (columns >= act / 1 are zero),
+ * gradients of loss = pg - ent_coef * entropy + vf_coef * vf with the means taken over the n samples. */
+int irrl_mlp_ppo_grads(int kind, size_t n, const int64_t *idx, int ob_dim, int hid, int act_dim, const float *obs, const float *actions,
+                       const float *returns, const float *old_values, const float *old_neglogp, const float *w1, const float *b1, const float *w2,
+                       const float *b2, const float *w3, const float *b3, const float *logstd, const float *adv_stats, float cliprange, float vf_coef,
+                       float *partials, int n_blocks, void *hip_stream);
+int irrl_mlp_ppo_partial_len(void);
+
 /* synthetic action stream of the benchmark (a = clip(sigma N(0,1), -1, 1) from Philox(seed, stream = env,
  * counter = step)): fills out[n_steps][n_envs][12] (device) for envs env0 .. and steps step0 ..; values depend only on
  * (seed, global env id, step), not on the shape of the request.  tests/ hold the numpy twin. */

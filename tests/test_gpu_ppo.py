@@ -452,6 +452,79 @@ def test_fused_heads_and_loss_gradients_match_autograd(M):
         assert float((a - 0.25 * b).abs().max()) < 2e-4 * scale, (name, "scaled")
 
 
+@pytest.mark.parametrize("n,indexed", [(16 * 7 + 5, False), (4096 * 6 + 3, True), (200000, True)])
+def test_mlp_policy_gradient_kernels_match_autograd(n, indexed):
+    """`irrl_mlp_ppo_grads` (MlpPolicy forward, PPO2 loss and every parameter gradient, one launch per network, minibatch rows read
+    through the index) against torch autograd of the eager policy + ppo_loss on the same rows: loss, statistics and all 13
+    gradients; n not a multiple of the 16-sample tile exercises the ragged last tile, the indexed cases a shuffled minibatch of
+    a larger rollout."""
+    from high_speed_quadrupedal_locomotion_by_irrl_amd import ppo2 as P2
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import MlpPolicy, diag_gaussian_neglogp, diag_gaussian_entropy
+    dev = torch.device("cuda")
+    torch.manual_seed(3)
+    pol = MlpPolicy().to(dev)
+    g = torch.Generator(device=dev); g.manual_seed(11)
+    rn = lambda *s: torch.randn(*s, device=dev, generator=g)
+    with torch.no_grad():
+        pol.pi.w.mul_(30.0); pol.pi.b.add_(0.1 * rn(12)); pol.logstd.add_(0.2 * rn(1, 12))     # away from the symmetric initial point
+        for l in (*pol.pi_fc, *pol.vf_fc):
+            l.b.add_(0.1 * rn(*l.b.shape))
+    rows = n if not indexed else 2 * n + 77
+    obs, actions, returns, old_v = rn(rows, 35), 0.5 * rn(rows, 12), rn(rows), rn(rows)
+    index = torch.randperm(rows, device=dev, generator=g)[:n].contiguous() if indexed else None
+    sel = (lambda t: t[index]) if indexed else (lambda t: t)
+    with torch.no_grad():
+        old_nlp = diag_gaussian_neglogp(actions, pol._run(obs)[0], pol.logstd) + 0.3 * rn(rows)
+    # reference: the eager graph in float64 (the f32 eager graph itself is up to 3e-3 of a gradient's scale off at these sizes:
+    # tools/mlp_grad_error.py)
+    import copy
+    p64 = copy.deepcopy(pol).double()
+    d = lambda t: sel(t).double()
+    advs = d(returns) - d(old_v)
+    stats64 = torch.stack([advs.mean(), advs.std(unbiased=False)])
+    stats_t = stats64.to(torch.float32)
+    mean, v = p64._run(d(obs))
+    nadv = (advs - stats_t[0].double()) / (stats_t[1].double() + 1e-8)
+    loss_e, pg, vf, ent, kl, cf = P2.ppo_loss(diag_gaussian_neglogp(d(actions), mean, p64.logstd), v, diag_gaussian_entropy(p64.logstd, mean),
+                                              None, nadv, d(returns), d(old_nlp), d(old_v), 0.2, 0.01, 0.5)
+    skip = lambda pp: [q for q in pp.sb_parameters() if q is not pp.q.w and q is not pp.q.b]
+    params = skip(pol)
+    ge = torch.autograd.grad(loss_e, skip(p64))
+    assert P2.mlp_ppo_grads_supported(pol, obs)
+    loss_f, st, grads = P2.mlp_ppo_grads(pol, obs, actions, returns, old_v, old_nlp, stats_t, 0.2, 0.01, 0.5, index=index)
+    assert abs(float(loss_f) - float(loss_e)) < 2e-5 * max(1.0, abs(float(loss_e)))
+    np.testing.assert_allclose(st.cpu().numpy(), torch.stack([pg, vf, ent, kl, cf]).detach().cpu().numpy(), rtol=2e-4, atol=2e-5)
+    assert len(grads) == len(params)
+    for q, b in zip(params, ge):
+        a = grads[q]
+        assert a.shape == b.shape
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a.double() - b).abs().max()) < 2e-5 * scale, (tuple(q.shape), float((a.double() - b).abs().max()), scale)
+    # deterministic: the same launch twice gives the same bits
+    _l2, _s2, grads2 = P2.mlp_ppo_grads(pol, obs, actions, returns, old_v, old_nlp, stats_t, 0.2, 0.01, 0.5, index=index)
+    assert all(torch.equal(grads[q], grads2[q]) for q in params)
+
+
+def test_mlp_ppo_update_with_gradient_kernels_follows_the_eager_update():
+    """One PPO2 update of the MlpPolicy learner (4 minibatches x 2 epochs) through the gradient kernels against the eager graph
+    from the same rollout, generator and initial weights: the parameters after 8 Adam steps agree to rounding."""
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import MlpPolicy
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.ppo2 import PPO2, Runner
+    after = {}
+    for fused in (True, False):
+        env = _env(64)
+        model = PPO2(policy=MlpPolicy, env=env, n_steps=32, nminibatches=4, noptepochs=2, seed=4)
+        model.fused_mlp = fused
+        model.fused_loss = fused
+        runner = Runner(env, model, 32, 0.99, 0.95)
+        batch = runner.run()
+        stats = model.update(batch, 3e-4, 0.2)
+        after[fused] = ([q.detach().clone() for q in model.policy.parameters()], stats)
+    for a, b in zip(after[True][0], after[False][0]):
+        assert float((a - b).abs().max()) < 5e-5, float((a - b).abs().max())
+    np.testing.assert_allclose(after[True][1].cpu().numpy(), after[False][1].cpu().numpy(), rtol=2e-3, atol=2e-4)
+
+
 def test_graph_capture_warmup_leaves_no_trace_and_setters_invalidate_the_graph():
     """Ways to issue the fused rollout -- "persistent" (ONE launch for the whole rollout), "one_launch" (one per step), "direct" (the default: 2 x T launches from one C call, irrl_lstm_rollout), "graph"
     (one hipGraph of 2 x T kernel nodes) and "eager" (one Python call per launch) -- give the same rollouts bit for bit:
