@@ -12,8 +12,8 @@
 // and the dx chain need no data movement at all.  The weight fragments of both directions stay in registers for the whole launch
 // (196 per lane), next to the weight-gradient accumulators (128): the contraction of dW = In^T dOut runs over the SAMPLES, so
 // its operands go through a per-wave LDS tile (written in C layout, read back sample-major).  Rows of the shuffled minibatch are
-// read in place through the index vector (no gathered copies).  Per tile: 324 MFMAs (policy) / 324 (value, the 1-wide head padded
-// to 16), 4.4 us at the f32 MFMA rate.  Per-workgroup partial sums (fixed order: deterministic) go to `partials`; the caller adds
+// read in place through the index vector (no gathered copies).  Per tile: 324 MFMAs (policy) / 276 (value: its 1-wide head is
+// lane-local arithmetic), 4.4 / 3.7 us at the f32 MFMA rate.  Per-workgroup partial sums (fixed order: deterministic) go to `partials`; the caller adds
 // the workgroups up.
 #pragma once
 #include "policy_step.hpp"
@@ -81,8 +81,13 @@ irrl_mlp_ppo_kernel(const MlpUpdateArgs a) {
   for (int n2 = 0; n2 < 4; n2++)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-      wa3[n2][r] = (c < OUT) ? a.w3[(16 * n2 + 4 * g + r) * OUT + c] : 0.0f;
-      wt3[n2][r] = (4 * g + r < OUT) ? a.w3[(16 * n2 + c) * OUT + 4 * g + r] : 0.0f;   // [kt = n2][r]
+      if (KIND == 0) {
+        wa3[n2][r] = (c < OUT) ? a.w3[(16 * n2 + 4 * g + r) * OUT + c] : 0.0f;
+        wt3[n2][r] = (4 * g + r < OUT) ? a.w3[(16 * n2 + c) * OUT + 4 * g + r] : 0.0f;   // [kt = n2][r]
+      } else {
+        wa3[n2][r] = a.w3[16 * n2 + 4 * g + r];   // the value head is one column: lane-local products, no MFMA
+        wt3[n2][r] = 0.0f;
+      }
     }
   if (threadIdx.x < H) { bias[threadIdx.x] = a.b1[threadIdx.x]; bias[H + threadIdx.x] = a.b2[threadIdx.x]; }
   if (threadIdx.x < 16) bias[2 * H + threadIdx.x] = (threadIdx.x < OUT) ? a.b3[threadIdx.x] : 0.0f;
@@ -170,13 +175,26 @@ irrl_mlp_ppo_kernel(const MlpUpdateArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; r++) h2[nt][r] = fast_tanh(h2[nt][r]);
     // head: four independent chains (one per 16 inputs), then added
-    f32x4 o4[4];
-    o4[0] = *(const f32x4 *)&bias[2 * H + 4 * g]; o4[1] = zero4; o4[2] = zero4; o4[3] = zero4;
+    f32x4 out;                                                 // out[r] = head output 4 g + r of sample c
+    if (KIND == 0) {
+      f32x4 o4[4];
+      o4[0] = *(const f32x4 *)&bias[2 * H + 4 * g]; o4[1] = zero4; o4[2] = zero4; o4[3] = zero4;
 #pragma unroll
-    for (int r = 0; r < 4; r++)
+      for (int r = 0; r < 4; r++)
 #pragma unroll
-      for (int n2 = 0; n2 < 4; n2++) o4[n2] = MU_MFMA(wa3[n2][r], h2[n2][r], o4[n2]);
-    const f32x4 out = (o4[0] + o4[1]) + (o4[2] + o4[3]);      // out[r] = head output 4 g + r of sample c
+        for (int n2 = 0; n2 < 4; n2++) o4[n2] = MU_MFMA(wa3[n2][r], h2[n2][r], o4[n2]);
+      out = (o4[0] + o4[1]) + (o4[2] + o4[3]);
+    } else {
+      // value head: the lane's 16 features times their weights, then the four lane groups of the sample
+      f32x4 pv = h2[0] * *(const f32x4 *)wa3[0];
+#pragma unroll
+      for (int n2 = 1; n2 < 4; n2++) pv += h2[n2] * *(const f32x4 *)wa3[n2];
+      float v = (pv[0] + pv[1]) + (pv[2] + pv[3]);
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      out = zero4;
+      out[0] = v + bias[2 * H];
+    }
 
     // ---- loss and d loss / d out (same arithmetic as irrl_ppo_loss_kernel) ----
     f32x4 dz3 = zero4;
@@ -212,31 +230,38 @@ irrl_mlp_ppo_kernel(const MlpUpdateArgs a) {
       const float l1 = (v - R) * (v - R), l2 = (vc - R) * (vc - R);
       const float g_clamp = (dv >= -clip && dv <= clip) ? 1.0f : 0.0f;
       const float dvf = (l1 > l2) ? (v - R) : ((l1 < l2) ? (vc - R) * g_clamp : 0.5f * (v - R) + 0.5f * (vc - R) * g_clamp);
-      if (valid && g == 0) {
-        dz3[0] = a.inv_n * a.vf_coef * dvf;
-        sc[0] += 0.5f * fmaxf(l1, l2);
-      }
+      dz3[0] = valid ? a.inv_n * a.vf_coef * dvf : 0.0f;     // (every lane group of the sample holds it; group 0 accounts for it)
+      if (valid && g == 0) sc[0] += 0.5f * fmaxf(l1, l2);
     }
-    gb3 += dz3;
+    if (KIND == 0 || g == 0) gb3 += dz3;
 
     // ---- backward: head ----
-#pragma unroll
-    for (int nt = 0; nt < 4; nt++) *(f32x4 *)&TA[c * LD + 16 * nt + 4 * g] = h2[nt];
-    *(f32x4 *)&TB[c * LD + 4 * g] = dz3;
-    MU_WAVE_SYNC();
-#pragma unroll
-    for (int st = 0; st < 4; st++) {
-      const float b = TB[(4 * st + g) * LD + c];
-#pragma unroll
-      for (int kt = 0; kt < 4; kt++) gw3[kt] = MU_MFMA(TA[(4 * st + g) * LD + 16 * kt + c], b, gw3[kt]);
-    }
     f32x4 d[4];
+    if (KIND == 0) {
 #pragma unroll
-    for (int kt = 0; kt < 4; kt++) d[kt] = zero4;
+      for (int nt = 0; nt < 4; nt++) *(f32x4 *)&TA[c * LD + 16 * nt + 4 * g] = h2[nt];
+      *(f32x4 *)&TB[c * LD + 4 * g] = dz3;
+      MU_WAVE_SYNC();
 #pragma unroll
-    for (int r = 0; r < 4; r++)
+      for (int st = 0; st < 4; st++) {
+        const float b = TB[(4 * st + g) * LD + c];
 #pragma unroll
-      for (int kt = 0; kt < 4; kt++) d[kt] = MU_MFMA(wt3[kt][r], dz3[r], d[kt]);
+        for (int kt = 0; kt < 4; kt++) gw3[kt] = MU_MFMA(TA[(4 * st + g) * LD + 16 * kt + c], b, gw3[kt]);
+      }
+#pragma unroll
+      for (int kt = 0; kt < 4; kt++) d[kt] = zero4;
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int kt = 0; kt < 4; kt++) d[kt] = MU_MFMA(wt3[kt][r], dz3[r], d[kt]);
+    } else {
+      // one output: d h2 = dv w3, d w3 += h2 dv per lane (summed over the sample lanes at the end)
+#pragma unroll
+      for (int kt = 0; kt < 4; kt++) {
+        d[kt] = dz3[0] * *(const f32x4 *)wa3[kt];
+        gw3[kt] += dz3[0] * h2[kt];
+      }
+    }
     f32x4 dz2[4];
 #pragma unroll
     for (int kt = 0; kt < 4; kt++) {
@@ -306,6 +331,10 @@ irrl_mlp_ppo_kernel(const MlpUpdateArgs a) {
 #pragma unroll
       for (int nt = 0; nt < 4; nt++) { gb1[nt][r] += __shfl_xor(gb1[nt][r], off, 64); gb2[nt][r] += __shfl_xor(gb2[nt][r], off, 64); }
       gb3[r] += __shfl_xor(gb3[r], off, 64);
+      if (KIND == 1) {
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) gw3[nt][r] += __shfl_xor(gw3[nt][r], off, 64);
+      }
       gls[r] += __shfl_xor(gls[r], off, 64);
       sc[r] += __shfl_xor(sc[r], off, 64);
     }
@@ -335,7 +364,8 @@ irrl_mlp_ppo_kernel(const MlpUpdateArgs a) {
             put(IRRL_MLP_P_DW2 + (16 * kt + 4 * g + r) * H + 16 * nt + c, gw2[kt][nt][r]);
             if (kt < 3) put(IRRL_MLP_P_DW1 + (16 * kt + 4 * g + r) * H + 16 * nt + c, gw1[kt][nt][r]);
           }
-          put(IRRL_MLP_P_DW3 + (16 * nt + 4 * g + r) * 16 + c, gw3[nt][r]);
+          // policy: gw3 is a D tile (row = input 16 nt + 4 g + r, column = action c); value: the lane's input 16 nt + 4 g + r, column 0
+          put(IRRL_MLP_P_DW3 + (16 * nt + 4 * g + r) * 16 + c, (KIND == 0 || c == 0) ? gw3[nt][r] : 0.0f);
         }
       }
     }

@@ -492,7 +492,7 @@ def test_mlp_policy_gradient_kernels_match_autograd(n, indexed):
     ge = torch.autograd.grad(loss_e, skip(p64))
     assert P2.mlp_ppo_grads_supported(pol, obs)
     loss_f, st, grads = P2.mlp_ppo_grads(pol, obs, actions, returns, old_v, old_nlp, stats_t, 0.2, 0.01, 0.5, index=index)
-    assert abs(float(loss_f) - float(loss_e)) < 2e-5 * max(1.0, abs(float(loss_e)))
+    assert abs(float(loss_f) - float(loss_e.detach())) < 2e-5 * max(1.0, abs(float(loss_e.detach())))
     np.testing.assert_allclose(st.cpu().numpy(), torch.stack([pg, vf, ent, kl, cf]).detach().cpu().numpy(), rtol=2e-4, atol=2e-5)
     assert len(grads) == len(params)
     for q, b in zip(params, ge):

@@ -16,7 +16,8 @@ for src, dst in (("pytest_gpu.log", "pytest_gpu.log"), ("smoke.log", "smoke.log"
                  ("ppo_lstm.log", "ppo_lstm_4096x750.log"), ("ppo_mlp.log", "ppo_mlp_4096x750.log"), ("solvers.log", "bench_by_contact_solver.log")):
     if os.path.exists(os.path.join(G, src)):
         shutil.copy(os.path.join(G, src), os.path.join(P, "%s_%s" % (tag, dst)))
-for pat, dst in (("prof_bench/*/*kernel_stats.csv", "bench_kernel_stats.csv"), ("prof_ppo/*/*kernel_stats.csv", "ppo_lstm_kernel_stats_2iters_2epochs.csv")):
+for pat, dst in (("prof_bench/*/*kernel_stats.csv", "bench_kernel_stats.csv"), ("prof_ppo/*/*kernel_stats.csv", "ppo_lstm_kernel_stats_2iters_2epochs.csv"),
+                 ("prof_mlp/*/*kernel_stats.csv", "ppo_mlp_kernel_stats.csv")):
     st = sorted(glob.glob(os.path.join(G, pat)), key=os.path.getmtime)
     if st:
         shutil.copy(st[-1], os.path.join(P, "%s_%s" % (tag, dst)))

@@ -12,6 +12,7 @@
 #   sweep          envs-per-GPU sweep + PCIe-inclusive numpy boundary
 #   prof           rocprofv3 --kernel-trace --stats of the bench command
 #   profppo        rocprofv3 --kernel-trace --stats of 2 PPO iterations x 2 epochs (LSTM)
+#   profmlp        rocprofv3 --kernel-trace --stats of 3 PPO iterations with the MlpPolicy learner (config 2)
 #   pmc            PMC passes of the env step kernel (separate --pmc runs, no trace domains besides kernel-trace)
 #   pmclstm        PMC passes of the LSTM sequence kernels
 #   ppo            tools/ppo_bench.py lstm + mlp, 3 iterations each
@@ -58,6 +59,9 @@ while [ $# -gt 0 ]; do
       (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python3 $R/bench.py --steps 20 --warmup 5 --cpu-seconds 0 --ppo-iters 0 --check-steps 500 > $O/rocprof_bench.log 2>&1) ;;
     profppo)
       (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ppo -- python3 $R/tools/ppo_bench.py --policy lstm --envs 4096 --iters 2 --epochs 2 > $O/rocprof_ppo.log 2>&1) ;;
+    profmlp)
+      rm -rf $O/prof_mlp
+      (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_mlp -- python3 $R/tools/ppo_bench.py --policy mlp --envs 4096 --iters 3 > $O/rocprof_mlp.log 2>&1) ;;
     pmc)
       rm -rf $O/pmc_env_*
       (cd /tmp && export TMPDIR=/tmp
