@@ -1123,7 +1123,49 @@ irrl_ppo_heads_loss_kernel(size_t M, const float *__restrict__ h_pi, const float
   for (int i = tid; i < P; i += 256) partials[(size_t)blockIdx.x * P + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
 }
 
+// ---- sum of per-workgroup partial rows: out[c] = sum_r part[r][c'] (fixed order: deterministic) -------------------------------
+// The gradient kernels leave one row of partial sums per workgroup ([256, 9216] for a weight matrix of the LSTM); the library's
+// reduction over the OUTER dimension of such a matrix takes 250 us (37 GB/s).  Here a workgroup owns 64 columns: its four waves
+// each add a quarter of the rows (coalesced 256-byte reads, eight loads in flight per lane), then the four add up through LDS.
+// unit_gate_hid > 0 additionally undoes the LSTM kernels' [unit][gate] column permutation inside each group of 4 * hid
+// columns: out column g * hid + u  <-  partial column 4 u + g.
+__global__ void __launch_bounds__(256)
+irrl_sum_rows_kernel(const float *__restrict__ part, int rows, int cols, int unit_gate_hid, float *__restrict__ out) {
+  __shared__ float red[4][64];
+  const int cx = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;
+  float acc = 0.0f;
+  if (col < cols) {
+    int src = col;
+    if (unit_gate_hid > 0) {
+      const int w4 = 4 * unit_gate_hid, base = col / w4 * w4, j = col - base;
+      src = base + 4 * (j % unit_gate_hid) + j / unit_gate_hid;
+    }
+    const int per = (rows + 3) / 4, r0 = rg * per, r1 = min(rows, r0 + per);
+    const float *p = part + (size_t)r0 * cols + src;
+    int r = r0;
+    for (; r + 8 <= r1; r += 8) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) v[i] = p[(size_t)i * cols];
+#pragma unroll
+      for (int i = 0; i < 8; i++) acc += v[i];
+      p += (size_t)8 * cols;
+    }
+    for (; r < r1; r++) { acc += *p; p += cols; }
+  }
+  red[rg][cx] = acc;
+  __syncthreads();
+  if (rg == 0 && col < cols) out[col] = ((red[0][cx] + red[1][cx]) + red[2][cx]) + red[3][cx];
+}
+
 extern "C" {
+
+int irrl_sum_rows(const float *part, int rows, int cols, int unit_gate_hid, float *out, void *hip_stream) {
+  if (rows <= 0 || cols <= 0 || (unit_gate_hid > 0 && cols % (4 * unit_gate_hid) != 0)) return 1;
+  hipLaunchKernelGGL(irrl_sum_rows_kernel, dim3((cols + 63) / 64), dim3(256), 0, (hipStream_t)hip_stream, part, rows, cols, unit_gate_hid, out);
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}
 
 // returns 0 on success; 1 = unsupported shape, 2 = launch error
 int irrl_lstm_seq_forward(int hid, int T, int N, const float *zx, const float *wh_p, const float *masks, const float *state0,

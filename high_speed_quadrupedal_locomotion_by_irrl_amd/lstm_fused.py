@@ -169,9 +169,14 @@ class _LstmSeqFn(torch.autograd.Function):
                                               _ptr(dwx_part), _ptr(dwh_part), _ptr(db_part), stream)
             if rc != 0:
                 raise RuntimeError("irrl_lstm_seq_backward_x failed (rc=%d)" % rc)
-            dwx = dwx_part.sum(0)[:, inv]
-            dwh = dwh_part.sum(0)[:, inv]
-            db = db_part.sum(0)[inv]
+            # workgroup rows added in one fixed order, gate columns back in the reference's order (the library's reduction over the
+            # outer dimension of a [256, 9216] matrix takes 250 us; irrl_sum_rows 10)
+            dwx = torch.empty(n_in, 4 * hid, device=dev, dtype=torch.float32)
+            dwh = torch.empty(hid, 4 * hid, device=dev, dtype=torch.float32)
+            db = torch.empty(4 * hid, device=dev, dtype=torch.float32)
+            for part, rows, out in ((dwx_part, nb, dwx), (dwh_part, nb, dwh), (db_part, nb * 4, db)):
+                if lib.irrl_sum_rows(_ptr(part), rows, out.numel(), hid, _ptr(out), stream) != 0:
+                    raise RuntimeError("irrl_sum_rows failed")
             dx = dx_k[:, :N] if dx_k is not None else None
             return dx, dwx, dwh, db, None, None
         dz = torch.empty(T, Np, hid, 4, device=x_k.device, dtype=torch.float32)

@@ -203,6 +203,11 @@ int irrl_lstm_seq_forward_x(int hid, int T, int N, int n_in, const float *x, con
 int irrl_lstm_seq_backward(int hid, int T, int N, const float *gates, const float *cseq, const float *masks, const float *state0,
                            const float *dh_in, const float *wh_p, float *dz, void *hip_stream);
 
+/* out[c] = sum over rows of part[rows, cols] in one fixed order (the per-workgroup partial sums the gradient kernels leave);
+ * unit_gate_hid > 0 also undoes the [unit][gate] column permutation inside each group of 4 * hid columns (out column g * hid + u
+ * <- partial column 4 u + g).  Returns 0, 1 = bad shape, 2 = launch error. */
+int irrl_sum_rows(const float *part, int rows, int cols, int unit_gate_hid, float *out, void *hip_stream);
+
 /* backward pass with everything that consumes dz fused in (no dz tensor, no separate weight-gradient GEMMs):
  * hseq / x are the forward outputs / inputs; dx [T,N,n_in] or NULL; dwx_part [N/16, n_in, 4 hid], dwh_part [N/16, hid,
  * 4 hid], db_part [N/16 * 4, 4 hid] receive per-workgroup partial sums (permuted gate columns) that the caller adds up
