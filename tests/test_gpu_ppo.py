@@ -505,6 +505,31 @@ def test_mlp_policy_gradient_kernels_match_autograd(n, indexed):
     assert all(torch.equal(grads[q], grads2[q]) for q in params)
 
 
+@pytest.mark.parametrize("rows,cols,hid", [(256, 48 * 192, 48), (1024, 192, 48), (7, 130, 0), (1, 64, 0), (256, 8356, 0)])
+def test_row_sum_kernel_matches_float64_sum_and_undoes_the_gate_permutation(rows, cols, hid):
+    """`irrl_sum_rows` (the fixed-order sum of the gradient kernels' per-workgroup partial rows) against a float64 sum; with hid > 0 the
+    [unit][gate] column order of the LSTM kernels comes back as the reference's [gate][unit]."""
+    import ctypes as C
+    from high_speed_quadrupedal_locomotion_by_irrl_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev); g.manual_seed(rows * 7 + cols)
+    part = torch.randn(rows, cols, device=dev, generator=g)
+    out = torch.full((cols,), float("nan"), device=dev)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    assert lib.irrl_sum_rows(C.c_void_p(part.data_ptr()), rows, cols, hid, C.c_void_p(out.data_ptr()), st) == 0
+    want = part.double().sum(0)
+    if hid:
+        j = torch.arange(4 * hid, device=dev)
+        src = 4 * (j % hid) + j // hid
+        want = want.view(-1, 4 * hid)[:, src].reshape(-1)
+    assert float((out.double() - want).abs().max()) < 1e-5 * max(1.0, float(want.abs().max()))
+    out2 = torch.empty_like(out)
+    assert lib.irrl_sum_rows(C.c_void_p(part.data_ptr()), rows, cols, hid, C.c_void_p(out2.data_ptr()), st) == 0
+    assert torch.equal(out, out2)
+    assert lib.irrl_sum_rows(C.c_void_p(part.data_ptr()), rows, 100, 48, C.c_void_p(out2.data_ptr()), st) == 1   # not a multiple of 4 hid
+
+
 def test_mlp_ppo_update_with_gradient_kernels_follows_the_eager_update():
     """One PPO2 update of the MlpPolicy learner (4 minibatches x 2 epochs) through the gradient kernels against the eager graph
     from the same rollout, generator and initial weights: the parameters after 8 Adam steps agree to rounding."""
