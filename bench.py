@@ -25,7 +25,7 @@ Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel = irr
 over the timed region on the stream it is launched on), `roofline_fp32` (the VALU-FP32 view: this path is
 latency/issue bound, not HBM bound), `cpu_baseline` (the f64 oracle with the reference's
 OpenMP-over-envs threading on the GPU box's host cores + its single-thread rate, bounded sample, rank 0 / N=1 only),
-`ppo` (second half of the metric).
+`ppo` (second half of the metric: the LSTM policy of config 3) and `ppo_mlp` (the same iteration with config 2's MlpPolicy learner).
 """
 import argparse
 import json
@@ -377,18 +377,24 @@ def worker(args):
         del env
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import ppo_bench
-        ppo = ppo_bench.measure("lstm", n, args.ppo_steps, args.ppo_iters + 1, args.ppo_epochs, "default_cfg.yaml", verbose=False, rank=rank)
-        if dist is not None:
-            t = torch.tensor([ppo["rollout_s"], ppo["update_s"], ppo["rollout_s"] + ppo["update_s"]], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            ppo["rollout_s"], ppo["update_s"], it_s = (float(x) for x in t.tolist())
-        else:
-            it_s = ppo["rollout_s"] + ppo["update_s"]
-        if out is not None:
+        def ppo_leg(policy, cfg_name, grad_note):
+            ppo = ppo_bench.measure(policy, n, args.ppo_steps, args.ppo_iters + 1, args.ppo_epochs, cfg_name, verbose=False, rank=rank)
+            if dist is not None:
+                t = torch.tensor([ppo["rollout_s"], ppo["update_s"], ppo["rollout_s"] + ppo["update_s"]], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                ppo["rollout_s"], ppo["update_s"], it_s = (float(x) for x in t.tolist())
+            else:
+                it_s = ppo["rollout_s"] + ppo["update_s"]
             ppo.update({"world": world, "global_envs": n * world, "ppo_iters_per_sec": 1.0 / it_s, "samples_per_sec": n * world * args.ppo_steps / it_s,
-                        "env_steps_per_sec_in_rollout": n * world * args.ppo_steps / ppo["rollout_s"],
-                        "collectives_per_optimizer_step": None if world == 1 else "all-reduce of the flat gradient (283 KB) + 3-float advantage moments"})
+                        "env_steps_per_sec_in_rollout": n * world * args.ppo_steps / ppo["rollout_s"], "cfg": cfg_name,
+                        "collectives_per_optimizer_step": None if world == 1 else grad_note})
+            return ppo
+        ppo = ppo_leg("lstm", "default_cfg.yaml", "all-reduce of the flat gradient (283 KB) + 3-float advantage moments")
+        # BASELINE config 2's learner beside it: MlpPolicy [64, 64] on the imitation-only config (4 minibatches x 10 epochs)
+        ppo_mlp = ppo_leg("mlp", "bp5_imitation.yaml", "all-reduce of the flat gradient (56 KB) + 3-float advantage moments")
+        if out is not None:
             out["ppo"] = ppo
+            out["ppo_mlp"] = ppo_mlp
     if out is not None:
         print(json.dumps(out), flush=True)
     if dist is not None:
