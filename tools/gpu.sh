@@ -15,6 +15,7 @@
 #   profmlp        rocprofv3 --kernel-trace --stats of 3 PPO iterations with the MlpPolicy learner (config 2)
 #   pmc            PMC passes of the env step kernel (separate --pmc runs, no trace domains besides kernel-trace)
 #   pmclstm        PMC passes of the LSTM sequence kernels
+#   pmcmlp         PMC passes of the MlpPolicy gradient kernels
 #   ppo            tools/ppo_bench.py lstm + mlp, 3 iterations each
 #   irrl2          the IRRL recipe at the benchmark scale: stage 1 imitation + stage 2 relaxation, 4096 envs, 300 updates each
 #   terrain        BASELINE config 5 on one GPU: 4096 envs on the Perlin height field with per-episode friction / mass / COM randomisation and the
@@ -76,6 +77,13 @@ while [ $# -gt 0 ]; do
          tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
          timeout 900 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/pmc_lstm_$tag -- python3 $R/tools/ppo_bench.py --policy lstm --envs 4096 --iters 1 --epochs 1 > $O/pmc_lstm_$tag.log 2>&1
        done) ;;
+    pmcmlp)
+      rm -rf $O/pmc_mlp_*
+      (cd /tmp && export TMPDIR=/tmp
+       for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
+         tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
+         timeout 900 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/pmc_mlp_$tag -- python3 $R/tools/ppo_bench.py --policy mlp --envs 4096 --iters 1 --epochs 1 > $O/pmc_mlp_$tag.log 2>&1
+       done) ;;      # then: python tools/pmc_summarize_lstm.py r03_pmc_mlp_kernels mlp
     ppo)
       timeout 300 python tools/ppo_bench.py --policy mlp --envs 4096 --iters 3 > $O/ppo_mlp.log 2>&1
       timeout 300 python tools/ppo_bench.py --policy lstm --envs 4096 --iters 3 > $O/ppo_lstm.log 2>&1 ;;

@@ -1,11 +1,15 @@
 """Summarise the rocprofv3 --pmc passes of `tools/gpu.sh pmclstm` (one PPO iteration with ONE epoch of the LSTM policy at
 4096 x 750; gpurun_out/pmc_lstm_*/<host>/<pid>_counter_collection.csv) into profiles/<name>.json: per-kernel medians per launch
-and the derived fractions DESIGN.md section 7 quotes.  usage: python tools/pmc_summarize_lstm.py r03_pmc_lstm_kernels"""
+and the derived fractions DESIGN.md section 7 quotes.  usage: python tools/pmc_summarize_lstm.py r03_pmc_lstm_kernels
+With a second argument `mlp`: the passes of `tools/gpu.sh pmcmlp` (gpurun_out/pmc_mlp_*: one PPO iteration, one epoch, of the MlpPolicy learner),
+kernels irrl_mlp_ppo_kernel<0|1> / mlp_policy_step_kernel:  python tools/pmc_summarize_lstm.py r03_pmc_mlp_kernels mlp"""
 import csv, glob, json, os, statistics, sys
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 name = sys.argv[1] if len(sys.argv) > 1 else "pmc_lstm_kernels"
+which = sys.argv[2] if len(sys.argv) > 2 else "lstm"
+tokens = ("lstm_seq", "ppo_heads", "policy_step") if which == "lstm" else ("irrl_mlp_ppo_kernel", "mlp_policy_step", "irrl_sum_rows")
 per = {}
-for d in sorted(glob.glob(os.path.join(root, "gpurun_out", "pmc_lstm_*"))):
+for d in sorted(glob.glob(os.path.join(root, "gpurun_out", "pmc_%s_*" % which))):
     if not os.path.isdir(d):
         continue
     files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
@@ -13,11 +17,12 @@ for d in sorted(glob.glob(os.path.join(root, "gpurun_out", "pmc_lstm_*"))):
         continue
     for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
         k = r["Kernel_Name"]
-        if any(t in k for t in ("lstm_seq", "ppo_heads", "policy_step")):
+        if any(t in k for t in tokens):
             per.setdefault(k.replace("void ", "").split("(")[0], {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-out = {"source": "rocprofv3 --pmc <group> --kernel-trace, one pass per group (tools/gpu.sh pmclstm): tools/ppo_bench.py --policy lstm --envs 4096 --iters 1 "
-                 "--epochs 1 (rollout of 750 policy steps + one epoch: 4 forward, 4 backward sequence kernels, heads + loss); medians per launch; "
-                 "counters are collected with kernels serialised, so co-residency of the two stacks' kernels is NOT in these numbers",
+src = ("(rollout of 750 policy steps + one epoch: 4 forward, 4 backward sequence kernels, heads + loss); medians per launch; "
+       "counters are collected with kernels serialised, so co-residency of the two stacks' kernels is NOT in these numbers") if which == "lstm" else (
+       "(rollout of 750 policy steps + one epoch = 4 minibatches of 768 k samples: 4 launches of each gradient kernel); medians per launch")
+out = {"source": "rocprofv3 --pmc <group> --kernel-trace, one pass per group (tools/gpu.sh pmc%s): tools/ppo_bench.py --policy %s --envs 4096 --iters 1 --epochs 1 " % (which, which) + src,
        "units": "SQ_*_CYCLES in quad-cycles (4 clocks) summed over waves / SIMDs; GRBM_GUI_ACTIVE summed over the 8 XCDs; FETCH/WRITE_SIZE in KB "
                 "(FETCH_SIZE x 2 on gfx950 for wide loads, MI355X_MICROARCH.md)", "kernels": {}}
 for k, cs in sorted(per.items()):
