@@ -374,3 +374,30 @@ irrl_mlp_ppo_kernel(const MlpUpdateArgs a) {
   float *dst = a.partials + (size_t)blockIdx.x * IRRL_MLP_P;
   for (int i = threadIdx.x; i < IRRL_MLP_P; i += 256) dst[i] = red[i];
 }
+
+// ---- moments of the raw advantages of one minibatch: sum (R - V), sum (R - V)^2 over the indexed rows, accumulated in double ------
+// (ppo2.py:262-263 normalises the advantages per minibatch; the eager form -- two gathers, two casts, a square, two reductions --
+// is ~8 launches per optimizer step.)  Two launches, fixed order: per-workgroup partials, then one workgroup adds them.
+__global__ void __launch_bounds__(256)
+irrl_adv_moments_kernel(const int64_t *__restrict__ idx, size_t n, const float *__restrict__ ret, const float *__restrict__ val, double *__restrict__ part) {
+  __shared__ double red[2][4];
+  double s = 0.0, ss = 0.0;
+  for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (size_t)gridDim.x * 256) {
+    const size_t r = idx ? (size_t)idx[j] : j;
+    const double a = (double)(ret[r] - val[r]);       // the advantage is formed in f32, as the rollout stores it
+    s += a; ss += a * a;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); ss += __shfl_down(ss, off, 64); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = ss; }
+  __syncthreads();
+  if (threadIdx.x < 2) part[2 * blockIdx.x + threadIdx.x] = ((red[threadIdx.x][0] + red[threadIdx.x][1]) + red[threadIdx.x][2]) + red[threadIdx.x][3];
+}
+__global__ void __launch_bounds__(64)
+irrl_adv_moments_final_kernel(const double *__restrict__ part, int blocks, size_t n, double *__restrict__ sums) {
+  double s = 0.0, ss = 0.0;
+  for (int b = threadIdx.x; b < blocks; b += 64) { s += part[2 * b]; ss += part[2 * b + 1]; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); ss += __shfl_down(ss, off, 64); }
+  if (threadIdx.x == 0) { sums[0] = s; sums[1] = ss; sums[2] = (double)n; }
+}

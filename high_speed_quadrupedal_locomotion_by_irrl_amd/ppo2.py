@@ -203,7 +203,10 @@ def mlp_ppo_grads(policy, obs, actions, returns, old_values, old_neglogp, adv_st
                                           p(old_values), p(old_neglogp), p(c(fc[0].w)), p(c(fc[0].b)), p(c(fc[1].w)), p(c(fc[1].b)),
                                           p(c(head.w)), p(c(head.b)), p(c(policy.logstd)), p(adv_stats), float(cliprange), float(vf_coef),
                                           p(partials[kind]), n_blocks, stream))
-    sums = partials.sum(1)                                   # [2, P]: workgroups added in one fixed order
+    sums = torch.empty(2, P, device=dev, dtype=torch.float32)   # workgroups added in one fixed order
+    for kind in (0, 1):
+        if lib.irrl_sum_rows(p(partials[kind]), n_blocks, P, 0, p(sums[kind]), stream) != 0:
+            raise RuntimeError("irrl_sum_rows failed")
     A = actions.shape[-1]
     pg, kl, cf, vf = sums[0, 0] / n, sums[0, 1] / n, sums[0, 2] / n, sums[1, 0] / n
     ent = (policy.logstd + 0.5 * (math.log(2.0 * math.pi) + 1.0)).sum()
@@ -472,11 +475,23 @@ class PPO2(object):
         self.log = []
 
     # -- one optimizer step on one minibatch (ppo2.py:243-298) --
-    def _adv_moments(self, returns, values):
-        """(mean, var) of the raw advantages over ALL ranks' samples (ppo2.py:263 `advs.mean()/std()`), float64 device scalars."""
-        advs = returns - values
-        n_local = torch.tensor([float(advs.numel())], device=advs.device, dtype=torch.float64)
-        moments = torch.stack([advs.double().sum(), (advs.double() ** 2).sum(), n_local[0]])
+    def _adv_moments(self, returns, values, index=None):
+        """(mean, var) of the raw advantages over ALL ranks' samples (ppo2.py:263 `advs.mean()/std()`), float64 device scalars.
+        index: the arrays are the flat rollout and `index` picks the minibatch (two launches of `irrl_adv_moments` instead of the
+        gathers, casts and reductions)."""
+        if index is not None:
+            from . import _lib
+            lib = _lib.load()
+            dev = returns.device
+            scratch = torch.empty(2 * 256 + 3, device=dev, dtype=torch.float64)
+            p = lambda t: C.c_void_p(t.data_ptr())
+            _lib.check(lib.irrl_adv_moments(int(index.numel()), p(index), p(returns), p(values), p(scratch), 256, p(scratch[512:]),
+                                            C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+            moments = scratch[512:]
+        else:
+            advs = returns - values
+            n_local = torch.tensor([float(advs.numel())], device=advs.device, dtype=torch.float64)
+            moments = torch.stack([advs.double().sum(), (advs.double() ** 2).sum(), n_local[0]])
         if self.world > 1:
             torch.distributed.all_reduce(moments)                     # C2: 3 floats
         mean = moments[0] / moments[2]
@@ -487,7 +502,7 @@ class PPO2(object):
         """index: the arrays are the FLAT rollout and `index` picks this minibatch's rows (MlpPolicy's gradient kernels read them
         in place); otherwise the arrays are the minibatch."""
         if index is not None:
-            mean, var = adv_moments if adv_moments is not None else self._adv_moments(returns[index], values[index])
+            mean, var = adv_moments if adv_moments is not None else self._adv_moments(returns, values, index=index)
             adv_stats = torch.stack([mean, torch.sqrt(var)]).to(torch.float32)
             _loss, stats, grads = mlp_ppo_grads(self.policy, obs, actions, returns, values, neglogpacs, adv_stats, cliprange_now, self.ent_coef,
                                                 self.vf_coef, index=index)

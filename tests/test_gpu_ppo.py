@@ -530,6 +530,25 @@ def test_row_sum_kernel_matches_float64_sum_and_undoes_the_gate_permutation(rows
     assert lib.irrl_sum_rows(C.c_void_p(part.data_ptr()), rows, 100, 48, C.c_void_p(out2.data_ptr()), st) == 1   # not a multiple of 4 hid
 
 
+@pytest.mark.parametrize("n,indexed", [(1, False), (1000, True), (768000, True)])
+def test_advantage_moments_kernel_matches_float64_sums(n, indexed):
+    """`irrl_adv_moments` (sum and sum of squares of returns - values over the minibatch's rows, accumulated in double) against torch."""
+    import ctypes as C
+    from high_speed_quadrupedal_locomotion_by_irrl_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev); g.manual_seed(n)
+    rows = 3 * n + 5
+    ret, val = torch.randn(rows, device=dev, generator=g) + 0.3, torch.randn(rows, device=dev, generator=g)
+    idx = torch.randperm(rows, device=dev, generator=g)[:n].contiguous() if indexed else None
+    scratch = torch.empty(2 * 256 + 3, device=dev, dtype=torch.float64)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    assert lib.irrl_adv_moments(n, p(idx), p(ret), p(val), p(scratch), 256, p(scratch[512:]), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)) == 0
+    a = ((ret[idx] - val[idx]) if indexed else (ret[:n] - val[:n])).double()
+    want = torch.stack([a.sum(), (a * a).sum(), torch.tensor(float(n), device=dev, dtype=torch.float64)])
+    np.testing.assert_allclose(scratch[512:].cpu().numpy(), want.cpu().numpy(), rtol=1e-12, atol=1e-9)
+
+
 def test_mlp_ppo_update_with_gradient_kernels_follows_the_eager_update():
     """One PPO2 update of the MlpPolicy learner (4 minibatches x 2 epochs) through the gradient kernels against the eager graph
     from the same rollout, generator and initial weights: the parameters after 8 Adam steps agree to rounding."""
