@@ -743,12 +743,13 @@ int irrl_mlp_ppo_grads(int kind, size_t n, const int64_t *idx, int ob_dim, int h
 }
 int irrl_mlp_ppo_partial_len(void) { return IRRL_MLP_P; }
 
-// sums[3] = (sum a, sum a^2, n) of a = returns[r] - old_values[r] over the minibatch's rows, in double; scratch: [2 * n_blocks] doubles
+// sums[3] = (sum a, sum a^2, n) of a = returns[r] - old_values[r] over the minibatch's rows, in double; scratch: [2 * n_blocks] doubles;
+// stats (may be NULL): (mean, population std) of a as floats, what the loss kernels take as adv_stats when there is one rank
 int irrl_adv_moments(size_t n, const int64_t *idx, const float *returns, const float *old_values, double *scratch, int n_blocks, double *sums,
-                     void *hip_stream) {
+                     float *stats, void *hip_stream) {
   if (n == 0 || n_blocks <= 0) { g_err = "irrl_adv_moments: empty batch"; return 1; }
   hipLaunchKernelGGL(irrl_adv_moments_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)hip_stream, idx, n, returns, old_values, scratch);
-  hipLaunchKernelGGL(irrl_adv_moments_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, scratch, n_blocks, n, sums);
+  hipLaunchKernelGGL(irrl_adv_moments_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, scratch, n_blocks, n, sums, stats);
   HIP_TRY(hipGetLastError());
   return 0;
 }

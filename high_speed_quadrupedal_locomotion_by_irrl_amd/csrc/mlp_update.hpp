@@ -394,10 +394,16 @@ irrl_adv_moments_kernel(const int64_t *__restrict__ idx, size_t n, const float *
   if (threadIdx.x < 2) part[2 * blockIdx.x + threadIdx.x] = ((red[threadIdx.x][0] + red[threadIdx.x][1]) + red[threadIdx.x][2]) + red[threadIdx.x][3];
 }
 __global__ void __launch_bounds__(64)
-irrl_adv_moments_final_kernel(const double *__restrict__ part, int blocks, size_t n, double *__restrict__ sums) {
+irrl_adv_moments_final_kernel(const double *__restrict__ part, int blocks, size_t n, double *__restrict__ sums, float *__restrict__ stats) {
   double s = 0.0, ss = 0.0;
   for (int b = threadIdx.x; b < blocks; b += 64) { s += part[2 * b]; ss += part[2 * b + 1]; }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off, 64); ss += __shfl_down(ss, off, 64); }
-  if (threadIdx.x == 0) { sums[0] = s; sums[1] = ss; sums[2] = (double)n; }
+  if (threadIdx.x == 0) {
+    sums[0] = s; sums[1] = ss; sums[2] = (double)n;
+    if (stats) {     // single-process job: (mean, std) as the loss kernels read them -- the same double arithmetic the host side applies to `sums`
+      const double mean = s / (double)n, var = fmax(ss / (double)n - mean * mean, 0.0);
+      stats[0] = (float)mean; stats[1] = (float)sqrt(var);
+    }
+  }
 }

@@ -179,7 +179,8 @@ def mlp_ppo_grads_supported(policy, obs):
                 and tuple(policy.pi.w.shape) == (64, 12) and tuple(policy.vf.w.shape) == (64, 1) and obs.dtype == torch.float32)
 
 
-def mlp_ppo_grads(policy, obs, actions, returns, old_values, old_neglogp, adv_stats, cliprange, ent_coef, vf_coef, index=None, n_blocks=256):
+def mlp_ppo_grads(policy, obs, actions, returns, old_values, old_neglogp, adv_stats, cliprange, ent_coef, vf_coef, index=None, n_blocks=256,
+                  want_loss=True):
     """loss = pg - ent_coef * entropy + vf_coef * vf of MlpPolicy on one minibatch, and its gradient with respect to every parameter,
     in two launches (policy network, value network; csrc/mlp_update.hpp) -- the whole of ppo2.py:243-298's graph evaluation.
     obs / actions / returns / old_values / old_neglogp are the FLAT rollout arrays; index (int64 device vector) picks the
@@ -208,9 +209,10 @@ def mlp_ppo_grads(policy, obs, actions, returns, old_values, old_neglogp, adv_st
         if lib.irrl_sum_rows(p(partials[kind]), n_blocks, P, 0, p(sums[kind]), stream) != 0:
             raise RuntimeError("irrl_sum_rows failed")
     A = actions.shape[-1]
-    pg, kl, cf, vf = sums[0, 0] / n, sums[0, 1] / n, sums[0, 2] / n, sums[1, 0] / n
-    ent = (policy.logstd + 0.5 * (math.log(2.0 * math.pi) + 1.0)).sum()
-    loss = pg - ent * ent_coef + vf * vf_coef
+    sc = sums[:, :4] / n                                        # per-sample means: [pg, kl, clipfrac, -] and [vf, -, -, -]
+    pg, kl, cf, vf = sc[0, 0], sc[0, 1], sc[0, 2], sc[1, 0]
+    ent = policy.logstd.detach().sum() + 0.5 * (math.log(2.0 * math.pi) + 1.0) * A
+    loss = (pg - ent * ent_coef + vf * vf_coef) if want_loss else None
     grads = {policy.logstd: (sums[0, 4:4 + A] - ent_coef).reshape(policy.logstd.shape)}
     o1, o2, o3, w1, w2, w3 = 20, 84, 148, 164, 164 + 48 * 64, 164 + 48 * 64 + 64 * 64
     for kind, fc, head in nets:
@@ -220,7 +222,7 @@ def mlp_ppo_grads(policy, obs, actions, returns, old_values, old_neglogp, adv_st
         grads[fc[0].w] = r[w1:w1 + 48 * 64].view(48, 64)[:35]
         grads[fc[1].w] = r[w2:w2 + 64 * 64].view(64, 64)
         grads[head.w] = r[w3:w3 + 64 * 16].view(64, 16)[:, :out]
-    return loss, torch.stack([pg, vf, ent.detach(), kl, cf]), grads
+    return loss, torch.stack([pg, vf, ent, kl, cf]), grads
 
 
 def fused_ppo_loss_supported(policy, obs):
@@ -475,20 +477,26 @@ class PPO2(object):
         self.log = []
 
     # -- one optimizer step on one minibatch (ppo2.py:243-298) --
-    def _adv_moments(self, returns, values, index=None):
+    def _adv_stats_indexed(self, returns, values, index):
+        """adv_stats = (mean, std) of the raw advantages of the minibatch `index` picks from the flat rollout, float32 [2] on the device:
+        two launches of `irrl_adv_moments` instead of the gathers, casts and reductions; several ranks all-reduce the sums first."""
+        from . import _lib
+        lib = _lib.load()
+        dev = returns.device
+        scratch = torch.empty(2 * 256 + 3, device=dev, dtype=torch.float64)
+        stats = torch.empty(2, device=dev, dtype=torch.float32)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        _lib.check(lib.irrl_adv_moments(int(index.numel()), p(index), p(returns), p(values), p(scratch), 256, p(scratch[512:]),
+                                        p(stats) if self.world == 1 else None, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        if self.world == 1:
+            return stats
+        mean, var = self._adv_moments(None, None, moments=scratch[512:])
+        return torch.stack([mean, torch.sqrt(var)]).to(torch.float32)
+
+    def _adv_moments(self, returns, values, moments=None):
         """(mean, var) of the raw advantages over ALL ranks' samples (ppo2.py:263 `advs.mean()/std()`), float64 device scalars.
-        index: the arrays are the flat rollout and `index` picks the minibatch (two launches of `irrl_adv_moments` instead of the
-        gathers, casts and reductions)."""
-        if index is not None:
-            from . import _lib
-            lib = _lib.load()
-            dev = returns.device
-            scratch = torch.empty(2 * 256 + 3, device=dev, dtype=torch.float64)
-            p = lambda t: C.c_void_p(t.data_ptr())
-            _lib.check(lib.irrl_adv_moments(int(index.numel()), p(index), p(returns), p(values), p(scratch), 256, p(scratch[512:]),
-                                            C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
-            moments = scratch[512:]
-        else:
+        moments: this rank's (sum, sum of squares, count) when they are already on the device."""
+        if moments is None:
             advs = returns - values
             n_local = torch.tensor([float(advs.numel())], device=advs.device, dtype=torch.float64)
             moments = torch.stack([advs.double().sum(), (advs.double() ** 2).sum(), n_local[0]])
@@ -502,10 +510,12 @@ class PPO2(object):
         """index: the arrays are the FLAT rollout and `index` picks this minibatch's rows (MlpPolicy's gradient kernels read them
         in place); otherwise the arrays are the minibatch."""
         if index is not None:
-            mean, var = adv_moments if adv_moments is not None else self._adv_moments(returns, values, index=index)
-            adv_stats = torch.stack([mean, torch.sqrt(var)]).to(torch.float32)
+            if adv_moments is not None:
+                adv_stats = torch.stack([adv_moments[0], torch.sqrt(adv_moments[1])]).to(torch.float32)
+            else:
+                adv_stats = self._adv_stats_indexed(returns, values, index)
             _loss, stats, grads = mlp_ppo_grads(self.policy, obs, actions, returns, values, neglogpacs, adv_stats, cliprange_now, self.ent_coef,
-                                                self.vf_coef, index=index)
+                                                self.vf_coef, index=index, want_loss=False)
             self.optimizer.zero_grad(set_to_none=True)
             for prm, grd in grads.items():
                 prm.grad = grd.contiguous()

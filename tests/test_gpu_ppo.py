@@ -543,10 +543,12 @@ def test_advantage_moments_kernel_matches_float64_sums(n, indexed):
     idx = torch.randperm(rows, device=dev, generator=g)[:n].contiguous() if indexed else None
     scratch = torch.empty(2 * 256 + 3, device=dev, dtype=torch.float64)
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-    assert lib.irrl_adv_moments(n, p(idx), p(ret), p(val), p(scratch), 256, p(scratch[512:]), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)) == 0
+    stats = torch.empty(2, device=dev)
+    assert lib.irrl_adv_moments(n, p(idx), p(ret), p(val), p(scratch), 256, p(scratch[512:]), p(stats), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)) == 0
     a = ((ret[idx] - val[idx]) if indexed else (ret[:n] - val[:n])).double()
     want = torch.stack([a.sum(), (a * a).sum(), torch.tensor(float(n), device=dev, dtype=torch.float64)])
     np.testing.assert_allclose(scratch[512:].cpu().numpy(), want.cpu().numpy(), rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(stats.cpu().numpy(), [float(a.mean()), float(a.std(unbiased=False))], rtol=2e-6, atol=1e-7)
 
 
 def test_mlp_ppo_update_with_gradient_kernels_follows_the_eager_update():
