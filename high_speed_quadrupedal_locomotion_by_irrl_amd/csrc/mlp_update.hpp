@@ -40,6 +40,9 @@ struct MlpUpdateArgs {
   float *partials;                // [gridDim.x, IRRL_MLP_P]
 };
 
+#ifndef IRRL_MLP_EXP
+#define IRRL_MLP_EXP 0   // diagnostics (wrong results): 1 = forward + loss only, 2 = no weight-gradient MFMAs; 3 = dx block before the dW block (A/B: slower, 10.7 vs 8.5 us per tile)
+#endif
 #define MU_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b_, c_, 0, 0, 0)
 #define MU_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
@@ -124,11 +127,15 @@ irrl_mlp_ppo_kernel(const MlpUpdateArgs a) {
     return a.idx ? (size_t)a.idx[j] : j;
   };
   auto load_tile = [&](size_t row, MlpTileIn &in) {
+    // no lane-dependent branches around the loads (a load under a branch makes the compiler drain every load in flight first: the
+    // next tile's rows would be waited for as soon as they are requested); lanes beyond the row read a valid neighbour and the value is
+    // masked where it is used
     const float *xr = a.obs + row * OB;
 #pragma unroll
-    for (int ks = 0; ks < 9; ks++) in.x[ks] = (4 * ks + g < OB) ? xr[4 * ks + g] : 0.0f;
+    for (int ks = 0; ks < 8; ks++) in.x[ks] = xr[4 * ks + g];
+    in.x[8] = xr[32 + (g < 3 ? g : 2)];
     if (KIND == 0) {
-      in.act = (g < 3) ? *(const f32x4 *)(a.actions + row * 12 + 4 * g) : zero4;
+      in.act = *(const f32x4 *)(a.actions + row * 12 + 4 * (g < 3 ? g : 2));
       in.onlp = a.old_neglogp[row];
     }
     in.ret = a.returns[row];
@@ -140,6 +147,10 @@ irrl_mlp_ppo_kernel(const MlpUpdateArgs a) {
     load_tile(row_of(tile), cur);
     if (tile + stride < ntiles) row_next = row_of(tile + stride);
   }
+  // every load of the prologue lands before the loop: with one of them still in flight at the loop's entry the compiler's wait in front of
+  // the first use of `cur` (vmcnt(5), counted on the path that skips the prefetch) also waits, in every later iteration, for the
+  // observations of the NEXT tile that were requested a few instructions earlier -- the whole gather latency, once per tile
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   for (; tile < ntiles; tile += stride) {
     const bool more = tile + stride < ntiles;
     if (more) {
@@ -149,6 +160,7 @@ irrl_mlp_ppo_kernel(const MlpUpdateArgs a) {
     const bool valid = tile * 16 + c < a.n;
 
     // ---- forward ----
+    cur.x[8] = (g < 3) ? cur.x[8] : 0.0f;            // observation 35 does not exist
 #pragma unroll
     for (int ks = 0; ks < 9; ks++) X[c * XLD + 4 * ks + g] = cur.x[ks];
     f32x4 h1[4], h2[4];
@@ -234,6 +246,10 @@ irrl_mlp_ppo_kernel(const MlpUpdateArgs a) {
       if (valid && g == 0) sc[0] += 0.5f * fmaxf(l1, l2);
     }
     if (KIND == 0 || g == 0) gb3 += dz3;
+#if IRRL_MLP_EXP == 1
+    if (more) cur = nxt;
+    continue;
+#endif
 
     // ---- backward: head ----
     f32x4 d[4];
@@ -243,17 +259,27 @@ irrl_mlp_ppo_kernel(const MlpUpdateArgs a) {
       *(f32x4 *)&TB[c * LD + 4 * g] = dz3;
       MU_WAVE_SYNC();
 #pragma unroll
+      for (int kt = 0; kt < 4; kt++) d[kt] = zero4;
+#if IRRL_MLP_EXP == 3
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int kt = 0; kt < 4; kt++) d[kt] = MU_MFMA(wt3[kt][r], dz3[r], d[kt]);
+#endif
+#if IRRL_MLP_EXP != 2
+#pragma unroll
       for (int st = 0; st < 4; st++) {
         const float b = TB[(4 * st + g) * LD + c];
 #pragma unroll
         for (int kt = 0; kt < 4; kt++) gw3[kt] = MU_MFMA(TA[(4 * st + g) * LD + 16 * kt + c], b, gw3[kt]);
       }
-#pragma unroll
-      for (int kt = 0; kt < 4; kt++) d[kt] = zero4;
+#endif
+#if IRRL_MLP_EXP != 3
 #pragma unroll
       for (int r = 0; r < 4; r++)
 #pragma unroll
         for (int kt = 0; kt < 4; kt++) d[kt] = MU_MFMA(wt3[kt][r], dz3[r], d[kt]);
+#endif
     } else {
       // one output: d h2 = dv w3, d w3 += h2 dv per lane (summed over the sample lanes at the end)
 #pragma unroll
@@ -277,6 +303,17 @@ irrl_mlp_ppo_kernel(const MlpUpdateArgs a) {
     }
     MU_WAVE_SYNC();
 #pragma unroll
+    for (int kt = 0; kt < 4; kt++) d[kt] = zero4;
+#if IRRL_MLP_EXP == 3
+#pragma unroll
+    for (int n2 = 0; n2 < 4; n2++)
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int kt = 0; kt < 4; kt++) d[kt] = MU_MFMA(wt2[kt][n2][r], dz2[n2][r], d[kt]);
+#endif
+#if IRRL_MLP_EXP != 2
+#pragma unroll
     for (int st = 0; st < 4; st++) {
       float b[4];
 #pragma unroll
@@ -288,14 +325,15 @@ irrl_mlp_ppo_kernel(const MlpUpdateArgs a) {
         for (int nt = 0; nt < 4; nt++) gw2[kt][nt] = MU_MFMA(av, b[nt], gw2[kt][nt]);
       }
     }
-#pragma unroll
-    for (int kt = 0; kt < 4; kt++) d[kt] = zero4;
+#endif
+#if IRRL_MLP_EXP != 3
 #pragma unroll
     for (int n2 = 0; n2 < 4; n2++)
 #pragma unroll
       for (int r = 0; r < 4; r++)
 #pragma unroll
         for (int kt = 0; kt < 4; kt++) d[kt] = MU_MFMA(wt2[kt][n2][r], dz2[n2][r], d[kt]);
+#endif
     f32x4 dz1[4];
 #pragma unroll
     for (int kt = 0; kt < 4; kt++) {
@@ -307,6 +345,7 @@ irrl_mlp_ppo_kernel(const MlpUpdateArgs a) {
 #pragma unroll
     for (int nt = 0; nt < 4; nt++) *(f32x4 *)&TB[c * LD + 16 * nt + 4 * g] = dz1[nt];
     MU_WAVE_SYNC();
+#if IRRL_MLP_EXP != 2
 #pragma unroll
     for (int st = 0; st < 4; st++) {
       float b[4];
@@ -319,6 +358,7 @@ irrl_mlp_ppo_kernel(const MlpUpdateArgs a) {
         for (int nt = 0; nt < 4; nt++) gw1[kt][nt] = MU_MFMA(av, b[nt], gw1[kt][nt]);
       }
     }
+#endif
     MU_WAVE_SYNC();
     if (more) cur = nxt;
   }
