@@ -18,6 +18,7 @@
 #   pmcmlp         PMC passes of the MlpPolicy gradient kernels
 #   ppo            tools/ppo_bench.py lstm + mlp, 3 iterations each
 #   irrl2          the IRRL recipe at the benchmark scale: stage 1 imitation + stage 2 relaxation, 4096 envs, 300 updates each
+#   trainmlp       BASELINE config 2 as a training run: MlpPolicy on bp5_imitation.yaml, 4096 envs, 400 updates through the gradient kernels + evaluation
 #   terrain        BASELINE config 5 on one GPU: 4096 envs on the Perlin height field with per-episode friction / mass / COM randomisation and the
 #                  command process, LSTM policy, 200 updates from scratch + evaluation of the result
 #   train200       the reference's command line (200 envs, 2e8 samples), headless evaluation of the result
@@ -94,6 +95,11 @@ while [ $# -gt 0 ]; do
       timeout 900 python scripts/run_bp_v5.py --train --cfg $RS/default_cfg.yaml --num_envs 4096 --l 0.0005 --max_iter $((4096*750*300)) --eval_every_n 0 --load $O/irrl2/stage1.pkl 2>&1 | grep -E "nupdates|final checkpoint" | awk 'NR%10==1 || /final/' | cut -c1-330 > $O/irrl2/stage2_relaxation.log
       cp "$(grep "final checkpoint" $O/irrl2/stage2_relaxation.log | awk '{print $3}')" $O/irrl2/stage2.pkl
       timeout 300 python tools/eval_checkpoint_gpu.py $O/irrl2/stage2.pkl 256 2>&1 | grep -E "rollout|deterministic" > $O/irrl2/eval_stage2.log ;;
+    trainmlp)
+      RS=high_speed_quadrupedal_locomotion_by_irrl_amd/rsc; mkdir -p $O/trainmlp; rm -f $O/trainmlp/*
+      timeout 900 python scripts/run_bp_v5.py --train --policy mlp --cfg $RS/bp5_imitation.yaml --num_envs 4096 --l ${MLP_LR:-0.0003} --max_iter $((4096*750*${MLP_UPDATES:-400})) --eval_every_n 0 2>&1 | grep -E "nupdates|final checkpoint" | awk 'NR%10==1 || /final/' | cut -c1-330 > $O/trainmlp/train.log
+      cp "$(grep "final checkpoint" $O/trainmlp/train.log | awk '{print $3}')" $O/trainmlp/final.pkl
+      timeout 300 python tools/eval_checkpoint_gpu.py $O/trainmlp/final.pkl 256 $RS/bp5_imitation.yaml 2>&1 | grep -E "rollout|deterministic" > $O/trainmlp/eval.log ;;
     terrain)
       RS=high_speed_quadrupedal_locomotion_by_irrl_amd/rsc; mkdir -p $O/terrain; rm -f $O/terrain/*
       timeout 900 python scripts/run_bp_v5.py --train --cfg $RS/bp5_terrain.yaml --num_envs 4096 --l 0.001 --max_iter $((4096*750*200)) --eval_every_n 0 2>&1 | grep -E "nupdates|final checkpoint" | awk 'NR%10==1 || /final/' | cut -c1-330 > $O/terrain/train.log
