@@ -58,7 +58,7 @@ def parse_args(argv=None):
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
                     help="override one key of the env configuration (YAML scalar), e.g. --set Crutial=true; the bench line names it")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget (0 disables)")
-    ap.add_argument("--ppo-iters", type=int, default=2, help="timed PPO iterations of the LSTM policy (0 disables)")
+    ap.add_argument("--ppo-iters", type=int, default=5, help="timed PPO iterations of each learner leg, reported with min / median / max (0 disables)")
     ap.add_argument("--ppo-steps", type=int, default=750, help="rollout length of the PPO leg (the metric's is 750)")
     ap.add_argument("--ppo-epochs", type=int, default=10, help="optimisation epochs of the PPO leg (the metric's is 10)")
     ap.add_argument("--launch", choices=("rows", "graph", "python"), default="rows",
@@ -298,16 +298,23 @@ def worker(args):
         raise SystemExit("bench.py: no episode ended inside the timed region of %d env-steps -- not the steady-state workload" % (n * world * args.steps))
     check = None
     if args.check_steps > 0:
+        # a longer window behind the timed region, in FIVE consecutive parts: mean and spread of us / step (the driver's --steps 20
+        # bracket is 0.8 ms long; this says what the same kernel does over thousands of steps and how much that moves)
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        parts = 5
+        per = max(1, args.check_steps // parts)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(parts + 1)]
         cc0 = env.counters()
-        e0.record()
-        run(args.check_steps)
-        e1.record()
+        evs[0].record()
+        for i in range(parts):
+            run(per)
+            evs[i + 1].record()
         torch.cuda.synchronize()
         cc1 = env.counters()
-        check = {"steps": args.check_steps, "us_per_step": 1e3 * e0.elapsed_time(e1) / args.check_steps,
-                 "contact_fraction": (cc1[1] - cc0[1]) / float(4 * loop_count * n * args.check_steps), "resets": cc1[0] - cc0[0]}
+        us = sorted(1e3 * evs[i].elapsed_time(evs[i + 1]) / per for i in range(parts))
+        check = {"steps": per * parts, "us_per_step": 1e3 * evs[0].elapsed_time(evs[parts]) / (per * parts),
+                 "us_per_step_min_median_max": [us[0], us[parts // 2], us[-1]], "windows": parts,
+                 "contact_fraction": (cc1[1] - cc0[1]) / float(4 * loop_count * n * per * parts), "resets": cc1[0] - cc0[0]}
 
     # the same K steps issued the way the reference's runner issues them: ONE FlexibleGymEnv.step() call (ctypes -> C-ABI) per
     # control step (RaisimGymVecEnv.py:31), wall clock around the loop -- reported beside `value`, never as `value`

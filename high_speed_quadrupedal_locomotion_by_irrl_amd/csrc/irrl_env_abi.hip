@@ -9,6 +9,7 @@
 #include "env_params.h"
 #include "lstm_kernels.hip"
 #include "mlp_update.hpp"
+#include "ppo_optim.hpp"
 
 // The env kernels are compiled in two lane layouts from the same source (csrc/env_kernels.hip, see build.py):
 //   _l16  16 lanes per robot (lanes_hip16.hpp): 4 robots per wave -- fills all 1024 SIMDs at 4096 robots, shortest step
@@ -750,6 +751,31 @@ int irrl_adv_moments(size_t n, const int64_t *idx, const float *returns, const f
   if (n == 0 || n_blocks <= 0) { g_err = "irrl_adv_moments: empty batch"; return 1; }
   hipLaunchKernelGGL(irrl_adv_moments_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)hip_stream, idx, n, returns, old_values, scratch);
   hipLaunchKernelGGL(irrl_adv_moments_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, scratch, n_blocks, n, sums, stats);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ---- the tail of an optimizer step on flat buffers (kernels: csrc/ppo_optim.hpp; ppo2.py:182-197 clip_by_global_norm + Adam) ----
+int irrl_clip_adam(int n, float *theta, const float *grad, float *m, float *v, float grad_scale, float max_norm, float lr, float beta1, float beta2,
+                   float eps, long long step, float *norm_out, void *hip_stream) {
+  if (n <= 0 || !theta || !grad || !m || !v) { g_err = "irrl_clip_adam: empty parameter set"; return 1; }
+  if (step < 1) { g_err = "irrl_clip_adam: step counts from 1"; return 1; }
+  if (((uintptr_t)theta | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15u) { g_err = "irrl_clip_adam: buffers must be 16-byte aligned"; return 1; }
+  ClipAdamArgs a;
+  a.n = n; a.theta = theta; a.g = grad; a.m = m; a.v = v; a.grad_scale = grad_scale; a.max_norm = max_norm;
+  a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+  a.step_size = (float)((double)lr / (1.0 - std::pow((double)beta1, (double)step)));
+  a.inv_bc2_sqrt = (float)(1.0 / std::sqrt(1.0 - std::pow((double)beta2, (double)step)));
+  a.norm_out = norm_out;
+  hipLaunchKernelGGL(irrl_clip_adam_kernel, dim3(1), dim3(1024), 0, (hipStream_t)hip_stream, a);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int irrl_sum_rows_scatter(const float *part, int nmat, int rows, int cols, const int *map, const float *add, float *out, void *hip_stream) {
+  if (nmat <= 0 || rows <= 0 || cols <= 0 || !part || !map || !out) { g_err = "irrl_sum_rows_scatter: empty request"; return 1; }
+  hipLaunchKernelGGL(irrl_sum_rows_scatter_kernel, dim3((unsigned)((cols + 63) / 64), (unsigned)nmat), dim3(256), 0, (hipStream_t)hip_stream, part, rows,
+                     cols, map, add, out);
   HIP_TRY(hipGetLastError());
   return 0;
 }

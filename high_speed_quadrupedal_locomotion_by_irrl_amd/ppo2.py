@@ -225,6 +225,139 @@ def mlp_ppo_grads(policy, obs, actions, returns, old_values, old_neglogp, adv_st
     return loss, torch.stack([pg, vf, ent, kl, cf]), grads
 
 
+class FlatParams(object):
+    """Every parameter of a policy as a VIEW of one persistent flat buffer, and the gradient and the Adam moments likewise.
+    The data-parallel exchange of an optimizer step (one all-reduce of the flat gradient) is then ONE collective on
+    `grad[:n]` with nothing packed or unpacked around it, and on the GPU clip_by_global_norm + Adam (ppo2.py:182-197) is one launch
+    over the four buffers (`irrl_clip_adam`, csrc/ppo_optim.hpp).  Parameters start at multiples of 64 floats (the kernels that take
+    a parameter pointer may load 16-byte vectors); the padding carries zero gradients and never moves.  `grad` has a tail of TAIL
+    floats behind the parameters' slots for per-step statistics that the gradient kernels write beside the gradients."""
+    ALIGN = 64
+    TAIL = 64
+
+    def __init__(self, policy):
+        self.params = list(policy.parameters())
+        dev = self.params[0].device
+        self.offsets = []
+        o = 0
+        for p in self.params:
+            self.offsets.append(o)
+            o += -(-p.numel() // self.ALIGN) * self.ALIGN
+        self.n = o
+        self.theta = torch.zeros(o, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(o + self.TAIL, device=dev, dtype=torch.float32)
+        self.m = torch.zeros(o, device=dev, dtype=torch.float32)
+        self.v = torch.zeros(o, device=dev, dtype=torch.float32)
+        self.step = 0
+        self.grad_views = []
+        with torch.no_grad():
+            for p, off in zip(self.params, self.offsets):
+                view = self.theta[off:off + p.numel()].view_as(p)
+                view.copy_(p)
+                p.data = view
+                self.grad_views.append(self.grad[off:off + p.numel()].view_as(p))
+        self._dirty = [False] * len(self.params)      # slot holds a gradient some earlier step wrote
+        self.offset_of = {id(p): off for p, off in zip(self.params, self.offsets)}
+
+    def gather(self):
+        """autograd left the gradients in separate tensors (p.grad): ONE multi-tensor copy into the flat buffer; slots of parameters
+        without a gradient are (kept) zero"""
+        src, dst, stale = [], [], []
+        for i, (p, gv) in enumerate(zip(self.params, self.grad_views)):
+            if p.grad is not None:
+                if p.grad.data_ptr() != gv.data_ptr():
+                    src.append(p.grad)
+                    dst.append(gv)
+                self._dirty[i] = True
+            elif self._dirty[i]:
+                stale.append(gv)
+                self._dirty[i] = False
+        if src:
+            torch._foreach_copy_(dst, src)
+        if stale:
+            torch._foreach_zero_(stale)
+
+    def point_grads_at_views(self):
+        for p, gv in zip(self.params, self.grad_views):
+            p.grad = gv
+
+
+_MLP_MAPS = {}
+
+
+def _mlp_scatter_map(policy, flat, ent_coef):
+    """column of a partial-sum row of the MlpPolicy gradient kernels (csrc/mlp_update.hpp: scalars[4] | d logstd[16] | d b1[64] | d b2[64] |
+    d b3[16] | d W1[48][64] | d W2[64][64] | d W3[64][16]) -> slot of the flat gradient buffer; the four scalars of network k go to the
+    tail slots n + 4 k ..; `add` carries -ent_coef for d logstd.  Built once per (policy, ent_coef)."""
+    from . import _lib
+    key = (id(flat), float(ent_coef))
+    hit = _MLP_MAPS.get(key)
+    if hit is not None:
+        return hit
+    P = _lib.load().irrl_mlp_ppo_partial_len()
+    A = policy.act_dim
+    mp = np.full((2, P), -1, np.int32)
+    add = np.zeros((2, P), np.float32)
+    o1, o2, o3, w1, w2, w3 = 20, 84, 148, 164, 164 + 48 * 64, 164 + 48 * 64 + 64 * 64
+    off = flat.offset_of
+    for kind, fc, head in ((0, policy.pi_fc, policy.pi), (1, policy.vf_fc, policy.vf)):
+        out = head.w.shape[1]
+        mp[kind, 0:4] = flat.n + 4 * kind + np.arange(4)
+        if kind == 0:
+            mp[0, 4:4 + A] = off[id(policy.logstd)] + np.arange(A)
+            add[0, 4:4 + A] = -float(ent_coef)
+        mp[kind, o1:o1 + 64] = off[id(fc[0].b)] + np.arange(64)
+        mp[kind, o2:o2 + 64] = off[id(fc[1].b)] + np.arange(64)
+        mp[kind, o3:o3 + out] = off[id(head.b)] + np.arange(out)
+        k35 = np.arange(35)[:, None] * 64 + np.arange(64)[None, :]
+        mp[kind, w1:w1 + 35 * 64] = (off[id(fc[0].w)] + k35).reshape(-1)
+        mp[kind, w2:w2 + 64 * 64] = off[id(fc[1].w)] + np.arange(64 * 64)
+        cols = (w3 + np.arange(64)[:, None] * 16 + np.arange(out)[None, :]).reshape(-1)
+        mp[kind, cols] = (off[id(head.w)] + np.arange(64)[:, None] * out + np.arange(out)[None, :]).reshape(-1)
+    dev = flat.grad.device
+    hit = (torch.from_numpy(mp).to(dev), torch.from_numpy(add).to(dev), P, {})
+    _MLP_MAPS.clear()          # one live learner per process is the rule; do not keep dead ones' buffers
+    _MLP_MAPS[key] = hit
+    return hit
+
+
+def mlp_ppo_grads_flat(policy, flat, obs, actions, returns, old_values, old_neglogp, adv_stats, cliprange, ent_coef, vf_coef, index, n_blocks=256):
+    """`mlp_ppo_grads` with the gradients summed over the workgroups STRAIGHT INTO the flat gradient buffer (one
+    `irrl_sum_rows_scatter` launch for both networks instead of two row sums + one copy per parameter).  -> the step's raw
+    statistics row [8 sums | logstd 12] (one small launch; `mlp_stats_rows` turns the rows of an update into the logged means)."""
+    from . import _lib
+    lib = _lib.load()
+    dev = obs.device
+    n = int(index.numel()) if index is not None else int(returns.numel())
+    mp, add, P, cache = _mlp_scatter_map(policy, flat, ent_coef)
+    partials = cache.get(n_blocks)
+    if partials is None:
+        partials = cache[n_blocks] = torch.empty(2, n_blocks, P, device=dev, dtype=torch.float32)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    c = lambda t: t if t.is_contiguous() else t.contiguous()
+    obs, actions, returns, old_values, old_neglogp = c(obs), c(actions), c(returns), c(old_values), c(old_neglogp)
+    ip = p(index) if index is not None else None
+    if index is not None:
+        assert index.dtype == torch.int64 and index.is_contiguous()
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    for kind, fc, head in ((0, policy.pi_fc, policy.pi), (1, policy.vf_fc, policy.vf)):
+        _lib.check(lib.irrl_mlp_ppo_grads(kind, n, ip, obs.shape[-1], fc[0].w.shape[1], actions.shape[-1], p(obs), p(actions), p(returns),
+                                          p(old_values), p(old_neglogp), p(fc[0].w), p(fc[0].b), p(fc[1].w), p(fc[1].b),
+                                          p(head.w), p(head.b), p(policy.logstd), p(adv_stats), float(cliprange), float(vf_coef),
+                                          p(partials[kind]), n_blocks, stream))
+    _lib.check(lib.irrl_sum_rows_scatter(p(partials), 2, n_blocks, P, p(mp), p(add), p(flat.grad), stream))
+    for i in range(len(flat._dirty)):
+        flat._dirty[i] = True
+    return torch.cat([flat.grad[flat.n:flat.n + 8], policy.logstd.detach().reshape(-1)])
+
+
+def mlp_stats_rows(rows, n, act_dim):
+    """[steps, 8 + A] raw rows of `mlp_ppo_grads_flat` -> [steps, 5] (pg, vf, entropy, approxkl, clipfrac)"""
+    r = torch.stack(rows)
+    ent = r[:, 8:8 + act_dim].sum(1) + 0.5 * (math.log(2.0 * math.pi) + 1.0) * act_dim
+    return torch.stack([r[:, 0] / n, r[:, 4] / n, ent, r[:, 1] / n, r[:, 2] / n], 1)
+
+
 def fused_ppo_loss_supported(policy, obs):
     return bool(obs.is_cuda and hasattr(policy, "evaluate_raw") and getattr(policy, "act_dim", 0) == 12)
 
@@ -460,7 +593,12 @@ class PPO2(object):
         self.generator = torch.Generator(device=self.device)
         self.generator.manual_seed(self.seed * 1000003 + 1)
         self.noise_seed = (self.seed * 1000003 + 1) & 0xFFFFFFFF   # key of the in-kernel sampling noise
-        self.env_id_offset = self.rank * int(self.n_envs or 0)     # global id of this rank's env 0
+        self.env_id_offset = 0                                     # global id of this rank's env 0: `_bind_env_ids`
+        self._bind_env_ids()
+        # parameters, gradients and Adam moments as views of flat buffers (FlatParams): one collective per optimizer step, and on
+        # the GPU clip + Adam as one launch (`flat_optim`; tests flip it to compare with torch.optim.Adam on the same views)
+        self.flat = FlatParams(self.policy)
+        self.flat_optim = self.device.type == "cuda"
         adam_kw = dict(lr=float(learning_rate) if not callable(learning_rate) else 1e-3, eps=1e-5, betas=(0.9, 0.999))
         try:  # one fused kernel over the 19 parameter tensors on the GPU
             self.optimizer = torch.optim.Adam(self.policy.parameters(), fused=(self.device.type == "cuda"), **adam_kw)
@@ -514,13 +652,10 @@ class PPO2(object):
                 adv_stats = torch.stack([adv_moments[0], torch.sqrt(adv_moments[1])]).to(torch.float32)
             else:
                 adv_stats = self._adv_stats_indexed(returns, values, index)
-            _loss, stats, grads = mlp_ppo_grads(self.policy, obs, actions, returns, values, neglogpacs, adv_stats, cliprange_now, self.ent_coef,
-                                                self.vf_coef, index=index, want_loss=False)
-            self.optimizer.zero_grad(set_to_none=True)
-            for prm, grd in grads.items():
-                prm.grad = grd.contiguous()
-            self._apply_gradients(lr_now)
-            return stats
+            row = mlp_ppo_grads_flat(self.policy, self.flat, obs, actions, returns, values, neglogpacs, adv_stats, cliprange_now, self.ent_coef,
+                                     self.vf_coef, index)
+            self._apply_gradients(lr_now, gathered=True)
+            return row      # raw sums: `update` turns the rows of all steps into the logged means at once (mlp_stats_rows)
         mean, var = adv_moments if adv_moments is not None else self._adv_moments(returns, values)
         advs = None if (self.fused_loss and fused_ppo_loss_supported(self.policy, obs)) else returns - values
         stats = None
@@ -549,22 +684,36 @@ class PPO2(object):
             return stats.detach()
         return torch.stack([pg.detach(), vf.detach(), ent.detach(), kl.detach(), cf.detach()])
 
-    def _apply_gradients(self, lr_now):
-        """Average over ranks, clip by the global norm, Adam (ppo2.py:182-189, 283-298)."""
-        params = [p for p in self.policy.parameters() if p.grad is not None]
+    def _apply_gradients(self, lr_now, gathered=False):
+        """Average over ranks, clip by the global norm, Adam (ppo2.py:182-189, 283-298).  The gradient lives in ONE flat buffer
+        (FlatParams): `gathered` says the gradient kernels wrote it there themselves, otherwise autograd's per-parameter tensors are
+        copied in by one multi-tensor launch.  Several ranks: ONE all-reduce of that buffer (283 KB for the LSTM
+        policy), nothing packed or unpacked around it; the mean over ranks is folded into the clip scale."""
+        fl = self.flat
+        if not gathered:
+            fl.gather()
         if self.world > 1:
-            flat = torch.cat([p.grad.reshape(-1) for p in params])    # C1: one flat bucket (283 KB for the LSTM policy)
-            torch.distributed.all_reduce(flat)
-            flat /= self.world
-            off = 0
-            for p in params:
-                p.grad.copy_(flat[off:off + p.numel()].view_as(p))
-                off += p.numel()
+            torch.distributed.all_reduce(fl.grad[:fl.n])              # C1: the only collective of the step besides the 3 moment floats
+        if self.flat_optim and self.device.type == "cuda":
+            from . import _lib
+            fl.step += 1
+            p = lambda t: C.c_void_p(t.data_ptr())
+            _lib.check(_lib.load().irrl_clip_adam(fl.n, p(fl.theta), p(fl.grad), p(fl.m), p(fl.v), 1.0 / self.world,
+                                                  float(self.max_grad_norm) if self.max_grad_norm is not None else 0.0, float(lr_now), 0.9, 0.999, 1e-5,
+                                                  fl.step, None, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+            if hasattr(self.policy, "prepare"):
+                self.policy.prepare()      # the LSTM kernels read [unit][gate]-permuted COPIES of the weights
+            return
+        if self.world > 1:
+            fl.grad[:fl.n] /= self.world
+        fl.point_grads_at_views()
         if self.max_grad_norm is not None:
-            torch.nn.utils.clip_grad_norm_(params, self.max_grad_norm)  # clip_by_global_norm AFTER averaging
+            torch.nn.utils.clip_grad_norm_(fl.params, self.max_grad_norm)  # clip_by_global_norm AFTER averaging
         for g in self.optimizer.param_groups:
             g['lr'] = lr_now
         self.optimizer.step()       # (its post-step hook refreshes the kernels' permuted weight copies)
+        for prm in fl.params:
+            prm.grad = None         # the next backward() leaves fresh tensors, gather() copies them into the views
 
     def update(self, batch, lr_now, cliprange_now):
         """All epochs / minibatches of one PPO iteration (ppo2.py:362-404)."""
@@ -607,6 +756,8 @@ class PPO2(object):
                         continue
                     losses.append(self._train_step(lr_now, cliprange_now, flat["obs"][mb], flat["returns"][mb], flat["masks"][mb],
                                                    flat["actions"][mb], flat["values"][mb], flat["neglogpacs"][mb]))
+            if in_place:
+                return mlp_stats_rows(losses, float(bs), self.policy.act_dim).mean(0)
         return torch.stack(losses).mean(0)
 
     def learn(self, total_timesteps, callback=None, seed=None, log_interval=1, tb_log_name="PPO2", eval_every_n=5,
@@ -690,6 +841,29 @@ class PPO2(object):
     def set_env(self, env):
         self.env = env
         self.n_envs = env.num_envs if env is not None else None
+        self._bind_env_ids()
+
+    def _bind_env_ids(self):
+        """Which robots of the one big pool this rank owns.  Every random draw of the path is addressed by the GLOBAL env id: the env
+        pool's own draws by its `EnvIdOffset`, the policy's sampling noise by `env_id_offset` -- the two must be the same number, and
+        the ranks' ranges must not overlap, or the N-rank job silently trains on N copies of the same data.  The offset is therefore
+        READ from the pool when it exposes one (`env.env_id_offset`: TorchVecEnv / RaisimGymVecEnv over the C-ABI pool), rank *
+        n_envs otherwise; with several ranks the ranges are all-gathered and checked."""
+        n = int(self.n_envs or 0)
+        off = getattr(self.env, "env_id_offset", None) if self.env is not None else None
+        self.env_id_offset = int(off) if off is not None else self.rank * n
+        if self.world > 1 and self.env is not None:
+            mine = torch.tensor([self.env_id_offset, n], dtype=torch.int64)
+            backend = torch.distributed.get_backend()
+            if backend == "nccl":
+                mine = mine.to(self.device)
+            got = [torch.zeros_like(mine) for _ in range(self.world)]
+            torch.distributed.all_gather(got, mine)
+            spans = sorted((int(g[0]), int(g[0]) + int(g[1])) for g in got)
+            for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+                if b0 < a1:
+                    raise ValueError("PPO2: ranks own overlapping global env ids %s -- give rank r's pool EnvIdOffset = r * num_envs "
+                                     "(cfg['environment']['EnvIdOffset']), otherwise every rank draws the same random streams" % (spans,))
 
     # -- checkpoints (ppo2.py:452-476): (data dict, parameter list in stable-baselines order) --
     def _data(self):

@@ -213,6 +213,13 @@ class TorchVecEnv(object):
         self.ep_len *= (1.0 - d)
         return self.obs, self.reward, self.done
 
+    @property
+    def env_id_offset(self):
+        """global id of this pool's env 0 (cfg `EnvIdOffset`; rank r of an N-GPU job owns r * num_envs ..): PPO2 addresses the policy's
+        sampling noise by the same ids and checks that the ranks' ranges do not overlap"""
+        v = self.wrapper.cfg_value("EnvIdOffset") if hasattr(self.wrapper, "cfg_value") else float("nan")
+        return 0 if v != v else int(v)
+
     def step_into(self, action, obs, reward, done):
         """step() writing straight into the caller's tensors and WITHOUT the per-step episode bookkeeping (one launch);
         the caller accounts whole rollouts with `account_rollout`."""

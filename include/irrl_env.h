@@ -186,6 +186,20 @@ int irrl_mlp_ppo_partial_len(void);
 int irrl_adv_moments(size_t n, const int64_t *idx, const float *returns, const float *old_values, double *scratch, int n_blocks, double *sums,
                      float *stats, void *hip_stream);
 
+/* ---- tail of one PPO2 optimizer step on FLAT buffers (ppo2.py:182-197: tf.clip_by_global_norm(max_grad_norm) then
+ * tf.train.AdamOptimizer(lr, epsilon).apply_gradients; kernels csrc/ppo_optim.hpp).  theta / grad / m / v: [n] floats (device,
+ * 16-byte aligned), the parameters, their gradient and the Adam moments; every parameter tensor of the policy is a view of theta.
+ * g = grad_scale * grad (1 / world after the all-reduce sum), clipped to max_norm by its global 2-norm (max_norm <= 0: no clip),
+ * then Adam step number `step` (1-based; bias corrections evaluated in double on the host).  ONE launch, fixed summation order:
+ * the same inputs give the same bits on every rank.  norm_out (device, may be NULL) receives the unclipped norm of g. */
+int irrl_clip_adam(int n, float *theta, const float *grad, float *m, float *v, float grad_scale, float max_norm, float lr, float beta1, float beta2,
+                   float eps, long long step, float *norm_out, void *hip_stream);
+
+/* out[map[m][c]] = (add ? add[m][c] : 0) + sum over r of part[m][r][c]  for the nmat matrices part [nmat, rows, cols] of per-workgroup
+ * partial sums (fixed order); map [nmat, cols] int32 (device), entries < 0 skip the column.  Used to drop the MlpPolicy gradient kernels'
+ * partial rows straight into the flat gradient buffer in parameter layout. */
+int irrl_sum_rows_scatter(const float *part, int nmat, int rows, int cols, const int *map, const float *add, float *out, void *hip_stream);
+
 /* synthetic action stream of the benchmark (a = clip(sigma N(0,1), -1, 1) from Philox(seed, stream = env,
  * counter = step)): fills out[n_steps][n_envs][12] (device) for envs env0 .. and steps step0 ..; values depend only on
  * (seed, global env id, step), not on the shape of the request.  tests/ hold the numpy twin. */

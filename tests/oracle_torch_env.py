@@ -11,6 +11,7 @@ class OracleTorchEnv(object):
         self.env = O.OracleVecEnv(env_cfg)
         self.num_envs, self.num_obs, self.num_acts = self.env.n, 35, 12
         self.device = torch.device("cpu")
+        self.env_id_offset = int(env_cfg.get("EnvIdOffset", 0))     # what TorchVecEnv reads from the C-ABI pool's configuration
         self._ret = np.zeros(self.num_envs)
         self._len = np.zeros(self.num_envs)
         self._fin = [0.0, 0.0, 0]

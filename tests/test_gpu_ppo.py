@@ -601,3 +601,90 @@ def test_graph_capture_warmup_leaves_no_trace_and_setters_invalidate_the_graph()
             for k in ("obs", "actions", "values", "true_reward", "masks", "neglogpacs", "returns"):
                 assert torch.equal(out[mode][i][k], out["eager"][i][k]), (mode, i, k)
     assert not torch.equal(out["graph"][1]["obs"], out["graph"][0]["obs"])
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# Round 4: the optimizer step on flat buffers (ppo2.FlatParams, csrc/ppo_optim.hpp)
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,max_norm,world", [(70741, 0.5, 1), (13 * 64 + 3, 0.5, 2), (4096, 0.0, 1), (70741, 1e9, 8)])
+def test_clip_adam_kernel_matches_torch_clip_and_adam(n, max_norm, world):
+    """`irrl_clip_adam` (global-norm clip + Adam over flat buffers in one launch; ppo2.py:182-197) against
+    torch.nn.utils.clip_grad_norm_ + torch.optim.Adam(eps 1e-5) over 12 steps with changing gradients and learning rates, including a
+    gradient far above / below the clip threshold and the 1 / world scale of the all-reduced sum; the same launch twice gives the same bits."""
+    import ctypes as C
+    from high_speed_quadrupedal_locomotion_by_irrl_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    theta0 = torch.randn(n, device=dev, generator=g)
+    pad = (-n) % 4
+    bufs = [torch.zeros(n + pad + 4, device=dev) for _ in range(8)]       # two sets of (theta, grad, m, v), 16-byte aligned
+    ref = torch.nn.Parameter(theta0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3, eps=1e-5, betas=(0.9, 0.999))
+    p = lambda t: C.c_void_p(t.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    for k in (0, 4):
+        bufs[k][:n].copy_(theta0)
+    norm_out = torch.zeros(1, device=dev)
+    for step in range(1, 13):
+        scale = [1.0, 300.0, 1e-3, 5.0][step % 4]
+        grad_sum = scale * torch.randn(n, device=dev, generator=g) * world          # what the all-reduce leaves: the SUM over ranks
+        lr = 1e-3 * (1.0 - step / 20.0)
+        ref.grad = (grad_sum / world).clone()
+        total = float(ref.grad.norm())
+        if max_norm > 0:
+            torch.nn.utils.clip_grad_norm_([ref], max_norm)
+        for gr in opt.param_groups:
+            gr["lr"] = lr
+        opt.step()
+        for k in (0, 4):
+            bufs[k + 1][:n].copy_(grad_sum)
+            _lib.check(lib.irrl_clip_adam(n, p(bufs[k]), p(bufs[k + 1]), p(bufs[k + 2]), p(bufs[k + 3]), 1.0 / world, max_norm, lr, 0.9, 0.999, 1e-5,
+                                          step, p(norm_out), stream))
+        assert torch.equal(bufs[0], bufs[4])                                          # deterministic
+        assert abs(float(norm_out) - total) < 2e-5 * total
+        err = float((bufs[0][:n] - ref.detach()).abs().max())
+        assert err < 3e-6, (step, err)
+    assert float((bufs[0][:n] - theta0).abs().max()) > 5e-3                           # the parameters did move
+    assert float(bufs[0][n:].abs().max()) == 0.0                                       # nothing written behind the n parameters
+
+
+@pytest.mark.parametrize("kind", ["lstm", "mlp"])
+def test_flat_optimizer_step_follows_torch_adam_on_the_same_views(kind):
+    """One PPO2 update with the optimizer step on flat buffers (one gather launch, `irrl_clip_adam`) against the same update with
+    clip_grad_norm_ + torch.optim.Adam on the same parameter views: same parameters to rounding; every parameter IS a view of the flat
+    buffer; the MlpPolicy gradient kernels' scatter into the flat gradient equals `mlp_ppo_grads` bit for bit."""
+    from high_speed_quadrupedal_locomotion_by_irrl_amd import ppo2 as P2
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import CustomLSTMPolicy, MlpPolicy
+    after = {}
+    for flat_optim in (True, False):
+        env = _env(64)
+        model = P2.PPO2(policy=CustomLSTMPolicy if kind == "lstm" else MlpPolicy, env=env, n_steps=32, nminibatches=1 if kind == "lstm" else 4,
+                        noptepochs=3, learning_rate=1e-3, seed=8)
+        model.flat_optim = flat_optim
+        fl = model.flat
+        for prm, off in zip(fl.params, fl.offsets):
+            assert prm.data_ptr() == fl.theta.data_ptr() + 4 * off and off % 64 == 0
+        runner = P2.Runner(env, model, 32, 0.99, 0.95)
+        batch = runner.run()
+        stats = model.update(batch, 1e-3, 0.2)
+        after[flat_optim] = (fl.theta.clone(), stats)
+        assert float(fl.theta.abs().max()) > 0 and model.flat.step == (3 if kind == "lstm" else 12) * int(flat_optim)
+    assert float((after[True][0] - after[False][0]).abs().max()) < 3e-6
+    np.testing.assert_allclose(after[True][1].cpu().numpy(), after[False][1].cpu().numpy(), rtol=1e-4, atol=1e-6)
+    if kind == "mlp":
+        dev = model.device
+        g = torch.Generator(device=dev); g.manual_seed(2)
+        rows = 5000
+        obs, actions = torch.randn(rows, 35, device=dev, generator=g), 0.5 * torch.randn(rows, 12, device=dev, generator=g)
+        ret, ov, onlp = (torch.randn(rows, device=dev, generator=g) for _ in range(3))
+        onlp = onlp + 9.0
+        index = torch.randperm(rows, device=dev, generator=g)[:3000].contiguous()
+        st = torch.tensor([0.1, 1.3], device=dev)
+        _loss, stats, grads = P2.mlp_ppo_grads(model.policy, obs, actions, ret, ov, onlp, st, 0.2, 0.01, 0.5, index=index)
+        model.ent_coef = 0.01
+        row = P2.mlp_ppo_grads_flat(model.policy, model.flat, obs, actions, ret, ov, onlp, st, 0.2, 0.01, 0.5, index)
+        for prm, gv in zip(model.flat.params, model.flat.grad_views):
+            if prm in grads:
+                assert torch.equal(gv, grads[prm].reshape(gv.shape)), tuple(prm.shape)
+        np.testing.assert_allclose(P2.mlp_stats_rows([row], 3000.0, 12)[0].cpu().numpy(), stats.cpu().numpy(), rtol=1e-6, atol=1e-7)

@@ -94,7 +94,7 @@ def _learn_worker(rank, world, port, out_dir):
     from oracle_torch_env import OracleTorchEnv
     from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import CustomLSTMPolicy
     from high_speed_quadrupedal_locomotion_by_irrl_amd.ppo2 import PPO2
-    env = OracleTorchEnv(load_env_cfg("default_cfg.yaml", num_envs=4, seedd=1 + rank))   # env shards differ per rank
+    env = OracleTorchEnv(load_env_cfg("default_cfg.yaml", num_envs=4, EnvIdOffset=4 * rank))   # rank r owns the global env ids 4 r .. 4 r + 3
     model = PPO2(policy=CustomLSTMPolicy, env=env, n_steps=10, nminibatches=1, noptepochs=2, gamma=0.99, lam=0.998, ent_coef=0.0,
                  learning_rate=1e-3, vf_coef=0.5, max_grad_norm=0.5, cliprange=0.2, verbose=1, seed=5)
     model.learn(total_timesteps=2 * 10 * 4 * world, eval_every_n=0)
@@ -167,3 +167,41 @@ def test_single_process_learn_with_mlp_and_lstm():
         after = np.concatenate([p.reshape(-1) for p in model.get_parameter_list()])
         assert np.isfinite(after).all() and np.abs(after - before).max() > 1e-5
         assert model.num_timesteps == 2 * 12 * 4
+
+
+def _overlap_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from conftest import load_env_cfg
+    from oracle_torch_env import OracleTorchEnv
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import MlpPolicy
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.ppo2 import PPO2
+    msg = "ok"
+    try:
+        # a launcher that forgot EnvIdOffset: both pools claim the global env ids 0 .. 3
+        PPO2(policy=MlpPolicy, env=OracleTorchEnv(load_env_cfg("default_cfg.yaml", num_envs=4)), n_steps=4, nminibatches=1, seed=5)
+    except ValueError as e:
+        msg = str(e)
+    # the same through set_env(): a model built without an env gets its ids when the env arrives
+    model = PPO2(policy=MlpPolicy, env=None, n_steps=4, nminibatches=1, seed=5, device="cpu")
+    model.set_env(OracleTorchEnv(load_env_cfg("default_cfg.yaml", num_envs=4, EnvIdOffset=4 * rank)))
+    with open(os.path.join(out_dir, "overlap_%d.txt" % rank), "w") as f:
+        f.write("%s\n%d\n" % (msg, model.env_id_offset))
+    torch.distributed.destroy_process_group()
+
+
+def test_ranks_with_overlapping_env_ids_are_refused(tmp_path):
+    """seeds are rank-independent, so what makes ranks differ is ONLY the global env ids they own.  Two pools that claim
+    the same ids (EnvIdOffset forgotten) must not train silently on two copies of the same data; PPO2(env=None) + set_env() must
+    pick the offset up."""
+    port = _free_port()
+    mp.spawn(_overlap_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        msg, off = open(tmp_path / ("overlap_%d.txt" % r)).read().strip().split("\n")
+        assert "overlapping global env ids" in msg, msg
+        assert int(off) == 4 * r

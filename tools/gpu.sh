@@ -10,6 +10,7 @@
 #   bench3         the three shipped configs, env leg only
 #   solvers        env leg of the benchmark config under ContactSolver 0 1 2 3
 #   sweep          envs-per-GPU sweep + PCIe-inclusive numpy boundary
+#   gloo8          bench.py --gpus 8 with all eight ranks on this one device (gloo): configs 4 / 5 at 32 768 envs, PPO collectives in the loop
 #   prof           rocprofv3 --kernel-trace --stats of the bench command
 #   profppo        rocprofv3 --kernel-trace --stats of 2 PPO iterations x 2 epochs (LSTM)
 #   profmlp        rocprofv3 --kernel-trace --stats of 3 PPO iterations with the MlpPolicy learner (config 2)
@@ -57,6 +58,12 @@ while [ $# -gt 0 ]; do
         timeout 300 python bench.py --cpu-seconds 0 --ppo-iters 0 --steps 1000 --warmup 100 --check-steps 0 --envs $n 2>/dev/null | line "envs=$n" >> $O/sweep.log
       done
       timeout 300 python tools/host_boundary_rate.py >> $O/sweep.log 2>&1 ;;
+    gloo8)
+      # BASELINE configs 4 / 5 at their real size WITHOUT the 8-GPU node: eight ranks x 4096 envs = the 32 768-env job, every rank on
+      # this one MI355X, barrier / all-reduces over gloo (the RCCL / xGMI transport itself stays unmeasured); the PPO legs run the
+      # per-optimizer-step collectives of SURVEY 8e.  The JSON line is copied to profiles/ by hand.
+      IRRL_BENCH_BACKEND=gloo IRRL_BENCH_ONE_DEVICE=1 OMP_NUM_THREADS=2 timeout 1500 python bench.py --gpus 8 --ppo-iters ${GLOO8_PPO_ITERS:-2} > $O/bench_gloo8.log 2>&1; echo "rc=$?" >> $O/bench_gloo8.log
+      IRRL_BENCH_BACKEND=gloo IRRL_BENCH_ONE_DEVICE=1 OMP_NUM_THREADS=2 timeout 900 python bench.py --gpus 8 --cfg bp5_terrain.yaml --ppo-iters 0 > $O/bench_gloo8_terrain.log 2>&1; echo "rc=$?" >> $O/bench_gloo8_terrain.log ;;
     prof)
       (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python3 $R/bench.py --steps 20 --warmup 5 --cpu-seconds 0 --ppo-iters 0 --check-steps 500 > $O/rocprof_bench.log 2>&1) ;;
     profppo)

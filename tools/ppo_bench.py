@@ -51,9 +51,15 @@ def measure(policy="lstm", envs=4096, steps=750, iters=3, epochs=10, cfg_name="d
     timed = rows[1:] if len(rows) > 1 else rows
     ro = sum(r[0] for r in timed) / len(timed)
     up = sum(r[1] for r in timed) / len(timed)
+    its = sorted(1.0 / (r[0] + r[1]) for r in timed)
+    med = lambda v: (v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2]))
     return {"policy": policy, "envs": envs, "n_steps": steps, "epochs": epochs, "timed_iters": len(timed), "rollout_s": ro, "update_s": up,
             "ppo_iters_per_sec": 1.0 / (ro + up), "env_steps_per_sec_in_rollout": envs * steps / ro,
-            "samples_per_sec": envs * steps / (ro + up), "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}
+            "samples_per_sec": envs * steps / (ro + up), "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9,
+            # spread over the timed iterations (the first, which warms the allocator, is left out): iterations / s
+            "iters_per_sec_min_median_max": [its[0], med(its), its[-1]],
+            "rollout_s_min_max": [min(r[0] for r in timed), max(r[0] for r in timed)],
+            "update_s_min_max": [min(r[1] for r in timed), max(r[1] for r in timed)]}
 
 
 def main():
