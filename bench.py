@@ -61,9 +61,10 @@ def parse_args(argv=None):
     ap.add_argument("--ppo-iters", type=int, default=5, help="timed PPO iterations of each learner leg, reported with min / median / max (0 disables)")
     ap.add_argument("--ppo-steps", type=int, default=750, help="rollout length of the PPO leg (the metric's is 750)")
     ap.add_argument("--ppo-epochs", type=int, default=10, help="optimisation epochs of the PPO leg (the metric's is 10)")
-    ap.add_argument("--launch", choices=("rows", "graph", "python"), default="rows",
-                    help="how the K timed steps are issued: 'rows' = one irrl_env_step_rows call (K back-to-back launches from C, default), "
-                         "'graph' = one hipGraph of K step-kernel nodes (what the PPO rollout is), 'python' = one ctypes call per step")
+    ap.add_argument("--launch", choices=("auto", "rows", "graph", "python"), default="auto",
+                    help="how the K timed steps are issued: 'rows' = one irrl_env_step_rows call (K back-to-back launches from C), "
+                         "'graph' = one hipGraph of K step-kernel nodes, 'python' = one ctypes call per step; 'auto' (default) = rows for long "
+                         "brackets, for K <= 400 whichever of the three was fastest on this box in two untimed warm-up brackets each")
     ap.add_argument("--no-graph", dest="launch", action="store_const", const="python", help="same as --launch python")
     ap.add_argument("--check-steps", type=int, default=2000, help="extra untimed-for-`value` window after the timed region that "
                     "re-measures us/step over a longer run (0 disables); reported as `steady_state_check`")
@@ -213,7 +214,7 @@ def worker(args):
     # synthetic action stream resident in HBM: row s = actions of global step s for this rank's envs (global env id =
     # rank * n + e).  Beyond 16384 steps the stream wraps (it would be 3 GB otherwise); the default run uses 5.5 k rows.
     preroll = max(MIN_PREROLL, args.preroll)
-    total = preroll + args.warmup + args.steps + 50 + args.check_steps
+    total = preroll + args.warmup + 8 * args.steps + 50 + args.check_steps
     rows = min(total, 16384)
     lib = _lib.load()
     actions = torch.empty(rows, n, 12, device=dev)
@@ -241,16 +242,63 @@ def worker(args):
     # per-step Python / ctypes latency inside the bracket, and the first kernel starts a few microseconds after the call -- with
     # the driver's --steps 20 the bracket is 0.8 ms long and a hipGraph launch (--launch graph: what the PPO rollout uses, 1500
     # nodes there) costs ~40 us before its first node runs.  Capturing records the launches without executing them.
-    graph = None
-    if args.launch == "graph" and args.steps <= 20000:
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        s_keep = cursor[0]
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=side):
-            run(args.steps, "python")
-        cursor[0] = s_keep
+    graph_cache = {}
+
+    def make_graph():
+        if "g" not in graph_cache:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            s_keep = cursor[0]
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                run(args.steps, "python")
+            cursor[0] = s_keep
+            torch.cuda.synchronize()
+            graph_cache["g"] = g
+        return graph_cache["g"]
+
+    def bracket(mode, events=None):
+        """args.steps env steps issued in `mode`, bracketed by synchronize on both sides -> wall seconds.  Completion is first seen by
+        polling the closing event (hipEventQuery), then confirmed by torch.cuda.synchronize(): on some boxes of this pool a host thread
+        BLOCKED in the synchronize behind a short burst is woken up milliseconds late (profiles/r04_burst_wakeup.log: 20 steps = 0.9 ms
+        of kernels, 2.0-3.4 ms of wall clock); a thread that polls is not."""
+        call = env.step_rows_call(args.steps, actions, cursor[0] % rows, ob, rew, done, extra) if mode == "rows" else None
+        g = make_graph() if mode == "graph" else None
+        e0, e1 = events if events is not None else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         torch.cuda.synchronize()
+        t_start = time.perf_counter()
+        e0.record()
+        if mode == "rows":
+            call()
+            cursor[0] += args.steps
+        elif mode == "graph":
+            g.replay()
+            cursor[0] += args.steps
+        else:
+            run(args.steps, "python")
+        e1.record()
+        while not e1.query():
+            pass
+        torch.cuda.synchronize()
+        return time.perf_counter() - t_start
+
+    # HOW the K timed steps are issued.  One irrl_env_step_rows call (K back-to-back launches from C) is the fastest way on most boxes
+    # (no per-step Python / ctypes latency inside the bracket); a hipGraph of K nodes costs ~40 us before its first node runs; one
+    # ctypes call per step adds ~2 us per step.  With the driver's --steps 20 the bracket is 0.9 ms long and box-to-box differences in
+    # launch / wake-up latency are a large part of it, so `--launch auto` (default) tries each way on THIS box during the warm-up
+    # (two untimed brackets of K steps each) and times the one that was fastest.  Long brackets (K > 400) amortise all of it: rows.
+    launch_probe = None
+    mode = args.launch
+    if mode == "auto":
+        if args.steps > 400 or world > 1:
+            mode = "rows"
+        else:
+            launch_probe = {}
+            for cand in ("rows", "graph", "python"):
+                launch_probe[cand] = min(bracket(cand) for _ in range(2)) * 1e6 / args.steps
+            mode = min(launch_probe, key=launch_probe.get)
+    if mode == "graph" and args.steps > 20000:
+        mode = "rows"
     # the kernels' counters are summed on the device, stream-ordered: no read-back (idle GPU) right before the timed region
     cnt0, cnt1 = torch.zeros(3, dtype=torch.int64, device=dev), torch.zeros(3, dtype=torch.int64, device=dev)
     env.counters_into(cnt0)
@@ -258,25 +306,10 @@ def worker(args):
         dist.barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    timed_rows = None
-    if graph is None and args.launch == "rows":     # arguments checked and marshalled outside the bracket: inside it only the K launches
-        timed_rows = env.step_rows_call(args.steps, actions, cursor[0] % rows, ob, rew, done, extra)
-    t0 = time.perf_counter()
-    ev0.record()
-    if graph is not None:
-        graph.replay()
-        cursor[0] += args.steps
-    elif timed_rows is not None:
-        timed_rows()
-        cursor[0] += args.steps
-    else:
-        run(args.steps, args.launch)
-    ev1.record()
-    torch.cuda.synchronize()
+    elapsed = bracket(mode, (ev0, ev1))      # synchronize | K steps | synchronize on this rank; the MAX over ranks is taken below
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
     env.counters_into(cnt1)      # nothing has stepped the pool since the timed region ended
     torch.cuda.synchronize()
     kernel_ms = ev0.elapsed_time(ev1) / args.steps   # events on the stream the kernel is launched on
@@ -319,7 +352,7 @@ def worker(args):
     # the same K steps issued the way the reference's runner issues them: ONE FlexibleGymEnv.step() call (ctypes -> C-ABI) per
     # control step (RaisimGymVecEnv.py:31), wall clock around the loop -- reported beside `value`, never as `value`
     per_call = None
-    if args.launch == "rows" and world == 1:
+    if mode == "rows" and world == 1:
         torch.cuda.synchronize()
         tc = time.perf_counter()
         run(args.steps, "python")
@@ -362,7 +395,8 @@ def worker(args):
                        "lanes_per_robot": env.lanes_per_robot, "preroll": preroll,
                        "launch": {"rows": "%d back-to-back launches from one irrl_env_step_rows call" % args.steps,
                                   "graph": "one hipGraph of %d step-kernel nodes" % args.steps,
-                                  "python": "one ctypes call per step"}[args.launch if (graph is not None or args.launch != "graph") else "python"]},
+                                  "python": "one ctypes call per step"}[mode],
+                       "launch_probe_us_per_step": launch_probe},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "irrl_step_kernel_l%d" % env.lanes_per_robot, "avg_launch_us": kernel_ms * 1e3,

@@ -719,6 +719,22 @@ IRRL_DEV v3 solve_contact_md(const ContactBlockMD &B, v3 c, v3 n, vf vstar, vf m
   const vf X1 = vsel(sep, 0.0f, pk_lo(X)), X2 = vsel(sep, 0.0f, pk_hi(X));
   return mk3(X1 * pk_lo(B.Tx) + X2 * pk_hi(B.Tx) + lnn * n.x, X1 * pk_lo(B.Ty) + X2 * pk_hi(B.Ty) + lnn * n.y, X1 * pk_lo(B.Tz) + X2 * pk_hi(B.Tz) + lnn * n.z);
 }
+// |G^-1 dc|^2: the size of a contact's (linear, sticking) answer to a change dc of its contact-point velocity -- what the NEXT sweep
+// would change at this contact if the other contacts' last change dlambda moved its velocity by dc (EnvParams::contact_exit).
+// Published rule: G^-1 through the contact frame's Schur complement that the block already holds (alpha' = -dc.n / G_nn,
+// x' = -A^-1 (dc_t + alpha' G_tn), lam_n' = alpha' + beta . x'); first rule: the explicit inverse.
+IRRL_DEV vf answer_norm2_md(const ContactBlockMD &B, v3 dc, v3 n) {
+  const vf alpha = -dot(dc, n) * B.ignn;
+  const vf2 b = dc.x * B.Tx + dc.y * B.Ty + dc.z * B.Tz + alpha * B.g;
+  const vf2 x = pk_lo(b) * B.NI1 + pk_hi(b) * B.NI2;
+  const vf ln = alpha + pk_hsum(B.be * x);
+  return pk_hsum(x * x) + ln * ln;
+}
+IRRL_DEV vf answer_norm2(const ContactBlock &B, v3 dc) {
+  const v3 l = mul(B.Gi, dc);
+  return dot(l, l);
+}
+
 // a contact that is solved once (trunk-box corners, meteorite): block + solve in one go, by the pool's rule (RULE: compile time --
 // the step kernel is instantiated once per rule, so neither rule's live values weigh on the other's register allocation)
 template <int RULE>
@@ -1269,27 +1285,67 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
       rank = vsel_i(leg == 0, 0, vsel_i(leg == 1, a0i, vsel_i(leg == 2, a0i + a1i, a0i + a1i + a2i)));
       nrank = wave_max_small(a0i + a1i + a2i + a3i);
     }
-    // ContactSolver 2 (default): the contacts of a robot update SIMULTANEOUSLY from the sweep's starting iterate -- one solve
+    // ContactSolver bit 1 (default): the contacts of a robot update SIMULTANEOUSLY from the sweep's starting iterate -- one solve
     // per sweep instead of one per contact.  The toes couple only through the heavy base (off-diagonal Delassus blocks are a
     // fraction of the diagonal ones), so this converges almost as fast as Gauss-Seidel (measured on the oracle: 2.4 vs 2.2
     // sweeps per substep, p99 5 vs 4, same fixed point), and the step no longer lasts as long as the wave whose robots
     // happen to have the most feet on the ground (tools/wave_spread.py).
     const bool jacobi = P.contact_jacobi != 0;
     const float tol2 = P.contact_tol * P.contact_tol;
+    // row r of the partner legs' coupling sum_p G_lp v_p for a 3-vector v every leg holds (lam or its last change): three independent
+    // accumulation chains (one per partner leg), then two adds -- the single resident wave issues a DEPENDENT VALU instruction every
+    // ~3.7 ns against 2.3 ns for independent ones, and this chain heads every sweep's critical path
+#define IRRL_COUPLING_ROW(V, INIT)                                                                                              \
+    (legs_rot_fma<1>((V).z, gx1[2], legs_rot_fma<1>((V).y, gx1[1], legs_rot_fma<1>((V).x, gx1[0], (INIT)))) +                  \
+     (legs_rot_fma<2>((V).z, gx2[2], legs_rot_fma<2>((V).y, gx2[1], legs_rot<2>((V).x) * gx2[0])) +                             \
+      legs_rot_fma<3>((V).z, gx3[2], legs_rot_fma<3>((V).y, gx3[1], legs_rot<3>((V).x) * gx3[0]))))
+    if (jacobi) {
+      // ONE loop for both exit rules (EnvParams::contact_exit).  The contact-point velocity is carried from sweep to sweep: the
+      // coupling of the impulses' last change dl is what the next sweep's solve needs, and -- answered linearly by each contact
+      // (answer_norm2*) -- it is also the PREDICTION of how far that sweep would move the impulses: with contact_exit the loop is
+      // left before a sweep that would change them by less than the tolerance, instead of after a sweep that did (the
+      // confirming sweep: one solve of ~130-200 VALU instructions per substep, against ~25 for the prediction).
+      const bool predicted = P.contact_exit != 0;
+      const vf cvr0 = IRRL_COUPLING_ROW(lam, cfree_r);
+      v3 cv = mk3(sub_bcast<0>(cvr0), sub_bcast<1>(cvr0), sub_bcast<2>(cvr0));
+      for (int it = 0; it < P.contact_iters; it++) {
+#ifdef IRRL_PROFILE_WAVES
+        L.prof_ranksteps += 1; L.prof_flags += 256;
+#endif
+        v3 ln = RULE ? solve_contact_md(CM, cv, nB, vstar, L.m.mu, active) : solve_contact(CB, cv, nB, vstar, L.m.mu, active);
+        v3 dl = mk3(vsel(active, ln.x - lam.x, 0.0f), vsel(active, ln.y - lam.y, 0.0f), vsel(active, ln.z - lam.z, 0.0f));
+        lam = lam + dl;
+        if (it + 1 >= P.contact_iters) break;
+        vf l2 = 0.0f;
+        if (tol2 > 0.0f) {
+          l2 = legs_sum(vsel(active, dot(lam, lam), 0.0f));
+          if (!predicted) {
+            vm unconverged = legs_sum(dot(dl, dl)) > tol2 * l2 + 1e-20f;
+            if (!wave_any(unconverged)) break;
+          }
+        }
+        const vf dcr = IRRL_COUPLING_ROW(dl, vf(0.0f));
+        const v3 dc = mk3(sub_bcast<0>(dcr), sub_bcast<1>(dcr), sub_bcast<2>(dcr));
+        // the prediction is only worth its ~25 instructions when it can succeed: the next sweep's change is the coupling's share of this
+        // sweep's (a few per cent to a few tens of per cent), so while some robot of the wave has just moved its impulses by more than
+        // 100 tolerances the wave sweeps again without asking (a late exit costs a sweep, never accuracy: the exit is per WAVE anyway)
+        if (predicted && tol2 > 0.0f && !wave_any(legs_sum(dot(dl, dl)) > (1.0e4f * tol2) * l2 + 1e-20f)) {
+          const vf p2 = RULE ? answer_norm2_md(CM, dc, nB) : answer_norm2(CB, dc);
+          vm unconverged = legs_sum(vsel(active, p2, 0.0f)) > tol2 * l2 + 1e-20f;
+          if (!wave_any(unconverged)) break;
+        }
+        cv = cv + dc;
+      }
+    } else {
     for (int it = 0; it < P.contact_iters; it++) {
       vf d2 = 0.0f;
 #ifdef IRRL_PROFILE_WAVES
       L.prof_ranksteps += nrank; L.prof_flags += 256;
 #endif
       for (int rk = 0; rk < nrank; rk++) {
-        // three independent accumulation chains (one per partner leg), then two adds: the single resident wave issues a DEPENDENT
-        // VALU instruction every ~3.7 ns against 2.3 ns for independent ones, and this chain heads every sweep's critical path
-        const vf c1 = legs_rot_fma<1>(lam.z, gx1[2], legs_rot_fma<1>(lam.y, gx1[1], legs_rot_fma<1>(lam.x, gx1[0], cfree_r)));
-        const vf c2 = legs_rot_fma<2>(lam.z, gx2[2], legs_rot_fma<2>(lam.y, gx2[1], legs_rot<2>(lam.x) * gx2[0]));
-        const vf c3 = legs_rot_fma<3>(lam.z, gx3[2], legs_rot_fma<3>(lam.y, gx3[1], legs_rot<3>(lam.x) * gx3[0]));
-        const vf cvr = c1 + (c2 + c3);
+        const vf cvr = IRRL_COUPLING_ROW(lam, cfree_r);
         v3 cv = mk3(sub_bcast<0>(cvr), sub_bcast<1>(cvr), sub_bcast<2>(cvr));
-        vm commit = jacobi ? active : (active & (rank == rk));
+        vm commit = active & (rank == rk);
         v3 ln = RULE ? solve_contact_md(CM, cv, nB, vstar, L.m.mu, commit) : solve_contact(CB, cv, nB, vstar, L.m.mu, commit);
         v3 dl = mk3(vsel(commit, ln.x - lam.x, 0.0f), vsel(commit, ln.y - lam.y, 0.0f), vsel(commit, ln.z - lam.z, 0.0f));
         lam = lam + dl;
@@ -1301,6 +1357,8 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
         if (!wave_any(unconverged)) break;
       }
     }
+    }
+#undef IRRL_COUPLING_ROW
   IRRL_MARK("contact_apply");
     lam.x = vsel(active, lam.x, 0.0f); lam.y = vsel(active, lam.y, 0.0f); lam.z = vsel(active, lam.z, 0.0f);
     // z = sum_legs sum_rows Y_r lam_r drives the base; the leg gets C^-1 Jl^T lam - D xb
@@ -1476,23 +1534,52 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     vi a0i = legs_bcast_i<0>(act_i), a1i = legs_bcast_i<1>(act_i), a2i = legs_bcast_i<2>(act_i);
     vi rank = vsel_i(leg == 0, 0, vsel_i(leg == 1, a0i, vsel_i(leg == 2, a0i + a1i, a0i + a1i + a2i)));
     int nrank = wave_max_small(legs_sum_i(act_i));
-    const bool jacobi = P.contact_jacobi != 0;   // ContactSolver 2: simultaneous updates (see the 16-lane instantiation)
-    if (jacobi) nrank = nrank > 0 ? 1 : 0;
+    const bool jacobi = P.contact_jacobi != 0;   // ContactSolver bit 1: simultaneous updates (see the 16-lane instantiation)
     const float tol2 = P.contact_tol * P.contact_tol;
+    // velocity at this contact from the OTHER legs' 3-vectors v (impulses, or their last change): Y_l (z - Y_l^T v_l), z = sum_legs
+    // Y_l^T v_l (G_{l,p} = Y_l Y_p^T).  One 6-vector reduction per solve instead of round 1's explicit partner blocks (4 x 9 x 6 FMAs
+    // + 72 broadcasts per substep): 90.2 us against 99.4 us per step at 32768 envs, same box.
+    auto coupling = [&](const v3 &v, v3 acc) {
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        const vf w = Y[0][i] * v.x + Y[1][i] * v.y + Y[2][i] * v.z;
+        const vf o = legs_sum(w) - w;
+        acc.x += Y[0][i] * o; acc.y += Y[1][i] * o; acc.z += Y[2][i] * o;
+      }
+      return acc;
+    };
+    if (jacobi) {
+      // one loop for both exit rules, contact-point velocity carried from sweep to sweep (see the 16-lane instantiation)
+      const bool predicted = P.contact_exit != 0;
+      v3 cv = coupling(lam, mk3(cfree[0], cfree[1], cfree[2]));
+      if (nrank > 0)
+      for (int it = 0; it < P.contact_iters; it++) {
+        v3 ln = RULE ? solve_contact_md(CM, cv, nB, vstar, L.m.mu, active) : solve_contact(CB, cv, nB, vstar, L.m.mu, active);
+        v3 dl = mk3(vsel(active, ln.x - lam.x, 0.0f), vsel(active, ln.y - lam.y, 0.0f), vsel(active, ln.z - lam.z, 0.0f));
+        lam = lam + dl;
+        if (it + 1 >= P.contact_iters) break;
+        vf l2 = 0.0f;
+        if (tol2 > 0.0f) {
+          l2 = legs_sum(vsel(active, dot(lam, lam), 0.0f));
+          if (!predicted) {
+            vm unconverged = legs_sum(dot(dl, dl)) > tol2 * l2 + 1e-20f;
+            if (!wave_any(unconverged)) break;
+          }
+        }
+        const v3 dc = coupling(dl, mk3(0.0f, 0.0f, 0.0f));
+        if (predicted && tol2 > 0.0f && !wave_any(legs_sum(dot(dl, dl)) > (1.0e4f * tol2) * l2 + 1e-20f)) {   // (see the 16-lane instantiation)
+          const vf p2 = RULE ? answer_norm2_md(CM, dc, nB) : answer_norm2(CB, dc);
+          vm unconverged = legs_sum(vsel(active, p2, 0.0f)) > tol2 * l2 + 1e-20f;
+          if (!wave_any(unconverged)) break;
+        }
+        cv = cv + dc;
+      }
+    } else {
     for (int it = 0; it < P.contact_iters; it++) {
       vf d2 = 0.0f;
       for (int rk = 0; rk < nrank; rk++) {
-        // velocity at this contact from the OTHER legs' impulses: Y_l (z - Y_l^T lam_l), z = sum_legs Y_l^T lam_l (G_{l,p} = Y_l
-        // Y_p^T).  One 6-vector reduction per solve instead of round 1's explicit partner blocks (4 x 9 x 6 FMAs + 72 broadcasts
-        // per substep): 90.2 us against 99.4 us per step at 32768 envs, same box.
-        v3 cv = mk3(cfree[0], cfree[1], cfree[2]);
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-          const vf w = Y[0][i] * lam.x + Y[1][i] * lam.y + Y[2][i] * lam.z;
-          const vf o = legs_sum(w) - w;
-          cv.x += Y[0][i] * o; cv.y += Y[1][i] * o; cv.z += Y[2][i] * o;
-        }
-        vm commit = jacobi ? active : (active & (rank == rk));
+        v3 cv = coupling(lam, mk3(cfree[0], cfree[1], cfree[2]));
+        vm commit = active & (rank == rk);
         v3 ln = RULE ? solve_contact_md(CM, cv, nB, vstar, L.m.mu, commit) : solve_contact(CB, cv, nB, vstar, L.m.mu, commit);
         v3 dl = mk3(vsel(commit, ln.x - lam.x, 0.0f), vsel(commit, ln.y - lam.y, 0.0f), vsel(commit, ln.z - lam.z, 0.0f));
         lam = lam + dl;
@@ -1504,6 +1591,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
         vm unconverged = legs_sum(d2) > tol2 * l2 + 1e-20f;
         if (!wave_any(unconverged)) break;
       }
+    }
     }
     // z = sum_l Y_l^T lam_l (6-vector shared by the quad) drives the base velocity update
     lam.x = vsel(active, lam.x, 0.0f); lam.y = vsel(active, lam.y, 0.0f); lam.z = vsel(active, lam.z, 0.0f);

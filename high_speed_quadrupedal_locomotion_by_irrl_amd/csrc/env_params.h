@@ -30,6 +30,9 @@ struct EnvParams {
   int32_t contact_jacobi;  // [ext] ContactSolver bit 1: set = all contacts of a robot update simultaneously in a sweep, clear = Gauss-Seidel FR, FL, HR, HL
   int32_t contact_rule;    // [ext] ContactSolver bit 0: set = the published per-contact rule of RaiSim's solver (maximum dissipation on the cone
                            //       boundary, Hwangbo et al. 2018), clear = the build's first sliding rule (along the sticking impulse)
+  int32_t contact_exit;    // [ext] ContactExit (simultaneous sweeps only): 1 = leave the sweep loop BEFORE a sweep whose change is predicted to be
+                           //       below ContactTolerance (the last change dlambda moves contact l's velocity by dc_l = sum_{p != l} G_lp dlambda_p,
+                           //       answered by -G_ll^-1 dc_l), 0 = after a sweep whose own change was (the confirming sweep of rounds 1-3)
   float clamp_r;           // tau_max / (w_max - w_crit)            (Environment.hpp:1279)
   float clamp_inv_den;     // 1 / (-w_max + w_crit)                 (Environment.hpp:1296-1297)
   // height field (Terrain: True, Environment.hpp:254-264); height == nullptr / terrain == 0 means the plane z = 0

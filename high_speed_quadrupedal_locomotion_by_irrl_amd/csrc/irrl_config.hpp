@@ -167,12 +167,17 @@ inline bool build_params(const Config &c, EnvParams &P, std::string &err) {
     if (solver < 0 || solver > 3) { err = "ContactSolver must be 0..3 (bit 1: simultaneous sweeps, bit 0: published per-contact rule)"; return false; }
     P.contact_jacobi = (solver & 2) ? 1 : 0;
     P.contact_rule = (solver & 1) ? 1 : 0;
+    // how ContactTolerance ends the simultaneous sweeps: 1 (default) = before a sweep whose change is PREDICTED to be below the
+    // tolerance, 0 = after a sweep whose own change was (rounds 1-3); Gauss-Seidel sweeps always use 0
+    const int ex = c.has("ContactExit") ? (int)num("ContactExit") : 1;
+    if (ex != 0 && ex != 1) { err = "ContactExit must be 0 (confirmed) or 1 (predicted)"; return false; }
+    P.contact_exit = (ex == 1 && P.contact_jacobi) ? 1 : 0;
   }
   // the build-defined contact keys are a closed set: a misspelt or unsupported one (e.g. a relaxation factor only some other
   // implementation knows) must not be ignored silently -- two engines would then solve different iterations
   for (const auto &it : c.kv)
     if (it.first.compare(0, 7, "Contact") == 0 && it.first != "ContactCoeff" && it.first != "ContactIterations" &&
-        it.first != "ContactTolerance" && it.first != "ContactSolver") { err = "unsupported build-defined key cfg[\"" + it.first + "\"]"; return false; }
+        it.first != "ContactTolerance" && it.first != "ContactSolver" && it.first != "ContactExit") { err = "unsupported build-defined key cfg[\"" + it.first + "\"]"; return false; }
   P.clamp_r = P.tau_max / (P.w_max - P.w_crit);
   P.clamp_inv_den = 1.0f / (-P.w_max + P.w_crit);
   P.shared_noise = c.has("SharedNoiseScalar") ? (int32_t)flag("SharedNoiseScalar") : 1;

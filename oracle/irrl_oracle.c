@@ -1166,6 +1166,7 @@ static void physics_substep(orc_env *h, env_t *e, const real *pTarget) {
   int group_of[4], n_groups;
   if (c->ContactSolver & 2) { for (int l = 0; l < 4; l++) group_of[l] = 0; n_groups = 1; }
   else { for (int l = 0; l < 4; l++) group_of[l] = l; n_groups = 4; }
+  real dlam[4][3] = {{RC(0)}};
   for (int it = 0; it < c->ContactIterations; it++) {
     real d2 = RC(0), l2 = RC(0);
     for (int g = 0; g < n_groups; g++) {
@@ -1186,13 +1187,32 @@ static void physics_substep(orc_env *h, env_t *e, const real *pTarget) {
         if (!active[l] || group_of[l] != g) continue;
         for (int a = 0; a < 3; a++) {
           real dd = newl[l][a] - lamB[l][a];
+          dlam[l][a] = dd;
           lamB[l][a] += dd;
           d2 += dd * dd; l2 += lamB[l][a] * lamB[l][a];
         }
       }
     }
     /* build-defined early exit (same rule in the kernels, evaluated per wave there) */
-    if (c->ContactTolerance > 0 && d2 <= RC(c->ContactTolerance * c->ContactTolerance) * l2 + RC(1e-20)) { it++; sweeps_done = it; goto gs_done; }
+    if (c->ContactTolerance > 0 && n_groups == 1 && c->ContactExit == 1) {
+      /* PREDICTED exit (orc_cfg::ContactExit): would the NEXT sweep still move the impulses by more than the tolerance?  Its change is
+       * estimated contact by contact from the velocity change this sweep's dlambda causes at the contact, answered linearly. */
+      if (it + 1 >= c->ContactIterations) { it++; sweeps_done = it; goto gs_done; }
+      real p2 = RC(0);
+      for (int l = 0; l < 4; l++) {
+        if (!active[l]) continue;
+        real dc[3] = {RC(0), RC(0), RC(0)}, ans[3];
+        for (int lb = 0; lb < 4; lb++) {
+          if (lb == l || !active[lb]) continue;
+          real t[3];
+          m3_mulv(t, G[l][lb], dlam[lb]);
+          v3_add(dc, dc, t);
+        }
+        m3_solve(G[l][l], dc, ans);
+        p2 += v3_dot(ans, ans);
+      }
+      if (p2 <= RC(c->ContactTolerance * c->ContactTolerance) * l2 + RC(1e-20)) { it++; sweeps_done = it; goto gs_done; }
+    } else if (c->ContactTolerance > 0 && d2 <= RC(c->ContactTolerance * c->ContactTolerance) * l2 + RC(1e-20)) { it++; sweeps_done = it; goto gs_done; }
   }
   sweeps_done = c->ContactIterations;
 gs_done:

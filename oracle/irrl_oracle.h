@@ -69,6 +69,13 @@ typedef struct orc_cfg {
                                  * impulse's tangential direction).  So 0 = GS + build rule, 1 = GS + published rule (the published method),
                                  * 2 = simultaneous + build rule, 3 = simultaneous + published rule (default of the shipped configs).
                                  * Trunk-box corners / meteorite: one pass of sequential impulses behind the toe iteration with the same rule. */
+  int32_t ContactExit;          /* how ContactTolerance ends the simultaneous sweeps (ContactSolver bit 1 set; Gauss-Seidel keeps rule 0):
+                                 * 0 = CONFIRMED: stop after a sweep whose OWN change was sum|dlambda|^2 <= tol^2 sum|lambda|^2 (rounds 1-3: the last
+                                 *     sweep of every substep only confirms what the one before it already reached);
+                                 * 1 = PREDICTED (default): stop BEFORE a sweep whose change is predicted to be that small -- the impulses' last
+                                 *     change dlambda moves contact l's velocity by dc_l = sum_{p != l} G_lp dlambda_p, to which a contact answers with
+                                 *     -G_ll^-1 dc_l (exactly, while it sticks; the cone only shortens the answer): stop once
+                                 *     sum_l |G_ll^-1 dc_l|^2 <= tol^2 sum|lambda|^2.  One solve less per substep for the same stated tolerance. */
 } orc_cfg;
 
 typedef struct orc_env orc_env; /* opaque vector-env handle */

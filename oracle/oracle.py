@@ -41,11 +41,11 @@ class OrcCfg(C.Structure):
         ("FPS", C.c_double), ("ActionNoise", C.c_double), ("ObsNoise", C.c_double), ("GaitType", C.c_int32),
         ("MotorMaxTorque", C.c_double), ("MotorCriticalSpeed", C.c_double), ("MotorMaxSpeed", C.c_double),
         ("ContactIterations", C.c_int32), ("SharedNoiseScalar", C.c_int32), ("RandomizePerEpisode", C.c_int32), ("EnvIdOffset", C.c_int32),
-        ("ContactTolerance", C.c_double), ("ContactSolver", C.c_int32),
+        ("ContactTolerance", C.c_double), ("ContactSolver", C.c_int32), ("ContactExit", C.c_int32),
     ]
 
 
-_EXT_DEFAULTS = {"ContactIterations": 6, "SharedNoiseScalar": 1, "RandomizePerEpisode": 0, "EnvIdOffset": 0, "ContactTolerance": 0.0, "ContactSolver": 3}
+_EXT_DEFAULTS = {"ContactIterations": 6, "SharedNoiseScalar": 1, "RandomizePerEpisode": 0, "EnvIdOffset": 0, "ContactTolerance": 0.0, "ContactSolver": 3, "ContactExit": 1}
 
 
 def cfg_from_dict(env_cfg):
@@ -53,7 +53,7 @@ def cfg_from_dict(env_cfg):
     ENV:1594-1659 / BASE:41-42)."""
     c = OrcCfg()
     for k in env_cfg:   # the build-defined contact keys are a closed set (same check as csrc/irrl_config.hpp)
-        if str(k).startswith("Contact") and k not in ("ContactCoeff", "ContactIterations", "ContactTolerance", "ContactSolver"):
+        if str(k).startswith("Contact") and k not in ("ContactCoeff", "ContactIterations", "ContactTolerance", "ContactSolver", "ContactExit"):
             raise KeyError("unsupported build-defined key cfg[%r]" % k)
     for name, ctype in OrcCfg._fields_:
         if name in env_cfg:

@@ -387,7 +387,7 @@ def test_every_contact_solver_matches_the_oracle_on_gpu(solver, lanes, monkeypat
     print("solver", solver, "lanes", lanes, worst)
     orc, cand = _pair(load_env_cfg("bp5_imitation.yaml", num_envs=32, ContactSolver=solver))
     h0 = orc.box_hits()
-    PL.check_teacher_forced(orc, cand, steps=30, seed=3, perturb=PL.tilt_onto_box_corner, max_factor=PL.CORNER_MAX_FACTOR)
+    PL.check_teacher_forced(orc, cand, steps=30, seed=3, perturb=PL.tilt_onto_box_corner, max_factor=PL.CORNER_MAX_FACTOR, cap_factor=PL.CORNER_CAP_FACTOR)
     assert orc.box_hits() - h0 > 32 * 30 * 4
     orc, cand = _pair(load_env_cfg("bp5_terrain.yaml", num_envs=32, ContactSolver=solver))
     PL.check_teacher_forced(orc, cand, steps=40, force_terminal_every=9, max_factor=PL.TERRAIN_MAX_FACTOR)
@@ -494,7 +494,7 @@ def test_trunk_box_corner_contacts_match_the_oracle_on_gpu(lanes, monkeypatch):
     orc, cand = _pair(load_env_cfg("bp5_imitation.yaml", num_envs=n))
     assert cand.impl.lanes_per_robot == lanes
     h0 = orc.box_hits()
-    worst, n_done = PL.check_teacher_forced(orc, cand, steps=40, seed=3, perturb=PL.tilt_onto_box_corner, max_factor=PL.CORNER_MAX_FACTOR)
+    worst, n_done = PL.check_teacher_forced(orc, cand, steps=40, seed=3, perturb=PL.tilt_onto_box_corner, max_factor=PL.CORNER_MAX_FACTOR, cap_factor=PL.CORNER_CAP_FACTOR)
     assert orc.box_hits() - h0 > n * 40 * 4 and n_done < n * 40 // 4
     print("box-corner teacher-forced worst errors (lanes %d):" % lanes, worst)
     orc, cand = _pair(load_env_cfg("bp5_terrain.yaml", num_envs=32))
@@ -523,7 +523,7 @@ def test_crutial_meteorite_matches_the_oracle_on_gpu(lanes, monkeypatch):
     PL.check_teacher_forced(orc, cand, steps=30, seed=2, force_terminal_every=11)       # crosses frame 125: park + release
     assert (orc.get_state()[:, k + 8] == 1).any()
     h0 = orc.sphere_hits()
-    worst, n_done = PL.check_teacher_forced(orc, cand, steps=40, seed=4, perturb=PL.drop_meteorite, max_factor=PL.CORNER_MAX_FACTOR)
+    worst, n_done = PL.check_teacher_forced(orc, cand, steps=40, seed=4, perturb=PL.drop_meteorite, max_factor=PL.CORNER_MAX_FACTOR, cap_factor=PL.CORNER_CAP_FACTOR)
     assert orc.sphere_hits() - h0 > 5 * n
     print("meteorite teacher-forced worst errors (lanes %d):" % lanes, worst)
     np.testing.assert_allclose(cand.sphere_info(), orc.sphere_info(), atol=2e-4)
@@ -574,8 +574,8 @@ def test_teacher_forced_at_the_benchmarked_pool_sizes(name, lanes, n, monkeypatc
     assert cand.impl.lanes_per_robot == lanes
     orc = _landed_oracle(cfg)
     rough = bool(cfg["Terrain"])
-    worst, n_done = PL.check_teacher_forced(orc, cand, steps=20, seed=4, force_terminal_every=3,
-                                            max_factor=PL.TERRAIN_MAX_FACTOR if rough else 10.0)
+    worst, n_done = PL.check_teacher_forced(orc, cand, steps=20, seed=4, force_terminal_every=3, cap_factor=PL.FULL_SIZE_CAP_FACTOR,
+                                            event_budget=PL.TERRAIN_EVENT_BUDGET if rough else 0.005)
     inc = orc.get_state()[:, PL.S["INCONTACT"]:PL.S["INCONTACT"] + 4]
     assert inc.sum() > n            # more than one foot on the ground per robot on average: the contact solve is what is compared
     assert n_done >= 6
@@ -622,6 +622,7 @@ def test_eight_shards_of_4096_are_the_32768_pool_bit_for_bit(name, monkeypatch):
     other = _hip(load_env_cfg(name, num_envs=n * k))
     assert other.impl.lanes_per_robot == 4
     rough = name == "bp5_terrain.yaml"
-    worst, _ = PL.check_teacher_forced(big, other, steps=10, seed=6, force_terminal_every=3, max_factor=PL.TERRAIN_MAX_FACTOR if rough else 10.0)
+    worst, _ = PL.check_teacher_forced(big, other, steps=10, seed=6, force_terminal_every=3, cap_factor=PL.FULL_SIZE_CAP_FACTOR,
+                                       event_budget=PL.TERRAIN_EVENT_BUDGET if rough else 0.005)
     assert worst["ob_p99"] < 1e-4 and worst["pos_p99"] < 1e-5      # two f32 evaluation orders: far inside the f32-vs-f64 tolerance
     print("32768-pool, 4-lane against 16-lane layout:", worst)
