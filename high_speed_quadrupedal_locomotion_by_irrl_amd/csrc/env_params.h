@@ -38,6 +38,10 @@ struct EnvParams {
   // height field (Terrain: True, Environment.hpp:254-264); height == nullptr / terrain == 0 means the plane z = 0
   int32_t terrain, hf_nx, hf_ny;
   float hf_x0, hf_y0, hf_inv_dx, hf_inv_dy;
+  // cell coordinate of world x: x * hf_inv_dx + hf_fx, plus hf_ix0 WHOLE cells added to the integer index (-x0 / dx = hf_ix0 + hf_fx, 0 <= hf_fx < 1);
+  // hf_xlo / hf_xhi: the table's edge in that shifted coordinate (irrl_host::derive_terrain_params)
+  int32_t hf_ix0, hf_iy0;
+  float hf_fx, hf_fy, hf_xlo, hf_xhi, hf_ylo, hf_yhi;
   float hf_max;            // highest sample of the height field (0 on the plane): pre-test of the trunk-box corner contacts
   const float *height;     // [hf_nx, hf_ny] row-major, shared by every robot of the pool
   // reference-trajectory mode (ManualTraj: False, Manual: False; Environment.hpp:17-21, 565-573, 972, 1100-1107, 1667-1671):

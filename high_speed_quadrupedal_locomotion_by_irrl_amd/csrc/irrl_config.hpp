@@ -194,6 +194,15 @@ inline bool build_params(const Config &c, EnvParams &P, std::string &err) {
   P.hf_nx = 5000; P.hf_ny = 500;  // Environment.hpp:259-260
   P.hf_x0 = -250.0f; P.hf_y0 = -10.0f; P.hf_max = 0.0f;
   P.hf_inv_dx = (float)((5000 - 1) / 500.0); P.hf_inv_dy = (float)((500 - 1) / 20.0);
+  {
+    // -x0 / dx split into whole cells and a fraction (env_core.hpp terrain_sample)
+    // (in double with the exact 1 / dx: the f32 rounding of hf_inv_dx then only multiplies |x| <~ 15 m, not the 250 m of the offset)
+    const double ox = -(double)P.hf_x0 * ((5000 - 1) / 500.0), oy = -(double)P.hf_y0 * ((500 - 1) / 20.0);
+    P.hf_ix0 = (int32_t)std::floor(ox); P.hf_iy0 = (int32_t)std::floor(oy);
+    P.hf_fx = (float)(ox - std::floor(ox)); P.hf_fy = (float)(oy - std::floor(oy));
+    P.hf_xlo = (float)(-(double)P.hf_ix0); P.hf_xhi = (float)((double)P.hf_nx - 1.001 - (double)P.hf_ix0);
+    P.hf_ylo = (float)(-(double)P.hf_iy0); P.hf_yhi = (float)((double)P.hf_ny - 1.001 - (double)P.hf_iy0);
+  }
   P.height = nullptr;
   P.ref_traj = (!manual_traj && !P.manual) ? 1 : 0;   // table attached by the owner of the pool (RefTraj CSV or irrl_env_set_ref_host)
   P.ref_rows = 0; P.ref = nullptr;

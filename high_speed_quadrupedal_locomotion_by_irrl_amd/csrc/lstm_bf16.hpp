@@ -1,0 +1,431 @@
+// lstm_bf16.hpp -- the persistent LSTM sequence kernels of the PPO2 update (run_bp_v5.py:143-176 network, ppo2.py:132-134 full-length
+// BPTT) on the bf16 matrix cores with COMPENSATED OPERAND SPLITS, f32 accumulation (round 4).
+//
+// Why: the exact-f32 kernels of lstm_kernels.hip issue v_mfma_f32_16x16x4_f32, which gfx950 runs at the vector rate -- 13.9 ns per
+// 16x16 tile and 4 units of K on a SIMD (3.48 ns per unit of K) -- while v_mfma_f32_16x16x32_bf16 takes 7.2 ns for 32 units of K
+// (0.226 ns per unit) and v_mfma_f32_16x16x16_bf16 7.3 ns for 16 (tools/microbench/mfma_bf16_rate.hip, profiles/r04_mfma_bf16_rate.log).
+// A float is split into NS bf16 planes x = p0 + p1 (+ p2) (each the round-to-nearest bf16 of what the planes before it left over:
+// the residuals are exact in f32), and a product of two split operands is the sum of the plane products whose weight is above
+// the target: NS = 2 -> p0 q0 + p0 q1 + p1 q0 (3 MFMAs, error ~2^-16 of the product), NS = 3 -> 6 MFMAs (~2^-24, the f32 level).
+// Per unit of K that is 0.68 / 1.36 ns against 3.48 ns.  Accumulation stays f32 inside the MFMA, small planes first.
+//
+// Mapping (HID = 48, n_in <= 48, the reference's network).  A workgroup owns 16 envs for all T steps.
+//   forward  (3 waves): wave w owns hidden units 16 w .. 16 w + 15 with their four gates; z_t = b + [h_{t-1} keep_t | x_t] [wh ; wx] is
+//            ONE contraction over K = 96 = 3 chunks of 32; the A operand ([env][k] bf16 planes, h written by its owners at the end of
+//            step t - 1, x_t staged by all lanes one step ahead) lives in a double-buffered LDS tile, the B fragments (weights,
+//            split once) stay in registers for the whole sequence.  36 (NS 2) / 72 (NS 3) MFMAs + the cell per wave and step, one
+//            workgroup barrier per step.
+//   backward (4 waves): waves 0-2 own 16 units each: gate arithmetic -> dz (4 envs x 4 gates per lane), which goes to LDS twice --
+//            [env][gate column] for the recurrence / dx products (K = the 192 gate columns: 6 chunks of 32; N-split: wave w
+//            produces dh_prev for ITS units and dx for input columns 16 w .. 16 w + 15, so no partial sums are exchanged) and
+//            [gate column][env] for the weight gradients (K = the 16 envs of the step: v_mfma_f32_16x16x16_bf16), next to
+//            (h_{t-1} keep_t)^T and x_t^T (staged by wave 3).  The 72 weight-gradient tiles (dwh 3 x 12, dwx 3 x 12) are shared out
+//            evenly: wave w' of the four accumulates gate-column tiles 3 w' .. 3 w' + 2 against all six M-tiles for all T steps.
+//            Double-buffered tiles, one barrier per step.  Per-workgroup partial gradients as in lstm_seq_bwd_x_kernel.
+#pragma once
+#include "policy_step.hpp"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
+
+LSTM_DEV unsigned short bf_bits(float x) { const __bf16 b = (__bf16)x; return __builtin_bit_cast(unsigned short, b); }   // v_cvt_pk_bf16_f32: round to nearest even
+LSTM_DEV float bf_val(unsigned short b) { return __builtin_bit_cast(float, (unsigned)b << 16); }
+template <int NS>
+LSTM_DEV void bf_split(float x, unsigned short (&p)[NS]) {
+  float r = x;
+#pragma unroll
+  for (int i = 0; i < NS; i++) { p[i] = bf_bits(r); r -= bf_val(p[i]); }   // the residual of a round-to-nearest bf16 is exact in f32
+}
+// plane products kept, smallest weight first: NS 2: (0,1) (1,0) (0,0); NS 3: (1,1) (0,2) (2,0) (0,1) (1,0) (0,0)
+template <int NS> struct BfProducts;
+template <> struct BfProducts<2> { static constexpr int N = 3; static constexpr int A[3] = {0, 1, 0}; static constexpr int B[3] = {1, 0, 0}; };
+template <> struct BfProducts<3> { static constexpr int N = 6; static constexpr int A[6] = {1, 0, 2, 0, 1, 0}; static constexpr int B[6] = {1, 2, 0, 1, 0, 0}; };
+#define BF_MFMA32(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a_), __builtin_bit_cast(bf16x8_t, b_), c_, 0, 0, 0)
+#define BF_MFMA16(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, a_), __builtin_bit_cast(s16x4_t, b_), c_, 0, 0, 0)
+
+// ---- forward ---------------------------------------------------------------------------------------------------------------------
+struct LstmFwdBf16Args {
+  const float *x, *wx_p, *b_p, *wh_p, *masks, *state0;
+  float *gates, *cseq, *hseq, *state_out;
+  int T, N, n_in;
+};
+constexpr int LBF_HID = 48, LBF_KX = 48, LBF_KF = LBF_HID + LBF_KX;   // forward contraction: [h | x], 96 = 3 chunks of 32
+constexpr int LBF_FROW = LBF_KF + 8;                                    // padded A-tile row (bf16 elements; 208 bytes: 16-byte aligned)
+template <int NS> constexpr int lstm_fwd_bf16_lds_bytes() { return 2 * NS * 16 * LBF_FROW * 2; }
+
+template <int NS>
+__global__ void __launch_bounds__(192)
+lstm_seq_fwd_bf16_kernel(const LstmFwdBf16Args a) {
+  constexpr int HID = LBF_HID, KC = LBF_KF / 32;
+  using PR = BfProducts<NS>;
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds_f[];
+  // At(buf, plane, env, k)
+  auto At = [&](int buf, int p, int env, int k) -> unsigned short * { return lds_f + (((size_t)(buf * NS + p) * 16 + env) * LBF_FROW + k); };
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  const int col = l & 15, rq = l >> 4;
+  const int e0 = blockIdx.x * 16;
+  const int u = 16 * w + col;
+  const int T = a.T, N = a.N, n_in = a.n_in;
+  // B fragments: B[k = 32 kc + 8 rq + i][column = unit u, gate g]; k < 48: wh_p[k][u][g], else wx_p[k - 48][u][g] (0 beyond n_in)
+  u16x8_t Bf[KC][4][NS];
+#pragma unroll
+  for (int kc = 0; kc < KC; kc++)
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const int k = 32 * kc + 8 * rq + i;
+        float v;
+        if (k < HID) v = a.wh_p[((size_t)k * HID + u) * 4 + g];
+        else v = (k - HID < n_in) ? a.wx_p[((size_t)(k - HID) * HID + u) * 4 + g] : 0.0f;
+        unsigned short pl[NS];
+        bf_split<NS>(v, pl);
+#pragma unroll
+        for (int p = 0; p < NS; p++) Bf[kc][g][p][i] = pl[p];
+      }
+  const f32x4 bias = *(const f32x4 *)&a.b_p[u * 4];
+  // x staging: the workgroup's 192 lanes cover 16 envs x 12 groups of 4 input elements
+  const int xe = tid / 12, xg = tid % 12;
+  auto load_x = [&](int t, float (&dst)[4]) {
+    const float *row = a.x + ((size_t)t * N + e0 + xe) * n_in;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const int k = 4 * xg + i; dst[i] = row[k < n_in ? k : n_in - 1]; }
+  };
+  auto stage_x = [&](int buf, const float (&src)[4]) {
+    u16x4_t pk[NS];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      unsigned short pl[NS];
+      bf_split<NS>((4 * xg + i < n_in) ? src[i] : 0.0f, pl);
+#pragma unroll
+      for (int p = 0; p < NS; p++) pk[p][i] = pl[p];
+    }
+#pragma unroll
+    for (int p = 0; p < NS; p++) *(u16x4_t *)At(buf, p, xe, HID + 4 * xg) = pk[p];
+  };
+  auto stage_h = [&](int buf, const float (&h)[4], const float (&keep)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      unsigned short pl[NS];
+      bf_split<NS>(h[j] * keep[j], pl);
+#pragma unroll
+      for (int p = 0; p < NS; p++) *At(buf, p, 4 * rq + j, u) = pl[p];
+    }
+  };
+  float c[4], hlast[4], mk_cur[4], mk_nxt[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int e = e0 + 4 * rq + j;
+    c[j] = a.state0[(size_t)e * 2 * HID + u];
+    hlast[j] = a.state0[(size_t)e * 2 * HID + HID + u];
+    mk_cur[j] = a.masks[e];
+  }
+  {
+    float keep0[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) keep0[j] = 1.0f - mk_cur[j];
+    stage_h(0, hlast, keep0);
+  }
+  float xa[4], xb[4];
+  load_x(0, xa);
+  stage_x(0, xa);
+  if (T > 1) load_x(1, xa);          // x_1, staged during step 0
+  if (T > 2) load_x(2, xb);          // x_2, staged during step 1
+#pragma unroll
+  for (int j = 0; j < 4; j++) mk_nxt[j] = a.masks[(size_t)(T > 1 ? 1 : 0) * N + e0 + 4 * rq + j];
+  __syncthreads();
+  // one step; xs: the registers holding x_{t+1} (loaded two steps ago), refilled with x_{t+3}
+  auto step = [&](int t, float (&xs)[4]) {
+    const int buf = t & 1;
+    u16x8_t av[KC][NS];
+#pragma unroll
+    for (int kc = 0; kc < KC; kc++)
+#pragma unroll
+      for (int p = 0; p < NS; p++) av[kc][p] = *(const u16x8_t *)At(buf, p, col, 32 * kc + 8 * rq);
+    // inputs of the following steps
+    if (t + 1 < T) stage_x(buf ^ 1, xs);
+    if (t + 3 < T) load_x(t + 3, xs);
+    float mk_nn[4];
+    const int t2 = (t + 2 < T) ? t + 2 : T - 1;
+#pragma unroll
+    for (int j = 0; j < 4; j++) mk_nn[j] = a.masks[(size_t)t2 * N + e0 + 4 * rq + j];
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) acc[g] = (f32x4){bias[g], bias[g], bias[g], bias[g]};
+#pragma unroll
+    for (int kc = KC - 1; kc >= 0; kc--)      // the x chunks first: they do not depend on the h the other waves have just published
+#pragma unroll
+      for (int q = 0; q < PR::N; q++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) acc[g] = BF_MFMA32(av[kc][PR::A[q]], Bf[kc][g][PR::B[q]], acc[g]);
+    float keepn[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float keepC = 1.0f - mk_cur[j];
+      const float ig = fast_sigmoid(acc[0][j]), fg = fast_sigmoid(acc[1][j]), og = fast_sigmoid(acc[2][j]), gg = fast_tanh(acc[3][j]);
+      const float cn = fg * (c[j] * keepC) + ig * gg;
+      const float hn = og * fast_tanh(cn);
+      c[j] = cn;
+      hlast[j] = hn;
+      const size_t row = (size_t)t * N + e0 + 4 * rq + j;
+      *(f32x4 *)&a.gates[(row * HID + u) * 4] = (f32x4){ig, fg, og, gg};
+      a.cseq[row * HID + u] = cn;
+      a.hseq[row * HID + u] = hn;
+      keepn[j] = 1.0f - mk_nxt[j];
+    }
+    if (t + 1 < T) stage_h(buf ^ 1, hlast, keepn);
+#pragma unroll
+    for (int j = 0; j < 4; j++) { mk_cur[j] = mk_nxt[j]; mk_nxt[j] = mk_nn[j]; }
+    __syncthreads();
+  };
+  for (int t = 0; t < T; t += 2) {
+    step(t, xa);
+    if (t + 1 < T) step(t + 1, xb);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int e = e0 + 4 * rq + j;
+    a.state_out[(size_t)e * 2 * HID + u] = c[j];
+    a.state_out[(size_t)e * 2 * HID + HID + u] = hlast[j];
+  }
+}
+
+// ---- backward --------------------------------------------------------------------------------------------------------------------
+struct LstmBwdBf16Args {
+  const float *gates, *cseq, *hseq, *x, *masks, *state0, *dh_in, *wh_p, *wx_p;
+  float *dx, *dwx_part, *dwh_part, *db_part;
+  int T, N, n_in;
+};
+constexpr int LBF_GC = 4 * LBF_HID;         // gate columns
+constexpr int LBF_RROW = LBF_GC + 8;        // dz tile [env][gate column]: padded row, 400 bytes (16-byte aligned)
+constexpr int LBF_CROW = 16 + 4;            // [gate column | unit | input][env]: padded row, 40 bytes (8-byte aligned)
+template <int NS> constexpr int lstm_bwd_bf16_lds_elems_per_buf() { return NS * (16 * LBF_RROW + LBF_GC * LBF_CROW + LBF_HID * LBF_CROW + LBF_KX * LBF_CROW); }
+template <int NS> constexpr int lstm_bwd_bf16_lds_bytes() { return 2 * lstm_bwd_bf16_lds_elems_per_buf<NS>() * 2; }
+
+template <int NS, bool NEED_DX>
+__global__ void __launch_bounds__(256)
+lstm_seq_bwd_bf16_kernel(const LstmBwdBf16Args a) {
+  constexpr int HID = LBF_HID, GC = LBF_GC, KX = LBF_KX, KC = GC / 32;
+  constexpr int DEPTH = (NS == 2) ? 3 : (NEED_DX ? 1 : 2);    // steps of operand loads in flight (36 registers per step; NS 3 has fewer to spare)
+  using PR = BfProducts<NS>;
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds_b[];
+  constexpr int PER_BUF = lstm_bwd_bf16_lds_elems_per_buf<NS>();
+  constexpr int OFF_C = NS * 16 * LBF_RROW, OFF_H = OFF_C + NS * GC * LBF_CROW, OFF_X = OFF_H + NS * HID * LBF_CROW;
+  auto Zr = [&](int buf, int p, int env, int c) -> unsigned short * { return lds_b + (size_t)buf * PER_BUF + ((size_t)p * 16 + env) * LBF_RROW + c; };
+  auto Zc = [&](int buf, int p, int c, int env) -> unsigned short * { return lds_b + (size_t)buf * PER_BUF + OFF_C + ((size_t)p * GC + c) * LBF_CROW + env; };
+  auto Ht = [&](int buf, int p, int k, int env) -> unsigned short * { return lds_b + (size_t)buf * PER_BUF + OFF_H + ((size_t)p * HID + k) * LBF_CROW + env; };
+  auto Xt = [&](int buf, int p, int i, int env) -> unsigned short * { return lds_b + (size_t)buf * PER_BUF + OFF_X + ((size_t)p * KX + i) * LBF_CROW + env; };
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  const int col = l & 15, rq = l >> 4;
+  const int e0 = blockIdx.x * 16;
+  const int T = a.T, N = a.N, n_in = a.n_in;
+  const bool main_wave = w < 3;
+  const int u = 16 * (main_wave ? w : 0) + col;
+  // weight-gradient accumulators of this wave: M-tile mt (0-2: hidden rows of dwh, 3-5: input rows of dwx) x gate-column tile 3 w + ci
+  f32x4 accW[6][3];
+#pragma unroll
+  for (int mt = 0; mt < 6; mt++)
+#pragma unroll
+    for (int ci = 0; ci < 3; ci++) accW[mt][ci] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+  auto weight_grads = [&](int buf) {
+    u16x4_t bz[3][NS], am[6][NS];
+#pragma unroll
+    for (int p = 0; p < NS; p++) {
+#pragma unroll
+      for (int ci = 0; ci < 3; ci++) bz[ci][p] = *(const u16x4_t *)Zc(buf, p, 16 * (3 * w + ci) + col, 4 * rq);
+#pragma unroll
+      for (int mt = 0; mt < 3; mt++) {
+        am[mt][p] = *(const u16x4_t *)Ht(buf, p, 16 * mt + col, 4 * rq);
+        am[3 + mt][p] = *(const u16x4_t *)Xt(buf, p, 16 * mt + col, 4 * rq);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < PR::N; q++)
+#pragma unroll
+      for (int mt = 0; mt < 6; mt++)
+#pragma unroll
+        for (int ci = 0; ci < 3; ci++) accW[mt][ci] = BF_MFMA16(am[mt][PR::A[q]], bz[ci][PR::B[q]], accW[mt][ci]);
+  };
+  auto store_weight_grads = [&]() {
+    const size_t blk = blockIdx.x;
+#pragma unroll
+    for (int ci = 0; ci < 3; ci++) {
+      const int cc = 16 * (3 * w + ci) + col;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int mt = 0; mt < 3; mt++) {
+          a.dwh_part[(blk * HID + 16 * mt + 4 * rq + r) * GC + cc] = accW[mt][ci][r];
+          const int i = 16 * mt + 4 * rq + r;
+          if (i < n_in) a.dwx_part[(blk * n_in + i) * GC + cc] = accW[3 + mt][ci][r];
+        }
+      }
+    }
+  };
+  if (!main_wave) {
+    // ---- wave 3: stages x_t^T for the weight gradients (coalesced row reads, two steps ahead) and takes its share of them ----
+    float xr[DEPTH + 1][12];
+    auto load_x = [&](int t, float (&dst)[12]) {
+#pragma unroll
+      for (int r = 0; r < 12; r++) {
+        const int idx = 64 * r + l, env = idx / KX, i = idx % KX;
+        dst[r] = a.x[((size_t)t * N + e0 + env) * n_in + (i < n_in ? i : n_in - 1)];
+      }
+    };
+    auto stage_x = [&](int buf, const float (&src)[12]) {
+#pragma unroll
+      for (int r = 0; r < 12; r++) {
+        const int idx = 64 * r + l, env = idx / KX, i = idx % KX;
+        unsigned short pl[NS];
+        bf_split<NS>(i < n_in ? src[r] : 0.0f, pl);
+#pragma unroll
+        for (int p = 0; p < NS; p++) *Xt(buf, p, i, env) = pl[p];
+      }
+    };
+    constexpr int HD = DEPTH + 1;
+#pragma unroll
+    for (int d = 0; d < HD; d++)
+      if (T - 1 - d >= 0) load_x(T - 1 - d, xr[d]);
+    for (int t = T - 1; t >= 0; t -= HD) {
+#pragma unroll
+      for (int d = 0; d < HD; d++) {
+        const int tt = t - d;
+        if (tt < 0) break;
+        stage_x(tt & 1, xr[d]);
+        if (tt - HD >= 0) load_x(tt - HD, xr[d]);
+        __syncthreads();
+        weight_grads(tt & 1);
+      }
+    }
+    store_weight_grads();
+    return;
+  }
+  // ---- waves 0-2 ----
+  // B fragments over K = gate column c = 32 kc + 8 rq + i: dh_prev[env][hidden k' = 16 w + col] = sum_c dz[env][c] wh[k'][c],
+  // dx[env][input i' = 16 w + col] = sum_c dz[env][c] wx[i'][c]  (rows of the permuted weight matrices are contiguous in c)
+  u16x8_t Bh[KC][NS], Bx[NEED_DX ? KC : 1][NS];
+#pragma unroll
+  for (int kc = 0; kc < KC; kc++)
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int cidx = 32 * kc + 8 * rq + i;
+      unsigned short pl[NS];
+      bf_split<NS>(a.wh_p[(size_t)u * GC + cidx], pl);
+#pragma unroll
+      for (int p = 0; p < NS; p++) Bh[kc][p][i] = pl[p];
+      if (NEED_DX) {
+        bf_split<NS>((u < n_in) ? a.wx_p[(size_t)u * GC + cidx] : 0.0f, pl);
+#pragma unroll
+        for (int p = 0; p < NS; p++) Bx[kc][p][i] = pl[p];
+      }
+    }
+  float dbacc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  float dc[4] = {0.0f, 0.0f, 0.0f, 0.0f}, dhrec[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  // The operands of a step are requested DEPTH steps ahead (DEPTH register sets used in turn).  A step of this kernel is ~2 us of
+  // arithmetic, less than the latency of its 24 KB of loads under a fully loaded memory system (the rows of consecutive steps are 3 MB
+  // apart in each of six arrays): with one step in flight the kernel ran at that latency -- 5.4 us per step, 1.4 TB/s (round 4, first
+  // version) -- not at its arithmetic.
+  struct StepOps { f32x4 g[4]; float ct[4], cp[4], dh[4], mk[4], hp[4]; };
+  auto fetch = [&](int t, StepOps &o) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int e = e0 + 4 * rq + j;
+      const size_t row = (size_t)t * N + e;
+      o.mk[j] = a.masks[row];
+      o.g[j] = *(const f32x4 *)&a.gates[(row * HID + u) * 4];
+      o.ct[j] = a.cseq[row * HID + u];
+      o.cp[j] = (t > 0) ? a.cseq[(row - N) * HID + u] : a.state0[(size_t)e * 2 * HID + u];
+      o.hp[j] = (t > 0) ? a.hseq[(row - N) * HID + u] : a.state0[(size_t)e * 2 * HID + HID + u];
+      o.dh[j] = a.dh_in[row * HID + u];
+    }
+  };
+  auto step = [&](int t, StepOps &o) {
+    const int buf = t & 1;
+    float keepC[4], ct[4], cpv[4], dhv[4], hpv[4];
+    f32x4 g4[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { keepC[j] = 1.0f - o.mk[j]; g4[j] = o.g[j]; ct[j] = o.ct[j]; cpv[j] = o.cp[j]; dhv[j] = o.dh[j]; hpv[j] = o.hp[j] * keepC[j]; }
+    if (t - DEPTH >= 0) fetch(t - DEPTH, o);
+    // (h_{t-1} keep_t)^T for the weight gradients: Ht[plane][unit u][env 4 rq .. 4 rq + 3]
+    {
+      u16x4_t pk[NS];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        unsigned short pl[NS];
+        bf_split<NS>(hpv[j], pl);
+#pragma unroll
+        for (int p = 0; p < NS; p++) pk[p][j] = pl[p];
+      }
+#pragma unroll
+      for (int p = 0; p < NS; p++) *(u16x4_t *)Ht(buf, p, u, 4 * rq) = pk[p];
+    }
+    // gate arithmetic -> dz (env 4 rq + j, unit u, gates i f o g), both LDS layouts
+    u16x4_t zc[4][NS];     // [gate][plane]: the four envs of this lane
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float cprev = cpv[j] * keepC[j];
+      const float dh = dhv[j] + dhrec[j];
+      const float ig = g4[j][0], fg = g4[j][1], og = g4[j][2], gg = g4[j][3];
+      const float tc = fast_tanh(ct[j]);
+      const float d_o = dh * tc;
+      const float dct = dc[j] + dh * og * (1.0f - tc * tc);
+      const float d_i = dct * gg, d_g = dct * ig, d_f = dct * cprev;
+      dc[j] = dct * fg * keepC[j];
+      const float dz4[4] = {d_i * ig * (1.0f - ig), d_f * fg * (1.0f - fg), d_o * og * (1.0f - og), d_g * (1.0f - gg * gg)};
+      u16x4_t zr[NS];
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        dbacc[g] += dz4[g];
+        unsigned short pl[NS];
+        bf_split<NS>(dz4[g], pl);
+#pragma unroll
+        for (int p = 0; p < NS; p++) { zr[p][g] = pl[p]; zc[g][p][j] = pl[p]; }
+      }
+#pragma unroll
+      for (int p = 0; p < NS; p++) *(u16x4_t *)Zr(buf, p, 4 * rq + j, 4 * u) = zr[p];
+    }
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+      for (int p = 0; p < NS; p++) *(u16x4_t *)Zc(buf, p, 4 * u + g, 4 * rq) = zc[g][p];
+    __syncthreads();      // dz_t, (h_{t-1} keep_t)^T and x_t^T of every wave are visible
+    // recurrence (+ dx): A[env = col][k = gate column]
+    u16x8_t av[KC][NS];
+#pragma unroll
+    for (int kc = 0; kc < KC; kc++)
+#pragma unroll
+      for (int p = 0; p < NS; p++) av[kc][p] = *(const u16x8_t *)Zr(buf, p, col, 32 * kc + 8 * rq);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}, accx = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int q = 0; q < PR::N; q++)
+#pragma unroll
+      for (int kc = 0; kc < KC; kc++) {
+        acc = BF_MFMA32(av[kc][PR::A[q]], Bh[kc][PR::B[q]], acc);
+        if (NEED_DX) accx = BF_MFMA32(av[kc][PR::A[q]], Bx[kc][PR::B[q]], accx);
+      }
+#pragma unroll
+    for (int j = 0; j < 4; j++) dhrec[j] = acc[j] * keepC[j];
+    if (NEED_DX && u < n_in) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) a.dx[((size_t)t * N + e0 + 4 * rq + j) * n_in + u] = accx[j];
+    }
+    weight_grads(buf);
+  };
+  StepOps ops[DEPTH];
+#pragma unroll
+  for (int d = 0; d < DEPTH; d++)
+    if (T - 1 - d >= 0) fetch(T - 1 - d, ops[d]);
+  for (int t = T - 1; t >= 0; t -= DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++)
+      if (t - d >= 0) step(t - d, ops[d]);
+  }
+  store_weight_grads();
+  const size_t blk = blockIdx.x;
+#pragma unroll
+  for (int g = 0; g < 4; g++) a.db_part[(blk * 4 + rq) * GC + u * 4 + g] = dbacc[g];
+}

@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include "policy_step.hpp"   // f32x4, LSTM_DEV, fast_sigmoid / fast_tanh, the rollout step of the LSTM policy
+#include "lstm_bf16.hpp"     // the sequence kernels on the bf16 matrix cores with compensated operand splits (round 4)
 
 template <int HID>
 __global__ void __launch_bounds__(HID / 16 * 64)
@@ -1316,6 +1317,55 @@ int irrl_mlp_policy_step(int hid, int ob_dim, int act_dim, int N, const float *o
   a.rng_step = rng_step; a.rng_seed = rng_seed; a.rng_on = rng_on; a.env_id_offset = (unsigned)env_id_offset;
   a.N = N; a.ob_dim = ob_dim; a.act_dim = act_dim;
   hipLaunchKernelGGL((mlp_policy_step_kernel<64>), dim3((N + 15) / 16), dim3(256), 0, (hipStream_t)hip_stream, a);
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+// ---- the sequence kernels on the bf16 matrix cores with compensated operand splits (csrc/lstm_bf16.hpp) ----
+// nsplit 2: three plane products per product (~2^-16 relative), 3: six (~2^-24, the f32 level).  Same tensors as the *_x entry points.
+// returns 0 on success; 1 = unsupported shape, 2 = launch error
+static int lstm_bf16_allow_lds(const void *kernel, int bytes) {
+  // the tiles exceed the 64 KB a kernel gets without asking (gfx950 has 160 KB per CU)
+  return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 0 : 2;
+}
+int irrl_lstm_seq_forward_bf16(int nsplit, int hid, int T, int N, int n_in, const float *x, const float *wx_p, const float *b_p, const float *wh_p,
+                               const float *masks, const float *state0, float *gates, float *cseq, float *hseq, float *state_out, void *hip_stream) {
+  if (N <= 0 || T <= 0 || (N % 16) != 0 || n_in <= 0 || n_in > LBF_KX || hid != LBF_HID || (nsplit != 2 && nsplit != 3)) return 1;
+  LstmFwdBf16Args a;
+  a.x = x; a.wx_p = wx_p; a.b_p = b_p; a.wh_p = wh_p; a.masks = masks; a.state0 = state0;
+  a.gates = gates; a.cseq = cseq; a.hseq = hseq; a.state_out = state_out; a.T = T; a.N = N; a.n_in = n_in;
+  hipStream_t s = (hipStream_t)hip_stream;
+  if (nsplit == 2) {
+    constexpr int bytes = lstm_fwd_bf16_lds_bytes<2>();
+    hipLaunchKernelGGL(lstm_seq_fwd_bf16_kernel<2>, dim3(N / 16), dim3(192), bytes, s, a);
+  } else {
+    constexpr int bytes = lstm_fwd_bf16_lds_bytes<3>();
+    hipLaunchKernelGGL(lstm_seq_fwd_bf16_kernel<3>, dim3(N / 16), dim3(192), bytes, s, a);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+int irrl_lstm_seq_backward_bf16(int nsplit, int hid, int T, int N, int n_in, const float *gates, const float *cseq, const float *hseq, const float *x,
+                                const float *masks, const float *state0, const float *dh_in, const float *wh_p, const float *wx_p, float *dx,
+                                float *dwx_part, float *dwh_part, float *db_part, void *hip_stream) {
+  if (N <= 0 || T <= 0 || (N % 16) != 0 || n_in <= 0 || n_in > LBF_KX || hid != LBF_HID || (nsplit != 2 && nsplit != 3)) return 1;
+  LstmBwdBf16Args a;
+  a.gates = gates; a.cseq = cseq; a.hseq = hseq; a.x = x; a.masks = masks; a.state0 = state0; a.dh_in = dh_in; a.wh_p = wh_p; a.wx_p = wx_p;
+  a.dx = dx; a.dwx_part = dwx_part; a.dwh_part = dwh_part; a.db_part = db_part; a.T = T; a.N = N; a.n_in = n_in;
+  hipStream_t s = (hipStream_t)hip_stream;
+  static int allowed = -1;
+  if (allowed < 0) {
+    allowed = lstm_bf16_allow_lds((const void *)lstm_seq_bwd_bf16_kernel<2, true>, lstm_bwd_bf16_lds_bytes<2>()) |
+              lstm_bf16_allow_lds((const void *)lstm_seq_bwd_bf16_kernel<2, false>, lstm_bwd_bf16_lds_bytes<2>()) |
+              lstm_bf16_allow_lds((const void *)lstm_seq_bwd_bf16_kernel<3, true>, lstm_bwd_bf16_lds_bytes<3>()) |
+              lstm_bf16_allow_lds((const void *)lstm_seq_bwd_bf16_kernel<3, false>, lstm_bwd_bf16_lds_bytes<3>());
+  }
+  if (allowed != 0) return 2;
+#define IRRL_BB(NS, D) hipLaunchKernelGGL((lstm_seq_bwd_bf16_kernel<NS, D>), dim3(N / 16), dim3(256), lstm_bwd_bf16_lds_bytes<NS>(), s, a)
+  if (nsplit == 2 && dx) IRRL_BB(2, true);
+  else if (nsplit == 2) IRRL_BB(2, false);
+  else if (dx) IRRL_BB(3, true);
+  else IRRL_BB(3, false);
+#undef IRRL_BB
   return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 

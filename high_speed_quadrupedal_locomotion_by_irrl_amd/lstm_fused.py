@@ -8,6 +8,7 @@ backward: `irrl_lstm_seq_backward` walks the sequence in reverse and emits dz [T
 Semantics = stable-baselines `lstm` (policies.SBLstm.sequence is the eager definition the tests compare with).
 """
 import ctypes as C
+import os
 import weakref
 
 import torch
@@ -17,6 +18,16 @@ from . import _lib
 _PERM_CACHE = {}
 FUSE_WEIGHT_GRADIENTS = True   # backward: dx / dwx / dwh / db inside the sequence kernel
 FUSE_INPUT_PROJECTION = True   # module switch (benchmarks / tests compare the two forward kernels)
+# Arithmetic of the two sequence kernels of the UPDATE (hid 48, n_in <= 48; the rollout's policy step always runs the exact-f32 MFMA):
+#   "bf16x3"  bf16 matrix cores, every operand split into 2 bf16 planes, 3 plane products per product (~2^-16 relative), f32 accumulation.
+#             DEFAULT since round 4: PPO update 158 -> 109 ms at 4096 x 750; weight gradients within 6e-6 / 8e-6 of float64 autograd
+#             (the eager f32 graph: 1.6e-5, the exact-f32 kernels: 2e-6), h and dx within 1e-5 (exact-f32 kernels: 4e-7)
+#             -- profiles/r04_lstm_precision_error_and_time.log
+#   "bf16x6"  3 planes, 6 plane products (~2^-24): every output within ~2x of the exact-f32 kernels' error, update 147 ms
+#   "f32"     v_mfma_f32_16x16x4_f32, bitwise an fmaf chain (rounds 1-3), update 158 ms
+# (csrc/lstm_bf16.hpp; IRRL_LSTM_PRECISION overrides the default)
+PRECISION = os.environ.get("IRRL_LSTM_PRECISION", "bf16x3")
+_NSPLIT = {"bf16x3": 2, "bf16x6": 3}
 
 
 def _perm(hid, device):
@@ -128,7 +139,12 @@ class _LstmSeqFn(torch.autograd.Function):
         hseq = torch.empty(T, Np, hid, device=x.device, dtype=torch.float32)
         state_out = torch.empty(Np, 2 * hid, device=x.device, dtype=torch.float32)
         stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        if n_in <= 48 and FUSE_INPUT_PROJECTION:
+        nsplit = _NSPLIT.get(PRECISION, 0) if (hid == 48 and n_in <= 48 and FUSE_INPUT_PROJECTION and FUSE_WEIGHT_GRADIENTS) else 0
+        ctx.nsplit = nsplit
+        if nsplit:
+            rc = lib.irrl_lstm_seq_forward_bf16(nsplit, hid, T, Np, n_in, _ptr(x_k), _ptr(wx_p), _ptr(b_p), _ptr(wh_p), _ptr(masks_k), _ptr(state0_k),
+                                                _ptr(gates), _ptr(cseq), _ptr(hseq), _ptr(state_out), stream)
+        elif n_in <= 48 and FUSE_INPUT_PROJECTION:
             # x wx + b inside the sequence kernel: no [T*N, 4H] zx round trip through HBM
             rc = lib.irrl_lstm_seq_forward_x(hid, T, Np, n_in, _ptr(x_k), _ptr(wx_p), _ptr(b_p), _ptr(wh_p), _ptr(masks_k), _ptr(state0_k),
                                              _ptr(gates), _ptr(cseq), _ptr(hseq), _ptr(state_out), stream)
@@ -164,9 +180,14 @@ class _LstmSeqFn(torch.autograd.Function):
             dwx_part = torch.empty(nb, n_in, 4 * hid, device=dev, dtype=torch.float32)
             dwh_part = torch.empty(nb, hid, 4 * hid, device=dev, dtype=torch.float32)
             db_part = torch.empty(nb * 4, 4 * hid, device=dev, dtype=torch.float32)
-            rc = lib.irrl_lstm_seq_backward_x(hid, T, Np, n_in, _ptr(gates), _ptr(cseq), _ptr(hseq), _ptr(x_k), _ptr(masks_k), _ptr(state0_k),
-                                              _ptr(dh_seq), _ptr(wh_p), _ptr(wx_p), _ptr(dx_k) if dx_k is not None else None,
-                                              _ptr(dwx_part), _ptr(dwh_part), _ptr(db_part), stream)
+            if getattr(ctx, "nsplit", 0):
+                rc = lib.irrl_lstm_seq_backward_bf16(ctx.nsplit, hid, T, Np, n_in, _ptr(gates), _ptr(cseq), _ptr(hseq), _ptr(x_k), _ptr(masks_k), _ptr(state0_k),
+                                                     _ptr(dh_seq), _ptr(wh_p), _ptr(wx_p), _ptr(dx_k) if dx_k is not None else None,
+                                                     _ptr(dwx_part), _ptr(dwh_part), _ptr(db_part), stream)
+            else:
+                rc = lib.irrl_lstm_seq_backward_x(hid, T, Np, n_in, _ptr(gates), _ptr(cseq), _ptr(hseq), _ptr(x_k), _ptr(masks_k), _ptr(state0_k),
+                                                  _ptr(dh_seq), _ptr(wh_p), _ptr(wx_p), _ptr(dx_k) if dx_k is not None else None,
+                                                  _ptr(dwx_part), _ptr(dwh_part), _ptr(db_part), stream)
             if rc != 0:
                 raise RuntimeError("irrl_lstm_seq_backward_x failed (rc=%d)" % rc)
             # workgroup rows added in one fixed order, gate columns back in the reference's order (the library's reduction over the
