@@ -361,6 +361,34 @@ def worker(args):
         per_call = {"value": float(n) * args.steps / per_call_s, "unit": "env-steps/s", "us_per_step": 1e6 * per_call_s / args.steps,
                     "what": "%d steps, one FlexibleGymEnv.step() call per step on device tensors (the reference-shaped call surface)" % args.steps}
 
+    # ... and through the COMPILED boundary (native/_flexible_robot: the pybind11 class of raisim_gym.cpp:14-46 over the C-ABI) with the same
+    # device tensors: what a reference-side caller who keeps its compiled module gets.  Its own pool (same configuration, same
+    # action stream, pre-rolled to the steady state), max(K, 500) steps, wall clock around the loop.
+    per_call_native = None
+    if per_call is not None and os.environ.get("IRRL_BENCH_NATIVE", "1") != "0":
+        try:
+            import importlib.util
+            from high_speed_quadrupedal_locomotion_by_irrl_amd import build as hip_build
+            spec = importlib.util.spec_from_file_location("_flexible_robot", hip_build.pybind_module_path())   # (the name PyInit__flexible_robot is looked up under)
+            nat_mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(nat_mod)
+            nat = nat_mod.FlexibleGymEnv(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY__, yaml.safe_dump(env_cfg), local_rank)
+            nat.init()
+            for k in range(preroll):
+                nat.step(actions[k % rows], ob, rew, done, extra)
+            kn = max(args.steps, 500)
+            torch.cuda.synchronize()
+            tn = time.perf_counter()
+            for k in range(kn):
+                nat.step(actions[(preroll + k) % rows], ob, rew, done, extra)
+            torch.cuda.synchronize()
+            tn = time.perf_counter() - tn
+            per_call_native = {"value": float(n) * kn / tn, "unit": "env-steps/s", "us_per_step": 1e6 * tn / kn,
+                               "what": "%d steps, one step() call per step on device tensors through the compiled pybind11 module (__cuda_array_interface__)" % kn}
+            del nat
+        except Exception as exc:      # the compiled module is an optional second call surface
+            per_call_native = {"error": "%s: %s" % (type(exc).__name__, exc)}
+
     out = None
     if rank == 0:
         # HBM bytes per launch from the PMC passes (FETCH_SIZE x calibrated correction + WRITE_SIZE), collected with
@@ -406,7 +434,7 @@ def worker(args):
                               "algorithmic_flops_per_launch": ALG_FLOPS_PER_ENV_STEP * n, "valu_issue": issue},
             "contact_fraction_in_timed_region": contact_fraction, "resets_in_timed_region": resets,
             "steady_state_check": check, "rccl_ranks_seen": ranks_seen, "backend": backend if world > 1 else None,
-            "library": lib.irrl_version().decode(), "pmc_note": pmc_note, "per_step_call": per_call,
+            "library": lib.irrl_version().decode(), "pmc_note": pmc_note, "per_step_call": per_call, "per_step_call_compiled": per_call_native,
             "contact_solver": int(env_cfg.get("ContactSolver", 3)),
         }
         if world == 1 and args.cpu_seconds > 0:

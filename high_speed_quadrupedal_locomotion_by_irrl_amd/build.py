@@ -54,6 +54,8 @@ def build_pybind(force=False, verbose=False):
     for f in (PYBIND_SRC, HEADER):
         with open(f, "rb") as fh:
             h.update(fh.read())
+    # ... and what the binary is tied to besides its sources: the interpreter's ABI tag and pybind11's version
+    h.update((sysconfig.get_config_var("EXT_SUFFIX") or "").encode() + b"\0" + getattr(pybind11, "__version__", "").encode())
     want = h.hexdigest()[:16]
     stamp = out + ".srchash"
     if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == want:

@@ -8,8 +8,12 @@
 // bounds).  The engine's errors (irrl_last_error) surface as RuntimeError where the reference aborts the process (RSFATAL_IF).
 //
 // Host-only translation unit: g++ -shared against libirrl_env.so (no HIP headers); built by build.py into
-// native/_flexible_robot<EXT_SUFFIX>.  The numpy arrays travel through the library's pinned staging (`*_host` entry points); the
-// zero-copy device-tensor path of the PPO runner is the Python class of the same name (flexible_robot.py).
+// native/_flexible_robot<EXT_SUFFIX>.  numpy arrays travel through the library's pinned staging (`*_host` entry points).
+// DEVICE BUFFERS (round 4): step / reset / observe / isTerminalState also take any object that exposes `__cuda_array_interface__`
+// (torch tensors on the MI355X, CuPy-style arrays): same shapes, dtypes and in-place semantics, no copy -- the pointers go straight to
+// the device entry points (irrl_env_step & co.), stream-ordered on torch's current stream when the object is a torch tensor (else on
+// the interface's `stream` entry, else the null stream).  A caller that keeps the reference's compiled boundary gets the same
+// zero-copy path as the ctypes class of flexible_robot.py.
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
@@ -48,6 +52,61 @@ uint8_t *bvec(BArr &a, py::ssize_t rows, const char *name) {
   return reinterpret_cast<uint8_t *>(a.mutable_data());   // numpy bool is one byte holding 0 / 1, like the engine's done flags
 }
 
+// ---- an argument of step / reset / observe / isTerminalState: a numpy array (host path) or a device buffer ----
+bool is_device(const py::handle &o) { return py::hasattr(o, "__cuda_array_interface__"); }
+// numpy with the reference's contract: no conversion, no copy (what `noconvert` array_t arguments do)
+FArr host_f32(const py::object &o, const char *name) {
+  if (!py::isinstance<py::array>(o)) throw py::type_error(std::string(name) + " must be a numpy float32 array or a device buffer (__cuda_array_interface__)");
+  py::array a = py::reinterpret_borrow<py::array>(o);
+  if (!a.dtype().is(py::dtype::of<float>()) || !(a.flags() & py::array::c_style))
+    throw py::type_error(std::string(name) + " must be a C-contiguous float32 array (no implicit conversion: the array is filled in place)");
+  return py::reinterpret_borrow<FArr>(o);
+}
+BArr host_bool(const py::object &o, const char *name) {
+  if (!py::isinstance<py::array>(o)) throw py::type_error(std::string(name) + " must be a numpy bool array or a device buffer (__cuda_array_interface__)");
+  py::array a = py::reinterpret_borrow<py::array>(o);
+  if (!a.dtype().is(py::dtype::of<bool>()) || !(a.flags() & py::array::c_style))
+    throw py::type_error(std::string(name) + " must be a C-contiguous bool array (no implicit conversion: the array is filled in place)");
+  return py::reinterpret_borrow<BArr>(o);
+}
+// device buffer: pointer of a C-contiguous array of the given item kind ('f' 4 bytes, or 'b' / 'u' 1 byte) and shape [rows] / [rows, cols]
+void *dev_ptr(const py::object &o, char kind, int itemsize, py::ssize_t rows, py::ssize_t cols, const char *name) {
+  py::dict ifc = o.attr("__cuda_array_interface__").cast<py::dict>();
+  const std::string typestr = ifc["typestr"].cast<std::string>();
+  const bool kind_ok = typestr.size() >= 3 && (typestr[1] == kind || (kind == 'b' && typestr[1] == 'u')) && std::stoi(typestr.substr(2)) == itemsize &&
+                       (itemsize == 1 || typestr[0] == '<' || typestr[0] == '=');
+  if (!kind_ok) throw py::type_error(std::string(name) + ": device buffer of the wrong dtype (" + typestr + ")");
+  py::tuple shape = ifc["shape"].cast<py::tuple>();
+  std::vector<py::ssize_t> sh;
+  for (auto d : shape) sh.push_back(d.cast<py::ssize_t>());
+  const bool shape_ok = cols > 0 ? (sh.size() == 2 && sh[0] == rows && sh[1] == cols) : ((sh.size() == 1 && sh[0] == rows) || (sh.size() == 2 && sh[0] == rows && sh[1] == 1));
+  if (!shape_ok) throw py::value_error(std::string(name) + ": device buffer of the wrong shape");
+  if (ifc.contains("strides") && !ifc["strides"].is_none()) {
+    py::tuple st = ifc["strides"].cast<py::tuple>();
+    py::ssize_t expect = itemsize;
+    for (int i = (int)sh.size() - 1; i >= 0; i--) {
+      if (sh[i] > 1 && st[i].cast<py::ssize_t>() != expect) throw py::type_error(std::string(name) + ": device buffer must be C-contiguous");
+      expect *= sh[i];
+    }
+  }
+  py::tuple data = ifc["data"].cast<py::tuple>();
+  return reinterpret_cast<void *>(data[0].cast<size_t>());
+}
+// the stream the caller's framework is issuing on: torch's current stream for torch tensors, else the interface's `stream`, else null
+void *dev_stream(const py::object &o) {
+  const std::string mod = py::str(py::type::of(o).attr("__module__"));
+  if (mod.rfind("torch", 0) == 0) {
+    py::object cs = py::module_::import("torch").attr("cuda").attr("current_stream")(o.attr("device"));
+    return reinterpret_cast<void *>(cs.attr("cuda_stream").cast<size_t>());
+  }
+  py::dict ifc = o.attr("__cuda_array_interface__").cast<py::dict>();
+  if (ifc.contains("stream") && !ifc["stream"].is_none()) {
+    const long long v = ifc["stream"].cast<long long>();
+    if (v > 2) return reinterpret_cast<void *>((size_t)v);     // 1 / 2: the legacy / per-thread default stream
+  }
+  return nullptr;
+}
+
 // VectorizedEnvironment<ENVIRONMENT> (VectorizedEnvironment.hpp:127-382) as the engine sees it: a handle
 class VecEnv {
  public:
@@ -65,11 +124,31 @@ class VecEnv {
     for (int j = 0; j < irrl_env_extra_dim(h_); j++) out.emplace_back(irrl_env_extra_name(h_, j));
     return out;
   }
-  void reset(FArr &ob) { check(irrl_env_reset_host(h_, mat(ob, n_, 35, "ob"))); }
-  void observe(FArr &ob) { check(irrl_env_observe_host(h_, mat(ob, n_, 35, "ob"))); }
-  void step(FArr &action, FArr &ob, FArr &reward, BArr &done, FArr &extra) {
-    check(irrl_env_step_host(h_, mat(action, n_, 12, "action"), mat(ob, n_, 35, "ob"), vec(reward, n_, "reward"), bvec(done, n_, "done"),
-                             mat(extra, n_, irrl_env_extra_dim(h_), "extraInfo")));
+  void reset(py::object ob) {
+    if (is_device(ob)) { check(irrl_env_set_stream(h_, dev_stream(ob))); check(irrl_env_reset(h_, (float *)dev_ptr(ob, 'f', 4, n_, 35, "ob"))); return; }
+    FArr a = host_f32(ob, "ob");
+    check(irrl_env_reset_host(h_, mat(a, n_, 35, "ob")));
+  }
+  void observe(py::object ob) {
+    if (is_device(ob)) { check(irrl_env_set_stream(h_, dev_stream(ob))); check(irrl_env_observe(h_, (float *)dev_ptr(ob, 'f', 4, n_, 35, "ob"))); return; }
+    FArr a = host_f32(ob, "ob");
+    check(irrl_env_observe_host(h_, mat(a, n_, 35, "ob")));
+  }
+  void step(py::object action, py::object ob, py::object reward, py::object done, py::object extra) {
+    const int E = irrl_env_extra_dim(h_);
+    if (is_device(action)) {
+      // all five on the device (a mixed call would need a copy somewhere: refused like a wrong dtype)
+      if (!(is_device(ob) && is_device(reward) && is_device(done) && is_device(extra)))
+        throw py::type_error("step: action is a device buffer, so ob / reward / done / extraInfo must be device buffers too");
+      check(irrl_env_set_stream(h_, dev_stream(action)));
+      check(irrl_env_step(h_, (const float *)dev_ptr(action, 'f', 4, n_, 12, "action"), (float *)dev_ptr(ob, 'f', 4, n_, 35, "ob"),
+                          (float *)dev_ptr(reward, 'f', 4, n_, 0, "reward"), (uint8_t *)dev_ptr(done, 'b', 1, n_, 0, "done"),
+                          (float *)dev_ptr(extra, 'f', 4, n_, E, "extraInfo")));
+      return;
+    }
+    FArr a = host_f32(action, "action"), o = host_f32(ob, "ob"), r = host_f32(reward, "reward"), x = host_f32(extra, "extraInfo");
+    BArr d = host_bool(done, "done");
+    check(irrl_env_step_host(h_, mat(a, n_, 12, "action"), mat(o, n_, 35, "ob"), vec(r, n_, "reward"), bvec(d, n_, "done"), mat(x, n_, E, "extraInfo")));
   }
   void test_step(FArr &action, FArr &ob, FArr &reward, BArr &done, FArr &extra) {
     check(irrl_env_test_step_host(h_, mat(action, n_, 12, "action"), mat(ob, n_, 35, "ob"), vec(reward, n_, "reward"), bvec(done, n_, "done"),
@@ -77,7 +156,11 @@ class VecEnv {
   }
   void set_seed(int seed) { check(irrl_env_set_seed(h_, seed)); }
   void close() { check(irrl_env_close(h_)); }
-  void is_terminal(BArr &done) { check(irrl_env_is_terminal_host(h_, bvec(done, n_, "done"))); }
+  void is_terminal(py::object done) {
+    if (is_device(done)) { check(irrl_env_set_stream(h_, dev_stream(done))); check(irrl_env_is_terminal(h_, (uint8_t *)dev_ptr(done, 'b', 1, n_, 0, "done"))); return; }
+    BArr d = host_bool(done, "done");
+    check(irrl_env_is_terminal_host(h_, bvec(d, n_, "done")));
+  }
   void set_sim_dt(double dt) { check(irrl_env_set_simulation_dt(h_, dt)); }
   void set_control_dt(double dt) { check(irrl_env_set_control_dt(h_, dt)); }
   int ob_dim() const { return irrl_env_ob_dim(h_); }
@@ -129,13 +212,13 @@ PYBIND11_MODULE(_flexible_robot, m) {
       .def(py::init<std::string, std::string, int>(), py::arg("resourceDir"), py::arg("cfg"), py::arg("device") = 0)   // raisim_gym.cpp:16
       .def("init", &VecEnv::init)                                                                                         // :17
       .def("getExtraInfoNames", &VecEnv::extra_names)                                                                    // :18
-      .def("reset", &VecEnv::reset, nc("ob"))                                                                            // :19
-      .def("observe", &VecEnv::observe, nc("ob"))                                                                        // :20
-      .def("step", &VecEnv::step, nc("action"), nc("ob"), nc("reward"), nc("done"), nc("extraInfo"))                     // :21, :23
+      .def("reset", &VecEnv::reset, py::arg("ob"))                                                                       // :19 (numpy or device buffer)
+      .def("observe", &VecEnv::observe, py::arg("ob"))                                                                   // :20
+      .def("step", &VecEnv::step, py::arg("action"), py::arg("ob"), py::arg("reward"), py::arg("done"), py::arg("extraInfo"))   // :21, :23
       .def("setSeed", &VecEnv::set_seed)                                                                                 // :22
       .def("testStep", &VecEnv::test_step, nc("action"), nc("ob"), nc("reward"), nc("done"), nc("extraInfo"))            // :24
       .def("close", &VecEnv::close)                                                                                      // :25
-      .def("isTerminalState", &VecEnv::is_terminal, nc("done"))                                                          // :26
+      .def("isTerminalState", &VecEnv::is_terminal, py::arg("done"))                                                     // :26
       .def("setSimulationTimeStep", &VecEnv::set_sim_dt)                                                                 // :27
       .def("setControlTimeStep", &VecEnv::set_control_dt)                                                                // :28
       .def("getObDim", &VecEnv::ob_dim)                                                                                  // :29

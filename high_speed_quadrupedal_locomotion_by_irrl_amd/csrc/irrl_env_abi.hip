@@ -297,6 +297,12 @@ int irrl_lstm_rollout(irrl_env *h, int steps, int hid, int ob_dim, int act_dim, 
   // 16 robots -- no grid-wide boundary between steps, layer-0 weights fetched into LDS once.  Same device code per step as the
   // other two paths, bit-identical buffers.
   if (fuse == 2 && one_tile && steps > 0) {
+    // the same argument checks the other two paths get from irrl_lstm_policy_step (a bad caller gets rc = 1, not an out-of-bounds access)
+    if (!(obs && dones && states_in && states_out && lstm_w && pi_w && pi_b && vf_w && vf_b && logstd && action && clipped && value && neglogp &&
+          env_reward && env_extra)) { g_err = "irrl_lstm_rollout: NULL argument on the persistent path"; return 1; }
+    for (int i = 0; i < 12; i++)
+      if (!lstm_w[i]) { g_err = "irrl_lstm_rollout: the LSTM weight table has a NULL entry"; return 1; }
+    if (!mb_rewards) { g_err = "irrl_lstm_rollout: the persistent path writes the reward rows (mb_rewards is mandatory)"; return 1; }
     PolicyStepArgs a;
     a.obs = obs; a.dones = dones; a.states_in = states_in; a.states_out = states_out;
     for (int i = 0; i < 12; i++) a.w[i] = lstm_w[i];

@@ -170,6 +170,8 @@ lstm_seq_fwd_bf16_kernel(const LstmFwdBf16Args a) {
       c[j] = cn;
       hlast[j] = hn;
       const size_t row = (size_t)t * N + e0 + 4 * rq + j;
+      // (non-temporal stores here and loads in the backward kernel -- the gates are written once and read once -- change nothing:
+      // PPO update 111.5 against 111.6 ms, same box)
       *(f32x4 *)&a.gates[(row * HID + u) * 4] = (f32x4){ig, fg, og, gg};
       a.cseq[row * HID + u] = cn;
       a.hseq[row * HID + u] = hn;

@@ -416,6 +416,12 @@ class Runner(object):
         full = list(shape)
         n = full[env_axis]
         full[env_axis] = n * world
+        # every rank materialises ALL ranks' draw and keeps its slice (what makes the union the single-process draw): memory and time
+        # grow with the world size.  Fine for the tests that compare the two noise sources; a multi-GPU TRAINING run uses the
+        # kernel's counter RNG (noise_source "kernel", the default), which addresses the noise by global env id and draws nothing else.
+        if int(np.prod(full)) * 4 > (1 << 29):
+            raise RuntimeError("noise_source='torch' would draw %.1f GB per rollout on every rank at world size %d: use the default "
+                               "noise_source='kernel' for multi-GPU runs" % (np.prod(full) * 4 / 1e9, world))
         return torch.randn(full, device=self.obs.device, dtype=self.obs.dtype, generator=self._gen).narrow(env_axis, rank * n, n)
 
     def _fused_step(self, t):

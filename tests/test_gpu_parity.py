@@ -626,3 +626,66 @@ def test_eight_shards_of_4096_are_the_32768_pool_bit_for_bit(name, monkeypatch):
                                        event_budget=PL.TERRAIN_EVENT_BUDGET if rough else 0.005)
     assert worst["ob_p99"] < 1e-4 and worst["pos_p99"] < 1e-5      # two f32 evaluation orders: far inside the f32-vs-f64 tolerance
     print("32768-pool, 4-lane against 16-lane layout:", worst)
+
+
+def test_compiled_pybind_boundary_takes_device_buffers_zero_copy():
+    """Round 4: the compiled boundary (native/_flexible_robot) with DEVICE buffers -- torch CUDA tensors through `__cuda_array_interface__`
+    in step / reset / observe / isTerminalState (raisim_gym.cpp:19-21, 26; RaisimGymEnv.hpp:46-49 array contract: same shapes, in
+    place, no conversion): bit-identical to the ctypes class's device path over 40 steps with resets, stream-ordered on torch's
+    current stream (a side stream here), TypeError on a wrong dtype / a non-contiguous view / a host-device mix, ValueError on a
+    wrong shape."""
+    import torch
+    import yaml
+    import high_speed_quadrupedal_locomotion_by_irrl_amd as pkg
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.flexible_robot import FlexibleGymEnv
+    from test_abi_surface import load_native_module
+    mod = load_native_module()
+    n = 256
+    text = yaml.safe_dump(load_env_cfg("default_cfg.yaml", num_envs=n))
+    nat = mod.FlexibleGymEnv(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY__, text)
+    nat.init()
+    ref = FlexibleGymEnv(pkg.__BLACKPANTHER_V55_RESOURCE_DIRECTORY__, text)
+    ref.init()
+    dev = torch.device("cuda")
+    mk = lambda: (torch.zeros(n, 35, device=dev), torch.zeros(n, device=dev), torch.zeros(n, dtype=torch.bool, device=dev), torch.zeros(n, 6, device=dev))
+    ob_n, rew_n, done_n, ex_n = mk()
+    ob_r, rew_r, done_r, ex_r = mk()
+    nat.reset(ob_n); ref.reset(ob_r)
+    assert torch.equal(ob_n, ob_r) and bool(ob_n.abs().sum() > 0)
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    side = torch.cuda.Stream(device=dev)
+    n_done = 0
+    for k in range(40):
+        a = torch.clamp(0.5 * torch.randn(n, 12, device=dev, generator=g), -1, 1)
+        if k == 6:
+            st = nat.get_state()
+            st[::9, PL.S["GC"] + 2] = 0.14
+            nat.set_state(st); ref.set_state(st)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side if k % 2 else torch.cuda.current_stream(dev)):
+            nat.step(a, ob_n, rew_n, done_n, ex_n)
+        ref.step(a, ob_r, rew_r, done_r, ex_r)
+        torch.cuda.synchronize()
+        assert torch.equal(ob_n, ob_r) and torch.equal(rew_n, rew_r) and torch.equal(done_n, done_r) and torch.equal(ex_n, ex_r), k
+        n_done += int(done_n.sum())
+    assert n_done >= 20
+    nat.observe(ob_n); ref.observe(ob_r)
+    assert torch.equal(ob_n, ob_r)
+    t_n, t_r = torch.zeros(n, dtype=torch.bool, device=dev), torch.zeros(n, dtype=torch.bool, device=dev)
+    nat.isTerminalState(t_n); ref.isTerminalState(t_r)
+    assert torch.equal(t_n, t_r)
+    a = torch.zeros(n, 12, device=dev)
+    with pytest.raises(TypeError):
+        nat.step(a.double(), ob_n, rew_n, done_n, ex_n)
+    with pytest.raises(TypeError):
+        nat.step(a, ob_n, rew_n, done_n.float(), ex_n)                      # done must be bool / uint8
+    with pytest.raises(TypeError):
+        nat.observe(torch.zeros(35, n, device=dev).t())                     # not C-contiguous
+    with pytest.raises(TypeError):
+        nat.step(a, np.zeros((n, 35), np.float32), rew_n, done_n, ex_n)     # host / device mix
+    with pytest.raises(ValueError):
+        nat.observe(torch.zeros(n, 34, device=dev))
+    # numpy still goes through the host entry points
+    ob_h = np.zeros((n, 35), np.float32)
+    nat.observe(ob_h)
+    assert np.array_equal(ob_h, ob_n.cpu().numpy())
