@@ -786,4 +786,15 @@ int irrl_sum_rows_scatter(const float *part, int nmat, int rows, int cols, const
   return 0;
 }
 
+int irrl_random_permutation(long long n, unsigned seed, unsigned counter, long long *out, void *hip_stream) {
+  if (n <= 0 || n > (1ll << 30) || !out) { g_err = "irrl_random_permutation: 0 < n <= 2^30"; return 1; }
+  int bits = 1;
+  while ((1ll << bits) < n) bits++;
+  const int half_bits = (bits + 1) / 2 < 1 ? 1 : (bits + 1) / 2;
+  hipLaunchKernelGGL(irrl_random_permutation_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, (uint32_t)n, half_bits, seed,
+                     counter, out);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 }  // extern "C"

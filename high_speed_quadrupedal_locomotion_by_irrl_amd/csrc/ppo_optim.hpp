@@ -111,3 +111,35 @@ irrl_sum_rows_scatter_kernel(const float *__restrict__ part, int rows, int cols,
     }
   }
 }
+
+// ---- a random permutation of 0 .. n-1 without a sort (the shuffled sample order of an epoch, ppo2.py:364-380: np.random.shuffle(inds)) ----
+// torch.randperm on the device is a radix sort of n random keys: 7 launches and 175 us for the 3.07 M samples of a 4096 x 750 rollout, ten
+// times per update -- 6 % of the MlpPolicy update.  Here out[i] = E(i) with E a keyed bijection of [0, n): a 4-round Feistel network on the
+// 2 b bits that hold n - 1 (round function: a 32-bit integer hash of the half and the round key), walked until the value falls below n
+// (cycle walking: E restricted to [0, n) is again a bijection; 2^(2b) < 4 n, so fewer than 4 evaluations on average, 1.4 at n = 3.07 M).
+// One launch, each element on its own: the order depends on (n, seed, counter) only -- every rank computes the same one, and the numpy
+// twin (ppo2.feistel_permutation) gives the CPU path the same bits.
+__device__ __host__ inline uint32_t irrl_perm_hash(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __host__ inline uint32_t irrl_perm_encrypt(uint32_t v, int half_bits, uint32_t seed, uint32_t counter) {
+  const uint32_t mask = (1u << half_bits) - 1u;
+  uint32_t L = v >> half_bits, R = v & mask;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const uint32_t k = irrl_perm_hash(seed + 0x9E3779B9u * (uint32_t)(r + 1)) ^ irrl_perm_hash(counter + 0x85EBCA6Bu * (uint32_t)(r + 1));
+    const uint32_t F = irrl_perm_hash(R ^ k) & mask;
+    const uint32_t nL = R, nR = L ^ F;
+    L = nL; R = nR;
+  }
+  return (L << half_bits) | R;
+}
+__global__ void __launch_bounds__(256)
+irrl_random_permutation_kernel(uint32_t n, int half_bits, uint32_t seed, uint32_t counter, long long *__restrict__ out) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  uint32_t v = irrl_perm_encrypt(i, half_bits, seed, counter);
+  while (v >= n) v = irrl_perm_encrypt(v, half_bits, seed, counter);
+  out[i] = (long long)v;
+}

@@ -358,6 +358,42 @@ def mlp_stats_rows(rows, n, act_dim):
     return torch.stack([r[:, 0] / n, r[:, 4] / n, ent, r[:, 1] / n, r[:, 2] / n], 1)
 
 
+def _perm_hash(x):
+    x = x ^ (x >> np.uint32(16)); x = x * np.uint32(0x7feb352d); x = x ^ (x >> np.uint32(15)); x = x * np.uint32(0x846ca68b); x = x ^ (x >> np.uint32(16))
+    return x
+
+
+def feistel_permutation(n, seed, counter):
+    """numpy twin of `irrl_random_permutation` (csrc/ppo_optim.hpp): the keyed bijection E of [0, n) -- 4-round Feistel network on the bits of
+    n - 1, cycle walking -- as an int64 vector out[i] = E(i).  Same bits as the kernel."""
+    bits = 1
+    while (1 << bits) < n:
+        bits += 1
+    hb = max(1, (bits + 1) // 2)
+    mask = np.uint32((1 << hb) - 1)
+    keys = []
+    with np.errstate(over="ignore"):
+        for r in range(4):
+            a = _perm_hash(np.uint32((seed + 0x9E3779B9 * (r + 1)) & 0xFFFFFFFF))
+            b = _perm_hash(np.uint32((counter + 0x85EBCA6B * (r + 1)) & 0xFFFFFFFF))
+            keys.append(np.uint32(a ^ b))
+
+        def enc(v):
+            L, R = v >> np.uint32(hb), v & mask
+            for k in keys:
+                F = _perm_hash(R ^ k) & mask
+                L, R = R, L ^ F
+            return (L << np.uint32(hb)) | R
+
+        v = enc(np.arange(n, dtype=np.uint32))
+        while True:
+            out_of_range = v >= np.uint32(n)
+            if not out_of_range.any():
+                break
+            v[out_of_range] = enc(v[out_of_range])
+    return v.astype(np.int64)
+
+
 def fused_ppo_loss_supported(policy, obs):
     return bool(obs.is_cuda and hasattr(policy, "evaluate_raw") and getattr(policy, "act_dim", 0) == 12)
 
@@ -721,6 +757,20 @@ class PPO2(object):
         for prm in fl.params:
             prm.grad = None         # the next backward() leaves fresh tensors, gather() copies them into the views
 
+    def _sample_order(self, n):
+        """np.random.shuffle(inds) of ppo2.py:366-367 as a keyed bijection of [0, n) (one launch on the GPU instead of the radix sort behind
+        torch.randperm; the numpy twin on the CPU gives the same order): depends on (n, seed, number of shuffles so far) only, so it is the
+        same on every rank and on either device."""
+        self._shuffles = getattr(self, "_shuffles", 0) + 1
+        key = (self.seed * 1000003 + 12345) & 0xFFFFFFFF
+        if self.device.type == "cuda" and n <= (1 << 30):
+            from . import _lib
+            out = torch.empty(n, dtype=torch.int64, device=self.device)
+            _lib.check(_lib.load().irrl_random_permutation(n, key, self._shuffles, C.c_void_p(out.data_ptr()),
+                                                           C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+            return out
+        return torch.from_numpy(feistel_permutation(n, key, self._shuffles)).to(self.device)
+
     def update(self, batch, lr_now, cliprange_now):
         """All epochs / minibatches of one PPO iteration (ppo2.py:362-404)."""
         T, N = batch["values"].shape
@@ -753,7 +803,7 @@ class PPO2(object):
                     ("obs", "returns", "masks", "actions", "values", "neglogpacs")}   # swap_and_flatten: env-major
             in_place = self.fused_mlp and mlp_ppo_grads_supported(self.policy, flat["obs"])
             for _ in range(self.noptepochs):
-                inds = torch.randperm(n_batch, device=self.device, generator=self.generator)
+                inds = self._sample_order(n_batch)
                 for start in range(0, n_batch, bs):
                     mb = inds[start:start + bs]
                     if in_place:     # the gradient kernels read the minibatch's rows through the index: nothing is gathered

@@ -200,6 +200,11 @@ int irrl_clip_adam(int n, float *theta, const float *grad, float *m, float *v, f
  * partial rows straight into the flat gradient buffer in parameter layout. */
 int irrl_sum_rows_scatter(const float *part, int nmat, int rows, int cols, const int *map, const float *add, float *out, void *hip_stream);
 
+/* out[i] = E(i), i < n: a keyed random permutation of 0 .. n-1 (int64, device) in ONE launch and without a sort -- the shuffled sample order of
+ * an optimisation epoch (ppo2.py:364-380).  E = 4-round Feistel network on the bits of n - 1 with cycle walking; depends on (n, seed, counter)
+ * only; `ppo2.feistel_permutation` is the numpy twin. */
+int irrl_random_permutation(long long n, unsigned seed, unsigned counter, long long *out, void *hip_stream);
+
 /* synthetic action stream of the benchmark (a = clip(sigma N(0,1), -1, 1) from Philox(seed, stream = env,
  * counter = step)): fills out[n_steps][n_envs][12] (device) for envs env0 .. and steps step0 ..; values depend only on
  * (seed, global env id, step), not on the shape of the request.  tests/ hold the numpy twin. */

@@ -698,3 +698,24 @@ def test_flat_optimizer_step_follows_torch_adam_on_the_same_views(kind):
             if prm in grads:
                 assert torch.equal(gv, grads[prm].reshape(gv.shape)), tuple(prm.shape)
         np.testing.assert_allclose(P2.mlp_stats_rows([row], 3000.0, 12)[0].cpu().numpy(), stats.cpu().numpy(), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("n", [1, 7, 4096, 100003, 4096 * 750])
+def test_random_permutation_kernel_is_a_permutation_and_equals_its_numpy_twin(n):
+    """`irrl_random_permutation` (the epoch's shuffled sample order without the radix sort of torch.randperm): a bijection of [0, n), the same
+    bits as ppo2.feistel_permutation (what the CPU path uses), a different order for a different counter."""
+    import ctypes as C
+    from high_speed_quadrupedal_locomotion_by_irrl_amd import _lib
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.ppo2 import feistel_permutation
+    lib = _lib.load()
+    dev = torch.device("cuda")
+    out = torch.empty(n, dtype=torch.int64, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(lib.irrl_random_permutation(n, 987654321, 5, C.c_void_p(out.data_ptr()), stream))
+    got = out.cpu().numpy()
+    assert np.array_equal(np.sort(got), np.arange(n))
+    assert np.array_equal(got, feistel_permutation(n, 987654321, 5))
+    if n > 100:
+        _lib.check(lib.irrl_random_permutation(n, 987654321, 6, C.c_void_p(out.data_ptr()), stream))
+        assert float((out.cpu().numpy() != got).mean()) > 0.99
+        assert abs(float(np.corrcoef(np.arange(n), got)[0, 1])) < 0.05

@@ -56,6 +56,8 @@ def measure(policy="lstm", envs=4096, steps=750, iters=3, epochs=10, cfg_name="d
     return {"policy": policy, "envs": envs, "n_steps": steps, "epochs": epochs, "timed_iters": len(timed), "rollout_s": ro, "update_s": up,
             "ppo_iters_per_sec": 1.0 / (ro + up), "env_steps_per_sec_in_rollout": envs * steps / ro,
             "samples_per_sec": envs * steps / (ro + up), "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9,
+            # arithmetic of the LSTM sequence kernels of the update (lstm_fused.PRECISION; the rollout's policy step is always exact f32)
+            "lstm_update_arithmetic": __import__("high_speed_quadrupedal_locomotion_by_irrl_amd.lstm_fused", fromlist=["PRECISION"]).PRECISION if lstm else None,
             # spread over the timed iterations (the first, which warms the allocator, is left out): iterations / s
             "iters_per_sec_min_median_max": [its[0], med(its), its[-1]],
             "rollout_s_min_max": [min(r[0] for r in timed), max(r[0] for r in timed)],
