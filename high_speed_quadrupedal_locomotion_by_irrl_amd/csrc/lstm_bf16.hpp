@@ -210,7 +210,11 @@ template <int NS, bool NEED_DX>
 __global__ void __launch_bounds__(256)
 lstm_seq_bwd_bf16_kernel(const LstmBwdBf16Args a) {
   constexpr int HID = LBF_HID, GC = LBF_GC, KX = LBF_KX, KC = GC / 32;
+#ifdef IRRL_LBF_DEPTH      /* A/B switch of tools/build_variants.py */
+  constexpr int DEPTH = (NS == 2) ? IRRL_LBF_DEPTH : (NEED_DX ? 1 : 2);
+#else
   constexpr int DEPTH = (NS == 2) ? 3 : (NEED_DX ? 1 : 2);    // steps of operand loads in flight (36 registers per step; NS 3 has fewer to spare)
+#endif
   using PR = BfProducts<NS>;
   extern __shared__ __attribute__((aligned(16))) unsigned short lds_b[];
   constexpr int PER_BUF = lstm_bwd_bf16_lds_elems_per_buf<NS>();

@@ -424,7 +424,7 @@ irrl_adv_moments_kernel(const int64_t *__restrict__ idx, size_t n, const float *
   double s = 0.0, ss = 0.0;
   for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (size_t)gridDim.x * 256) {
     const size_t r = idx ? (size_t)idx[j] : j;
-    const double a = (double)(ret[r] - val[r]);       // the advantage is formed in f32, as the rollout stores it
+    const double a = (double)(val ? ret[r] - val[r] : ret[r]);   // the advantage is formed in f32, as the rollout stores it (val == NULL: ret IS the advantage)
     s += a; ss += a * a;
   }
 #pragma unroll

@@ -666,7 +666,10 @@ class PPO2(object):
         scratch = torch.empty(2 * 256 + 3, device=dev, dtype=torch.float64)
         stats = torch.empty(2, device=dev, dtype=torch.float32)
         p = lambda t: C.c_void_p(t.data_ptr())
-        _lib.check(lib.irrl_adv_moments(int(index.numel()), p(index), p(returns), p(values), p(scratch), 256, p(scratch[512:]),
+        adv = getattr(self, "_flat_adv", None)      # returns - values of the whole rollout, formed once per update (`update`): one gather, not two
+        if adv is not None and adv.numel() == returns.numel():
+            returns, values = adv, None
+        _lib.check(lib.irrl_adv_moments(int(index.numel()), p(index), p(returns), p(values) if values is not None else None, p(scratch), 256, p(scratch[512:]),
                                         p(stats) if self.world == 1 else None, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         if self.world == 1:
             return stats
@@ -802,6 +805,7 @@ class PPO2(object):
             flat = {k: batch[k].transpose(0, 1).reshape(n_batch, *batch[k].shape[2:]) for k in
                     ("obs", "returns", "masks", "actions", "values", "neglogpacs")}   # swap_and_flatten: env-major
             in_place = self.fused_mlp and mlp_ppo_grads_supported(self.policy, flat["obs"])
+            self._flat_adv = (flat["returns"] - flat["values"]).contiguous() if in_place else None
             for _ in range(self.noptepochs):
                 inds = self._sample_order(n_batch)
                 for start in range(0, n_batch, bs):
@@ -812,6 +816,7 @@ class PPO2(object):
                         continue
                     losses.append(self._train_step(lr_now, cliprange_now, flat["obs"][mb], flat["returns"][mb], flat["masks"][mb],
                                                    flat["actions"][mb], flat["values"][mb], flat["neglogpacs"][mb]))
+            self._flat_adv = None
             if in_place:
                 return mlp_stats_rows(losses, float(bs), self.policy.act_dim).mean(0)
         return torch.stack(losses).mean(0)

@@ -181,6 +181,7 @@ int irrl_mlp_ppo_partial_len(void);
 
 /* moments of the raw advantages a = returns[r] - old_values[r] of one minibatch (ppo2.py:262-263 normalises them per minibatch):
  * sums[3] = (sum a, sum a^2, n) as doubles, rows through idx [n] (int64, device) or 0..n-1 (NULL), fixed summation order.
+ * old_values may be NULL: `returns` then holds the advantages themselves (formed once per update: one gathered array per minibatch instead of two).
  * scratch: 2 * n_blocks doubles (device).  stats (device, may be NULL): also (mean, population std) of a as two floats -- the adv_stats
  * argument of the loss kernels when the job has one rank (several ranks all-reduce `sums` first). */
 int irrl_adv_moments(size_t n, const int64_t *idx, const float *returns, const float *old_values, double *scratch, int n_blocks, double *sums,
