@@ -287,10 +287,11 @@ def worker(args):
     # ctypes call per step adds ~2 us per step.  With the driver's --steps 20 the bracket is 0.9 ms long and box-to-box differences in
     # launch / wake-up latency are a large part of it, so `--launch auto` (default) tries each way on THIS box during the warm-up
     # (two untimed brackets of K steps each) and times the one that was fastest.  Long brackets (K > 400) amortise all of it: rows.
+    # (Several ranks: every rank runs the same six probe brackets and picks for its own GPU; the barrier sits around the timed bracket.)
     launch_probe = None
     mode = args.launch
     if mode == "auto":
-        if args.steps > 400 or world > 1:
+        if args.steps > 400:
             mode = "rows"
         else:
             launch_probe = {}
