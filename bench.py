@@ -13,6 +13,8 @@ pre-roll (--preroll, default 1000, at least 200 steps: the robots land within ~6
 resets that follows has passed by step ~500) so that the timed region sees the stationary workload; it reads the
 kernels' own counters (toe-substeps in the contact list, episodes started) around the timed region, reports
 `contact_fraction_in_timed_region` / `resets_in_timed_region`, and FAILS when the region was free flight.
+The last HOT_STEPS (300) untimed steps go out straight in front of the synchronize that opens the timed bracket (after --warmup and the
+launch-mode probes), so that the GPU arrives there from work and not from milliseconds of idling on host set-up (bracket()).
 
 Multi-GPU: `python bench.py --gpus N` with N > 1 starts N ranks by itself (python -m torch.distributed.run, one
 rank per GPU, rendezvous on 127.0.0.1) unless it already runs under a launcher (WORLD_SIZE set).  4096 envs per
@@ -45,6 +47,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s
 FP32_PEAK_TFLOPS = 157.3
 ACTION_SEED = 1
 MIN_PREROLL = 200
+HOT_STEPS = 300                 # untimed steps of the same workload right in front of a bracket's opening synchronize (see bracket())
 
 
 def parse_args(argv=None):
@@ -214,7 +217,7 @@ def worker(args):
     # synthetic action stream resident in HBM: row s = actions of global step s for this rank's envs (global env id =
     # rank * n + e).  Beyond 16384 steps the stream wraps (it would be 3 GB otherwise); the default run uses 5.5 k rows.
     preroll = max(MIN_PREROLL, args.preroll)
-    total = preroll + args.warmup + 8 * args.steps + 50 + args.check_steps
+    total = preroll + args.warmup + 8 * (args.steps + HOT_STEPS) + 50 + args.check_steps
     rows = min(total, 16384)
     lib = _lib.load()
     actions = torch.empty(rows, n, 12, device=dev)
@@ -257,14 +260,26 @@ def worker(args):
             graph_cache["g"] = g
         return graph_cache["g"]
 
-    def bracket(mode, events=None):
-        """args.steps env steps issued in `mode`, bracketed by synchronize on both sides -> wall seconds.  Completion is first seen by
-        polling the closing event (hipEventQuery), then confirmed by torch.cuda.synchronize(): on some boxes of this pool a host thread
-        BLOCKED in the synchronize behind a short burst is woken up milliseconds late (profiles/r04_burst_wakeup.log: 20 steps = 0.9 ms
-        of kernels, 2.0-3.4 ms of wall clock); a thread that polls is not."""
-        call = env.step_rows_call(args.steps, actions, cursor[0] % rows, ob, rew, done, extra) if mode == "rows" else None
+    def bracket(mode, events=None, barrier=False):
+        """args.steps env steps issued in `mode`, bracketed by (barrier +) synchronize on both sides -> wall seconds.  Completion is first
+        seen by polling the closing event (hipEventQuery), then confirmed by torch.cuda.synchronize(): on some boxes of this pool a host
+        thread BLOCKED in the synchronize behind a short burst is woken up milliseconds late (profiles/r04_burst_wakeup.log: 20 steps =
+        0.9 ms of kernels, 2.0-3.4 ms of wall clock); a thread that polls is not.
+        HOT_STEPS untimed steps of the same workload go out right in front of the opening synchronize -- the tail of the pre-roll: a GPU
+        that has idled for a few milliseconds (set-up work on the host, the probe brackets) runs every launch of the next millisecond
+        6 % slower than one that arrives from work (47.3 against 44.5 us per launch with an event between launches, same box,
+        profiles/r04_bracket_launches.log), and --warmup 5 (0.2 ms) does not bring it back.  What the bracket then measures is the
+        kernel at its working clock plus the start-up of the first launch behind a synchronize, which belongs to the contract."""
         g = make_graph() if mode == "graph" else None
         e0, e1 = events if events is not None else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        run(HOT_STEPS)
+        eh = torch.cuda.Event()
+        eh.record()
+        call = env.step_rows_call(args.steps, actions, cursor[0] % rows, ob, rew, done, extra) if mode == "rows" else None
+        while not eh.query():        # the host thread arrives from work too: it polls through the 12 ms of the hot steps instead of sleeping in the synchronize
+            pass
+        if barrier and dist is not None:
+            dist.barrier()
         torch.cuda.synchronize()
         t_start = time.perf_counter()
         e0.record()
@@ -303,11 +318,8 @@ def worker(args):
     # the kernels' counters are summed on the device, stream-ordered: no read-back (idle GPU) right before the timed region
     cnt0, cnt1 = torch.zeros(3, dtype=torch.int64, device=dev), torch.zeros(3, dtype=torch.int64, device=dev)
     env.counters_into(cnt0)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    elapsed = bracket(mode, (ev0, ev1))      # synchronize | K steps | synchronize on this rank; the MAX over ranks is taken below
+    elapsed = bracket(mode, (ev0, ev1), barrier=True)   # barrier + synchronize | K steps | synchronize (+ barrier below); the MAX over ranks is taken below
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -353,7 +365,8 @@ def worker(args):
     # the same K steps issued the way the reference's runner issues them: ONE FlexibleGymEnv.step() call (ctypes -> C-ABI) per
     # control step (RaisimGymVecEnv.py:31), wall clock around the loop -- reported beside `value`, never as `value`
     per_call = None
-    if mode == "rows" and world == 1:
+    if world == 1:
+        run(HOT_STEPS)
         torch.cuda.synchronize()
         tc = time.perf_counter()
         run(args.steps, "python")
@@ -419,9 +432,10 @@ def worker(args):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE config 2: %d envs/GPU x 1 env.step (8 substeps @4 kHz + obs + reward + "
                                    "termination + in-step reset), cfg %s%s, actions clip(0.3 N(0,1)) from Philox(seed 1, stream env, counter step), "
-                                   "%d-step untimed pre-roll before the warm-up" % (n, args.cfg, (" with " + ", ".join(args.set)) if args.set else "", preroll),
+                                   "%d-step untimed pre-roll before the warm-up, %d more untimed steps straight in front of the bracket's opening synchronize"
+                                   % (n, args.cfg, (" with " + ", ".join(args.set)) if args.set else "", preroll, HOT_STEPS),
                        "envs_per_gpu": n, "global_envs": n * world, "parallelism": "env-sharded x%d" % world,
-                       "lanes_per_robot": env.lanes_per_robot, "preroll": preroll,
+                       "lanes_per_robot": env.lanes_per_robot, "preroll": preroll, "hot_steps_before_bracket": HOT_STEPS,
                        "launch": {"rows": "%d back-to-back launches from one irrl_env_step_rows call" % args.steps,
                                   "graph": "one hipGraph of %d step-kernel nodes" % args.steps,
                                   "python": "one ctypes call per step"}[mode],
