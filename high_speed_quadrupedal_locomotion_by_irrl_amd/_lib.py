@@ -63,6 +63,7 @@ SIGNATURES = {
     "irrl_ppo_loss": (C.c_int, [C.c_size_t, C.c_int] + [vp] * 8 + [C.c_float, C.c_float] + [vp] * 3 + [C.c_int, vp]),
     "irrl_ppo_heads_loss": (C.c_int, [C.c_size_t, C.c_int, C.c_int] + [vp] * 12 + [C.c_float, C.c_float] + [vp] * 5 + [C.c_int, vp]),
     "irrl_mlp_ppo_grads": (C.c_int, [C.c_int, C.c_size_t, vp, C.c_int, C.c_int, C.c_int] + [vp] * 13 + [C.c_float, C.c_float, vp, C.c_int, vp]),
+    "irrl_mlp_ppo_grads_bf16": (C.c_int, [C.c_int, C.c_size_t, vp, C.c_int, C.c_int, C.c_int] + [vp] * 13 + [C.c_float, C.c_float, vp, C.c_int, vp]),
     "irrl_mlp_ppo_partial_len": (C.c_int, []),
     "irrl_adv_moments": (C.c_int, [C.c_size_t, vp, vp, vp, vp, C.c_int, vp, vp, vp]),
     "irrl_sum_rows": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),

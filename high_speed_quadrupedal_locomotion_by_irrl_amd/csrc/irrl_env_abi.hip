@@ -9,6 +9,7 @@
 #include "env_params.h"
 #include "lstm_kernels.hip"
 #include "mlp_update.hpp"
+#include "mlp_bf16.hpp"
 #include "ppo_optim.hpp"
 
 // The env kernels are compiled in two lane layouts from the same source (csrc/env_kernels.hip, see build.py):
@@ -749,6 +750,30 @@ int irrl_mlp_ppo_grads(int kind, size_t n, const int64_t *idx, int ob_dim, int h
   return 0;
 }
 int irrl_mlp_ppo_partial_len(void) { return IRRL_MLP_P; }
+
+// the same gradients with every product formed as three bf16 plane products on the matrix cores (kernel: csrc/mlp_bf16.hpp); same arguments,
+// same partial-sum rows.  returns 0 on success
+int irrl_mlp_ppo_grads_bf16(int kind, size_t n, const int64_t *idx, int ob_dim, int hid, int act_dim, const float *obs, const float *actions,
+                            const float *returns, const float *old_values, const float *old_neglogp, const float *w1, const float *b1, const float *w2,
+                            const float *b2, const float *w3, const float *b3, const float *logstd, const float *adv_stats, float cliprange, float vf_coef,
+                            float *partials, int n_blocks, void *hip_stream) {
+  if (n == 0 || n_blocks <= 0) { g_err = "irrl_mlp_ppo_grads_bf16: empty batch"; return 1; }
+  if (ob_dim != IRRL_MLP_OB || hid != IRRL_MLP_H || act_dim != 12) { g_err = "irrl_mlp_ppo_grads_bf16: built for 35 observations, [64, 64] hidden units and 12 actions"; return 1; }
+  if (kind != 0 && kind != 1) { g_err = "irrl_mlp_ppo_grads_bf16: kind is 0 (policy network) or 1 (value network)"; return 1; }
+  static int allowed = -1;
+  if (allowed < 0)    // the weight planes and the waves' images exceed the 64 KB a kernel gets without asking (gfx950 has 160 KB per CU)
+    allowed = (hipFuncSetAttribute((const void *)irrl_mlp_ppo_bf16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, mlp_bf16_lds_bytes()) == hipSuccess &&
+               hipFuncSetAttribute((const void *)irrl_mlp_ppo_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, mlp_bf16_lds_bytes()) == hipSuccess) ? 0 : 1;
+  if (allowed != 0) { g_err = "irrl_mlp_ppo_grads_bf16: the device refused the kernel's LDS size"; return 1; }
+  MlpUpdateArgs a;
+  a.n = n; a.idx = idx; a.obs = obs; a.actions = actions; a.returns = returns; a.old_values = old_values; a.old_neglogp = old_neglogp;
+  a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.logstd = logstd; a.adv_stats = adv_stats;
+  a.cliprange = cliprange; a.vf_coef = vf_coef; a.inv_n = 1.0f / (float)n; a.partials = partials;
+  if (kind == 0) hipLaunchKernelGGL(irrl_mlp_ppo_bf16_kernel<0>, dim3((unsigned)n_blocks), dim3(256), mlp_bf16_lds_bytes(), (hipStream_t)hip_stream, a);
+  else hipLaunchKernelGGL(irrl_mlp_ppo_bf16_kernel<1>, dim3((unsigned)n_blocks), dim3(256), mlp_bf16_lds_bytes(), (hipStream_t)hip_stream, a);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
 
 // sums[3] = (sum a, sum a^2, n) of a = returns[r] - old_values[r] over the minibatch's rows, in double; scratch: [2 * n_blocks] doubles;
 // stats (may be NULL): (mean, population std) of a as floats, what the loss kernels take as adv_stats when there is one rank

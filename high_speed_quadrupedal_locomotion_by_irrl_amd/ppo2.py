@@ -171,6 +171,19 @@ class _FusedHeadsLoss(torch.autograd.Function):
         return d_hp, d_hv, d_wpi, d_bpi, d_wv, d_bv, d_logstd, None, None, None, None, None, None, None, None, None
 
 
+# arithmetic of the MlpPolicy gradient kernels: "bf16x3" = every product as three bf16 plane products on the matrix cores (two planes per
+# operand, f32 accumulation, ~2^-16 relative per product; csrc/mlp_bf16.hpp), "f32" = v_mfma_f32_16x16x4_f32 (csrc/mlp_update.hpp)
+MLP_PRECISION = os.environ.get("IRRL_MLP_PRECISION", "bf16x3")
+
+
+def _mlp_grads_entry(lib):
+    if MLP_PRECISION == "bf16x3":
+        return lib.irrl_mlp_ppo_grads_bf16
+    if MLP_PRECISION == "f32":
+        return lib.irrl_mlp_ppo_grads
+    raise ValueError("IRRL_MLP_PRECISION / ppo2.MLP_PRECISION is 'bf16x3' or 'f32', not %r" % (MLP_PRECISION,))
+
+
 def mlp_ppo_grads_supported(policy, obs):
     """The single-launch-per-network gradient kernels (`irrl_mlp_ppo_grads`) cover the reference's MlpPolicy as configured:
     35 observations, [64, 64] tanh stacks, 12 actions."""
@@ -200,7 +213,7 @@ def mlp_ppo_grads(policy, obs, actions, returns, old_values, old_neglogp, adv_st
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     nets = ((0, policy.pi_fc, policy.pi), (1, policy.vf_fc, policy.vf))
     for kind, fc, head in nets:
-        _lib.check(lib.irrl_mlp_ppo_grads(kind, n, ip, obs.shape[-1], fc[0].w.shape[1], actions.shape[-1], p(obs), p(actions), p(returns),
+        _lib.check(_mlp_grads_entry(lib)(kind, n, ip, obs.shape[-1], fc[0].w.shape[1], actions.shape[-1], p(obs), p(actions), p(returns),
                                           p(old_values), p(old_neglogp), p(c(fc[0].w)), p(c(fc[0].b)), p(c(fc[1].w)), p(c(fc[1].b)),
                                           p(c(head.w)), p(c(head.b)), p(c(policy.logstd)), p(adv_stats), float(cliprange), float(vf_coef),
                                           p(partials[kind]), n_blocks, stream))
@@ -341,7 +354,7 @@ def mlp_ppo_grads_flat(policy, flat, obs, actions, returns, old_values, old_negl
         assert index.dtype == torch.int64 and index.is_contiguous()
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     for kind, fc, head in ((0, policy.pi_fc, policy.pi), (1, policy.vf_fc, policy.vf)):
-        _lib.check(lib.irrl_mlp_ppo_grads(kind, n, ip, obs.shape[-1], fc[0].w.shape[1], actions.shape[-1], p(obs), p(actions), p(returns),
+        _lib.check(_mlp_grads_entry(lib)(kind, n, ip, obs.shape[-1], fc[0].w.shape[1], actions.shape[-1], p(obs), p(actions), p(returns),
                                           p(old_values), p(old_neglogp), p(fc[0].w), p(fc[0].b), p(fc[1].w), p(fc[1].b),
                                           p(head.w), p(head.b), p(policy.logstd), p(adv_stats), float(cliprange), float(vf_coef),
                                           p(partials[kind]), n_blocks, stream))

@@ -178,6 +178,13 @@ int irrl_mlp_ppo_grads(int kind, size_t n, const int64_t *idx, int ob_dim, int h
                        const float *b2, const float *w3, const float *b3, const float *logstd, const float *adv_stats, float cliprange, float vf_coef,
                        float *partials, int n_blocks, void *hip_stream);
 int irrl_mlp_ppo_partial_len(void);
+/* The same gradients with every matrix product formed as THREE bf16 plane products on the matrix cores (each operand split into two
+ * bf16 planes, f32 accumulation: ~2^-16 relative per product, csrc/mlp_bf16.hpp): same arguments, same partial-sum rows, ~3x faster.
+ * What the learner uses by default; irrl_mlp_ppo_grads stays the exact-f32 form. */
+int irrl_mlp_ppo_grads_bf16(int kind, size_t n, const int64_t *idx, int ob_dim, int hid, int act_dim, const float *obs, const float *actions,
+                            const float *returns, const float *old_values, const float *old_neglogp, const float *w1, const float *b1, const float *w2,
+                            const float *b2, const float *w3, const float *b3, const float *logstd, const float *adv_stats, float cliprange, float vf_coef,
+                            float *partials, int n_blocks, void *hip_stream);
 
 /* moments of the raw advantages a = returns[r] - old_values[r] of one minibatch (ppo2.py:262-263 normalises them per minibatch):
  * sums[3] = (sum a, sum a^2, n) as doubles, rows through idx [n] (int64, device) or 0..n-1 (NULL), fixed summation order.

@@ -38,11 +38,28 @@ def main(n):
 
     g32, params, stats_t = eager(pol, torch.float32)
     g64, _, _ = eager(copy.deepcopy(pol).double(), torch.float64)
-    _l, _s, grads = P2.mlp_ppo_grads(pol, obs, actions, returns, old_v, old_nlp, stats_t, 0.2, 0.01, 0.5, index=index)
+    res = {}
+    for prec in ("f32", "bf16x3"):
+        P2.MLP_PRECISION = prec
+        _l, _s, grads = P2.mlp_ppo_grads(pol, obs, actions, returns, old_v, old_nlp, stats_t, 0.2, 0.01, 0.5, index=index)
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        for _ in range(5):
+            P2.mlp_ppo_grads(pol, obs, actions, returns, old_v, old_nlp, stats_t, 0.2, 0.01, 0.5, index=index, want_loss=False)
+        ev[1].record()
+        torch.cuda.synchronize()
+        res[prec] = (grads, 1e3 * ev[0].elapsed_time(ev[1]) / 5)
+    print("n = %d; both networks' kernels + row sums: f32 %.1f us, bf16x3 %.1f us" % (n, res["f32"][1], res["bf16x3"][1]))
+    worst = {"f32": 0.0, "bf16x3": 0.0, "eager": 0.0}
     for q, a32, a64 in zip(params, g32, g64):
         scale = float(a64.abs().max())
-        print("%-10s scale %.3e   kernel-f64 %.3e   eager32-f64 %.3e" % (tuple(q.shape), scale, float((grads[q].double() - a64).abs().max()),
-                                                                        float((a32.double() - a64).abs().max())))
+        e = {k: float((res[k][0][q].double() - a64).abs().max()) for k in ("f32", "bf16x3")}
+        e["eager"] = float((a32.double() - a64).abs().max())
+        for k in worst:
+            worst[k] = max(worst[k], e[k] / scale)
+        print("%-10s scale %.3e   |kernel - f64|: f32 %.3e  bf16x3 %.3e   eager f32 graph %.3e" % (tuple(q.shape), scale, e["f32"], e["bf16x3"], e["eager"]))
+    print("worst error / largest entry of the parameter's gradient: f32 %.2e  bf16x3 %.2e  eager f32 graph %.2e" % (worst["f32"], worst["bf16x3"], worst["eager"]))
 
 
 if __name__ == "__main__":

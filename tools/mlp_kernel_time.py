@@ -18,17 +18,18 @@ def main(n, rows):
     ret, val, nlp = torch.randn(rows, device=dev), torch.randn(rows, device=dev), torch.randn(rows, device=dev) + 12.0
     idx = torch.randperm(rows, device=dev)[:n].contiguous()
     stats = torch.tensor([0.0, 1.0], device=dev)
-    P = 8356
+    P = lib.irrl_mlp_ppo_partial_len()
     part = torch.empty(2, 256, P, device=dev)
     p = lambda t: C.c_void_p(t.data_ptr())
     st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     nets = ((0, pol.pi_fc, pol.pi), (1, pol.vf_fc, pol.vf))
 
     def launch(kind, fc, head, index):
-        rc = lib.irrl_mlp_ppo_grads(kind, n, p(index) if index is not None else None, 35, 64, 12, p(obs), p(act), p(ret), p(val), p(nlp), p(fc[0].w), p(fc[0].b),
+        rc = entry(kind, n, p(index) if index is not None else None, 35, 64, 12, p(obs), p(act), p(ret), p(val), p(nlp), p(fc[0].w), p(fc[0].b),
                                     p(fc[1].w), p(fc[1].b), p(head.w), p(head.b), p(pol.logstd), p(stats), 0.2, 0.5, p(part[kind]), 256, st)
         assert rc == 0
-    for label, index in (("indexed", idx), ("rows 0..n-1", None)):
+    for prec, label, index in [(pr, lb, ix) for pr in ("f32", "bf16x3") for lb, ix in (("indexed", idx), ("rows 0..n-1", None))]:
+        entry = lib.irrl_mlp_ppo_grads if prec == "f32" else lib.irrl_mlp_ppo_grads_bf16
         for kind, fc, head in nets:
             for _ in range(3):
                 launch(kind, fc, head, index)
@@ -40,7 +41,7 @@ def main(n, rows):
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 100.0
             tiles = (n + 15) // 16 / 1024.0
-            print("%-12s kind %d: %.1f us per launch, %.2f us per 16-sample tile per wave" % (label, kind, us, us / tiles))
+            print("%-7s %-12s kind %d: %.1f us per launch, %.2f us per 16-sample tile per wave" % (prec, label, kind, us, us / tiles))
 
 
 if __name__ == "__main__":
