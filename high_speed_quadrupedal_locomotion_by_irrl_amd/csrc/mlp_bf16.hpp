@@ -198,6 +198,24 @@ irrl_mlp_ppo_bf16_kernel(const MlpUpdateArgs a) {
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see the f32 kernel
   load_w1();
+  // A wave issues one MFMA per 16 clocks and, in a burst of MFMAs, nothing else; in a burst of VALU work the matrix core idles
+  // (PMC of the first version: VALU 35 %, MFMA 26 %, LDS 9 %, waiting 20 % of a tile -- one after the other).  So the two are ZIPPED by
+  // hand where independent work exists: an activation / delta element is three small VALU parts (MB_PIN keeps the order), and every
+  // part carries one MFMA of (a) the next output tile's chain of the same layer, (b) the weight-gradient products of the layer
+  // behind -- those of layer 1 are carried over the loop's back edge (their operands wait in registers) and run under the next tile's
+  // first layer.
+#define MB_PIN() __builtin_amdgcn_sched_barrier(0)
+  auto act_a = [&](float x) -> float { return __expf(-2.0f * x); };
+  auto act_b = [&](float e) -> float { return 2.0f * __builtin_amdgcn_rcpf(1.0f + e) - 1.0f; };     // == fast_tanh
+  u16x4_t pat[3][2], pbz[4][2];     // operands of the PENDING d W1 products (zero in front of the first tile)
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int p2 = 0; p2 < 2; p2++) { pbz[i][p2] = (u16x4_t){0, 0, 0, 0}; if (i < 3) pat[i][p2] = (u16x4_t){0, 0, 0, 0}; }
+  auto dw1_mfma = [&](int i) {      // i = 0 .. 35
+    const int nt = i / 9, kt = (i / 3) % 3, q = i % 3;
+    gw1[kt][nt] = BF_MFMA16(pat[kt][PR::A[q]], pbz[nt][PR::B[q]], gw1[kt][nt]);
+  };
 #ifdef IRRL_MB_PROFILE
   float ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long pts_ = wall_clock64();
@@ -210,13 +228,14 @@ irrl_mlp_ppo_bf16_kernel(const MlpUpdateArgs a) {
     row_next = row_of(tile + 2 * stride < ntiles ? tile + 2 * stride : tile);
     const bool valid = tile * 16 + c < a.n;
 
-    // ---- observations: planes as the B operand (k = 8 g + j; 32 + 4 g + j) and into the image for dW1 ----
+    // ---- observations: planes as the B operand (k = 8 g + j; 32 + 8 g + j) and into the image for dW1 ----
     u16x8_t xp[2], xq[2];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       unsigned short pl[2];
       bf_split<2>(cur.x[j], pl);
       xp[0][j] = pl[0]; xp[1][j] = pl[1];
+      if (j < 6) { dw1_mfma(j); MB_PIN(); }
     }
 #pragma unroll
     for (int j = 0; j < 8; j++) {
@@ -229,30 +248,36 @@ irrl_mlp_ppo_bf16_kernel(const MlpUpdateArgs a) {
       *(u16x8_t *)(IX(p) + c * MB_RS + 8 * g) = xp[p];
       if (g == 0) *(u16x4_t *)(IX(p) + c * MB_RS + 32) = (u16x4_t){xq[p][0], xq[p][1], xq[p][2], xq[p][3]};
     }
-    // ---- layer 1: the four output tiles' chains go out first (weights already in `wr`), the activations follow while they run ----
+    // ---- layer 1 ----
     f32x4 h1[4], h2[4];
     u16x4_t h1p[4][2], h2p[4][2];
     {
       f32x4 acc[4];
+      auto chain1 = [&](int nt, int j) {      // MFMA j (0..5) of output tile nt
+        if (j == 0) acc[nt] = *(const f32x4 *)&bias[16 * nt + 4 * g];
+        const int q = j >> 1;
+        if (j & 1) acc[nt] = BF_MFMA32(wr[4 * nt + PR::A[q]], xp[PR::B[q]], acc[nt]);
+        else acc[nt] = BF_MFMA32(wr[4 * nt + 2 + PR::A[q]], xq[PR::B[q]], acc[nt]);
+      };
 #pragma unroll
-      for (int nt = 0; nt < 4; nt++) {
-        acc[nt] = *(const f32x4 *)&bias[16 * nt + 4 * g];
+      for (int j = 0; j < 6; j++) chain1(0, j);
+      MB_PIN();
 #pragma unroll
-        for (int q = 0; q < PR::N; q++) {
-          acc[nt] = BF_MFMA32(wr[4 * nt + 2 + PR::A[q]], xq[PR::B[q]], acc[nt]);
-          acc[nt] = BF_MFMA32(wr[4 * nt + PR::A[q]], xp[PR::B[q]], acc[nt]);
+      for (int st = 0; st < 4; st++) {
+        if (st == 3) { load_w2(); MB_PIN(); }       // every chain of this layer is out: its weight registers take the next layer's
+        float e_[4];
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+          const int r = j / 3, part = j % 3;
+          if (st < 3 && j < 6) chain1(st + 1, j);
+          else dw1_mfma(st < 3 ? 6 + 6 * st + (j - 6) : 24 + j);
+          if (part == 0) e_[r] = act_a(acc[st][r]);
+          else if (part == 1) h1[st][r] = act_b(e_[r]);
+          else { unsigned short pl[2]; bf_split<2>(h1[st][r], pl); h1p[st][0][r] = pl[0]; h1p[st][1][r] = pl[1]; }
+          MB_PIN();
         }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      load_w2();            // lands under the activations
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int nt = 0; nt < 4; nt++) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) h1[nt][r] = fast_tanh(acc[nt][r]);
-        split4(h1[nt], h1p[nt]);
-#pragma unroll
-        for (int p = 0; p < 2; p++) *(u16x4_t *)(IH1(p) + c * MB_RS + 16 * nt + 4 * g) = h1p[nt][p];
+        for (int p = 0; p < 2; p++) *(u16x4_t *)(IH1(p) + c * MB_RS + 16 * st + 4 * g) = h1p[st][p];
       }
     }
     MB_STAMP(0);   // observations + layer 1
@@ -264,24 +289,29 @@ irrl_mlp_ppo_bf16_kernel(const MlpUpdateArgs a) {
 #pragma unroll
         for (int p = 0; p < 2; p++) b[m][p] = pair8(h1p[2 * m][p], h1p[2 * m + 1][p]);
       f32x4 acc[4];
+      auto chain2 = [&](int n2, int j) {
+        if (j == 0) acc[n2] = *(const f32x4 *)&bias[H + 16 * n2 + 4 * g];
+        const int m = j / 3, q = j % 3;
+        acc[n2] = BF_MFMA32(wr[4 * n2 + 2 * m + PR::A[q]], b[m][PR::B[q]], acc[n2]);
+      };
 #pragma unroll
-      for (int n2 = 0; n2 < 4; n2++) {
-        acc[n2] = *(const f32x4 *)&bias[H + 16 * n2 + 4 * g];
+      for (int j = 0; j < 6; j++) chain2(0, j);
+      MB_PIN();
 #pragma unroll
-        for (int m = 0; m < 2; m++)
+      for (int st = 0; st < 4; st++) {
+        if (st == 3) { if (KIND == 0) load_head(); else load_w2t(); MB_PIN(); }
+        float e_[4];
 #pragma unroll
-          for (int q = 0; q < PR::N; q++) acc[n2] = BF_MFMA32(wr[4 * n2 + 2 * m + PR::A[q]], b[m][PR::B[q]], acc[n2]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (KIND == 0) load_head(); else load_w2t();
-      __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < 12; j++) {
+          const int r = j / 3, part = j % 3;
+          if (st < 3 && j < 6) chain2(st + 1, j);
+          if (part == 0) e_[r] = act_a(acc[st][r]);
+          else if (part == 1) h2[st][r] = act_b(e_[r]);
+          else { unsigned short pl[2]; bf_split<2>(h2[st][r], pl); h2p[st][0][r] = pl[0]; h2p[st][1][r] = pl[1]; }
+          MB_PIN();
+        }
 #pragma unroll
-      for (int n2 = 0; n2 < 4; n2++) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) h2[n2][r] = fast_tanh(acc[n2][r]);
-        split4(h2[n2], h2p[n2]);
-#pragma unroll
-        for (int p = 0; p < 2; p++) *(u16x4_t *)(IH2(p) + c * MB_RS + 16 * n2 + 4 * g) = h2p[n2][p];
+        for (int p = 0; p < 2; p++) *(u16x4_t *)(IH2(p) + c * MB_RS + 16 * st + 4 * g) = h2p[st][p];
       }
     }
     MB_STAMP(1);   // layer 2
@@ -345,9 +375,10 @@ irrl_mlp_ppo_bf16_kernel(const MlpUpdateArgs a) {
     if (KIND == 0 || g == 0) gb3 += dz3;
 
     MB_STAMP(2);   // head + loss
-    // ---- backward: head.  In every layer the chain that feeds the next delta (d h = W dz, operands in registers) goes out FIRST, the
-    // weight-gradient products (operands back from the images, transposed) behind it: they run while the VALU forms the delta ----
+    // ---- backward: head.  In every layer the chain that feeds the next delta (d h = W dz, operands in registers) goes out FIRST; the
+    // weight-gradient products (operands back from the images, transposed) are zipped with the VALU parts of that delta ----
     f32x4 d[4];
+    u16x4_t z2[4][2], z1[4][2];
     if (KIND == 0) {
       u16x4_t z3[2];
       split4(dz3, z3);
@@ -360,19 +391,6 @@ irrl_mlp_ppo_bf16_kernel(const MlpUpdateArgs a) {
         for (int q = 0; q < PR::N; q++) d[kt] = BF_MFMA16(w3t[2 * kt + PR::A[q]], z3[PR::B[q]], d[kt]);
       }
       MU_WAVE_SYNC();
-      {
-        const u16x4_t bz[2] = {TR(ID(0), 0), TR(ID(1), 0)};
-        u16x4_t at[4][2];
-#pragma unroll
-        for (int kt = 0; kt < 4; kt++) { at[kt][0] = TR(IH2(0), kt); at[kt][1] = TR(IH2(1), kt); }
-        __builtin_amdgcn_sched_barrier(0);
-        load_w2t();
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kt = 0; kt < 4; kt++)
-#pragma unroll
-          for (int q = 0; q < PR::N; q++) gw3[kt] = BF_MFMA16(at[kt][PR::A[q]], bz[PR::B[q]], gw3[kt]);
-      }
     } else {
 #pragma unroll
       for (int kt = 0; kt < 4; kt++) {
@@ -380,12 +398,29 @@ irrl_mlp_ppo_bf16_kernel(const MlpUpdateArgs a) {
         gw3[kt] += dz3[0] * h2[kt];
       }
     }
-    u16x4_t z2[4][2];
+    {
+      u16x4_t bz[2], at[4][2];
+      if (KIND == 0) {
+        bz[0] = TR(ID(0), 0); bz[1] = TR(ID(1), 0);
 #pragma unroll
-    for (int kt = 0; kt < 4; kt++) {
-      const f32x4 dz = d[kt] * (1.0f - h2[kt] * h2[kt]);
-      gb2[kt] += dz;
-      split4(dz, z2[kt]);
+        for (int kt = 0; kt < 4; kt++) { at[kt][0] = TR(IH2(0), kt); at[kt][1] = TR(IH2(1), kt); }
+        MB_PIN();
+        load_w2t();
+        MB_PIN();
+      }
+#pragma unroll
+      for (int e = 0; e < 16; e++) {
+        const int kt = e >> 2, r = e & 3;
+        float t = 0.0f;
+#pragma unroll
+        for (int part = 0; part < 3; part++) {
+          if (KIND == 0 && part == 0 && e < 12) gw3[e / 3] = BF_MFMA16(at[e / 3][PR::A[e % 3]], bz[PR::B[e % 3]], gw3[e / 3]);
+          if (part == 0) t = d[kt][r] * (1.0f - h2[kt][r] * h2[kt][r]);
+          else if (part == 1) gb2[kt][r] += t;
+          else { unsigned short pl[2]; bf_split<2>(t, pl); z2[kt][0][r] = pl[0]; z2[kt][1][r] = pl[1]; }
+          MB_PIN();
+        }
+      }
     }
     MB_STAMP(3);   // d W3, d h2, d z2
     // ---- layer 2 ----
@@ -411,54 +446,46 @@ irrl_mlp_ppo_bf16_kernel(const MlpUpdateArgs a) {
     }
     MU_WAVE_SYNC();
     {
-      u16x4_t at[4][2];
+      u16x4_t at[4][2], bz[4][2];
 #pragma unroll
-      for (int kt = 0; kt < 4; kt++) { at[kt][0] = TR(IH1(0), kt); at[kt][1] = TR(IH1(1), kt); }
-      __builtin_amdgcn_sched_barrier(0);
+      for (int kt = 0; kt < 4; kt++) { at[kt][0] = TR(IH1(0), kt); at[kt][1] = TR(IH1(1), kt); bz[kt][0] = TR(ID(0), kt); bz[kt][1] = TR(ID(1), kt); }
+      MB_PIN();
       load_w1();          // the next tile's first layer
-      __builtin_amdgcn_sched_barrier(0);
+      MB_PIN();
 #pragma unroll
-      for (int nt = 0; nt < 4; nt++) {
-        const u16x4_t bz[2] = {TR(ID(0), nt), TR(ID(1), nt)};
+      for (int e = 0; e < 16; e++) {
+        const int kt = e >> 2, r = e & 3;
+        float t = 0.0f;
 #pragma unroll
-        for (int kt = 0; kt < 4; kt++)
-#pragma unroll
-          for (int q = 0; q < PR::N; q++) gw2[kt][nt] = BF_MFMA16(at[kt][PR::A[q]], bz[PR::B[q]], gw2[kt][nt]);
+        for (int part = 0; part < 3; part++) {
+          const int i = 3 * e + part, nt = i / 12, k2 = (i / 3) % 4, q = i % 3;
+          gw2[k2][nt] = BF_MFMA16(at[k2][PR::A[q]], bz[nt][PR::B[q]], gw2[k2][nt]);
+          if (part == 0) t = d[kt][r] * (1.0f - h1[kt][r] * h1[kt][r]);
+          else if (part == 1) gb1[kt][r] += t;
+          else { unsigned short pl[2]; bf_split<2>(t, pl); z1[kt][0][r] = pl[0]; z1[kt][1][r] = pl[1]; }
+          MB_PIN();
+        }
       }
     }
-    u16x4_t z1[4][2];
-#pragma unroll
-    for (int kt = 0; kt < 4; kt++) {
-      const f32x4 dz = d[kt] * (1.0f - h1[kt] * h1[kt]);
-      gb1[kt] += dz;
-      split4(dz, z1[kt]);
-    }
     MB_STAMP(4);   // d W2, d h1, d z1
-    // ---- layer 1 ----
+    // ---- layer 1: the delta goes into the image, the operands of d W1 come back transposed and WAIT: the products run under the next tile ----
     MU_WAVE_SYNC();
 #pragma unroll
     for (int nt = 0; nt < 4; nt++)
 #pragma unroll
       for (int p = 0; p < 2; p++) *(u16x4_t *)(ID(p) + c * MB_RS + 16 * nt + 4 * g) = z1[nt][p];
     MU_WAVE_SYNC();
-    {
-      u16x4_t at[3][2];
 #pragma unroll
-      for (int kt = 0; kt < 3; kt++) { at[kt][0] = TR(IX(0), kt); at[kt][1] = TR(IX(1), kt); }
+    for (int kt = 0; kt < 3; kt++) { pat[kt][0] = TR(IX(0), kt); pat[kt][1] = TR(IX(1), kt); }
 #pragma unroll
-      for (int nt = 0; nt < 4; nt++) {
-        const u16x4_t bz[2] = {TR(ID(0), nt), TR(ID(1), nt)};
-#pragma unroll
-        for (int kt = 0; kt < 3; kt++)
-#pragma unroll
-          for (int q = 0; q < PR::N; q++) gw1[kt][nt] = BF_MFMA16(at[kt][PR::A[q]], bz[PR::B[q]], gw1[kt][nt]);
-      }
-    }
+    for (int nt = 0; nt < 4; nt++) { pbz[nt][0] = TR(ID(0), nt); pbz[nt][1] = TR(ID(1), nt); }
     MU_WAVE_SYNC();
     cur = nxt;
     (void)more;
     MB_STAMP(5);   // d W1
   }
+#pragma unroll
+  for (int i = 0; i < 36; i++) dw1_mfma(i);      // the last tile's d W1
 #ifdef IRRL_MB_PROFILE
   gls = (f32x4){ph_[0], ph_[1], ph_[2], ph_[3]};
   if (g == 1) gls = (f32x4){ph_[4], ph_[5], 0.0f, 0.0f};
