@@ -195,6 +195,44 @@ irrl_rollout_persistent_kernel_l16(EnvParams P, EnvState S, float *ob, float *re
 }
 #endif
 
+#if IRRL_LANES_PER_ROBOT == 16
+// THE SAME FOR MlpPolicy (BASELINE config 2's learner): the whole rollout in one launch, a workgroup = 16 robots = four env waves = the
+// four waves of the policy step (two per network).  The policy's 52 KB of weights and biases are copied to LDS ONCE; a step of the
+// policy part is then two short MFMA blocks on LDS operands + the heads (a few us against 8.7 us for the stand-alone launch, whose
+// life is launch + weight fetch), and a step costs the workgroup its own time instead of the slowest of the 1024 env waves.
+// Same device functions, same order: the buffers are bit-identical to the two-launch sequence.
+__global__ void __launch_bounds__(256, 1)
+irrl_rollout_persistent_mlp_kernel_l16(EnvParams P, EnvState S, float *ob, float *reward, uint8_t *done, float *extra, PolicyStepArgs a, int steps) {
+  __shared__ float h1[2][16 * 65], h2[2][16 * 65];
+  __shared__ float terms[16][17];
+  __shared__ float head_w[64 * 17];
+  __shared__ __attribute__((aligned(16))) float wl[MlpLdsImage<64>::FLOATS];
+  mlp_policy_stage_lds<64>(a, wl, head_w, (int)threadIdx.x, 256);
+  const float *noise0 = a.noise;
+  const long long row0 = a.row, rng0 = a.rng_step;
+  const size_t noise_stride = (size_t)a.N * (size_t)a.act_dim;
+  __syncthreads();
+  for (int k = 0; k < steps; k++) {
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));     // (see irrl_rollout_persistent_kernel_l16: keeps the per-lane addresses inside the loop)
+    a.row = row0 + k; a.rng_step = rng0 + k;
+    a.noise = noise0 ? noise0 + (size_t)k * noise_stride : nullptr;
+    mlp_policy_step_body<64, true>(a, (int)blockIdx.x * 16, h1, h2, terms, head_w, wl, tid);
+    __syncthreads();   // this workgroup's clipped actions (and the rollout rows) are stored and visible to its own loads
+    {
+      const int lane_ = tid & 63;
+      const int wave_ = (int)blockIdx.x * 4 + (tid >> 6);
+      int env_ = wave_ * 4 + (lane_ >> 4);
+      const int leg_ = (lane_ >> 2) & 3;
+      const bool valid_ = (env_ < P.n_envs) && ((lane_ & 3) == 0);
+      if (env_ >= P.n_envs) env_ = P.n_envs - 1;
+      irrl_plain::step_body<1>(P, S, env_, leg_, valid_, (const float *)a.clipped, ob, reward, done, extra);
+    }
+    __syncthreads();   // obs / dones / reward of step k are stored and visible: the next policy step reads them
+  }
+}
+#endif
+
 __global__ void __launch_bounds__(256, 1) IRRL_K(irrl_init_kernel)(EnvParams P, EnvState S) {
   IRRL_LANE_PROLOGUE
   irrl::init_body(P, S, env_, leg_, valid_);

@@ -30,6 +30,7 @@ IRRL_DECLARE_KERNELS(_l4)
 extern "C" __global__ void irrl_terminal_kernel(EnvParams, EnvState, uint8_t *);
 extern "C" __global__ void irrl_step_policy_kernel_l16(EnvParams, EnvState, const float *, float *, float *, uint8_t *, float *, PolicyStepArgs);
 extern "C" __global__ void irrl_rollout_persistent_kernel_l16(EnvParams, EnvState, float *, float *, uint8_t *, float *, PolicyStepArgs, int);
+extern "C" __global__ void irrl_rollout_persistent_mlp_kernel_l16(EnvParams, EnvState, float *, float *, uint8_t *, float *, PolicyStepArgs, int);
 
 #include "irrl_config.hpp"
 #include "irrl_state_pool.hpp"
@@ -338,6 +339,53 @@ int irrl_lstm_rollout(irrl_env *h, int steps, int hid, int ob_dim, int act_dim, 
       IRRL_LAUNCH_STEP(h, lane_grid(h, n), h->P, h->S, (const float *)clipped, obs, env_reward, dones, env_extra);
       if (k + 1 < steps && policy(k + 1) != 0) { g_err = "irrl_lstm_rollout: policy step refused its arguments"; return 1; }
     }
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// The MlpPolicy twin of irrl_lstm_rollout (no recurrent state).  fuse == 2 (and a pool the combined kernel is instantiated for: 16 lanes
+// per robot, no meteorite, published contact rule, 64 hidden units, 35 observations): the whole rollout as ONE persistent launch
+// (irrl_rollout_persistent_mlp_kernel_l16); otherwise 2 x steps launches back to back.  Bit-identical buffers either way.
+int irrl_mlp_rollout(irrl_env *h, int steps, int hid, int ob_dim, int act_dim, float *obs, uint8_t *dones, const float *const *mlp_w, const float *pi_w,
+                     const float *pi_b, const float *vf_w, const float *vf_b, const float *logstd, const float *noise, int rng_on, unsigned rng_seed,
+                     long long rng_step, const long long *rng_base, int env_id_offset, float *action, float *clipped, float *value, float *neglogp,
+                     long long row, float *mb_obs, float *mb_actions, float *mb_values, float *mb_neglogp, uint8_t *mb_dones, float *mb_rewards,
+                     float *env_reward, float *env_extra, int fuse, void *hip_stream) {
+  if (need_init(h)) return 1;
+  if (steps < 0 || row < 0 || act_dim != 12 || ob_dim != 35 || hid != 64) { g_err = "irrl_mlp_rollout: steps >= 0, row >= 0, ob 35, act 12, hid 64"; return 1; }
+  if (!(mb_obs && mb_actions && mb_values && mb_neglogp && mb_dones)) { g_err = "irrl_mlp_rollout: the rollout buffers are mandatory"; return 1; }
+  if (!(obs && dones && mlp_w && pi_w && pi_b && vf_w && vf_b && logstd && action && clipped && value && neglogp && env_reward && env_extra)) {
+    g_err = "irrl_mlp_rollout: NULL argument"; return 1;
+  }
+  for (int i = 0; i < 8; i++)
+    if (!mlp_w[i]) { g_err = "irrl_mlp_rollout: the weight table has a NULL entry"; return 1; }
+  HIP_TRY(hipSetDevice(h->device));
+  h->stream = (hipStream_t)hip_stream;
+  const int n = h->P.n_envs;
+  auto noise_at = [&](int k) { return noise ? noise + (size_t)k * (size_t)n * (size_t)act_dim : nullptr; };
+  const bool one_tile = h->lanes == 16 && !h->P.crutial && h->P.contact_rule;
+  if (fuse == 2 && one_tile && steps > 0) {
+    if (!mb_rewards) { g_err = "irrl_mlp_rollout: the persistent path writes the reward rows (mb_rewards is mandatory)"; return 1; }
+    PolicyStepArgs a;
+    a.obs = obs; a.dones = dones; a.states_in = nullptr; a.states_out = nullptr;
+    for (int i = 0; i < 12; i++) a.w[i] = i < 8 ? mlp_w[i] : nullptr;
+    a.pi_w = pi_w; a.pi_b = pi_b; a.vf_w = vf_w; a.vf_b = vf_b; a.logstd = logstd; a.noise = noise;
+    a.action = action; a.clipped = clipped; a.value = value; a.neglogp = neglogp;
+    a.row = row; a.rng_base = rng_base;
+    a.mb_obs = mb_obs; a.mb_actions = mb_actions; a.mb_values = mb_values; a.mb_neglogp = mb_neglogp; a.mb_dones = mb_dones;
+    a.mb_rewards = mb_rewards; a.prev_reward = env_reward;
+    a.rng_step = rng_step; a.rng_seed = rng_seed; a.rng_on = rng_on; a.env_id_offset = (unsigned)env_id_offset;
+    a.N = n; a.ob_dim = ob_dim; a.act_dim = act_dim;
+    hipLaunchKernelGGL(irrl_rollout_persistent_mlp_kernel_l16, dim3((n + 15) / 16), dim3(256), 0, h->stream, h->P, h->S, obs, env_reward, dones, env_extra, a, steps);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
+  for (int k = 0; k < steps; k++) {
+    if (irrl_mlp_policy_step(hid, ob_dim, act_dim, n, obs, dones, mlp_w, pi_w, pi_b, vf_w, vf_b, logstd, noise_at(k), rng_on, rng_seed, rng_step + k, rng_base,
+                             env_id_offset, action, clipped, value, neglogp, row + k, mb_obs, mb_actions, mb_values, mb_neglogp, mb_dones, mb_rewards, env_reward,
+                             hip_stream) != 0) { g_err = "irrl_mlp_rollout: policy step refused its arguments"; return 1; }
+    IRRL_LAUNCH_STEP(h, lane_grid(h, n), h->P, h->S, (const float *)clipped, obs, env_reward, dones, env_extra);
   }
   HIP_TRY(hipGetLastError());
   return 0;

@@ -776,52 +776,10 @@ lstm_policy_step_kernel(PolicyStepArgs a) {
 template <int H>
 __global__ void __launch_bounds__(256)
 mlp_policy_step_kernel(PolicyStepArgs a) {
-  constexpr int LD = H + 1;
-  constexpr int NT = H / 32;                 // 16-column tiles per wave (two waves per net)
-  __shared__ float h1[2][16 * LD], h2[2][16 * LD];
+  __shared__ float h1[2][16 * (H + 1)], h2[2][16 * (H + 1)];
   __shared__ float terms[16][17];
   __shared__ float head_w[H * 17];
-  const int tid = threadIdx.x;
-  const int w = tid >> 6, l = tid & 63;
-  const int col = l & 15, rq = l >> 4;
-  const int net = w >> 1, half = w & 1;
-  const int e0 = blockIdx.x * 16;
-  const long long t = a.row;
-  const long long gstep = a.rng_step + (a.rng_base ? *a.rng_base : 0ll);
-  const int eA = (e0 + col < a.N) ? e0 + col : a.N - 1;
-  const float *__restrict__ w1 = net ? a.w[4] : a.w[0], *__restrict__ b1 = net ? a.w[5] : a.w[1];
-  const float *__restrict__ w2 = net ? a.w[6] : a.w[2], *__restrict__ b2 = net ? a.w[7] : a.w[3];
-  for (int i = tid; i < H * a.act_dim; i += blockDim.x) head_w[i] = a.pi_w[i];
-  if (tid < H) head_w[H * a.act_dim + tid] = a.vf_w[tid];
-  const int ksx = (a.ob_dim + 3) >> 2;
-  f32x4 acc[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; nt++) { const float bv = b1[16 * (half * NT + nt) + col]; acc[nt] = (f32x4){bv, bv, bv, bv}; }
-  for (int kk = 0; kk < ksx; kk++) {
-    const int k = 4 * kk + rq, kc = k < a.ob_dim ? k : a.ob_dim - 1;
-    const float av = (k < a.ob_dim) ? a.obs[(size_t)eA * a.ob_dim + kc] : 0.0f;
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) acc[nt] = PS_MFMA(av, w1[(size_t)kc * H + 16 * (half * NT + nt) + col], acc[nt]);
-  }
-#pragma unroll
-  for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) h1[net][(4 * rq + j) * LD + 16 * (half * NT + nt) + col] = fast_tanh(acc[nt][j]);
-  __syncthreads();
-#pragma unroll
-  for (int nt = 0; nt < NT; nt++) { const float bv = b2[16 * (half * NT + nt) + col]; acc[nt] = (f32x4){bv, bv, bv, bv}; }
-#pragma unroll
-  for (int kk = 0; kk < H / 4; kk++) {
-    const float av = h1[net][col * LD + 4 * kk + rq];
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) acc[nt] = PS_MFMA(av, w2[(size_t)(4 * kk + rq) * H + 16 * (half * NT + nt) + col], acc[nt]);
-  }
-#pragma unroll
-  for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) h2[net][(4 * rq + j) * LD + 16 * (half * NT + nt) + col] = fast_tanh(acc[nt][j]);
-  __syncthreads();
-  policy_heads<H>(a, h2[0], h2[1], LD, head_w, terms, e0, tid, t, gstep);
+  mlp_policy_step_body<H, false>(a, blockIdx.x * 16, h1, h2, terms, head_w, nullptr, (int)threadIdx.x);
 }
 
 // ---- PPO2 clipped-surrogate loss, forward AND backward in one pass (ppo2.py:152-175 + DiagGaussian neglogp / entropy) ----

@@ -133,6 +133,78 @@ LSTM_DEV void policy_heads(const PolicyStepArgs &a, const float *hpi, const floa
 }
 
 #define PS_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b_, c_, 0, 0, 0)
+
+// ---------------------------------------------------------------------------------------------------------------
+// One rollout step of MlpPolicy (policies.py:430-446: separate pi / vf nets of two tanh layers of H units) for the 16 envs e0 .. e0 + 15
+// by one workgroup of 256 threads: waves 0-1 run the pi net, waves 2-3 the vf net, two 16-column tiles each; exact f32 on
+// v_mfma_f32_16x16x4_f32.  a.w[] = pi_w1 [ob][H], pi_b1, pi_w2 [H][H], pi_b2, vf_w1, vf_b1, vf_w2, vf_b2 (plain row-major).
+// LDSW: the eight arrays were copied to LDS once (mlp_policy_stage_lds: the persistent rollout kernel, whose workgroup keeps them for all
+// steps) in the image [net][w1 (ob x H) | b1 (H) | w2 (H x H) | b2 (H)], and the head weights sit in head_w already; otherwise they are
+// read from global memory / staged here (the stand-alone kernel).  Same values, same order of operations: the two agree bit for bit.
+template <int H>
+struct MlpLdsImage { static constexpr int OBMAX = 36, NET = OBMAX * H + H + H * H + H, FLOATS = 2 * NET; };
+template <int H>
+LSTM_DEV void mlp_policy_stage_lds(const PolicyStepArgs &a, float *wl, float *head_w, int tid, int nthr) {
+  for (int net = 0; net < 2; net++) {
+    float *dst = wl + net * MlpLdsImage<H>::NET;
+    const float *w1 = a.w[4 * net], *b1 = a.w[4 * net + 1], *w2 = a.w[4 * net + 2], *b2 = a.w[4 * net + 3];
+    for (int i = tid; i < a.ob_dim * H; i += nthr) dst[i] = w1[i];
+    for (int i = tid; i < H; i += nthr) { dst[MlpLdsImage<H>::OBMAX * H + i] = b1[i]; dst[MlpLdsImage<H>::OBMAX * H + H + H * H + i] = b2[i]; }
+    for (int i = tid; i < H * H; i += nthr) dst[MlpLdsImage<H>::OBMAX * H + H + i] = w2[i];
+  }
+  for (int i = tid; i < H * a.act_dim; i += nthr) head_w[i] = a.pi_w[i];
+  if (tid < H) head_w[H * a.act_dim + tid] = a.vf_w[tid];
+}
+template <int H, bool LDSW>
+LSTM_DEV void mlp_policy_step_body(const PolicyStepArgs &a, const int e0, float (*h1)[16 * (H + 1)], float (*h2)[16 * (H + 1)], float (*terms)[17],
+                                   float *head_w, const float *wl, const int tid) {
+  constexpr int LD = H + 1;
+  constexpr int NT = H / 32;                 // 16-column tiles per wave (two waves per net)
+  const int w = tid >> 6, l = tid & 63;
+  const int col = l & 15, rq = l >> 4;
+  const int net = w >> 1, half = w & 1;
+  const long long t = a.row;
+  const long long gstep = a.rng_step + (a.rng_base ? *a.rng_base : 0ll);
+  const int eA = (e0 + col < a.N) ? e0 + col : a.N - 1;
+  const float *w1, *b1, *w2, *b2;
+  if (LDSW) {
+    const float *base = wl + net * MlpLdsImage<H>::NET;
+    w1 = base; b1 = base + MlpLdsImage<H>::OBMAX * H; w2 = b1 + H; b2 = w2 + H * H;
+  } else {
+    w1 = net ? a.w[4] : a.w[0]; b1 = net ? a.w[5] : a.w[1]; w2 = net ? a.w[6] : a.w[2]; b2 = net ? a.w[7] : a.w[3];
+    for (int i = tid; i < H * a.act_dim; i += 256) head_w[i] = a.pi_w[i];
+    if (tid < H) head_w[H * a.act_dim + tid] = a.vf_w[tid];
+  }
+  const int ksx = (a.ob_dim + 3) >> 2;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++) { const float bv = b1[16 * (half * NT + nt) + col]; acc[nt] = (f32x4){bv, bv, bv, bv}; }
+  for (int kk = 0; kk < ksx; kk++) {
+    const int k = 4 * kk + rq, kc = k < a.ob_dim ? k : a.ob_dim - 1;
+    const float av = (k < a.ob_dim) ? a.obs[(size_t)eA * a.ob_dim + kc] : 0.0f;
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) acc[nt] = PS_MFMA(av, w1[(size_t)kc * H + 16 * (half * NT + nt) + col], acc[nt]);
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) h1[net][(4 * rq + j) * LD + 16 * (half * NT + nt) + col] = fast_tanh(acc[nt][j]);
+  __syncthreads();
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++) { const float bv = b2[16 * (half * NT + nt) + col]; acc[nt] = (f32x4){bv, bv, bv, bv}; }
+#pragma unroll
+  for (int kk = 0; kk < H / 4; kk++) {
+    const float av = h1[net][col * LD + 4 * kk + rq];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) acc[nt] = PS_MFMA(av, w2[(size_t)(4 * kk + rq) * H + 16 * (half * NT + nt) + col], acc[nt]);
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) h2[net][(4 * rq + j) * LD + 16 * (half * NT + nt) + col] = fast_tanh(acc[nt][j]);
+  __syncthreads();
+  policy_heads<H>(a, h2[0], h2[1], LD, head_w, terms, e0, tid, t, gstep);
+}
 #ifdef IRRL_PROFILE_POLICY   /* diagnostic build (tools/policy_phases.py): 100 MHz time stamps of the phases of one workgroup */
 #define IRRL_PS_STAMP() do { __builtin_amdgcn_sched_barrier(0); ts_[tsn_++] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else

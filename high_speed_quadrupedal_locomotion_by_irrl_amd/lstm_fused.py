@@ -359,3 +359,44 @@ def mlp_policy_step(policy, obs, dones, noise=None, rng=None, rollout=None, out=
     if rc != 0:
         raise RuntimeError("irrl_mlp_policy_step failed (rc=%d)" % rc)
     return action, clipped, value, neglogp
+
+
+# how the MlpPolicy rollout is issued by `mlp_policy_rollout`: "persistent" = ONE launch for the whole rollout (csrc/env_kernels.hip
+# irrl_rollout_persistent_mlp_kernel_l16: a workgroup keeps its 16 robots and the policy's weights for all steps), "direct" = 2 x steps
+# launches from one C call.  Same bits.
+MLP_ROLLOUT = os.environ.get("IRRL_MLP_ROLLOUT", "persistent")
+
+
+def mlp_policy_rollout(policy, env_impl, steps, obs, dones, rng, rollout, out, env_reward, env_extra, noise_all=None, fused=None):
+    """MlpPolicy counterpart of `policy_rollout` (irrl_mlp_rollout): `steps` rollout steps from one C call; obs / dones updated in place,
+    rows row .. row + steps - 1 of the rollout buffers written (rewards one row behind, the last one is left in `env_reward`).
+    fused: 2 = one persistent launch, 0 = two launches per step; None: by MLP_ROLLOUT."""
+    lib = _lib.load()
+    N, ob_dim = obs.shape
+    act = policy.act_dim
+    dev = obs.device
+    ws = [policy.pi_fc[0].w, policy.pi_fc[0].b, policy.pi_fc[1].w, policy.pi_fc[1].b,
+          policy.vf_fc[0].w, policy.vf_fc[0].b, policy.vf_fc[1].w, policy.vf_fc[1].b]
+    assert all(t.is_contiguous() for t in ws)
+    warr = (C.c_void_p * 8)(*[t.data_ptr() for t in ws])
+    assert obs.is_contiguous() and dones.is_contiguous() and dones.element_size() == 1
+    assert env_reward.is_contiguous() and env_extra.is_contiguous() and tuple(env_extra.shape) == (N, 6)
+    action, clipped, value, neglogp = out
+    rng_on, seed, step, base, env0 = 0, 0, 0, None, 0
+    if noise_all is not None:
+        assert noise_all.is_contiguous() and tuple(noise_all.shape[1:]) == (N, act) and noise_all.shape[0] >= steps
+    elif rng is not None:
+        rng_on, seed, step = 1, int(rng[0]) & 0xFFFFFFFF, int(rng[1])
+        base = _ptr(rng[2]) if len(rng) > 2 and rng[2] is not None else None
+        env0 = int(rng[3]) if len(rng) > 3 else 0      # global id of env 0 (multi-GPU shards)
+    if fused is None:
+        if MLP_ROLLOUT not in ("persistent", "direct"):
+            raise ValueError("IRRL_MLP_ROLLOUT / lstm_fused.MLP_ROLLOUT is 'persistent' or 'direct', not %r" % (MLP_ROLLOUT,))
+        fused = 2 if MLP_ROLLOUT == "persistent" else 0
+    rc = lib.irrl_mlp_rollout(env_impl._h, int(steps), 64, ob_dim, act, _ptr(obs), _ptr(dones), warr, _ptr(policy.pi.w), _ptr(policy.pi.b),
+                              _ptr(policy.vf.w), _ptr(policy.vf.b), _ptr(policy.logstd), _ptr(noise_all) if noise_all is not None else None,
+                              rng_on, seed, step, base, env0, _ptr(action), _ptr(clipped), _ptr(value), _ptr(neglogp), int(rollout["row"]),
+                              _ptr(rollout["mb_obs"]), _ptr(rollout["mb_actions"]), _ptr(rollout["mb_values"]), _ptr(rollout["mb_neglogpacs"]),
+                              _ptr(rollout["mb_dones"]), _ptr(rollout["mb_rewards"]), _ptr(env_reward), _ptr(env_extra), int(fused),
+                              C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    _lib.check(rc)

@@ -301,6 +301,14 @@ class MlpPolicy(ActorCriticPolicy):
         return action, clipped, value, neglogp, states
 
     @torch.no_grad()
+    def fused_rollout(self, env_impl, steps, obs, states, dones, rng, rollout, out, env_reward, env_extra, noise_all=None, fused=False):
+        """`steps` fused_step + env.step pairs issued by one C call (lstm_fused.mlp_policy_rollout): by default ONE persistent launch for the
+        whole rollout (lstm_fused.MLP_ROLLOUT); fused = 2 / "direct" semantics as in the LSTM policy's."""
+        from . import lstm_fused
+        lstm_fused.mlp_policy_rollout(self, env_impl, steps, obs, dones, rng, rollout, out, env_reward, env_extra, noise_all=noise_all,
+                                      fused=(int(fused) if fused else None))
+
+    @torch.no_grad()
     def step(self, obs, states=None, masks=None, deterministic=False, generator=None, noise=None):
         mean, value = self._run(obs)
         if deterministic:

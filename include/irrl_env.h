@@ -308,6 +308,17 @@ int irrl_mlp_policy_step(int hid, int ob_dim, int act_dim, int N, const float *o
                          float *value, float *neglogp, long long row, float *mb_obs, float *mb_actions, float *mb_values, float *mb_neglogp,
                          uint8_t *mb_dones, float *mb_rewards, const float *prev_reward, void *hip_stream);
 
+/* `steps` consecutive rollout steps of MlpPolicy (policy step t, then env.step on its clipped action) from ONE call -- the MlpPolicy twin of
+ * irrl_lstm_rollout (no recurrent state; mlp_w as in irrl_mlp_policy_step; ob 35, act 12, hid 64).  fuse == 2 and a pool the combined
+ * kernel exists for (16 lanes per robot, Crutial off, published contact rule): the whole rollout as ONE persistent launch -- a workgroup
+ * keeps its 16 robots and the policy's weights (in LDS) for all `steps`, no grid-wide boundary between steps; otherwise 2 x steps launches
+ * back to back.  Bit-identical buffers either way (what ppo2.Runner records as a hipGraph of 2 x steps nodes otherwise). */
+int irrl_mlp_rollout(irrl_env *env, int steps, int hid, int ob_dim, int act_dim, float *obs, uint8_t *dones, const float *const *mlp_w, const float *pi_w,
+                     const float *pi_b, const float *vf_w, const float *vf_b, const float *logstd, const float *noise, int rng_on, unsigned rng_seed,
+                     long long rng_step, const long long *rng_base, int env_id_offset, float *action, float *clipped, float *value, float *neglogp,
+                     long long row, float *mb_obs, float *mb_actions, float *mb_values, float *mb_neglogp, uint8_t *mb_dones, float *mb_rewards,
+                     float *env_reward, float *env_extra, int fuse, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

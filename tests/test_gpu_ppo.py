@@ -616,6 +616,35 @@ def test_graph_capture_warmup_leaves_no_trace_and_setters_invalidate_the_graph()
     assert not torch.equal(out["graph"][1]["obs"], out["graph"][0]["obs"])
 
 
+def test_mlp_rollout_modes_give_the_same_rollouts_bit_for_bit(monkeypatch):
+    """MlpPolicy rollouts (config 2's learner): "persistent" (the default: ONE launch for the whole rollout, a workgroup keeps its 16 robots
+    and the policy's weights in LDS for all steps -- irrl_rollout_persistent_mlp_kernel_l16), "direct" (2 x T launches from one C call,
+    irrl_mlp_rollout), "graph" (one hipGraph of 2 x T nodes) and "eager" (one Python call per launch) agree bit for bit over three
+    rollouts of 160 steps with a reseed in between (in-step resets included when robots fall)."""
+    from high_speed_quadrupedal_locomotion_by_irrl_amd import lstm_fused
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import MlpPolicy
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.ppo2 import PPO2, Runner
+    assert lstm_fused.MLP_ROLLOUT == "persistent"
+    out = {}
+    for mode in ("persistent", "direct", "graph", "eager"):
+        monkeypatch.setattr(lstm_fused, "MLP_ROLLOUT", "direct" if mode == "direct" else "persistent")
+        env = _env(96)
+        model = PPO2(policy=MlpPolicy, env=env, n_steps=160, nminibatches=1, noptepochs=1, seed=9)
+        runner = Runner(env, model, 160, 0.99, 0.998, use_graph=(mode != "eager"))
+        assert runner.rollout_launch == "direct"      # what a Runner picks by itself on the HIP engine: the policy's own rollout call
+        runner.rollout_launch = "direct" if mode in ("direct", "persistent") else "graph"
+        b1 = {k: v.clone() for k, v in runner.run().items() if torch.is_tensor(v)}
+        env.wrapper.setSeed(77)
+        b2 = {k: v.clone() for k, v in runner.run().items() if torch.is_tensor(v)}
+        b3 = {k: v.clone() for k, v in runner.run().items() if torch.is_tensor(v)}
+        out[mode] = (b1, b2, b3)
+    print("[mlp rollout modes] episodes ended inside the three rollouts:", [int(out["eager"][i]["masks"].sum()) for i in range(3)])
+    for mode in ("persistent", "direct", "graph"):
+        for i in range(3):
+            for k in ("obs", "actions", "values", "true_reward", "masks", "neglogpacs", "returns"):
+                assert torch.equal(out[mode][i][k], out["eager"][i][k]), (mode, i, k)
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # Round 4: the optimizer step on flat buffers (ppo2.FlatParams, csrc/ppo_optim.hpp)
 # ------------------------------------------------------------------------------------------------------------------------
