@@ -64,10 +64,12 @@ def parse_args(argv=None):
     ap.add_argument("--ppo-iters", type=int, default=5, help="timed PPO iterations of each learner leg, reported with min / median / max (0 disables)")
     ap.add_argument("--ppo-steps", type=int, default=750, help="rollout length of the PPO leg (the metric's is 750)")
     ap.add_argument("--ppo-epochs", type=int, default=10, help="optimisation epochs of the PPO leg (the metric's is 10)")
-    ap.add_argument("--launch", choices=("auto", "rows", "graph", "python"), default="auto",
-                    help="how the K timed steps are issued: 'rows' = one irrl_env_step_rows call (K back-to-back launches from C), "
-                         "'graph' = one hipGraph of K step-kernel nodes, 'python' = one ctypes call per step; 'auto' (default) = rows for long "
-                         "brackets, for K <= 400 whichever of the three was fastest on this box in two untimed warm-up brackets each")
+    ap.add_argument("--launch", choices=("auto", "persistent", "rows", "graph", "python"), default="auto",
+                    help="how the K timed steps are issued: 'persistent' = ONE launch in which every wave walks its own robots through the K steps "
+                         "(irrl_env_step_rows_persistent: robots never interact, so nothing has to wait for the slowest wave of a step), "
+                         "'rows' = K back-to-back launches from one irrl_env_step_rows call, 'graph' = one hipGraph of K step-kernel nodes, "
+                         "'python' = one ctypes call per step; 'auto' (default) = persistent for long brackets, for K <= 400 whichever of "
+                         "the four was fastest on this box in two untimed warm-up brackets each")
     ap.add_argument("--no-graph", dest="launch", action="store_const", const="python", help="same as --launch python")
     ap.add_argument("--check-steps", type=int, default=2000, help="extra untimed-for-`value` window after the timed region that "
                     "re-measures us/step over a longer run (0 disables); reported as `steady_state_check`")
@@ -231,8 +233,8 @@ def worker(args):
 
     def run(k_steps, mode="rows"):
         s0 = cursor[0]
-        if mode == "rows":
-            env.step_rows(k_steps, actions, s0 % rows, ob, rew, done, extra)
+        if mode in ("rows", "persistent"):
+            env.step_rows(k_steps, actions, s0 % rows, ob, rew, done, extra, persistent=(mode == "persistent"))
         else:
             for k in range(k_steps):
                 env.step(actions[(s0 + k) % rows], ob, rew, done, extra)
@@ -275,7 +277,8 @@ def worker(args):
         run(HOT_STEPS)
         eh = torch.cuda.Event()
         eh.record()
-        call = env.step_rows_call(args.steps, actions, cursor[0] % rows, ob, rew, done, extra) if mode == "rows" else None
+        call = (env.step_rows_call(args.steps, actions, cursor[0] % rows, ob, rew, done, extra, persistent=(mode == "persistent"))
+                if mode in ("rows", "persistent") else None)
         while not eh.query():        # the host thread arrives from work too: it polls through the 12 ms of the hot steps instead of sleeping in the synchronize
             pass
         if barrier and dist is not None:
@@ -283,7 +286,7 @@ def worker(args):
         torch.cuda.synchronize()
         t_start = time.perf_counter()
         e0.record()
-        if mode == "rows":
+        if mode in ("rows", "persistent"):
             call()
             cursor[0] += args.steps
         elif mode == "graph":
@@ -297,20 +300,23 @@ def worker(args):
         torch.cuda.synchronize()
         return time.perf_counter() - t_start
 
-    # HOW the K timed steps are issued.  One irrl_env_step_rows call (K back-to-back launches from C) is the fastest way on most boxes
-    # (no per-step Python / ctypes latency inside the bracket); a hipGraph of K nodes costs ~40 us before its first node runs; one
-    # ctypes call per step adds ~2 us per step.  With the driver's --steps 20 the bracket is 0.9 ms long and box-to-box differences in
-    # launch / wake-up latency are a large part of it, so `--launch auto` (default) tries each way on THIS box during the warm-up
-    # (two untimed brackets of K steps each) and times the one that was fastest.  Long brackets (K > 400) amortise all of it: rows.
-    # (Several ranks: every rank runs the same six probe brackets and picks for its own GPU; the barrier sits around the timed bracket.)
+    # HOW the K timed steps are issued.  The engine's multi-step entry point takes the K action rows resident in HBM and runs the K steps
+    # as ONE launch (irrl_env_step_rows_persistent): robots never interact (VEC:273), so every wave walks its own robots through the K
+    # steps and nothing waits for the slowest wave of a step -- what the fused rollout kernels of the learner do with the env part.  The
+    # other ways keep one launch per step: K back-to-back launches from one C call (rows), a hipGraph of K nodes (~40 us before its
+    # first node runs), one ctypes call per step (+ ~2 us per step; also reported as `per_step_call`: the reference-shaped surface).
+    # With the driver's --steps 20 the bracket is under a millisecond and box-to-box differences in launch / wake-up latency are a
+    # large part of it, so `--launch auto` (default) tries each way on THIS box during the warm-up (two untimed brackets of K steps
+    # each) and times the one that was fastest; all four times are in the line.  Long brackets (K > 400): persistent.
+    # (Several ranks: every rank runs the same probe brackets and picks for its own GPU; the barrier sits around the timed bracket.)
     launch_probe = None
     mode = args.launch
     if mode == "auto":
         if args.steps > 400:
-            mode = "rows"
+            mode = "persistent"
         else:
             launch_probe = {}
-            for cand in ("rows", "graph", "python"):
+            for cand in ("persistent", "rows", "graph", "python"):
                 launch_probe[cand] = min(bracket(cand) for _ in range(2)) * 1e6 / args.steps
             mode = min(launch_probe, key=launch_probe.get)
     if mode == "graph" and args.steps > 20000:
@@ -358,7 +364,14 @@ def worker(args):
         torch.cuda.synchronize()
         cc1 = env.counters()
         us = sorted(1e3 * evs[i].elapsed_time(evs[i + 1]) / per for i in range(parts))
-        check = {"steps": per * parts, "us_per_step": 1e3 * evs[0].elapsed_time(evs[parts]) / (per * parts),
+        pe0, pe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        pe0.record()
+        run(per * parts, "persistent")
+        pe1.record()
+        torch.cuda.synchronize()
+        check = {"what": "one launch per step (irrl_env_step_rows), five consecutive windows; persistent_us_per_step: the same number of steps as ONE launch",
+                 "persistent_us_per_step": 1e3 * pe0.elapsed_time(pe1) / (per * parts),
+                 "steps": per * parts, "us_per_step": 1e3 * evs[0].elapsed_time(evs[parts]) / (per * parts),
                  "us_per_step_min_median_max": [us[0], us[parts // 2], us[-1]], "windows": parts,
                  "contact_fraction": (cc1[1] - cc0[1]) / float(4 * loop_count * n * per * parts), "resets": cc1[0] - cc0[0]}
 
@@ -415,7 +428,10 @@ def worker(args):
             if pmc.get("library") != _lib.version():
                 pmc_note = "profiles/pmc_summary_latest.json was measured on %s, this run is %s: counters withheld" % (pmc.get("library"), _lib.version())
             elif int(pmc.get("envs", 4096)) == n and env.lanes_per_robot == 16 and not args.set and args.cfg == "bp5_imitation.yaml":
-                traffic = float(pmc["hbm_bytes_per_launch"]["total"])
+                if mode == "persistent":      # counters of the persistent kernel (per step of its launches) x the steps of THIS launch
+                    traffic = float(pmc["persistent"]["hbm_bytes_per_step"]["total"]) * args.steps if "persistent" in pmc else None
+                else:
+                    traffic = float(pmc["hbm_bytes_per_launch"]["total"])
                 # how close the single resident wave per SIMD runs to its issue limit of one VALU instruction per 4 cycles
                 issue = {"valu_insts_per_wave": pmc["derived"]["valu_insts_per_wave"], "cycles_per_valu_inst": pmc["derived"]["cycles_per_valu_inst"],
                          "frac_of_single_wave_issue_peak": 4.0 / pmc["derived"]["cycles_per_valu_inst"], "source": "profiles/pmc_summary_latest.json"}
@@ -423,7 +439,8 @@ def worker(args):
             pmc_note = "no usable profiles/pmc_summary_latest.json (%s)" % e
         total_env_steps = float(n) * world * args.steps
         value = total_env_steps / elapsed
-        launch_s = kernel_ms * 1e-3
+        launch_s = kernel_ms * 1e-3         # per STEP (HIP events around the K steps / K)
+        spl = args.steps if mode == "persistent" else 1     # steps one launch of the dominant kernel processes
         ach_gbs = ALG_BYTES_PER_ENV_STEP * n / launch_s / 1e9
         ach_tf = ALG_FLOPS_PER_ENV_STEP * n / launch_s / 1e12
         out = {
@@ -436,17 +453,20 @@ def worker(args):
                                    % (n, args.cfg, (" with " + ", ".join(args.set)) if args.set else "", preroll, HOT_STEPS),
                        "envs_per_gpu": n, "global_envs": n * world, "parallelism": "env-sharded x%d" % world,
                        "lanes_per_robot": env.lanes_per_robot, "preroll": preroll, "hot_steps_before_bracket": HOT_STEPS,
-                       "launch": {"rows": "%d back-to-back launches from one irrl_env_step_rows call" % args.steps,
+                       "launch": {"persistent": "ONE launch: every wave walks its own robots through the %d steps (irrl_env_step_rows_persistent; "
+                                                "robots never interact, VEC:273 -- no grid-wide boundary between steps)" % args.steps,
+                                  "rows": "%d back-to-back launches from one irrl_env_step_rows call" % args.steps,
                                   "graph": "one hipGraph of %d step-kernel nodes" % args.steps,
                                   "python": "one ctypes call per step"}[mode],
                        "launch_probe_us_per_step": launch_probe},
             "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "irrl_step_kernel_l%d" % env.lanes_per_robot, "avg_launch_us": kernel_ms * 1e3,
-                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n},
+                         "kernel": ("irrl_steps_persistent_kernel_l%d" if mode == "persistent" else "irrl_step_kernel_l%d") % env.lanes_per_robot,
+                         "steps_per_launch": spl, "avg_launch_us": kernel_ms * 1e3 * spl, "avg_step_us": kernel_ms * 1e3,
+                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n * spl},
             "roofline_fp32": {"bound": "valu_fp32 (latency/issue bound: 1 wave per SIMD at 4096 envs)", "achieved": ach_tf,
                               "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP32_PEAK_TFLOPS,
-                              "algorithmic_flops_per_launch": ALG_FLOPS_PER_ENV_STEP * n, "valu_issue": issue},
+                              "algorithmic_flops_per_launch": ALG_FLOPS_PER_ENV_STEP * n * spl, "valu_issue": issue},
             "contact_fraction_in_timed_region": contact_fraction, "resets_in_timed_region": resets,
             "steady_state_check": check, "rccl_ranks_seen": ranks_seen, "backend": backend if world > 1 else None,
             "library": lib.irrl_version().decode(), "pmc_note": pmc_note, "per_step_call": per_call, "per_step_call_compiled": per_call_native,

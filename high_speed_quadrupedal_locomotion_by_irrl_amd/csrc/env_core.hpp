@@ -214,6 +214,11 @@ IRRL_DEV void model_nominal(LegModel &m, vi leg) {
 }
 // ENV:435-477 with the counter RNG (purposes DR_*); identical draw addresses in the oracle
 IRRL_DEV void model_randomize(LegModel &m, vi leg, vu seed, vu env, vu episode) {
+  // No contraction in here: which multiply-add pairs of these expressions fuse must not depend on the kernel the function is inlined into --
+  // with RandomizePerEpisode the in-step reset runs it inside the step kernel, the multi-step persistent kernels and the rollout kernels,
+  // which promise bit-identical pools (round 4: the persistent launch's robots left the step kernel's by an ulp of a link mass after
+  // their first reset).  Runs once per episode: the cost is nothing.
+#pragma clang fp contract(off)
   model_nominal(m, leg);
   vf u[16];
   rng4 r = philox_u01(seed, env, episode, 0u, IRRL_P_DR_MATERIAL);

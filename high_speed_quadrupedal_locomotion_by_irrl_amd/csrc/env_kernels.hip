@@ -233,6 +233,42 @@ irrl_rollout_persistent_mlp_kernel_l16(EnvParams P, EnvState S, float *ob, float
 }
 #endif
 
+// `count` CONSECUTIVE env.step()s IN ONE LAUNCH (irrl_env_step_rows_persistent): step k takes action row (first_row + k) % n_rows of a table
+// resident in HBM.  Robots never interact (VEC:273), so a wave simply walks its own robots through the `count` steps: no grid-wide
+// boundary between steps -- a step costs a wave its own time (mean 33.7 us at 4096 envs) instead of the slowest of the 1024 waves
+// (40.8 us), and the launch boundaries are gone.  The body of a step is the step kernel's (same device function, same order): states
+// and outputs are bit-identical to `count` launches.  A wave's stores of step k and its loads of step k + 1 touch the same addresses
+// from the same lanes, in program order.  Default pool kind only (no meteorite, published rule); the launcher falls back otherwise.
+__global__ void __launch_bounds__(256, 1)
+IRRL_K(irrl_steps_persistent_kernel)(EnvParams P, EnvState S, const float *action_rows, int n_rows, int first_row, int count, float *ob, float *reward,
+                                     uint8_t *done, float *extra) {
+  const int blk = irrl_xcd_block();
+  const size_t row = (size_t)P.n_envs * 12;
+  for (int k = 0; k < count; k++) {
+    // threadIdx.x made opaque once per iteration: the per-lane addresses are then computed inside the loop (hoisted, they are
+    // hundreds of 64-bit values that spill)
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane_ = tid & 63;
+#if IRRL_LANES_PER_ROBOT == 16
+    const int wave_ = blk * (int)(blockDim.x >> 6) + (tid >> 6);
+    int env_ = wave_ * 4 + (lane_ >> 4);
+    const int leg_ = (lane_ >> 2) & 3;
+    const bool valid_ = (env_ < P.n_envs) && ((lane_ & 3) == 0);
+    if (env_ >= P.n_envs) env_ = P.n_envs - 1;
+#else
+    int env_ = (blk * (int)(blockDim.x >> 6) + (tid >> 6)) * 16 + (lane_ >> 2);
+    const int leg_ = lane_ & 3;
+    const bool valid_ = env_ < P.n_envs;
+    if (!valid_) env_ = P.n_envs - 1;
+#endif
+    const float *action = action_rows + row * (size_t)((first_row + k) % n_rows);
+    irrl_plain::step_body<1>(P, S, env_, leg_, valid_, action, ob, reward, done, extra);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
 __global__ void __launch_bounds__(256, 1) IRRL_K(irrl_init_kernel)(EnvParams P, EnvState S) {
   IRRL_LANE_PROLOGUE
   irrl::init_body(P, S, env_, leg_, valid_);

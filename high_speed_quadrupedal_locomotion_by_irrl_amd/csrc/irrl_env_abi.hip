@@ -21,6 +21,7 @@
   extern "C" __global__ void irrl_step_kernel_dir##sfx(EnvParams, EnvState, const float *, float *, float *, uint8_t *, float *); \
   extern "C" __global__ void irrl_step_kernel_crutial##sfx(EnvParams, EnvState, const float *, float *, float *, uint8_t *, float *); \
   extern "C" __global__ void irrl_step_kernel_crutial_md##sfx(EnvParams, EnvState, const float *, float *, float *, uint8_t *, float *); \
+  extern "C" __global__ void irrl_steps_persistent_kernel##sfx(EnvParams, EnvState, const float *, int, int, int, float *, float *, uint8_t *, float *); \
   extern "C" __global__ void irrl_init_kernel##sfx(EnvParams, EnvState);                                                       \
   extern "C" __global__ void irrl_reset_kernel##sfx(EnvParams, EnvState, float *);                                             \
   extern "C" __global__ void irrl_observe_kernel##sfx(EnvParams, EnvState, float *);                                           \
@@ -268,6 +269,19 @@ int irrl_env_step_rows(irrl_env *h, int count, const float *action_rows, int n_r
     const float *action = action_rows + row * (size_t)((first_row + k) % n_rows);
     IRRL_LAUNCH_STEP(h, lane_grid(h, h->P.n_envs), h->P, h->S, action, ob, reward, done, extra);
   }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// the same `count` steps as ONE launch (env_kernels.hip irrl_steps_persistent_kernel: a wave walks its robots through all of them, no
+// grid-wide boundary between steps); pools the kernel is not instantiated for (meteorite, first contact rule) take irrl_env_step_rows
+int irrl_env_step_rows_persistent(irrl_env *h, int count, const float *action_rows, int n_rows, int first_row, float *ob, float *reward,
+                                  uint8_t *done, float *extra) {
+  if (need_init(h)) return 1;
+  if (count < 0 || n_rows <= 0 || first_row < 0) { g_err = "irrl_env_step_rows_persistent: count >= 0, n_rows > 0, first_row >= 0"; return 1; }
+  if (h->P.crutial || !h->P.contact_rule) return irrl_env_step_rows(h, count, action_rows, n_rows, first_row, ob, reward, done, extra);
+  if (use_device(h)) return 1;
+  if (count > 0) IRRL_LAUNCH(h, irrl_steps_persistent_kernel, lane_grid(h, h->P.n_envs), h->P, h->S, action_rows, n_rows, first_row, count, ob, reward, done, extra);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -120,20 +120,21 @@ class FlexibleGymEnv(object):
                 self._h, _np_f32(action, (n, 12), "action"), _np_f32(ob, (n, 35), "ob"), _np_f32(reward, (n,), "reward"),
                 _np_bool(done, (n,), "done"), _np_f32(extraInfo, (n, 6), "extraInfo")))
 
-    def step_rows(self, count, action_rows, first_row, ob, reward, done, extraInfo):
+    def step_rows(self, count, action_rows, first_row, ob, reward, done, extraInfo, persistent=False):
         """build-defined: `count` consecutive steps from a device-resident action table [rows, N, 12] (step k takes row
-        (first_row + k) % rows) in one call -- the launches go out back to back from C (irrl_env_step_rows)"""
+        (first_row + k) % rows) in one call -- the launches go out back to back from C (irrl_env_step_rows), or, with persistent=True,
+        as ONE launch in which every wave walks its own robots through all the steps (irrl_env_step_rows_persistent; same bits)"""
         import torch
         n = self._n
         rows = int(action_rows.shape[0])
         self._sync_stream()
         f32 = (torch.float32,)
-        _lib.check(self._lib.irrl_env_step_rows(
+        _lib.check((self._lib.irrl_env_step_rows_persistent if persistent else self._lib.irrl_env_step_rows)(
             self._h, int(count), _dev_ptr(action_rows, (rows, n, 12), f32, "action_rows"), rows, int(first_row),
             _dev_ptr(ob, (n, 35), f32, "ob"), _dev_ptr(reward, (n,), f32, "reward"),
             _dev_ptr(done, (n,), (torch.bool, torch.uint8), "done"), _dev_ptr(extraInfo, (n, 6), f32, "extraInfo")))
 
-    def step_rows_call(self, count, action_rows, first_row, ob, reward, done, extraInfo):
+    def step_rows_call(self, count, action_rows, first_row, ob, reward, done, extraInfo, persistent=False):
         """the same call with its arguments checked and marshalled NOW: returns a zero-argument callable that only issues the
         launches (for callers that time them: bench.py's 20-step bracket is 0.8 ms long and the checks above cost ~15 us)"""
         import torch
@@ -144,7 +145,7 @@ class FlexibleGymEnv(object):
         args = (self._h, int(count), _dev_ptr(action_rows, (rows, n, 12), f32, "action_rows"), rows, int(first_row),
                 _dev_ptr(ob, (n, 35), f32, "ob"), _dev_ptr(reward, (n,), f32, "reward"),
                 _dev_ptr(done, (n,), (torch.bool, torch.uint8), "done"), _dev_ptr(extraInfo, (n, 6), f32, "extraInfo"))
-        fn = self._lib.irrl_env_step_rows
+        fn = self._lib.irrl_env_step_rows_persistent if persistent else self._lib.irrl_env_step_rows
         return lambda: _lib.check(fn(*args))
 
     def testStep(self, action, ob, reward, done, extraInfo):

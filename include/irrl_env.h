@@ -70,6 +70,11 @@ int irrl_env_step_host(irrl_env *h, const float *action, float *ob, float *rewar
  * host round trip per step.  Outputs as irrl_env_step (those of the last step survive). */
 int irrl_env_step_rows(irrl_env *h, int count, const float *action_rows, int n_rows, int first_row, float *ob, float *reward,
                        uint8_t *done, float *extra);
+/* the same `count` steps as ONE launch: a wave walks its own robots through all of them (robots never interact, VEC:273), so there is no
+ * grid-wide boundary between steps and no launch per step.  States and outputs bit-identical to irrl_env_step_rows (which it falls back
+ * to for pools with the meteorite or the build's first contact rule). */
+int irrl_env_step_rows_persistent(irrl_env *h, int count, const float *action_rows, int n_rows, int first_row, float *ob, float *reward,
+                                  uint8_t *done, float *extra);
 /* PYB:24 testStep -> VEC:280-290: env 0 only in the reference (visual eval); here it steps env 0 only and
  * leaves rows 1.. of the outputs untouched (headless: no rendering). */
 int irrl_env_test_step_host(irrl_env *h, const float *action, float *ob, float *reward, uint8_t *done, float *extra);

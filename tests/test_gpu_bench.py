@@ -53,6 +53,33 @@ def test_step_rows_equals_the_same_steps_one_by_one():
             a.impl.step_rows(-1, table, 0, *outs[0])
 
 
+@pytest.mark.parametrize("n,cfg_name,over", [(4096, "bp5_imitation.yaml", {}), (330, "default_cfg.yaml", {}), (8192, "bp5_terrain.yaml", {}),
+                                             (96, "default_cfg.yaml", {"Crutial": True})])
+def test_persistent_multi_step_launch_equals_back_to_back_launches(n, cfg_name, over):
+    """irrl_env_step_rows_persistent (ONE launch: every wave walks its own robots through all K steps, no grid-wide boundary between
+    steps) leaves the pool and the outputs bit-identical to irrl_env_step_rows (K launches): 400 steps with in-step resets, in the
+    16-lane layout (4096 and a ragged 330), the 4-lane layout (8192 envs, rough ground) and a Crutial pool (the launcher's fallback)."""
+    import torch
+    from hip_env import HipVecEnv
+    K, rows = 400, 64
+    a, b = HipVecEnv(load_env_cfg(cfg_name, num_envs=n, **over)), HipVecEnv(load_env_cfg(cfg_name, num_envs=n, **over))
+    assert a.impl.lanes_per_robot == (4 if n > 6144 else 16)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    table = (0.5 * torch.randn(rows, n, 12, device="cuda", generator=g)).clamp(-1, 1)
+    outs = [(torch.zeros(n, 35, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(n, dtype=torch.bool, device="cuda"), torch.zeros(n, 6, device="cuda"))
+            for _ in range(2)]
+    c0 = a.impl.counters()
+    a.impl.step_rows(K, table, 11, *outs[0], persistent=True)
+    b.impl.step_rows(K, table, 11, *outs[1])
+    torch.cuda.synchronize()
+    for x, y in zip(outs[0], outs[1]):
+        assert torch.equal(x, y)
+    np.testing.assert_array_equal(a.get_state(), b.get_state())
+    assert a.impl.counters()[0] - c0[0] > 0          # episodes ended and restarted inside the launch
+    with pytest.raises(RuntimeError, match="step_rows"):
+        a.impl.step_rows(-1, table, 0, *outs[0], persistent=True)
+
+
 def test_counters_see_landing_and_resets():
     from hip_env import HipVecEnv
     n = 64

@@ -616,11 +616,14 @@ def test_graph_capture_warmup_leaves_no_trace_and_setters_invalidate_the_graph()
     assert not torch.equal(out["graph"][1]["obs"], out["graph"][0]["obs"])
 
 
-def test_mlp_rollout_modes_give_the_same_rollouts_bit_for_bit(monkeypatch):
+@pytest.mark.parametrize("cfg", ["default_cfg.yaml", "bp5_terrain.yaml"])
+def test_mlp_rollout_modes_give_the_same_rollouts_bit_for_bit(monkeypatch, cfg):
     """MlpPolicy rollouts (config 2's learner): "persistent" (the default: ONE launch for the whole rollout, a workgroup keeps its 16 robots
     and the policy's weights in LDS for all steps -- irrl_rollout_persistent_mlp_kernel_l16), "direct" (2 x T launches from one C call,
     irrl_mlp_rollout), "graph" (one hipGraph of 2 x T nodes) and "eager" (one Python call per launch) agree bit for bit over three
-    rollouts of 160 steps with a reseed in between (in-step resets included when robots fall)."""
+    rollouts of 160 steps with a reseed in between (in-step resets included when robots fall) -- on the training configuration and on
+    bp5_terrain.yaml, whose in-step resets re-draw every robot's masses / centres of mass / friction (RandomizePerEpisode: the persistent
+    kernels' robots once left the step kernel's by an ulp there, csrc/env_core.hpp model_randomize)."""
     from high_speed_quadrupedal_locomotion_by_irrl_amd import lstm_fused
     from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import MlpPolicy
     from high_speed_quadrupedal_locomotion_by_irrl_amd.ppo2 import PPO2, Runner
@@ -628,7 +631,7 @@ def test_mlp_rollout_modes_give_the_same_rollouts_bit_for_bit(monkeypatch):
     out = {}
     for mode in ("persistent", "direct", "graph", "eager"):
         monkeypatch.setattr(lstm_fused, "MLP_ROLLOUT", "direct" if mode == "direct" else "persistent")
-        env = _env(96)
+        env = _env(96, cfg)
         model = PPO2(policy=MlpPolicy, env=env, n_steps=160, nminibatches=1, noptepochs=1, seed=9)
         runner = Runner(env, model, 160, 0.99, 0.998, use_graph=(mode != "eager"))
         assert runner.rollout_launch == "direct"      # what a Runner picks by itself on the HIP engine: the policy's own rollout call

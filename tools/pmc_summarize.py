@@ -10,6 +10,7 @@ root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 name = sys.argv[1] if len(sys.argv) > 1 else "pmc_summary"
 per = {}
 calib = {}
+pers = {}
 for d in sorted(glob.glob(os.path.join(root, "gpurun_out", "pmc_env_*"))):
     if not os.path.isdir(d):
         continue
@@ -21,6 +22,8 @@ for d in sorted(glob.glob(os.path.join(root, "gpurun_out", "pmc_env_*"))):
         k, c, v = r["Kernel_Name"], r["Counter_Name"], float(r["Counter_Value"])
         if k.startswith("irrl_step_kernel"):
             per.setdefault(k, {}).setdefault(c, []).append(v)
+        elif k.startswith("irrl_steps_persistent_kernel"):
+            pers.setdefault(c, []).append(v)
         elif k.startswith("irrl_calib_copy_kernel"):
             calib.setdefault(c, []).append(v)
 step_name = max(per, key=lambda k: len(next(iter(per[k].values()))))
@@ -44,6 +47,18 @@ out = {"envs": 4096, "kernel": step_name, "library": open(ver_file).read().strip
                    "wait_inst_any_fraction": m("SQ_WAIT_INST_ANY") / m("SQ_WAVE_CYCLES"),
                    "l2_hit_rate": m("TCC_HIT_sum") / (m("TCC_HIT_sum") + m("TCC_MISS_sum")),
                    "note": "SQ_WAVE_CYCLES etc. are in units of 4 clocks (quad-cycles)"}}
+if pers:      # the multi-step persistent kernel: tools/pmc_workload.py issues launches of 100 steps each
+    PERSIST_STEPS = 100
+    pm = {c: statistics.median(v) for c, v in pers.items()}
+    prd, pwr = pm["FETCH_SIZE"] * 1024.0 * cal["fetch_correction"], pm["WRITE_SIZE"] * 1024.0 * cal["write_correction"]
+    out["persistent"] = {"kernel": "irrl_steps_persistent_kernel_l16", "steps_per_launch": PERSIST_STEPS, "launches": len(pers["FETCH_SIZE"]),
+                         "hbm_bytes_per_launch": {"read": prd, "written": pwr, "total": prd + pwr},
+                         "hbm_bytes_per_step": {"read": prd / PERSIST_STEPS, "written": pwr / PERSIST_STEPS, "total": (prd + pwr) / PERSIST_STEPS, "algorithmic": 1521 * 4096},
+                         "derived": {"valu_insts_per_wave_per_step": pm["SQ_INSTS_VALU"] / pm["SQ_WAVES"] / PERSIST_STEPS,
+                                     "cycles_per_valu_inst": 4.0 * pm["SQ_WAVE_CYCLES"] / pm["SQ_INSTS_VALU"],
+                                     "valu_active_fraction": pm["SQ_ACTIVE_INST_VALU"] / pm["SQ_WAVE_CYCLES"],
+                                     "wait_inst_any_fraction": pm["SQ_WAIT_INST_ANY"] / pm["SQ_WAVE_CYCLES"],
+                                     "l2_hit_rate": pm["TCC_HIT_sum"] / (pm["TCC_HIT_sum"] + pm["TCC_MISS_sum"])}}
 for fn in (name + ".json", "pmc_summary_latest.json"):
     json.dump(out, open(os.path.join(root, "profiles", fn), "w"), indent=1)
-print(json.dumps({k: out[k] for k in ("kernel", "hbm_bytes_per_launch", "derived")}, indent=1))
+print(json.dumps({k: out[k] for k in ("kernel", "hbm_bytes_per_launch", "derived", "persistent") if k in out}, indent=1))

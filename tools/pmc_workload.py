@@ -43,5 +43,9 @@ done = torch.zeros(envs, dtype=torch.bool, device=dev)
 extra = torch.zeros(envs, 6, device=dev)
 for k in range(rows):
     env.step(actions[k], ob, rew, done, extra)
+# the multi-step persistent kernel (bench.py --launch persistent): five launches of PERSIST_STEPS steps each from the same steady state
+PERSIST_STEPS = 100
+for i in range(5):
+    env.step_rows(PERSIST_STEPS, actions, (i * PERSIST_STEPS) % rows, ob, rew, done, extra, persistent=True)
 torch.cuda.synchronize()
 print("ok", float(rew.mean()))
