@@ -302,11 +302,12 @@ class MlpPolicy(ActorCriticPolicy):
 
     @torch.no_grad()
     def fused_rollout(self, env_impl, steps, obs, states, dones, rng, rollout, out, env_reward, env_extra, noise_all=None, fused=False):
-        """`steps` fused_step + env.step pairs issued by one C call (lstm_fused.mlp_policy_rollout): by default ONE persistent launch for the
-        whole rollout (lstm_fused.MLP_ROLLOUT); fused = 2 / "direct" semantics as in the LSTM policy's."""
+        """`steps` fused_step + env.step pairs issued by one C call (lstm_fused.mlp_policy_rollout): ONE persistent launch for the whole
+        rollout, or 2 x steps launches -- by lstm_fused.MLP_ROLLOUT / IRRL_MLP_ROLLOUT ("persistent" by default; `fused` is the LSTM
+        policy's switch and not looked at here)."""
         from . import lstm_fused
         lstm_fused.mlp_policy_rollout(self, env_impl, steps, obs, dones, rng, rollout, out, env_reward, env_extra, noise_all=noise_all,
-                                      fused=(int(fused) if fused else None))
+                                      fused=None)
 
     @torch.no_grad()
     def step(self, obs, states=None, masks=None, deterministic=False, generator=None, noise=None):

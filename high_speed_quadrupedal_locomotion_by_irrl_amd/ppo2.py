@@ -443,9 +443,10 @@ class Runner(object):
         # re-capture after a setter, start sooner and run ~0.5 us per kernel shorter than graph nodes (ROCm 7.2, MI355X)
         self.rollout_launch = "direct" if (self._fused and hasattr(model.policy, "fused_rollout") and hasattr(getattr(env, "wrapper", None), "_h")
                                            and hasattr(env, "extra")) else "graph"
-        # 0 = two launches per step, 1 = env.step k + policy step k + 1 in one kernel (an experiment, slower), 2 = the whole rollout as ONE
-        # persistent launch (a workgroup loops over all steps for its 16 robots; falls back to 0 where the kernel is not instantiated)
-        self.rollout_one_launch_per_step = int(os.environ.get("IRRL_ROLLOUT_FUSED", "0"))
+        # 0 = two launches per step, 1 = env.step k + policy step k + 1 in one kernel (an experiment, slower), 2 (default) = the whole rollout as
+        # ONE persistent launch (a workgroup loops over all steps for its 16 robots: nothing waits for the slowest wave of a step; falls back
+        # to 0 where the kernel is not instantiated).  Same bits.  (MlpPolicy: lstm_fused.MLP_ROLLOUT, persistent by default as well.)
+        self.rollout_one_launch_per_step = int(os.environ.get("IRRL_ROLLOUT_FUSED", "2"))
         self._raw_env = hasattr(env, "step_into") and hasattr(env, "account_rollout") and dev.type == "cuda"
         # sampling noise: "kernel" = the engine's counter RNG inside the fused policy kernel (fused path only; the generic
         # path draws from the model's generator per step), "torch" = standard normals for the whole rollout drawn up front

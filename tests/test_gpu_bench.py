@@ -122,8 +122,20 @@ def test_bench_single_gpu_line_is_steady_state():
     assert out["n_gpus"] == 1 and out["steps"] == 20 and out["warmup"] == 5
     assert out["contact_fraction_in_timed_region"] > 0.1 and out["resets_in_timed_region"] > 0
     assert out["config"]["preroll"] >= 200
-    # the 20-step timed region and the 200-step check window measure the same regime
-    assert abs(out["roofline"]["avg_launch_us"] - out["steady_state_check"]["us_per_step"]) < 0.10 * out["steady_state_check"]["us_per_step"]
+    # the 20-step timed region and the 200-step check window measure the same regime: the timed kernel against the check's figure for the
+    # same way of launching (one launch per step, or ONE persistent launch for all the steps -- what `--launch auto` picked on this box)
+    r, chk = out["roofline"], out["steady_state_check"]
+    assert r["steps_per_launch"] in (1, 20) and abs(r["avg_launch_us"] - r["steps_per_launch"] * r["avg_step_us"]) < 1e-6 * r["avg_launch_us"]
+    assert r["algorithmic_bytes_per_launch"] == 1521.0 * 4096 * r["steps_per_launch"]
+    ref_us = chk["persistent_us_per_step"] if r["steps_per_launch"] > 1 else chk["us_per_step"]
+    assert abs(r["avg_step_us"] - ref_us) < 0.15 * ref_us
+    assert set(out["config"]["launch_probe_us_per_step"]) == {"persistent", "rows", "graph", "python"}
+
+
+def test_bench_every_launch_mode_gives_a_line():
+    for mode in ("persistent", "rows", "graph", "python"):
+        out = _run_bench(["--steps", "20", "--warmup", "5", "--ppo-iters", "0", "--cpu-seconds", "0", "--check-steps", "0", "--launch", mode], {"IRRL_BENCH_NATIVE": "0"})
+        assert out["roofline"]["steps_per_launch"] == (20 if mode == "persistent" else 1) and out["value"] > 5e7, (mode, out["value"])
 
 
 def test_bench_gpus_2_runs_two_ranks_with_the_ppo_collectives():

@@ -33,7 +33,7 @@ mkdir -p "$O"
 line() { python3 -c "import sys,json
 for l in sys.stdin:
     if l.startswith('{') and 'metric' in l:
-        d=json.loads(l); print('$1', round(d['value']/1e6,2), 'M env-steps/s', round(d['roofline']['avg_launch_us'],2), 'us per launch', 'fp32_frac', round(d['roofline_fp32']['frac'],4))"; }
+        d=json.loads(l); print('$1', round(d['value']/1e6,2), 'M env-steps/s', round(d['roofline']['avg_step_us'],2), 'us per step', 'fp32_frac', round(d['roofline_fp32']['frac'],4))"; }
 while [ $# -gt 0 ]; do
   stage=$1; shift
   case $stage in
@@ -55,7 +55,8 @@ while [ $# -gt 0 ]; do
     sweep)
       rm -f $O/sweep.log
       for n in 1024 4096 8192 16384 32768 131072; do
-        timeout 300 python bench.py --cpu-seconds 0 --ppo-iters 0 --steps 1000 --warmup 100 --check-steps 0 --envs $n 2>/dev/null | line "envs=$n" >> $O/sweep.log
+        timeout 300 python bench.py --cpu-seconds 0 --ppo-iters 0 --steps 1000 --warmup 100 --check-steps 0 --envs $n --launch rows 2>/dev/null | line "envs=$n, one launch per step:" >> $O/sweep.log
+        timeout 300 python bench.py --cpu-seconds 0 --ppo-iters 0 --steps 1000 --warmup 100 --check-steps 0 --envs $n --launch persistent 2>/dev/null | line "envs=$n, ONE persistent launch:" >> $O/sweep.log
       done
       timeout 300 python tools/host_boundary_rate.py >> $O/sweep.log 2>&1 ;;
     gloo8)
