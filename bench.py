@@ -262,7 +262,7 @@ def worker(args):
             graph_cache["g"] = g
         return graph_cache["g"]
 
-    def bracket(mode, events=None, barrier=False):
+    def bracket(mode, events=None, barrier=False, counters=None):
         """args.steps env steps issued in `mode`, bracketed by (barrier +) synchronize on both sides -> wall seconds.  Completion is first
         seen by polling the closing event (hipEventQuery), then confirmed by torch.cuda.synchronize(): on some boxes of this pool a host
         thread BLOCKED in the synchronize behind a short burst is woken up milliseconds late (profiles/r04_burst_wakeup.log: 20 steps =
@@ -275,6 +275,8 @@ def worker(args):
         g = make_graph() if mode == "graph" else None
         e0, e1 = events if events is not None else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         run(HOT_STEPS)
+        if counters is not None:
+            env.counters_into(counters)       # stream-ordered, behind the hot steps: what the kernels have counted up to the timed region
         eh = torch.cuda.Event()
         eh.record()
         call = (env.step_rows_call(args.steps, actions, cursor[0] % rows, ob, rew, done, extra, persistent=(mode == "persistent"))
@@ -323,9 +325,8 @@ def worker(args):
         mode = "rows"
     # the kernels' counters are summed on the device, stream-ordered: no read-back (idle GPU) right before the timed region
     cnt0, cnt1 = torch.zeros(3, dtype=torch.int64, device=dev), torch.zeros(3, dtype=torch.int64, device=dev)
-    env.counters_into(cnt0)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    elapsed = bracket(mode, (ev0, ev1), barrier=True)   # barrier + synchronize | K steps | synchronize (+ barrier below); the MAX over ranks is taken below
+    elapsed = bracket(mode, (ev0, ev1), barrier=True, counters=cnt0)   # barrier + synchronize | K steps | synchronize (+ barrier below); the MAX over ranks is taken below
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -433,8 +434,14 @@ def worker(args):
                 else:
                     traffic = float(pmc["hbm_bytes_per_launch"]["total"])
                 # how close the single resident wave per SIMD runs to its issue limit of one VALU instruction per 4 cycles
-                issue = {"valu_insts_per_wave": pmc["derived"]["valu_insts_per_wave"], "cycles_per_valu_inst": pmc["derived"]["cycles_per_valu_inst"],
-                         "frac_of_single_wave_issue_peak": 4.0 / pmc["derived"]["cycles_per_valu_inst"], "source": "profiles/pmc_summary_latest.json"}
+                if mode == "persistent" and "persistent" in pmc:
+                    pd = pmc["persistent"]["derived"]
+                    issue = {"valu_insts_per_wave_per_step": pd["valu_insts_per_wave_per_step"], "cycles_per_valu_inst": pd["cycles_per_valu_inst"],
+                             "frac_of_single_wave_issue_peak": 4.0 / pd["cycles_per_valu_inst"], "l2_hit_rate": pd["l2_hit_rate"],
+                             "source": "profiles/pmc_summary_latest.json (irrl_steps_persistent_kernel_l16, launches of 100 steps)"}
+                else:
+                    issue = {"valu_insts_per_wave": pmc["derived"]["valu_insts_per_wave"], "cycles_per_valu_inst": pmc["derived"]["cycles_per_valu_inst"],
+                             "frac_of_single_wave_issue_peak": 4.0 / pmc["derived"]["cycles_per_valu_inst"], "source": "profiles/pmc_summary_latest.json"}
         except Exception as e:
             pmc_note = "no usable profiles/pmc_summary_latest.json (%s)" % e
         total_env_steps = float(n) * world * args.steps
