@@ -66,7 +66,7 @@ while [ $# -gt 0 ]; do
       IRRL_BENCH_BACKEND=gloo IRRL_BENCH_ONE_DEVICE=1 OMP_NUM_THREADS=2 timeout 1500 python bench.py --gpus 8 --ppo-iters ${GLOO8_PPO_ITERS:-2} > $O/bench_gloo8.log 2>&1; echo "rc=$?" >> $O/bench_gloo8.log
       IRRL_BENCH_BACKEND=gloo IRRL_BENCH_ONE_DEVICE=1 OMP_NUM_THREADS=2 timeout 900 python bench.py --gpus 8 --cfg bp5_terrain.yaml --ppo-iters 0 > $O/bench_gloo8_terrain.log 2>&1; echo "rc=$?" >> $O/bench_gloo8_terrain.log ;;
     prof)
-      (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python3 $R/bench.py --steps 20 --warmup 5 --cpu-seconds 0 --ppo-iters 0 --check-steps 500 > $O/rocprof_bench.log 2>&1) ;;
+      (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python3 $R/bench.py --steps 20 --warmup 5 --cpu-seconds 0 --ppo-iters 0 --check-steps 0 > $O/rocprof_bench.log 2>&1) ;;
     profppo)
       (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ppo -- python3 $R/tools/ppo_bench.py --policy lstm --envs 4096 --iters 2 --epochs 2 > $O/rocprof_ppo.log 2>&1) ;;
     profmlp)
