@@ -274,7 +274,7 @@ def worker(args):
         kernel at its working clock plus the start-up of the first launch behind a synchronize, which belongs to the contract."""
         g = make_graph() if mode == "graph" else None
         e0, e1 = events if events is not None else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        run(HOT_STEPS)
+        run(HOT_STEPS, "persistent" if mode == "persistent" else "rows")      # (the same kernel as the timed steps: its code is warm in the L2s)
         if counters is not None:
             env.counters_into(counters)       # stream-ordered, behind the hot steps: what the kernels have counted up to the timed region
         eh = torch.cuda.Event()

@@ -489,11 +489,12 @@ LSTM_DEV void policy_step_body(const PolicyStepArgs &a, const int e0, float (*hb
   policy_heads<HID>(a, hbuf[0], hbuf[1], LD, head_w, terms, e0, tid, t, gstep);
   IRRL_PS_STAMP();   // 6: heads, sample, buffer rows
 #ifdef IRRL_PROFILE_POLICY
+  __syncthreads();   // (this workgroup's own neglogp entries are written: the stamps go over them)
   if (blockIdx.x == gridDim.x / 2 && tid == 0) {
-    for (int k = 0; k < 7; k++) a.neglogp[k] = (float)(ts_[k] - ts_[0]);
+    for (int k = 0; k < 7; k++) a.neglogp[e0 + k] = (float)(ts_[k] - ts_[0]);
     // fused kernel: kernel start -> this wave's env part done -> policy part entered (behind the workgroup barrier)
-    a.neglogp[7] = prof_t0 ? (float)(prof_t1 - prof_t0) : 0.0f;
-    a.neglogp[8] = prof_t0 ? (float)(ts_[0] - prof_t0) : 0.0f;
+    a.neglogp[e0 + 7] = prof_t0 ? (float)(prof_t1 - prof_t0) : 0.0f;
+    a.neglogp[e0 + 8] = prof_t0 ? (float)(ts_[0] - prof_t0) : 0.0f;
   }
 #else
   (void)prof_t0; (void)prof_t1;

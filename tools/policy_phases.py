@@ -16,7 +16,7 @@ rows = []
 for k in range(30):
     out = pol.fused_step(obs, st, dones, rng=(1, k), states_out=st)
     torch.cuda.synchronize()
-    rows.append(out[3][:7].cpu().numpy() * 0.01)
+    rows.append(out[3][N // 2:N // 2 + 7].cpu().numpy() * 0.01)
 t = np.median(np.array(rows[5:]), axis=0)
 names = ["start", "loads issued", "L0 + recurrent L1 MFMAs (loads landed)", "barrier", "L0 cell + L1 input MFMAs", "L1 cell", "heads / sample / rows"]
 for n, a, b in zip(names[1:], t[:-1], t[1:]):

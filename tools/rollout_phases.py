@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Phase time stamps of ONE workgroup of a rollout step (diagnostic build: tools/build_variants.py pol=-DIRRL_PROFILE_POLICY; the
-policy code then writes 100 MHz stamps over neglogp[0:9] of the last launch).  Runs short direct rollouts of the PPO runner.
+policy code then writes 100 MHz stamps over neglogp[N/2 : N/2 + 9] (the middle workgroup's own entries) of the last launch).  Runs short direct rollouts of the PPO runner.
     IRRL_ENV_LIB=.../libirrl_env_pol.so [IRRL_ROLLOUT_FUSED=1] python tools/rollout_phases.py"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -21,7 +21,7 @@ for k in range(12):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     runner.run()
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    rows.append(runner._out[3][:9].cpu().numpy() * 0.01)
+    rows.append(runner._out[3][n // 2:n // 2 + 9].cpu().numpy() * 0.01)
 t = np.median(np.array(rows[3:]), axis=0)
 names = ["start", "loads issued", "L0 + recurrent L1 MFMAs (loads landed)", "barrier", "L0 cell + L1 input MFMAs", "L1 cell", "heads / sample / rows"]
 print("fused kernel: this wave's env part %.2f us, policy part entered at %.2f us" % (t[7], t[8]) if t[8] > 0 else "stand-alone policy kernel")
