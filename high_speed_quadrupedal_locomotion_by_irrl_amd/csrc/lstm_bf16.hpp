@@ -172,9 +172,13 @@ lstm_seq_fwd_bf16_kernel(const LstmFwdBf16Args a) {
       const size_t row = (size_t)t * N + e0 + 4 * rq + j;
       // (non-temporal stores here and loads in the backward kernel -- the gates are written once and read once -- change nothing:
       // PPO update 111.5 against 111.6 ms, same box)
+#ifndef IRRL_LBF_AB_NO_GATE_STORES      /* A/B switches of tools/build_variants.py (wrong results): which of the forward kernel's stores cost what */
       *(f32x4 *)&a.gates[(row * HID + u) * 4] = (f32x4){ig, fg, og, gg};
+#endif
+#ifndef IRRL_LBF_AB_NO_CH_STORES
       a.cseq[row * HID + u] = cn;
       a.hseq[row * HID + u] = hn;
+#endif
       keepn[j] = 1.0f - mk_nxt[j];
     }
     if (t + 1 < T) stage_h(buf ^ 1, hlast, keepn);

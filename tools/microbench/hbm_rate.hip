@@ -56,6 +56,31 @@ __global__ void __launch_bounds__(192) walk_k(f32x4 *p, f32x4 *q, int T, int N, 
   }
 }
 
+// the forward LSTM kernel's STORE MIX per step and workgroup (16 envs, 48 units): gates [env][unit][4] as float4 (lane (col, rq) of wave w: unit
+// 16 w + col, envs 4 rq + j: 256-byte pieces), c and h [env][unit] as dwords (64-byte pieces), three separate arrays -- or (PACKED) one array of
+// [env][unit][6]-float records (24 bytes: gates, c, h together), or (WIDE) c and h through float4 stores of 256-byte pieces
+template <int KIND>   // 0: as the kernel; 1: gates only; 2: c/h only; 3: packed records; 4: c/h as float4
+__global__ void __launch_bounds__(192) lstm_store_mix_k(float *gates, float *cs, float *hs, int T, int N) {
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, col = l & 15, rq = l >> 4, u = 16 * w + col, e0 = blockIdx.x * 16;
+  for (int t = 0; t < T; t++) {
+    const float v = (float)(t + tid);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const size_t row = (size_t)t * N + e0 + 4 * rq + j;
+      if (KIND == 0 || KIND == 1) *(f32x4 *)&gates[(row * 48 + u) * 4] = (f32x4){v, v + 1, v + 2, v + 3};
+      if (KIND == 0 || KIND == 2) { cs[row * 48 + u] = v; hs[row * 48 + u] = v + 1; }
+      if (KIND == 3) { float *r = gates + (row * 48 + u) * 6; *(float2 *)r = make_float2(v, v + 1); *(float2 *)(r + 2) = make_float2(v + 2, v + 3); *(float2 *)(r + 4) = make_float2(v, v + 1); }
+    }
+    if (KIND == 4) {      // the workgroup's 16 x 48 block of c and of h is contiguous (3 KB each): 192 lanes x float4 per array
+      const size_t base = ((size_t)t * N + e0) * 48;
+      *(f32x4 *)&cs[base + 4 * tid] = (f32x4){v, v, v, v};
+      *(f32x4 *)&hs[base + 4 * tid] = (f32x4){v, v, v, v};
+#pragma unroll
+      for (int j = 0; j < 4; j++) { const size_t row = (size_t)t * N + e0 + 4 * rq + j; *(f32x4 *)&gates[(row * 48 + u) * 4] = (f32x4){v, v + 1, v + 2, v + 3}; }
+    }
+  }
+}
+
 static hipEvent_t e0, e1;
 template <class F> static double timed(F f, int reps = 3) {
   double best = 1e30;
@@ -91,6 +116,21 @@ int main() {
     double c3 = timed([&] { hipLaunchKernelGGL((walk_k<2, 3>), dim3(wgs), dim3(192), 0, 0, p, q, T, N, C4, epw, out); });
     printf("walking, %4d workgroups x %2d envs: store %6.3f ms = %5.2f TB/s   load depth 1 / 3 / 6: %5.2f / %5.2f / %5.2f TB/s   load + store (depth 3) %5.2f TB/s\n", wgs, epw, a,
            bytes / a / 1e9, bytes / b1 / 1e9, bytes / b3 / 1e9, bytes / b6 / 1e9, 2.0 * bytes / c3 / 1e9);
+  }
+  {
+    float *g = (float *)p, *cc = (float *)q, *hh = (float *)q + (size_t)T * N * 48;      // gates 2.36 GB in p (as packed records: 3.54 GB), c | h 0.59 GB each in q
+    const double gb = (double)T * N * 48 * 4;
+    const char *names[5] = {"gates float4 + c, h dwords (the kernel)", "gates only", "c, h only", "packed [unit][6] records", "gates float4 + c, h as float4 blocks"};
+    const double bytes_k[5] = {6 * gb, 4 * gb, 2 * gb, 6 * gb, 6 * gb};
+    double ms;
+    for (int k = 0; k < 5; k++) {
+      if (k == 0) ms = timed([&] { hipLaunchKernelGGL((lstm_store_mix_k<0>), dim3(N / 16), dim3(192), 0, 0, g, cc, hh, T, N); });
+      if (k == 1) ms = timed([&] { hipLaunchKernelGGL((lstm_store_mix_k<1>), dim3(N / 16), dim3(192), 0, 0, g, cc, hh, T, N); });
+      if (k == 2) ms = timed([&] { hipLaunchKernelGGL((lstm_store_mix_k<2>), dim3(N / 16), dim3(192), 0, 0, g, cc, hh, T, N); });
+      if (k == 3) ms = timed([&] { hipLaunchKernelGGL((lstm_store_mix_k<3>), dim3(N / 16), dim3(192), 0, 0, g, cc, hh, T, N); });
+      if (k == 4) ms = timed([&] { hipLaunchKernelGGL((lstm_store_mix_k<4>), dim3(N / 16), dim3(192), 0, 0, g, cc, hh, T, N); });
+      printf("LSTM forward store mix, %-44s %6.3f ms = %5.2f TB/s\n", names[k], ms, bytes_k[k] / ms / 1e9);
+    }
   }
   return 0;
 }
