@@ -816,8 +816,10 @@ class PPO2(object):
             n_batch = T * N
             assert n_batch % self.nminibatches == 0
             bs = n_batch // self.nminibatches
-            flat = {k: batch[k].transpose(0, 1).reshape(n_batch, *batch[k].shape[2:]) for k in
-                    ("obs", "returns", "masks", "actions", "values", "neglogpacs")}   # swap_and_flatten: env-major
+            # ppo2.py:573 swap_and_flatten makes the batch env-major; for a non-recurrent policy the order of the flat batch only names the
+            # samples (every epoch draws a uniform shuffle of them, ppo2.py:366-367), so the [T, N, ...] buffers are flattened as they lie:
+            # views, no 0.6 GB of copies per update
+            flat = {k: batch[k].reshape(n_batch, *batch[k].shape[2:]) for k in ("obs", "returns", "masks", "actions", "values", "neglogpacs")}
             in_place = self.fused_mlp and mlp_ppo_grads_supported(self.policy, flat["obs"])
             self._flat_adv = (flat["returns"] - flat["values"]).contiguous() if in_place else None
             for _ in range(self.noptepochs):
