@@ -7,14 +7,17 @@
 // to the f32 kernel that bought nothing (profiles/r04_lstm_precision_error_and_time.log: the planes of 196 weight registers plus the
 // split arithmetic spilled).  This kernel is built around the planes:
 //   * the weight planes live in LDS, one lane-linear 1 KB block per (layer, output tile, K chunk, plane), written once per workgroup and
-//     fetched with one ds_read_b128 right in front of the MFMAs that use them -- no weight registers at all;
+//     fetched with ds_read_b128 ONE STAGE AHEAD of the MFMAs that use them (a layer's 16 blocks = 64 registers in flight instead of the
+//     f32 kernel's 196 resident weight registers);
 //   * everything is still computed transposed (sample = C/D column), and the C layout of a 16x16 f32 tile -- lane (c, g) holds rows
 //     4 g .. 4 g + 3 -- IS the K = 16 B-operand layout, two tiles side by side the K = 32 one: a layer's output is split to bf16 where
 //     it sits and becomes the next layer's operand without moving (the weight blocks carry the matching permuted k order);
 //   * the weight gradients contract over the SAMPLES: each tensor is written once, as planes, into a per-wave [sample][feature] image
 //     and read back TRANSPOSED by ds_read_b64_tr_b16 (gfx950) straight into the A / B operand layout of v_mfma_f32_16x16x16_bf16.
-// A workgroup is four independent waves, one per SIMD; a wave walks 16-sample tiles.  ~650 VALU + 186 MFMA + ~150 LDS instructions per
-// tile (policy network).  Gradients: ~2^-16 relative per product before the f32 accumulation (tools/mlp_grad_error.py).
+// A workgroup is four independent waves, one per SIMD; a wave walks 16-sample tiles.  883 VALU + 186 MFMA + 147 LDS instructions per tile
+// (policy network, PMC); the VALU parts of the activations / deltas are zipped by hand with the MFMAs that do not depend on them (below).
+// Gradients within 7e-6 of each tensor's largest entry of float64 autograd (tools/mlp_grad_error.py).  One MFMA shape per accumulator
+// chain: K = 16 and K = 32 instructions alternating on one accumulator are miscompiled (tools/microbench/mfma_mixed_chain.hip).
 #pragma once
 #include "mlp_update.hpp"
 #include "lstm_bf16.hpp"
