@@ -19,8 +19,9 @@
 //            [env][gate column] for the recurrence / dx products (K = the 192 gate columns: 6 chunks of 32; N-split: wave w
 //            produces dh_prev for ITS units and dx for input columns 16 w .. 16 w + 15, so no partial sums are exchanged) and
 //            [gate column][env] for the weight gradients (K = the 16 envs of the step: v_mfma_f32_16x16x16_bf16), next to
-//            (h_{t-1} keep_t)^T and x_t^T (staged by wave 3).  The 72 weight-gradient tiles (dwh 3 x 12, dwx 3 x 12) are shared out
-//            evenly: wave w' of the four accumulates gate-column tiles 3 w' .. 3 w' + 2 against all six M-tiles for all T steps.
+//            (h_{t-1} keep_t)^T and x_t^T (staged by wave 3).  Of the 72 weight-gradient tiles (dwh 3 x 12, dwx 3 x 12) waves 0-2 accumulate
+//            gate-column tiles 2 w, 2 w + 1 against all six M-tiles (12 tiles each), wave 3 -- which has nothing else to compute -- tiles 6 .. 11
+//            (36 tiles), for all T steps.
 //            Double-buffered tiles, one barrier per step.  Per-workgroup partial gradients as in lstm_seq_bwd_x_kernel.
 #pragma once
 #include "policy_step.hpp"
@@ -210,6 +211,49 @@ constexpr int LBF_CROW = 16 + 4;            // [gate column | unit | input][env]
 template <int NS> constexpr int lstm_bwd_bf16_lds_elems_per_buf() { return NS * (16 * LBF_RROW + LBF_GC * LBF_CROW + LBF_HID * LBF_CROW + LBF_KX * LBF_CROW); }
 template <int NS> constexpr int lstm_bwd_bf16_lds_bytes() { return 2 * lstm_bwd_bf16_lds_elems_per_buf<NS>() * 2; }
 
+// the weight-gradient products of one step for NCI gate-column tiles (first one: ci0) against all six M-tiles (0-2: hidden rows of dwh, 3-5: input
+// rows of dwx); `bufbase` = the step's LDS buffer.  Per accumulator tile the plane products arrive in the same order whoever owns the tile.
+template <int NS, int NCI>
+LSTM_DEV void lbf_weight_grads(f32x4 (&accW)[6][NCI], const unsigned short *bufbase, int ci0, int col, int rq) {
+  using PR = BfProducts<NS>;
+  constexpr int OFF_C = NS * 16 * LBF_RROW, OFF_H = OFF_C + NS * LBF_GC * LBF_CROW, OFF_X = OFF_H + NS * LBF_HID * LBF_CROW;
+  u16x4_t bz[NCI][NS], am[6][NS];
+#pragma unroll
+  for (int p = 0; p < NS; p++) {
+#pragma unroll
+    for (int ci = 0; ci < NCI; ci++) bz[ci][p] = *(const u16x4_t *)(bufbase + OFF_C + ((size_t)p * LBF_GC + 16 * (ci0 + ci) + col) * LBF_CROW + 4 * rq);
+#pragma unroll
+    for (int mt = 0; mt < 3; mt++) {
+      am[mt][p] = *(const u16x4_t *)(bufbase + OFF_H + ((size_t)p * LBF_HID + 16 * mt + col) * LBF_CROW + 4 * rq);
+      am[3 + mt][p] = *(const u16x4_t *)(bufbase + OFF_X + ((size_t)p * LBF_KX + 16 * mt + col) * LBF_CROW + 4 * rq);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int q = 0; q < PR::N; q++)
+#pragma unroll
+    for (int mt = 0; mt < 6; mt++)
+#pragma unroll
+      for (int ci = 0; ci < NCI; ci++) accW[mt][ci] = BF_MFMA16(am[mt][PR::A[q]], bz[ci][PR::B[q]], accW[mt][ci]);
+}
+template <int NCI>
+LSTM_DEV void lbf_store_weight_grads(const f32x4 (&accW)[6][NCI], const LstmBwdBf16Args &a, int ci0, int col, int rq) {
+  const size_t blk = blockIdx.x;
+#pragma unroll
+  for (int ci = 0; ci < NCI; ci++) {
+    const int cc = 16 * (ci0 + ci) + col;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+      for (int mt = 0; mt < 3; mt++) {
+        a.dwh_part[(blk * LBF_HID + 16 * mt + 4 * rq + r) * LBF_GC + cc] = accW[mt][ci][r];
+        const int i = 16 * mt + 4 * rq + r;
+        if (i < a.n_in) a.dwx_part[(blk * a.n_in + i) * LBF_GC + cc] = accW[3 + mt][ci][r];
+      }
+    }
+  }
+}
+
 template <int NS, bool NEED_DX>
 __global__ void __launch_bounds__(256)
 lstm_seq_bwd_bf16_kernel(const LstmBwdBf16Args a) {
@@ -233,48 +277,15 @@ lstm_seq_bwd_bf16_kernel(const LstmBwdBf16Args a) {
   const int T = a.T, N = a.N, n_in = a.n_in;
   const bool main_wave = w < 3;
   const int u = 16 * (main_wave ? w : 0) + col;
-  // weight-gradient accumulators of this wave: M-tile mt (0-2: hidden rows of dwh, 3-5: input rows of dwx) x gate-column tile 3 w + ci
-  f32x4 accW[6][3];
-#pragma unroll
-  for (int mt = 0; mt < 6; mt++)
-#pragma unroll
-    for (int ci = 0; ci < 3; ci++) accW[mt][ci] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-  auto weight_grads = [&](int buf) {
-    u16x4_t bz[3][NS], am[6][NS];
-#pragma unroll
-    for (int p = 0; p < NS; p++) {
-#pragma unroll
-      for (int ci = 0; ci < 3; ci++) bz[ci][p] = *(const u16x4_t *)Zc(buf, p, 16 * (3 * w + ci) + col, 4 * rq);
-#pragma unroll
-      for (int mt = 0; mt < 3; mt++) {
-        am[mt][p] = *(const u16x4_t *)Ht(buf, p, 16 * mt + col, 4 * rq);
-        am[3 + mt][p] = *(const u16x4_t *)Xt(buf, p, 16 * mt + col, 4 * rq);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int q = 0; q < PR::N; q++)
-#pragma unroll
-      for (int mt = 0; mt < 6; mt++)
-#pragma unroll
-        for (int ci = 0; ci < 3; ci++) accW[mt][ci] = BF_MFMA16(am[mt][PR::A[q]], bz[ci][PR::B[q]], accW[mt][ci]);
-  };
-  auto store_weight_grads = [&]() {
-    const size_t blk = blockIdx.x;
-#pragma unroll
-    for (int ci = 0; ci < 3; ci++) {
-      const int cc = 16 * (3 * w + ci) + col;
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-#pragma unroll
-        for (int mt = 0; mt < 3; mt++) {
-          a.dwh_part[(blk * HID + 16 * mt + 4 * rq + r) * GC + cc] = accW[mt][ci][r];
-          const int i = 16 * mt + 4 * rq + r;
-          if (i < n_in) a.dwx_part[(blk * n_in + i) * GC + cc] = accW[3 + mt][ci][r];
-        }
-      }
-    }
-  };
+#ifdef IRRL_LBF_MAIN_TILES      /* A/B switch of tools/build_variants.py: gate-column tiles per main wave (3 = 18 accumulator tiles per wave, the even split) */
+  constexpr int MAIN_CI = IRRL_LBF_MAIN_TILES;
+#else
+  constexpr int MAIN_CI = 2;
+#endif
+  constexpr int HELP_PARTS = (12 - 3 * MAIN_CI) / 3;     // the helper wave's tiles in parts of three
+  // The 72 weight-gradient tiles (12 gate-column tiles x 6 M-tiles): waves 0-2, which also carry the gate arithmetic and the recurrence, own
+  // gate-column tiles 2 w, 2 w + 1 (12 accumulator tiles, 36 MFMAs per step); wave 3, which otherwise only stages x_t^T, owns tiles 6 .. 11 (36
+  // accumulator tiles, 108 MFMAs per step).  (Shared out evenly -- 18 tiles each -- the main waves were the step's critical path.)
   if (!main_wave) {
     // ---- wave 3: stages x_t^T for the weight gradients (coalesced row reads, two steps ahead) and takes its share of them ----
     float xr[DEPTH + 1][12];
@@ -295,6 +306,13 @@ lstm_seq_bwd_bf16_kernel(const LstmBwdBf16Args a) {
         for (int p = 0; p < NS; p++) *Xt(buf, p, i, env) = pl[p];
       }
     };
+    f32x4 accH[HELP_PARTS][6][3];      // parts of three gate-column tiles: one part's operands are in flight at a time
+#pragma unroll
+    for (int hf = 0; hf < HELP_PARTS; hf++)
+#pragma unroll
+      for (int mt = 0; mt < 6; mt++)
+#pragma unroll
+        for (int ci = 0; ci < 3; ci++) accH[hf][mt][ci] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     constexpr int HD = DEPTH + 1;
 #pragma unroll
     for (int d = 0; d < HD; d++)
@@ -307,10 +325,12 @@ lstm_seq_bwd_bf16_kernel(const LstmBwdBf16Args a) {
         stage_x(tt & 1, xr[d]);
         if (tt - HD >= 0) load_x(tt - HD, xr[d]);
         __syncthreads();
-        weight_grads(tt & 1);
+#pragma unroll
+        for (int hf = 0; hf < HELP_PARTS; hf++) lbf_weight_grads<NS, 3>(accH[hf], lds_b + (size_t)(tt & 1) * PER_BUF, 3 * MAIN_CI + 3 * hf, col, rq);
       }
     }
-    store_weight_grads();
+#pragma unroll
+    for (int hf = 0; hf < HELP_PARTS; hf++) lbf_store_weight_grads<3>(accH[hf], a, 3 * MAIN_CI + 3 * hf, col, rq);
     return;
   }
   // ---- waves 0-2 ----
@@ -338,6 +358,11 @@ lstm_seq_bwd_bf16_kernel(const LstmBwdBf16Args a) {
   // arithmetic, less than the latency of its 24 KB of loads under a fully loaded memory system (the rows of consecutive steps are 3 MB
   // apart in each of six arrays): with one step in flight the kernel ran at that latency -- 5.4 us per step, 1.4 TB/s (round 4, first
   // version) -- not at its arithmetic.
+  f32x4 accW[6][MAIN_CI];
+#pragma unroll
+  for (int mt = 0; mt < 6; mt++)
+#pragma unroll
+    for (int ci = 0; ci < MAIN_CI; ci++) accW[mt][ci] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
   struct StepOps { f32x4 g[4]; float ct[4], cp[4], dh[4], mk[4], hp[4]; };
   auto fetch = [&](int t, StepOps &o) {
 #pragma unroll
@@ -423,7 +448,7 @@ lstm_seq_bwd_bf16_kernel(const LstmBwdBf16Args a) {
 #pragma unroll
       for (int j = 0; j < 4; j++) a.dx[((size_t)t * N + e0 + 4 * rq + j) * n_in + u] = accx[j];
     }
-    weight_grads(buf);
+    lbf_weight_grads<NS, MAIN_CI>(accW, lds_b + (size_t)buf * PER_BUF, MAIN_CI * w, col, rq);
   };
   StepOps ops[DEPTH];
 #pragma unroll
@@ -434,7 +459,7 @@ lstm_seq_bwd_bf16_kernel(const LstmBwdBf16Args a) {
     for (int d = 0; d < DEPTH; d++)
       if (t - d >= 0) step(t - d, ops[d]);
   }
-  store_weight_grads();
+  lbf_store_weight_grads<MAIN_CI>(accW, a, MAIN_CI * w, col, rq);
   const size_t blk = blockIdx.x;
 #pragma unroll
   for (int g = 0; g < 4; g++) a.db_part[(blk * 4 + rq) * GC + u * 4 + g] = dbacc[g];
