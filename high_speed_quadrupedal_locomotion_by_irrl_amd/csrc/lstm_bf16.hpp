@@ -15,10 +15,10 @@
 //            step t - 1, x_t staged by all lanes one step ahead) lives in a double-buffered LDS tile, the B fragments (weights,
 //            split once) stay in registers for the whole sequence.  36 (NS 2) / 72 (NS 3) MFMAs + the cell per wave and step, one
 //            workgroup barrier per step.
-//   backward (4 waves): waves 0-2 own 16 units each: gate arithmetic -> dz (4 envs x 4 gates per lane), which goes to LDS twice --
-//            [env][gate column] for the recurrence / dx products (K = the 192 gate columns: 6 chunks of 32; N-split: wave w
-//            produces dh_prev for ITS units and dx for input columns 16 w .. 16 w + 15, so no partial sums are exchanged) and
-//            [gate column][env] for the weight gradients (K = the 16 envs of the step: v_mfma_f32_16x16x16_bf16), next to
+//   backward (4 waves): waves 0-2 own 16 units each: gate arithmetic -> dz (4 envs x 4 gates per lane), which goes to LDS as an
+//            [env][gate column] tile: read row-wise for the recurrence / dx products (K = the 192 gate columns: 6 chunks of 32; N-split:
+//            wave w produces dh_prev for ITS units and dx for input columns 16 w .. 16 w + 15, so no partial sums are exchanged) and
+//            TRANSPOSED (ds_read_b64_tr_b16) for the weight gradients (K = the 16 envs of the step: v_mfma_f32_16x16x16_bf16), next to
 //            (h_{t-1} keep_t)^T and x_t^T (staged by wave 3).  Of the 72 weight-gradient tiles (dwh 3 x 12, dwx 3 x 12) waves 0-2 accumulate
 //            gate-column tiles 2 w, 2 w + 1 against all six M-tiles (12 tiles each), wave 3 -- which has nothing else to compute -- tiles 6 .. 11
 //            (36 tiles), for all T steps.
@@ -208,7 +208,7 @@ struct LstmBwdBf16Args {
 constexpr int LBF_GC = 4 * LBF_HID;         // gate columns
 constexpr int LBF_RROW = LBF_GC + 8;        // dz tile [env][gate column]: padded row, 400 bytes (16-byte aligned)
 constexpr int LBF_CROW = 16 + 4;            // [gate column | unit | input][env]: padded row, 40 bytes (8-byte aligned)
-template <int NS> constexpr int lstm_bwd_bf16_lds_elems_per_buf() { return NS * (16 * LBF_RROW + LBF_GC * LBF_CROW + LBF_HID * LBF_CROW + LBF_KX * LBF_CROW); }
+template <int NS> constexpr int lstm_bwd_bf16_lds_elems_per_buf() { return NS * (16 * LBF_RROW + LBF_HID * LBF_CROW + LBF_KX * LBF_CROW); }
 template <int NS> constexpr int lstm_bwd_bf16_lds_bytes() { return 2 * lstm_bwd_bf16_lds_elems_per_buf<NS>() * 2; }
 
 // the weight-gradient products of one step for NCI gate-column tiles (first one: ci0) against all six M-tiles (0-2: hidden rows of dwh, 3-5: input
@@ -216,12 +216,20 @@ template <int NS> constexpr int lstm_bwd_bf16_lds_bytes() { return 2 * lstm_bwd_
 template <int NS, int NCI>
 LSTM_DEV void lbf_weight_grads(f32x4 (&accW)[6][NCI], const unsigned short *bufbase, int ci0, int col, int rq) {
   using PR = BfProducts<NS>;
-  constexpr int OFF_C = NS * 16 * LBF_RROW, OFF_H = OFF_C + NS * LBF_GC * LBF_CROW, OFF_X = OFF_H + NS * LBF_HID * LBF_CROW;
+  constexpr int OFF_H = NS * 16 * LBF_RROW, OFF_X = OFF_H + NS * LBF_HID * LBF_CROW;
   u16x4_t bz[NCI][NS], am[6][NS];
+  // dz as the B operand (k = the step's envs) comes TRANSPOSED out of the [env][gate column] tile the recurrence reads row-wise
+  // (ds_read_b64_tr_b16: lane 4 q + p of a 16-lane group addresses row 4 rq + q, columns 4 p .. 4 p + 3 of the 16-column block; lane i gets
+  // column i of the four rows) -- no second copy of dz in a [gate column][env] layout
+  const int tr_off = (4 * rq + (col >> 2)) * LBF_RROW + 4 * (col & 3);
 #pragma unroll
   for (int p = 0; p < NS; p++) {
 #pragma unroll
-    for (int ci = 0; ci < NCI; ci++) bz[ci][p] = *(const u16x4_t *)(bufbase + OFF_C + ((size_t)p * LBF_GC + 16 * (ci0 + ci) + col) * LBF_CROW + 4 * rq);
+    for (int ci = 0; ci < NCI; ci++) {
+      typedef short lbf_s16x4 __attribute__((ext_vector_type(4)));
+      const lbf_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lbf_s16x4 __attribute__((address_space(3))) *)(bufbase + (size_t)p * 16 * LBF_RROW + tr_off + 16 * (ci0 + ci)));
+      bz[ci][p] = __builtin_bit_cast(u16x4_t, v);
+    }
 #pragma unroll
     for (int mt = 0; mt < 3; mt++) {
       am[mt][p] = *(const u16x4_t *)(bufbase + OFF_H + ((size_t)p * LBF_HID + 16 * mt + col) * LBF_CROW + 4 * rq);
@@ -266,9 +274,8 @@ lstm_seq_bwd_bf16_kernel(const LstmBwdBf16Args a) {
   using PR = BfProducts<NS>;
   extern __shared__ __attribute__((aligned(16))) unsigned short lds_b[];
   constexpr int PER_BUF = lstm_bwd_bf16_lds_elems_per_buf<NS>();
-  constexpr int OFF_C = NS * 16 * LBF_RROW, OFF_H = OFF_C + NS * GC * LBF_CROW, OFF_X = OFF_H + NS * HID * LBF_CROW;
+  constexpr int OFF_H = NS * 16 * LBF_RROW, OFF_X = OFF_H + NS * HID * LBF_CROW;
   auto Zr = [&](int buf, int p, int env, int c) -> unsigned short * { return lds_b + (size_t)buf * PER_BUF + ((size_t)p * 16 + env) * LBF_RROW + c; };
-  auto Zc = [&](int buf, int p, int c, int env) -> unsigned short * { return lds_b + (size_t)buf * PER_BUF + OFF_C + ((size_t)p * GC + c) * LBF_CROW + env; };
   auto Ht = [&](int buf, int p, int k, int env) -> unsigned short * { return lds_b + (size_t)buf * PER_BUF + OFF_H + ((size_t)p * HID + k) * LBF_CROW + env; };
   auto Xt = [&](int buf, int p, int i, int env) -> unsigned short * { return lds_b + (size_t)buf * PER_BUF + OFF_X + ((size_t)p * KX + i) * LBF_CROW + env; };
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
@@ -397,8 +404,7 @@ lstm_seq_bwd_bf16_kernel(const LstmBwdBf16Args a) {
 #pragma unroll
       for (int p = 0; p < NS; p++) *(u16x4_t *)Ht(buf, p, u, 4 * rq) = pk[p];
     }
-    // gate arithmetic -> dz (env 4 rq + j, unit u, gates i f o g), both LDS layouts
-    u16x4_t zc[4][NS];     // [gate][plane]: the four envs of this lane
+    // gate arithmetic -> dz (env 4 rq + j, unit u, gates i f o g) into the [env][gate column] tile
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const float cprev = cpv[j] * keepC[j];
@@ -417,15 +423,11 @@ lstm_seq_bwd_bf16_kernel(const LstmBwdBf16Args a) {
         unsigned short pl[NS];
         bf_split<NS>(dz4[g], pl);
 #pragma unroll
-        for (int p = 0; p < NS; p++) { zr[p][g] = pl[p]; zc[g][p][j] = pl[p]; }
+        for (int p = 0; p < NS; p++) zr[p][g] = pl[p];
       }
 #pragma unroll
       for (int p = 0; p < NS; p++) *(u16x4_t *)Zr(buf, p, 4 * rq + j, 4 * u) = zr[p];
     }
-#pragma unroll
-    for (int g = 0; g < 4; g++)
-#pragma unroll
-      for (int p = 0; p < NS; p++) *(u16x4_t *)Zc(buf, p, 4 * u + g, 4 * rq) = zc[g][p];
     __syncthreads();      // dz_t, (h_{t-1} keep_t)^T and x_t^T of every wave are visible
     // recurrence (+ dx): A[env = col][k = gate column]
     u16x8_t av[KC][NS];
