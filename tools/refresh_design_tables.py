@@ -38,7 +38,7 @@ builds as SURVEY §8d asks.
 a, e = s.index("| CustomLSTMPolicy 2×48 + 2×48 (config 3), update on the bf16 matrix cores"), s.index("## 7. Learner (rows 20-23) and multi-GPU (row e)")
 pl, pm, dl, dm = b["ppo"], b["ppo_mlp"], dr["ppo"], dr["ppo_mlp"]
 lo, hi = (lambda k, x, y: 1e3 * min(x[k], y[k])), (lambda k, x, y: 1e3 * max(x[k], y[k]))
-s = s[:a] + '''| CustomLSTMPolicy 2×48 + 2×48 (config 3), update on the bf16 matrix cores (`bf16x3`, §3.3), persistent rollout (§3.2) | %.1f-%.1f ms | **%.1f-%.1f ms** (the two committed lines; 107-113.5 over the round's boxes) | **%.2f-%.2f** (6.28-6.65 over the round's boxes) | 47 + 157 ms, 4.9 |
+s = s[:a] + '''| CustomLSTMPolicy 2×48 + 2×48 (config 3), update on the bf16 matrix cores (`bf16x3`, §3.3), persistent rollout (§3.2) | %.1f-%.1f ms | **%.1f-%.1f ms** (the two committed lines; 101.5-113.5 over the round's boxes and builds) | **%.2f-%.2f** (6.28-6.85 over the round's boxes and builds) | 47 + 157 ms, 4.9 |
 | same, `IRRL_LSTM_PRECISION=bf16x6` / `f32` | 45.5 ms | 146.8 / 158.3 ms | 5.20 / 4.91 | |
 | MlpPolicy [64, 64] (config 2): persistent rollout (§3.2) + bf16x3 gradient kernels (§3.5) | **%.1f-%.1f ms** | **%.1f-%.1f ms** | **%.1f-%.1f** | 39 + 32 ms, 14.0 |
 | same, `IRRL_MLP_ROLLOUT=direct` / `IRRL_MLP_PRECISION=f32` (same box A/B) | 40.8 ms | 27.2 ms | 16.7 / 14.7 (20.1 with both new) | |
