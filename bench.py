@@ -23,11 +23,14 @@ collectives there are only the timing barrier and the max-over-ranks.  The PPO l
 north_star's collectives in the loop (flat 283 KB gradient all-reduce + 3-float advantage moments per optimizer
 step, ppo2.py) and reports whole-job iterations/s and samples/s.
 
-Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel = irrl_step_kernel, HIP-event timed
-over the timed region on the stream it is launched on), `roofline_fp32` (the VALU-FP32 view: this path is
-latency/issue bound, not HBM bound), `cpu_baseline` (the f64 oracle with the reference's
-OpenMP-over-envs threading on the GPU box's host cores + its single-thread rate, bounded sample, rank 0 / N=1 only),
-`ppo` (second half of the metric: the LSTM policy of config 3) and `ppo_mlp` (the same iteration with config 2's MlpPolicy learner).
+Prints ONE JSON line (rank 0).  `value` = env-steps/s of the K timed steps issued the way --launch says (default: ONE persistent
+launch, irrl_env_step_rows_persistent_out) with EVERY step's ob / reward / done / extraInfo stored to its own row in HBM.  Extra
+objects: `roofline` (the binding one: FP32 VALU, dominant kernel HIP-event timed over the timed region on the stream it is launched
+on; `traffic` = its HBM bytes from the PMC passes), `roofline_hbm` (the HBM view: this path is latency/issue bound, not HBM bound,
+SURVEY 8d), `launch_modes` (the other ways of issuing the same steps, measured after the timed bracket), `cpu_baseline` (the f64 oracle
+with the reference's OpenMP-over-envs threading on the GPU box's host cores + its single-thread rate, bounded sample, rank 0 / N=1 only),
+`ppo` (second half of the metric: the LSTM policy of config 3; default precision of the update + `f32_level`: the same iteration with
+the update at the f32 level) and `ppo_mlp` (the same with config 2's MlpPolicy learner).
 """
 import argparse
 import json
@@ -64,12 +67,14 @@ def parse_args(argv=None):
     ap.add_argument("--ppo-iters", type=int, default=5, help="timed PPO iterations of each learner leg, reported with min / median / max (0 disables)")
     ap.add_argument("--ppo-steps", type=int, default=750, help="rollout length of the PPO leg (the metric's is 750)")
     ap.add_argument("--ppo-epochs", type=int, default=10, help="optimisation epochs of the PPO leg (the metric's is 10)")
-    ap.add_argument("--launch", choices=("auto", "persistent", "rows", "graph", "python"), default="auto",
-                    help="how the K timed steps are issued: 'persistent' = ONE launch in which every wave walks its own robots through the K steps "
-                         "(irrl_env_step_rows_persistent: robots never interact, so nothing has to wait for the slowest wave of a step), "
-                         "'rows' = K back-to-back launches from one irrl_env_step_rows call, 'graph' = one hipGraph of K step-kernel nodes, "
-                         "'python' = one ctypes call per step; 'auto' (default) = persistent for long brackets, for K <= 400 whichever of "
-                         "the four was fastest on this box in two untimed warm-up brackets each")
+    ap.add_argument("--launch", choices=("persistent", "rows", "graph", "python"), default="persistent",
+                    help="how the K timed steps are issued -- FIXED by this flag, nothing is probed or selected inside the measured run.  In every "
+                         "mode EVERY step's ob / reward / done / extraInfo is stored to its own row of [K, N, .] tables in HBM (what K step() calls "
+                         "of the reference return).  'persistent' (default) = ONE launch in which every wave walks its own robots through the K "
+                         "steps (irrl_env_step_rows_persistent_out: robots never interact, so nothing has to wait for the slowest wave of a step), "
+                         "'rows' = K back-to-back launches from one irrl_env_step_rows_out call, 'graph' = one hipGraph of K step-kernel nodes, "
+                         "'python' = one ctypes call per step.  The modes that were not timed are reported as extras (`launch_modes`).")
+    ap.add_argument("--no-mode-extras", action="store_true", help="skip the untimed extras that measure the other launch modes")
     ap.add_argument("--no-graph", dest="launch", action="store_const", const="python", help="same as --launch python")
     ap.add_argument("--check-steps", type=int, default=2000, help="extra untimed-for-`value` window after the timed region that "
                     "re-measures us/step over a longer run (0 disables); reported as `steady_state_check`")
@@ -191,7 +196,9 @@ def worker(args):
     dev = torch.device("cuda", local_rank)
     dist = None
     ranks_seen = 1
-    if world > 1:
+    if world > 1 or "WORLD_SIZE" in os.environ:
+        # under a launcher (WORLD_SIZE set), ALSO with one rank: the job then runs its barrier / reductions / PPO collectives over RCCL
+        # on device tensors like an N-GPU job does -- the way to exercise the nccl path on a 1-GPU box
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -229,6 +236,13 @@ def worker(args):
     rew = torch.zeros(n, device=dev)
     done = torch.zeros(n, dtype=torch.bool, device=dev)
     extra = torch.zeros(n, 6, device=dev)
+    # the timed steps keep EVERY step's outputs: row k of these tables is what the k-th step() call of the reference returns
+    # (VEC:268-278, RaisimGymVecEnv.py:26-52) -- 173 B per env-step delivered to HBM, nothing overwritten inside the bracket
+    K = args.steps
+    ob_rows = torch.zeros(K, n, 35, device=dev)
+    rew_rows = torch.zeros(K, n, device=dev)
+    done_rows = torch.zeros(K, n, dtype=torch.bool, device=dev)
+    extra_rows = torch.zeros(K, n, 6, device=dev)
     cursor = [0]
 
     def run(k_steps, mode="rows"):
@@ -249,21 +263,25 @@ def worker(args):
     # nodes there) costs ~40 us before its first node runs.  Capturing records the launches without executing them.
     graph_cache = {}
 
+    def run_kept(s0):
+        """the K timed steps, one FlexibleGymEnv.step() call per step, every step's outputs into its own row"""
+        for k in range(K):
+            env.step(actions[(s0 + k) % rows], ob_rows[k], rew_rows[k], done_rows[k], extra_rows[k])
+
     def make_graph():
         if "g" not in graph_cache:
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
-            s_keep = cursor[0]
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=side):
-                run(args.steps, "python")
-            cursor[0] = s_keep
+                run_kept(cursor[0])
             torch.cuda.synchronize()
             graph_cache["g"] = g
         return graph_cache["g"]
 
-    def bracket(mode, events=None, barrier=False, counters=None):
-        """args.steps env steps issued in `mode`, bracketed by (barrier +) synchronize on both sides -> wall seconds.  Completion is first
+    def bracket(mode, events=None, barrier=False, counters=None, keep=True):
+        """args.steps env steps issued in `mode` (keep: every step's outputs into its own row of the [K, N, .] tables; keep=False, an extra
+        only: the [N, .] arrays every step overwrites), bracketed by (barrier +) synchronize on both sides -> wall seconds.  Completion is first
         seen by polling the closing event (hipEventQuery), then confirmed by torch.cuda.synchronize(): on some boxes of this pool a host
         thread BLOCKED in the synchronize behind a short burst is woken up milliseconds late (profiles/r04_burst_wakeup.log: 20 steps =
         0.9 ms of kernels, 2.0-3.4 ms of wall clock); a thread that polls is not.
@@ -279,7 +297,8 @@ def worker(args):
             env.counters_into(counters)       # stream-ordered, behind the hot steps: what the kernels have counted up to the timed region
         eh = torch.cuda.Event()
         eh.record()
-        call = (env.step_rows_call(args.steps, actions, cursor[0] % rows, ob, rew, done, extra, persistent=(mode == "persistent"))
+        outs = (ob_rows, rew_rows, done_rows, extra_rows) if keep else (ob, rew, done, extra)
+        call = (env.step_rows_call(args.steps, actions, cursor[0] % rows, *outs, persistent=(mode == "persistent"))
                 if mode in ("rows", "persistent") else None)
         while not eh.query():        # the host thread arrives from work too: it polls through the 12 ms of the hot steps instead of sleeping in the synchronize
             pass
@@ -295,34 +314,24 @@ def worker(args):
             g.replay()
             cursor[0] += args.steps
         else:
-            run(args.steps, "python")
+            run_kept(cursor[0])
+            cursor[0] += args.steps
         e1.record()
         while not e1.query():
             pass
         torch.cuda.synchronize()
         return time.perf_counter() - t_start
 
-    # HOW the K timed steps are issued.  The engine's multi-step entry point takes the K action rows resident in HBM and runs the K steps
-    # as ONE launch (irrl_env_step_rows_persistent): robots never interact (VEC:273), so every wave walks its own robots through the K
-    # steps and nothing waits for the slowest wave of a step -- what the fused rollout kernels of the learner do with the env part.  The
-    # other ways keep one launch per step: K back-to-back launches from one C call (rows), a hipGraph of K nodes (~40 us before its
-    # first node runs), one ctypes call per step (+ ~2 us per step; also reported as `per_step_call`: the reference-shaped surface).
-    # With the driver's --steps 20 the bracket is under a millisecond and box-to-box differences in launch / wake-up latency are a
-    # large part of it, so `--launch auto` (default) tries each way on THIS box during the warm-up (two untimed brackets of K steps
-    # each) and times the one that was fastest; all four times are in the line.  Long brackets (K > 400): persistent.
-    # (Several ranks: every rank runs the same probe brackets and picks for its own GPU; the barrier sits around the timed bracket.)
-    launch_probe = None
+    # HOW the K timed steps are issued is FIXED by --launch (default: persistent); nothing is probed or selected inside the measured run.
+    # In every mode every step's outputs are stored to their own rows.  persistent: the engine's multi-step entry point takes the K action
+    # rows resident in HBM and runs the K steps as ONE launch (irrl_env_step_rows_persistent_out): robots never interact (VEC:273), so every
+    # wave walks its own robots through the K steps and nothing waits for the slowest wave of a step -- what the fused rollout kernels of the
+    # learner do with the env part.  The other ways keep one launch per step: K back-to-back launches from one C call (rows), a hipGraph of
+    # K nodes (~40 us before its first node runs), one ctypes call per step (the reference-shaped surface).  Those not timed are measured
+    # AFTER the timed bracket and reported as extras (`launch_modes`).
     mode = args.launch
-    if mode == "auto":
-        if args.steps > 400:
-            mode = "persistent"
-        else:
-            launch_probe = {}
-            for cand in ("persistent", "rows", "graph", "python"):
-                launch_probe[cand] = min(bracket(cand) for _ in range(2)) * 1e6 / args.steps
-            mode = min(launch_probe, key=launch_probe.get)
     if mode == "graph" and args.steps > 20000:
-        mode = "rows"
+        raise SystemExit("bench.py: --launch graph with more than 20000 nodes is not supported; use --launch rows")
     # the kernels' counters are summed on the device, stream-ordered: no read-back (idle GPU) right before the timed region
     cnt0, cnt1 = torch.zeros(3, dtype=torch.int64, device=dev), torch.zeros(3, dtype=torch.int64, device=dev)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -343,12 +352,28 @@ def worker(args):
         agg = torch.tensor([float(resets), contact_fraction], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(agg)
         resets, contact_fraction = int(agg[0].item()), float(agg[1].item()) / world
-    assert torch.isfinite(ob).all() and torch.isfinite(rew).all(), "non-finite env outputs"
+    assert torch.isfinite(ob_rows).all() and torch.isfinite(rew_rows).all() and torch.isfinite(extra_rows).all(), "non-finite env outputs in the kept rows"
+    # every one of the K rows was delivered: a step's observation carries the gait phase (sin, cos) in columns 3:5 (ENV:964-968), whose
+    # squares sum to ~1 after un-scaling -- a row the kernel had not written would still hold the zeros it was allocated with
+    assert bool((ob_rows[:, :, 3:5].abs().sum(dim=(1, 2)) > 0).all()), "a step's output row was not written"
     # the timed region must be the steady state (robots on the ground, episodes ending inside the step), not free flight
     if contact_fraction <= 0.0:
         raise SystemExit("bench.py: no toe was in contact during the timed region (free flight) -- not a valid measurement")
     if resets == 0 and n * world * args.steps >= 50000:
         raise SystemExit("bench.py: no episode ended inside the timed region of %d env-steps -- not the steady-state workload" % (n * world * args.steps))
+    # EXTRAS, untimed for `value`: the same K steps issued in the other ways (every step's outputs kept, as in the timed bracket), two
+    # brackets each, the faster one reported; and the persistent launch that keeps only the last step's outputs (round 4's headline form)
+    launch_modes = None
+    if not args.no_mode_extras and args.steps <= 20000:
+        launch_modes = {}
+        for cand in ("persistent", "rows", "graph", "python"):
+            t_c = min(bracket(cand) for _ in range(2))
+            launch_modes[cand] = {"us_per_step": t_c * 1e6 / args.steps, "env_steps_per_sec": float(n) * args.steps / t_c}
+        t_c = min(bracket("persistent", keep=False) for _ in range(2))
+        launch_modes["persistent_last_step_outputs_only"] = {"us_per_step": t_c * 1e6 / args.steps, "env_steps_per_sec": float(n) * args.steps / t_c}
+        launch_modes["what"] = ("wall clock of the same synchronize | %d steps | synchronize bracket on this rank, best of two, measured AFTER the timed bracket; "
+                                "all outputs of every step kept except in persistent_last_step_outputs_only (irrl_env_step_rows_persistent: the form "
+                                "BENCH_r04 timed)" % args.steps)
     check = None
     if args.check_steps > 0:
         # a longer window behind the timed region, in FIVE consecutive parts: mean and spread of us / step (the driver's --steps 20
@@ -429,17 +454,19 @@ def worker(args):
             if pmc.get("library") != _lib.version():
                 pmc_note = "profiles/pmc_summary_latest.json was measured on %s, this run is %s: counters withheld" % (pmc.get("library"), _lib.version())
             elif int(pmc.get("envs", 4096)) == n and env.lanes_per_robot == 16 and not args.set and args.cfg == "bp5_imitation.yaml":
-                if mode == "persistent":      # counters of the persistent kernel (per step of its launches) x the steps of THIS launch
-                    traffic = float(pmc["persistent"]["hbm_bytes_per_step"]["total"]) * args.steps if "persistent" in pmc else None
+                if mode == "persistent":      # counters of the persistent kernel WITH every step's outputs kept (per step of its launches) x the steps of THIS launch
+                    pp = pmc.get("persistent")
+                    if pp and pp.get("outputs_kept"):
+                        traffic = float(pp["hbm_bytes_per_step"]["total"]) * args.steps
+                        pd = pp["derived"]
+                        issue = {"valu_insts_per_wave_per_step": pd["valu_insts_per_wave_per_step"], "cycles_per_valu_inst": pd["cycles_per_valu_inst"],
+                                 "frac_of_single_wave_issue_peak": 4.0 / pd["cycles_per_valu_inst"], "l2_hit_rate": pd["l2_hit_rate"],
+                                 "source": "profiles/pmc_summary_latest.json (irrl_steps_persistent_kernel_l16, launches of %d steps, every step's outputs kept)" % pp["steps_per_launch"]}
+                    else:
+                        pmc_note = "profiles/pmc_summary_latest.json has no counters of the persistent kernel with every step's outputs kept"
                 else:
                     traffic = float(pmc["hbm_bytes_per_launch"]["total"])
-                # how close the single resident wave per SIMD runs to its issue limit of one VALU instruction per 4 cycles
-                if mode == "persistent" and "persistent" in pmc:
-                    pd = pmc["persistent"]["derived"]
-                    issue = {"valu_insts_per_wave_per_step": pd["valu_insts_per_wave_per_step"], "cycles_per_valu_inst": pd["cycles_per_valu_inst"],
-                             "frac_of_single_wave_issue_peak": 4.0 / pd["cycles_per_valu_inst"], "l2_hit_rate": pd["l2_hit_rate"],
-                             "source": "profiles/pmc_summary_latest.json (irrl_steps_persistent_kernel_l16, launches of 100 steps)"}
-                else:
+                    # how close the single resident wave per SIMD runs to its issue limit of one VALU instruction per 4 cycles
                     issue = {"valu_insts_per_wave": pmc["derived"]["valu_insts_per_wave"], "cycles_per_valu_inst": pmc["derived"]["cycles_per_valu_inst"],
                              "frac_of_single_wave_issue_peak": 4.0 / pmc["derived"]["cycles_per_valu_inst"], "source": "profiles/pmc_summary_latest.json"}
         except Exception as e:
@@ -460,22 +487,30 @@ def worker(args):
                                    % (n, args.cfg, (" with " + ", ".join(args.set)) if args.set else "", preroll, HOT_STEPS),
                        "envs_per_gpu": n, "global_envs": n * world, "parallelism": "env-sharded x%d" % world,
                        "lanes_per_robot": env.lanes_per_robot, "preroll": preroll, "hot_steps_before_bracket": HOT_STEPS,
-                       "launch": {"persistent": "ONE launch: every wave walks its own robots through the %d steps (irrl_env_step_rows_persistent; "
-                                                "robots never interact, VEC:273 -- no grid-wide boundary between steps)" % args.steps,
-                                  "rows": "%d back-to-back launches from one irrl_env_step_rows call" % args.steps,
-                                  "graph": "one hipGraph of %d step-kernel nodes" % args.steps,
-                                  "python": "one ctypes call per step"}[mode],
-                       "launch_probe_us_per_step": launch_probe},
-            "roofline": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                       "launch": mode,
+                       "launch_what": {"persistent": "ONE launch: every wave walks its own robots through the %d steps (irrl_env_step_rows_persistent_out; "
+                                                     "robots never interact, VEC:273 -- no grid-wide boundary between steps)" % args.steps,
+                                       "rows": "%d back-to-back launches from one irrl_env_step_rows_out call" % args.steps,
+                                       "graph": "one hipGraph of %d step-kernel nodes" % args.steps,
+                                       "python": "one ctypes call per step"}[mode] + "; fixed by --launch, nothing probed or selected inside the run",
+                       "outputs": "every one of the %d steps stores its ob [N,35] / reward [N] / done [N] / extraInfo [N,6] to its own row of [K,N,.] tables "
+                                  "in HBM (173 B per env-step): what K step() calls of the reference return (VEC:268-278)" % args.steps},
+            # the binding roofline of this path is the FP32 vector ALU (~78 flop per algorithmic byte), so THAT is `roofline`;
+            # `traffic` = HBM bytes of one launch of the timed kernel from the PMC passes (hash-gated file under profiles/)
+            "roofline": {"bound": "valu_fp32", "achieved": ach_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP32_PEAK_TFLOPS,
+                         "traffic": traffic,
                          "kernel": ("irrl_steps_persistent_kernel_l%d" if mode == "persistent" else "irrl_step_kernel_l%d") % env.lanes_per_robot,
                          "steps_per_launch": spl, "avg_launch_us": kernel_ms * 1e3 * spl, "avg_step_us": kernel_ms * 1e3,
-                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n * spl},
-            "roofline_fp32": {"bound": "valu_fp32 (latency/issue bound: 1 wave per SIMD at 4096 envs)", "achieved": ach_tf,
-                              "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP32_PEAK_TFLOPS,
-                              "algorithmic_flops_per_launch": ALG_FLOPS_PER_ENV_STEP * n * spl, "valu_issue": issue},
+                         "algorithmic_flops_per_launch": ALG_FLOPS_PER_ENV_STEP * n * spl, "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n * spl,
+                         "valu_issue": issue,
+                         "note": "latency / issue bound: one wave per SIMD at 4096 envs; flop constant = the instrumented oracle's exact count"},
+            "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS,
+                             "traffic": traffic, "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n * spl,
+                             "counter_traffic_over_algorithmic": (traffic / (ALG_BYTES_PER_ENV_STEP * n * spl)) if traffic else None,
+                             "note": "not the binding roofline; kept so that wasted re-reads would show"},
+            "launch_modes": launch_modes,
             "contact_fraction_in_timed_region": contact_fraction, "resets_in_timed_region": resets,
-            "steady_state_check": check, "rccl_ranks_seen": ranks_seen, "backend": backend if world > 1 else None,
+            "steady_state_check": check, "rccl_ranks_seen": ranks_seen, "backend": backend if dist is not None else None,
             "library": lib.irrl_version().decode(), "pmc_note": pmc_note, "per_step_call": per_call, "per_step_call_compiled": per_call_native,
             "contact_solver": int(env_cfg.get("ContactSolver", 3)),
         }
@@ -488,8 +523,8 @@ def worker(args):
         del env
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import ppo_bench
-        def ppo_leg(policy, cfg_name, grad_note):
-            ppo = ppo_bench.measure(policy, n, args.ppo_steps, args.ppo_iters + 1, args.ppo_epochs, cfg_name, verbose=False, rank=rank)
+        def ppo_leg(policy, cfg_name, grad_note, precision=None):
+            ppo = ppo_bench.measure(policy, n, args.ppo_steps, args.ppo_iters + 1, args.ppo_epochs, cfg_name, verbose=False, rank=rank, precision=precision)
             if dist is not None:
                 t = torch.tensor([ppo["rollout_s"], ppo["update_s"], ppo["rollout_s"] + ppo["update_s"]], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -498,11 +533,18 @@ def worker(args):
                 it_s = ppo["rollout_s"] + ppo["update_s"]
             ppo.update({"world": world, "global_envs": n * world, "ppo_iters_per_sec": 1.0 / it_s, "samples_per_sec": n * world * args.ppo_steps / it_s,
                         "env_steps_per_sec_in_rollout": n * world * args.ppo_steps / ppo["rollout_s"], "cfg": cfg_name,
-                        "collectives_per_optimizer_step": None if world == 1 else grad_note})
+                        "collectives_per_optimizer_step": None if dist is None else grad_note})
             return ppo
+        # every learner leg twice: at the learner's DEFAULT arithmetic (bf16x3: two bf16 planes per operand, ~2^-16 per product) and at the
+        # f32 level (bf16x6 for the LSTM sequence kernels = three planes, ~2^-24; the exact-f32 MFMA kernels for the MlpPolicy gradients)
+        f32_level = os.environ.get("IRRL_BENCH_F32_LEVEL", "1") != "0"
         ppo = ppo_leg("lstm", "default_cfg.yaml", "all-reduce of the flat gradient (283 KB) + 3-float advantage moments")
+        if f32_level:
+            ppo["f32_level"] = ppo_leg("lstm", "default_cfg.yaml", "all-reduce of the flat gradient (283 KB) + 3-float advantage moments", precision="bf16x6")
         # BASELINE config 2's learner beside it: MlpPolicy [64, 64] on the imitation-only config (4 minibatches x 10 epochs)
         ppo_mlp = ppo_leg("mlp", "bp5_imitation.yaml", "all-reduce of the flat gradient (56 KB) + 3-float advantage moments")
+        if f32_level:
+            ppo_mlp["f32_level"] = ppo_leg("mlp", "bp5_imitation.yaml", "all-reduce of the flat gradient (56 KB) + 3-float advantage moments", precision="f32")
         if out is not None:
             out["ppo"] = ppo
             out["ppo_mlp"] = ppo_mlp

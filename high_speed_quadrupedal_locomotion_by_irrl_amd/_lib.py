@@ -29,6 +29,8 @@ SIGNATURES = {
     "irrl_env_step_host": (C.c_int, [vp, fp, fp, fp, u8, fp]),
     "irrl_env_step_rows": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp]),
     "irrl_env_step_rows_persistent": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp]),
+    "irrl_env_step_rows_out": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp]),
+    "irrl_env_step_rows_persistent_out": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp, vp]),
     "irrl_env_test_step_host": (C.c_int, [vp, fp, fp, fp, u8, fp]),
     "irrl_env_reset": (C.c_int, [vp, vp]),
     "irrl_env_reset_host": (C.c_int, [vp, fp]),

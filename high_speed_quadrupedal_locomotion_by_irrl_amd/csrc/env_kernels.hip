@@ -241,9 +241,12 @@ irrl_rollout_persistent_mlp_kernel_l16(EnvParams P, EnvState S, float *ob, float
 // from the same lanes, in program order.  Default pool kind only (no meteorite, published rule); the launcher falls back otherwise.
 __global__ void __launch_bounds__(256, 1)
 IRRL_K(irrl_steps_persistent_kernel)(EnvParams P, EnvState S, const float *action_rows, int n_rows, int first_row, int count, float *ob, float *reward,
-                                     uint8_t *done, float *extra) {
+                                     uint8_t *done, float *extra, int out_rows) {
   const int blk = irrl_xcd_block();
   const size_t row = (size_t)P.n_envs * 12;
+  // out_rows != 0: the outputs are [count, N, .] tables and step k fills row k -- the trajectory `count` step() calls of the reference
+  // would have returned (VEC:268-278, RaisimGymVecEnv.py:26-52); 0: [N, .] arrays every step overwrites (the last step's survive)
+  const size_t orow = out_rows ? (size_t)P.n_envs : (size_t)0;
   for (int k = 0; k < count; k++) {
     // threadIdx.x made opaque once per iteration: the per-lane addresses are then computed inside the loop (hoisted, they are
     // hundreds of 64-bit values that spill)
@@ -263,7 +266,8 @@ IRRL_K(irrl_steps_persistent_kernel)(EnvParams P, EnvState S, const float *actio
     if (!valid_) env_ = P.n_envs - 1;
 #endif
     const float *action = action_rows + row * (size_t)((first_row + k) % n_rows);
-    irrl_plain::step_body<1>(P, S, env_, leg_, valid_, action, ob, reward, done, extra);
+    irrl_plain::step_body<1>(P, S, env_, leg_, valid_, action, ob + orow * 35 * (size_t)k, reward + orow * (size_t)k, done + orow * (size_t)k,
+                             extra + orow * 6 * (size_t)k);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }

@@ -21,7 +21,7 @@
   extern "C" __global__ void irrl_step_kernel_dir##sfx(EnvParams, EnvState, const float *, float *, float *, uint8_t *, float *); \
   extern "C" __global__ void irrl_step_kernel_crutial##sfx(EnvParams, EnvState, const float *, float *, float *, uint8_t *, float *); \
   extern "C" __global__ void irrl_step_kernel_crutial_md##sfx(EnvParams, EnvState, const float *, float *, float *, uint8_t *, float *); \
-  extern "C" __global__ void irrl_steps_persistent_kernel##sfx(EnvParams, EnvState, const float *, int, int, int, float *, float *, uint8_t *, float *); \
+  extern "C" __global__ void irrl_steps_persistent_kernel##sfx(EnvParams, EnvState, const float *, int, int, int, float *, float *, uint8_t *, float *, int); \
   extern "C" __global__ void irrl_init_kernel##sfx(EnvParams, EnvState);                                                       \
   extern "C" __global__ void irrl_reset_kernel##sfx(EnvParams, EnvState, float *);                                             \
   extern "C" __global__ void irrl_observe_kernel##sfx(EnvParams, EnvState, float *);                                           \
@@ -259,31 +259,52 @@ int irrl_env_step(irrl_env *h, const float *action, float *ob, float *reward, ui
   return 0;
 }
 
-int irrl_env_step_rows(irrl_env *h, int count, const float *action_rows, int n_rows, int first_row, float *ob, float *reward,
-                       uint8_t *done, float *extra) {
+// `count` steps from an action table, one launch per step.  out_rows != 0: ob / reward / done / extra are [count, N, .] tables and step k
+// fills row k (what `count` step() calls of the reference return, VEC:268-278 / RaisimGymVecEnv.py:26-52); 0: [N, .] arrays, overwritten
+static int step_rows_impl(irrl_env *h, int count, const float *action_rows, int n_rows, int first_row, float *ob, float *reward,
+                          uint8_t *done, float *extra, int out_rows, const char *who) {
   if (need_init(h)) return 1;
-  if (count < 0 || n_rows <= 0 || first_row < 0) { g_err = "irrl_env_step_rows: count >= 0, n_rows > 0, first_row >= 0"; return 1; }
+  if (count < 0 || n_rows <= 0 || first_row < 0) { g_err = std::string(who) + ": count >= 0, n_rows > 0, first_row >= 0"; return 1; }
+  if (!action_rows || !ob || !reward || !done || !extra) { g_err = std::string(who) + ": NULL argument"; return 1; }
   if (use_device(h)) return 1;
-  const size_t row = (size_t)h->P.n_envs * 12;
+  const size_t row = (size_t)h->P.n_envs * 12, orow = out_rows ? (size_t)h->P.n_envs : (size_t)0;
   for (int k = 0; k < count; k++) {
     const float *action = action_rows + row * (size_t)((first_row + k) % n_rows);
-    IRRL_LAUNCH_STEP(h, lane_grid(h, h->P.n_envs), h->P, h->S, action, ob, reward, done, extra);
+    IRRL_LAUNCH_STEP(h, lane_grid(h, h->P.n_envs), h->P, h->S, action, ob + orow * 35 * (size_t)k, reward + orow * (size_t)k, done + orow * (size_t)k,
+                     extra + orow * 6 * (size_t)k);
   }
   HIP_TRY(hipGetLastError());
   return 0;
 }
-
 // the same `count` steps as ONE launch (env_kernels.hip irrl_steps_persistent_kernel: a wave walks its robots through all of them, no
-// grid-wide boundary between steps); pools the kernel is not instantiated for (meteorite, first contact rule) take irrl_env_step_rows
-int irrl_env_step_rows_persistent(irrl_env *h, int count, const float *action_rows, int n_rows, int first_row, float *ob, float *reward,
-                                  uint8_t *done, float *extra) {
+// grid-wide boundary between steps); pools the kernel is not instantiated for (meteorite, first contact rule) take the launch-per-step path
+static int step_rows_persistent_impl(irrl_env *h, int count, const float *action_rows, int n_rows, int first_row, float *ob, float *reward,
+                                     uint8_t *done, float *extra, int out_rows, const char *who) {
   if (need_init(h)) return 1;
-  if (count < 0 || n_rows <= 0 || first_row < 0) { g_err = "irrl_env_step_rows_persistent: count >= 0, n_rows > 0, first_row >= 0"; return 1; }
-  if (h->P.crutial || !h->P.contact_rule) return irrl_env_step_rows(h, count, action_rows, n_rows, first_row, ob, reward, done, extra);
+  if (count < 0 || n_rows <= 0 || first_row < 0) { g_err = std::string(who) + ": count >= 0, n_rows > 0, first_row >= 0"; return 1; }
+  if (!action_rows || !ob || !reward || !done || !extra) { g_err = std::string(who) + ": NULL argument"; return 1; }
+  if (h->P.crutial || !h->P.contact_rule) return step_rows_impl(h, count, action_rows, n_rows, first_row, ob, reward, done, extra, out_rows, who);
   if (use_device(h)) return 1;
-  if (count > 0) IRRL_LAUNCH(h, irrl_steps_persistent_kernel, lane_grid(h, h->P.n_envs), h->P, h->S, action_rows, n_rows, first_row, count, ob, reward, done, extra);
+  if (count > 0) IRRL_LAUNCH(h, irrl_steps_persistent_kernel, lane_grid(h, h->P.n_envs), h->P, h->S, action_rows, n_rows, first_row, count, ob, reward, done, extra, out_rows);
   HIP_TRY(hipGetLastError());
   return 0;
+}
+
+int irrl_env_step_rows(irrl_env *h, int count, const float *action_rows, int n_rows, int first_row, float *ob, float *reward,
+                       uint8_t *done, float *extra) {
+  return step_rows_impl(h, count, action_rows, n_rows, first_row, ob, reward, done, extra, 0, "irrl_env_step_rows");
+}
+int irrl_env_step_rows_persistent(irrl_env *h, int count, const float *action_rows, int n_rows, int first_row, float *ob, float *reward,
+                                  uint8_t *done, float *extra) {
+  return step_rows_persistent_impl(h, count, action_rows, n_rows, first_row, ob, reward, done, extra, 0, "irrl_env_step_rows_persistent");
+}
+int irrl_env_step_rows_out(irrl_env *h, int count, const float *action_rows, int n_rows, int first_row, float *ob_rows, float *reward_rows,
+                           uint8_t *done_rows, float *extra_rows) {
+  return step_rows_impl(h, count, action_rows, n_rows, first_row, ob_rows, reward_rows, done_rows, extra_rows, 1, "irrl_env_step_rows_out");
+}
+int irrl_env_step_rows_persistent_out(irrl_env *h, int count, const float *action_rows, int n_rows, int first_row, float *ob_rows,
+                                      float *reward_rows, uint8_t *done_rows, float *extra_rows) {
+  return step_rows_persistent_impl(h, count, action_rows, n_rows, first_row, ob_rows, reward_rows, done_rows, extra_rows, 1, "irrl_env_step_rows_persistent_out");
 }
 
 int irrl_lstm_rollout(irrl_env *h, int steps, int hid, int ob_dim, int act_dim, float *obs, uint8_t *dones, const float *states_in,
@@ -836,7 +857,13 @@ int irrl_mlp_ppo_grads_bf16(int kind, size_t n, const int64_t *idx, int ob_dim, 
   if (n == 0 || n_blocks <= 0) { g_err = "irrl_mlp_ppo_grads_bf16: empty batch"; return 1; }
   if (ob_dim != IRRL_MLP_OB || hid != IRRL_MLP_H || act_dim != 12) { g_err = "irrl_mlp_ppo_grads_bf16: built for 35 observations, [64, 64] hidden units and 12 actions"; return 1; }
   if (kind != 0 && kind != 1) { g_err = "irrl_mlp_ppo_grads_bf16: kind is 0 (policy network) or 1 (value network)"; return 1; }
-  static int allowed = -1;
+  // the opt-in belongs to the CURRENT device (a process may drive several GPUs): remembered per device ordinal
+  static int allowed_on[IRRL_MAX_DEVICES];
+  static bool allowed_init = false;
+  if (!allowed_init) { for (int i = 0; i < IRRL_MAX_DEVICES; i++) allowed_on[i] = -1; allowed_init = true; }
+  int dev_ = 0;
+  if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= IRRL_MAX_DEVICES) { g_err = "irrl_mlp_ppo_grads_bf16: no current device"; return 1; }
+  int &allowed = allowed_on[dev_];
   if (allowed < 0)    // the weight planes and the waves' images exceed the 64 KB a kernel gets without asking (gfx950 has 160 KB per CU)
     allowed = (hipFuncSetAttribute((const void *)irrl_mlp_ppo_bf16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, mlp_bf16_lds_bytes()) == hipSuccess &&
                hipFuncSetAttribute((const void *)irrl_mlp_ppo_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, mlp_bf16_lds_bytes()) == hipSuccess) ? 0 : 1;

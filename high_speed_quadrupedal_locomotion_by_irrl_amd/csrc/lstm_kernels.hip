@@ -1280,6 +1280,9 @@ int irrl_mlp_policy_step(int hid, int ob_dim, int act_dim, int N, const float *o
 
 // ---- the sequence kernels on the bf16 matrix cores with compensated operand splits (csrc/lstm_bf16.hpp) ----
 // nsplit 2: three plane products per product (~2^-16 relative), 3: six (~2^-24, the f32 level).  Same tensors as the *_x entry points.
+#ifndef IRRL_MAX_DEVICES
+#define IRRL_MAX_DEVICES 64
+#endif
 // returns 0 on success; 1 = unsupported shape, 2 = launch error
 static int lstm_bf16_allow_lds(const void *kernel, int bytes) {
   // the tiles exceed the 64 KB a kernel gets without asking (gfx950 has 160 KB per CU)
@@ -1310,7 +1313,13 @@ int irrl_lstm_seq_backward_bf16(int nsplit, int hid, int T, int N, int n_in, con
   a.gates = gates; a.cseq = cseq; a.hseq = hseq; a.x = x; a.masks = masks; a.state0 = state0; a.dh_in = dh_in; a.wh_p = wh_p; a.wx_p = wx_p;
   a.dx = dx; a.dwx_part = dwx_part; a.dwh_part = dwh_part; a.db_part = db_part; a.T = T; a.N = N; a.n_in = n_in;
   hipStream_t s = (hipStream_t)hip_stream;
-  static int allowed = -1;
+  // the opt-in belongs to the CURRENT device (a process may drive several GPUs): remembered per device ordinal
+  static int allowed_on[IRRL_MAX_DEVICES];
+  static bool allowed_init = false;
+  if (!allowed_init) { for (int i = 0; i < IRRL_MAX_DEVICES; i++) allowed_on[i] = -1; allowed_init = true; }
+  int dev_ = 0;
+  if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= IRRL_MAX_DEVICES) return 2;
+  int &allowed = allowed_on[dev_];
   if (allowed < 0) {
     allowed = lstm_bf16_allow_lds((const void *)lstm_seq_bwd_bf16_kernel<2, true>, lstm_bwd_bf16_lds_bytes<2>()) |
               lstm_bf16_allow_lds((const void *)lstm_seq_bwd_bf16_kernel<2, false>, lstm_bwd_bf16_lds_bytes<2>()) |

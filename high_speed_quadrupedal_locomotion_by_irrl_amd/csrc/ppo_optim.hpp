@@ -8,7 +8,8 @@
 //
 //   irrl_clip_adam_kernel        ONE workgroup of 1024 lanes: sum g^2 in a fixed order (deterministic: every rank computes the
 //                                same bits from the same all-reduced gradient, so replicas never drift), scale =
-//                                grad_scale * min(1, max_norm / (grad_scale * |g| + 1e-6)), then Adam in place.  70 741
+//                                grad_scale * max_norm / max(grad_scale * |g|, max_norm) (tf.clip_by_global_norm), then
+//                                TensorFlow's Adam in place (epsilon outside the bias correction, see the kernel).  70 741
 //                                parameters = 17 float4 per lane per array, L2-resident.
 //   irrl_sum_rows_scatter_kernel out[map[m][c]] = add[m][c] + sum_r part[m][r][c]: the per-workgroup partial rows the MlpPolicy
 //                                gradient kernels leave, summed in a fixed order and written STRAIGHT into the flat gradient
@@ -53,7 +54,7 @@ irrl_clip_adam_kernel(const ClipAdamArgs a) {
     for (int i = 0; i < 16; i++) s += red[i];
     const float norm = a.grad_scale * sqrtf(s);
     float coef = 1.0f;
-    if (a.max_norm > 0.0f) coef = fminf(1.0f, a.max_norm / (norm + 1e-6f));   // torch.nn.utils.clip_grad_norm_
+    if (a.max_norm > 0.0f) coef = a.max_norm / fmaxf(norm, a.max_norm);   // tf.clip_by_global_norm: t * clip_norm / max(global_norm, clip_norm)
     bc = a.grad_scale * coef;
     if (a.norm_out) *a.norm_out = norm;
   }
@@ -63,7 +64,10 @@ irrl_clip_adam_kernel(const ClipAdamArgs a) {
     g *= sc;
     m = m + ob1 * (g - m);                 // lerp(m, g, 1 - beta1)
     v = b2 * v + ob2 * (g * g);
-    const float denom = sqrtf(v) * a.inv_bc2_sqrt + a.eps;
+    // tf.train.AdamOptimizer: theta -= lr * sqrt(1 - b2^t) / (1 - b1^t) * m / (sqrt(v) + eps) -- epsilon sits OUTSIDE the bias correction
+    // ("epsilon hat" of Kingma & Ba), i.e. an effective epsilon of eps / sqrt(1 - b2^t): 3e-4 at t = 1 for eps 1e-5, where
+    // torch.optim.Adam (sqrt(v) / sqrt(1 - b2^t) + eps) would use 1e-5
+    const float denom = (sqrtf(v) + a.eps) * a.inv_bc2_sqrt;
     th -= a.step_size * (m / denom);
     (void)b1;
   };

@@ -120,32 +120,35 @@ class FlexibleGymEnv(object):
                 self._h, _np_f32(action, (n, 12), "action"), _np_f32(ob, (n, 35), "ob"), _np_f32(reward, (n,), "reward"),
                 _np_bool(done, (n,), "done"), _np_f32(extraInfo, (n, 6), "extraInfo")))
 
-    def step_rows(self, count, action_rows, first_row, ob, reward, done, extraInfo, persistent=False):
-        """build-defined: `count` consecutive steps from a device-resident action table [rows, N, 12] (step k takes row
-        (first_row + k) % rows) in one call -- the launches go out back to back from C (irrl_env_step_rows), or, with persistent=True,
-        as ONE launch in which every wave walks its own robots through all the steps (irrl_env_step_rows_persistent; same bits)"""
+    def _step_rows_args(self, count, action_rows, first_row, ob, reward, done, extraInfo, persistent):
+        """-> (C function, argument tuple).  Outputs of shape [N, .] are overwritten by every step (the last step's survive); outputs of
+        shape [count, N, .] select the `_out` entry points: step k fills row k, the trajectory `count` step() calls would have returned"""
         import torch
-        n = self._n
+        n, count = self._n, int(count)
         rows = int(action_rows.shape[0])
         self._sync_stream()
         f32 = (torch.float32,)
-        _lib.check((self._lib.irrl_env_step_rows_persistent if persistent else self._lib.irrl_env_step_rows)(
-            self._h, int(count), _dev_ptr(action_rows, (rows, n, 12), f32, "action_rows"), rows, int(first_row),
-            _dev_ptr(ob, (n, 35), f32, "ob"), _dev_ptr(reward, (n,), f32, "reward"),
-            _dev_ptr(done, (n,), (torch.bool, torch.uint8), "done"), _dev_ptr(extraInfo, (n, 6), f32, "extraInfo")))
+        per_step = ob.dim() == 3
+        lead = (count,) if per_step else ()
+        args = (self._h, count, _dev_ptr(action_rows, (rows, n, 12), f32, "action_rows"), rows, int(first_row),
+                _dev_ptr(ob, lead + (n, 35), f32, "ob"), _dev_ptr(reward, lead + (n,), f32, "reward"),
+                _dev_ptr(done, lead + (n,), (torch.bool, torch.uint8), "done"), _dev_ptr(extraInfo, lead + (n, 6), f32, "extraInfo"))
+        name = "irrl_env_step_rows" + ("_persistent" if persistent else "") + ("_out" if per_step else "")
+        return getattr(self._lib, name), args
+
+    def step_rows(self, count, action_rows, first_row, ob, reward, done, extraInfo, persistent=False):
+        """build-defined: `count` consecutive steps from a device-resident action table [rows, N, 12] (step k takes row
+        (first_row + k) % rows) in one call -- the launches go out back to back from C (irrl_env_step_rows), or, with persistent=True,
+        as ONE launch in which every wave walks its own robots through all the steps (irrl_env_step_rows_persistent; same bits).
+        ob / reward / done / extraInfo of shape [count, N, .] receive EVERY step's outputs (row k = step k: irrl_env_step_rows[_persistent]_out,
+        what `count` step() calls return one after the other); of shape [N, .] only the last step's survive."""
+        fn, args = self._step_rows_args(count, action_rows, first_row, ob, reward, done, extraInfo, persistent)
+        _lib.check(fn(*args))
 
     def step_rows_call(self, count, action_rows, first_row, ob, reward, done, extraInfo, persistent=False):
         """the same call with its arguments checked and marshalled NOW: returns a zero-argument callable that only issues the
         launches (for callers that time them: bench.py's 20-step bracket is 0.8 ms long and the checks above cost ~15 us)"""
-        import torch
-        n = self._n
-        rows = int(action_rows.shape[0])
-        self._sync_stream()
-        f32 = (torch.float32,)
-        args = (self._h, int(count), _dev_ptr(action_rows, (rows, n, 12), f32, "action_rows"), rows, int(first_row),
-                _dev_ptr(ob, (n, 35), f32, "ob"), _dev_ptr(reward, (n,), f32, "reward"),
-                _dev_ptr(done, (n,), (torch.bool, torch.uint8), "done"), _dev_ptr(extraInfo, (n, 6), f32, "extraInfo"))
-        fn = self._lib.irrl_env_step_rows_persistent if persistent else self._lib.irrl_env_step_rows
+        fn, args = self._step_rows_args(count, action_rows, first_row, ob, reward, done, extraInfo, persistent)
         return lambda: _lib.check(fn(*args))
 
     def testStep(self, action, ob, reward, done, extraInfo):

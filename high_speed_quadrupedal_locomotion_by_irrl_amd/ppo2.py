@@ -238,6 +238,48 @@ def mlp_ppo_grads(policy, obs, actions, returns, old_values, old_neglogp, adv_st
     return loss, torch.stack([pg, vf, ent, kl, cf]), grads
 
 
+def clip_by_global_norm_(params, max_norm):
+    """tf.clip_by_global_norm (ppo2.py:192) on the .grad tensors, in place: g *= max_norm / max(|g|_global, max_norm).  -> |g|_global"""
+    grads = [p.grad for p in params if p.grad is not None]
+    norm = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g) for g in grads]))
+    coef = max_norm / torch.clamp(norm, min=max_norm)
+    torch._foreach_mul_(grads, coef)
+    return norm
+
+
+class TFAdam(torch.optim.Optimizer):
+    """tf.train.AdamOptimizer(learning_rate, epsilon) as the reference builds it (ppo2.py:195), TensorFlow 1 semantics:
+        lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t);  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  theta -= lr_t * m / (sqrt(v) + eps)
+    i.e. epsilon sits OUTSIDE the bias correction ("epsilon hat" of Kingma & Ba) -- an effective epsilon of eps / sqrt(1 - beta2^t),
+    3e-4 at t = 1 for eps 1e-5, where torch.optim.Adam (sqrt(v) / sqrt(1 - beta2^t) + eps) uses 1e-5: the early updates of parameters with
+    small gradients differ.  The kernel `irrl_clip_adam` (csrc/ppo_optim.hpp) implements the same formula on the flat buffers."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-5):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    @torch.no_grad()
+    def step(self):
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            for p in ps:
+                st = self.state[p]
+                if not st:
+                    st["step"], st["m"], st["v"] = 0, torch.zeros_like(p), torch.zeros_like(p)
+                st["step"] += 1
+            t = self.state[ps[0]]["step"]
+            lr_t = group["lr"] * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+            gs, ms, vs = [p.grad for p in ps], [self.state[p]["m"] for p in ps], [self.state[p]["v"] for p in ps]
+            torch._foreach_lerp_(ms, gs, 1.0 - b1)
+            torch._foreach_mul_(vs, b2)
+            torch._foreach_addcmul_(vs, gs, gs, value=1.0 - b2)
+            den = torch._foreach_sqrt(vs)
+            torch._foreach_add_(den, group["eps"])
+            torch._foreach_addcdiv_(ps, ms, den, value=-lr_t)
+
+
 class FlatParams(object):
     """Every parameter of a policy as a VIEW of one persistent flat buffer, and the gradient and the Adam moments likewise.
     The data-parallel exchange of an optimizer step (one all-reduce of the flat gradient) is then ONE collective on
@@ -636,6 +678,9 @@ class PPO2(object):
         self.num_timesteps = 0
         self.world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
         self.rank = torch.distributed.get_rank() if self.world > 1 else 0
+        # a job started under a launcher runs its collectives whatever its size: with ONE rank the all-reduces are identities, and the
+        # RCCL path (backend "nccl": device tensors, the library loaded, a communicator created) is exercised on a single-GPU box
+        self.collective = torch.distributed.is_available() and torch.distributed.is_initialized()
         self.seed = 0 if seed is None else int(seed)
         # identical initial weights and identical generators on every rank; what differs per rank is WHICH robots it owns: rank r
         # holds the global env ids r * n_envs .. (r + 1) * n_envs - 1 of the one big pool (env RNG: the pool's EnvIdOffset; sampling
@@ -652,16 +697,15 @@ class PPO2(object):
         self.env_id_offset = 0                                     # global id of this rank's env 0: `_bind_env_ids`
         self._bind_env_ids()
         # parameters, gradients and Adam moments as views of flat buffers (FlatParams): one collective per optimizer step, and on
-        # the GPU clip + Adam as one launch (`flat_optim`; tests flip it to compare with torch.optim.Adam on the same views)
+        # the GPU clip + Adam as one launch (`flat_optim`; tests flip it to compare with `TFAdam` on the same views)
         self.flat = FlatParams(self.policy)
         self.flat_optim = self.device.type == "cuda"
         adam_kw = dict(lr=float(learning_rate) if not callable(learning_rate) else 1e-3, eps=1e-5, betas=(0.9, 0.999))
-        try:  # one fused kernel over the 19 parameter tensors on the GPU
-            self.optimizer = torch.optim.Adam(self.policy.parameters(), fused=(self.device.type == "cuda"), **adam_kw)
-        except Exception:
-            self.optimizer = torch.optim.Adam(self.policy.parameters(), **adam_kw)
-        # the LSTM kernels read [unit][gate]-permuted COPIES of the weights; fused Adam updates the parameters without bumping
-        # their `_version`, so the copies are refreshed explicitly after every step of this optimizer, whoever calls it
+        # TensorFlow's Adam (epsilon outside the bias correction), like the reference's tf.train.AdamOptimizer -- the CPU path and what the
+        # tests compare the flat-buffer kernel with
+        self.optimizer = TFAdam(self.policy.parameters(), **adam_kw)
+        # the LSTM kernels read [unit][gate]-permuted COPIES of the weights; the in-place update does not tell them,
+        # so the copies are refreshed explicitly after every step of this optimizer, whoever calls it
         if hasattr(self.policy, "prepare") and hasattr(self.optimizer, "register_step_post_hook"):
             self.optimizer.register_step_post_hook(lambda *_a, **_k: self.policy.prepare())
         self.loss_names = ['policy_loss', 'value_loss', 'policy_entropy', 'approxkl', 'clipfrac']
@@ -684,8 +728,8 @@ class PPO2(object):
         if adv is not None and adv.numel() == returns.numel():
             returns, values = adv, None
         _lib.check(lib.irrl_adv_moments(int(index.numel()), p(index), p(returns), p(values) if values is not None else None, p(scratch), 256, p(scratch[512:]),
-                                        p(stats) if self.world == 1 else None, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
-        if self.world == 1:
+                                        p(stats) if not self.collective else None, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        if not self.collective:
             return stats
         mean, var = self._adv_moments(None, None, moments=scratch[512:])
         return torch.stack([mean, torch.sqrt(var)]).to(torch.float32)
@@ -697,15 +741,24 @@ class PPO2(object):
             advs = returns - values
             n_local = torch.tensor([float(advs.numel())], device=advs.device, dtype=torch.float64)
             moments = torch.stack([advs.double().sum(), (advs.double() ** 2).sum(), n_local[0]])
-        if self.world > 1:
+        if self.collective:
             torch.distributed.all_reduce(moments)                     # C2: 3 floats
         mean = moments[0] / moments[2]
         var = torch.clamp(moments[1] / moments[2] - mean * mean, min=0.0)
         return mean, var
 
-    def _train_step(self, lr_now, cliprange_now, obs, returns, masks, actions, values, neglogpacs, states=None, adv_moments=None, index=None):
+    def _train_step(self, lr_now, cliprange_now, obs, returns, masks, actions, values, neglogpacs, states=None, adv_moments=None, index=None,
+                    grad_weight=1.0, empty=False):
         """index: the arrays are the FLAT rollout and `index` picks this minibatch's rows (MlpPolicy's gradient kernels read them
-        in place); otherwise the arrays are the minibatch."""
+        in place); otherwise the arrays are the minibatch.  grad_weight: this rank's share of a GLOBAL minibatch that the ranks hold
+        unequal parts of (`_global_minibatches`): its mean gradient is weighted m_r * world / m before the all-reduce, so that the
+        averaged sum is the mean over the global minibatch's m samples; empty: this rank holds none of them (it still joins the collectives)."""
+        if empty:
+            if adv_moments is None:
+                self._adv_moments(None, None, moments=torch.zeros(3, device=self.device, dtype=torch.float64))
+            self.flat.grad[:self.flat.n].zero_()
+            self._apply_gradients(lr_now, gathered=True)
+            return None
         if index is not None:
             if adv_moments is not None:
                 adv_stats = torch.stack([adv_moments[0], torch.sqrt(adv_moments[1])]).to(torch.float32)
@@ -713,7 +766,7 @@ class PPO2(object):
                 adv_stats = self._adv_stats_indexed(returns, values, index)
             row = mlp_ppo_grads_flat(self.policy, self.flat, obs, actions, returns, values, neglogpacs, adv_stats, cliprange_now, self.ent_coef,
                                      self.vf_coef, index)
-            self._apply_gradients(lr_now, gathered=True)
+            self._apply_gradients(lr_now, gathered=True, weight=grad_weight)
             return row      # raw sums: `update` turns the rows of all steps into the logged means at once (mlp_stats_rows)
         mean, var = adv_moments if adv_moments is not None else self._adv_moments(returns, values)
         advs = None if (self.fused_loss and fused_ppo_loss_supported(self.policy, obs)) else returns - values
@@ -738,12 +791,12 @@ class PPO2(object):
                                                  self.ent_coef, self.vf_coef)
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
-        self._apply_gradients(lr_now)
+        self._apply_gradients(lr_now, weight=grad_weight)
         if stats is not None:
             return stats.detach()
         return torch.stack([pg.detach(), vf.detach(), ent.detach(), kl.detach(), cf.detach()])
 
-    def _apply_gradients(self, lr_now, gathered=False):
+    def _apply_gradients(self, lr_now, gathered=False, weight=1.0):
         """Average over ranks, clip by the global norm, Adam (ppo2.py:182-189, 283-298).  The gradient lives in ONE flat buffer
         (FlatParams): `gathered` says the gradient kernels wrote it there themselves, otherwise autograd's per-parameter tensors are
         copied in by one multi-tensor launch.  Several ranks: ONE all-reduce of that buffer (283 KB for the LSTM
@@ -751,7 +804,9 @@ class PPO2(object):
         fl = self.flat
         if not gathered:
             fl.gather()
-        if self.world > 1:
+        if weight != 1.0:
+            fl.grad[:fl.n] *= float(weight)      # this rank's share of a global minibatch held in unequal parts (`_global_minibatches`)
+        if self.collective:
             torch.distributed.all_reduce(fl.grad[:fl.n])              # C1: the only collective of the step besides the 3 moment floats
         if self.flat_optim and self.device.type == "cuda":
             from . import _lib
@@ -767,7 +822,7 @@ class PPO2(object):
             fl.grad[:fl.n] /= self.world
         fl.point_grads_at_views()
         if self.max_grad_norm is not None:
-            torch.nn.utils.clip_grad_norm_(fl.params, self.max_grad_norm)  # clip_by_global_norm AFTER averaging
+            clip_by_global_norm_(fl.params, self.max_grad_norm)  # tf.clip_by_global_norm AFTER averaging (ppo2.py:192)
         for g in self.optimizer.param_groups:
             g['lr'] = lr_now
         self.optimizer.step()       # (its post-step hook refreshes the kernels' permuted weight copies)
@@ -788,6 +843,27 @@ class PPO2(object):
             return out
         return torch.from_numpy(feistel_permutation(n, key, self._shuffles)).to(self.device)
 
+    def _global_minibatches(self, order, per_row, size):
+        """Several ranks, nminibatches > 1: the reference draws ONE permutation over ALL samples (non-recurrent, ppo2.py:364-380) resp. ALL
+        envs (recurrent, ppo2.py:387-402) and cuts it into minibatches.  `order` is that permutation of the GLOBAL ids, identical on every
+        rank (global sample id = t * (world * N) + global env id; global env id = rank * N + local env id, the pool's EnvIdOffset layout);
+        this rank keeps, of every global minibatch of `size` ids, the ones whose env it owns -- an unequal share m_r of the minibatch
+        (binomial around size / world).  Yields (local ids, grad_weight = m_r * world / size): the weighted, all-reduced, averaged
+        gradients are the mean over the global minibatch, so the N-rank update equals the single-process one up to summation order.
+        per_row: ids per time row of the GLOBAL layout (world * N for sample ids, None for env ids)."""
+        n_loc = int(self.n_envs)
+        lo = self.rank * n_loc
+        if per_row is None:
+            env_g, t = order, None
+        else:
+            t = torch.div(order, per_row, rounding_mode="floor")
+            env_g = order - t * per_row
+        mine = (env_g >= lo) & (env_g < lo + n_loc)
+        local = (env_g - lo) if t is None else (t * n_loc + (env_g - lo))
+        for start in range(0, int(order.numel()), size):
+            part = local[start:start + size][mine[start:start + size]].contiguous()     # (one host sync per minibatch: its length)
+            yield part, float(part.numel()) * self.world / float(size)
+
     def update(self, batch, lr_now, cliprange_now):
         """All epochs / minibatches of one PPO iteration (ppo2.py:362-404)."""
         T, N = batch["values"].shape
@@ -799,7 +875,19 @@ class PPO2(object):
             envs_per_batch = N // self.nminibatches
             # one minibatch = the whole rollout: the advantage moments are the same in every epoch
             whole = self._adv_moments(batch["returns"], batch["values"]) if self.nminibatches == 1 else None
+            split = self.world > 1 and self.nminibatches > 1      # one permutation over ALL ranks' envs, every rank keeps its own (ppo2.py:387-402)
             for _ in range(self.noptepochs):
+                if split:
+                    perm_g = torch.randperm(N * self.world, device=self.device, generator=self.generator)   # same generator state on every rank
+                    for idx, w in self._global_minibatches(perm_g, None, envs_per_batch * self.world):
+                        if idx.numel() == 0:
+                            self._train_step(lr_now, cliprange_now, None, None, None, None, None, None, empty=True)
+                            continue
+                        sl = lambda x: x[:, idx]
+                        losses.append(w / self.world * self._train_step(lr_now, cliprange_now, sl(batch["obs"]), sl(batch["returns"]), sl(batch["masks"]),
+                                                                        sl(batch["actions"]), sl(batch["values"]), sl(batch["neglogpacs"]),
+                                                                        states=batch["states"][idx], grad_weight=w))
+                    continue
                 perm = torch.randperm(N, device=self.device, generator=self.generator)
                 for start in range(0, N, envs_per_batch):
                     idx = perm[start:start + envs_per_batch]
@@ -812,6 +900,10 @@ class PPO2(object):
                     losses.append(self._train_step(lr_now, cliprange_now, sl(batch["obs"]), sl(batch["returns"]), sl(batch["masks"]),
                                                    sl(batch["actions"]), sl(batch["values"]), sl(batch["neglogpacs"]), states=st,
                                                    adv_moments=whole))
+            if split:
+                tot = torch.stack(losses).sum(0) / (self.noptepochs * self.nminibatches)    # this rank's share of every global minibatch's mean
+                torch.distributed.all_reduce(tot)
+                return tot
         else:
             n_batch = T * N
             assert n_batch % self.nminibatches == 0
@@ -822,16 +914,38 @@ class PPO2(object):
             flat = {k: batch[k].reshape(n_batch, *batch[k].shape[2:]) for k in ("obs", "returns", "masks", "actions", "values", "neglogpacs")}
             in_place = self.fused_mlp and mlp_ppo_grads_supported(self.policy, flat["obs"])
             self._flat_adv = (flat["returns"] - flat["values"]).contiguous() if in_place else None
+            split = self.world > 1 and self.nminibatches > 1      # ONE permutation over ALL ranks' samples (ppo2.py:364-380), every rank keeps its own
+            weights = []
             for _ in range(self.noptepochs):
-                inds = self._sample_order(n_batch)
-                for start in range(0, n_batch, bs):
-                    mb = inds[start:start + bs]
+                if split:
+                    order = self._sample_order(n_batch * self.world)
+                    parts = self._global_minibatches(order, N * self.world, bs * self.world)
+                else:
+                    inds = self._sample_order(n_batch)
+                    parts = ((inds[start:start + bs], 1.0) for start in range(0, n_batch, bs))
+                for mb, w in parts:
+                    if mb.numel() == 0:
+                        self._train_step(lr_now, cliprange_now, None, None, None, None, None, None, empty=True)
+                        continue
+                    weights.append(w / self.world)
                     if in_place:     # the gradient kernels read the minibatch's rows through the index: nothing is gathered
                         losses.append(self._train_step(lr_now, cliprange_now, flat["obs"], flat["returns"], flat["masks"], flat["actions"],
-                                                       flat["values"], flat["neglogpacs"], index=mb.contiguous()))
+                                                       flat["values"], flat["neglogpacs"], index=mb.contiguous(), grad_weight=w))
                         continue
                     losses.append(self._train_step(lr_now, cliprange_now, flat["obs"][mb], flat["returns"][mb], flat["masks"][mb],
-                                                   flat["actions"][mb], flat["values"][mb], flat["neglogpacs"][mb]))
+                                                   flat["actions"][mb], flat["values"][mb], flat["neglogpacs"][mb], grad_weight=w))
+            if split:
+                # logged means over the GLOBAL minibatches: every rank's rows are sums (kernels) / means (graph) over ITS share
+                self._flat_adv = None
+                if in_place:
+                    tot = mlp_stats_rows(losses, float(bs * self.world), self.policy.act_dim)
+                    tot[:, 2] *= torch.tensor(weights, device=tot.device, dtype=tot.dtype)      # (the entropy column is not a sum over samples)
+                    tot = tot.sum(0)
+                else:
+                    tot = (torch.stack(losses) * torch.tensor(weights, device=self.device, dtype=torch.float32).unsqueeze(1)).sum(0)
+                tot = tot / (self.noptepochs * self.nminibatches)
+                torch.distributed.all_reduce(tot)
+                return tot
             self._flat_adv = None
             if in_place:
                 return mlp_stats_rows(losses, float(bs), self.policy.act_dim).mean(0)
@@ -924,19 +1038,25 @@ class PPO2(object):
         """Which robots of the one big pool this rank owns.  Every random draw of the path is addressed by the GLOBAL env id: the env
         pool's own draws by its `EnvIdOffset`, the policy's sampling noise by `env_id_offset` -- the two must be the same number, and
         the ranks' ranges must not overlap, or the N-rank job silently trains on N copies of the same data.  The offset is therefore
-        READ from the pool when it exposes one (`env.env_id_offset`: TorchVecEnv / RaisimGymVecEnv over the C-ABI pool), rank *
-        n_envs otherwise; with several ranks the ranges are all-gathered and checked."""
+        READ from the pool when it exposes one (`env.env_id_offset`: TorchVecEnv / RaisimGymVecEnv over the C-ABI pool); an env without
+        one gets rank * n_envs and, with several ranks, a warning; with several ranks the ranges are all-gathered (by every rank) and checked."""
         n = int(self.n_envs or 0)
         off = getattr(self.env, "env_id_offset", None) if self.env is not None else None
+        if off is None and self.env is not None and self.world > 1:
+            import warnings
+            warnings.warn("PPO2: %s exposes no `env_id_offset`; assuming this rank's pool was created with EnvIdOffset = rank * num_envs = %d. "
+                          "If it was not, every rank draws the same env random streams and the overlap check below cannot see it."
+                          % (type(self.env).__name__, self.rank * n))
         self.env_id_offset = int(off) if off is not None else self.rank * n
-        if self.world > 1 and self.env is not None:
-            mine = torch.tensor([self.env_id_offset, n], dtype=torch.int64)
+        if self.collective:
+            # entered by EVERY rank (a rank without an env contributes an empty range): ranks that disagree on having an env must not hang
+            mine = torch.tensor([self.env_id_offset, n if self.env is not None else 0], dtype=torch.int64)
             backend = torch.distributed.get_backend()
             if backend == "nccl":
                 mine = mine.to(self.device)
             got = [torch.zeros_like(mine) for _ in range(self.world)]
             torch.distributed.all_gather(got, mine)
-            spans = sorted((int(g[0]), int(g[0]) + int(g[1])) for g in got)
+            spans = sorted((int(g[0]), int(g[0]) + int(g[1])) for g in got if int(g[1]) > 0)
             for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
                 if b0 < a1:
                     raise ValueError("PPO2: ranks own overlapping global env ids %s -- give rank r's pool EnvIdOffset = r * num_envs "

@@ -48,6 +48,12 @@ class RaisimGymVecEnv(object):
     def seed(self, seed=None):
         self.wrapper.setSeed(0 if seed is None else int(seed))
 
+    @property
+    def env_id_offset(self):
+        """global id of this pool's env 0 (cfg `EnvIdOffset`; build-defined, see TorchVecEnv.env_id_offset): what PPO2 checks across ranks"""
+        v = self.wrapper.cfg_value("EnvIdOffset") if hasattr(self.wrapper, "cfg_value") else float("nan")
+        return 0 if v != v else int(v)
+
     def step(self, action, visualize=False):                            # RaisimGymVecEnv.py:26-52
         action = np.ascontiguousarray(action, dtype=np.float32)
         if not visualize:

@@ -67,7 +67,7 @@ int irrl_env_step(irrl_env *h, const float *action, float *ob, float *reward, ui
 int irrl_env_step_host(irrl_env *h, const float *action, float *ob, float *reward, uint8_t *done, float *extra);
 /* build-defined: `count` consecutive steps from a device-resident action table [n_rows, N, 12] (step k takes row
  * (first_row + k) % n_rows), launched back to back on the env's stream by one call -- open-loop playback / benchmarking without a
- * host round trip per step.  Outputs as irrl_env_step (those of the last step survive). */
+ * host round trip per step.  Outputs as irrl_env_step: [N, .] arrays that every step overwrites (those of the last step survive). */
 int irrl_env_step_rows(irrl_env *h, int count, const float *action_rows, int n_rows, int first_row, float *ob, float *reward,
                        uint8_t *done, float *extra);
 /* the same `count` steps as ONE launch: a wave walks its own robots through all of them (robots never interact, VEC:273), so there is no
@@ -75,6 +75,14 @@ int irrl_env_step_rows(irrl_env *h, int count, const float *action_rows, int n_r
  * to for pools with the meteorite or the build's first contact rule). */
 int irrl_env_step_rows_persistent(irrl_env *h, int count, const float *action_rows, int n_rows, int first_row, float *ob, float *reward,
                                   uint8_t *done, float *extra);
+/* the two calls above WITH EVERY STEP'S OUTPUTS KEPT: ob_rows [count, N, 35], reward_rows [count, N], done_rows [count, N] u8,
+ * extra_rows [count, N, 6] (device); step k fills row k -- exactly what `count` calls of the reference's step() hand back one after the
+ * other (VEC:268-278 fills ob / reward / done / extraInfo on every control step; RaisimGymVecEnv.py:26-52 copies them out), so the caller
+ * of the K-step entry point gets the trajectory it simulated.  Rows bit-identical to `count` irrl_env_step calls. */
+int irrl_env_step_rows_out(irrl_env *h, int count, const float *action_rows, int n_rows, int first_row, float *ob_rows, float *reward_rows,
+                           uint8_t *done_rows, float *extra_rows);
+int irrl_env_step_rows_persistent_out(irrl_env *h, int count, const float *action_rows, int n_rows, int first_row, float *ob_rows,
+                                      float *reward_rows, uint8_t *done_rows, float *extra_rows);
 /* PYB:24 testStep -> VEC:280-290: env 0 only in the reference (visual eval); here it steps env 0 only and
  * leaves rows 1.. of the outputs untouched (headless: no rendering). */
 int irrl_env_test_step_host(irrl_env *h, const float *action, float *ob, float *reward, uint8_t *done, float *extra);

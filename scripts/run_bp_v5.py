@@ -132,7 +132,8 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    launched = world > 1 or "WORLD_SIZE" in os.environ      # under a launcher, also with one rank: the collectives run over RCCL
+    if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
@@ -175,7 +176,7 @@ def main(argv=None):
                 record_video=bool(cfg.get("record_video", False)))
     if rank == 0 and log_path:
         print("final checkpoint:", model.save(log_path + "_final"))
-    if world > 1:
+    if launched:
         torch.distributed.destroy_process_group()
 
 

@@ -80,6 +80,45 @@ def test_persistent_multi_step_launch_equals_back_to_back_launches(n, cfg_name, 
         a.impl.step_rows(-1, table, 0, *outs[0], persistent=True)
 
 
+@pytest.mark.parametrize("n,cfg_name,over", [(4096, "bp5_imitation.yaml", {}), (330, "default_cfg.yaml", {}), (8192, "bp5_terrain.yaml", {}),
+                                             (96, "default_cfg.yaml", {"Crutial": True})])
+def test_multi_step_entry_points_return_every_steps_outputs(n, cfg_name, over):
+    """irrl_env_step_rows_out / irrl_env_step_rows_persistent_out: row k of ob [K,N,35], reward [K,N], done [K,N], extraInfo [K,N,6] is
+    what the k-th of K irrl_env_step calls returns (VEC:268-278 fills them on EVERY control step; RaisimGymVecEnv.py:26-52) -- bit for
+    bit, in both lane layouts, with in-step resets, for one launch per step and for the ONE persistent launch; and the pool ends equal."""
+    import torch
+    from hip_env import HipVecEnv
+    K, rows = 120, 32
+    envs = [HipVecEnv(load_env_cfg(cfg_name, num_envs=n, **over)) for _ in range(3)]
+    g = torch.Generator(device="cuda").manual_seed(9)
+    table = (0.6 * torch.randn(rows, n, 12, device="cuda", generator=g)).clamp(-1, 1)
+    for env in envs:                                      # five robots start below the termination height: in-step resets at step 0 for certain
+        st = env.get_state()
+        st[:5, 2] = 0.1
+        env.set_state(st)
+    def outs(lead):
+        return (torch.full(lead + (n, 35), float("nan"), device="cuda"), torch.full(lead + (n,), float("nan"), device="cuda"),
+                torch.zeros(lead + (n,), dtype=torch.bool, device="cuda"), torch.full(lead + (n, 6), float("nan"), device="cuda"))
+    pers, back = outs((K,)), outs((K,))
+    envs[0].impl.step_rows(K, table, 5, *pers, persistent=True)
+    envs[1].impl.step_rows(K, table, 5, *back)
+    one = outs(())
+    want = outs((K,))
+    for k in range(K):
+        envs[2].impl.step(table[(5 + k) % rows], *one)
+        for w, o in zip(want, one):
+            w[k].copy_(o)
+    torch.cuda.synchronize()
+    for name, p, b, w in zip(("ob", "reward", "done", "extraInfo"), pers, back, want):
+        assert torch.equal(p, w), "persistent launch: %s rows differ from K step() calls" % name
+        assert torch.equal(b, w), "one launch per step: %s rows differ from K step() calls" % name
+    assert want[2][0, :5].all(), "the forced terminations of step 0 are missing from row 0"
+    np.testing.assert_array_equal(envs[0].get_state(), envs[2].get_state())
+    np.testing.assert_array_equal(envs[1].get_state(), envs[2].get_state())
+    with pytest.raises(TypeError):                      # a [K, N, .] request with one array of the wrong leading size
+        envs[0].impl.step_rows(K, table, 0, pers[0], pers[1][:-1].contiguous(), pers[2], pers[3], persistent=True)
+
+
 def test_counters_see_landing_and_resets():
     from hip_env import HipVecEnv
     n = 64
@@ -122,19 +161,27 @@ def test_bench_single_gpu_line_is_steady_state():
     assert out["n_gpus"] == 1 and out["steps"] == 20 and out["warmup"] == 5
     assert out["contact_fraction_in_timed_region"] > 0.1 and out["resets_in_timed_region"] > 0
     assert out["config"]["preroll"] >= 200
-    # the 20-step timed region and the 200-step check window measure the same regime: the timed kernel against the check's figure for the
-    # same way of launching (one launch per step, or ONE persistent launch for all the steps -- what `--launch auto` picked on this box)
+    # the launch mode is FIXED by the flag (default: the persistent launch with every step's outputs kept); nothing is selected inside the run
+    assert out["config"]["launch"] == "persistent" and "every one of the 20 steps stores" in out["config"]["outputs"]
+    # the 20-step timed region and the 200-step check window measure the same regime
     r, chk = out["roofline"], out["steady_state_check"]
-    assert r["steps_per_launch"] in (1, 20) and abs(r["avg_launch_us"] - r["steps_per_launch"] * r["avg_step_us"]) < 1e-6 * r["avg_launch_us"]
-    assert r["algorithmic_bytes_per_launch"] == 1521.0 * 4096 * r["steps_per_launch"]
-    ref_us = chk["persistent_us_per_step"] if r["steps_per_launch"] > 1 else chk["us_per_step"]
-    assert abs(r["avg_step_us"] - ref_us) < 0.15 * ref_us
-    assert set(out["config"]["launch_probe_us_per_step"]) == {"persistent", "rows", "graph", "python"}
+    assert r["bound"] == "valu_fp32" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["steps_per_launch"] == 20 and abs(r["avg_launch_us"] - 20 * r["avg_step_us"]) < 1e-6 * r["avg_launch_us"]
+    assert r["algorithmic_bytes_per_launch"] == 1521.0 * 4096 * 20 and r["algorithmic_flops_per_launch"] == 1.18e5 * 4096 * 20
+    assert abs(r["achieved"] - 1.18e5 * 4096 / (r["avg_step_us"] * 1e-6) / 1e12) < 1e-6 * r["achieved"]
+    assert out["roofline_hbm"]["bound"] == "hbm"
+    assert abs(r["avg_step_us"] - chk["persistent_us_per_step"]) < 0.15 * chk["persistent_us_per_step"]
+    # the other ways of issuing the same steps are extras, all four + round 4's last-step-only form
+    lm = out["launch_modes"]
+    assert {"persistent", "rows", "graph", "python", "persistent_last_step_outputs_only"} <= set(lm)
+    assert all(lm[k]["env_steps_per_sec"] > 5e7 for k in ("persistent", "rows", "graph", "python"))
 
 
 def test_bench_every_launch_mode_gives_a_line():
     for mode in ("persistent", "rows", "graph", "python"):
-        out = _run_bench(["--steps", "20", "--warmup", "5", "--ppo-iters", "0", "--cpu-seconds", "0", "--check-steps", "0", "--launch", mode], {"IRRL_BENCH_NATIVE": "0"})
+        out = _run_bench(["--steps", "20", "--warmup", "5", "--ppo-iters", "0", "--cpu-seconds", "0", "--check-steps", "0", "--launch", mode, "--no-mode-extras"],
+                         {"IRRL_BENCH_NATIVE": "0"})
+        assert out["config"]["launch"] == mode and out["launch_modes"] is None
         assert out["roofline"]["steps_per_launch"] == (20 if mode == "persistent" else 1) and out["value"] > 5e7, (mode, out["value"])
 
 

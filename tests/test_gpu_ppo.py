@@ -89,6 +89,53 @@ def test_fused_lstm_sequence_matches_eager_definition(T, N, n_in, hid, prec, mon
         assert float((a - b).abs().max()) / scale < tol, (name, prec, float((a - b).abs().max()), scale)
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16x6", "f32"])
+def test_lstm_sequence_kernels_hold_their_error_bounds_at_the_training_shape(prec, monkeypatch):
+    """BPTT error grows with T, so the bound is asserted where the learner runs: T = 750 steps x N = 4096 envs, one SBLstm layer
+    (48 -> 48), forward + full-length BPTT, against FLOAT64 autograd of the eager stable-baselines definition (run_bp_v5.py:143-176),
+    per tensor relative to its largest entry.  Bounds = what profiles/r04_lstm_precision_error_and_time.log measured, with headroom:
+      bf16x3 (the learner's default: two bf16 planes, ~2^-16 per product)   h, state, dx <= 2e-5;  dwx, dwh, db <= 1e-5
+      bf16x6 / f32 (the f32 level)                                          h, state, dx <= 2e-6;  dwx, dwh, db <= 1e-5
+    For scale: PyTorch's eager f32 graph itself reaches 1.6e-5 on dwx at this shape (its reduction order)."""
+    import copy
+    from high_speed_quadrupedal_locomotion_by_irrl_amd import lstm_fused
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import SBLstm
+    monkeypatch.setattr(lstm_fused, "PRECISION", prec)
+    T, N, n_in, hid = 750, 4096, 48, 48
+    dev = torch.device("cuda")
+    torch.manual_seed(T + N)
+    layer = SBLstm(n_in, hid).to(dev)
+    with torch.no_grad():
+        layer.b.copy_(torch.randn(4 * hid, device=dev) * 0.1)
+    x = torch.randn(T, N, n_in, device=dev)
+    state = torch.randn(N, 2 * hid, device=dev) * 0.5
+    masks = (torch.rand(T, N, device=dev) < 0.01).float()
+    wgt = torch.randn(T, N, hid, device=dev) / (T * N) ** 0.5
+
+    def run(lay, xx, st, mk, wg):
+        xx = xx.clone().requires_grad_(True)
+        for p in lay.parameters():
+            p.grad = None
+        h, s = lay.sequence(xx, st, mk)
+        (h * wg).sum().backward()
+        return [h.detach(), s.detach(), xx.grad] + [p.grad for p in lay.parameters()]
+
+    try:
+        SBLstm.use_fused = False
+        ref = run(copy.deepcopy(layer).double(), x.double(), state.double(), masks.double(), wgt.double())
+        SBLstm.use_fused = True
+        out = run(layer, x, state, masks, wgt)
+    finally:
+        SBLstm.use_fused = True
+    act_tol = 2e-5 if prec == "bf16x3" else 2e-6
+    errs = {}
+    for name, a, b in zip(["h_seq", "state", "dx", "dwx", "dwh", "db"], out, ref):
+        errs[name] = float((a.double() - b).abs().max()) / (float(b.abs().max()) + 1e-30)
+    print("\n[lstm kernels %s, T 750 x N 4096] max |kernel - float64| / max |float64|: %s" % (prec, {k: "%.2e" % v for k, v in errs.items()}))
+    for name, e in errs.items():
+        assert e <= (act_tol if name in ("h_seq", "state", "dx") else 1e-5), (prec, name, e)
+
+
 def test_fused_lstm_policy_full_size_agrees_with_eager():
     """CustomLSTMPolicy.evaluate at the training shape (T=750 is covered by the PPO bench; here T=96 x 4096 envs)."""
     from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import CustomLSTMPolicy, SBLstm
@@ -126,6 +173,60 @@ def test_two_rank_ppo_iteration_on_the_hip_engine_equals_the_single_process_one(
     from test_ppo_distributed import check_two_ranks_equal_single_process
     two, one = check_two_ranks_equal_single_process(tmp_path, "cuda", 64, 24, policy, cfg)
     assert int(one["fused_rollout"]) == 1 and int(two[0]["fused_rollout"]) == 1
+
+
+def test_two_rank_mlp_iteration_with_four_minibatches_on_the_hip_engine_equals_the_single_process_one(tmp_path):
+    """The shipped MlpPolicy configuration (BASELINE config 2's learner: 4 minibatches, ppo2.py:364-380) on two ranks: ONE global
+    permutation of all ranks' samples per epoch (the Feistel kernel over world * n ids), every rank keeps the ids of its shard and
+    weights its mean gradient by its share before the all-reduce -- through the in-place gradient kernels (`irrl_mlp_ppo_grads_bf16` reading
+    the minibatch's rows through the index).  Rollouts bit-identical, parameters equal up to summation order."""
+    import sys, os
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_ppo_distributed import check_two_ranks_equal_single_process
+    two, one = check_two_ranks_equal_single_process(tmp_path, "cuda", 64, 24, "mlp", "bp5_imitation.yaml", nminibatches=4)
+    assert int(one["fused_rollout"]) == 1 and int(two[0]["collective"]) == 1 and int(one["collective"]) == 0
+
+
+@pytest.mark.parametrize("policy", ["lstm", "mlp"])
+def test_rccl_one_rank_communicator_runs_the_ppo_collectives_on_device_tensors(tmp_path, policy):
+    """RCCL itself (backend "nccl"), as far as a 1-GPU box allows: a FRESH child process creates a one-rank communicator
+    (init_process_group("nccl", world_size=1, device_id=cuda:0)) before anything else touches the GPU, and runs one PPO iteration whose
+    update goes through the `collective` branches -- the env-id all_gather, the 3-float advantage-moment all-reduce and the
+    flat-gradient all-reduce, all on DEVICE tensors through librccl.  With one rank every reduction is an identity: the result must
+    equal the same iteration without a process group up to nothing at all (same kernels, same order)."""
+    import sys, os
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_ppo_distributed import _run_workers
+    (tmp_path / "nccl").mkdir(); (tmp_path / "plain").mkdir()
+    with_rccl = _run_workers(tmp_path / "nccl", "cuda", 1, 64, 24, policy, backend="nccl")[0]
+    plain = _run_workers(tmp_path / "plain", "cuda", 1, 64, 24, policy)[0]
+    assert str(with_rccl["backend"]) == "nccl" and int(with_rccl["collective"]) == 1 and int(plain["collective"]) == 0
+    for key in ("obs", "actions", "values", "neglogpacs", "returns", "masks", "params", "losses"):
+        assert np.array_equal(with_rccl[key], plain[key]), key
+
+
+def test_bench_under_a_one_rank_launcher_uses_rccl():
+    """bench.py the way the driver starts it for N > 1 (RANK / WORLD_SIZE / MASTER_* in the environment), with ONE rank: the process group
+    is created with the default backend (nccl = RCCL, device_id = its GPU), the barrier around the timed bracket, the max-over-ranks
+    and the PPO legs' collectives run on device tensors.  What a 1-GPU box can show of the N-GPU launch path."""
+    import json, os, socket, subprocess, sys
+    from conftest import ROOT
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+               IRRL_BENCH_NATIVE="0", IRRL_BENCH_F32_LEVEL="0")
+    env.pop("IRRL_BENCH_BACKEND", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--envs", "512", "--cpu-seconds", "0",
+                        "--check-steps", "0", "--no-mode-extras", "--ppo-iters", "1", "--ppo-steps", "32", "--ppo-epochs", "2"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["backend"] == "nccl" and out["rccl_ranks_seen"] == 1 and out["n_gpus"] == 1
+    assert out["ppo"]["collectives_per_optimizer_step"] and out["ppo"]["ppo_iters_per_sec"] > 0
+    assert out["ppo_mlp"]["collectives_per_optimizer_step"] and out["ppo_mlp"]["ppo_iters_per_sec"] > 0
 
 
 @pytest.mark.parametrize("N,prec", [(1, "f32"), (37, "f32"), (37, "bf16x6"), (37, "bf16x3")])
@@ -652,10 +753,12 @@ def test_mlp_rollout_modes_give_the_same_rollouts_bit_for_bit(monkeypatch, cfg):
 # Round 4: the optimizer step on flat buffers (ppo2.FlatParams, csrc/ppo_optim.hpp)
 # ------------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n,max_norm,world", [(70741, 0.5, 1), (13 * 64 + 3, 0.5, 2), (4096, 0.0, 1), (70741, 1e9, 8)])
-def test_clip_adam_kernel_matches_torch_clip_and_adam(n, max_norm, world):
-    """`irrl_clip_adam` (global-norm clip + Adam over flat buffers in one launch; ppo2.py:182-197) against
-    torch.nn.utils.clip_grad_norm_ + torch.optim.Adam(eps 1e-5) over 12 steps with changing gradients and learning rates, including a
-    gradient far above / below the clip threshold and the 1 / world scale of the all-reduced sum; the same launch twice gives the same bits."""
+def test_clip_adam_kernel_matches_tf_clip_and_adam(n, max_norm, world):
+    """`irrl_clip_adam` (global-norm clip + Adam over flat buffers in one launch; ppo2.py:182-197) against tf.clip_by_global_norm +
+    tf.train.AdamOptimizer(eps 1e-5) -- `ppo2.clip_by_global_norm_` + `ppo2.TFAdam`, themselves pinned to a float64 transcription of the
+    TensorFlow formulas in tests/test_ppo_math.py -- over 12 steps with changing gradients and learning rates, including a gradient far
+    above / below the clip threshold and the 1 / world scale of the all-reduced sum; the same launch twice gives the same bits.  The first
+    step also shows that this is TensorFlow's epsilon placement, not torch.optim.Adam's."""
     import ctypes as C
     from high_speed_quadrupedal_locomotion_by_irrl_amd import _lib
     lib = _lib.load()
@@ -664,8 +767,9 @@ def test_clip_adam_kernel_matches_torch_clip_and_adam(n, max_norm, world):
     theta0 = torch.randn(n, device=dev, generator=g)
     pad = (-n) % 4
     bufs = [torch.zeros(n + pad + 4, device=dev) for _ in range(8)]       # two sets of (theta, grad, m, v), 16-byte aligned
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.ppo2 import TFAdam, clip_by_global_norm_
     ref = torch.nn.Parameter(theta0.clone())
-    opt = torch.optim.Adam([ref], lr=1e-3, eps=1e-5, betas=(0.9, 0.999))
+    opt = TFAdam([ref], lr=1e-3, eps=1e-5, betas=(0.9, 0.999))
     p = lambda t: C.c_void_p(t.data_ptr())
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     for k in (0, 4):
@@ -678,7 +782,7 @@ def test_clip_adam_kernel_matches_torch_clip_and_adam(n, max_norm, world):
         ref.grad = (grad_sum / world).clone()
         total = float(ref.grad.norm())
         if max_norm > 0:
-            torch.nn.utils.clip_grad_norm_([ref], max_norm)
+            clip_by_global_norm_([ref], max_norm)
         for gr in opt.param_groups:
             gr["lr"] = lr
         opt.step()
@@ -697,7 +801,7 @@ def test_clip_adam_kernel_matches_torch_clip_and_adam(n, max_norm, world):
 @pytest.mark.parametrize("kind", ["lstm", "mlp"])
 def test_flat_optimizer_step_follows_torch_adam_on_the_same_views(kind):
     """One PPO2 update with the optimizer step on flat buffers (one gather launch, `irrl_clip_adam`) against the same update with
-    clip_grad_norm_ + torch.optim.Adam on the same parameter views: same parameters to rounding; every parameter IS a view of the flat
+    `clip_by_global_norm_` + `TFAdam` on the same parameter views: same parameters to rounding; every parameter IS a view of the flat
     buffer; the MlpPolicy gradient kernels' scatter into the flat gradient equals `mlp_ppo_grads` bit for bit."""
     from high_speed_quadrupedal_locomotion_by_irrl_amd import ppo2 as P2
     from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import CustomLSTMPolicy, MlpPolicy

@@ -38,15 +38,15 @@ def _slice(batch, lo, hi):
     return out
 
 
-def _new_model(policy_kind):
+def _new_model(policy_kind, nminibatches=1):
     from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import CustomLSTMPolicy, MlpPolicy
     from high_speed_quadrupedal_locomotion_by_irrl_amd.ppo2 import PPO2
     pol = (CustomLSTMPolicy if policy_kind == "lstm" else MlpPolicy)
-    return PPO2(policy=pol, env=None, n_steps=6, nminibatches=1, noptepochs=2, learning_rate=1e-3, cliprange=0.2, ent_coef=0.0,
+    return PPO2(policy=pol, env=None, n_steps=6, nminibatches=nminibatches, noptepochs=2, learning_rate=1e-3, cliprange=0.2, ent_coef=0.0,
                 vf_coef=0.5, max_grad_norm=0.5, seed=3, device="cpu")
 
 
-def _worker(rank, world, port, policy_kind, out_dir):
+def _worker(rank, world, port, policy_kind, out_dir, nminibatches=1):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -54,10 +54,10 @@ def _worker(rank, world, port, policy_kind, out_dir):
     torch.set_num_threads(1)
     T, N = 6, 8
     full = _make_batch(policy_kind, T, N, seed=11)
-    model = _new_model(policy_kind)
+    model = _new_model(policy_kind, nminibatches)
     model.n_envs = N // world
     shard = _slice(full, rank * N // world, (rank + 1) * N // world)
-    # non-recurrent minibatching shuffles per rank; with nminibatches = 1 the minibatch is the whole shard anyway
+    # nminibatches > 1: ONE permutation over all ranks' samples (resp. envs), every rank keeps the members it owns (`_global_minibatches`)
     losses = model.update(shard, 1e-3, 0.2)
     params = np.concatenate([p.reshape(-1) for p in model.get_parameter_list()])
     np.save(os.path.join(out_dir, "params_%d.npy" % rank), params)
@@ -79,6 +79,27 @@ def test_two_rank_update_equals_single_process(tmp_path, policy_kind):
     # same gradient up to summation order (mean over shards of shard-means == full mean for equal shards)
     np.testing.assert_allclose(p0, ps, atol=2e-6)
     assert np.abs(ps - np.concatenate([p.reshape(-1) for p in _new_model(policy_kind).get_parameter_list()])).max() > 1e-4
+
+
+@pytest.mark.parametrize("policy_kind,nminibatches", [("mlp", 4), ("lstm", 2), ("lstm", 4)])
+def test_two_rank_update_with_several_minibatches_equals_single_process(tmp_path, policy_kind, nminibatches):
+    """ppo2.py:364-380 / 387-402: the reference shuffles ALL samples (MlpPolicy: the shipped config 2 uses 4 minibatches) resp. ALL envs
+    (recurrent) once per epoch and cuts the order into minibatches.  Two ranks draw that one global order, each keeps the members it
+    owns (unequal shares, weighted m_r * world / m before the all-reduce; advantage moments all-reduced per minibatch): same parameters
+    as the single process on the concatenated batch up to summation order, replicas bit-identical, the logged loss means equal too.
+    (("lstm", 4): 8 envs in 4 minibatches of 2 -- some minibatches live entirely on one rank: the other joins the collectives empty.)"""
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, policy_kind, str(tmp_path), nminibatches), nprocs=2, join=True)
+    p0, p1 = np.load(tmp_path / "params_0.npy"), np.load(tmp_path / "params_1.npy")
+    np.testing.assert_array_equal(p0, p1)
+    sys.path.insert(0, ROOT)
+    single = _new_model(policy_kind, nminibatches)
+    single.n_envs = 8
+    ls = single.update(_make_batch(policy_kind, 6, 8, seed=11), 1e-3, 0.2)
+    ps = np.concatenate([p.reshape(-1) for p in single.get_parameter_list()])
+    np.testing.assert_allclose(p0, ps, atol=3e-6)
+    np.testing.assert_allclose(np.load(tmp_path / "loss_0.npy"), ls.numpy(), rtol=2e-4, atol=2e-6)
+    np.testing.assert_array_equal(np.load(tmp_path / "loss_0.npy"), np.load(tmp_path / "loss_1.npy"))
 
 
 def _learn_worker(rank, world, port, out_dir):
@@ -112,26 +133,29 @@ def test_two_rank_learn_loop_keeps_replicas_in_sync(tmp_path):
     assert len(np.load(tmp_path / "log_0.npy")) == 2 and np.isfinite(p0).all()
 
 
-def _run_workers(tmp_path, device, world, envs, steps, policy, cfg="default_cfg.yaml"):
-    """start `world` processes of tests/two_rank_ppo_worker.py (gloo on 127.0.0.1) and return their saved dicts"""
+def _run_workers(tmp_path, device, world, envs, steps, policy, cfg="default_cfg.yaml", nminibatches=1, backend="gloo"):
+    """start `world` processes of tests/two_rank_ppo_worker.py (gloo on 127.0.0.1; backend "nccl": RCCL, one rank only on a 1-GPU box) and
+    return their saved dicts"""
     import subprocess
     port = _free_port()
     procs = []
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "two_rank_ppo_worker.py"), "--device", device, "--envs", str(envs),
-                                       "--steps", str(steps), "--policy", policy, "--cfg", cfg, "--out", str(tmp_path)], env=env))
+                                       "--steps", str(steps), "--policy", policy, "--cfg", cfg, "--out", str(tmp_path), "--backend", backend,
+                                       "--nminibatches", str(nminibatches)], env=env))
     for p in procs:
         assert p.wait(timeout=900) == 0
     return [dict(np.load(os.path.join(str(tmp_path), "rank%dof%d.npz" % (r, world)))) for r in range(world)]
 
 
-def check_two_ranks_equal_single_process(tmp_path, device, envs, steps, policy, cfg="default_cfg.yaml"):
+def check_two_ranks_equal_single_process(tmp_path, device, envs, steps, policy, cfg="default_cfg.yaml", nminibatches=1):
     """N-rank job == the single-process job on the concatenated pool: the ranks' rollouts ARE the halves of the big rollout (bit for
     bit: global env ids address every random draw -- env RNG and sampling noise), and the data-parallel update gives the same
     parameters up to the summation order of the gradient.  (Exact equality of the rollouts is asserted on the GPU path.)"""
-    two = _run_workers(tmp_path, device, 2, envs, steps, policy, cfg)
-    one = _run_workers(tmp_path, device, 1, 2 * envs, steps, policy, cfg)[0]
+    two = _run_workers(tmp_path, device, 2, envs, steps, policy, cfg, nminibatches)
+    one = _run_workers(tmp_path, device, 1, 2 * envs, steps, policy, cfg, nminibatches)[0]
     for key in ("obs", "actions", "values", "neglogpacs", "returns", "masks"):
         a = np.concatenate([two[0][key], two[1][key]], axis=1)      # [T, N, ...]
         assert a.shape == one[key].shape, key
@@ -147,9 +171,9 @@ def check_two_ranks_equal_single_process(tmp_path, device, envs, steps, policy, 
     return two, one
 
 
-@pytest.mark.parametrize("policy", ["lstm", "mlp"])
-def test_two_rank_iteration_equals_single_process_on_the_concatenated_pool(tmp_path, policy):
-    check_two_ranks_equal_single_process(tmp_path, "cpu", 3, 12, policy)
+@pytest.mark.parametrize("policy,nminibatches", [("lstm", 1), ("mlp", 1), ("mlp", 4)])
+def test_two_rank_iteration_equals_single_process_on_the_concatenated_pool(tmp_path, policy, nminibatches):
+    check_two_ranks_equal_single_process(tmp_path, "cpu", 3, 12, policy, nminibatches=nminibatches)
 
 
 def test_single_process_learn_with_mlp_and_lstm():

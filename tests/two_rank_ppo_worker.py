@@ -21,13 +21,20 @@ def main():
     ap.add_argument("--policy", default="lstm")
     ap.add_argument("--cfg", default="default_cfg.yaml")
     ap.add_argument("--out", required=True)
+    ap.add_argument("--backend", default="gloo", help="gloo, or nccl (= RCCL: one rank per GPU; with WORLD_SIZE=1 a one-rank communicator)")
+    ap.add_argument("--nminibatches", type=int, default=1)
     a = ap.parse_args()
     import torch
     import yaml
     from conftest import load_env_cfg
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    launched = world > 1 or a.backend == "nccl"
+    if launched:
+        if a.backend == "nccl":
+            torch.cuda.set_device(0)
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+        else:
+            torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
     cfg = load_env_cfg(a.cfg, num_envs=a.envs, EnvIdOffset=rank * a.envs)
     from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import CustomLSTMPolicy, MlpPolicy
@@ -42,7 +49,7 @@ def main():
         env = OracleTorchEnv(cfg)
     lstm = a.policy == "lstm"
     model = PPO2(policy=CustomLSTMPolicy if lstm else MlpPolicy, env=env, gamma=0.99, n_steps=a.steps, ent_coef=0.0, learning_rate=1e-3,
-                 vf_coef=0.5, max_grad_norm=0.5, lam=0.998, nminibatches=1, noptepochs=2, cliprange=0.2, verbose=0, seed=7)
+                 vf_coef=0.5, max_grad_norm=0.5, lam=0.998, nminibatches=a.nminibatches, noptepochs=2, cliprange=0.2, verbose=0, seed=7)
     runner = Runner(env, model, a.steps, 0.99, 0.998)
     batch = runner.run()
     losses = model.update(batch, 1e-3, 0.2)
@@ -50,8 +57,10 @@ def main():
     out["params"] = np.concatenate([p.reshape(-1) for p in model.get_parameter_list()])
     out["losses"] = losses.detach().cpu().numpy() if hasattr(losses, "detach") else np.asarray(losses)
     out["fused_rollout"] = np.array(int(bool(getattr(runner, "_fused", False))))
+    out["collective"] = np.array(int(bool(model.collective)))
+    out["backend"] = np.array(torch.distributed.get_backend() if launched else "none")
     np.savez(os.path.join(a.out, "rank%dof%d.npz" % (rank, world)), **out)
-    if world > 1:
+    if launched:
         torch.distributed.destroy_process_group()
 
 

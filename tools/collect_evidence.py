@@ -25,6 +25,6 @@ if glob.glob(os.path.join(G, "pmc_env_*")):
     print(subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_summarize.py"), tag + "_pmc_summary"], capture_output=True, text=True).stdout[-600:])
 for f in sorted(glob.glob(os.path.join(P, tag + "_bench*.json"))):
     d = json.loads(open(f).read())
-    print(os.path.basename(f), round(d["value"] / 1e6, 2), "M env-steps/s", round(d["roofline"].get("avg_step_us", d["roofline"]["avg_launch_us"]), 2), "us per step (", d["roofline"].get("steps_per_launch", 1), "per launch)  fp32", round(d["roofline_fp32"]["frac"], 4),
+    print(os.path.basename(f), round(d["value"] / 1e6, 2), "M env-steps/s", round(d["roofline"].get("avg_step_us", d["roofline"]["avg_launch_us"]), 2), "us per step (", d["roofline"].get("steps_per_launch", 1), "per launch)  fp32", round((d.get("roofline_fp32") or d["roofline"])["frac"], 4),
           "traffic", d["roofline"]["traffic"], "| per-call", d.get("per_step_call") and round(d["per_step_call"]["value"] / 1e6, 1), "| ppo", d.get("ppo", {}).get("ppo_iters_per_sec"),
           "| cpu", d.get("cpu_baseline", {}).get("value"))

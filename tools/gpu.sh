@@ -23,6 +23,8 @@
 #   terrain        BASELINE config 5 on one GPU: 4096 envs on the Perlin height field with per-episode friction / mass / COM randomisation and the
 #                  command process, LSTM policy, 200 updates from scratch + evaluation of the result
 #   train200       the reference's command line (200 envs, 2e8 samples), headless evaluation of the result
+#   abprec         item 2 of the round-4 verdict: config 3 trained 300 updates from the SAME seeds with the LSTM update's arithmetic at bf16x3 (default),
+#                  bf16x6 and f32; every update's reward / explained variance kept (tools/ab_precision_table.py overlays them)
 #   variants       A/B of every csrc/_variants/libirrl_env_*.so (tools/build_variants.py) on this one box, interleaved
 #   spread         per-wave durations of the step kernel (needs the `prof` variant library)
 #   ab <cmd...>    run the rest of the line verbatim (one-off A/B)
@@ -33,7 +35,7 @@ mkdir -p "$O"
 line() { python3 -c "import sys,json
 for l in sys.stdin:
     if l.startswith('{') and 'metric' in l:
-        d=json.loads(l); print('$1', round(d['value']/1e6,2), 'M env-steps/s', round(d['roofline']['avg_step_us'],2), 'us per step', 'fp32_frac', round(d['roofline_fp32']['frac'],4))"; }
+        d=json.loads(l); print('$1', round(d['value']/1e6,2), 'M env-steps/s', round(d['roofline']['avg_step_us'],2), 'us per step', 'fp32_frac', round(d['roofline']['frac'],4))"; }
 while [ $# -gt 0 ]; do
   stage=$1; shift
   case $stage in
@@ -120,6 +122,11 @@ while [ $# -gt 0 ]; do
       timeout 300 python tools/eval_checkpoint_gpu.py $O/irrl/stage1_final.pkl 256 2>&1 | grep -E "rollout|deterministic" >> $O/irrl/eval.log
       for c in 1.0 2.0 3.0; do
         timeout 300 python scripts/run_bp_v5.py --test --model $O/irrl/stage1_final.pkl --cmd $c --steps 2000 2>&1 | grep "^test:" >> $O/irrl/eval.log
+      done ;;
+    abprec)
+      RS=high_speed_quadrupedal_locomotion_by_irrl_amd/rsc; mkdir -p $O/abprec; rm -f $O/abprec/*
+      for p in bf16x3 bf16x6 f32; do
+        IRRL_LSTM_PRECISION=$p timeout 900 python scripts/run_bp_v5.py --train --save 0 --cfg $RS/default_cfg.yaml --num_envs 4096 --l 0.001 --max_iter $((4096*750*${ABPREC_UPDATES:-300})) --eval_every_n 0 2>&1 | grep -E "nupdates" | cut -c1-400 > $O/abprec/train_$p.log
       done ;;
     variants)
       V=high_speed_quadrupedal_locomotion_by_irrl_amd/csrc/_variants; rm -f $O/variants.log

@@ -43,9 +43,14 @@ done = torch.zeros(envs, dtype=torch.bool, device=dev)
 extra = torch.zeros(envs, 6, device=dev)
 for k in range(rows):
     env.step(actions[k], ob, rew, done, extra)
-# the multi-step persistent kernel (bench.py --launch persistent): five launches of PERSIST_STEPS steps each from the same steady state
+# the multi-step persistent kernel as bench.py times it (--launch persistent: EVERY step's outputs kept in [K, N, .] tables): five launches
+# of PERSIST_STEPS steps each from the same steady state
 PERSIST_STEPS = 100
+ob_rows = torch.zeros(PERSIST_STEPS, envs, 35, device=dev)
+rew_rows = torch.zeros(PERSIST_STEPS, envs, device=dev)
+done_rows = torch.zeros(PERSIST_STEPS, envs, dtype=torch.bool, device=dev)
+extra_rows = torch.zeros(PERSIST_STEPS, envs, 6, device=dev)
 for i in range(5):
-    env.step_rows(PERSIST_STEPS, actions, (i * PERSIST_STEPS) % rows, ob, rew, done, extra, persistent=True)
+    env.step_rows(PERSIST_STEPS, actions, (i * PERSIST_STEPS) % rows, ob_rows, rew_rows, done_rows, extra_rows, persistent=True)
 torch.cuda.synchronize()
 print("ok", float(rew.mean()))
