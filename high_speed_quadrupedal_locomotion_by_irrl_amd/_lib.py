@@ -69,6 +69,10 @@ SIGNATURES = {
     "irrl_mlp_ppo_grads_bf16": (C.c_int, [C.c_int, C.c_size_t, vp, C.c_int, C.c_int, C.c_int] + [vp] * 13 + [C.c_float, C.c_float, vp, C.c_int, vp]),
     "irrl_mlp_ppo_partial_len": (C.c_int, []),
     "irrl_adv_moments": (C.c_int, [C.c_size_t, vp, vp, vp, vp, C.c_int, vp, vp, vp]),
+    "irrl_mlp_pack_records": (C.c_int, [C.c_size_t, vp, vp, vp, vp, vp, vp, vp]),
+    "irrl_mlp_record_floats": (C.c_int, []),
+    "irrl_mlp_ppo_grads_bf16_rec": (C.c_int, [C.c_int, C.c_size_t, vp, vp] + [vp] * 8 + [C.c_float, C.c_float, vp, C.c_int, vp]),
+    "irrl_adv_moments_rec": (C.c_int, [C.c_size_t, vp, vp, vp, C.c_int, vp, vp, vp]),
     "irrl_sum_rows": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     "irrl_lstm_seq_forward_bf16": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] + [vp] * 11),
     "irrl_lstm_seq_backward_bf16": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] + [vp] * 14),

@@ -838,7 +838,7 @@ int irrl_mlp_ppo_grads(int kind, size_t n, const int64_t *idx, int ob_dim, int h
   if (ob_dim != IRRL_MLP_OB || hid != IRRL_MLP_H || act_dim != 12) { g_err = "irrl_mlp_ppo_grads: built for 35 observations, [64, 64] hidden units and 12 actions"; return 1; }
   if (kind != 0 && kind != 1) { g_err = "irrl_mlp_ppo_grads: kind is 0 (policy network) or 1 (value network)"; return 1; }
   MlpUpdateArgs a;
-  a.n = n; a.idx = idx; a.obs = obs; a.actions = actions; a.returns = returns; a.old_values = old_values; a.old_neglogp = old_neglogp;
+  a.n = n; a.idx = idx; a.obs = obs; a.actions = actions; a.returns = returns; a.old_values = old_values; a.old_neglogp = old_neglogp; a.rec = nullptr;
   a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.logstd = logstd; a.adv_stats = adv_stats;
   a.cliprange = cliprange; a.vf_coef = vf_coef; a.inv_n = 1.0f / (float)n; a.partials = partials;
   if (kind == 0) hipLaunchKernelGGL(irrl_mlp_ppo_kernel<0>, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)hip_stream, a);
@@ -850,32 +850,71 @@ int irrl_mlp_ppo_partial_len(void) { return IRRL_MLP_P; }
 
 // the same gradients with every product formed as three bf16 plane products on the matrix cores (kernel: csrc/mlp_bf16.hpp); same arguments,
 // same partial-sum rows.  returns 0 on success
-int irrl_mlp_ppo_grads_bf16(int kind, size_t n, const int64_t *idx, int ob_dim, int hid, int act_dim, const float *obs, const float *actions,
-                            const float *returns, const float *old_values, const float *old_neglogp, const float *w1, const float *b1, const float *w2,
-                            const float *b2, const float *w3, const float *b3, const float *logstd, const float *adv_stats, float cliprange, float vf_coef,
-                            float *partials, int n_blocks, void *hip_stream) {
-  if (n == 0 || n_blocks <= 0) { g_err = "irrl_mlp_ppo_grads_bf16: empty batch"; return 1; }
-  if (ob_dim != IRRL_MLP_OB || hid != IRRL_MLP_H || act_dim != 12) { g_err = "irrl_mlp_ppo_grads_bf16: built for 35 observations, [64, 64] hidden units and 12 actions"; return 1; }
-  if (kind != 0 && kind != 1) { g_err = "irrl_mlp_ppo_grads_bf16: kind is 0 (policy network) or 1 (value network)"; return 1; }
+static int mlp_bf16_launch(const char *who, int kind, bool use_rec, size_t n, int n_blocks, const MlpUpdateArgs &a, void *hip_stream) {
+  if (n == 0 || n_blocks <= 0) { g_err = std::string(who) + ": empty batch"; return 1; }
+  if (kind != 0 && kind != 1) { g_err = std::string(who) + ": kind is 0 (policy network) or 1 (value network)"; return 1; }
   // the opt-in belongs to the CURRENT device (a process may drive several GPUs): remembered per device ordinal
   static int allowed_on[IRRL_MAX_DEVICES];
   static bool allowed_init = false;
   if (!allowed_init) { for (int i = 0; i < IRRL_MAX_DEVICES; i++) allowed_on[i] = -1; allowed_init = true; }
   int dev_ = 0;
-  if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= IRRL_MAX_DEVICES) { g_err = "irrl_mlp_ppo_grads_bf16: no current device"; return 1; }
+  if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= IRRL_MAX_DEVICES) { g_err = std::string(who) + ": no current device"; return 1; }
   int &allowed = allowed_on[dev_];
-  if (allowed < 0)    // the weight planes and the waves' images exceed the 64 KB a kernel gets without asking (gfx950 has 160 KB per CU)
-    allowed = (hipFuncSetAttribute((const void *)irrl_mlp_ppo_bf16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, mlp_bf16_lds_bytes()) == hipSuccess &&
-               hipFuncSetAttribute((const void *)irrl_mlp_ppo_bf16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, mlp_bf16_lds_bytes()) == hipSuccess) ? 0 : 1;
-  if (allowed != 0) { g_err = "irrl_mlp_ppo_grads_bf16: the device refused the kernel's LDS size"; return 1; }
-  MlpUpdateArgs a;
-  a.n = n; a.idx = idx; a.obs = obs; a.actions = actions; a.returns = returns; a.old_values = old_values; a.old_neglogp = old_neglogp;
-  a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.logstd = logstd; a.adv_stats = adv_stats;
-  a.cliprange = cliprange; a.vf_coef = vf_coef; a.inv_n = 1.0f / (float)n; a.partials = partials;
-  if (kind == 0) hipLaunchKernelGGL(irrl_mlp_ppo_bf16_kernel<0>, dim3((unsigned)n_blocks), dim3(256), mlp_bf16_lds_bytes(), (hipStream_t)hip_stream, a);
-  else hipLaunchKernelGGL(irrl_mlp_ppo_bf16_kernel<1>, dim3((unsigned)n_blocks), dim3(256), mlp_bf16_lds_bytes(), (hipStream_t)hip_stream, a);
+  if (allowed < 0) {   // the weight planes and the waves' images exceed the 64 KB a kernel gets without asking (gfx950 has 160 KB per CU)
+    const void *ks[4] = {(const void *)irrl_mlp_ppo_bf16_kernel<0, false>, (const void *)irrl_mlp_ppo_bf16_kernel<1, false>,
+                         (const void *)irrl_mlp_ppo_bf16_kernel<0, true>, (const void *)irrl_mlp_ppo_bf16_kernel<1, true>};
+    allowed = 0;
+    for (int i = 0; i < 4; i++)
+      if (hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, mlp_bf16_lds_bytes()) != hipSuccess) allowed = 1;
+  }
+  if (allowed != 0) { g_err = std::string(who) + ": the device refused the kernel's LDS size"; return 1; }
+  const dim3 grid((unsigned)n_blocks), block(256);
+  hipStream_t st = (hipStream_t)hip_stream;
+  if (use_rec) {
+    if (kind == 0) hipLaunchKernelGGL((irrl_mlp_ppo_bf16_kernel<0, true>), grid, block, mlp_bf16_lds_bytes(), st, a);
+    else hipLaunchKernelGGL((irrl_mlp_ppo_bf16_kernel<1, true>), grid, block, mlp_bf16_lds_bytes(), st, a);
+  } else {
+    if (kind == 0) hipLaunchKernelGGL((irrl_mlp_ppo_bf16_kernel<0, false>), grid, block, mlp_bf16_lds_bytes(), st, a);
+    else hipLaunchKernelGGL((irrl_mlp_ppo_bf16_kernel<1, false>), grid, block, mlp_bf16_lds_bytes(), st, a);
+  }
   HIP_TRY(hipGetLastError());
   return 0;
+}
+
+int irrl_mlp_ppo_grads_bf16(int kind, size_t n, const int64_t *idx, int ob_dim, int hid, int act_dim, const float *obs, const float *actions,
+                            const float *returns, const float *old_values, const float *old_neglogp, const float *w1, const float *b1, const float *w2,
+                            const float *b2, const float *w3, const float *b3, const float *logstd, const float *adv_stats, float cliprange, float vf_coef,
+                            float *partials, int n_blocks, void *hip_stream) {
+  if (ob_dim != IRRL_MLP_OB || hid != IRRL_MLP_H || act_dim != 12) { g_err = "irrl_mlp_ppo_grads_bf16: built for 35 observations, [64, 64] hidden units and 12 actions"; return 1; }
+  MlpUpdateArgs a;
+  a.n = n; a.idx = idx; a.obs = obs; a.actions = actions; a.returns = returns; a.old_values = old_values; a.old_neglogp = old_neglogp; a.rec = nullptr;
+  a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.logstd = logstd; a.adv_stats = adv_stats;
+  a.cliprange = cliprange; a.vf_coef = vf_coef; a.inv_n = 1.0f / (float)n; a.partials = partials;
+  return mlp_bf16_launch("irrl_mlp_ppo_grads_bf16", kind, false, n, n_blocks, a, hip_stream);
+}
+
+// the five per-sample arrays of the flat rollout -> packed 256-byte records (csrc/mlp_update.hpp IRRL_MLP_REC), once per update
+int irrl_mlp_pack_records(size_t n, const float *obs, const float *actions, const float *returns, const float *old_values, const float *old_neglogp,
+                          float *rec, void *hip_stream) {
+  if (n == 0) { g_err = "irrl_mlp_pack_records: empty batch"; return 1; }
+  if (!obs || !actions || !returns || !old_values || !old_neglogp || !rec) { g_err = "irrl_mlp_pack_records: NULL argument"; return 1; }
+  if ((uintptr_t)rec & 255u) { g_err = "irrl_mlp_pack_records: rec must be 256-byte aligned (a record = two 128-byte lines)"; return 1; }
+  hipLaunchKernelGGL(irrl_mlp_pack_kernel, dim3(4096), dim3(256), 0, (hipStream_t)hip_stream, n, obs, actions, returns, old_values, old_neglogp, rec);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int irrl_mlp_record_floats(void) { return IRRL_MLP_REC; }
+
+// irrl_mlp_ppo_grads_bf16 reading the minibatch's samples out of the packed records: same arithmetic on the same values, bit-identical rows
+int irrl_mlp_ppo_grads_bf16_rec(int kind, size_t n, const int64_t *idx, const float *rec, const float *w1, const float *b1, const float *w2,
+                                const float *b2, const float *w3, const float *b3, const float *logstd, const float *adv_stats, float cliprange,
+                                float vf_coef, float *partials, int n_blocks, void *hip_stream) {
+  if (!rec || ((uintptr_t)rec & 255u)) { g_err = "irrl_mlp_ppo_grads_bf16_rec: rec is NULL or not 256-byte aligned"; return 1; }
+  MlpUpdateArgs a;
+  a.n = n; a.idx = idx; a.obs = nullptr; a.actions = nullptr; a.returns = nullptr; a.old_values = nullptr; a.old_neglogp = nullptr; a.rec = rec;
+  a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.w3 = w3; a.b3 = b3; a.logstd = logstd; a.adv_stats = adv_stats;
+  a.cliprange = cliprange; a.vf_coef = vf_coef; a.inv_n = 1.0f / (float)n; a.partials = partials;
+  return mlp_bf16_launch("irrl_mlp_ppo_grads_bf16_rec", kind, true, n, n_blocks, a, hip_stream);
 }
 
 // sums[3] = (sum a, sum a^2, n) of a = returns[r] - old_values[r] over the minibatch's rows, in double; scratch: [2 * n_blocks] doubles;
@@ -883,7 +922,16 @@ int irrl_mlp_ppo_grads_bf16(int kind, size_t n, const int64_t *idx, int ob_dim, 
 int irrl_adv_moments(size_t n, const int64_t *idx, const float *returns, const float *old_values, double *scratch, int n_blocks, double *sums,
                      float *stats, void *hip_stream) {
   if (n == 0 || n_blocks <= 0) { g_err = "irrl_adv_moments: empty batch"; return 1; }
-  hipLaunchKernelGGL(irrl_adv_moments_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)hip_stream, idx, n, returns, old_values, scratch);
+  hipLaunchKernelGGL(irrl_adv_moments_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)hip_stream, idx, n, returns, old_values, scratch, (size_t)1);
+  hipLaunchKernelGGL(irrl_adv_moments_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, scratch, n_blocks, n, sums, stats);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+// the same moments with the advantages read out of the packed records (word 51 = return - old value, formed in f32 by the pack kernel)
+int irrl_adv_moments_rec(size_t n, const int64_t *idx, const float *rec, double *scratch, int n_blocks, double *sums, float *stats, void *hip_stream) {
+  if (n == 0 || n_blocks <= 0 || !rec) { g_err = "irrl_adv_moments_rec: empty batch"; return 1; }
+  hipLaunchKernelGGL(irrl_adv_moments_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)hip_stream, idx, n, rec + 51, (const float *)nullptr, scratch,
+                     (size_t)IRRL_MLP_REC);
   hipLaunchKernelGGL(irrl_adv_moments_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, scratch, n_blocks, n, sums, stats);
   HIP_TRY(hipGetLastError());
   return 0;

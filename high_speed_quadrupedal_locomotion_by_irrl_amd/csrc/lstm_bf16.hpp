@@ -22,8 +22,7 @@
 //            (h_{t-1} keep_t)^T and x_t^T (staged by wave 3).  Of the 72 weight-gradient tiles (dwh 3 x 12, dwx 3 x 12) waves 0-2 accumulate
 //            gate-column tiles 2 w, 2 w + 1 against all six M-tiles (12 tiles each), wave 3 -- which has nothing else to compute -- tiles 6 .. 11
 //            (36 tiles), for all T steps.
-//            Double-buffered tiles, one barrier per step.  Per-workgroup partial gradients as in lstm_seq_bwd_x_kernel.  hseq is not read:
-//            h_{t-1} = o_{t-1} tanh(c_{t-1}) comes out of the operands of step t - 1, which are in registers by then (round 5).
+//            Double-buffered tiles, one barrier per step.  Per-workgroup partial gradients as in lstm_seq_bwd_x_kernel.
 #pragma once
 #include "policy_step.hpp"
 
@@ -268,11 +267,10 @@ __global__ void __launch_bounds__(256)
 lstm_seq_bwd_bf16_kernel(const LstmBwdBf16Args a) {
   constexpr int HID = LBF_HID, GC = LBF_GC, KX = LBF_KX, KC = GC / 32;
 #ifdef IRRL_LBF_DEPTH      /* A/B switch of tools/build_variants.py */
-  constexpr int DEPTH = (NS == 2) ? IRRL_LBF_DEPTH : 2;
+  constexpr int DEPTH = (NS == 2) ? IRRL_LBF_DEPTH : (NEED_DX ? 1 : 2);
 #else
-  constexpr int DEPTH = (NS == 2) ? 4 : 2;    // steps of operand loads in flight (28 registers per step; NS 3 has fewer to spare)
+  constexpr int DEPTH = (NS == 2) ? 3 : (NEED_DX ? 1 : 2);    // steps of operand loads in flight (36 registers per step; NS 3 has fewer to spare)
 #endif
-  static_assert(DEPTH >= 2, "step t reads c_{t-1} and o_{t-1} out of the operands of step t - 1, which must be resident");
   using PR = BfProducts<NS>;
   extern __shared__ __attribute__((aligned(16))) unsigned short lds_b[];
   constexpr int PER_BUF = lstm_bwd_bf16_lds_elems_per_buf<NS>();
@@ -372,18 +370,7 @@ lstm_seq_bwd_bf16_kernel(const LstmBwdBf16Args a) {
   for (int mt = 0; mt < 6; mt++)
 #pragma unroll
     for (int ci = 0; ci < MAIN_CI; ci++) accW[mt][ci] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-  // What step t needs of step t - 1 -- c_{t-1} and h_{t-1} -- is NOT loaded (round 5): the operands of step t - 1 are already in registers
-  // (requested DEPTH - 1 steps ago), c_{t-1} is its `ct`, and h_{t-1} = o_{t-1} tanh(c_{t-1}) is formed from its output gate exactly as the
-  // forward kernel formed it (same fast_tanh, same product: the same bits hseq holds).  A step then reads 1.73 instead of 1.92 KB per env
-  // (hseq is no longer an input of this kernel; c is read once instead of twice) and a step's operand set is 28 instead of 36 registers.
-  struct StepOps { f32x4 g[4]; float ct[4], dh[4], mk[4]; };
-  float c0[4], h0[4];        // the state in front of step 0
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int e = e0 + 4 * rq + j;
-    c0[j] = a.state0[(size_t)e * 2 * HID + u];
-    h0[j] = a.state0[(size_t)e * 2 * HID + HID + u];
-  }
+  struct StepOps { f32x4 g[4]; float ct[4], cp[4], dh[4], mk[4], hp[4]; };
   auto fetch = [&](int t, StepOps &o) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -392,20 +379,17 @@ lstm_seq_bwd_bf16_kernel(const LstmBwdBf16Args a) {
       o.mk[j] = a.masks[row];
       o.g[j] = *(const f32x4 *)&a.gates[(row * HID + u) * 4];
       o.ct[j] = a.cseq[row * HID + u];
+      o.cp[j] = (t > 0) ? a.cseq[(row - N) * HID + u] : a.state0[(size_t)e * 2 * HID + u];
+      o.hp[j] = (t > 0) ? a.hseq[(row - N) * HID + u] : a.state0[(size_t)e * 2 * HID + HID + u];
       o.dh[j] = a.dh_in[row * HID + u];
     }
   };
-  // o: the operands of step t; prev: those of step t - 1 (fetched one step later than o; untouched until step t - 1 itself runs)
-  auto step = [&](int t, StepOps &o, const StepOps &prev) {
+  auto step = [&](int t, StepOps &o) {
     const int buf = t & 1;
     float keepC[4], ct[4], cpv[4], dhv[4], hpv[4];
     f32x4 g4[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      keepC[j] = 1.0f - o.mk[j]; g4[j] = o.g[j]; ct[j] = o.ct[j]; dhv[j] = o.dh[j];
-      cpv[j] = (t > 0) ? prev.ct[j] : c0[j];
-      hpv[j] = ((t > 0) ? prev.g[j][2] * fast_tanh(prev.ct[j]) : h0[j]) * keepC[j];
-    }
+    for (int j = 0; j < 4; j++) { keepC[j] = 1.0f - o.mk[j]; g4[j] = o.g[j]; ct[j] = o.ct[j]; cpv[j] = o.cp[j]; dhv[j] = o.dh[j]; hpv[j] = o.hp[j] * keepC[j]; }
     if (t - DEPTH >= 0) fetch(t - DEPTH, o);
     // (h_{t-1} keep_t)^T for the weight gradients: Ht[plane][unit u][env 4 rq .. 4 rq + 3]
     {
@@ -475,7 +459,7 @@ lstm_seq_bwd_bf16_kernel(const LstmBwdBf16Args a) {
   for (int t = T - 1; t >= 0; t -= DEPTH) {
 #pragma unroll
     for (int d = 0; d < DEPTH; d++)
-      if (t - d >= 0) step(t - d, ops[d], ops[(d + 1) % DEPTH]);
+      if (t - d >= 0) step(t - d, ops[d]);
   }
   lbf_store_weight_grads<MAIN_CI>(accW, a, MAIN_CI * w, col, rq);
   const size_t blk = blockIdx.x;

@@ -43,7 +43,7 @@ LSTM_DEV int mb_feat(int j, int g, int m) { return 16 * (2 * m + (j >> 2)) + 4 *
 #define MB_STAMP(i) do { } while (0)
 #endif
 
-template <int KIND>
+template <int KIND, bool REC = false>      // REC: the samples come as packed 256-byte records (a.rec, mlp_update.hpp IRRL_MLP_REC) instead of five arrays
 __global__ void __launch_bounds__(256)
 irrl_mlp_ppo_bf16_kernel(const MlpUpdateArgs a) {
   constexpr int OB = IRRL_MLP_OB, H = IRRL_MLP_H, OUT = KIND == 0 ? 12 : 1;
@@ -181,6 +181,19 @@ irrl_mlp_ppo_bf16_kernel(const MlpUpdateArgs a) {
     return a.idx ? (size_t)a.idx[j] : j;
   };
   auto load_tile = [&](size_t row, TileIn &in) {
+    if (REC) {
+      // two 128-byte lines per sample, 16-byte loads: observation words 8 g .. 8 g + 7, the tail 32 .. 34 (+ the zero at 35), the action
+      // quad, and (return, old value, old neglogp, advantage) as one vector -- the same values the five arrays hold, so the results are bit-identical
+      const float *r = a.rec + row * IRRL_MLP_REC;
+      const f32x4 x0 = *(const f32x4 *)(r + 8 * g), x1 = *(const f32x4 *)(r + 8 * g + 4), xt = *(const f32x4 *)(r + 32);
+      in.x[0] = x0[0]; in.x[1] = x0[1]; in.x[2] = x0[2]; in.x[3] = x0[3]; in.x[4] = x1[0]; in.x[5] = x1[1]; in.x[6] = x1[2]; in.x[7] = x1[3];
+      in.xt[0] = xt[0]; in.xt[1] = xt[1]; in.xt[2] = xt[2];
+      if (KIND == 0) in.act = *(const f32x4 *)(r + 36 + 4 * (g < 3 ? g : 2));
+      const f32x4 s4 = *(const f32x4 *)(r + 48);
+      in.ret = s4[0]; in.ov = s4[1];
+      if (KIND == 0) in.onlp = s4[2];
+      return;
+    }
     const float *xr = a.obs + row * OB;
 #pragma unroll
     for (int j = 0; j < 8; j++) in.x[j] = xr[8 * g + j];

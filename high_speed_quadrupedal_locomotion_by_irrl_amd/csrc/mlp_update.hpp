@@ -34,11 +34,38 @@ struct MlpUpdateArgs {
   size_t n;                       // samples of this minibatch
   const int64_t *idx;             // [n] rows of the flat rollout arrays, or NULL (rows 0..n-1)
   const float *obs, *actions, *returns, *old_values, *old_neglogp;   // [rows, 35], [rows, 12], [rows] x 3
+  const float *rec;               // or (bf16 kernels, REC instantiation): the same five arrays as ONE packed record per sample, see IRRL_MLP_REC below
   const float *w1, *b1, *w2, *b2, *w3, *b3;                          // [35,64] [64] [64,64] [64] [64,OUT] [OUT]
   const float *logstd, *adv_stats;                                    // [12]; (mean, std) of the raw advantages
   float cliprange, vf_coef, inv_n;
   float *partials;                // [gridDim.x, IRRL_MLP_P]
 };
+
+// PACKED SAMPLE RECORD (round 5): a minibatch row is a random sample of the flat rollout, so every tensor it touches costs whole 128-byte
+// lines -- 140 B of observations over 2-3 lines, 48 B of actions over 1-2, and a line EACH for the 4-byte return, old value and old neglogp:
+// 614 / 391 MB fetched per minibatch of 768 k samples by the policy / value kernel against 161 / 119 MB of payload (PMC, rounds 3-4).  The
+// record holds everything a sample needs in 256 aligned bytes = exactly two lines:
+//   [0, 35) observation | 35 zero | [36, 48) action | 48 return | 49 old value | 50 old neglogp | 51 raw advantage (return - old value) | zeros
+// built ONCE per update by irrl_mlp_pack_kernel (the rollout does not change over the update's 10 epochs x 4 minibatches) and read by the
+// REC instantiations of the bf16 gradient kernels with 16-byte loads (5 per lane and tile instead of 15 dword loads).
+#define IRRL_MLP_REC 64
+__global__ void __launch_bounds__(256)
+irrl_mlp_pack_kernel(size_t n, const float *__restrict__ obs, const float *__restrict__ actions, const float *__restrict__ returns,
+                     const float *__restrict__ old_values, const float *__restrict__ old_neglogp, float *__restrict__ rec) {
+  // one lane per record word: 64 consecutive lanes write one record (256 contiguous bytes)
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n * IRRL_MLP_REC; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / IRRL_MLP_REC;
+    const int k = (int)(i % IRRL_MLP_REC);
+    float v = 0.0f;
+    if (k < IRRL_MLP_OB) v = obs[r * IRRL_MLP_OB + k];
+    else if (k >= 36 && k < 48) v = actions[r * 12 + (k - 36)];
+    else if (k == 48) v = returns[r];
+    else if (k == 49) v = old_values[r];
+    else if (k == 50) v = old_neglogp[r];
+    else if (k == 51) v = returns[r] - old_values[r];
+    rec[i] = v;
+  }
+}
 
 #ifndef IRRL_MLP_EXP
 #define IRRL_MLP_EXP 0   // diagnostics (wrong results): 1 = forward + loss only, 2 = no weight-gradient MFMAs; 3 = dx block before the dW block (A/B: slower, 10.7 vs 8.5 us per tile)
@@ -419,11 +446,12 @@ irrl_mlp_ppo_kernel(const MlpUpdateArgs a) {
 // (ppo2.py:262-263 normalises the advantages per minibatch; the eager form -- two gathers, two casts, a square, two reductions --
 // is ~8 launches per optimizer step.)  Two launches, fixed order: per-workgroup partials, then one workgroup adds them.
 __global__ void __launch_bounds__(256)
-irrl_adv_moments_kernel(const int64_t *__restrict__ idx, size_t n, const float *__restrict__ ret, const float *__restrict__ val, double *__restrict__ part) {
+irrl_adv_moments_kernel(const int64_t *__restrict__ idx, size_t n, const float *__restrict__ ret, const float *__restrict__ val, double *__restrict__ part,
+                        size_t stride) {
   __shared__ double red[2][4];
   double s = 0.0, ss = 0.0;
   for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (size_t)gridDim.x * 256) {
-    const size_t r = idx ? (size_t)idx[j] : j;
+    const size_t r = (idx ? (size_t)idx[j] : j) * stride;      // stride 1: plain arrays; IRRL_MLP_REC: word 51 of the packed records (val == NULL)
     const double a = (double)(val ? ret[r] - val[r] : ret[r]);   // the advantage is formed in f32, as the rollout stores it (val == NULL: ret IS the advantage)
     s += a; ss += a * a;
   }

@@ -174,6 +174,8 @@ class _FusedHeadsLoss(torch.autograd.Function):
 # arithmetic of the MlpPolicy gradient kernels: "bf16x3" = every product as three bf16 plane products on the matrix cores (two planes per
 # operand, f32 accumulation, ~2^-16 relative per product; csrc/mlp_bf16.hpp), "f32" = v_mfma_f32_16x16x4_f32 (csrc/mlp_update.hpp)
 MLP_PRECISION = os.environ.get("IRRL_MLP_PRECISION", "bf16x3")
+# the update's samples as packed 256-byte records (csrc/mlp_update.hpp IRRL_MLP_REC; bf16x3 kernels): IRRL_MLP_RECORDS=0 reads the five arrays instead
+MLP_RECORDS = os.environ.get("IRRL_MLP_RECORDS", "0") != "0"
 
 
 def _mlp_grads_entry(lib):
@@ -376,10 +378,26 @@ def _mlp_scatter_map(policy, flat, ent_coef):
     return hit
 
 
-def mlp_ppo_grads_flat(policy, flat, obs, actions, returns, old_values, old_neglogp, adv_stats, cliprange, ent_coef, vf_coef, index, n_blocks=256):
+def mlp_pack_records(obs, actions, returns, old_values, old_neglogp):
+    """The five per-sample arrays of the flat rollout as ONE 256-byte record per sample (csrc/mlp_update.hpp IRRL_MLP_REC; built once per
+    update): a shuffled minibatch row then costs two 128-byte lines instead of seven or eight (`irrl_mlp_ppo_grads_bf16_rec`)."""
+    from . import _lib
+    lib = _lib.load()
+    n = int(returns.numel())
+    rec = torch.empty(n, lib.irrl_mlp_record_floats(), device=obs.device, dtype=torch.float32)
+    assert rec.data_ptr() % 256 == 0
+    p = lambda t: C.c_void_p(t.data_ptr())
+    c = lambda t: t if t.is_contiguous() else t.contiguous()
+    _lib.check(lib.irrl_mlp_pack_records(n, p(c(obs)), p(c(actions)), p(c(returns)), p(c(old_values)), p(c(old_neglogp)), p(rec),
+                                         C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)))
+    return rec
+
+
+def mlp_ppo_grads_flat(policy, flat, obs, actions, returns, old_values, old_neglogp, adv_stats, cliprange, ent_coef, vf_coef, index, n_blocks=256, rec=None):
     """`mlp_ppo_grads` with the gradients summed over the workgroups STRAIGHT INTO the flat gradient buffer (one
     `irrl_sum_rows_scatter` launch for both networks instead of two row sums + one copy per parameter).  -> the step's raw
-    statistics row [8 sums | logstd 12] (one small launch; `mlp_stats_rows` turns the rows of an update into the logged means)."""
+    statistics row [8 sums | logstd 12] (one small launch; `mlp_stats_rows` turns the rows of an update into the logged means).
+    rec: the samples as packed records (`mlp_pack_records`; bf16x3 kernels only) -- same values, bit-identical gradients."""
     from . import _lib
     lib = _lib.load()
     dev = obs.device
@@ -396,6 +414,10 @@ def mlp_ppo_grads_flat(policy, flat, obs, actions, returns, old_values, old_negl
         assert index.dtype == torch.int64 and index.is_contiguous()
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     for kind, fc, head in ((0, policy.pi_fc, policy.pi), (1, policy.vf_fc, policy.vf)):
+        if rec is not None and MLP_PRECISION == "bf16x3":
+            _lib.check(lib.irrl_mlp_ppo_grads_bf16_rec(kind, n, ip, p(rec), p(fc[0].w), p(fc[0].b), p(fc[1].w), p(fc[1].b), p(head.w), p(head.b),
+                                                       p(policy.logstd), p(adv_stats), float(cliprange), float(vf_coef), p(partials[kind]), n_blocks, stream))
+            continue
         _lib.check(_mlp_grads_entry(lib)(kind, n, ip, obs.shape[-1], fc[0].w.shape[1], actions.shape[-1], p(obs), p(actions), p(returns),
                                           p(old_values), p(old_neglogp), p(fc[0].w), p(fc[0].b), p(fc[1].w), p(fc[1].b),
                                           p(head.w), p(head.b), p(policy.logstd), p(adv_stats), float(cliprange), float(vf_coef),
@@ -724,11 +746,16 @@ class PPO2(object):
         scratch = torch.empty(2 * 256 + 3, device=dev, dtype=torch.float64)
         stats = torch.empty(2, device=dev, dtype=torch.float32)
         p = lambda t: C.c_void_p(t.data_ptr())
+        rec = getattr(self, "_records", None)       # the packed sample records of this update (`update`): the advantage is word 51 of a record
         adv = getattr(self, "_flat_adv", None)      # returns - values of the whole rollout, formed once per update (`update`): one gather, not two
-        if adv is not None and adv.numel() == returns.numel():
-            returns, values = adv, None
-        _lib.check(lib.irrl_adv_moments(int(index.numel()), p(index), p(returns), p(values) if values is not None else None, p(scratch), 256, p(scratch[512:]),
-                                        p(stats) if not self.collective else None, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        if rec is not None and rec.shape[0] == returns.numel():
+            _lib.check(lib.irrl_adv_moments_rec(int(index.numel()), p(index), p(rec), p(scratch), 256, p(scratch[512:]),
+                                                p(stats) if not self.collective else None, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+        else:
+            if adv is not None and adv.numel() == returns.numel():
+                returns, values = adv, None
+            _lib.check(lib.irrl_adv_moments(int(index.numel()), p(index), p(returns), p(values) if values is not None else None, p(scratch), 256, p(scratch[512:]),
+                                            p(stats) if not self.collective else None, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
         if not self.collective:
             return stats
         mean, var = self._adv_moments(None, None, moments=scratch[512:])
@@ -765,7 +792,7 @@ class PPO2(object):
             else:
                 adv_stats = self._adv_stats_indexed(returns, values, index)
             row = mlp_ppo_grads_flat(self.policy, self.flat, obs, actions, returns, values, neglogpacs, adv_stats, cliprange_now, self.ent_coef,
-                                     self.vf_coef, index)
+                                     self.vf_coef, index, rec=getattr(self, "_records", None))
             self._apply_gradients(lr_now, gathered=True, weight=grad_weight)
             return row      # raw sums: `update` turns the rows of all steps into the logged means at once (mlp_stats_rows)
         mean, var = adv_moments if adv_moments is not None else self._adv_moments(returns, values)
@@ -913,7 +940,10 @@ class PPO2(object):
             # views, no 0.6 GB of copies per update
             flat = {k: batch[k].reshape(n_batch, *batch[k].shape[2:]) for k in ("obs", "returns", "masks", "actions", "values", "neglogpacs")}
             in_place = self.fused_mlp and mlp_ppo_grads_supported(self.policy, flat["obs"])
-            self._flat_adv = (flat["returns"] - flat["values"]).contiguous() if in_place else None
+            # the samples as packed 256-byte records, built once for the update's noptepochs x nminibatches passes (`MLP_RECORDS`; bf16x3 kernels)
+            self._records = (mlp_pack_records(flat["obs"], flat["actions"], flat["returns"], flat["values"], flat["neglogpacs"])
+                             if in_place and MLP_RECORDS and MLP_PRECISION == "bf16x3" else None)
+            self._flat_adv = (flat["returns"] - flat["values"]).contiguous() if in_place and self._records is None else None
             split = self.world > 1 and self.nminibatches > 1      # ONE permutation over ALL ranks' samples (ppo2.py:364-380), every rank keeps its own
             weights = []
             for _ in range(self.noptepochs):
@@ -937,6 +967,7 @@ class PPO2(object):
             if split:
                 # logged means over the GLOBAL minibatches: every rank's rows are sums (kernels) / means (graph) over ITS share
                 self._flat_adv = None
+                self._records = None
                 if in_place:
                     tot = mlp_stats_rows(losses, float(bs * self.world), self.policy.act_dim)
                     tot[:, 2] *= torch.tensor(weights, device=tot.device, dtype=tot.dtype)      # (the entropy column is not a sum over samples)
@@ -947,6 +978,7 @@ class PPO2(object):
                 torch.distributed.all_reduce(tot)
                 return tot
             self._flat_adv = None
+            self._records = None
             if in_place:
                 return mlp_stats_rows(losses, float(bs), self.policy.act_dim).mean(0)
         return torch.stack(losses).mean(0)

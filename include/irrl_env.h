@@ -199,6 +199,19 @@ int irrl_mlp_ppo_grads_bf16(int kind, size_t n, const int64_t *idx, int ob_dim, 
                             const float *b2, const float *w3, const float *b3, const float *logstd, const float *adv_stats, float cliprange, float vf_coef,
                             float *partials, int n_blocks, void *hip_stream);
 
+/* PACKED SAMPLE RECORDS (round 5).  A minibatch row is a random sample of the flat rollout (ppo2.py:364-380), so each of the five arrays above
+ * costs whole 128-byte lines per sample (3.8x / 3.3x the payload, PMC).  irrl_mlp_pack_records builds, once per update, one 256-byte record per
+ * sample -- rec [n, irrl_mlp_record_floats() = 64]: words [0, 35) observation | [36, 48) action | 48 return | 49 old value | 50 old neglogp |
+ * 51 return - old value | the rest zero; rec 256-byte aligned -- and irrl_mlp_ppo_grads_bf16_rec / irrl_adv_moments_rec read the minibatch's rows
+ * out of it: two lines per sample, same values, bit-identical results. */
+int irrl_mlp_pack_records(size_t n, const float *obs, const float *actions, const float *returns, const float *old_values, const float *old_neglogp,
+                          float *rec, void *hip_stream);
+int irrl_mlp_record_floats(void);
+int irrl_mlp_ppo_grads_bf16_rec(int kind, size_t n, const int64_t *idx, const float *rec, const float *w1, const float *b1, const float *w2,
+                                const float *b2, const float *w3, const float *b3, const float *logstd, const float *adv_stats, float cliprange,
+                                float vf_coef, float *partials, int n_blocks, void *hip_stream);
+int irrl_adv_moments_rec(size_t n, const int64_t *idx, const float *rec, double *scratch, int n_blocks, double *sums, float *stats, void *hip_stream);
+
 /* moments of the raw advantages a = returns[r] - old_values[r] of one minibatch (ppo2.py:262-263 normalises them per minibatch):
  * sums[3] = (sum a, sum a^2, n) as doubles, rows through idx [n] (int64, device) or 0..n-1 (NULL), fixed summation order.
  * old_values may be NULL: `returns` then holds the advantages themselves (formed once per update: one gathered array per minibatch instead of two).

@@ -798,6 +798,75 @@ def test_clip_adam_kernel_matches_tf_clip_and_adam(n, max_norm, world):
     assert float(bufs[0][n:].abs().max()) == 0.0                                       # nothing written behind the n parameters
 
 
+@pytest.mark.parametrize("n,indexed", [(16 * 7 + 5, False), (4096 * 6 + 3, True), (200000, True)])
+def test_packed_sample_records_give_the_same_gradients_bit_for_bit(n, indexed, monkeypatch):
+    """Round 5: the update's samples as ONE 256-byte record each (`irrl_mlp_pack_records`: observation | action | return | old value |
+    old neglogp | advantage; two 128-byte lines instead of the seven or eight a shuffled row of the five arrays costs).  The record holds
+    the same values, the REC instantiation of the bf16 gradient kernels does the same arithmetic on them: every gradient, the statistics
+    row and the advantage moments equal the five-array path BIT FOR BIT (ragged last tile, shuffled index into a larger rollout)."""
+    import ctypes as C
+    from high_speed_quadrupedal_locomotion_by_irrl_amd import _lib, ppo2 as P2
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import MlpPolicy, diag_gaussian_neglogp
+    monkeypatch.setattr(P2, "MLP_PRECISION", "bf16x3")
+    dev = torch.device("cuda")
+    torch.manual_seed(4)
+    pol = MlpPolicy().to(dev)
+    flat = P2.FlatParams(pol)
+    g = torch.Generator(device=dev); g.manual_seed(12)
+    rn = lambda *s: torch.randn(*s, device=dev, generator=g)
+    rows = n if not indexed else 2 * n + 77
+    obs, actions, returns, old_v = rn(rows, 35), 0.5 * rn(rows, 12), rn(rows), rn(rows)
+    with torch.no_grad():
+        old_nlp = diag_gaussian_neglogp(actions, pol._run(obs)[0], pol.logstd) + 0.3 * rn(rows)
+    index = torch.randperm(rows, device=dev, generator=g)[:n].contiguous() if indexed else None
+    rec = P2.mlp_pack_records(obs, actions, returns, old_v, old_nlp)
+    assert rec.shape == (rows, 64) and rec.data_ptr() % 256 == 0
+    r = rec.cpu().numpy()
+    np.testing.assert_array_equal(r[:, :35], obs.cpu().numpy()); np.testing.assert_array_equal(r[:, 36:48], actions.cpu().numpy())
+    np.testing.assert_array_equal(r[:, 48], returns.cpu().numpy()); np.testing.assert_array_equal(r[:, 49], old_v.cpu().numpy())
+    np.testing.assert_array_equal(r[:, 50], old_nlp.cpu().numpy()); np.testing.assert_array_equal(r[:, 51], (returns - old_v).cpu().numpy())
+    assert float(np.abs(r[:, 35]).max()) == 0.0 and float(np.abs(r[:, 52:]).max()) == 0.0
+    # advantage moments: records against the arrays
+    lib = _lib.load()
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    sums, stats = [], []
+    for use_rec in (False, True):
+        scratch = torch.zeros(2 * 256 + 3, device=dev, dtype=torch.float64)
+        st = torch.zeros(2, device=dev)
+        if use_rec:
+            _lib.check(lib.irrl_adv_moments_rec(n, p(index), p(rec), p(scratch), 256, p(scratch[512:]), p(st), stream))
+        else:
+            _lib.check(lib.irrl_adv_moments(n, p(index), p(returns), p(old_v), p(scratch), 256, p(scratch[512:]), p(st), stream))
+        sums.append(scratch[512:].clone()); stats.append(st.clone())
+    assert torch.equal(sums[0], sums[1]) and torch.equal(stats[0], stats[1])
+    out = []
+    for use_rec in (False, True):
+        flat.grad.zero_()
+        row = P2.mlp_ppo_grads_flat(pol, flat, obs, actions, returns, old_v, old_nlp, stats[0], 0.2, 0.01, 0.5, index, rec=rec if use_rec else None)
+        out.append((flat.grad.clone(), row.clone()))
+    assert float(out[0][0].abs().max()) > 0
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
+def test_mlp_update_through_packed_records_equals_the_update_through_the_arrays(monkeypatch):
+    """PPO2.update of the shipped MlpPolicy configuration (4 minibatches x 3 epochs here) with the packed records (the default) and without
+    (`ppo2.MLP_RECORDS = False`): the same parameters and statistics, bit for bit."""
+    from high_speed_quadrupedal_locomotion_by_irrl_amd import ppo2 as P2
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import MlpPolicy
+    after = {}
+    for use_rec in (True, False):
+        monkeypatch.setattr(P2, "MLP_RECORDS", use_rec)
+        env = _env(256)
+        model = P2.PPO2(policy=MlpPolicy, env=env, n_steps=48, nminibatches=4, noptepochs=3, learning_rate=1e-3, seed=8)
+        runner = P2.Runner(env, model, 48, 0.99, 0.95)
+        batch = runner.run()
+        stats = model.update(batch, 1e-3, 0.2)
+        after[use_rec] = (model.flat.theta.clone(), stats.clone())
+        assert model._records is None
+    assert torch.equal(after[True][0], after[False][0]) and torch.equal(after[True][1], after[False][1])
+
+
 @pytest.mark.parametrize("kind", ["lstm", "mlp"])
 def test_flat_optimizer_step_follows_torch_adam_on_the_same_views(kind):
     """One PPO2 update with the optimizer step on flat buffers (one gather launch, `irrl_clip_adam`) against the same update with

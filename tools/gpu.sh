@@ -26,6 +26,8 @@
 #   abprec         item 2 of the round-4 verdict: config 3 trained 300 updates from the SAME seeds with the LSTM update's arithmetic at bf16x3 (default),
 #                  bf16x6 and f32; every update's reward / explained variance kept (tools/ab_precision_table.py overlays them)
 #   variants       A/B of every csrc/_variants/libirrl_env_*.so (tools/build_variants.py) on this one box, interleaved
+#   ablstm         same-box A/B of the PPO-LSTM update (bf16x3 and bf16x6) over every csrc/_variants/libirrl_env_*.so
+#   abmlp          same-box A/B of the PPO-MLP update with / without the packed sample records (IRRL_MLP_RECORDS)
 #   spread         per-wave durations of the step kernel (needs the `prof` variant library)
 #   ab <cmd...>    run the rest of the line verbatim (one-off A/B)
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -70,7 +72,9 @@ while [ $# -gt 0 ]; do
     prof)
       (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python3 $R/bench.py --steps 20 --warmup 5 --cpu-seconds 0 --ppo-iters 0 --check-steps 0 > $O/rocprof_bench.log 2>&1) ;;
     profppo)
-      (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ppo -- python3 $R/tools/ppo_bench.py --policy lstm --envs 4096 --iters 2 --epochs 2 > $O/rocprof_ppo.log 2>&1) ;;
+      (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ppo -- python3 $R/tools/ppo_bench.py --policy lstm --envs 4096 --iters 2 --epochs 2 > $O/rocprof_ppo.log 2>&1)
+      # the row-sum kernel's trace durations against what ran beside it (verdict r4 item 11)
+      python3 tools/kernel_overlap.py "$(ls -t $O/prof_ppo/*/*_kernel_trace.csv | head -1)" irrl_sum_rows > $O/sum_rows_overlap.log 2>&1 ;;
     profmlp)
       rm -rf $O/prof_mlp
       (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_mlp -- python3 $R/tools/ppo_bench.py --policy mlp --envs 4096 --iters 3 > $O/rocprof_mlp.log 2>&1) ;;
@@ -93,8 +97,8 @@ while [ $# -gt 0 ]; do
       (cd /tmp && export TMPDIR=/tmp
        for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
          tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
-         timeout 900 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/pmc_mlp_$tag -- python3 $R/tools/ppo_bench.py --policy mlp --envs 4096 --iters 1 --epochs 1 > $O/pmc_mlp_$tag.log 2>&1
-       done) ;;      # then: python tools/pmc_summarize_lstm.py r03_pmc_mlp_kernels mlp
+         timeout 900 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/pmc_mlp_$tag -- python3 $R/tools/pmc_mlp_workload.py > $O/pmc_mlp_$tag.log 2>&1
+       done) ;;      # then: python tools/pmc_summarize_lstm.py r05_pmc_mlp_kernels mlp   (both ways of reading the samples: <kind, false> arrays, <kind, true> packed records)
     ppo)
       timeout 300 python tools/ppo_bench.py --policy mlp --envs 4096 --iters 3 > $O/ppo_mlp.log 2>&1
       timeout 300 python tools/ppo_bench.py --policy lstm --envs 4096 --iters 3 > $O/ppo_lstm.log 2>&1 ;;
@@ -136,6 +140,19 @@ while [ $# -gt 0 ]; do
       if [ -n "$VARIANTS_PPO" ]; then for f in $V/libirrl_env_*.so; do
         IRRL_ENV_LIB=$PWD/$f timeout 300 python tools/ppo_bench.py --policy lstm --envs 4096 --iters 3 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$(basename $f .so) ppo rollout', round(d['rollout_s']*1e3,2), 'ms update', round(d['update_s']*1e3,2), 'ms')" >> $O/variants.log
       done; fi ;;
+    ablstm)
+      # same-box A/B of the LSTM update over every csrc/_variants/libirrl_env_*.so, interleaved, two rounds: PPO-LSTM iteration with the update at
+      # bf16x3 (default) and bf16x6 (f32 level)
+      V=high_speed_quadrupedal_locomotion_by_irrl_amd/csrc/_variants; rm -f $O/ablstm.log
+      for r in 1 2; do for f in $V/libirrl_env_*.so; do for prec in bf16x3 bf16x6; do
+        IRRL_ENV_LIB=$PWD/$f timeout 300 python tools/ppo_bench.py --policy lstm --envs 4096 --iters 4 --precision $prec 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$(basename $f .so) $prec rollout', round(d['rollout_s']*1e3,2), 'ms update', round(d['update_s']*1e3,2), 'ms', round(d['ppo_iters_per_sec'],3), 'it/s')" >> $O/ablstm.log
+      done; done; done ;;
+    abmlp)
+      # same-box A/B of the MlpPolicy update with / without the packed sample records, interleaved, three rounds
+      rm -f $O/abmlp.log
+      for r in 1 2 3; do for rec in 1 0; do
+        IRRL_MLP_RECORDS=$rec timeout 300 python tools/ppo_bench.py --policy mlp --envs 4096 --iters 5 --cfg bp5_imitation.yaml 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('IRRL_MLP_RECORDS=$rec rollout', round(d['rollout_s']*1e3,2), 'ms update', round(d['update_s']*1e3,2), 'ms', round(d['ppo_iters_per_sec'],3), 'it/s')" >> $O/abmlp.log
+      done; done ;;
     spread)
       V=high_speed_quadrupedal_locomotion_by_irrl_amd/csrc/_variants; rm -f $O/wave_spread.log
       IRRL_ENV_LIB=$PWD/$V/libirrl_env_prof.so timeout 300 python tools/wave_spread.py 2>/dev/null | tail -1 >> $O/wave_spread.log

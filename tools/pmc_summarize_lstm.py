@@ -7,7 +7,7 @@ import csv, glob, json, os, statistics, sys
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 name = sys.argv[1] if len(sys.argv) > 1 else "pmc_lstm_kernels"
 which = sys.argv[2] if len(sys.argv) > 2 else "lstm"
-tokens = ("lstm_seq", "ppo_heads", "policy_step", "rollout_persistent") if which == "lstm" else ("irrl_mlp_ppo", "mlp_policy_step", "irrl_sum_rows", "rollout_persistent")
+tokens = ("lstm_seq", "ppo_heads", "policy_step", "rollout_persistent") if which == "lstm" else ("irrl_mlp_ppo", "irrl_mlp_pack", "mlp_policy_step", "irrl_sum_rows", "rollout_persistent")
 per = {}
 for d in sorted(glob.glob(os.path.join(root, "gpurun_out", "pmc_%s_*" % which))):
     if not os.path.isdir(d):
