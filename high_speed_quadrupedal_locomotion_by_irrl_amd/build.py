@@ -79,7 +79,13 @@ def hipcc():
     raise RuntimeError("hipcc not found (expected /opt/rocm/bin/hipcc)")
 
 
-COMMON_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-fno-signed-zeros"]
+# -ffp-contract=on (round 5): a multiply-add fuses where the SOURCE writes `a * b + c` in one expression (the front end emits llvm.fmuladd) and
+# nowhere else.  HIP's default, `fast`, lets the back end fuse across statements, and which pairs it picks depends on the code AROUND the
+# expression: the same device function inlined into two kernels -- the env step in the step kernel and in the multi-step kernel that carries
+# the lane context in registers; the policy step in the stand-alone and in the rollout kernels, which even live in two translation units -- then
+# differs in the last bit (measured: 15 of 1250 v_fmac), which breaks the bit-identity the entry points promise.  Same instruction counts and
+# the same times within noise for every kernel of the library (env step 41.9 us, LSTM update 101.9 ms, MLP update 18.9 ms).
+COMMON_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-fno-signed-zeros", "-ffp-contract=on"]
 # Env kernels only (measured on MI355X, 4096 envs, same box): the SLP vectorizer's packed-f32 pairs cost more v_mov than
 # they save in this scalar-per-lane code (56.6 -> 51.4 us per step without it), and the single resident wave per SIMD
 # wants ILP-first scheduling (-> 50.1 us).

@@ -2185,11 +2185,17 @@ struct NoStepHook { IRRL_DEV void operator()() const {} };
 // `before_substeps` runs once between the step prologue (all of this step's global loads are behind it) and the substep loop:
 // the fused env + policy kernel starts its LDS prefetch of the policy weights there (env_kernels.hip)
 // RULE: the per-contact rule of the pool (EnvParams::contact_rule), a compile-time constant of the instantiation the launcher picks
-template <int RULE, class Hook = NoStepHook>
-IRRL_DEV void step_body(const EnvParams &P, const EnvState &S, vi env, vi leg, vm valid, const float *action, float *ob_out,
-                        float *reward_out, uint8_t *done_out, float *extra_out, Hook before_substeps = Hook()) {
-  EnvLane L;
-  load_lane(P, S, env, leg, L, true);
+// step_compute: the step on a lane context that is ALREADY in registers -- everything between load_lane and store_lane.  `tail(L)` runs at the
+// end of the epilogue, inside its sub-lane-0 region: step_body stores the context there; the multi-step kernels, which keep the context in
+// registers from one step to the next (env_kernels.hip), pass nothing and call lane_carry() behind it.
+struct NoStepTail { IRRL_DEV void operator()(const EnvLane &) const {} };
+// where a lane's three action components come from: the action batch in memory (row-major [N, 12]), or registers the caller filled ahead of
+// time (the multi-step kernel requests step k + 1's row while step k runs)
+struct ActionRow { const float *p; IRRL_DEV vf get(vi env, vi leg, int k) const { return ld(p, env * 12 + leg * 3 + k); } };
+struct ActionRegs { vf a[3]; IRRL_DEV vf get(vi, vi, int k) const { return a[k]; } };
+template <int RULE, class Hook = NoStepHook, class Tail = NoStepTail, class Action = ActionRow>
+IRRL_DEV void step_compute(const EnvParams &P, EnvLane &L, vi env, vi leg, vm valid, const Action action, float *ob_out,
+                           float *reward_out, uint8_t *done_out, float *extra_out, Hook before_substeps = Hook(), Tail tail = Tail()) {
 #ifdef IRRL_PROFILE_WAVES
   L.prof_ranksteps = 0; L.prof_flags = 0;
 #endif
@@ -2241,7 +2247,7 @@ IRRL_DEV void step_body(const EnvParams &P, const EnvState &S, vi env, vi leg, v
     vf nominal[3] = {L.m.sy * P.abad, -0.78f, 1.57f};
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      vf p = ld(action, env * 12 + leg * 3 + k) * 1.0f + nominal[k];
+      vf p = action.get(env, leg, k) * 1.0f + nominal[k];
       p = (1.0f - P.filter_para) * p + P.filter_para * L.ptl[k];
       p = p * (P.action_noise * an[k]) + p;
       pT[k] = p; L.ptl[k] = p;
@@ -2337,8 +2343,80 @@ IRRL_DEV void step_body(const EnvParams &P, const EnvState &S, vi env, vi leg, v
   stm(extra_out, env * 6 + 3, (float)L.prof_ranksteps); stm(extra_out, env * 6 + 4, (float)L.prof_flags);
 #endif
   IRRL_MASKED_END
-  store_lane(P, S, env, leg, valid, L, P.randomize_per_episode != 0);
+  tail(L);
   IRRL_SUB0_ONLY_END
+}
+
+template <int RULE, class Hook = NoStepHook>
+IRRL_DEV void step_body(const EnvParams &P, const EnvState &S, vi env, vi leg, vm valid, const float *action, float *ob_out,
+                        float *reward_out, uint8_t *done_out, float *extra_out, Hook before_substeps = Hook()) {
+  EnvLane L;
+  load_lane(P, S, env, leg, L, true);
+  step_compute<RULE>(P, L, env, leg, valid, ActionRow{action}, ob_out, reward_out, done_out, extra_out, before_substeps,
+                     [&](const EnvLane &Lf) { store_lane(P, S, env, leg, valid, Lf, P.randomize_per_episode != 0); });
+}
+
+// THE LANE CONTEXT CARRIED FROM STEP k TO STEP k + 1 IN REGISTERS (round 5: the multi-step kernels of env_kernels.hip load it once in front of
+// their step loop and store it once behind it).  Three things make the carried context equal, bit for bit, to what store_lane + load_lane(for_step)
+// would have handed over: (1) the per-ENV words (base pose and velocity, command, clock, model of the trunk ...) are stored by the lane of leg 0
+// and read back by every lane of the robot -- the legs' own copies may differ from leg 0's in the last bit (each leg sums the partner legs'
+// contributions in its own order) -- so leg 0's words are broadcast to the robot's lanes; (2) with 16 lanes per robot the epilogue ran on
+// sub-lane 0 of every quad only, so for the per-LEG words sub-lane 0's are broadcast to the quad; one DPP move per word either way;
+// (3) the words load_lane does not fetch for a step -- the step overwrites them before it reads them -- are cleared the same way.
+IRRL_DEV void lane_carry(EnvLane &L) {
+#define IRRL_BE(x) x = legs_bcast<0>(x)
+#define IRRL_BEI(x) x = legs_bcast_i<0>(x)
+#define IRRL_BEU(x) x = legs_bcast_u<0>(x)
+#define IRRL_BE3(v) do { IRRL_BE(v.x); IRRL_BE(v.y); IRRL_BE(v.z); } while (0)
+  IRRL_BE3(L.pos); IRRL_BE(L.qw); IRRL_BE(L.qx); IRRL_BE(L.qy); IRRL_BE(L.qz); IRRL_BE3(L.vw); IRRL_BE3(L.ww);
+#pragma unroll
+  for (int k = 0; k < 3; k++) { IRRL_BE(L.cmd[k]); IRRL_BE(L.cmdf[k]); }
+#pragma unroll
+  for (int k = 0; k < 11; k++) IRRL_BE(L.obl_env[k]);
+  IRRL_BE(L.t0); IRRL_BEI(L.frame); IRRL_BEU(L.episode); IRRL_BE(L.up_height);
+  IRRL_BE(L.m.m0); IRRL_BE3(L.m.com0); IRRL_BE(L.m.mu); IRRL_BE(L.m.rest); IRRL_BE(L.m.rest_thr); IRRL_BE(L.m.dz);
+  IRRL_BE3(L.sp); IRRL_BE3(L.sv); IRRL_BE(L.srad); IRRL_BE(L.smass); IRRL_BEI(L.sdyn);
+#undef IRRL_BE
+#undef IRRL_BEI
+#undef IRRL_BEU
+#undef IRRL_BE3
+#ifdef IRRL_L16
+#define IRRL_BC(x) x = sub_bcast<0>(x)
+#define IRRL_BC3(v) do { IRRL_BC(v.x); IRRL_BC(v.y); IRRL_BC(v.z); } while (0)
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    IRRL_BC(L.q[k]); IRRL_BC(L.qd[k]); IRRL_BC(L.ptl[k]); IRRL_BC(L.tql[k]); IRRL_BC(L.jr[k]); IRRL_BC(L.jrl[k]); IRRL_BC(L.jdr[k]); IRRL_BC(L.eer[k]);
+    IRRL_BC(L.lamw[k]); IRRL_BC(L.obl_q[k]); IRRL_BC(L.obl_qd[k]);
+  }
+  L.in_contact = sub_bcast_i<0>(L.in_contact); L.ccount = sub_bcast_u<0>(L.ccount);
+  IRRL_BC(L.m.mA); IRRL_BC(L.m.mT); IRRL_BC(L.m.mS); IRRL_BC3(L.m.comA); IRRL_BC3(L.m.comT); IRRL_BC3(L.m.comS);
+#undef IRRL_BC
+#undef IRRL_BC3
+#endif
+#pragma unroll
+  for (int k = 0; k < 3; k++) { L.tq[k] = 0.0f; L.ob_cmd[k] = 0.0f; L.ob_post[k] = 0.0f; L.ob_omega[k] = 0.0f; L.ob_q[k] = 0.0f; L.ob_qd[k] = 0.0f; }
+  L.contact = 0.0f; L.ob_phase[0] = 0.0f; L.ob_phase[1] = 0.0f;
+  L.bodyLinVel = mk3(0.0f, 0.0f, 0.0f); L.bodyAngVel = mk3(0.0f, 0.0f, 0.0f);
+  // (4) every carried word is handed to the next step as an OPAQUE register, the way a load would hand it over: left visible, the optimizer
+  // sees which words a step does not change (the model, most of the time the command) -- it hoists their products out of the step loop and
+  // contracts multiply-adds differently from the one-step kernel, whose results then differ in the last bit (measured: the first carried
+  // build was 3 % faster and NOT bit-identical; the promise of the multi-step entry points is bit-identity)
+#define IRRL_OQ(x) IRRL_OPAQUE(x)
+#define IRRL_OQ3(v) do { IRRL_OQ(v.x); IRRL_OQ(v.y); IRRL_OQ(v.z); } while (0)
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    IRRL_OQ(L.q[k]); IRRL_OQ(L.qd[k]); IRRL_OQ(L.ptl[k]); IRRL_OQ(L.tql[k]); IRRL_OQ(L.jr[k]); IRRL_OQ(L.jrl[k]); IRRL_OQ(L.jdr[k]); IRRL_OQ(L.eer[k]);
+    IRRL_OQ(L.lamw[k]); IRRL_OQ(L.cmd[k]); IRRL_OQ(L.cmdf[k]); IRRL_OQ(L.obl_q[k]); IRRL_OQ(L.obl_qd[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < 11; k++) IRRL_OQ(L.obl_env[k]);
+  IRRL_OQ(L.in_contact); IRRL_OQ(L.ccount);
+  IRRL_OQ3(L.pos); IRRL_OQ(L.qw); IRRL_OQ(L.qx); IRRL_OQ(L.qy); IRRL_OQ(L.qz); IRRL_OQ3(L.vw); IRRL_OQ3(L.ww);
+  IRRL_OQ(L.t0); IRRL_OQ(L.frame); IRRL_OQ(L.episode); IRRL_OQ(L.up_height);
+  IRRL_OQ(L.m.mA); IRRL_OQ(L.m.mT); IRRL_OQ(L.m.mS); IRRL_OQ3(L.m.comA); IRRL_OQ3(L.m.comT); IRRL_OQ3(L.m.comS); IRRL_OQ(L.m.m0); IRRL_OQ3(L.m.com0);
+  IRRL_OQ(L.m.mu); IRRL_OQ(L.m.rest); IRRL_OQ(L.m.rest_thr); IRRL_OQ(L.m.dz);
+#undef IRRL_OQ
+#undef IRRL_OQ3
 }
 
 // VEC:145-194 per env: constructor randomisation (ENV:435-477) + first reset

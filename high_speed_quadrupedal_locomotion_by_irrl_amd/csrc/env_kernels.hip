@@ -211,6 +211,15 @@ irrl_rollout_persistent_mlp_kernel_l16(EnvParams P, EnvState S, float *ob, float
   const float *noise0 = a.noise;
   const long long row0 = a.row, rng0 = a.rng_step;
   const size_t noise_stride = (size_t)a.N * (size_t)a.act_dim;
+  // the env part's lane context stays in registers across the steps (round 5; irrl_steps_persistent_kernel below): this policy's step needs
+  // few registers (its weights and activations live in LDS), so the context survives it without spilling
+  const int lane0_ = (int)(threadIdx.x & 63u);
+  int env0_ = ((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * 4 + (lane0_ >> 4);
+  const int leg0_ = (lane0_ >> 2) & 3;
+  const bool valid0_ = (env0_ < P.n_envs) && ((lane0_ & 3) == 0);
+  if (env0_ >= P.n_envs) env0_ = P.n_envs - 1;
+  irrl_plain::EnvLane L;
+  irrl_plain::load_lane(P, S, env0_, leg0_, L, true);
   __syncthreads();
   for (int k = 0; k < steps; k++) {
     int tid = (int)threadIdx.x;
@@ -220,25 +229,29 @@ irrl_rollout_persistent_mlp_kernel_l16(EnvParams P, EnvState S, float *ob, float
     mlp_policy_step_body<64, true>(a, (int)blockIdx.x * 16, h1, h2, terms, head_w, wl, tid);
     __syncthreads();   // this workgroup's clipped actions (and the rollout rows) are stored and visible to its own loads
     {
-      const int lane_ = tid & 63;
-      const int wave_ = (int)blockIdx.x * 4 + (tid >> 6);
-      int env_ = wave_ * 4 + (lane_ >> 4);
-      const int leg_ = (lane_ >> 2) & 3;
-      const bool valid_ = (env_ < P.n_envs) && ((lane_ & 3) == 0);
-      if (env_ >= P.n_envs) env_ = P.n_envs - 1;
-      irrl_plain::step_body<1>(P, S, env_, leg_, valid_, (const float *)a.clipped, ob, reward, done, extra);
+      int env_ = env0_;
+      asm volatile("" : "+v"(env_));
+      if (k > 0) irrl_plain::lane_carry(L);
+      irrl_plain::step_compute<1>(P, L, env_, leg0_, valid0_, irrl_plain::ActionRow{(const float *)a.clipped}, ob, reward, done, extra);
     }
     __syncthreads();   // obs / dones / reward of step k are stored and visible: the next policy step reads them
+  }
+  if (steps > 0) {
+    IRRL_SUB0_ONLY_BEGIN
+    irrl_plain::store_lane(P, S, env0_, leg0_, valid0_, L, P.randomize_per_episode != 0);
+    IRRL_SUB0_ONLY_END
   }
 }
 #endif
 
-// `count` CONSECUTIVE env.step()s IN ONE LAUNCH (irrl_env_step_rows_persistent): step k takes action row (first_row + k) % n_rows of a table
+// `count` CONSECUTIVE env.step()s IN ONE LAUNCH (irrl_env_step_rows_persistent[_out]): step k takes action row (first_row + k) % n_rows of a table
 // resident in HBM.  Robots never interact (VEC:273), so a wave simply walks its own robots through the `count` steps: no grid-wide
-// boundary between steps -- a step costs a wave its own time (mean 33.7 us at 4096 envs) instead of the slowest of the 1024 waves
-// (40.8 us), and the launch boundaries are gone.  The body of a step is the step kernel's (same device function, same order): states
-// and outputs are bit-identical to `count` launches.  A wave's stores of step k and its loads of step k + 1 touch the same addresses
-// from the same lanes, in program order.  Default pool kind only (no meteorite, published rule); the launcher falls back otherwise.
+// boundary between steps -- a step costs a wave its own time instead of the slowest of the 1024 waves, and the launch boundaries are gone.
+// Round 5: the robots' lane context STAYS IN REGISTERS from step to step (load_lane once in front of the loop, store_lane once behind it;
+// lane_carry() between two steps hands the next step exactly the words a store + load would have: env_core.hpp) -- a step no longer starts
+// behind a round trip of ~90 stores and ~90 loads per lane through the L2.  The body of a step is the step kernel's (step_compute, same
+// order): states and outputs are bit-identical to `count` launches.  Default pool kind only (no meteorite, published rule); the launcher
+// falls back otherwise.
 __global__ void __launch_bounds__(256, 1)
 IRRL_K(irrl_steps_persistent_kernel)(EnvParams P, EnvState S, const float *action_rows, int n_rows, int first_row, int count, float *ob, float *reward,
                                      uint8_t *done, float *extra, int out_rows) {
@@ -247,29 +260,45 @@ IRRL_K(irrl_steps_persistent_kernel)(EnvParams P, EnvState S, const float *actio
   // out_rows != 0: the outputs are [count, N, .] tables and step k fills row k -- the trajectory `count` step() calls of the reference
   // would have returned (VEC:268-278, RaisimGymVecEnv.py:26-52); 0: [N, .] arrays every step overwrites (the last step's survive)
   const size_t orow = out_rows ? (size_t)P.n_envs : (size_t)0;
-  for (int k = 0; k < count; k++) {
-    // threadIdx.x made opaque once per iteration: the per-lane addresses are then computed inside the loop (hoisted, they are
-    // hundreds of 64-bit values that spill)
-    int tid = (int)threadIdx.x;
-    asm volatile("" : "+v"(tid));
-    const int lane_ = tid & 63;
+  const int lane0_ = (int)(threadIdx.x & 63u);
 #if IRRL_LANES_PER_ROBOT == 16
-    const int wave_ = blk * (int)(blockDim.x >> 6) + (tid >> 6);
-    int env_ = wave_ * 4 + (lane_ >> 4);
-    const int leg_ = (lane_ >> 2) & 3;
-    const bool valid_ = (env_ < P.n_envs) && ((lane_ & 3) == 0);
-    if (env_ >= P.n_envs) env_ = P.n_envs - 1;
+  int env0_ = (blk * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6)) * 4 + (lane0_ >> 4);
+  const int leg0_ = (lane0_ >> 2) & 3;
+  const bool valid0_ = (env0_ < P.n_envs) && ((lane0_ & 3) == 0);
+  if (env0_ >= P.n_envs) env0_ = P.n_envs - 1;
 #else
-    int env_ = (blk * (int)(blockDim.x >> 6) + (tid >> 6)) * 16 + (lane_ >> 2);
-    const int leg_ = lane_ & 3;
-    const bool valid_ = env_ < P.n_envs;
-    if (!valid_) env_ = P.n_envs - 1;
+  int env0_ = (blk * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6)) * 16 + (lane0_ >> 2);
+  const int leg0_ = lane0_ & 3;
+  const bool valid0_ = env0_ < P.n_envs;
+  if (!valid0_) env0_ = P.n_envs - 1;
 #endif
-    const float *action = action_rows + row * (size_t)((first_row + k) % n_rows);
-    irrl_plain::step_body<1>(P, S, env_, leg_, valid_, action, ob + orow * 35 * (size_t)k, reward + orow * (size_t)k, done + orow * (size_t)k,
-                             extra + orow * 6 * (size_t)k);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  irrl_plain::EnvLane L;
+  irrl_plain::load_lane(P, S, env0_, leg0_, L, true);
+  // the action row of step k + 1 is requested while step k runs (three words per lane): a step does not start behind that round trip either
+  irrl_plain::ActionRegs act_next;
+  {
+    const float *a0 = action_rows + row * (size_t)(first_row % n_rows) + (size_t)env0_ * 12 + leg0_ * 3;
+    act_next.a[0] = a0[0]; act_next.a[1] = a0[1]; act_next.a[2] = a0[2];
+  }
+  for (int k = 0; k < count; k++) {
+    // the lane's robot made opaque once per iteration: the per-lane addresses of the action row and of the output rows are then computed
+    // inside the loop (hoisted, they are dozens of 64-bit values that spill)
+    int env_ = env0_;
+    asm volatile("" : "+v"(env_));
+    if (k > 0) irrl_plain::lane_carry(L);
+    const irrl_plain::ActionRegs act = act_next;
+    {
+      const int kn = (k + 1 < count) ? k + 1 : k;      // (behind the last step: that step's own row once more)
+      const float *an = action_rows + row * (size_t)((first_row + kn) % n_rows) + (size_t)env_ * 12 + leg0_ * 3;
+      act_next.a[0] = an[0]; act_next.a[1] = an[1]; act_next.a[2] = an[2];
+    }
+    irrl_plain::step_compute<1, irrl_plain::NoStepHook, irrl_plain::NoStepTail, irrl_plain::ActionRegs>(
+        P, L, env_, leg0_, valid0_, act, ob + orow * 35 * (size_t)k, reward + orow * (size_t)k, done + orow * (size_t)k, extra + orow * 6 * (size_t)k);
+  }
+  if (count > 0) {
+    IRRL_SUB0_ONLY_BEGIN
+    irrl_plain::store_lane(P, S, env0_, leg0_, valid0_, L, P.randomize_per_episode != 0);
+    IRRL_SUB0_ONLY_END
   }
 }
 

@@ -14,6 +14,8 @@
 #include <stdint.h>
 
 #define IRRL_DEV __device__ __forceinline__
+// value made opaque to the optimizer (no instruction): what comes out is "some register", not the expression that produced it
+#define IRRL_OPAQUE(x) asm volatile("" : "+v"(x))
 
 typedef float vf;
 typedef int32_t vi;
@@ -69,6 +71,8 @@ template <int K>
 IRRL_DEV vf legs_bcast(vf x) { return dpp_quad<K * 0x55>(x); }
 template <int K>
 IRRL_DEV vi legs_bcast_i(vi x) { return dpp_quad_i<K * 0x55>(x); }
+template <int K>
+IRRL_DEV vu legs_bcast_u(vu x) { return (vu)dpp_quad_i<K * 0x55>((vi)x); }
 
 // ---- masks / selects ----
 IRRL_DEV vf vsel(vm m, vf a, vf b) { return m ? a : b; }

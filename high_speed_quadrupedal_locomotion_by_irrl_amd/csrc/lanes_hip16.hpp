@@ -13,6 +13,8 @@
 #include <stdint.h>
 
 #define IRRL_DEV __device__ __forceinline__
+// value made opaque to the optimizer (no instruction): what comes out is "some register", not the expression that produced it
+#define IRRL_OPAQUE(x) asm volatile("" : "+v"(x))
 #define IRRL_L16 1
 
 typedef float vf;
@@ -57,12 +59,14 @@ IRRL_DEV vf legs_sum(vf x) { x += dpp_f<0x124>(x); x += dpp_f<0x128>(x); return 
 IRRL_DEV vi legs_sum_i(vi x) { x += dpp_i<0x124>(x); x += dpp_i<0x128>(x); return x; }
 template <int K> IRRL_DEV vf legs_bcast(vf x) { return dpp_f<0x150 + 4 * K>(x); }          // row_newbcast:4K (sub-lane 0 of leg K)
 template <int K> IRRL_DEV vi legs_bcast_i(vi x) { return dpp_i<0x150 + 4 * K>(x); }
+template <int K> IRRL_DEV vu legs_bcast_u(vu x) { return (vu)dpp_i<0x150 + 4 * K>((vi)x); }
 template <int N> IRRL_DEV vf row_bcast(vf x) { return dpp_f<0x150 + N>(x); }               // row_newbcast:N (lane N of the robot's row)
 template <int D> IRRL_DEV vf legs_rot(vf x) { return dpp_f<0x120 + 4 * D>(x); }            // the leg D quads away (direction immaterial)
 // ---- inside a leg (the four sub-lanes of the quad) ----
 IRRL_DEV vf sub_sum(vf x) { x += dpp_f<0xB1>(x); x += dpp_f<0x4E>(x); return x; }          // quad_perm [1,0,3,2], [2,3,0,1]
 template <int K> IRRL_DEV vf sub_bcast(vf x) { return dpp_f<K * 0x55>(x); }                 // quad_perm [K,K,K,K]
 template <int K> IRRL_DEV vi sub_bcast_i(vi x) { return dpp_i<K * 0x55>(x); }
+template <int K> IRRL_DEV vu sub_bcast_u(vu x) { return (vu)dpp_i<K * 0x55>((vi)x); }
 // inclusive suffix sum over the sub-lanes, x_s + ... + x_3; REQUIRES x_3 == 0: quad_perm [1,2,3,3] then [2,3,3,3]
 IRRL_DEV vf sub_suffix_sum(vf x) { x += dpp_f<0xF9>(x); x += dpp_f<0xFE>(x); return x; }
 // ---- acc + exchange(x) * y in ONE instruction (v_fmac_f32_dpp) ----

@@ -11,6 +11,9 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // a 16-byte vector at a 4-byte aligned address
 #define LSTM_DEV __device__ __forceinline__
+// (This device code is compiled into TWO translation units -- the stand-alone policy-step kernels beside the update kernels, the rollout
+// kernels beside the env kernels -- and the rollout modes promise bit-identical buffers: the whole library is built with -ffp-contract=on
+// (build.py), i.e. a multiply-add fuses where the source writes a * b + c in one expression and nowhere else, whatever surrounds it.)
 LSTM_DEV float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 LSTM_DEV float fast_tanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
 #endif

@@ -35,6 +35,8 @@ def lib(width=4):
                          emu_set_state=[vp, dp]).items():
             getattr(l, n).restype = None
             getattr(l, n).argtypes = a
+        l.emu_steps_carried.restype = None
+        l.emu_steps_carried.argtypes = [vp, C.c_int, fp, fp, fp, u8, fp, C.c_int]
         l.emu_num_envs.restype = C.c_int
         l.emu_num_envs.argtypes = [vp]
         _LIB[width] = l
@@ -86,6 +88,18 @@ class EmuVecEnv(object):
         done = np.zeros(self.n, np.uint8)
         extra = np.zeros((self.n, 6), np.float32)
         self.l.emu_step(self.h, _fp(action), _fp(ob), _fp(rew), done.ctypes.data_as(C.POINTER(C.c_uint8)), _fp(extra))
+        return ob, rew, done.astype(bool), extra
+
+    def steps_carried(self, action_rows, poison=False):
+        """`len(action_rows)` steps with the lane context carried in registers from step to step (the step loop of the multi-step kernels):
+        -> per-step outputs [K, N, .]"""
+        action_rows = np.ascontiguousarray(action_rows, np.float32)
+        k = action_rows.shape[0]
+        ob = np.zeros((k, self.n, 35), np.float32)
+        rew = np.zeros((k, self.n), np.float32)
+        done = np.zeros((k, self.n), np.uint8)
+        extra = np.zeros((k, self.n, 6), np.float32)
+        self.l.emu_steps_carried(self.h, k, _fp(action_rows), _fp(ob), _fp(rew), done.ctypes.data_as(C.POINTER(C.c_uint8)), _fp(extra), int(poison))
         return ob, rew, done.astype(bool), extra
 
     def probe(self):

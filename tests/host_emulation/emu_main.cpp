@@ -13,6 +13,8 @@
 #include "irrl_terrain.hpp"
 #include "irrl_csv.hpp"
 
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -22,6 +24,7 @@ struct Emu {
   std::vector<char> mem;
   std::vector<float> height;
   std::vector<float> ref;
+  std::vector<uint32_t> counters;     // EnvState::contact_count (the product allocates it beside the pool: irrl_env_abi.hip)
   EnvState S;
 };
 static std::string g_err;
@@ -36,6 +39,47 @@ static inline vm store_mask() {
 #endif
 }
 
+// `count` steps with the lane context CARRIED IN REGISTERS from step to step -- the step loop of the product's multi-step kernels
+// (env_kernels.hip: irrl_steps_persistent_kernel and the persistent rollout kernels): load once, { step_compute; lane_carry } x count, store
+// once.  Outputs [count, N, .].  poison != 0 (16 lanes per robot): behind every step the context of sub-lanes 1-3 of every quad is overwritten
+// with garbage first -- on the GPU those lanes did not run the epilogue, so whatever lane_carry does not re-broadcast from sub-lane 0 is stale.
+template <int RULE>
+static void steps_carried(Emu *h, int count, const float *action_rows, float *ob, float *reward, uint8_t *done, float *extra, int poison) {
+  const size_t n = (size_t)h->P.n_envs;
+  for (int e = 0; e < h->P.n_envs; e++) {
+    const vi env = lanes_env(e), leg = lanes::leg_id();
+    const vm mask = store_mask();
+    irrl::EnvLane L;
+    irrl::load_lane(h->P, h->S, env, leg, L, true);
+    for (int k = 0; k < count; k++) {
+      if (k > 0) {
+        if (getenv("IRRL_EMU_CARRY_DEBUG")) {
+          irrl::store_lane(h->P, h->S, env, leg, mask, L, true);
+          irrl::EnvLane L2;
+          irrl::load_lane(h->P, h->S, env, leg, L2, true);
+          irrl::EnvLane L1 = L;
+          irrl::lane_carry(L1);
+          const uint32_t *a = (const uint32_t *)&L1, *b = (const uint32_t *)&L2;
+          for (size_t i = 0; i < sizeof(irrl::EnvLane) / 4; i++)
+            if (a[i] != b[i]) { fprintf(stderr, "env %d step %d: word %zu (vector %zu, lane %zu) carried %08x loaded %08x\n", e, k, i, i / W, i % W, a[i], b[i]); break; }
+        }
+        irrl::lane_carry(L);      // (between steps only: the final store wants the last step's own torque / contact / observation words)
+      }
+      irrl::step_compute<RULE>(h->P, L, env, leg, mask, irrl::ActionRow{action_rows + (size_t)k * n * 12}, ob + (size_t)k * n * 35, reward + (size_t)k * n,
+                               done + (size_t)k * n, extra + (size_t)k * n * 6);
+#if IRRL_EMU_W == 16
+      if (poison) {
+        static_assert(sizeof(irrl::EnvLane) % (4 * W) == 0, "EnvLane is made of 32-bit lane vectors");
+        uint32_t *w = (uint32_t *)&L;
+        for (size_t i = 0; i < sizeof(irrl::EnvLane) / 4; i++)
+          if ((i % W) & 3) w[i] = 0x7fc00000u ^ (uint32_t)(i * 2654435761u);
+        irrl::model_signs(L.m, leg);      // (per-lane constants, not part of the carried state)
+      }
+#endif
+    }
+    irrl::store_lane(h->P, h->S, env, leg, mask, L, true);
+  }
+}
 extern "C" {
 const char *emu_last_error() { return g_err.c_str(); }
 void *emu_create(const char *cfg_yaml) {
@@ -46,6 +90,8 @@ void *emu_create(const char *cfg_yaml) {
   h->pool = irrl_host::StatePool(h->P.n_envs);
   h->mem.assign(h->pool.bytes, 0);
   h->S = h->pool.view(h->mem.data());
+  h->counters.assign((size_t)h->P.n_envs * 4, 0u);
+  h->S.contact_count = h->counters.data();
   if (h->P.terrain) {
     irrl_host::generate_heightfield(irrl_host::TerrainSpec(), h->P.seed, h->height);
     h->P.height = h->height.data();
@@ -91,6 +137,11 @@ void emu_step(void *hv, const float *action, float *ob, float *reward, uint8_t *
   for (int e = 0; e < h->P.n_envs; e++)
     if (h->P.contact_rule) irrl::step_body<1>(h->P, h->S, lanes_env(e), lanes::leg_id(), store_mask(), action, ob, reward, done, extra);
     else irrl::step_body<0>(h->P, h->S, lanes_env(e), lanes::leg_id(), store_mask(), action, ob, reward, done, extra);
+}
+void emu_steps_carried(void *hv, int count, const float *action_rows, float *ob, float *reward, uint8_t *done, float *extra, int poison) {
+  Emu *h = (Emu *)hv;
+  if (h->P.contact_rule) steps_carried<1>(h, count, action_rows, ob, reward, done, extra, poison);
+  else steps_carried<0>(h, count, action_rows, ob, reward, done, extra, poison);
 }
 void emu_probe(void *hv, float *minv, float *nonlin) {
   Emu *h = (Emu *)hv;

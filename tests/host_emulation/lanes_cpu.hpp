@@ -10,6 +10,7 @@
 #include <cstring>
 
 #define IRRL_DEV inline
+#define IRRL_OPAQUE(x) do { } while (0)
 // on the GPU this region runs on sub-lane 0 of every leg only; the emulation lets every lane compute (same values)
 #define IRRL_SUB0_ONLY_BEGIN {
 #define IRRL_SUB0_ONLY_END }
@@ -81,6 +82,7 @@ inline vf legs_sum(vf x) {
 inline vi legs_sum_i(vi x) { int s = x.v[0] + x.v[1] + x.v[2] + x.v[3]; return vi(s); }
 template <int K> inline vf legs_bcast(vf x) { return vf(x.v[K]); }
 template <int K> inline vi legs_bcast_i(vi x) { return vi(x.v[K]); }
+template <int K> inline vu legs_bcast_u(vu x) { return vu(x.v[K]); }
 #else
 inline vi leg_id() { vi r; for (int i = 0; i < W; i++) r.v[i] = (i >> 2) & 3; return r; }
 inline vi sub_id() { vi r; for (int i = 0; i < W; i++) r.v[i] = i & 3; return r; }
@@ -99,6 +101,7 @@ inline vi legs_sum_i(vi x) {
 }
 template <int K> inline vf legs_bcast(vf x) { return vf(x.v[4 * K]); }      // row_newbcast:4K (sub-lane 0 of leg K)
 template <int K> inline vi legs_bcast_i(vi x) { return vi(x.v[4 * K]); }
+template <int K> inline vu legs_bcast_u(vu x) { return vu(x.v[4 * K]); }
 // same sub-lane of the leg D quads away (the rotation direction is immaterial to the algorithms built on it)
 template <int N> inline vf row_bcast(vf x) { return vf(x.v[N]); }            // row_newbcast:N
 template <int D> inline vf legs_rot(vf x) { vf r; for (int i = 0; i < 16; i++) r.v[i] = x.v[(i + 4 * D) & 15]; return r; }
@@ -110,6 +113,7 @@ inline vf sub_sum(vf x) {
 }
 template <int K> inline vf sub_bcast(vf x) { vf r; for (int i = 0; i < 16; i++) r.v[i] = x.v[(i & ~3) | K]; return r; }
 template <int K> inline vi sub_bcast_i(vi x) { vi r; for (int i = 0; i < 16; i++) r.v[i] = x.v[(i & ~3) | K]; return r; }
+template <int K> inline vu sub_bcast_u(vu x) { vu r; for (int i = 0; i < 16; i++) r.v[i] = x.v[(i & ~3) | K]; return r; }
 template <int K> inline vf sub_bcast_fma(vf x, vf y, vf acc) { return acc + sub_bcast<K>(x) * y; }
 template <int D> inline vf legs_rot_fma(vf x, vf y, vf acc) { return acc + legs_rot<D>(x) * y; }
 // inclusive suffix sum over the sub-lanes (sub-lane s gets x_s + .. + x_3); REQUIRES x_3 == 0 (quad_perm [1,2,3,3], [2,3,3,3])

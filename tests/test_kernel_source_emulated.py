@@ -272,3 +272,30 @@ def test_policy_trained_on_the_hip_engine_trots_in_the_oracle(make):
     vx, falls = PL.closed_loop_reference_policy(make(cfg), cfg, 1.5, 900, fixture="actor_trained_on_hip_engine.npz")
     assert falls == 0
     assert -1.75 < vx[450:].mean() < -1.2, vx[450:].mean()
+
+
+@pytest.mark.parametrize("width", [4, 16])
+@pytest.mark.parametrize("cfg_name,over", [("default_cfg.yaml", {}), ("bp5_terrain.yaml", {}), ("bp5_manual_eval.yaml", {"ObsFilter": True})])
+def test_lane_context_carried_in_registers_equals_store_and_load(width, cfg_name, over):
+    """Round 5: the multi-step kernels (env_kernels.hip: `irrl_steps_persistent_kernel`, the persistent rollout kernels) keep a robot's lane
+    context in registers from one control step to the next -- load_lane once, { step_compute; lane_carry } per step, store_lane once -- instead
+    of storing and re-loading it around every step.  The same kernel source on the host: K steps carried == K `step_body` calls (store + load
+    every step), EVERY step's outputs and the final pool bit for bit -- with in-step resets, noise, per-episode model randomisation (terrain
+    config), the observation filter's history -- and, in the 16-lane layout, with the context of sub-lanes 1-3 POISONED behind every step: on the
+    GPU those lanes skip the epilogue, so every word the next step reads must come back from sub-lane 0 (`lane_carry`)."""
+    from host_emulation.emu import EmuVecEnv
+    n, K = 6, 60
+    cfg = load_env_cfg(cfg_name, num_envs=n, **over)
+    a, b = EmuVecEnv(cfg, width=width), EmuVecEnv(cfg, width=width)
+    rng = np.random.default_rng(7)
+    acts = np.clip(0.6 * rng.standard_normal((K, n, 12)), -1, 1).astype(np.float32)
+    st = a.get_state()
+    st[:2, 2] = 0.1                    # two robots start below the termination height: an in-step reset in the very first step
+    a.set_state(st); b.set_state(st)
+    want = [a.step(acts[k]) for k in range(K)]
+    got = b.steps_carried(acts, poison=(width == 16))
+    for j, name in enumerate(("ob", "reward", "done", "extraInfo")):
+        w = np.stack([x[j] for x in want])
+        assert np.array_equal(w, got[j], equal_nan=True), "%s differs at step %d" % (name, int(np.argwhere(w != got[j])[0][0]))
+    assert np.stack([x[2] for x in want]).sum() >= 2
+    np.testing.assert_array_equal(a.get_state(), b.get_state())

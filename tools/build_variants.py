@@ -10,7 +10,7 @@ for spec in sys.argv[1:]:
     name, _, flags = spec.partition("=")
     flags = [f for f in flags.split(",") if f]
     objs = []
-    common = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-fno-signed-zeros"] + flags
+    common = list(B.COMMON_FLAGS) + flags
     for src, fl, obj in (("env_kernels.hip", ["-DIRRL_LANES_PER_ROBOT=16"] + B.ENV_FLAGS, "l16"), ("env_kernels.hip", ["-DIRRL_LANES_PER_ROBOT=4"] + B.ENV_FLAGS, "l4"),
                          ("irrl_env_abi.hip", [], "abi")):
         o = os.path.join(out, f"{name}_{obj}.o")

@@ -130,7 +130,7 @@ while [ $# -gt 0 ]; do
     abprec)
       RS=high_speed_quadrupedal_locomotion_by_irrl_amd/rsc; mkdir -p $O/abprec; rm -f $O/abprec/*
       for p in bf16x3 bf16x6 f32; do
-        IRRL_LSTM_PRECISION=$p timeout 900 python scripts/run_bp_v5.py --train --save 0 --cfg $RS/default_cfg.yaml --num_envs 4096 --l 0.001 --max_iter $((4096*750*${ABPREC_UPDATES:-300})) --eval_every_n 0 2>&1 | grep -E "nupdates" | cut -c1-400 > $O/abprec/train_$p.log
+        IRRL_LSTM_PRECISION=$p timeout 900 python scripts/run_bp_v5.py --train --save 0 --cfg $RS/default_cfg.yaml --num_envs 4096 --l 0.001 --max_iter $((4096*750*${ABPREC_UPDATES:-300})) --eval_every_n 0 2>&1 > $O/abprec/raw_$p.log; grep -E "nupdates" $O/abprec/raw_$p.log | cut -c1-400 > $O/abprec/train_$p.log; tail -5 $O/abprec/raw_$p.log > $O/abprec/tail_$p.log; rm -f $O/abprec/raw_$p.log
       done ;;
     variants)
       V=high_speed_quadrupedal_locomotion_by_irrl_amd/csrc/_variants; rm -f $O/variants.log
@@ -138,7 +138,9 @@ while [ $# -gt 0 ]; do
         IRRL_ENV_LIB=$PWD/$f timeout 300 python bench.py ${VARIANT_ARGS} --cpu-seconds 0 --ppo-iters 0 --steps 2000 2>/dev/null | line "$(basename $f .so)" >> $O/variants.log
       done; done
       if [ -n "$VARIANTS_PPO" ]; then for f in $V/libirrl_env_*.so; do
-        IRRL_ENV_LIB=$PWD/$f timeout 300 python tools/ppo_bench.py --policy lstm --envs 4096 --iters 3 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$(basename $f .so) ppo rollout', round(d['rollout_s']*1e3,2), 'ms update', round(d['update_s']*1e3,2), 'ms')" >> $O/variants.log
+        for pol in ${VARIANTS_PPO}; do
+          IRRL_ENV_LIB=$PWD/$f timeout 300 python tools/ppo_bench.py --policy $pol --envs 4096 --iters 4 --cfg $([ $pol = mlp ] && echo bp5_imitation.yaml || echo default_cfg.yaml) 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$(basename $f .so) ppo $pol rollout', round(d['rollout_s']*1e3,2), 'ms update', round(d['update_s']*1e3,2), 'ms')" >> $O/variants.log
+        done
       done; fi ;;
     ablstm)
       # same-box A/B of the LSTM update over every csrc/_variants/libirrl_env_*.so, interleaved, two rounds: PPO-LSTM iteration with the update at
