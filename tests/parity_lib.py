@@ -27,16 +27,18 @@ TOL_STEP = dict(ob=5e-4, rew=2e-4, extra=2e-4, pos=2e-5, vel=5e-3)
 #   rough ground, small pools     100x  (TERRAIN_*; rounds 1-3 allowed 400x and counted events only from 40x)
 #   trunk-box corners, meteorite  400x  (CORNER_CAP_FACTOR: a robot dropped onto a corner / a 6 m/s sphere of up to 20 kg hitting the trunk
 #                                        a substep apart moves joint rates by several rad/s: observation 0.14 measured in 960 env-steps)
-#   full-size pools (8e4-3e5 env-steps per test) 120x (FULL_SIZE_CAP_FACTOR: the rare hard landing among 3e5 env-steps; measured worst
-#                                        102x in a position, 78x in a velocity, 77x in an observation -- profiles/r04_pytest_gpu.log and,
-#                                        the same seeded runs, profiles/r05_pytest_gpu.log; round 4 allowed 200x)
+#   full-size pools (8e4-3e5 env-steps per test) 150x (FULL_SIZE_CAP_FACTOR: the rare hard landing among 3e5 env-steps.  WHICH toe lands a substep
+#                                        apart in the two precisions depends on the kernels' last bits, so the worst factor moves with every
+#                                        build: 102x (position) / 78x / 77x with round 4's binary, 115x (observation) / 109x (velocity) /
+#                                        102x with round 5's (-ffp-contract=on) on the same seeded runs -- profiles/r04_pytest_gpu.log,
+#                                        r05_pytest_gpu.log.  The cap is 1.3 x the larger; round 4 allowed 200x)
 # Measured event rates on the MI355X at full size (profiles/r04_pytest_gpu.log): 0.09-0.2 % of the env-steps on flat AND on rough ground.
 # (Before round 4's fix of the f32 cell coordinate of the height field -- env_core.hpp terrain_sample -- rough ground had 0.8 % and a 20x
 # larger position error than flat ground: x - x0 was formed at ~250 m.)
 TERRAIN_MAX_FACTOR = 10.0
 CORNER_MAX_FACTOR = 10.0
 CORNER_CAP_FACTOR = 400.0
-FULL_SIZE_CAP_FACTOR = 120.0
+FULL_SIZE_CAP_FACTOR = 150.0
 TERRAIN_EVENT_BUDGET = 0.005
 
 
