@@ -196,6 +196,67 @@ irrl_rollout_persistent_kernel_l16(EnvParams P, EnvState S, float *ob, float *re
 #endif
 
 #if IRRL_LANES_PER_ROBOT == 16
+// THE LSTM ROLLOUT WITH THE CRITIC OFF THE PER-STEP PATH (round 5; irrl_lstm_rollout fuse = 3).  The value V(s_t) is a function of the
+// observation history only -- nothing in the rollout depends on it until GAE -- so the per-step part runs the ACTOR stack alone and the
+// caller evaluates the critic stack over the recorded [T, N, 35] observations afterwards with the update's sequence kernels (two launches
+// for the whole rollout; ppo2.Runner).  What that buys per step: half the policy part's MFMAs and cells, and -- the LDS that held the critic's
+// layer-0 operands now holds the actor's layer-1 operands -- NO weight fetched from L2 inside the step loop; the head weights are staged
+// once.  Same device functions and per-element arithmetic as the full kernel above: actions, clipped actions, neglogp, observations,
+// rewards, dones and the actor's LSTM state are bit-identical to every other rollout mode; `value` / `mb_values` are not written.
+__global__ void __launch_bounds__(256, 1)
+irrl_rollout_persistent_actor_kernel_l16(EnvParams P, EnvState S, float *ob, float *reward, uint8_t *done, float *extra, PolicyStepArgs a, int steps) {
+  __shared__ float hbuf[2][16 * 49];
+  __shared__ float terms[16][17];
+  __shared__ float head_w[48 * 17];
+  __shared__ __attribute__((aligned(1024))) float lds_w[PolicyLdsImage<48>::FLOATS];   // wh0 | wx0 | wh1 | wx1 of the ACTOR stack
+  policy_prefetch_lds_actor<48, 256>(a, lds_w);
+  for (int i = (int)threadIdx.x; i < 48 * a.act_dim; i += 256) head_w[i] = a.pi_w[i];
+  const float *states_first = a.states_in, *noise0 = a.noise;
+  const long long row0 = a.row, rng0 = a.rng_step;
+  const size_t noise_stride = (size_t)a.N * (size_t)a.act_dim;
+  // the env part's lane context stays in registers across the steps (irrl_steps_persistent_kernel below): with one virtual wave per wave the
+  // policy part leaves room for it (379 registers, no scratch beyond the reset branch's)
+  const int lane0_ = (int)(threadIdx.x & 63u);
+  int env0_ = ((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * 4 + (lane0_ >> 4);
+  const int leg0_ = (lane0_ >> 2) & 3;
+  const bool valid0_ = (env0_ < P.n_envs) && ((lane0_ & 3) == 0);
+  if (env0_ >= P.n_envs) env0_ = P.n_envs - 1;
+#ifndef IRRL_ACTOR_NO_CARRY      /* A/B switch of tools/build_variants.py */
+  irrl_plain::EnvLane L;
+  irrl_plain::load_lane(P, S, env0_, leg0_, L, true);
+#endif
+  __syncthreads();   // the LDS image and the head weights have landed
+  for (int k = 0; k < steps; k++) {
+    int tid = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid));     // (see irrl_rollout_persistent_kernel_l16: keeps the per-lane addresses inside the loop)
+    a.row = row0 + k; a.rng_step = rng0 + k;
+    a.noise = noise0 ? noise0 + (size_t)k * noise_stride : nullptr;
+    a.states_in = k == 0 ? states_first : a.states_out;
+    policy_step_body<48, 9, 1, 256, true, true>(a, (int)blockIdx.x * 16, hbuf, terms, head_w, lds_w, 0, 0, tid);
+    __syncthreads();   // this workgroup's clipped actions (and the rollout rows) are stored and visible to its own loads
+    {
+      int env_ = env0_;
+      asm volatile("" : "+v"(env_));
+#ifndef IRRL_ACTOR_NO_CARRY
+      if (k > 0) irrl_plain::lane_carry(L);
+      irrl_plain::step_compute<1>(P, L, env_, leg0_, valid0_, irrl_plain::ActionRow{(const float *)a.clipped}, ob, reward, done, extra);
+#else
+      irrl_plain::step_body<1>(P, S, env_, leg0_, valid0_, (const float *)a.clipped, ob, reward, done, extra);
+#endif
+    }
+    __syncthreads();   // obs / dones / reward of step k are stored and visible: the next policy step reads them
+  }
+#ifndef IRRL_ACTOR_NO_CARRY
+  if (steps > 0) {
+    IRRL_SUB0_ONLY_BEGIN
+    irrl_plain::store_lane(P, S, env0_, leg0_, valid0_, L, P.randomize_per_episode != 0);
+    IRRL_SUB0_ONLY_END
+  }
+#endif
+}
+#endif
+
+#if IRRL_LANES_PER_ROBOT == 16
 // THE SAME FOR MlpPolicy (BASELINE config 2's learner): the whole rollout in one launch, a workgroup = 16 robots = four env waves = the
 // four waves of the policy step (two per network).  The policy's 52 KB of weights and biases are copied to LDS ONCE; a step of the
 // policy part is then two short MFMA blocks on LDS operands + the heads (a few us against 8.7 us for the stand-alone launch, whose

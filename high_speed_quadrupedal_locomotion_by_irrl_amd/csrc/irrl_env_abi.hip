@@ -31,6 +31,7 @@ IRRL_DECLARE_KERNELS(_l4)
 extern "C" __global__ void irrl_terminal_kernel(EnvParams, EnvState, uint8_t *);
 extern "C" __global__ void irrl_step_policy_kernel_l16(EnvParams, EnvState, const float *, float *, float *, uint8_t *, float *, PolicyStepArgs);
 extern "C" __global__ void irrl_rollout_persistent_kernel_l16(EnvParams, EnvState, float *, float *, uint8_t *, float *, PolicyStepArgs, int);
+extern "C" __global__ void irrl_rollout_persistent_actor_kernel_l16(EnvParams, EnvState, float *, float *, uint8_t *, float *, PolicyStepArgs, int);
 extern "C" __global__ void irrl_rollout_persistent_mlp_kernel_l16(EnvParams, EnvState, float *, float *, uint8_t *, float *, PolicyStepArgs, int);
 
 #include "irrl_config.hpp"
@@ -333,7 +334,10 @@ int irrl_lstm_rollout(irrl_env *h, int steps, int hid, int ob_dim, int act_dim, 
   // fuse == 2: THE WHOLE ROLLOUT AS ONE PERSISTENT LAUNCH (irrl_rollout_persistent_kernel_l16): a workgroup loops over all steps for its
   // 16 robots -- no grid-wide boundary between steps, layer-0 weights fetched into LDS once.  Same device code per step as the
   // other two paths, bit-identical buffers.
-  if (fuse == 2 && one_tile && steps > 0) {
+  // fuse == 3: the persistent launch with the CRITIC OFF THE PER-STEP PATH (irrl_rollout_persistent_actor_kernel_l16): the actor stack alone per
+  // step, all of its LSTM operands resident in LDS; `value` / mb_values and the critic's half of `states` are NOT written -- the caller
+  // evaluates the critic over the recorded observations afterwards (ppo2.Runner).  Everything else bit-identical to the other paths.
+  if ((fuse == 2 || fuse == 3) && one_tile && steps > 0) {
     // the same argument checks the other two paths get from irrl_lstm_policy_step (a bad caller gets rc = 1, not an out-of-bounds access)
     if (!(obs && dones && states_in && states_out && lstm_w && pi_w && pi_b && vf_w && vf_b && logstd && action && clipped && value && neglogp &&
           env_reward && env_extra)) { g_err = "irrl_lstm_rollout: NULL argument on the persistent path"; return 1; }
@@ -350,10 +354,14 @@ int irrl_lstm_rollout(irrl_env *h, int steps, int hid, int ob_dim, int act_dim, 
     a.mb_rewards = mb_rewards; a.prev_reward = mb_rewards ? env_reward : nullptr;
     a.rng_step = rng_step; a.rng_seed = rng_seed; a.rng_on = rng_on; a.env_id_offset = (unsigned)env_id_offset;
     a.N = n; a.ob_dim = ob_dim; a.act_dim = act_dim;
-    hipLaunchKernelGGL(irrl_rollout_persistent_kernel_l16, dim3((n + 15) / 16), dim3(256), 0, h->stream, h->P, h->S, obs, env_reward, dones, env_extra, a, steps);
+    if (fuse == 3)
+      hipLaunchKernelGGL(irrl_rollout_persistent_actor_kernel_l16, dim3((n + 15) / 16), dim3(256), 0, h->stream, h->P, h->S, obs, env_reward, dones, env_extra, a, steps);
+    else
+      hipLaunchKernelGGL(irrl_rollout_persistent_kernel_l16, dim3((n + 15) / 16), dim3(256), 0, h->stream, h->P, h->S, obs, env_reward, dones, env_extra, a, steps);
     HIP_TRY(hipGetLastError());
     return 0;
   }
+  if (fuse == 3) { g_err = "irrl_lstm_rollout: fuse = 3 (critic off the per-step path) exists for the persistent kernel only: 16 lanes per robot, hid 48, no Crutial, published contact rule"; return 1; }
   const bool fused = fuse == 1 && one_tile && steps > 1;
   if (steps > 0 && policy(0) != 0) { g_err = "irrl_lstm_rollout: policy step refused its arguments"; return 1; }
   for (int k = 0; k < steps; k++) {

@@ -56,7 +56,9 @@ constexpr int LBF_HID = 48, LBF_KX = 48, LBF_KF = LBF_HID + LBF_KX;   // forward
 constexpr int LBF_FROW = LBF_KF + 8;                                    // padded A-tile row (bf16 elements; 208 bytes: 16-byte aligned)
 template <int NS> constexpr int lstm_fwd_bf16_lds_bytes() { return 2 * NS * 16 * LBF_FROW * 2; }
 
-template <int NS>
+// STORE_GC: the gates and c rows are kept for the backward kernel (the update).  false = INFERENCE (round 5: the critic pass behind an actor-only
+// rollout, ppo2.Runner._critic_pass): only h and the final state leave the kernel -- 384 instead of 1152 bytes stored per env and step.
+template <int NS, bool STORE_GC = true>
 __global__ void __launch_bounds__(192)
 lstm_seq_fwd_bf16_kernel(const LstmFwdBf16Args a) {
   constexpr int HID = LBF_HID, KC = LBF_KF / 32;
@@ -174,10 +176,10 @@ lstm_seq_fwd_bf16_kernel(const LstmFwdBf16Args a) {
       // (non-temporal stores here and loads in the backward kernel -- the gates are written once and read once -- change nothing:
       // PPO update 111.5 against 111.6 ms, same box)
 #ifndef IRRL_LBF_AB_NO_GATE_STORES      /* A/B switches of tools/build_variants.py (wrong results): which of the forward kernel's stores cost what */
-      *(f32x4 *)&a.gates[(row * HID + u) * 4] = (f32x4){ig, fg, og, gg};
+      if (STORE_GC) *(f32x4 *)&a.gates[(row * HID + u) * 4] = (f32x4){ig, fg, og, gg};
 #endif
 #ifndef IRRL_LBF_AB_NO_CH_STORES
-      a.cseq[row * HID + u] = cn;
+      if (STORE_GC) a.cseq[row * HID + u] = cn;
       a.hseq[row * HID + u] = hn;
 #endif
       keepn[j] = 1.0f - mk_nxt[j];

@@ -1295,12 +1295,16 @@ int irrl_lstm_seq_forward_bf16(int nsplit, int hid, int T, int N, int n_in, cons
   a.x = x; a.wx_p = wx_p; a.b_p = b_p; a.wh_p = wh_p; a.masks = masks; a.state0 = state0;
   a.gates = gates; a.cseq = cseq; a.hseq = hseq; a.state_out = state_out; a.T = T; a.N = N; a.n_in = n_in;
   hipStream_t s = (hipStream_t)hip_stream;
+  const bool train = gates != nullptr && cseq != nullptr;     // both NULL: inference -- only hseq and state_out are written
+  if (!train && (gates != nullptr || cseq != nullptr)) return 1;
   if (nsplit == 2) {
     constexpr int bytes = lstm_fwd_bf16_lds_bytes<2>();
-    hipLaunchKernelGGL(lstm_seq_fwd_bf16_kernel<2>, dim3(N / 16), dim3(192), bytes, s, a);
+    if (train) hipLaunchKernelGGL((lstm_seq_fwd_bf16_kernel<2, true>), dim3(N / 16), dim3(192), bytes, s, a);
+    else hipLaunchKernelGGL((lstm_seq_fwd_bf16_kernel<2, false>), dim3(N / 16), dim3(192), bytes, s, a);
   } else {
     constexpr int bytes = lstm_fwd_bf16_lds_bytes<3>();
-    hipLaunchKernelGGL(lstm_seq_fwd_bf16_kernel<3>, dim3(N / 16), dim3(192), bytes, s, a);
+    if (train) hipLaunchKernelGGL((lstm_seq_fwd_bf16_kernel<3, true>), dim3(N / 16), dim3(192), bytes, s, a);
+    else hipLaunchKernelGGL((lstm_seq_fwd_bf16_kernel<3, false>), dim3(N / 16), dim3(192), bytes, s, a);
   }
   return hipGetLastError() == hipSuccess ? 0 : 2;
 }

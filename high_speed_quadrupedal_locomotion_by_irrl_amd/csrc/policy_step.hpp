@@ -67,7 +67,9 @@ LSTM_DEV void policy_philox(unsigned seed, unsigned c0, unsigned c1, unsigned c2
 // Heads, sample, neglogp, clip and rollout-buffer rows shared by the LSTM and MLP policy-step kernels: thread (env, action)
 // for the mean / sample, 16 more threads for the value and the neglogp sum.  hpi / hv: the two nets' last hidden
 // activations [16 envs][LD] in LDS; head_w: pi_w [HID][act] then vf_w [HID] staged in LDS.
-template <int HID>
+// NO_VALUE: the critic is not part of this step (the actor-only rollout kernel: values are computed for the whole rollout afterwards) --
+// `value` / `mb_values` are not written, everything else is.
+template <int HID, bool NO_VALUE = false>
 LSTM_DEV void policy_heads(const PolicyStepArgs &a, const float *hpi, const float *hv, int LD, const float *head_w, float (*terms)[17],
                            int e0, int tid, long long t, long long gstep) {
   // heads: thread (env, action) for the mean / sample, 16 more threads for the value and the neglogp sum
@@ -106,7 +108,7 @@ LSTM_DEV void policy_heads(const PolicyStepArgs &a, const float *hpi, const floa
   float val = 0.0f;
   const int vt = tid - 16 * A;
   const bool vok = vt >= 0 && vt < 16 && e0 + vt < a.N;
-  if (vok) {
+  if (vok && !NO_VALUE) {
     val = a.vf_b[0];
 #pragma unroll
     for (int k = 0; k < HID; k++) val = __builtin_fmaf(hv[vt * LD + k], head_w[HID * A + k], val);
@@ -118,10 +120,10 @@ LSTM_DEV void policy_heads(const PolicyStepArgs &a, const float *hpi, const floa
     nl = __builtin_fmaf((float)A, 0.918938533204672742f, nl);   // 0.5 log(2 pi) per action dimension (an explicit FMA: inside a step loop the
                                                                   // product is loop-invariant and would otherwise be rounded on its own)
     const int e = e0 + vt;
-    a.value[e] = val;
+    if (!NO_VALUE) a.value[e] = val;
     a.neglogp[e] = nl;
     if (a.mb_values) {
-      a.mb_values[(size_t)t * a.N + e] = val;
+      if (!NO_VALUE) a.mb_values[(size_t)t * a.N + e] = val;
       a.mb_neglogp[(size_t)t * a.N + e] = nl;
       a.mb_dones[(size_t)t * a.N + e] = a.dones[e];
       if (a.prev_reward && t > 0) a.mb_rewards[(size_t)(t - 1) * a.N + e] = a.prev_reward[e];
@@ -257,21 +259,49 @@ LSTM_DEV void policy_prefetch_lds(const PolicyStepArgs &a, float *lds_w) {
   }
 }
 
-template <int HID, int OBK, int VPW, int NTHR, bool LDSW = false>
+// the ACTOR-ONLY image (round 5: irrl_rollout_persistent_actor_kernel): with the critic off the per-step path the same LDS holds ALL of the
+// actor's LSTM operands -- [wh0 | wx0 | wh1 | wx1], 4 x 9216 floats for HID 48 -- so a step of the policy part fetches no weight from L2 at all
+template <int HID, int NTHR>
+LSTM_DEV void policy_prefetch_lds_actor(const PolicyStepArgs &a, float *lds_w) {
+  typedef PolicyLdsImage<HID> IMG;
+  static_assert(IMG::WX0 == HID * HID * 4, "the layer-1 input weights [HID][HID][4] fill the slot of the padded layer-0 input weights");
+  constexpr int NWAVES = NTHR / 64;
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int wx_floats = a.ob_dim * HID * 4;
+  const int wx_pieces = (wx_floats + 255) / 256;
+  const float *src[3] = {a.w[1], a.w[4], a.w[3]};                      // wh0, wh1, wx1: whole 1 KiB pieces
+  const int dsto[3] = {0, IMG::STACK, IMG::STACK + IMG::WH0};
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+    for (int c = w; c < IMG::WH0 / 256; c += NWAVES)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src[i] + c * 256 + l * 4),
+                                       (__attribute__((address_space(3))) void *)(lds_w + dsto[i] + c * 256), 16, 0, 0);
+  for (int c = w; c < wx_pieces; c += NWAVES) {                         // wx0: ob_dim rows, the last piece ragged
+    int idx = c * 256 + l * 4;
+    idx = idx < wx_floats - 4 ? idx : wx_floats - 4;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.w[0] + idx),
+                                     (__attribute__((address_space(3))) void *)(lds_w + IMG::WH0 + c * 256), 16, 0, 0);
+  }
+}
+
+// ACTOR_ONLY (needs VPW == 1, NTHR == 256, LDSW): waves 0 .. NW-1 run the actor stack's virtual waves, nobody runs the critic; all four
+// weight matrices of the actor come from the LDS image of policy_prefetch_lds_actor; `value` is not produced.  Per output element of the
+// actor the arithmetic and its order are those of every other instantiation: actions, neglogp and the actor's states agree bit for bit.
+template <int HID, int OBK, int VPW, int NTHR, bool LDSW = false, bool ACTOR_ONLY = false>
 LSTM_DEV void policy_step_body(const PolicyStepArgs &a, const int e0, float (*hbuf)[16 * (HID + 1)], float (*terms)[17], float *head_w,
                                const float *lds_w = nullptr, unsigned long long prof_t0 = 0, unsigned long long prof_t1 = 0, const int tid_opaque = -1) {
   constexpr int NW = HID / 16;
   constexpr int KS = HID / 4;
   constexpr int LD = HID + 1;
   constexpr int SD = 8 * HID;
-  static_assert(VPW == 1 ? NTHR == 2 * NW * 64 : (VPW == 2 && NTHR >= NW * 64), "workgroup shape");
+  static_assert(ACTOR_ONLY ? (VPW == 1 && NTHR >= NW * 64 && LDSW) : (VPW == 1 ? NTHR == 2 * NW * 64 : (VPW == 2 && NTHR >= NW * 64)), "workgroup shape");
   // tid_opaque: the persistent rollout kernel hands in threadIdx.x through an empty asm every iteration, so that the per-lane
   // address arithmetic below stays INSIDE its step loop (hoisted, it is hundreds of live 64-bit registers: 2 KB of scratch)
   const int tid = tid_opaque >= 0 ? tid_opaque : (int)threadIdx.x;
   const int w = tid >> 6, l = tid & 63;
   const int col = l & 15, rq = l >> 4;
-  const bool mine = VPW == 1 ? true : (w < NW);                 // wave-uniform: this wave owns virtual waves
-  const int ws = VPW == 1 ? w % NW : (w < NW ? w : 0);
+  const bool mine = (VPW == 1 && !ACTOR_ONLY) ? true : (w < NW);                 // wave-uniform: this wave owns virtual waves
+  const int ws = (VPW == 1 && !ACTOR_ONLY) ? w % NW : (w < NW ? w : 0);
 #ifdef IRRL_PROFILE_POLICY
   unsigned long long ts_[8];
   int tsn_ = 0;
@@ -303,7 +333,7 @@ LSTM_DEV void policy_step_body(const PolicyStepArgs &a, const int e0, float (*hb
   int stk[VPW];
 #pragma unroll
   for (int v = 0; v < VPW; v++) {
-    const int stack = VPW == 1 ? w / NW : v;
+    const int stack = ACTOR_ONLY ? 0 : (VPW == 1 ? w / NW : v);
     stk[v] = stack;
     // selects between kernel arguments (scalar registers), not an indexed load of the argument block
     wx0[v] = stack ? a.w[6] : a.w[0]; wh0[v] = stack ? a.w[7] : a.w[1]; b0[v] = stack ? a.w[8] : a.w[2];
@@ -360,7 +390,9 @@ LSTM_DEV void policy_step_body(const PolicyStepArgs &a, const int e0, float (*hb
 #pragma unroll
       for (int m = 0; m < KV; m++) hp1[v][m] = *(const f32x4 *)&a.states_in[(size_t)eA * SD + soff1[v] + HID + 16 * m + 4 * rq];
 #pragma unroll
-      for (int kk = 0; kk < KS; kk++) Wh1[v][kk] = *(const f32x4 *)&wh1[v][((size_t)(16 * (kk / 4) + 4 * rq + (kk % 4)) * HID + u) * 4];
+      for (int kk = 0; kk < KS; kk++)
+        Wh1[v][kk] = ACTOR_ONLY ? *(const f32x4 *)&lds_w[PolicyLdsImage<HID>::STACK + ((16 * (kk / 4) + 4 * rq + (kk % 4)) * HID + u) * 4]
+                                : *(const f32x4 *)&wh1[v][((size_t)(16 * (kk / 4) + 4 * rq + (kk % 4)) * HID + u) * 4];
     }
 #pragma unroll
     for (int v = 0; v < VPW; v++) {
@@ -373,8 +405,9 @@ LSTM_DEV void policy_step_body(const PolicyStepArgs &a, const int e0, float (*hb
     }
   }
   // head weights: pi_w [HID][act] then vf_w [HID] = HID * (act + 1) <= HID * 17 floats over the workgroup's threads
-  constexpr int NHW = (HID * 17 + NTHR - 1) / NTHR;
-  const int n_head = HID * (a.act_dim + 1);
+  // (ACTOR_ONLY: the rollout kernel staged pi_w in `head_w` once, in front of its step loop)
+  constexpr int NHW = ACTOR_ONLY ? 1 : (HID * 17 + NTHR - 1) / NTHR;
+  const int n_head = ACTOR_ONLY ? 0 : HID * (a.act_dim + 1);
   float hw[NHW];
 #pragma unroll
   for (int i = 0; i < NHW; i++) {
@@ -426,7 +459,9 @@ LSTM_DEV void policy_step_body(const PolicyStepArgs &a, const int e0, float (*hb
 #pragma unroll
     for (int v = 0; v < VPW; v++)
 #pragma unroll
-      for (int kk = 0; kk < KS; kk++) Wx1[v][kk] = *(const f32x4 *)&wx1[v][((size_t)(4 * kk + rq) * HID + u) * 4];
+      for (int kk = 0; kk < KS; kk++)
+        Wx1[v][kk] = ACTOR_ONLY ? *(const f32x4 *)&lds_w[PolicyLdsImage<HID>::STACK + PolicyLdsImage<HID>::WH0 + ((4 * kk + rq) * HID + u) * 4]
+                                : *(const f32x4 *)&wx1[v][((size_t)(4 * kk + rq) * HID + u) * 4];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kk = 0; kk < KS; kk++) {
@@ -489,7 +524,7 @@ LSTM_DEV void policy_step_body(const PolicyStepArgs &a, const int e0, float (*hb
   }
   __syncthreads();
   IRRL_PS_STAMP();   // 5: layer-1 cell
-  policy_heads<HID>(a, hbuf[0], hbuf[1], LD, head_w, terms, e0, tid, t, gstep);
+  policy_heads<HID, ACTOR_ONLY>(a, hbuf[0], hbuf[ACTOR_ONLY ? 0 : 1], LD, head_w, terms, e0, tid, t, gstep);
   IRRL_PS_STAMP();   // 6: heads, sample, buffer rows
 #ifdef IRRL_PROFILE_POLICY
   __syncthreads();   // (this workgroup's own neglogp entries are written: the stamps go over them)

@@ -117,7 +117,7 @@ def tall_linear(x, w, b):
 
 class _LstmSeqFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, wx, wh, b, state0, masks):
+    def forward(ctx, x, wx, wh, b, state0, masks, no_grad=False):
         lib = _lib.load()
         T, N, n_in = x.shape
         hid = wh.shape[0]
@@ -134,16 +134,20 @@ class _LstmSeqFn(torch.autograd.Function):
         else:
             x_k, masks_k, state0_k = x, masks, state0
         Np = N + pad
-        gates = torch.empty(T, Np, hid, 4, device=x.device, dtype=torch.float32)
-        cseq = torch.empty(T, Np, hid, device=x.device, dtype=torch.float32)
+        nsplit = _NSPLIT.get(PRECISION, 0) if (hid == 48 and n_in <= 48 and FUSE_INPUT_PROJECTION and FUSE_WEIGHT_GRADIENTS) else 0
+        # no gradient will be asked for (the caller ran under torch.no_grad(): the critic pass behind an actor-only rollout): the bf16 kernels'
+        # inference form keeps neither the gates nor the c rows -- a third of the stores.  (`no_grad` comes from the caller: inside forward()
+        # autograd has switched grad mode off whatever the caller's was.)
+        infer = bool(nsplit) and bool(no_grad)
+        gates = None if infer else torch.empty(T, Np, hid, 4, device=x.device, dtype=torch.float32)
+        cseq = None if infer else torch.empty(T, Np, hid, device=x.device, dtype=torch.float32)
         hseq = torch.empty(T, Np, hid, device=x.device, dtype=torch.float32)
         state_out = torch.empty(Np, 2 * hid, device=x.device, dtype=torch.float32)
         stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        nsplit = _NSPLIT.get(PRECISION, 0) if (hid == 48 and n_in <= 48 and FUSE_INPUT_PROJECTION and FUSE_WEIGHT_GRADIENTS) else 0
         ctx.nsplit = nsplit
         if nsplit:
             rc = lib.irrl_lstm_seq_forward_bf16(nsplit, hid, T, Np, n_in, _ptr(x_k), _ptr(wx_p), _ptr(b_p), _ptr(wh_p), _ptr(masks_k), _ptr(state0_k),
-                                                _ptr(gates), _ptr(cseq), _ptr(hseq), _ptr(state_out), stream)
+                                                None if infer else _ptr(gates), None if infer else _ptr(cseq), _ptr(hseq), _ptr(state_out), stream)
         elif n_in <= 48 and FUSE_INPUT_PROJECTION:
             # x wx + b inside the sequence kernel: no [T*N, 4H] zx round trip through HBM
             rc = lib.irrl_lstm_seq_forward_x(hid, T, Np, n_in, _ptr(x_k), _ptr(wx_p), _ptr(b_p), _ptr(wh_p), _ptr(masks_k), _ptr(state0_k),
@@ -154,7 +158,8 @@ class _LstmSeqFn(torch.autograd.Function):
                                            _ptr(hseq), _ptr(state_out), stream)
         if rc != 0:
             raise RuntimeError("irrl_lstm_seq_forward failed (rc=%d, hid=%d, T=%d, N=%d)" % (rc, hid, T, Np))
-        ctx.save_for_backward(x_k, wx_p, wh_p, gates, cseq, hseq, masks_k, state0_k)
+        if not infer:
+            ctx.save_for_backward(x_k, wx_p, wh_p, gates, cseq, hseq, masks_k, state0_k)
         ctx.dims = (T, N, Np, n_in, hid)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(state_out)
@@ -199,7 +204,7 @@ class _LstmSeqFn(torch.autograd.Function):
                 if lib.irrl_sum_rows(_ptr(part), rows, out.numel(), hid, _ptr(out), stream) != 0:
                     raise RuntimeError("irrl_sum_rows failed")
             dx = dx_k[:, :N] if dx_k is not None else None
-            return dx, dwx, dwh, db, None, None
+            return dx, dwx, dwh, db, None, None, None
         dz = torch.empty(T, Np, hid, 4, device=x_k.device, dtype=torch.float32)
         rc = lib.irrl_lstm_seq_backward(hid, T, Np, _ptr(gates), _ptr(cseq), _ptr(masks_k), _ptr(state0_k), _ptr(dh_seq), _ptr(wh_p),
                                         _ptr(dz), stream)
@@ -214,12 +219,12 @@ class _LstmSeqFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = (dzf @ wx_p.t()).reshape(T, Np, n_in)[:, :N]
-        return dx, dwx, dwh, db, None, None
+        return dx, dwx, dwh, db, None, None, None
 
 
 def lstm_sequence(x, wx, wh, b, state0, masks):
     """x [T,N,n_in], state0 [N,2H] = [c|h], masks [T,N] -> (h_seq [T,N,H], final state [N,2H]) on the MI355X."""
-    return _LstmSeqFn.apply(x, wx, wh, b, state0, masks)
+    return _LstmSeqFn.apply(x, wx, wh, b, state0, masks, not torch.is_grad_enabled())
 
 
 def supported(x, hid):

@@ -171,6 +171,10 @@ class _FusedHeadsLoss(torch.autograd.Function):
         return d_hp, d_hv, d_wpi, d_bpi, d_wv, d_bv, d_logstd, None, None, None, None, None, None, None, None, None
 
 
+# arithmetic of the critic's sequence kernels when the rollout's values are computed after the rollout (Runner._critic_pass): the f32 level
+# ("bf16x6": three bf16 planes per operand, ~2^-24 per product; "f32": the exact-f32 MFMA kernels), whatever the update itself uses
+CRITIC_PASS_PRECISION = os.environ.get("IRRL_CRITIC_PASS_PRECISION", "bf16x6")
+
 # arithmetic of the MlpPolicy gradient kernels: "bf16x3" = every product as three bf16 plane products on the matrix cores (two planes per
 # operand, f32 accumulation, ~2^-16 relative per product; csrc/mlp_bf16.hpp), "f32" = v_mfma_f32_16x16x4_f32 (csrc/mlp_update.hpp)
 MLP_PRECISION = os.environ.get("IRRL_MLP_PRECISION", "bf16x3")
@@ -507,10 +511,16 @@ class Runner(object):
         # re-capture after a setter, start sooner and run ~0.5 us per kernel shorter than graph nodes (ROCm 7.2, MI355X)
         self.rollout_launch = "direct" if (self._fused and hasattr(model.policy, "fused_rollout") and hasattr(getattr(env, "wrapper", None), "_h")
                                            and hasattr(env, "extra")) else "graph"
-        # 0 = two launches per step, 1 = env.step k + policy step k + 1 in one kernel (an experiment, slower), 2 (default) = the whole rollout as
+        # 0 = two launches per step, 1 = env.step k + policy step k + 1 in one kernel (an experiment, slower), 2 (default until round 5) = the whole rollout as
         # ONE persistent launch (a workgroup loops over all steps for its 16 robots: nothing waits for the slowest wave of a step; falls back
         # to 0 where the kernel is not instantiated).  Same bits.  (MlpPolicy: lstm_fused.MLP_ROLLOUT, persistent by default as well.)
-        self.rollout_one_launch_per_step = int(os.environ.get("IRRL_ROLLOUT_FUSED", "2"))
+        # 3 (round 5, the default) = 2 with the CRITIC OFF THE PER-STEP PATH: V(s_t) depends on the observation history only and nothing in the rollout
+        # needs it before GAE (ppo2.py:519-568), so the persistent launch runs the actor stack alone -- all of its operands resident in LDS -- and
+        # `_critic_pass` evaluates the critic stack over the recorded observations afterwards with the sequence kernels (two launches for the
+        # whole rollout).  Actor-side buffers (obs, actions, neglogp, rewards, dones, actor states) bit-identical to the other modes; values at
+        # the f32 level of the sequence kernels (CRITIC_PASS_PRECISION), i.e. within ~1e-6 of the step-by-step ones.  Falls back to 2 where
+        # the kernel is not instantiated.
+        self.rollout_one_launch_per_step = int(os.environ.get("IRRL_ROLLOUT_FUSED", "3"))
         self._raw_env = hasattr(env, "step_into") and hasattr(env, "account_rollout") and dev.type == "cuda"
         # sampling noise: "kernel" = the engine's counter RNG inside the fused policy kernel (fused path only; the generic
         # path draws from the model's generator per step), "torch" = standard normals for the whole rollout drawn up front
@@ -537,6 +547,26 @@ class Runner(object):
             raise RuntimeError("noise_source='torch' would draw %.1f GB per rollout on every rank at world size %d: use the default "
                                "noise_source='kernel' for multi-GPU runs" % (np.prod(full) * 4 / 1e9, world))
         return torch.randn(full, device=self.obs.device, dtype=self.obs.dtype, generator=self._gen).narrow(env_axis, rank * n, n)
+
+    @torch.no_grad()
+    def _critic_pass(self, states0):
+        """The values of a rollout whose per-step part ran the actor alone (`rollout_one_launch_per_step` = 3): the critic stack over the
+        recorded observations [T, N, 35] from its state in front of the rollout, masks = the recorded dones (the state is cleared where an
+        episode ended before step t, run_bp_v5.py:143-176) -- the sequence kernels of the update, at CRITIC_PASS_PRECISION -- then the
+        value head; writes mb_values and the critic's half of the carried LSTM state."""
+        from . import lstm_fused
+        pol = self.model.policy
+        k = len(pol.n_lstm)
+        parts = pol._split(states0)
+        keep = lstm_fused.PRECISION
+        lstm_fused.PRECISION = CRITIC_PASS_PRECISION
+        try:
+            latent_v, new_v = pol._stack(pol.lstm_v, self.mb_obs, parts[k:], self.mb_dones.to(self.mb_obs.dtype))
+        finally:
+            lstm_fused.PRECISION = keep
+        self.mb_values.copy_(pol.vf(latent_v).squeeze(-1))
+        off = sum(2 * h for h in pol.n_lstm)
+        self.states[:, off:].copy_(torch.cat(new_v, 1))
 
     def _fused_step(self, t):
         """Rollout step t as two launches: the whole policy step (sample, clip, buffer rows incl. the previous reward) and
@@ -650,10 +680,22 @@ class Runner(object):
             if direct:
                 d = self.dones if self.dones.element_size() == 1 else None
                 assert d is not None
-                pol.fused_rollout(self.env.wrapper, self.n_steps, self.obs, self.states, d, (self.model.noise_seed, 0, self.rng_base, self.model.env_id_offset),
-                                  dict(row=0, mb_obs=self.mb_obs, mb_actions=self.mb_actions, mb_values=self.mb_values,
-                                       mb_neglogpacs=self.mb_neglogpacs, mb_dones=self.mb_dones, mb_rewards=self.mb_rewards),
-                                  self._out, self.rew, self.env.extra, noise_all=self.noise_all, fused=self.rollout_one_launch_per_step)
+                args = (self.env.wrapper, self.n_steps, self.obs, self.states, d, (self.model.noise_seed, 0, self.rng_base, self.model.env_id_offset),
+                        dict(row=0, mb_obs=self.mb_obs, mb_actions=self.mb_actions, mb_values=self.mb_values,
+                             mb_neglogpacs=self.mb_neglogpacs, mb_dones=self.mb_dones, mb_rewards=self.mb_rewards),
+                        self._out, self.rew, self.env.extra)
+                mode = self.rollout_one_launch_per_step
+                if mode == 3 and hasattr(pol, "lstm_v") and not getattr(self, "_actor_only_refused", False):
+                    try:
+                        pol.fused_rollout(*args, noise_all=self.noise_all, fused=3)
+                        self._critic_pass(mb_states)
+                    except RuntimeError as exc:      # the actor-only kernel is not instantiated for this pool / network: nothing was launched
+                        if "fuse = 3" not in str(exc):
+                            raise
+                        self._actor_only_refused = True
+                        pol.fused_rollout(*args, noise_all=self.noise_all, fused=2)
+                else:
+                    pol.fused_rollout(*args, noise_all=self.noise_all, fused=2 if mode == 3 else mode)
             elif self._graph is not None:
                 self._graph.replay()
             else:

@@ -280,6 +280,7 @@ int irrl_lstm_seq_backward_x(int hid, int T, int N, int n_in, const float *gates
  * n_in <= 48): every operand is split into nsplit bf16 planes (2: ~2^-16 relative product error, 3: ~2^-24, the f32 level) and a product is the
  * sum of the plane products above that weight (3 resp. 6 MFMAs); v_mfma_f32_16x16x32_bf16 covers 32 units of K in half the time the exact-f32
  * v_mfma_f32_16x16x4_f32 needs for 4.  Tensors, layouts and return codes as irrl_lstm_seq_forward_x / irrl_lstm_seq_backward_x. */
+/* (forward: gates == NULL and cseq == NULL selects the INFERENCE form -- only hseq and state_out are written: the critic pass behind an actor-only rollout) */
 int irrl_lstm_seq_forward_bf16(int nsplit, int hid, int T, int N, int n_in, const float *x, const float *wx_p, const float *b_p, const float *wh_p,
                                const float *masks, const float *state0, float *gates, float *cseq, float *hseq, float *state_out, void *hip_stream);
 int irrl_lstm_seq_backward_bf16(int nsplit, int hid, int T, int N, int n_in, const float *gates, const float *cseq, const float *hseq, const float *x,
@@ -317,7 +318,11 @@ int irrl_lstm_policy_step(int hid, int ob_dim, int act_dim, int N, const float *
  * the four env waves of 16 robots = one MFMA M-tile; 16-lane layout, hid 48, no Crutial; otherwise ignored) -- bit-identical
  * results, measured slower than the two-launch sequence on MI355X.  fuse == 2: the whole rollout as ONE persistent launch (a workgroup
  * loops over all `steps` for its 16 robots: no grid-wide boundary between steps; same conditions, otherwise the two-launch sequence) --
- * bit-identical results again. */
+ * bit-identical results again.  fuse == 3 (round 5): that persistent launch with the CRITIC OFF THE PER-STEP PATH -- V(s_t) depends on the observation
+ * history only and nothing in the rollout needs it before GAE, so the per-step part runs the actor stack alone (all of its operands resident in LDS) and
+ * writes everything EXCEPT `value` / `mb_values` and the critic's half of `states`, which the caller obtains for the whole rollout afterwards with the
+ * sequence kernels over the recorded observations (ppo2.Runner does); actor-side buffers bit-identical to the other modes; an error where the persistent
+ * kernel is not instantiated. */
 int irrl_lstm_rollout(irrl_env *env, int steps, int hid, int ob_dim, int act_dim, float *obs, uint8_t *dones, const float *states_in,
                       float *states_out, const float *const *lstm_w, const float *pi_w, const float *pi_b, const float *vf_w,
                       const float *vf_b, const float *logstd, const float *noise, int rng_on, unsigned rng_seed, long long rng_step,

@@ -136,6 +136,28 @@ def test_lstm_sequence_kernels_hold_their_error_bounds_at_the_training_shape(pre
         assert e <= (act_tol if name in ("h_seq", "state", "dx") else 1e-5), (prec, name, e)
 
 
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16x6"])
+def test_lstm_sequence_inference_form_equals_the_training_form(prec, monkeypatch):
+    """Under torch.no_grad() the bf16 forward sequence kernel runs in its inference form (no gates / c rows stored: the critic pass behind an
+    actor-only rollout, ppo2.Runner._critic_pass): h and the final state are bit-identical to the training form's."""
+    from high_speed_quadrupedal_locomotion_by_irrl_amd import lstm_fused
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import SBLstm
+    monkeypatch.setattr(lstm_fused, "PRECISION", prec)
+    dev = torch.device("cuda")
+    torch.manual_seed(5)
+    T, N, n_in, hid = 40, 80, 35, 48
+    layer = SBLstm(n_in, hid).to(dev)
+    x = torch.randn(T, N, n_in, device=dev)
+    state = torch.randn(N, 2 * hid, device=dev) * 0.5
+    masks = (torch.rand(T, N, device=dev) < 0.1).float()
+    SBLstm.use_fused = True
+    h_train, s_train = layer.sequence(x, state, masks)
+    with torch.no_grad():
+        h_inf, s_inf = layer.sequence(x, state, masks)
+    assert h_train.requires_grad and not h_inf.requires_grad
+    assert torch.equal(h_train.detach(), h_inf) and torch.equal(s_train.detach(), s_inf)
+
+
 def test_fused_lstm_policy_full_size_agrees_with_eager():
     """CustomLSTMPolicy.evaluate at the training shape (T=750 is covered by the PPO bench; here T=96 x 4096 envs)."""
     from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import CustomLSTMPolicy, SBLstm
@@ -691,21 +713,25 @@ def test_graph_capture_warmup_leaves_no_trace_and_setters_invalidate_the_graph()
     (a) the three warm-up steps in front of the hipGraph capture are undone (device snapshot of the env pool + the runner's
     tensors), i.e. the FIRST rollout of a graph runner starts from env.reset();
     (b) a setter that changes a by-value kernel argument after the capture (setSeed) is not silently ignored: the graph runner
-    re-captures; the direct runner reads the parameters at launch time anyway."""
+    re-captures; the direct runner reads the parameters at launch time anyway.
+    "persistent_actor" (round 5: the persistent launch with the critic OFF the per-step path -- the actor stack alone per step, the values of
+    the whole rollout from the critic's sequence kernels afterwards): everything the actor and the env produce -- observations, actions,
+    neglogp, rewards, dones -- is bit-identical to the other modes; values and returns agree at the f32 level (2e-5 of their scale)."""
     from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import CustomLSTMPolicy
     from high_speed_quadrupedal_locomotion_by_irrl_amd.ppo2 import PPO2, Runner
     out = {}
-    for mode in ("direct", "one_launch", "persistent", "graph", "eager"):
+    for mode in ("direct", "one_launch", "persistent", "persistent_actor", "graph", "eager"):
         env = _env(64 if mode != "persistent" else 64)
         model = PPO2(policy=CustomLSTMPolicy, env=env, n_steps=20, nminibatches=1, noptepochs=1, seed=9)
         runner = Runner(env, model, 20, 0.99, 0.998, use_graph=(mode != "eager"))
         assert runner.rollout_launch == "direct"      # what a Runner picks by itself for the LSTM policy on the HIP engine
-        runner.rollout_launch = "direct" if mode in ("direct", "one_launch", "persistent") else "graph"
+        runner.rollout_launch = "direct" if mode in ("direct", "one_launch", "persistent", "persistent_actor") else "graph"
         # 1: env.step k + policy step k + 1 in one kernel; 2: the whole rollout as ONE persistent launch (a workgroup loops over all
         # steps for its 16 robots, irrl_rollout_persistent_kernel_l16)
-        runner.rollout_one_launch_per_step = {"one_launch": 1, "persistent": 2}.get(mode, 0)
+        runner.rollout_one_launch_per_step = {"one_launch": 1, "persistent": 2, "persistent_actor": 3}.get(mode, 0)
         b1 = {k: v.clone() for k, v in runner.run().items() if torch.is_tensor(v)}
         assert (runner._graph is not None) == (mode == "graph")
+        assert not getattr(runner, "_actor_only_refused", False)
         env.wrapper.setSeed(77)                       # new noise / command streams from the next reset on
         b2 = {k: v.clone() for k, v in runner.run().items() if torch.is_tensor(v)}
         b3 = {k: v.clone() for k, v in runner.run().items() if torch.is_tensor(v)}
@@ -714,6 +740,16 @@ def test_graph_capture_warmup_leaves_no_trace_and_setters_invalidate_the_graph()
         for i in range(3):
             for k in ("obs", "actions", "values", "true_reward", "masks", "neglogpacs", "returns"):
                 assert torch.equal(out[mode][i][k], out["eager"][i][k]), (mode, i, k)
+    for i in range(3):
+        for k in ("obs", "actions", "true_reward", "masks", "neglogpacs", "states"):
+            assert torch.equal(out["persistent_actor"][i][k], out["eager"][i][k]) or k == "states", ("persistent_actor", i, k)
+        # the carried LSTM state: the actor's half bit-identical, the critic's half (from the sequence kernels) at the f32 level
+        sa, se = out["persistent_actor"][i]["states"], out["eager"][i]["states"]
+        assert torch.equal(sa[:, :192], se[:, :192])
+        assert float((sa[:, 192:] - se[:, 192:]).abs().max()) < 2e-5 * (1.0 + float(se[:, 192:].abs().max()))
+        for k in ("values", "returns"):
+            a, b = out["persistent_actor"][i][k], out["eager"][i][k]
+            assert float((a - b).abs().max()) < 2e-5 * (1.0 + float(b.abs().max())), ("persistent_actor", i, k, float((a - b).abs().max()))
     assert not torch.equal(out["graph"][1]["obs"], out["graph"][0]["obs"])
 
 
