@@ -271,7 +271,10 @@ lstm_seq_bwd_bf16_kernel(const LstmBwdBf16Args a) {
 #ifdef IRRL_LBF_DEPTH      /* A/B switch of tools/build_variants.py */
   constexpr int DEPTH = (NS == 2) ? IRRL_LBF_DEPTH : (NEED_DX ? 1 : 2);
 #else
-  constexpr int DEPTH = (NS == 2) ? 3 : (NEED_DX ? 1 : 2);    // steps of operand loads in flight (36 registers per step; NS 3 has fewer to spare)
+#ifndef IRRL_LBF_DEPTH_X6
+#define IRRL_LBF_DEPTH_X6 (NEED_DX ? 1 : 2)
+#endif
+  constexpr int DEPTH = (NS == 2) ? 3 : IRRL_LBF_DEPTH_X6;    // steps of operand loads in flight (36 registers per step; NS 3 has fewer to spare)
 #endif
   using PR = BfProducts<NS>;
   extern __shared__ __attribute__((aligned(16))) unsigned short lds_b[];
@@ -289,7 +292,10 @@ lstm_seq_bwd_bf16_kernel(const LstmBwdBf16Args a) {
 #ifdef IRRL_LBF_MAIN_TILES      /* A/B switch of tools/build_variants.py: gate-column tiles per main wave (3 = 18 accumulator tiles per wave, the even split) */
   constexpr int MAIN_CI = IRRL_LBF_MAIN_TILES;
 #else
-  constexpr int MAIN_CI = 2;
+  // two planes: 2 tiles per main wave (12 accumulator tiles; shared out evenly the main waves' chain got longer: +1-1.5 % per update, round 4);
+  // three planes (six products per tile: wave 3's 216 MFMAs per step were the longest chain): 3 each -- 138.1 -> 134.0 ms per update, same box
+  // (round 5, profiles/r05_ab_lstm_bwd_x6_tile_split_same_box.log)
+  constexpr int MAIN_CI = (NS == 3) ? 3 : 2;
 #endif
   constexpr int HELP_PARTS = (12 - 3 * MAIN_CI) / 3;     // the helper wave's tiles in parts of three
   // The 72 weight-gradient tiles (12 gate-column tiles x 6 M-tiles): waves 0-2, which also carry the gate arithmetic and the recurrence, own
