@@ -474,465 +474,3 @@ lstm_seq_bwd_bf16_kernel(const LstmBwdBf16Args a) {
 #pragma unroll
   for (int g = 0; g < 4; g++) a.db_part[(blk * 4 + rq) * GC + u * 4 + g] = dbacc[g];
 }
-
-// ---- backward, EIGHT waves per workgroup (round 5) ---------------------------------------------------------------------------------------
-// The four-wave kernel above is bound by two serial chains per step that are both as long as the step (waves 0-2: operands -> gate arithmetic
-// -> dz -> barrier -> recurrence MFMAs -> dh, with 36-54 weight-gradient / dx MFMAs of their own in between; wave 3: rows -> split -> LDS ->
-// barrier -> 108 MFMAs), at 491 registers = one wave per SIMD.  Here the recurrence chain is ALL that waves 0-2 do; everything that only
-// CONSUMES dz lives on five more waves of the same workgroup, two waves per SIMD at <= 256 registers each:
-//   waves 0-2  gate arithmetic -> dz tile, (h_{t-1} keep)^T tile, barrier, 18 recurrence MFMAs (K = 192 gate columns), dh for their 16 units
-//   wave 3     dx = dz Wx^T for all 48 input columns (54 MFMAs; the Wx fragments of the three column tiles in its registers); without dx it
-//              stages x_t^T instead of wave 4
-//   waves 4-7  the 72 weight-gradient tiles: gate-column tiles 3 h .. 3 h + 2 against all six M-tiles each (54 MFMAs); wave 4 stages x_t^T
-// Same tiles, same plane products in the same order per accumulator as the four-wave kernel: dz, dx and every partial sum are bit-identical to it.
-// LDS: the two step buffers of the four-wave kernel + the split recurrent weights wh [plane][unit 48][gate column, padded row] (the B operand
-// of the recurrence, read by waves 0-2 every step: 48 registers less on the waves whose 256 have to hold three steps of operands in flight)
-template <int NS> constexpr int lstm_bwd8_bf16_lds_bytes() { return lstm_bwd_bf16_lds_bytes<NS>() + NS * LBF_HID * LBF_RROW * 2; }
-template <int NS> constexpr int lstm_bwd62_bf16_lds_bytes() { return lstm_bwd8_bf16_lds_bytes<NS>() + NS * LBF_KX * LBF_RROW * 2; }   // + the input weights (dx)
-template <int NS, bool NEED_DX>
-__global__ void __launch_bounds__(512)
-lstm_seq_bwd8_bf16_kernel(const LstmBwdBf16Args a) {
-  constexpr int HID = LBF_HID, GC = LBF_GC, KX = LBF_KX, KC = GC / 32;
-#ifndef IRRL_LBF8_DEPTH      /* A/B switch of tools/build_variants.py */
-#define IRRL_LBF8_DEPTH 3
-#endif
-  constexpr int DEPTH = IRRL_LBF8_DEPTH;      // steps of the main waves' operand loads in flight (36 registers each)
-  using PR = BfProducts<NS>;
-  extern __shared__ __attribute__((aligned(16))) unsigned short lds_b[];
-  constexpr int PER_BUF = lstm_bwd_bf16_lds_elems_per_buf<NS>();
-  constexpr int OFF_H = NS * 16 * LBF_RROW, OFF_X = OFF_H + NS * HID * LBF_CROW;
-  auto Zr = [&](int buf, int p, int env, int c) -> unsigned short * { return lds_b + (size_t)buf * PER_BUF + ((size_t)p * 16 + env) * LBF_RROW + c; };
-  auto Ht = [&](int buf, int p, int k, int env) -> unsigned short * { return lds_b + (size_t)buf * PER_BUF + OFF_H + ((size_t)p * HID + k) * LBF_CROW + env; };
-  auto Xt = [&](int buf, int p, int i, int env) -> unsigned short * { return lds_b + (size_t)buf * PER_BUF + OFF_X + ((size_t)p * KX + i) * LBF_CROW + env; };
-  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-  const int col = l & 15, rq = l >> 4;
-  const int e0 = blockIdx.x * 16;
-  const int T = a.T, N = a.N, n_in = a.n_in;
-  const int x_wave = NEED_DX ? 4 : 3;      // who stages x_t^T
-  // the recurrent weights as bf16 planes in LDS: Wl(plane, unit, gate column); written once by all 512 lanes
-  unsigned short *const wl_base = lds_b + 2 * (size_t)PER_BUF;
-  auto Wl = [&](int p, int unit, int c) -> unsigned short * { return wl_base + ((size_t)p * HID + unit) * LBF_RROW + c; };
-  for (int i = tid; i < HID * GC; i += 512) {
-    const int unit = i / GC, c = i % GC;
-    unsigned short pl[NS];
-    bf_split<NS>(a.wh_p[(size_t)unit * GC + c], pl);
-#pragma unroll
-    for (int p = 0; p < NS; p++) *Wl(p, unit, c) = pl[p];
-  }
-  __syncthreads();
-  if (w >= 3) {
-    // ---------------- the consumers of dz ----------------
-    const bool stages_x = w == x_wave;
-    constexpr int HD = 4;                   // x row sets in flight (the staging wave only)
-    float xr[HD][12];
-    auto load_x = [&](int t, float (&dst)[12]) {
-#pragma unroll
-      for (int r = 0; r < 12; r++) {
-        const int idx = 64 * r + l, env = idx / KX, i = idx % KX;
-        dst[r] = a.x[((size_t)t * N + e0 + env) * n_in + (i < n_in ? i : n_in - 1)];
-      }
-    };
-    auto stage_x = [&](int buf, const float (&src)[12]) {
-#pragma unroll
-      for (int r = 0; r < 12; r++) {
-        const int idx = 64 * r + l, env = idx / KX, i = idx % KX;
-        unsigned short pl[NS];
-        bf_split<NS>(i < n_in ? src[r] : 0.0f, pl);
-#pragma unroll
-        for (int p = 0; p < NS; p++) *Xt(buf, p, i, env) = pl[p];
-      }
-    };
-    if (NEED_DX && w == 3) {
-      // ---- wave 3: dx[env][input i = 16 j + col] = sum_c dz[env][c] wx[i][c] for the three column tiles j ----
-      u16x8_t Bx[3][KC][NS];
-#pragma unroll
-      for (int j = 0; j < 3; j++)
-#pragma unroll
-        for (int kc = 0; kc < KC; kc++)
-#pragma unroll
-          for (int i = 0; i < 8; i++) {
-            const int cidx = 32 * kc + 8 * rq + i, u = 16 * j + col;
-            unsigned short pl[NS];
-            bf_split<NS>((u < n_in) ? a.wx_p[(size_t)u * GC + cidx] : 0.0f, pl);
-#pragma unroll
-            for (int p = 0; p < NS; p++) Bx[j][kc][p][i] = pl[p];
-          }
-      for (int t = T - 1; t >= 0; t--) {
-        const int buf = t & 1;
-        __syncthreads();      // dz_t is visible
-        u16x8_t av[KC][NS];
-#pragma unroll
-        for (int kc = 0; kc < KC; kc++)
-#pragma unroll
-          for (int p = 0; p < NS; p++) av[kc][p] = *(const u16x8_t *)Zr(buf, p, col, 32 * kc + 8 * rq);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-          f32x4 accx = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-          for (int q = 0; q < PR::N; q++)
-#pragma unroll
-            for (int kc = 0; kc < KC; kc++) accx = BF_MFMA32(av[kc][PR::A[q]], Bx[j][kc][PR::B[q]], accx);
-          const int u = 16 * j + col;
-          if (u < n_in) {
-#pragma unroll
-            for (int jj = 0; jj < 4; jj++) a.dx[((size_t)t * N + e0 + 4 * rq + jj) * n_in + u] = accx[jj];
-          }
-        }
-      }
-      return;
-    }
-    if (w == 3) {
-      // ---- wave 3 without dx: stages x_t^T (HD steps ahead), no products ----
-#pragma unroll
-      for (int d = 0; d < HD; d++)
-        if (T - 1 - d >= 0) load_x(T - 1 - d, xr[d]);
-      for (int t = T - 1; t >= 0; t -= HD) {
-#pragma unroll
-        for (int d = 0; d < HD; d++) {
-          const int tt = t - d;
-          if (tt < 0) break;
-          stage_x(tt & 1, xr[d]);
-          if (tt - HD >= 0) load_x(tt - HD, xr[d]);
-          __syncthreads();
-        }
-      }
-      return;
-    }
-    // ---- waves 4-7: weight-gradient tiles 3 h .. 3 h + 2 (x all six M-tiles); wave 4 stages x_t^T when wave 3 computes dx ----
-    const int hh = w - 4;
-    f32x4 accH[6][3];
-#pragma unroll
-    for (int mt = 0; mt < 6; mt++)
-#pragma unroll
-      for (int ci = 0; ci < 3; ci++) accH[mt][ci] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-    if (stages_x) {
-#pragma unroll
-      for (int d = 0; d < HD; d++)
-        if (T - 1 - d >= 0) load_x(T - 1 - d, xr[d]);
-    }
-    for (int t = T - 1; t >= 0; t -= HD) {
-#pragma unroll
-      for (int d = 0; d < HD; d++) {
-        const int tt = t - d;
-        if (tt < 0) break;
-        if (stages_x) {
-          stage_x(tt & 1, xr[d]);
-          if (tt - HD >= 0) load_x(tt - HD, xr[d]);
-        }
-        __syncthreads();
-        lbf_weight_grads<NS, 3>(accH, lds_b + (size_t)(tt & 1) * PER_BUF, 3 * hh, col, rq);
-      }
-    }
-    lbf_store_weight_grads<3>(accH, a, 3 * hh, col, rq);
-    return;
-  }
-  // ---------------- waves 0-2: the recurrence chain ----------------
-  const int u = 16 * w + col;
-  float dbacc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  float dc[4] = {0.0f, 0.0f, 0.0f, 0.0f}, dhrec[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  struct StepOps { f32x4 g[4]; float ct[4], cp[4], dh[4], mk[4], hp[4]; };
-  auto fetch = [&](int t, StepOps &o) {
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int e = e0 + 4 * rq + j;
-      const size_t row = (size_t)t * N + e;
-      o.mk[j] = a.masks[row];
-      o.g[j] = *(const f32x4 *)&a.gates[(row * HID + u) * 4];
-      o.ct[j] = a.cseq[row * HID + u];
-      o.cp[j] = (t > 0) ? a.cseq[(row - N) * HID + u] : a.state0[(size_t)e * 2 * HID + u];
-      o.hp[j] = (t > 0) ? a.hseq[(row - N) * HID + u] : a.state0[(size_t)e * 2 * HID + HID + u];
-      o.dh[j] = a.dh_in[row * HID + u];
-    }
-  };
-  auto step = [&](int t, StepOps &o) {
-    const int buf = t & 1;
-    float keepC[4], ct[4], cpv[4], dhv[4], hpv[4];
-    f32x4 g4[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) { keepC[j] = 1.0f - o.mk[j]; g4[j] = o.g[j]; ct[j] = o.ct[j]; cpv[j] = o.cp[j]; dhv[j] = o.dh[j]; hpv[j] = o.hp[j] * keepC[j]; }
-    if (t - DEPTH >= 0) fetch(t - DEPTH, o);
-    {
-      u16x4_t pk[NS];
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        unsigned short pl[NS];
-        bf_split<NS>(hpv[j], pl);
-#pragma unroll
-        for (int p = 0; p < NS; p++) pk[p][j] = pl[p];
-      }
-#pragma unroll
-      for (int p = 0; p < NS; p++) *(u16x4_t *)Ht(buf, p, u, 4 * rq) = pk[p];
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const float cprev = cpv[j] * keepC[j];
-      const float dh = dhv[j] + dhrec[j];
-      const float ig = g4[j][0], fg = g4[j][1], og = g4[j][2], gg = g4[j][3];
-      const float tc = fast_tanh(ct[j]);
-      const float d_o = dh * tc;
-      const float dct = dc[j] + dh * og * (1.0f - tc * tc);
-      const float d_i = dct * gg, d_g = dct * ig, d_f = dct * cprev;
-      dc[j] = dct * fg * keepC[j];
-      const float dz4[4] = {d_i * ig * (1.0f - ig), d_f * fg * (1.0f - fg), d_o * og * (1.0f - og), d_g * (1.0f - gg * gg)};
-      u16x4_t zr[NS];
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        dbacc[g] += dz4[g];
-        unsigned short pl[NS];
-        bf_split<NS>(dz4[g], pl);
-#pragma unroll
-        for (int p = 0; p < NS; p++) zr[p][g] = pl[p];
-      }
-#pragma unroll
-      for (int p = 0; p < NS; p++) *(u16x4_t *)Zr(buf, p, 4 * rq + j, 4 * u) = zr[p];
-    }
-    __syncthreads();      // dz_t, (h_{t-1} keep_t)^T and x_t^T are visible to all eight waves
-    u16x8_t av[KC][NS];
-#pragma unroll
-    for (int kc = 0; kc < KC; kc++)
-#pragma unroll
-      for (int p = 0; p < NS; p++) av[kc][p] = *(const u16x8_t *)Zr(buf, p, col, 32 * kc + 8 * rq);
-    __builtin_amdgcn_sched_barrier(0);
-    // B fragments over K = gate column c = 32 kc + 8 rq + i: dh_prev[env][hidden k' = u] = sum_c dz[env][c] wh[k'][c], out of the LDS planes
-    u16x8_t bh[KC][NS];
-#pragma unroll
-    for (int kc = 0; kc < KC; kc++)
-#pragma unroll
-      for (int p = 0; p < NS; p++) bh[kc][p] = *(const u16x8_t *)Wl(p, u, 32 * kc + 8 * rq);
-    f32x4 acc = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int q = 0; q < PR::N; q++)
-#pragma unroll
-      for (int kc = 0; kc < KC; kc++) acc = BF_MFMA32(av[kc][PR::A[q]], bh[kc][PR::B[q]], acc);
-#pragma unroll
-    for (int j = 0; j < 4; j++) dhrec[j] = acc[j] * keepC[j];
-  };
-  StepOps ops[DEPTH];
-#pragma unroll
-  for (int d = 0; d < DEPTH; d++)
-    if (T - 1 - d >= 0) fetch(T - 1 - d, ops[d]);
-  for (int t = T - 1; t >= 0; t -= DEPTH) {
-#pragma unroll
-    for (int d = 0; d < DEPTH; d++)
-      if (t - d >= 0) step(t - d, ops[d]);
-  }
-  const size_t blk = blockIdx.x;
-#pragma unroll
-  for (int g = 0; g < 4; g++) a.db_part[(blk * 4 + rq) * GC + u * 4 + g] = dbacc[g];
-}
-
-// ---- backward, SIX half-main waves + TWO weight-gradient waves (round 5, second attempt) -------------------------------------------------
-// What the eight-wave kernel above taught (same time as the four-wave one): shedding the consumers' MFMAs from waves 0-2 buys nothing -- those
-// MFMAs ran under the next step's gate arithmetic anyway; a main wave's step is ~550 VALU instructions of gate arithmetic, bf16 splits and
-// tile writes for its 4 x 64 (env, unit) elements, issued by ONE wave on its SIMD.  Here that work is halved per wave: the (env, unit) elements
-// of unit tile w are shared by TWO waves (half h takes envs 4 rq + 2 h, 4 rq + 2 h + 1 of every quarter), both run the tile's 18 recurrence
-// MFMAs (duplicated: 0.13 us) and keep their own envs' rows of the result; half 0 also forms the dx tile.  Of the 72 weight-gradient tiles
-// every half-main wave takes one gate-column tile (6 accumulator tiles), the two remaining waves three each (18); wave 6 stages x_t^T.
-// Eight waves, two per SIMD, <= 256 registers.
-template <int NS, bool NEED_DX>
-__global__ void __launch_bounds__(512)
-lstm_seq_bwd62_bf16_kernel(const LstmBwdBf16Args a) {
-  constexpr int HID = LBF_HID, GC = LBF_GC, KX = LBF_KX, KC = GC / 32;
-#ifndef IRRL_LBF62_DEPTH      /* A/B switch of tools/build_variants.py */
-#define IRRL_LBF62_DEPTH 3
-#endif
-  constexpr int DEPTH = IRRL_LBF62_DEPTH;      // steps of a half-main wave's operand loads in flight (18 registers each)
-  using PR = BfProducts<NS>;
-  extern __shared__ __attribute__((aligned(16))) unsigned short lds_b[];
-  constexpr int PER_BUF = lstm_bwd_bf16_lds_elems_per_buf<NS>();
-  constexpr int OFF_H = NS * 16 * LBF_RROW, OFF_X = OFF_H + NS * HID * LBF_CROW;
-  auto Zr = [&](int buf, int p, int env, int c) -> unsigned short * { return lds_b + (size_t)buf * PER_BUF + ((size_t)p * 16 + env) * LBF_RROW + c; };
-  auto Ht = [&](int buf, int p, int k, int env) -> unsigned short * { return lds_b + (size_t)buf * PER_BUF + OFF_H + ((size_t)p * HID + k) * LBF_CROW + env; };
-  auto Xt = [&](int buf, int p, int i, int env) -> unsigned short * { return lds_b + (size_t)buf * PER_BUF + OFF_X + ((size_t)p * KX + i) * LBF_CROW + env; };
-  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-  const int col = l & 15, rq = l >> 4;
-  const int e0 = blockIdx.x * 16;
-  const int T = a.T, N = a.N, n_in = a.n_in;
-  unsigned short *const wl_base = lds_b + 2 * (size_t)PER_BUF;
-  auto Wl = [&](int p, int unit, int c) -> unsigned short * { return wl_base + ((size_t)p * HID + unit) * LBF_RROW + c; };
-  // (with dx: the split input weights wx behind them, same layout -- the B operand of the dx tiles)
-  auto Wxl = [&](int p, int row, int c) -> unsigned short * { return wl_base + (size_t)NS * HID * LBF_RROW + ((size_t)p * KX + row) * LBF_RROW + c; };
-  for (int i = tid; i < HID * GC; i += 512) {
-    const int unit = i / GC, c = i % GC;
-    unsigned short pl[NS];
-    bf_split<NS>(a.wh_p[(size_t)unit * GC + c], pl);
-#pragma unroll
-    for (int p = 0; p < NS; p++) *Wl(p, unit, c) = pl[p];
-    if (NEED_DX) {
-      bf_split<NS>((unit < n_in) ? a.wx_p[(size_t)unit * GC + c] : 0.0f, pl);
-#pragma unroll
-      for (int p = 0; p < NS; p++) *Wxl(p, unit, c) = pl[p];
-    }
-  }
-  __syncthreads();
-  if (w >= 6) {
-    // ---- waves 6, 7: weight-gradient tiles 6 + 3 hh .. 8 + 3 hh (x all six M-tiles; tiles 0-5: one per half-main wave); wave 6 stages x_t^T ----
-    const int hh = w - 6;
-    const bool stages_x = hh == 0;
-    constexpr int HD = 4;
-    float xr[HD][12];
-    auto load_x = [&](int t, float (&dst)[12]) {
-#pragma unroll
-      for (int r = 0; r < 12; r++) {
-        const int idx = 64 * r + l, env = idx / KX, i = idx % KX;
-        dst[r] = a.x[((size_t)t * N + e0 + env) * n_in + (i < n_in ? i : n_in - 1)];
-      }
-    };
-    auto stage_x = [&](int buf, const float (&src)[12]) {
-#pragma unroll
-      for (int r = 0; r < 12; r++) {
-        const int idx = 64 * r + l, env = idx / KX, i = idx % KX;
-        unsigned short pl[NS];
-        bf_split<NS>(i < n_in ? src[r] : 0.0f, pl);
-#pragma unroll
-        for (int p = 0; p < NS; p++) *Xt(buf, p, i, env) = pl[p];
-      }
-    };
-    f32x4 accH[6][3];
-#pragma unroll
-    for (int mt = 0; mt < 6; mt++)
-#pragma unroll
-      for (int ci = 0; ci < 3; ci++) accH[mt][ci] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-    if (stages_x) {
-#pragma unroll
-      for (int d = 0; d < HD; d++)
-        if (T - 1 - d >= 0) load_x(T - 1 - d, xr[d]);
-    }
-    for (int t = T - 1; t >= 0; t -= HD) {
-#pragma unroll
-      for (int d = 0; d < HD; d++) {
-        const int tt = t - d;
-        if (tt < 0) break;
-        if (stages_x) {
-          stage_x(tt & 1, xr[d]);
-          if (tt - HD >= 0) load_x(tt - HD, xr[d]);
-        }
-        __syncthreads();
-        lbf_weight_grads<NS, 3>(accH, lds_b + (size_t)(tt & 1) * PER_BUF, 6 + 3 * hh, col, rq);
-      }
-    }
-    lbf_store_weight_grads<3>(accH, a, 6 + 3 * hh, col, rq);
-    __syncthreads();      // (the two barriers of the main waves' epilogue below)
-    __syncthreads();
-    return;
-  }
-  // ---- waves 0-5: wave = (unit tile wt = w >> 1, half = w & 1) ----
-  const int wt = w >> 1, half = w & 1;
-  const int u = 16 * wt + col;
-  const int j0 = 2 * half;                    // this wave's envs of every quarter: 4 rq + j0, 4 rq + j0 + 1
-  float dbacc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  float dc[2] = {0.0f, 0.0f}, dhrec[2] = {0.0f, 0.0f};
-  f32x4 accW[6][1];      // this wave's weight-gradient tile: gate-column tile w against the six M-tiles
-#pragma unroll
-  for (int mt = 0; mt < 6; mt++) accW[mt][0] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-  struct StepOps { f32x4 g[2]; float ct[2], cp[2], dh[2], mk[2], hp[2]; };
-  auto fetch = [&](int t, StepOps &o) {
-#pragma unroll
-    for (int jj = 0; jj < 2; jj++) {
-      const int e = e0 + 4 * rq + j0 + jj;
-      const size_t row = (size_t)t * N + e;
-      o.mk[jj] = a.masks[row];
-      o.g[jj] = *(const f32x4 *)&a.gates[(row * HID + u) * 4];
-      o.ct[jj] = a.cseq[row * HID + u];
-      o.cp[jj] = (t > 0) ? a.cseq[(row - N) * HID + u] : a.state0[(size_t)e * 2 * HID + u];
-      o.hp[jj] = (t > 0) ? a.hseq[(row - N) * HID + u] : a.state0[(size_t)e * 2 * HID + HID + u];
-      o.dh[jj] = a.dh_in[row * HID + u];
-    }
-  };
-  auto step = [&](int t, StepOps &o) {
-    const int buf = t & 1;
-    float keepC[2], ct[2], cpv[2], dhv[2], hpv[2];
-    f32x4 g4[2];
-#pragma unroll
-    for (int jj = 0; jj < 2; jj++) { keepC[jj] = 1.0f - o.mk[jj]; g4[jj] = o.g[jj]; ct[jj] = o.ct[jj]; cpv[jj] = o.cp[jj]; dhv[jj] = o.dh[jj]; hpv[jj] = o.hp[jj] * keepC[jj]; }
-    if (t - DEPTH >= 0) fetch(t - DEPTH, o);
-    {
-      // (h_{t-1} keep_t)^T: this wave's two envs of unit u, 4 bytes per plane
-      unsigned short pa[NS], pb[NS];
-      bf_split<NS>(hpv[0], pa);
-      bf_split<NS>(hpv[1], pb);
-#pragma unroll
-      for (int p = 0; p < NS; p++) *(unsigned *)Ht(buf, p, u, 4 * rq + j0) = (unsigned)pa[p] | ((unsigned)pb[p] << 16);
-    }
-#pragma unroll
-    for (int jj = 0; jj < 2; jj++) {
-      const float cprev = cpv[jj] * keepC[jj];
-      const float dh = dhv[jj] + dhrec[jj];
-      const float ig = g4[jj][0], fg = g4[jj][1], og = g4[jj][2], gg = g4[jj][3];
-      const float tc = fast_tanh(ct[jj]);
-      const float d_o = dh * tc;
-      const float dct = dc[jj] + dh * og * (1.0f - tc * tc);
-      const float d_i = dct * gg, d_g = dct * ig, d_f = dct * cprev;
-      dc[jj] = dct * fg * keepC[jj];
-      const float dz4[4] = {d_i * ig * (1.0f - ig), d_f * fg * (1.0f - fg), d_o * og * (1.0f - og), d_g * (1.0f - gg * gg)};
-      u16x4_t zr[NS];
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        dbacc[g] += dz4[g];
-        unsigned short pl[NS];
-        bf_split<NS>(dz4[g], pl);
-#pragma unroll
-        for (int p = 0; p < NS; p++) zr[p][g] = pl[p];
-      }
-#pragma unroll
-      for (int p = 0; p < NS; p++) *(u16x4_t *)Zr(buf, p, 4 * rq + j0 + jj, 4 * u) = zr[p];
-    }
-    __syncthreads();      // dz_t, (h_{t-1} keep_t)^T and x_t^T are visible to all eight waves
-    u16x8_t av[KC][NS], bh[KC][NS];
-#pragma unroll
-    for (int kc = 0; kc < KC; kc++)
-#pragma unroll
-      for (int p = 0; p < NS; p++) {
-        av[kc][p] = *(const u16x8_t *)Zr(buf, p, col, 32 * kc + 8 * rq);
-        bh[kc][p] = *(const u16x8_t *)Wl(p, u, 32 * kc + 8 * rq);
-      }
-    __builtin_amdgcn_sched_barrier(0);
-    f32x4 acc = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}, accx = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int q = 0; q < PR::N; q++)
-#pragma unroll
-      for (int kc = 0; kc < KC; kc++) acc = BF_MFMA32(av[kc][PR::A[q]], bh[kc][PR::B[q]], acc);
-    dhrec[0] = acc[j0] * keepC[0];
-    dhrec[1] = acc[j0 + 1] * keepC[1];
-    if (NEED_DX && half == 0) {
-      u16x8_t bx[KC][NS];
-#pragma unroll
-      for (int kc = 0; kc < KC; kc++)
-#pragma unroll
-        for (int p = 0; p < NS; p++) bx[kc][p] = *(const u16x8_t *)Wxl(p, u, 32 * kc + 8 * rq);
-#pragma unroll
-      for (int q = 0; q < PR::N; q++)
-#pragma unroll
-        for (int kc = 0; kc < KC; kc++) accx = BF_MFMA32(av[kc][PR::A[q]], bx[kc][PR::B[q]], accx);
-      if (u < n_in) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) a.dx[((size_t)t * N + e0 + 4 * rq + j) * n_in + u] = accx[j];
-      }
-    }
-    lbf_weight_grads<NS, 1>(accW, lds_b + (size_t)buf * PER_BUF, w, col, rq);
-  };
-  StepOps ops[DEPTH];
-#pragma unroll
-  for (int d = 0; d < DEPTH; d++)
-    if (T - 1 - d >= 0) fetch(T - 1 - d, ops[d]);
-  for (int t = T - 1; t >= 0; t -= DEPTH) {
-#pragma unroll
-    for (int d = 0; d < DEPTH; d++)
-      if (t - d >= 0) step(t - d, ops[d]);
-  }
-  lbf_store_weight_grads<1>(accW, a, w, col, rq);
-  // the two halves' bias-gradient sums of (rq, unit, gate) are added here, half 1 through LDS (the step buffers are free now)
-  float *dbx = (float *)lds_b;
-  __syncthreads();
-  if (half == 1) {
-#pragma unroll
-    for (int g = 0; g < 4; g++) dbx[((wt * 4 + rq) * 16 + col) * 4 + g] = dbacc[g];
-  }
-  __syncthreads();
-  if (half == 0) {
-    const size_t blk = blockIdx.x;
-#pragma unroll
-    for (int g = 0; g < 4; g++) a.db_part[(blk * 4 + rq) * GC + u * 4 + g] = dbacc[g] + dbx[((wt * 4 + rq) * 16 + col) * 4 + g];
-  }
-}

@@ -1331,36 +1331,6 @@ int irrl_lstm_seq_backward_bf16(int nsplit, int hid, int T, int N, int n_in, con
               lstm_bf16_allow_lds((const void *)lstm_seq_bwd_bf16_kernel<3, false>, lstm_bwd_bf16_lds_bytes<3>());
   }
   if (allowed != 0) return 2;
-  // the eight-wave form (lstm_seq_bwd8_bf16_kernel: the recurrence chain alone on waves 0-2, dx and the weight gradients on five more waves of
-  // the workgroup); IRRL_LSTM_BWD8=0 selects the four-wave kernel of round 4 (same results bit for bit)
-  static const int use8 = [] { const char *e = getenv("IRRL_LSTM_BWD8"); return e ? atoi(e) : 0; }();      // 0: four waves (round 4), 1: 3 + 5, 2: 6 half-mains + 2
-  if (use8) {
-    static int allowed8_on[IRRL_MAX_DEVICES];
-    static bool allowed8_init = false;
-    if (!allowed8_init) { for (int i = 0; i < IRRL_MAX_DEVICES; i++) allowed8_on[i] = -1; allowed8_init = true; }
-    int &allowed8 = allowed8_on[dev_];
-    if (allowed8 < 0) {
-      allowed8 = lstm_bf16_allow_lds((const void *)lstm_seq_bwd8_bf16_kernel<2, true>, lstm_bwd8_bf16_lds_bytes<2>()) |
-                 lstm_bf16_allow_lds((const void *)lstm_seq_bwd8_bf16_kernel<2, false>, lstm_bwd8_bf16_lds_bytes<2>()) |
-                 lstm_bf16_allow_lds((const void *)lstm_seq_bwd62_bf16_kernel<2, true>, lstm_bwd62_bf16_lds_bytes<2>()) |
-                 lstm_bf16_allow_lds((const void *)lstm_seq_bwd62_bf16_kernel<2, false>, lstm_bwd62_bf16_lds_bytes<2>());
-    }
-    if (allowed8 != 0) return 2;
-  }
-  if (use8 == 2 && nsplit == 2) {
-#define IRRL_BB62(D) hipLaunchKernelGGL((lstm_seq_bwd62_bf16_kernel<2, D>), dim3(N / 16), dim3(512), lstm_bwd62_bf16_lds_bytes<2>(), s, a)
-    if (dx) IRRL_BB62(true);
-    else IRRL_BB62(false);
-#undef IRRL_BB62
-    return hipGetLastError() == hipSuccess ? 0 : 2;
-  }
-  if (use8 && nsplit == 2) {      // (three planes: the dx wave's Wx fragments alone are 216 registers -- the four-wave kernel)
-#define IRRL_BB8(D) hipLaunchKernelGGL((lstm_seq_bwd8_bf16_kernel<2, D>), dim3(N / 16), dim3(512), lstm_bwd8_bf16_lds_bytes<2>(), s, a)
-    if (dx) IRRL_BB8(true);
-    else IRRL_BB8(false);
-#undef IRRL_BB8
-    return hipGetLastError() == hipSuccess ? 0 : 2;
-  }
 #define IRRL_BB(NS, D) hipLaunchKernelGGL((lstm_seq_bwd_bf16_kernel<NS, D>), dim3(N / 16), dim3(256), lstm_bwd_bf16_lds_bytes<NS>(), s, a)
   if (nsplit == 2 && dx) IRRL_BB(2, true);
   else if (nsplit == 2) IRRL_BB(2, false);
