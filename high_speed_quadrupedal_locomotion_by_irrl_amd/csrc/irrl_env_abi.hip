@@ -10,6 +10,7 @@
 #include "lstm_kernels.hip"
 #include "mlp_update.hpp"
 #include "mlp_bf16.hpp"
+#include "mlp_bf16_pc.hpp"
 #include "ppo_optim.hpp"
 
 // The env kernels are compiled in two lane layouts from the same source (csrc/env_kernels.hip, see build.py):
@@ -871,14 +872,30 @@ static int mlp_bf16_launch(const char *who, int kind, bool use_rec, size_t n, in
   if (allowed < 0) {   // the weight planes and the waves' images exceed the 64 KB a kernel gets without asking (gfx950 has 160 KB per CU)
     const void *ks[4] = {(const void *)irrl_mlp_ppo_bf16_kernel<0, false>, (const void *)irrl_mlp_ppo_bf16_kernel<1, false>,
                          (const void *)irrl_mlp_ppo_bf16_kernel<0, true>, (const void *)irrl_mlp_ppo_bf16_kernel<1, true>};
+    const void *kp[4] = {(const void *)irrl_mlp_ppo_bf16_pc_kernel<0, false>, (const void *)irrl_mlp_ppo_bf16_pc_kernel<1, false>,
+                         (const void *)irrl_mlp_ppo_bf16_pc_kernel<0, true>, (const void *)irrl_mlp_ppo_bf16_pc_kernel<1, true>};
     allowed = 0;
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 4; i++) {
       if (hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, mlp_bf16_lds_bytes()) != hipSuccess) allowed = 1;
+      if (hipFuncSetAttribute(kp[i], hipFuncAttributeMaxDynamicSharedMemorySize, mlp_bf16_pc_lds_bytes()) != hipSuccess) allowed = 1;
+    }
   }
   if (allowed != 0) { g_err = std::string(who) + ": the device refused the kernel's LDS size"; return 1; }
-  const dim3 grid((unsigned)n_blocks), block(256);
+  // IRRL_MLP_WAVES=4: the one-wave-per-SIMD kernel of mlp_bf16.hpp; default: producer / consumer wave pairs (mlp_bf16_pc.hpp) -- same partial rows, bit for bit
+  // (read per call: the parity test runs both kernels in one process)
+  const char *waves_env = getenv("IRRL_MLP_WAVES");
+  const bool pairs = !(waves_env && waves_env[0] == '4');
+  const dim3 grid((unsigned)n_blocks), block(pairs ? 512 : 256);
   hipStream_t st = (hipStream_t)hip_stream;
-  if (use_rec) {
+  if (pairs) {
+    if (use_rec) {
+      if (kind == 0) hipLaunchKernelGGL((irrl_mlp_ppo_bf16_pc_kernel<0, true>), grid, block, mlp_bf16_pc_lds_bytes(), st, a);
+      else hipLaunchKernelGGL((irrl_mlp_ppo_bf16_pc_kernel<1, true>), grid, block, mlp_bf16_pc_lds_bytes(), st, a);
+    } else {
+      if (kind == 0) hipLaunchKernelGGL((irrl_mlp_ppo_bf16_pc_kernel<0, false>), grid, block, mlp_bf16_pc_lds_bytes(), st, a);
+      else hipLaunchKernelGGL((irrl_mlp_ppo_bf16_pc_kernel<1, false>), grid, block, mlp_bf16_pc_lds_bytes(), st, a);
+    }
+  } else if (use_rec) {
     if (kind == 0) hipLaunchKernelGGL((irrl_mlp_ppo_bf16_kernel<0, true>), grid, block, mlp_bf16_lds_bytes(), st, a);
     else hipLaunchKernelGGL((irrl_mlp_ppo_bf16_kernel<1, true>), grid, block, mlp_bf16_lds_bytes(), st, a);
   } else {

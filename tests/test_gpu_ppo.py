@@ -885,6 +885,44 @@ def test_packed_sample_records_give_the_same_gradients_bit_for_bit(n, indexed, m
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
 
 
+@pytest.mark.parametrize("n,indexed,n_blocks", [(16 * 7 + 5, False, 256), (16 * 1024 * 3 + 16 * 5 + 3, True, 256), (200000, True, 256), (50000, True, 7)])
+def test_wave_pair_mlp_gradient_kernels_equal_the_four_wave_kernels_bit_for_bit(n, indexed, n_blocks, monkeypatch):
+    """Round 5: the bf16 MlpPolicy gradient kernels with two waves per SIMD (csrc/mlp_bf16_pc.hpp: producer waves leave the tensors of a tile in
+    LDS images, consumer waves run the weight-gradient products a tile behind) against the one-wave-per-SIMD kernels of mlp_bf16.hpp
+    (`IRRL_MLP_WAVES=4`): the same products in the same order on the same accumulators -- every per-workgroup partial row, hence every gradient
+    and statistic, BIT FOR BIT; sample counts that leave the last tile ragged, pairs that run out of tiles before others (their barriers
+    still run), workgroups without any tile, and the packed-record instantiations."""
+    from high_speed_quadrupedal_locomotion_by_irrl_amd import ppo2 as P2
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import MlpPolicy, diag_gaussian_neglogp
+    monkeypatch.setattr(P2, "MLP_PRECISION", "bf16x3")
+    dev = torch.device("cuda")
+    torch.manual_seed(5)
+    pol = MlpPolicy().to(dev)
+    flat = P2.FlatParams(pol)
+    g = torch.Generator(device=dev); g.manual_seed(21)
+    rn = lambda *s: torch.randn(*s, device=dev, generator=g)
+    rows = n if not indexed else 2 * n + 77
+    obs, actions, returns, old_v = rn(rows, 35), 0.5 * rn(rows, 12), rn(rows), rn(rows)
+    with torch.no_grad():
+        old_nlp = diag_gaussian_neglogp(actions, pol._run(obs)[0], pol.logstd) + 0.3 * rn(rows)
+    index = torch.randperm(rows, device=dev, generator=g)[:n].contiguous() if indexed else None
+    rec = P2.mlp_pack_records(obs, actions, returns, old_v, old_nlp)
+    stats = torch.tensor([0.1, 0.9], device=dev)
+    out = {}
+    for waves in ("4", "8"):
+        monkeypatch.setenv("IRRL_MLP_WAVES", waves)
+        for use_rec in (False, True):
+            flat.grad.zero_()
+            row = P2.mlp_ppo_grads_flat(pol, flat, obs, actions, returns, old_v, old_nlp, stats, 0.2, 0.01, 0.5, index, n_blocks=n_blocks,
+                                        rec=rec if use_rec else None)
+            torch.cuda.synchronize()
+            out[waves, use_rec] = (flat.grad.clone(), row.clone())
+    assert float(out["4", False][0].abs().max()) > 0
+    for use_rec in (False, True):
+        assert torch.equal(out["4", use_rec][0], out["8", use_rec][0]), use_rec
+        assert torch.equal(out["4", use_rec][1], out["8", use_rec][1]), use_rec
+
+
 def test_mlp_update_through_packed_records_equals_the_update_through_the_arrays(monkeypatch):
     """PPO2.update of the shipped MlpPolicy configuration (4 minibatches x 3 epochs here) with the packed records (the default) and without
     (`ppo2.MLP_RECORDS = False`): the same parameters and statistics, bit for bit."""

@@ -28,6 +28,7 @@
 #   variants       A/B of every csrc/_variants/libirrl_env_*.so (tools/build_variants.py) on this one box, interleaved
 #   ablstm         same-box A/B of the PPO-LSTM update (bf16x3 and bf16x6) over every csrc/_variants/libirrl_env_*.so
 #   abmlp          same-box A/B of the PPO-MLP update with / without the packed sample records (IRRL_MLP_RECORDS)
+#   abmlpw         same-box A/B of the MlpPolicy gradient kernels, four waves against producer / consumer wave pairs (IRRL_MLP_WAVES)
 #   spread         per-wave durations of the step kernel (needs the `prof` variant library)
 #   ab <cmd...>    run the rest of the line verbatim (one-off A/B)
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -154,6 +155,16 @@ while [ $# -gt 0 ]; do
       rm -f $O/abmlp.log
       for r in 1 2 3; do for rec in 1 0; do
         IRRL_MLP_RECORDS=$rec timeout 300 python tools/ppo_bench.py --policy mlp --envs 4096 --iters 5 --cfg bp5_imitation.yaml 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('IRRL_MLP_RECORDS=$rec rollout', round(d['rollout_s']*1e3,2), 'ms update', round(d['update_s']*1e3,2), 'ms', round(d['ppo_iters_per_sec'],3), 'it/s')" >> $O/abmlp.log
+      done; done ;;
+    abmlpw)
+      # same-box A/B of the MlpPolicy gradient kernels: one wave per SIMD (IRRL_MLP_WAVES=4) against producer / consumer wave pairs (default)
+      rm -f $O/abmlpw.log
+      for r in 1 2; do for w in 4 8; do
+        echo "IRRL_MLP_WAVES=$w" >> $O/abmlpw.log
+        IRRL_MLP_WAVES=$w timeout 300 python tools/mlp_kernel_time.py 2>&1 | grep bf16x3 >> $O/abmlpw.log
+      done; done
+      for r in 1 2 3; do for w in 4 8; do
+        IRRL_MLP_WAVES=$w timeout 300 python tools/ppo_bench.py --policy mlp --envs 4096 --iters 5 --cfg bp5_imitation.yaml 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('IRRL_MLP_WAVES=$w rollout', round(d['rollout_s']*1e3,2), 'ms update', round(d['update_s']*1e3,2), 'ms', round(d['ppo_iters_per_sec'],3), 'it/s')" >> $O/abmlpw.log
       done; done ;;
     spread)
       V=high_speed_quadrupedal_locomotion_by_irrl_amd/csrc/_variants; rm -f $O/wave_spread.log
