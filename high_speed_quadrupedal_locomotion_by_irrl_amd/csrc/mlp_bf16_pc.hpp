@@ -27,7 +27,14 @@ static_assert(4 * PC_PAIR * 2 >= IRRL_MLP_P * 4, "the block reduction reuses the
 static_assert(mlp_bf16_pc_lds_bytes() <= 160 * 1024, "one workgroup per CU: the CU's whole LDS");
 
 // every LDS operation of this wave has completed, then the workgroup's barrier (no vmcnt wait: the next tile's rows stay in flight)
+#ifndef IRRL_PC_AB
+#define IRRL_PC_AB 0      /* diagnostics (WRONG results), tools/build_variants.py: 1 no transcendentals, 2 no splits of the activations, 3 weight operands fetched once, 4 no image writes, 5 no barriers, 6 one tile's rows for every tile, 7 no consumer products */
+#endif
+#if IRRL_PC_AB == 5
+#define PC_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
 #define PC_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
 
 template <int KIND, bool REC = false>
 __global__ void __launch_bounds__(512)
@@ -147,7 +154,7 @@ irrl_mlp_ppo_bf16_pc_kernel(const MlpUpdateArgs a) {
     bool have = false;
     for (size_t it = 0; it < iters; it++) {
       PC_BARRIER();                                    // B: the last tile's operands are in registers (nothing pending in front of the first tile)
-      if (have) products();
+      if (have && IRRL_PC_AB != 7) products();
       PC_BARRIER();                                    // A: the producer's images of tile `it` are complete
       have = tile0 + it * stride < ntiles;
       if (have) {
@@ -230,18 +237,21 @@ irrl_mlp_ppo_bf16_pc_kernel(const MlpUpdateArgs a) {
         for (int p = 0; p < 2; p++) { wr[4 * nt + p] = W8(p, MB_W1A + 512 * nt); wr[4 * nt + 2 + p] = W8(p, MB_W1B + 512 * nt); }
     };
     auto load_w2 = [&]() {
+      if (IRRL_PC_AB == 3) return;
 #pragma unroll
       for (int b = 0; b < 8; b++)
 #pragma unroll
         for (int p = 0; p < 2; p++) wr[2 * b + p] = W8(p, MB_W2 + 512 * b);
     };
     auto load_w2t = [&]() {
+      if (IRRL_PC_AB == 3) return;
 #pragma unroll
       for (int b = 0; b < 8; b++)
 #pragma unroll
         for (int p = 0; p < 2; p++) wr[2 * b + p] = W8(p, MB_W2T + 512 * b);
     };
     auto load_head = [&]() {
+      if (IRRL_PC_AB == 3) return;
 #pragma unroll
       for (int m = 0; m < 2; m++)
 #pragma unroll
@@ -290,8 +300,13 @@ irrl_mlp_ppo_bf16_pc_kernel(const MlpUpdateArgs a) {
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): see the f32 kernel
     load_w1();
+#if IRRL_PC_AB == 1
+    auto act_a = [&](float x) -> float { return -2.0f * x; };
+    auto act_b = [&](float e) -> float { return 2.0f * (1.0f + e) - 1.0f; };
+#else
     auto act_a = [&](float x) -> float { return __expf(-2.0f * x); };
     auto act_b = [&](float e) -> float { return 2.0f * __builtin_amdgcn_rcpf(1.0f + e) - 1.0f; };     // == fast_tanh
+#endif
 #ifdef IRRL_MB_PROFILE   /* tools/mlp_bf16_phases.py: where a producer's tile goes, in 100 MHz ticks (the d logstd slots carry the sums) */
     float ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long pts_ = wall_clock64();
@@ -302,8 +317,10 @@ irrl_mlp_ppo_bf16_pc_kernel(const MlpUpdateArgs a) {
         PC_BARRIER();
         continue;
       }
-      load_tile(row_next, nxt);
-      row_next = row_of(tile + 2 * stride < ntiles ? tile + 2 * stride : tile);
+      if (IRRL_PC_AB != 6) {
+        load_tile(row_next, nxt);
+        row_next = row_of(tile + 2 * stride < ntiles ? tile + 2 * stride : tile);
+      }
       const bool valid = tile * 16 + c < a.n;
 
       // ---- observations: planes as the B operand (k = 8 g + j; 32 + 8 g + j) ----
@@ -344,7 +361,13 @@ irrl_mlp_ppo_bf16_pc_kernel(const MlpUpdateArgs a) {
             if (st < 3 && j < 6) chain1(st + 1, j);
             if (part == 0) e_[r] = act_a(acc[st][r]);
             else if (part == 1) h1[st][r] = act_b(e_[r]);
-            else { unsigned short pl[2]; bf_split<2>(h1[st][r], pl); h1p[st][0][r] = pl[0]; h1p[st][1][r] = pl[1]; }
+            else {
+#if IRRL_PC_AB == 2
+              h1p[st][0][r] = (unsigned short)(__builtin_bit_cast(unsigned, h1[st][r]) >> 16); h1p[st][1][r] = 0;
+#else
+              unsigned short pl[2]; bf_split<2>(h1[st][r], pl); h1p[st][0][r] = pl[0]; h1p[st][1][r] = pl[1];
+#endif
+            }
             MB_PIN();
           }
         }
@@ -354,10 +377,10 @@ irrl_mlp_ppo_bf16_pc_kernel(const MlpUpdateArgs a) {
       MB_STAMP(1);   // waiting at B
 #pragma unroll
       for (int p = 0; p < 2; p++) {
-        *(u16x8_t *)(IM(PC_OX, p) + c * PC_RSX + 8 * g) = xp[p];
-        if (g == 0) *(u16x4_t *)(IM(PC_OX, p) + c * PC_RSX + 32) = (u16x4_t){xq[p][0], xq[p][1], xq[p][2], xq[p][3]};
+        if (IRRL_PC_AB != 4) *(u16x8_t *)(IM(PC_OX, p) + c * PC_RSX + 8 * g) = xp[p];
+        if (IRRL_PC_AB != 4 && g == 0) *(u16x4_t *)(IM(PC_OX, p) + c * PC_RSX + 32) = (u16x4_t){xq[p][0], xq[p][1], xq[p][2], xq[p][3]};
 #pragma unroll
-        for (int st = 0; st < 4; st++) *(u16x4_t *)(IM(PC_OH1, p) + c * MB_RS + 16 * st + 4 * g) = h1p[st][p];
+        for (int st = 0; st < 4; st++) if (IRRL_PC_AB != 4) *(u16x4_t *)(IM(PC_OH1, p) + c * MB_RS + 16 * st + 4 * g) = h1p[st][p];
       }
       // ---- layer 2 ----
       {
@@ -385,12 +408,18 @@ irrl_mlp_ppo_bf16_pc_kernel(const MlpUpdateArgs a) {
             if (st < 3 && j < 6) chain2(st + 1, j);
             if (part == 0) e_[r] = act_a(acc[st][r]);
             else if (part == 1) h2[st][r] = act_b(e_[r]);
-            else { unsigned short pl[2]; bf_split<2>(h2[st][r], pl); h2p[st][0][r] = pl[0]; h2p[st][1][r] = pl[1]; }
+            else {
+#if IRRL_PC_AB == 2
+              h2p[st][0][r] = (unsigned short)(__builtin_bit_cast(unsigned, h2[st][r]) >> 16); h2p[st][1][r] = 0;
+#else
+              unsigned short pl[2]; bf_split<2>(h2[st][r], pl); h2p[st][0][r] = pl[0]; h2p[st][1][r] = pl[1];
+#endif
+            }
             MB_PIN();
           }
           if (KIND == 0) {
 #pragma unroll
-            for (int p = 0; p < 2; p++) *(u16x4_t *)(IM(PC_OH2, p) + c * MB_RS + 16 * st + 4 * g) = h2p[st][p];
+            for (int p = 0; p < 2; p++) if (IRRL_PC_AB != 4) *(u16x4_t *)(IM(PC_OH2, p) + c * MB_RS + 16 * st + 4 * g) = h2p[st][p];
           }
         }
       }
@@ -461,7 +490,7 @@ irrl_mlp_ppo_bf16_pc_kernel(const MlpUpdateArgs a) {
         u16x4_t z3[2];
         split4(dz3, z3);
 #pragma unroll
-        for (int p = 0; p < 2; p++) *(u16x4_t *)(IM(PC_OD3, p) + c * PC_RS3 + 4 * g) = z3[p];
+        for (int p = 0; p < 2; p++) if (IRRL_PC_AB != 4) *(u16x4_t *)(IM(PC_OD3, p) + c * PC_RS3 + 4 * g) = z3[p];
 #pragma unroll
         for (int kt = 0; kt < 4; kt++) {
           d[kt] = zero4;
@@ -492,7 +521,7 @@ irrl_mlp_ppo_bf16_pc_kernel(const MlpUpdateArgs a) {
 #pragma unroll
       for (int nt = 0; nt < 4; nt++)
 #pragma unroll
-        for (int p = 0; p < 2; p++) *(u16x4_t *)(IM(PC_OD2, p) + c * MB_RS + 16 * nt + 4 * g) = z2[nt][p];
+        for (int p = 0; p < 2; p++) if (IRRL_PC_AB != 4) *(u16x4_t *)(IM(PC_OD2, p) + c * MB_RS + 16 * nt + 4 * g) = z2[nt][p];
       {
         u16x8_t b[2][2];
 #pragma unroll
@@ -509,7 +538,7 @@ irrl_mlp_ppo_bf16_pc_kernel(const MlpUpdateArgs a) {
         }
       }
       MB_PIN();
-      load_w1();          // the next tile's first layer
+      if (IRRL_PC_AB != 3) load_w1();          // the next tile's first layer
       MB_PIN();
 #pragma unroll
       for (int e = 0; e < 16; e++) {
@@ -523,11 +552,11 @@ irrl_mlp_ppo_bf16_pc_kernel(const MlpUpdateArgs a) {
 #pragma unroll
       for (int nt = 0; nt < 4; nt++)
 #pragma unroll
-        for (int p = 0; p < 2; p++) *(u16x4_t *)(IM(PC_OD1, p) + c * MB_RS + 16 * nt + 4 * g) = z1[nt][p];
+        for (int p = 0; p < 2; p++) if (IRRL_PC_AB != 4) *(u16x4_t *)(IM(PC_OD1, p) + c * MB_RS + 16 * nt + 4 * g) = z1[nt][p];
       MB_STAMP(5);   // d h1, d z1
       PC_BARRIER();       // A: this tile's images are complete
       MB_STAMP(6);   // waiting at A
-      cur = nxt;
+      if (IRRL_PC_AB != 6) cur = nxt;
       MB_STAMP(7);   // the next tile's rows arriving
     }
 #ifdef IRRL_MB_PROFILE
