@@ -2138,8 +2138,8 @@ IRRL_DEV void store_lane(const EnvParams &P, const EnvState &S, vi env, vi leg, 
 
 // ENV:1248-1268 + obs scaling ENV:375-393: writes this lane's share of the scaled [N,35] row.  The scaling divides by
 // constants (1, 5 / 35 / 40, 0.7, 3): multiplications by their reciprocals here, one rounding away from the quotient.
+IRRL_DEV void observe_write(const EnvParams &P, vi env, vi leg, vm valid, const EnvLane &L, float *ob_out);
 IRRL_DEV void observe_lane(const EnvParams &P, vi env, vi leg, vm valid, EnvLane &L, float *ob_out) {
-  vm lead = valid & (leg == 0);
   if (P.obs_filter) {  // filter touches obs[5:35]
     float al = P.obs_filter_alpha;
 #pragma unroll
@@ -2153,6 +2153,12 @@ IRRL_DEV void observe_lane(const EnvParams &P, vi env, vi leg, vm valid, EnvLane
     }
     L.obl_env[3] = L.ob_phase[0]; L.obl_env[4] = L.ob_phase[1];
   }
+  observe_write(P, env, leg, valid, L, ob_out);
+}
+// the scaled row itself (no state is touched): observe_lane's stores; the persistent MlpPolicy rollout kernel calls it a second time with its
+// wave's LDS scratch as `ob_out` and the robot's index inside the wave as `env` (env_kernels.hip)
+IRRL_DEV void observe_write(const EnvParams &P, vi env, vi leg, vm valid, const EnvLane &L, float *ob_out) {
+  vm lead = valid & (leg == 0);
   vi ob = env * 35;
   const float ijstd[3] = {1.0f / 5.0f, 1.0f / 35.0f, 1.0f / 40.0f};
   vf nominal[3] = {L.m.sy * P.abad, -0.78f, 1.57f};
@@ -2188,7 +2194,7 @@ struct NoStepHook { IRRL_DEV void operator()() const {} };
 // step_compute: the step on a lane context that is ALREADY in registers -- everything between load_lane and store_lane.  `tail(L)` runs at the
 // end of the epilogue, inside its sub-lane-0 region: step_body stores the context there; the multi-step kernels, which keep the context in
 // registers from one step to the next (env_kernels.hip), pass nothing and call lane_carry() behind it.
-struct NoStepTail { IRRL_DEV void operator()(const EnvLane &) const {} };
+struct NoStepTail { IRRL_DEV void operator()(const EnvLane &, vf, vm) const {} };
 // where a lane's three action components come from: the action batch in memory (row-major [N, 12]), or registers the caller filled ahead of
 // time (the multi-step kernel requests step k + 1's row while step k runs)
 struct ActionRow { const float *p; IRRL_DEV vf get(vi env, vi leg, int k) const { return ld(p, env * 12 + leg * 3 + k); } };
@@ -2343,7 +2349,7 @@ IRRL_DEV void step_compute(const EnvParams &P, EnvLane &L, vi env, vi leg, vm va
   stm(extra_out, env * 6 + 3, (float)L.prof_ranksteps); stm(extra_out, env * 6 + 4, (float)L.prof_flags);
 #endif
   IRRL_MASKED_END
-  tail(L);
+  tail(L, rew, done);      // (the step's reward and termination flag next to the final context)
   IRRL_SUB0_ONLY_END
 }
 
@@ -2353,7 +2359,7 @@ IRRL_DEV void step_body(const EnvParams &P, const EnvState &S, vi env, vi leg, v
   EnvLane L;
   load_lane(P, S, env, leg, L, true);
   step_compute<RULE>(P, L, env, leg, valid, ActionRow{action}, ob_out, reward_out, done_out, extra_out, before_substeps,
-                     [&](const EnvLane &Lf) { store_lane(P, S, env, leg, valid, Lf, P.randomize_per_episode != 0); });
+                     [&](const EnvLane &Lf, vf, vm) { store_lane(P, S, env, leg, valid, Lf, P.randomize_per_episode != 0); });
 }
 
 // THE LANE CONTEXT CARRIED FROM STEP k TO STEP k + 1 IN REGISTERS (round 5: the multi-step kernels of env_kernels.hip load it once in front of

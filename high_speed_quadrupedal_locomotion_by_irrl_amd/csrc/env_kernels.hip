@@ -264,8 +264,7 @@ irrl_rollout_persistent_actor_kernel_l16(EnvParams P, EnvState S, float *ob, flo
 // Same device functions, same order: the buffers are bit-identical to the two-launch sequence.
 __global__ void __launch_bounds__(256, 1)
 irrl_rollout_persistent_mlp_kernel_l16(EnvParams P, EnvState S, float *ob, float *reward, uint8_t *done, float *extra, PolicyStepArgs a, int steps) {
-  __shared__ float h1[2][16 * 65], h2[2][16 * 65];
-  __shared__ float terms[16][17];
+  __shared__ __attribute__((aligned(16))) float wsl[4][MlpWaveLds<64>::FLOATS];      // per wave: its four robots' scratch (policy_step.hpp)
   __shared__ float head_w[64 * 17];
   __shared__ __attribute__((aligned(16))) float wl[MlpLdsImage<64>::FLOATS];
   mlp_policy_stage_lds<64>(a, wl, head_w, (int)threadIdx.x, 256);
@@ -275,27 +274,52 @@ irrl_rollout_persistent_mlp_kernel_l16(EnvParams P, EnvState S, float *ob, float
   // the env part's lane context stays in registers across the steps (round 5; irrl_steps_persistent_kernel below): this policy's step needs
   // few registers (its weights and activations live in LDS), so the context survives it without spilling
   const int lane0_ = (int)(threadIdx.x & 63u);
-  int env0_ = ((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * 4 + (lane0_ >> 4);
+  const int wave_ = (int)(threadIdx.x >> 6);
+  const int e4_ = ((int)blockIdx.x * 4 + wave_) * 4;            // the wave's first robot
+  const int rl_ = lane0_ >> 4;                                   // this lane's robot inside the wave
+  int env0_ = e4_ + rl_;
   const int leg0_ = (lane0_ >> 2) & 3;
   const bool valid0_ = (env0_ < P.n_envs) && ((lane0_ & 3) == 0);
   if (env0_ >= P.n_envs) env0_ = P.n_envs - 1;
   irrl_plain::EnvLane L;
   irrl_plain::load_lane(P, S, env0_, leg0_, L, true);
+  // Round 5: the policy of a wave's four robots is that wave's own work (mlp_policy_wave_body): no workgroup barrier in the step loop, no wait
+  // for the slowest of the four env waves in every step -- and what a wave hands from its env step to its policy step and back (observations,
+  // reward, done flag; clipped actions) goes through its LDS scratch next to the stores to memory, so no load inside the loop waits for a store.
+  float *ws = wsl[wave_];
+  {   // the state of things in front of step 0, from memory: observations, done flags, the last reward
+    const int n = ((a.N - e4_ < 4) ? a.N - e4_ : 4);
+    for (int i = lane0_; i < 4 * 35; i += 64) ws[MlpWaveLds<64>::X + i] = (i < n * 35) ? a.obs[(size_t)e4_ * 35 + i] : 0.0f;
+    if (lane0_ < 4) {
+      const int e = (e4_ + lane0_ < a.N) ? e4_ + lane0_ : a.N - 1;
+      ws[MlpWaveLds<64>::DON + lane0_] = a.dones[e] ? 1.0f : 0.0f;
+      ws[MlpWaveLds<64>::REW + lane0_] = a.prev_reward ? a.prev_reward[e] : 0.0f;
+    }
+  }
   __syncthreads();
   for (int k = 0; k < steps; k++) {
-    int tid = (int)threadIdx.x;
-    asm volatile("" : "+v"(tid));     // (see irrl_rollout_persistent_kernel_l16: keeps the per-lane addresses inside the loop)
+    int lane = lane0_;
+    asm volatile("" : "+v"(lane));     // (see irrl_rollout_persistent_kernel_l16: keeps the per-lane addresses inside the loop)
     a.row = row0 + k; a.rng_step = rng0 + k;
     a.noise = noise0 ? noise0 + (size_t)k * noise_stride : nullptr;
-    mlp_policy_step_body<64, true>(a, (int)blockIdx.x * 16, h1, h2, terms, head_w, wl, tid);
-    __syncthreads();   // this workgroup's clipped actions (and the rollout rows) are stored and visible to its own loads
+    mlp_policy_wave_body<64, true, true>(a, e4_, ws, wl, head_w, lane);
+    PS_WAVE_SYNC();    // this wave's clipped actions are in its scratch
     {
       int env_ = env0_;
       asm volatile("" : "+v"(env_));
       if (k > 0) irrl_plain::lane_carry(L);
-      irrl_plain::step_compute<1>(P, L, env_, leg0_, valid0_, irrl_plain::ActionRow{(const float *)a.clipped}, ob, reward, done, extra);
+      irrl_plain::ActionRegs act;
+#pragma unroll
+      for (int j = 0; j < 3; j++) act.a[j] = ws[MlpWaveLds<64>::ACT + rl_ * 12 + leg0_ * 3 + j];
+      irrl_plain::step_compute<1, irrl_plain::NoStepHook>(
+          P, L, env_, leg0_, valid0_, act, ob, reward, done, extra, irrl_plain::NoStepHook(),
+          [&](const irrl_plain::EnvLane &Lf, float rew, bool dn) {
+            // (inside the epilogue's sub-lane-0 region) the scaled observation row, the reward and the done flag once more, into the scratch
+            irrl_plain::observe_write(P, rl_, leg0_, valid0_, Lf, ws + MlpWaveLds<64>::X);
+            if (valid0_ && leg0_ == 0) { ws[MlpWaveLds<64>::REW + rl_] = rew; ws[MlpWaveLds<64>::DON + rl_] = dn ? 1.0f : 0.0f; }
+          });
     }
-    __syncthreads();   // obs / dones / reward of step k are stored and visible: the next policy step reads them
+    PS_WAVE_SYNC();    // observations / done flags / rewards of step k are in the scratch: the wave's next policy step reads them
   }
   if (steps > 0) {
     IRRL_SUB0_ONLY_BEGIN

@@ -776,10 +776,12 @@ lstm_policy_step_kernel(PolicyStepArgs a) {
 template <int H>
 __global__ void __launch_bounds__(256)
 mlp_policy_step_kernel(PolicyStepArgs a) {
-  __shared__ float h1[2][16 * (H + 1)], h2[2][16 * (H + 1)];
-  __shared__ float terms[16][17];
-  __shared__ float head_w[H * 17];
-  mlp_policy_step_body<H, false>(a, blockIdx.x * 16, h1, h2, terms, head_w, nullptr, (int)threadIdx.x);
+  // four independent waves, four envs each (mlp_policy_wave_body: no workgroup barrier)
+  __shared__ __attribute__((aligned(16))) float ws[4][MlpWaveLds<H>::FLOATS];
+  const int wv = (int)(threadIdx.x >> 6);
+  const int e4 = (int)blockIdx.x * 16 + 4 * wv;
+  if (e4 >= a.N) return;
+  mlp_policy_wave_body<H, false>(a, e4, ws[wv], nullptr, nullptr, (int)(threadIdx.x & 63u));
 }
 
 // ---- PPO2 clipped-surrogate loss, forward AND backward in one pass (ppo2.py:152-175 + DiagGaussian neglogp / entropy) ----
@@ -1260,7 +1262,7 @@ int irrl_mlp_policy_step(int hid, int ob_dim, int act_dim, int N, const float *o
                          int rng_on, unsigned rng_seed, long long rng_step, const long long *rng_base, int env_id_offset, float *action, float *clipped,
                          float *value, float *neglogp, long long row, float *mb_obs, float *mb_actions, float *mb_values, float *mb_neglogp,
                          uint8_t *mb_dones, float *mb_rewards, const float *prev_reward, void *hip_stream) {
-  if (N <= 0 || ob_dim <= 0 || act_dim <= 0 || act_dim > 15 || hid != 64) return 1;
+  if (N <= 0 || ob_dim <= 0 || ob_dim > 64 || act_dim <= 0 || act_dim > 15 || hid != 64) return 1;
   PolicyStepArgs a;
   a.obs = obs; a.dones = dones; a.states_in = nullptr; a.states_out = nullptr;
   for (int i = 0; i < 12; i++) a.w[i] = i < 8 ? mlp_w[i] : nullptr;

@@ -140,12 +140,11 @@ LSTM_DEV void policy_heads(const PolicyStepArgs &a, const float *hpi, const floa
 #define PS_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b_, c_, 0, 0, 0)
 
 // ---------------------------------------------------------------------------------------------------------------
-// One rollout step of MlpPolicy (policies.py:430-446: separate pi / vf nets of two tanh layers of H units) for the 16 envs e0 .. e0 + 15
-// by one workgroup of 256 threads: waves 0-1 run the pi net, waves 2-3 the vf net, two 16-column tiles each; exact f32 on
-// v_mfma_f32_16x16x4_f32.  a.w[] = pi_w1 [ob][H], pi_b1, pi_w2 [H][H], pi_b2, vf_w1, vf_b1, vf_w2, vf_b2 (plain row-major).
+// One rollout step of MlpPolicy (policies.py:430-446: separate pi / vf nets of two tanh layers of H units).
+// a.w[] = pi_w1 [ob][H], pi_b1, pi_w2 [H][H], pi_b2, vf_w1, vf_b1, vf_w2, vf_b2 (plain row-major).
 // LDSW: the eight arrays were copied to LDS once (mlp_policy_stage_lds: the persistent rollout kernel, whose workgroup keeps them for all
-// steps) in the image [net][w1 (ob x H) | b1 (H) | w2 (H x H) | b2 (H)], and the head weights sit in head_w already; otherwise they are
-// read from global memory / staged here (the stand-alone kernel).  Same values, same order of operations: the two agree bit for bit.
+// steps) in the image [net][w1 (36 x H, rows beyond ob_dim zero) | b1 (H) | w2 (H x H) | b2 (H)], and the head weights sit in head_w; otherwise
+// they are read from global memory (the stand-alone kernel).  Same values, same order of operations: the two agree bit for bit.
 template <int H>
 struct MlpLdsImage { static constexpr int OBMAX = 36, NET = OBMAX * H + H + H * H + H, FLOATS = 2 * NET; };
 template <int H>
@@ -153,62 +152,162 @@ LSTM_DEV void mlp_policy_stage_lds(const PolicyStepArgs &a, float *wl, float *he
   for (int net = 0; net < 2; net++) {
     float *dst = wl + net * MlpLdsImage<H>::NET;
     const float *w1 = a.w[4 * net], *b1 = a.w[4 * net + 1], *w2 = a.w[4 * net + 2], *b2 = a.w[4 * net + 3];
-    for (int i = tid; i < a.ob_dim * H; i += nthr) dst[i] = w1[i];
+    for (int i = tid; i < MlpLdsImage<H>::OBMAX * H; i += nthr) dst[i] = (i < a.ob_dim * H) ? w1[i] : 0.0f;      // (rows beyond ob_dim: zeros)
     for (int i = tid; i < H; i += nthr) { dst[MlpLdsImage<H>::OBMAX * H + i] = b1[i]; dst[MlpLdsImage<H>::OBMAX * H + H + H * H + i] = b2[i]; }
     for (int i = tid; i < H * H; i += nthr) dst[MlpLdsImage<H>::OBMAX * H + H + i] = w2[i];
   }
   for (int i = tid; i < H * a.act_dim; i += nthr) head_w[i] = a.pi_w[i];
   if (tid < H) head_w[H * a.act_dim + tid] = a.vf_w[tid];
 }
-template <int H, bool LDSW>
-LSTM_DEV void mlp_policy_step_body(const PolicyStepArgs &a, const int e0, float (*h1)[16 * (H + 1)], float (*h2)[16 * (H + 1)], float (*terms)[17],
-                                   float *head_w, const float *wl, const int tid) {
-  constexpr int LD = H + 1;
-  constexpr int NT = H / 32;                 // 16-column tiles per wave (two waves per net)
-  const int w = tid >> 6, l = tid & 63;
-  const int col = l & 15, rq = l >> 4;
-  const int net = w >> 1, half = w & 1;
+// ---------------------------------------------------------------------------------------------------------------
+// THE STEP, BY ONE WAVE FOR ITS OWN FOUR ENVS (round 5; rounds 2-4: a workgroup of four waves for 16 envs on v_mfma_f32_16x16x4_f32, two waves
+// per network).  MlpPolicy is per-robot arithmetic: nothing tied the 16 robots of a workgroup together except that 16-row MFMA tile -- and with
+// it two workgroup barriers per step and, inside the persistent rollout kernel, the wait for the slowest of the workgroup's four env waves in
+// EVERY step.  Here a wave (= the four robots its env step integrates, 16 lanes each) runs both networks for those four robots on
+// v_mfma_f32_4x4x1_16b_f32: 16 blocks of a 4 x 4 outer product per instruction,
+//   D[block b][robot i][unit 4 b + j] += x[robot i][k] * W[k][unit 4 b + j]        (lane = unit 4 b + j, accumulator register = robot i)
+// so one instruction per k covers all 64 hidden units of the four robots -- no idle rows -- with the A operand the robot's activation
+// (lane & 3 picks the robot: four distinct LDS words per read, broadcast) and the B operand row k of the weight matrix as it lies in memory
+// (64 consecutive floats).  A network's layer is a chain of K dependent 2-pass MFMAs; the two networks' chains alternate.  Heads, sample,
+// neglogp, clip and buffer rows: policy_heads' arithmetic, element for element, on 4 x act_dim + 4 lanes.  No workgroup barrier anywhere:
+// the wave's LDS scratch is its own, and in the persistent rollout kernel a robot's next env step starts when ITS wave's policy is done.
+// LDSW as above (the weight image of mlp_policy_stage_lds; head weights in `head_w`), else weights and head weights from global memory.
+#define PS_MFMA4(a_, b_, c_) __builtin_amdgcn_mfma_f32_4x4x1f32(a_, b_, c_, 0, 0, 0)
+// the wave's own LDS stores are ordered before its own later LDS loads (other lanes' words): compiler ordering; the LDS itself serves a wave in order
+#define PS_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+// a wave's LDS scratch (floats): the four robots' observations [4][ob_dim <= 64] | clipped actions [4][act_dim <= 15] | last reward [4] |
+// last done flag [4] | h1 (pi, vf) [2][4][LD] | h2 (pi, vf) | neglogp terms [4][17]
+template <int H>
+struct MlpWaveLds {
+  static constexpr int LD = H + 4, X = 0, ACT = 4 * 64, REW = ACT + 64, DON = REW + 4, H1 = DON + 4, H2 = H1 + 8 * LD, TERMS = H2 + 8 * LD, FLOATS = TERMS + 4 * 17;
+};
+
+// XLDS: the persistent rollout kernel -- observations, reward and done flag of the wave's robots are in its scratch already (its own env step
+// left them there next to the stores to memory), and the clipped actions are left there for that env step: inside the step loop nothing a wave
+// reads comes back from memory, so nothing waits for a store to complete
+template <int HID, bool XLDS>
+LSTM_DEV void policy_heads_wave(const PolicyStepArgs &a, float *ws, const float *hpi, const float *hv, int LD, const float *pw, const float *vw, float (*terms)[17],
+                                int e4, int l, long long t, long long gstep) {
+  // lane (env, action) for the mean / sample, four more lanes for the value and the neglogp sum (policy_heads with 4 envs instead of 16)
+  const int A = a.act_dim;
+  if (l < 4 * A && e4 + l / A < a.N) {
+    const int env = l / A, ai = l - env * A;
+    float mean = a.pi_b[ai];
+#pragma unroll
+    for (int k = 0; k < HID; k++) mean = __builtin_fmaf(hpi[env * LD + k], pw[k * A + ai], mean);
+    const float ls = a.logstd[ai];
+    const float sd = __expf(ls);
+    const size_t o = (size_t)(e4 + env) * A + ai;
+    float z = 0.0f;
+    if (a.noise) {
+      z = a.noise[o];
+    } else if (a.rng_on) {
+      float r[4];
+      policy_philox(a.rng_seed, (unsigned)(e4 + env) + a.env_id_offset, (unsigned)((unsigned long long)gstep >> 32), (unsigned)gstep, IRRL_P_POLICY_NOISE + (unsigned)(ai >> 2), r);
+      const int pair = (ai >> 1) & 1;
+      const float ua = pair ? r[2] : r[0], ub = pair ? r[3] : r[1];
+      const float rad = __builtin_sqrtf(-2.0f * __logf(1.0f - ua));
+      const float ang = 6.283185307179586f * ub;
+      z = rad * ((ai & 1) ? __sinf(ang) : __cosf(ang));
+    }
+    const float act = __builtin_fmaf(sd, z, mean);
+    const float d = (act - mean) / sd;
+    terms[env][ai] = __builtin_fmaf(0.5f * d, d, ls);
+    const float cl = fminf(fmaxf(act, -1.0f), 1.0f);
+    a.action[o] = act;
+    a.clipped[o] = cl;
+    if (XLDS) ws[MlpWaveLds<HID>::ACT + env * A + ai] = cl;
+    if (a.mb_actions) a.mb_actions[(size_t)t * a.N * A + o] = act;
+  }
+  float val = 0.0f;
+  const int vt = l - 4 * A;
+  const bool vok = vt >= 0 && vt < 4 && e4 + vt < a.N;
+  if (vok) {
+    val = a.vf_b[0];
+#pragma unroll
+    for (int k = 0; k < HID; k++) val = __builtin_fmaf(hv[vt * LD + k], vw[k], val);
+  }
+  PS_WAVE_SYNC();
+  if (vok) {
+    float nl = 0.0f;
+    for (int ai = 0; ai < A; ai++) nl += terms[vt][ai];
+    nl = __builtin_fmaf((float)A, 0.918938533204672742f, nl);
+    const int e = e4 + vt;
+    a.value[e] = val;
+    a.neglogp[e] = nl;
+    if (a.mb_values) {
+      a.mb_values[(size_t)t * a.N + e] = val;
+      a.mb_neglogp[(size_t)t * a.N + e] = nl;
+      a.mb_dones[(size_t)t * a.N + e] = XLDS ? (uint8_t)(ws[MlpWaveLds<HID>::DON + vt] != 0.0f) : a.dones[e];
+      if (a.prev_reward && t > 0) a.mb_rewards[(size_t)(t - 1) * a.N + e] = XLDS ? ws[MlpWaveLds<HID>::REW + vt] : a.prev_reward[e];
+    }
+  }
+  if (a.mb_obs && e4 < a.N) {      // the row of the observations the step was computed from: out of the scratch (the values a.obs holds)
+    const int n = ((a.N - e4 < 4) ? a.N - e4 : 4) * a.ob_dim;
+    float *dst = a.mb_obs + ((size_t)t * a.N + e4) * a.ob_dim;
+    for (int i = l; i < n; i += 64) dst[i] = ws[MlpWaveLds<HID>::X + i];
+  }
+}
+
+template <int H, bool LDSW, bool XLDS = false>
+LSTM_DEV void mlp_policy_wave_body(const PolicyStepArgs &a, const int e4, float *ws, const float *wl, const float *head_w, const int l) {
+  static_assert(H == 64, "one lane per hidden unit");
+  constexpr int LD = MlpWaveLds<H>::LD;
+  float *xs = ws + MlpWaveLds<H>::X, *h1 = ws + MlpWaveLds<H>::H1, *h2 = ws + MlpWaveLds<H>::H2;
+  float (*terms)[17] = (float (*)[17])(ws + MlpWaveLds<H>::TERMS);
   const long long t = a.row;
   const long long gstep = a.rng_step + (a.rng_base ? *a.rng_base : 0ll);
-  const int eA = (e0 + col < a.N) ? e0 + col : a.N - 1;
-  const float *w1, *b1, *w2, *b2;
+  const int r4 = l & 3, OB = a.ob_dim;
+  const float *w1p, *b1p, *w2p, *b2p, *w1v, *b1v, *w2v, *b2v;
   if (LDSW) {
-    const float *base = wl + net * MlpLdsImage<H>::NET;
-    w1 = base; b1 = base + MlpLdsImage<H>::OBMAX * H; w2 = b1 + H; b2 = w2 + H * H;
+    w1p = wl; b1p = w1p + MlpLdsImage<H>::OBMAX * H; w2p = b1p + H; b2p = w2p + H * H;
+    w1v = wl + MlpLdsImage<H>::NET; b1v = w1v + MlpLdsImage<H>::OBMAX * H; w2v = b1v + H; b2v = w2v + H * H;
   } else {
-    w1 = net ? a.w[4] : a.w[0]; b1 = net ? a.w[5] : a.w[1]; w2 = net ? a.w[6] : a.w[2]; b2 = net ? a.w[7] : a.w[3];
-    for (int i = tid; i < H * a.act_dim; i += 256) head_w[i] = a.pi_w[i];
-    if (tid < H) head_w[H * a.act_dim + tid] = a.vf_w[tid];
+    w1p = a.w[0]; b1p = a.w[1]; w2p = a.w[2]; b2p = a.w[3]; w1v = a.w[4]; b1v = a.w[5]; w2v = a.w[6]; b2v = a.w[7];
   }
-  const int ksx = (a.ob_dim + 3) >> 2;
-  f32x4 acc[NT];
+  if (!XLDS) {      // the four robots' observations -> xs[robot][k] (rows of ob_dim words, as in memory)
+    const int n = ((a.N - e4 < 4) ? a.N - e4 : 4) * OB;
+    const float *src = a.obs + (size_t)e4 * OB;
+    for (int i = l; i < 4 * OB; i += 64) xs[i] = (i < n) ? src[i] : 0.0f;
+    PS_WAVE_SYNC();
+  }
+  f32x4 ap, av;
+  { const float bp = b1p[l], bv = b1v[l]; ap = (f32x4){bp, bp, bp, bp}; av = (f32x4){bv, bv, bv, bv}; }
+  // (groups of four k with the operands of a group requested together; beyond ob_dim: x = 0 against a clamped weight row -- adds nothing)
+#pragma unroll 3
+  for (int k = 0; k < OB; k += 4) {
+    float x[4], bp[4], bv[4];
 #pragma unroll
-  for (int nt = 0; nt < NT; nt++) { const float bv = b1[16 * (half * NT + nt) + col]; acc[nt] = (f32x4){bv, bv, bv, bv}; }
-  for (int kk = 0; kk < ksx; kk++) {
-    const int k = 4 * kk + rq, kc = k < a.ob_dim ? k : a.ob_dim - 1;
-    const float av = (k < a.ob_dim) ? a.obs[(size_t)eA * a.ob_dim + kc] : 0.0f;
+    for (int kk = 0; kk < 4; kk++) {
+      const int kc = (k + kk < OB) ? k + kk : OB - 1;
+      const float xv = xs[r4 * OB + kc];
+      x[kk] = (k + kk < OB) ? xv : 0.0f;
+      bp[kk] = w1p[(size_t)kc * H + l];
+      bv[kk] = w1v[(size_t)kc * H + l];
+    }
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++) acc[nt] = PS_MFMA(av, w1[(size_t)kc * H + 16 * (half * NT + nt) + col], acc[nt]);
+    for (int kk = 0; kk < 4; kk++) {
+      ap = PS_MFMA4(x[kk], bp[kk], ap);
+      av = PS_MFMA4(x[kk], bv[kk], av);
+    }
   }
 #pragma unroll
-  for (int nt = 0; nt < NT; nt++)
+  for (int r = 0; r < 4; r++) { h1[r * LD + l] = fast_tanh(ap[r]); h1[4 * LD + r * LD + l] = fast_tanh(av[r]); }
+  PS_WAVE_SYNC();
+  { const float bp = b2p[l], bv = b2v[l]; ap = (f32x4){bp, bp, bp, bp}; av = (f32x4){bv, bv, bv, bv}; }
+#pragma unroll 4
+  for (int k = 0; k < H; k += 4) {
+    const f32x4 p4 = *(const f32x4 *)&h1[r4 * LD + k], v4 = *(const f32x4 *)&h1[4 * LD + r4 * LD + k];
 #pragma unroll
-    for (int j = 0; j < 4; j++) h1[net][(4 * rq + j) * LD + 16 * (half * NT + nt) + col] = fast_tanh(acc[nt][j]);
-  __syncthreads();
-#pragma unroll
-  for (int nt = 0; nt < NT; nt++) { const float bv = b2[16 * (half * NT + nt) + col]; acc[nt] = (f32x4){bv, bv, bv, bv}; }
-#pragma unroll
-  for (int kk = 0; kk < H / 4; kk++) {
-    const float av = h1[net][col * LD + 4 * kk + rq];
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) acc[nt] = PS_MFMA(av, w2[(size_t)(4 * kk + rq) * H + 16 * (half * NT + nt) + col], acc[nt]);
+    for (int kk = 0; kk < 4; kk++) {
+      ap = PS_MFMA4(p4[kk], w2p[(size_t)(k + kk) * H + l], ap);
+      av = PS_MFMA4(v4[kk], w2v[(size_t)(k + kk) * H + l], av);
+    }
   }
 #pragma unroll
-  for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) h2[net][(4 * rq + j) * LD + 16 * (half * NT + nt) + col] = fast_tanh(acc[nt][j]);
-  __syncthreads();
-  policy_heads<H>(a, h2[0], h2[1], LD, head_w, terms, e0, tid, t, gstep);
+  for (int r = 0; r < 4; r++) { h2[r * LD + l] = fast_tanh(ap[r]); h2[4 * LD + r * LD + l] = fast_tanh(av[r]); }
+  PS_WAVE_SYNC();
+  policy_heads_wave<H, XLDS>(a, ws, h2, h2 + 4 * LD, LD, LDSW ? head_w : a.pi_w, LDSW ? head_w + H * a.act_dim : a.vf_w, terms, e4, l, t, gstep);
 }
 #ifdef IRRL_PROFILE_POLICY   /* diagnostic build (tools/policy_phases.py): 100 MHz time stamps of the phases of one workgroup */
 #define IRRL_PS_STAMP() do { __builtin_amdgcn_sched_barrier(0); ts_[tsn_++] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
