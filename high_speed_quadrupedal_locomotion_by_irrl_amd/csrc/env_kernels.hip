@@ -257,6 +257,106 @@ irrl_rollout_persistent_actor_kernel_l16(EnvParams P, EnvState S, float *ob, flo
 #endif
 
 #if IRRL_LANES_PER_ROBOT == 16
+// THE ACTOR-ONLY ROLLOUT WITH THE POLICY AS EACH WAVE'S OWN WORK (round 5, second half; irrl_lstm_rollout fuse = 3, the default form of it).
+// The kernel above still runs the actor for a workgroup's 16 robots on 16-row MFMA tiles: three barriers per step and, in every step, the
+// wait for the slowest of the workgroup's four env waves.  Here a wave runs the actor stack for ITS four robots (lstm_actor_wave_body,
+// policy_step.hpp: v_mfma_f32_4x4x1, operands out of a transposed LDS image), keeps h of both layers in its LDS scratch and c in registers for
+// the whole rollout, and hands observations / reward / done flag / clipped actions between its env step and its policy step through that
+// scratch next to the stores to memory -- no workgroup barrier and no load behind a store inside the step loop.  Actions, neglogp,
+// observations, rewards, dones and the actor's final LSTM state are bit-identical to every other rollout mode.
+__global__ void __launch_bounds__(256, 1)
+irrl_rollout_persistent_actor_wave_kernel_l16(EnvParams P, EnvState S, float *ob, float *reward, uint8_t *done, float *extra, PolicyStepArgs a, int steps) {
+  constexpr int HID = 48, NG = HID / 16, SD = 8 * HID;
+  typedef LstmWaveLds<HID> LAY;
+  __shared__ __attribute__((aligned(16))) float wsl[4][LAY::FLOATS];
+  __shared__ float head_w[HID * 16];
+  __shared__ __attribute__((aligned(16))) float lds_w[LstmWaveImage<HID>::FLOATS];      // the ACTOR's operands, [gate column][K] (policy_step.hpp)
+  lstm_wave_image_stage<HID, 256>(a, lds_w);
+  for (int i = (int)threadIdx.x; i < HID * a.act_dim; i += 256) head_w[i] = a.pi_w[i];
+  const float *noise0 = a.noise;
+  const long long row0 = a.row, rng0 = a.rng_step;
+  const size_t noise_stride = (size_t)a.N * (size_t)a.act_dim;
+  const int lane0_ = (int)(threadIdx.x & 63u);
+  const int wave_ = (int)(threadIdx.x >> 6);
+  const int e4_ = ((int)blockIdx.x * 4 + wave_) * 4;            // the wave's first robot
+  const int rl_ = lane0_ >> 4;                                   // the robot this lane integrates (env part)
+  int env0_ = e4_ + rl_;
+  const int leg0_ = (lane0_ >> 2) & 3;
+  const bool valid0_ = (env0_ < P.n_envs) && ((lane0_ & 3) == 0);
+  if (env0_ >= P.n_envs) env0_ = P.n_envs - 1;
+  irrl_plain::EnvLane L;
+  irrl_plain::load_lane(P, S, env0_, leg0_, L, true);
+  float *ws = wsl[wave_];
+  // policy part: this lane's robot is l & 3, its unit inside a column group l >> 2
+  const int pr_ = lane0_ & 3, pq_ = lane0_ >> 2;
+  const bool pok_ = e4_ + pr_ < a.N;
+  const int pe_ = pok_ ? e4_ + pr_ : a.N - 1;
+  float cst[2][NG], bias[2][NG];
+#pragma unroll
+  for (int G = 0; G < NG; G++) {
+    cst[0][G] = a.states_in[(size_t)pe_ * SD + 16 * G + pq_];
+    cst[1][G] = a.states_in[(size_t)pe_ * SD + 2 * HID + 16 * G + pq_];
+    bias[0][G] = a.w[2][64 * G + lane0_];
+    bias[1][G] = a.w[5][64 * G + lane0_];
+  }
+  {   // the state of things in front of step 0, from memory: observations, done flags, the last reward, h of both layers
+    const int n = ((a.N - e4_ < 4) ? a.N - e4_ : 4);
+    for (int i = lane0_; i < 4 * 35; i += 64) ws[LAY::X + i] = (i < n * 35) ? a.obs[(size_t)e4_ * 35 + i] : 0.0f;
+    for (int i = lane0_; i < 4 * HID; i += 64) {
+      const int r = i / HID, k = i - r * HID;
+      const int e = (e4_ + r < a.N) ? e4_ + r : a.N - 1;
+      ws[LAY::H0 + i] = a.states_in[(size_t)e * SD + HID + k];
+      ws[LAY::H1 + i] = a.states_in[(size_t)e * SD + 3 * HID + k];
+    }
+    if (lane0_ < 4) {
+      const int e = (e4_ + lane0_ < a.N) ? e4_ + lane0_ : a.N - 1;
+      ws[LAY::DON + lane0_] = a.dones[e] ? 1.0f : 0.0f;
+      ws[LAY::REW + lane0_] = a.prev_reward ? a.prev_reward[e] : 0.0f;
+    }
+  }
+  __syncthreads();   // the LDS image and the head weights have landed
+  for (int k = 0; k < steps; k++) {
+    int lane = lane0_;
+    asm volatile("" : "+v"(lane));
+    a.row = row0 + k; a.rng_step = rng0 + k;
+    a.noise = noise0 ? noise0 + (size_t)k * noise_stride : nullptr;
+    lstm_actor_wave_body<HID>(a, e4_, ws, lds_w, head_w, lane, cst, bias);
+    PS_WAVE_SYNC();    // this wave's clipped actions are in its scratch
+    {
+      int env_ = env0_;
+      asm volatile("" : "+v"(env_));
+      if (k > 0) irrl_plain::lane_carry(L);
+      irrl_plain::ActionRegs act;
+#pragma unroll
+      for (int j = 0; j < 3; j++) act.a[j] = ws[LAY::ACT + rl_ * 12 + leg0_ * 3 + j];
+      irrl_plain::step_compute<1, irrl_plain::NoStepHook>(
+          P, L, env_, leg0_, valid0_, act, ob, reward, done, extra, irrl_plain::NoStepHook(),
+          [&](const irrl_plain::EnvLane &Lf, float rew, bool dn) {
+            irrl_plain::observe_write(P, rl_, leg0_, valid0_, Lf, ws + LAY::X);
+            if (valid0_ && leg0_ == 0) { ws[LAY::REW + rl_] = rew; ws[LAY::DON + rl_] = dn ? 1.0f : 0.0f; }
+          });
+    }
+    PS_WAVE_SYNC();    // observations / done flags / rewards of step k are in the scratch
+  }
+  if (steps > 0) {
+    IRRL_SUB0_ONLY_BEGIN
+    irrl_plain::store_lane(P, S, env0_, leg0_, valid0_, L, P.randomize_per_episode != 0);
+    IRRL_SUB0_ONLY_END
+    if (pok_) {      // the actor's LSTM state behind the last step (the critic's half is the caller's: ppo2.Runner._critic_pass)
+#pragma unroll
+      for (int G = 0; G < NG; G++) {
+        const int u = 16 * G + pq_;
+        a.states_out[(size_t)pe_ * SD + u] = cst[0][G];
+        a.states_out[(size_t)pe_ * SD + HID + u] = ws[LAY::H0 + pr_ * HID + u];
+        a.states_out[(size_t)pe_ * SD + 2 * HID + u] = cst[1][G];
+        a.states_out[(size_t)pe_ * SD + 3 * HID + u] = ws[LAY::H1 + pr_ * HID + u];
+      }
+    }
+  }
+}
+#endif
+
+#if IRRL_LANES_PER_ROBOT == 16
 // THE SAME FOR MlpPolicy (BASELINE config 2's learner): the whole rollout in one launch, a workgroup = 16 robots = four env waves = the
 // four waves of the policy step (two per network).  The policy's 52 KB of weights and biases are copied to LDS ONCE; a step of the
 // policy part is then two short MFMA blocks on LDS operands + the heads (a few us against 8.7 us for the stand-alone launch, whose

@@ -33,6 +33,7 @@ extern "C" __global__ void irrl_terminal_kernel(EnvParams, EnvState, uint8_t *);
 extern "C" __global__ void irrl_step_policy_kernel_l16(EnvParams, EnvState, const float *, float *, float *, uint8_t *, float *, PolicyStepArgs);
 extern "C" __global__ void irrl_rollout_persistent_kernel_l16(EnvParams, EnvState, float *, float *, uint8_t *, float *, PolicyStepArgs, int);
 extern "C" __global__ void irrl_rollout_persistent_actor_kernel_l16(EnvParams, EnvState, float *, float *, uint8_t *, float *, PolicyStepArgs, int);
+extern "C" __global__ void irrl_rollout_persistent_actor_wave_kernel_l16(EnvParams, EnvState, float *, float *, uint8_t *, float *, PolicyStepArgs, int);
 extern "C" __global__ void irrl_rollout_persistent_mlp_kernel_l16(EnvParams, EnvState, float *, float *, uint8_t *, float *, PolicyStepArgs, int);
 
 #include "irrl_config.hpp"
@@ -355,9 +356,14 @@ int irrl_lstm_rollout(irrl_env *h, int steps, int hid, int ob_dim, int act_dim, 
     a.mb_rewards = mb_rewards; a.prev_reward = mb_rewards ? env_reward : nullptr;
     a.rng_step = rng_step; a.rng_seed = rng_seed; a.rng_on = rng_on; a.env_id_offset = (unsigned)env_id_offset;
     a.N = n; a.ob_dim = ob_dim; a.act_dim = act_dim;
-    if (fuse == 3)
-      hipLaunchKernelGGL(irrl_rollout_persistent_actor_kernel_l16, dim3((n + 15) / 16), dim3(256), 0, h->stream, h->P, h->S, obs, env_reward, dones, env_extra, a, steps);
-    else
+    if (fuse == 3) {
+      // the actor as each wave's own work (round 5, second half); IRRL_ACTOR_WAVES=0: the workgroup-wide actor step (same buffers, bit for bit)
+      const char *aw = getenv("IRRL_ACTOR_WAVES");
+      if (aw && aw[0] == '0')
+        hipLaunchKernelGGL(irrl_rollout_persistent_actor_kernel_l16, dim3((n + 15) / 16), dim3(256), 0, h->stream, h->P, h->S, obs, env_reward, dones, env_extra, a, steps);
+      else
+        hipLaunchKernelGGL(irrl_rollout_persistent_actor_wave_kernel_l16, dim3((n + 15) / 16), dim3(256), 0, h->stream, h->P, h->S, obs, env_reward, dones, env_extra, a, steps);
+    } else
       hipLaunchKernelGGL(irrl_rollout_persistent_kernel_l16, dim3((n + 15) / 16), dim3(256), 0, h->stream, h->P, h->S, obs, env_reward, dones, env_extra, a, steps);
     HIP_TRY(hipGetLastError());
     return 0;

@@ -185,7 +185,8 @@ struct MlpWaveLds {
 // XLDS: the persistent rollout kernel -- observations, reward and done flag of the wave's robots are in its scratch already (its own env step
 // left them there next to the stores to memory), and the clipped actions are left there for that env step: inside the step loop nothing a wave
 // reads comes back from memory, so nothing waits for a store to complete
-template <int HID, bool XLDS>
+// LAY: the scratch layout (offsets X, ACT, REW, DON); NO_VALUE: the critic is not part of the step (the actor-only LSTM rollout)
+template <int HID, bool XLDS, class LAY, bool NO_VALUE = false>
 LSTM_DEV void policy_heads_wave(const PolicyStepArgs &a, float *ws, const float *hpi, const float *hv, int LD, const float *pw, const float *vw, float (*terms)[17],
                                 int e4, int l, long long t, long long gstep) {
   // lane (env, action) for the mean / sample, four more lanes for the value and the neglogp sum (policy_heads with 4 envs instead of 16)
@@ -216,13 +217,13 @@ LSTM_DEV void policy_heads_wave(const PolicyStepArgs &a, float *ws, const float 
     const float cl = fminf(fmaxf(act, -1.0f), 1.0f);
     a.action[o] = act;
     a.clipped[o] = cl;
-    if (XLDS) ws[MlpWaveLds<HID>::ACT + env * A + ai] = cl;
+    if (XLDS) ws[LAY::ACT + env * A + ai] = cl;
     if (a.mb_actions) a.mb_actions[(size_t)t * a.N * A + o] = act;
   }
   float val = 0.0f;
   const int vt = l - 4 * A;
   const bool vok = vt >= 0 && vt < 4 && e4 + vt < a.N;
-  if (vok) {
+  if (vok && !NO_VALUE) {
     val = a.vf_b[0];
 #pragma unroll
     for (int k = 0; k < HID; k++) val = __builtin_fmaf(hv[vt * LD + k], vw[k], val);
@@ -233,19 +234,19 @@ LSTM_DEV void policy_heads_wave(const PolicyStepArgs &a, float *ws, const float 
     for (int ai = 0; ai < A; ai++) nl += terms[vt][ai];
     nl = __builtin_fmaf((float)A, 0.918938533204672742f, nl);
     const int e = e4 + vt;
-    a.value[e] = val;
+    if (!NO_VALUE) a.value[e] = val;
     a.neglogp[e] = nl;
     if (a.mb_values) {
-      a.mb_values[(size_t)t * a.N + e] = val;
+      if (!NO_VALUE) a.mb_values[(size_t)t * a.N + e] = val;
       a.mb_neglogp[(size_t)t * a.N + e] = nl;
-      a.mb_dones[(size_t)t * a.N + e] = XLDS ? (uint8_t)(ws[MlpWaveLds<HID>::DON + vt] != 0.0f) : a.dones[e];
-      if (a.prev_reward && t > 0) a.mb_rewards[(size_t)(t - 1) * a.N + e] = XLDS ? ws[MlpWaveLds<HID>::REW + vt] : a.prev_reward[e];
+      a.mb_dones[(size_t)t * a.N + e] = XLDS ? (uint8_t)(ws[LAY::DON + vt] != 0.0f) : a.dones[e];
+      if (a.prev_reward && t > 0) a.mb_rewards[(size_t)(t - 1) * a.N + e] = XLDS ? ws[LAY::REW + vt] : a.prev_reward[e];
     }
   }
   if (a.mb_obs && e4 < a.N) {      // the row of the observations the step was computed from: out of the scratch (the values a.obs holds)
     const int n = ((a.N - e4 < 4) ? a.N - e4 : 4) * a.ob_dim;
     float *dst = a.mb_obs + ((size_t)t * a.N + e4) * a.ob_dim;
-    for (int i = l; i < n; i += 64) dst[i] = ws[MlpWaveLds<HID>::X + i];
+    for (int i = l; i < n; i += 64) dst[i] = ws[LAY::X + i];
   }
 }
 
@@ -307,7 +308,7 @@ LSTM_DEV void mlp_policy_wave_body(const PolicyStepArgs &a, const int e4, float 
 #pragma unroll
   for (int r = 0; r < 4; r++) { h2[r * LD + l] = fast_tanh(ap[r]); h2[4 * LD + r * LD + l] = fast_tanh(av[r]); }
   PS_WAVE_SYNC();
-  policy_heads_wave<H, XLDS>(a, ws, h2, h2 + 4 * LD, LD, LDSW ? head_w : a.pi_w, LDSW ? head_w + H * a.act_dim : a.vf_w, terms, e4, l, t, gstep);
+  policy_heads_wave<H, XLDS, MlpWaveLds<H>>(a, ws, h2, h2 + 4 * LD, LD, LDSW ? head_w : a.pi_w, LDSW ? head_w + H * a.act_dim : a.vf_w, terms, e4, l, t, gstep);
 }
 #ifdef IRRL_PROFILE_POLICY   /* diagnostic build (tools/policy_phases.py): 100 MHz time stamps of the phases of one workgroup */
 #define IRRL_PS_STAMP() do { __builtin_amdgcn_sched_barrier(0); ts_[tsn_++] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -636,4 +637,160 @@ LSTM_DEV void policy_step_body(const PolicyStepArgs &a, const int e0, float (*hb
 #else
   (void)prof_t0; (void)prof_t1;
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// THE ACTOR STACK OF CustomLSTMPolicy BY ONE WAVE FOR ITS OWN FOUR ENVS (round 5; the LSTM twin of mlp_policy_wave_body, for the actor-only
+// persistent rollout).  Same idea: v_mfma_f32_4x4x1_16b_f32 with lane = gate column, accumulator register = robot -- the 192 gate columns of a
+// layer are three column groups, i.e. three independent chains over K -- the operand rows out of the LDS image of policy_prefetch_lds_actor as
+// they lie there ([k][unit][gate]: a row is 192 consecutive floats), h of both layers in the wave's scratch, c in registers for the whole
+// rollout.  BIT-IDENTICAL to policy_step_body's actor (so to every other rollout mode): a 16 x 16 x 4 MFMA adds its four products to the
+// accumulator one after the other in k order, which is what four 4 x 4 x 1 instructions do -- so the chains below walk K in policy_step_body's
+// order (recurrent part first, in its permuted order 16 m + 4 rq + j; then the input part), and the cell is its cell, statement for statement.
+// A gate column's four robots sit in one lane's accumulator registers and a unit's four gates in the four lanes of a quad: a 4 x 4 transpose
+// inside the quad (two DPP butterflies) hands lane (unit, j) the four gates of robot j, and every lane runs ONE cell per column group.
+template <int HID>
+struct LstmWaveLds { static constexpr int X = 0, ACT = 144, REW = 192, DON = 196, H0 = 200, H1 = H0 + 4 * HID, TERMS = H1 + 4 * HID, FLOATS = TERMS + 4 * 17; };
+
+LSTM_DEV float ps_quad_xor1(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true)); }
+LSTM_DEV float ps_quad_xor2(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true)); }
+// M[lane of the quad][register] -> its transpose
+LSTM_DEV void ps_quad_transpose(f32x4 &m, int l) {
+  const bool o1 = l & 1, o2 = l & 2;
+  {
+    const float r01 = ps_quad_xor1(o1 ? m[0] : m[1]), r23 = ps_quad_xor1(o1 ? m[2] : m[3]);
+    if (o1) { m[0] = r01; m[2] = r23; } else { m[1] = r01; m[3] = r23; }
+  }
+  {
+    const float r02 = ps_quad_xor2(o2 ? m[0] : m[2]), r13 = ps_quad_xor2(o2 ? m[1] : m[3]);
+    if (o2) { m[0] = r02; m[1] = r13; } else { m[2] = r02; m[3] = r13; }
+  }
+}
+
+// The actor's operands for the wave body: TRANSPOSED, [gate column][K] with K = wh0 (HID) | wx0 (36: ob_dim rows, the rest copies of the last
+// row -- what policy_step_body's masked k-step multiplies by zero) | wh1 (HID) | wx1 (HID) -- a lane owns a gate column per column group, so its
+// B operands for FOUR consecutive k are one ds_read_b128 (a quarter of the LDS instructions of row-wise reads, which is what the step waited
+// for: 13.6 -> see DESIGN 3.2); rows of 180 floats: 16 consecutive lanes' 16-byte reads fall into 16 different bank quads.
+template <int HID>
+struct LstmWaveImage { static constexpr int XK = 36, K = 3 * HID + XK, OWH0 = 0, OWX0 = HID, OWH1 = HID + XK, OWX1 = 2 * HID + XK, FLOATS = 4 * HID * K; };
+template <int HID, int NTHR>
+LSTM_DEV void lstm_wave_image_stage(const PolicyStepArgs &a, float *wt) {
+  typedef LstmWaveImage<HID> IMG;
+  constexpr int GC = 4 * HID;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < HID * GC; i += NTHR) {
+    const int k = i / GC, c = i - k * GC;
+    wt[c * IMG::K + IMG::OWH0 + k] = a.w[1][i];
+    wt[c * IMG::K + IMG::OWH1 + k] = a.w[4][i];
+    wt[c * IMG::K + IMG::OWX1 + k] = a.w[3][i];
+  }
+  for (int i = tid; i < IMG::XK * GC; i += NTHR) {
+    const int k = i / GC, c = i - k * GC, kc = k < a.ob_dim ? k : a.ob_dim - 1;
+    wt[c * IMG::K + IMG::OWX0 + k] = a.w[0][kc * GC + c];
+  }
+}
+
+// cst: c of layer 0 / layer 1 for (robot l & 3, unit 16 G + (l >> 2)), G = 0 .. HID / 16 - 1; bias: the lane's gate columns 64 G + l of both layers
+template <int HID>
+LSTM_DEV void lstm_actor_wave_body(const PolicyStepArgs &a, const int e4, float *ws, const float *wt, const float *head_w, const int l,
+                                   float (&cst)[2][HID / 16], const float (&bias)[2][HID / 16]) {
+  typedef LstmWaveLds<HID> LAY;
+  typedef LstmWaveImage<HID> IMG;
+  constexpr int NG = HID / 16, GC = 4 * HID;
+  static_assert(GC == 64 * NG, "three column groups of 64 lanes");
+  float *xs = ws + LAY::X, *h0 = ws + LAY::H0, *h1 = ws + LAY::H1;
+  float (*terms)[17] = (float (*)[17])(ws + LAY::TERMS);
+  const long long t = a.row;
+  const long long gstep = a.rng_step + (a.rng_base ? *a.rng_base : 0ll);
+  const int r4 = l & 3, q = l >> 2, OB = a.ob_dim;
+  const float keep = ws[LAY::DON + r4] != 0.0f ? 0.0f : 1.0f;
+  const float *wl = wt + (size_t)l * IMG::K;      // this lane's column of group 0; group G: + 64 G columns
+  f32x4 acc[NG];
+  // sixteen k of a chain in policy_step_body's order k = 16 m + 4 rq + j (j outer, rq inner: one of its MFMAs is the four rq); av[rq][j]: the A operand
+  auto group16 = [&](const f32x4 (&av)[4], int off) {
+    f32x4 wv[NG][4];
+#pragma unroll
+    for (int G = 0; G < NG; G++)
+#pragma unroll
+      for (int rq = 0; rq < 4; rq++) wv[G][rq] = *(const f32x4 *)&wl[64 * G * IMG::K + off + 4 * rq];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int rq = 0; rq < 4; rq++)
+#pragma unroll
+        for (int G = 0; G < NG; G++) acc[G] = PS_MFMA4(av[rq][j], wv[G][rq][j], acc[G]);
+  };
+  auto recurrent = [&](const float *hprev, int off) {
+#pragma unroll
+    for (int m = 0; m < HID / 16; m++) {
+      f32x4 hv[4];
+#pragma unroll
+      for (int rq = 0; rq < 4; rq++) hv[rq] = *(const f32x4 *)&hprev[r4 * HID + 16 * m + 4 * rq] * keep;
+      group16(hv, off + 16 * m);
+    }
+  };
+  // the cell of (robot r4, unit 16 G + q) for every column group; h into `hout`
+  auto cell = [&](float (&c)[NG], float *hout) {
+#pragma unroll
+    for (int G = 0; G < NG; G++) {
+      ps_quad_transpose(acc[G], l);
+      const float ig = fast_sigmoid(acc[G][0]), fg = fast_sigmoid(acc[G][1]), og = fast_sigmoid(acc[G][2]), gg = fast_tanh(acc[G][3]);
+      const float cn = fg * (c[G] * keep) + ig * gg;
+      const float hn = og * fast_tanh(cn);
+      c[G] = cn;
+      hout[r4 * HID + 16 * G + q] = hn;
+    }
+  };
+  // ---- layer 0 ----
+#pragma unroll
+  for (int G = 0; G < NG; G++) acc[G] = (f32x4){bias[0][G], bias[0][G], bias[0][G], bias[0][G]};
+  recurrent(h0, IMG::OWH0);
+  {
+    // the observation part in policy_step_body's order: whole groups of 16 permuted like the recurrent part, the rest in plain order, padded
+    // to a multiple of four with x = 0 against the last row
+    const int obv = ((OB + 3) / 4 - 1) / 4;          // whole 16-element groups (its OBV)
+    for (int m = 0; m < obv; m++) {
+      f32x4 xv[4];
+#pragma unroll
+      for (int rq = 0; rq < 4; rq++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) xv[rq][j] = xs[r4 * OB + 16 * m + 4 * rq + j];
+      group16(xv, IMG::OWX0 + 16 * m);
+    }
+    for (int k = 16 * obv; k < ((OB + 3) & ~3); k += 4) {
+      f32x4 wv[NG];
+#pragma unroll
+      for (int G = 0; G < NG; G++) wv[G] = *(const f32x4 *)&wl[64 * G * IMG::K + IMG::OWX0 + k];
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        const int kc = k + kk < OB ? k + kk : OB - 1;
+        const float xv = xs[r4 * OB + kc];
+        const float av = k + kk < OB ? xv : 0.0f;
+#pragma unroll
+        for (int G = 0; G < NG; G++) acc[G] = PS_MFMA4(av, wv[G][kk], acc[G]);
+      }
+    }
+  }
+  PS_WAVE_SYNC();      // every lane has read the previous h of layer 0
+  cell(cst[0], h0);
+  PS_WAVE_SYNC();
+  // ---- layer 1: the recurrent part first, then the input part (layer 0's new h, plain k order, no mask) ----
+#pragma unroll
+  for (int G = 0; G < NG; G++) acc[G] = (f32x4){bias[1][G], bias[1][G], bias[1][G], bias[1][G]};
+  recurrent(h1, IMG::OWH1);
+#pragma unroll
+  for (int k = 0; k < HID; k += 4) {
+    const f32x4 x4 = *(const f32x4 *)&h0[r4 * HID + k];
+    f32x4 wv[NG];
+#pragma unroll
+    for (int G = 0; G < NG; G++) wv[G] = *(const f32x4 *)&wl[64 * G * IMG::K + IMG::OWX1 + k];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+      for (int G = 0; G < NG; G++) acc[G] = PS_MFMA4(x4[kk], wv[G][kk], acc[G]);
+  }
+  PS_WAVE_SYNC();
+  cell(cst[1], h1);
+  PS_WAVE_SYNC();
+  policy_heads_wave<HID, true, LAY, true>(a, ws, h1, h1, HID, head_w, head_w, terms, e4, l, t, gstep);
 }
