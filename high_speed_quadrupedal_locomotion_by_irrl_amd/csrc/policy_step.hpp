@@ -143,18 +143,21 @@ LSTM_DEV void policy_heads(const PolicyStepArgs &a, const float *hpi, const floa
 // One rollout step of MlpPolicy (policies.py:430-446: separate pi / vf nets of two tanh layers of H units).
 // a.w[] = pi_w1 [ob][H], pi_b1, pi_w2 [H][H], pi_b2, vf_w1, vf_b1, vf_w2, vf_b2 (plain row-major).
 // LDSW: the eight arrays were copied to LDS once (mlp_policy_stage_lds: the persistent rollout kernel, whose workgroup keeps them for all
-// steps) in the image [net][w1 (36 x H, rows beyond ob_dim zero) | b1 (H) | w2 (H x H) | b2 (H)], and the head weights sit in head_w; otherwise
-// they are read from global memory (the stand-alone kernel).  Same values, same order of operations: the two agree bit for bit.
+// steps), TRANSPOSED: per network [hidden unit][K = 36 rows of w1 (beyond ob_dim: the last row again, which is what the other form multiplies its x = 0 with) | 64 rows of w2] -- a lane owns a hidden unit, so its B
+// operands for four consecutive k are one ds_read_b128 (rows of 100 floats: 16 consecutive lanes' reads fall into 16 different bank quads) --
+// then b1 | b2; the head weights sit in head_w.  Otherwise everything is read from global memory as it lies there (the stand-alone kernel).
+// Same values, same order of operations: the two agree bit for bit.
 template <int H>
-struct MlpLdsImage { static constexpr int OBMAX = 36, NET = OBMAX * H + H + H * H + H, FLOATS = 2 * NET; };
+struct MlpLdsImage { static constexpr int OBMAX = 36, KW = OBMAX + H, B1 = H * KW, B2 = B1 + H, NET = B2 + H, FLOATS = 2 * NET; };
 template <int H>
 LSTM_DEV void mlp_policy_stage_lds(const PolicyStepArgs &a, float *wl, float *head_w, int tid, int nthr) {
+  typedef MlpLdsImage<H> IMG;
   for (int net = 0; net < 2; net++) {
-    float *dst = wl + net * MlpLdsImage<H>::NET;
+    float *dst = wl + net * IMG::NET;
     const float *w1 = a.w[4 * net], *b1 = a.w[4 * net + 1], *w2 = a.w[4 * net + 2], *b2 = a.w[4 * net + 3];
-    for (int i = tid; i < MlpLdsImage<H>::OBMAX * H; i += nthr) dst[i] = (i < a.ob_dim * H) ? w1[i] : 0.0f;      // (rows beyond ob_dim: zeros)
-    for (int i = tid; i < H; i += nthr) { dst[MlpLdsImage<H>::OBMAX * H + i] = b1[i]; dst[MlpLdsImage<H>::OBMAX * H + H + H * H + i] = b2[i]; }
-    for (int i = tid; i < H * H; i += nthr) dst[MlpLdsImage<H>::OBMAX * H + H + i] = w2[i];
+    for (int i = tid; i < IMG::OBMAX * H; i += nthr) { const int k = i / H, u = i - k * H; dst[u * IMG::KW + k] = w1[(k < a.ob_dim ? k : a.ob_dim - 1) * H + u]; }
+    for (int i = tid; i < H * H; i += nthr) { const int k = i / H, u = i - k * H; dst[u * IMG::KW + IMG::OBMAX + k] = w2[i]; }
+    for (int i = tid; i < H; i += nthr) { dst[IMG::B1 + i] = b1[i]; dst[IMG::B2 + i] = b2[i]; }
   }
   for (int i = tid; i < H * a.act_dim; i += nthr) head_w[i] = a.pi_w[i];
   if (tid < H) head_w[H * a.act_dim + tid] = a.vf_w[tid];
@@ -260,9 +263,11 @@ LSTM_DEV void mlp_policy_wave_body(const PolicyStepArgs &a, const int e4, float 
   const long long gstep = a.rng_step + (a.rng_base ? *a.rng_base : 0ll);
   const int r4 = l & 3, OB = a.ob_dim;
   const float *w1p, *b1p, *w2p, *b2p, *w1v, *b1v, *w2v, *b2v;
+  typedef MlpLdsImage<H> IMG;
+  const float *tp = wl + (size_t)l * IMG::KW, *tv = tp + IMG::NET;      // (LDSW) this lane's unit in the transposed images
   if (LDSW) {
-    w1p = wl; b1p = w1p + MlpLdsImage<H>::OBMAX * H; w2p = b1p + H; b2p = w2p + H * H;
-    w1v = wl + MlpLdsImage<H>::NET; b1v = w1v + MlpLdsImage<H>::OBMAX * H; w2v = b1v + H; b2v = w2v + H * H;
+    w1p = w2p = w1v = w2v = nullptr;
+    b1p = wl + IMG::B1; b2p = wl + IMG::B2; b1v = b1p + IMG::NET; b2v = b2p + IMG::NET;
   } else {
     w1p = a.w[0]; b1p = a.w[1]; w2p = a.w[2]; b2p = a.w[3]; w1v = a.w[4]; b1v = a.w[5]; w2v = a.w[6]; b2v = a.w[7];
   }
@@ -278,13 +283,15 @@ LSTM_DEV void mlp_policy_wave_body(const PolicyStepArgs &a, const int e4, float 
 #pragma unroll 3
   for (int k = 0; k < OB; k += 4) {
     float x[4], bp[4], bv[4];
+    f32x4 p4 = {0.0f, 0.0f, 0.0f, 0.0f}, v4 = p4;
+    if (LDSW) { p4 = *(const f32x4 *)&tp[k]; v4 = *(const f32x4 *)&tv[k]; }
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) {
       const int kc = (k + kk < OB) ? k + kk : OB - 1;
       const float xv = xs[r4 * OB + kc];
       x[kk] = (k + kk < OB) ? xv : 0.0f;
-      bp[kk] = w1p[(size_t)kc * H + l];
-      bv[kk] = w1v[(size_t)kc * H + l];
+      bp[kk] = LDSW ? p4[kk] : w1p[(size_t)kc * H + l];
+      bv[kk] = LDSW ? v4[kk] : w1v[(size_t)kc * H + l];
     }
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) {
@@ -299,10 +306,12 @@ LSTM_DEV void mlp_policy_wave_body(const PolicyStepArgs &a, const int e4, float 
 #pragma unroll 4
   for (int k = 0; k < H; k += 4) {
     const f32x4 p4 = *(const f32x4 *)&h1[r4 * LD + k], v4 = *(const f32x4 *)&h1[4 * LD + r4 * LD + k];
+    f32x4 wp = {0.0f, 0.0f, 0.0f, 0.0f}, wv = wp;
+    if (LDSW) { wp = *(const f32x4 *)&tp[IMG::OBMAX + k]; wv = *(const f32x4 *)&tv[IMG::OBMAX + k]; }
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) {
-      ap = PS_MFMA4(p4[kk], w2p[(size_t)(k + kk) * H + l], ap);
-      av = PS_MFMA4(v4[kk], w2v[(size_t)(k + kk) * H + l], av);
+      ap = PS_MFMA4(p4[kk], LDSW ? wp[kk] : w2p[(size_t)(k + kk) * H + l], ap);
+      av = PS_MFMA4(v4[kk], LDSW ? wv[kk] : w2v[(size_t)(k + kk) * H + l], av);
     }
   }
 #pragma unroll
