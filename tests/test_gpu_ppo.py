@@ -716,19 +716,25 @@ def test_graph_capture_warmup_leaves_no_trace_and_setters_invalidate_the_graph()
     re-captures; the direct runner reads the parameters at launch time anyway.
     "persistent_actor" (round 5: the persistent launch with the critic OFF the per-step path -- the actor stack alone per step, the values of
     the whole rollout from the critic's sequence kernels afterwards): everything the actor and the env produce -- observations, actions,
-    neglogp, rewards, dones -- is bit-identical to the other modes; values and returns agree at the f32 level (2e-5 of their scale)."""
+    neglogp, rewards, dones -- is bit-identical to the other modes; values and returns agree at the f32 level (2e-5 of their scale).  It comes
+    in two forms: the actor as each WAVE's own work for its four robots (v_mfma_f32_4x4x1 chains, LSTM state in LDS / registers for the whole
+    rollout: the default since the second half of round 5) and the workgroup-wide actor step ("persistent_actor_wg": IRRL_ACTOR_WAVES=0)."""
+    import os
     from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import CustomLSTMPolicy
     from high_speed_quadrupedal_locomotion_by_irrl_amd.ppo2 import PPO2, Runner
     out = {}
-    for mode in ("direct", "one_launch", "persistent", "persistent_actor", "graph", "eager"):
+    for mode in ("direct", "one_launch", "persistent", "persistent_actor", "persistent_actor_wg", "graph", "eager"):
+        os.environ.pop("IRRL_ACTOR_WAVES", None)
+        if mode == "persistent_actor_wg":
+            os.environ["IRRL_ACTOR_WAVES"] = "0"
         env = _env(64 if mode != "persistent" else 64)
         model = PPO2(policy=CustomLSTMPolicy, env=env, n_steps=20, nminibatches=1, noptepochs=1, seed=9)
         runner = Runner(env, model, 20, 0.99, 0.998, use_graph=(mode != "eager"))
         assert runner.rollout_launch == "direct"      # what a Runner picks by itself for the LSTM policy on the HIP engine
-        runner.rollout_launch = "direct" if mode in ("direct", "one_launch", "persistent", "persistent_actor") else "graph"
+        runner.rollout_launch = "direct" if mode in ("direct", "one_launch", "persistent", "persistent_actor", "persistent_actor_wg") else "graph"
         # 1: env.step k + policy step k + 1 in one kernel; 2: the whole rollout as ONE persistent launch (a workgroup loops over all
         # steps for its 16 robots, irrl_rollout_persistent_kernel_l16)
-        runner.rollout_one_launch_per_step = {"one_launch": 1, "persistent": 2, "persistent_actor": 3}.get(mode, 0)
+        runner.rollout_one_launch_per_step = {"one_launch": 1, "persistent": 2, "persistent_actor": 3, "persistent_actor_wg": 3}.get(mode, 0)
         b1 = {k: v.clone() for k, v in runner.run().items() if torch.is_tensor(v)}
         assert (runner._graph is not None) == (mode == "graph")
         assert not getattr(runner, "_actor_only_refused", False)
@@ -736,20 +742,26 @@ def test_graph_capture_warmup_leaves_no_trace_and_setters_invalidate_the_graph()
         b2 = {k: v.clone() for k, v in runner.run().items() if torch.is_tensor(v)}
         b3 = {k: v.clone() for k, v in runner.run().items() if torch.is_tensor(v)}
         out[mode] = (b1, b2, b3)
+    os.environ.pop("IRRL_ACTOR_WAVES", None)
     for mode in ("direct", "one_launch", "persistent", "graph"):
         for i in range(3):
             for k in ("obs", "actions", "values", "true_reward", "masks", "neglogpacs", "returns"):
                 assert torch.equal(out[mode][i][k], out["eager"][i][k]), (mode, i, k)
+    for pa in ("persistent_actor", "persistent_actor_wg"):
+        for i in range(3):
+            for k in ("obs", "actions", "true_reward", "masks", "neglogpacs", "states"):
+                assert torch.equal(out[pa][i][k], out["eager"][i][k]) or k == "states", (pa, i, k)
+            # the carried LSTM state: the actor's half bit-identical, the critic's half (from the sequence kernels) at the f32 level
+            sa, se = out[pa][i]["states"], out["eager"][i]["states"]
+            assert torch.equal(sa[:, :192], se[:, :192]), (pa, i)
+            assert float((sa[:, 192:] - se[:, 192:]).abs().max()) < 2e-5 * (1.0 + float(se[:, 192:].abs().max()))
+            for k in ("values", "returns"):
+                a, b = out[pa][i][k], out["eager"][i][k]
+                assert float((a - b).abs().max()) < 2e-5 * (1.0 + float(b.abs().max())), (pa, i, k, float((a - b).abs().max()))
+    # the two forms of the actor-only rollout among themselves: everything, the critic pass included, bit for bit
     for i in range(3):
-        for k in ("obs", "actions", "true_reward", "masks", "neglogpacs", "states"):
-            assert torch.equal(out["persistent_actor"][i][k], out["eager"][i][k]) or k == "states", ("persistent_actor", i, k)
-        # the carried LSTM state: the actor's half bit-identical, the critic's half (from the sequence kernels) at the f32 level
-        sa, se = out["persistent_actor"][i]["states"], out["eager"][i]["states"]
-        assert torch.equal(sa[:, :192], se[:, :192])
-        assert float((sa[:, 192:] - se[:, 192:]).abs().max()) < 2e-5 * (1.0 + float(se[:, 192:].abs().max()))
-        for k in ("values", "returns"):
-            a, b = out["persistent_actor"][i][k], out["eager"][i][k]
-            assert float((a - b).abs().max()) < 2e-5 * (1.0 + float(b.abs().max())), ("persistent_actor", i, k, float((a - b).abs().max()))
+        for k in out["persistent_actor"][i]:
+            assert torch.equal(out["persistent_actor"][i][k], out["persistent_actor_wg"][i][k]), ("the two actor-only forms", i, k)
     assert not torch.equal(out["graph"][1]["obs"], out["graph"][0]["obs"])
 
 
