@@ -357,10 +357,10 @@ irrl_rollout_persistent_actor_wave_kernel_l16(EnvParams P, EnvState S, float *ob
 #endif
 
 #if IRRL_LANES_PER_ROBOT == 16
-// THE SAME FOR MlpPolicy (BASELINE config 2's learner): the whole rollout in one launch, a workgroup = 16 robots = four env waves = the
-// four waves of the policy step (two per network).  The policy's 52 KB of weights and biases are copied to LDS ONCE; a step of the
-// policy part is then two short MFMA blocks on LDS operands + the heads (a few us against 8.7 us for the stand-alone launch, whose
-// life is launch + weight fetch), and a step costs the workgroup its own time instead of the slowest of the 1024 env waves.
+// THE SAME FOR MlpPolicy (BASELINE config 2's learner): the whole rollout in one launch.  The policy's 52 KB of weights and biases are copied
+// to LDS ONCE (transposed: mlp_policy_stage_lds); a step of the policy part is then two MFMA chains on LDS operands + the heads (a few us
+// against 8.7 us for the stand-alone launch, whose life is launch + weight fetch), and a step costs a WAVE its own time instead of the slowest
+// of the 1024 env waves: since the second half of round 5 the policy of a wave's four robots is that wave's own work (see inside).
 // Same device functions, same order: the buffers are bit-identical to the two-launch sequence.
 __global__ void __launch_bounds__(256, 1)
 irrl_rollout_persistent_mlp_kernel_l16(EnvParams P, EnvState S, float *ob, float *reward, uint8_t *done, float *extra, PolicyStepArgs a, int steps) {

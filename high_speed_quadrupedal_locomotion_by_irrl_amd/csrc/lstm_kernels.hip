@@ -771,7 +771,7 @@ lstm_policy_step_kernel(PolicyStepArgs a) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // The same single-launch rollout step for MlpPolicy (policies.py:430-446: separate pi / vf nets of two tanh layers of H
-// units).  A workgroup owns 16 envs; waves 0-1 run the pi net, waves 2-3 the vf net, two 16-column tiles each.
+// units).  A workgroup owns 16 envs, each of its four waves four of them (mlp_policy_wave_body, policy_step.hpp: both nets on 4 x 4 x 1 MFMAs).
 // a.w[] = pi_w1 [ob][H], pi_b1, pi_w2 [H][H], pi_b2, vf_w1, vf_b1, vf_w2, vf_b2 (plain row-major, no permutation).
 template <int H>
 __global__ void __launch_bounds__(256)
