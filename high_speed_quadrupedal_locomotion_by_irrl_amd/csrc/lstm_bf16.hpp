@@ -10,7 +10,7 @@
 // Per unit of K that is 0.68 / 1.36 ns against 3.48 ns.  Accumulation stays f32 inside the MFMA, small planes first.
 //
 // Mapping (HID = 48, n_in <= 48, the reference's network).  A workgroup owns 16 envs for all T steps.
-//   forward  (3 waves): wave w owns hidden units 16 w .. 16 w + 15 with their four gates; z_t = b + [h_{t-1} keep_t | x_t] [wh ; wx] is
+//   forward  (3 compute waves + the loader wave, see the kernel): wave w owns hidden units 16 w .. 16 w + 15 with their four gates; z_t = b + [h_{t-1} keep_t | x_t] [wh ; wx] is
 //            ONE contraction over K = 96 = 3 chunks of 32; the A operand ([env][k] bf16 planes, h written by its owners at the end of
 //            step t - 1, x_t staged by all lanes one step ahead) lives in a double-buffered LDS tile, the B fragments (weights,
 //            split once) stay in registers for the whole sequence.  36 (NS 2) / 72 (NS 3) MFMAs + the cell per wave and step, one
@@ -54,23 +54,102 @@ struct LstmFwdBf16Args {
 };
 constexpr int LBF_HID = 48, LBF_KX = 48, LBF_KF = LBF_HID + LBF_KX;   // forward contraction: [h | x], 96 = 3 chunks of 32
 constexpr int LBF_FROW = LBF_KF + 8;                                    // padded A-tile row (bf16 elements; 208 bytes: 16-byte aligned)
-template <int NS> constexpr int lstm_fwd_bf16_lds_bytes() { return 2 * NS * 16 * LBF_FROW * 2; }
 
 // STORE_GC: the gates and c rows are kept for the backward kernel (the update).  false = INFERENCE (round 5: the critic pass behind an actor-only
 // rollout, ppo2.Runner._critic_pass): only h and the final state leave the kernel -- 384 instead of 1152 bytes stored per env and step.
+//
+// ROUND 5, LAST CHANGE: A FOURTH WAVE THAT DOES ALL THE LOADING, WITH FEW, WIDE LOADS.  Rounds 4-5 measured the symptom -- a pair of forward launches
+// "bound by its stores" at 3.5 TB/s although the same store mix alone streams at 5.9 -- and a probe found the cause
+// (profiles/r05_ab_lstm_fwd_prefetch_same_box.log): with every store kept and NO vector-memory load in the step loop the kernel runs at 751
+// instead of 1216 us; the loads and the stores get in each other's way in the CU's one memory pipeline.  So the two kinds of traffic are split
+// over different waves and the loads made few: waves 0-2 compute and STORE (no vector-memory load after the prologue); wave 3 LOADS -- the x rows
+// (16-byte loads where the row allows, requested XD steps ahead, split to planes and staged into the A tile a step ahead) and the mask rows
+// (published through a small LDS ring) -- and stores nothing.  Same arithmetic, same values, same results bit for bit; the pair 2059 -> ~1600 us.
+#ifndef IRRL_LBF_FWD_XD
+#define IRRL_LBF_FWD_XD 8
+#endif
+constexpr int LBF_FWD_XD = IRRL_LBF_FWD_XD;                             // steps of x / mask rows the loader wave has in flight
+template <int NS> constexpr int lstm_fwd_bf16_lds_bytes() { return 2 * NS * 16 * LBF_FROW * 2 + 4 * 16 * 4; }      // two A tiles + the mask ring
 template <int NS, bool STORE_GC = true>
-__global__ void __launch_bounds__(192)
+__global__ void __launch_bounds__(256)
 lstm_seq_fwd_bf16_kernel(const LstmFwdBf16Args a) {
-  constexpr int HID = LBF_HID, KC = LBF_KF / 32;
+  constexpr int HID = LBF_HID, KC = LBF_KF / 32, XD = LBF_FWD_XD;
   using PR = BfProducts<NS>;
   extern __shared__ __attribute__((aligned(16))) unsigned short lds_f[];
   // At(buf, plane, env, k)
   auto At = [&](int buf, int p, int env, int k) -> unsigned short * { return lds_f + (((size_t)(buf * NS + p) * 16 + env) * LBF_FROW + k); };
+  float *mring = (float *)(lds_f + 2 * NS * 16 * LBF_FROW);            // [4 slots][16 envs]: slot t & 3 holds the masks of step t
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
   const int col = l & 15, rq = l >> 4;
   const int e0 = blockIdx.x * 16;
-  const int u = 16 * w + col;
   const int T = a.T, N = a.N, n_in = a.n_in;
+
+  if (w == 3) {
+    // ---------------- the loader wave: lane (env = l / 4, quarter = l % 4) owns input elements 12 quarter .. 12 quarter + 11 of its env ----------------
+    const int xe = l >> 2, xq = l & 3;
+    // 16-byte loads where a group of four lies inside the row (rows are only 4-byte aligned for n_in = 35), single words at its ragged end, nothing
+    // beyond it: few vector-memory instructions per step, so that XD steps of them fit the wave's 63 outstanding operations
+    auto load_x = [&](int t, float (&dst)[12]) {
+      const float *row = a.x + ((size_t)t * N + e0 + xe) * n_in;
+#pragma unroll
+      for (int g4 = 0; g4 < 3; g4++) {
+        const int k0 = 12 * xq + 4 * g4;
+        if (k0 + 3 < n_in) {
+          const f32x4u v = *(const f32x4u *)&row[k0];
+          dst[4 * g4] = v[0]; dst[4 * g4 + 1] = v[1]; dst[4 * g4 + 2] = v[2]; dst[4 * g4 + 3] = v[3];
+        } else if (k0 < n_in) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) dst[4 * g4 + i] = row[k0 + i < n_in ? k0 + i : n_in - 1];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; i++) dst[4 * g4 + i] = 0.0f;
+        }
+      }
+    };
+    auto stage_x = [&](int buf, const float (&src)[12]) {
+#pragma unroll
+      for (int g4 = 0; g4 < 3; g4++) {
+        u16x4_t pk[NS];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const int k = 12 * xq + 4 * g4 + i;
+          unsigned short pl[NS];
+          bf_split<NS>(k < n_in ? src[4 * g4 + i] : 0.0f, pl);
+#pragma unroll
+          for (int p = 0; p < NS; p++) pk[p][i] = pl[p];
+        }
+#pragma unroll
+        for (int p = 0; p < NS; p++) *(u16x4_t *)At(buf, p, xe, HID + 12 * xq + 4 * g4) = pk[p];
+      }
+    };
+    auto load_m = [&](int t) -> float { const int tc = t < T ? t : T - 1; return a.masks[(size_t)tc * N + e0 + (l & 15)]; };
+    float xr[XD][12], mr[XD];
+    load_x(0, xr[0]);
+    stage_x(0, xr[0]);
+#pragma unroll
+    for (int d = 0; d < XD; d++) {
+      if (d + 1 < T) load_x(d + 1, xr[d]);          // x_{d+1}, staged during step d
+      mr[d] = load_m(d + 2);                         // the masks of step d + 2, published during step d
+    }
+    __syncthreads();
+    for (int t = 0; t < T; t += XD) {
+#pragma unroll
+      for (int d = 0; d < XD; d++) {
+        const int tt = t + d;
+        if (tt < T) {
+          if (tt + 1 < T) stage_x((tt + 1) & 1, xr[d]);
+          if (l < 16) mring[((tt + 2) & 3) * 16 + l] = mr[d];
+          if (tt + 1 + XD < T) load_x(tt + 1 + XD, xr[d]);
+          mr[d] = load_m(tt + 2 + XD);
+          __syncthreads();
+        }
+      }
+    }
+    return;
+  }
+
+  // ---------------- waves 0-2: wave w owns hidden units 16 w .. 16 w + 15 with their four gates ----------------
+  const int u = 16 * w + col;
   // B fragments: B[k = 32 kc + 8 rq + i][column = unit u, gate g]; k < 48: wh_p[k][u][g], else wx_p[k - 48][u][g] (0 beyond n_in)
   u16x8_t Bf[KC][4][NS];
 #pragma unroll
@@ -89,25 +168,6 @@ lstm_seq_fwd_bf16_kernel(const LstmFwdBf16Args a) {
         for (int p = 0; p < NS; p++) Bf[kc][g][p][i] = pl[p];
       }
   const f32x4 bias = *(const f32x4 *)&a.b_p[u * 4];
-  // x staging: the workgroup's 192 lanes cover 16 envs x 12 groups of 4 input elements
-  const int xe = tid / 12, xg = tid % 12;
-  auto load_x = [&](int t, float (&dst)[4]) {
-    const float *row = a.x + ((size_t)t * N + e0 + xe) * n_in;
-#pragma unroll
-    for (int i = 0; i < 4; i++) { const int k = 4 * xg + i; dst[i] = row[k < n_in ? k : n_in - 1]; }
-  };
-  auto stage_x = [&](int buf, const float (&src)[4]) {
-    u16x4_t pk[NS];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      unsigned short pl[NS];
-      bf_split<NS>((4 * xg + i < n_in) ? src[i] : 0.0f, pl);
-#pragma unroll
-      for (int p = 0; p < NS; p++) pk[p][i] = pl[p];
-    }
-#pragma unroll
-    for (int p = 0; p < NS; p++) *(u16x4_t *)At(buf, p, xe, HID + 4 * xg) = pk[p];
-  };
   auto stage_h = [&](int buf, const float (&h)[4], const float (&keep)[4]) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -124,6 +184,7 @@ lstm_seq_fwd_bf16_kernel(const LstmFwdBf16Args a) {
     c[j] = a.state0[(size_t)e * 2 * HID + u];
     hlast[j] = a.state0[(size_t)e * 2 * HID + HID + u];
     mk_cur[j] = a.masks[e];
+    mk_nxt[j] = a.masks[(size_t)(T > 1 ? 1 : 0) * N + e];        // (the last loads of these waves: from here on they only store)
   }
   {
     float keep0[4];
@@ -131,29 +192,18 @@ lstm_seq_fwd_bf16_kernel(const LstmFwdBf16Args a) {
     for (int j = 0; j < 4; j++) keep0[j] = 1.0f - mk_cur[j];
     stage_h(0, hlast, keep0);
   }
-  float xa[4], xb[4];
-  load_x(0, xa);
-  stage_x(0, xa);
-  if (T > 1) load_x(1, xa);          // x_1, staged during step 0
-  if (T > 2) load_x(2, xb);          // x_2, staged during step 1
-#pragma unroll
-  for (int j = 0; j < 4; j++) mk_nxt[j] = a.masks[(size_t)(T > 1 ? 1 : 0) * N + e0 + 4 * rq + j];
   __syncthreads();
-  // one step; xs: the registers holding x_{t+1} (loaded two steps ago), refilled with x_{t+3}
-  auto step = [&](int t, float (&xs)[4]) {
+  for (int t = 0; t < T; t++) {
     const int buf = t & 1;
     u16x8_t av[KC][NS];
 #pragma unroll
     for (int kc = 0; kc < KC; kc++)
 #pragma unroll
       for (int p = 0; p < NS; p++) av[kc][p] = *(const u16x8_t *)At(buf, p, col, 32 * kc + 8 * rq);
-    // inputs of the following steps
-    if (t + 1 < T) stage_x(buf ^ 1, xs);
-    if (t + 3 < T) load_x(t + 3, xs);
-    float mk_nn[4];
-    const int t2 = (t + 2 < T) ? t + 2 : T - 1;
-#pragma unroll
-    for (int j = 0; j < 4; j++) mk_nn[j] = a.masks[(size_t)t2 * N + e0 + 4 * rq + j];
+    if (t > 0) {      // the masks of step t + 1: published by the loader wave during step t - 1
+      const f32x4 m4 = *(const f32x4 *)&mring[((t + 1) & 3) * 16 + 4 * rq];
+      mk_nxt[0] = m4[0]; mk_nxt[1] = m4[1]; mk_nxt[2] = m4[2]; mk_nxt[3] = m4[3];
+    }
     f32x4 acc[4];
 #pragma unroll
     for (int g = 0; g < 4; g++) acc[g] = (f32x4){bias[g], bias[g], bias[g], bias[g]};
@@ -173,8 +223,6 @@ lstm_seq_fwd_bf16_kernel(const LstmFwdBf16Args a) {
       c[j] = cn;
       hlast[j] = hn;
       const size_t row = (size_t)t * N + e0 + 4 * rq + j;
-      // (non-temporal stores here and loads in the backward kernel -- the gates are written once and read once -- change nothing:
-      // PPO update 111.5 against 111.6 ms, same box)
 #ifndef IRRL_LBF_AB_NO_GATE_STORES      /* A/B switches of tools/build_variants.py (wrong results): which of the forward kernel's stores cost what */
       if (STORE_GC) *(f32x4 *)&a.gates[(row * HID + u) * 4] = (f32x4){ig, fg, og, gg};
 #endif
@@ -186,12 +234,8 @@ lstm_seq_fwd_bf16_kernel(const LstmFwdBf16Args a) {
     }
     if (t + 1 < T) stage_h(buf ^ 1, hlast, keepn);
 #pragma unroll
-    for (int j = 0; j < 4; j++) { mk_cur[j] = mk_nxt[j]; mk_nxt[j] = mk_nn[j]; }
+    for (int j = 0; j < 4; j++) mk_cur[j] = mk_nxt[j];
     __syncthreads();
-  };
-  for (int t = 0; t < T; t += 2) {
-    step(t, xa);
-    if (t + 1 < T) step(t + 1, xb);
   }
 #pragma unroll
   for (int j = 0; j < 4; j++) {

@@ -1301,12 +1301,12 @@ int irrl_lstm_seq_forward_bf16(int nsplit, int hid, int T, int N, int n_in, cons
   if (!train && (gates != nullptr || cseq != nullptr)) return 1;
   if (nsplit == 2) {
     constexpr int bytes = lstm_fwd_bf16_lds_bytes<2>();
-    if (train) hipLaunchKernelGGL((lstm_seq_fwd_bf16_kernel<2, true>), dim3(N / 16), dim3(192), bytes, s, a);
-    else hipLaunchKernelGGL((lstm_seq_fwd_bf16_kernel<2, false>), dim3(N / 16), dim3(192), bytes, s, a);
+    if (train) hipLaunchKernelGGL((lstm_seq_fwd_bf16_kernel<2, true>), dim3(N / 16), dim3(256), bytes, s, a);
+    else hipLaunchKernelGGL((lstm_seq_fwd_bf16_kernel<2, false>), dim3(N / 16), dim3(256), bytes, s, a);
   } else {
     constexpr int bytes = lstm_fwd_bf16_lds_bytes<3>();
-    if (train) hipLaunchKernelGGL((lstm_seq_fwd_bf16_kernel<3, true>), dim3(N / 16), dim3(192), bytes, s, a);
-    else hipLaunchKernelGGL((lstm_seq_fwd_bf16_kernel<3, false>), dim3(N / 16), dim3(192), bytes, s, a);
+    if (train) hipLaunchKernelGGL((lstm_seq_fwd_bf16_kernel<3, true>), dim3(N / 16), dim3(256), bytes, s, a);
+    else hipLaunchKernelGGL((lstm_seq_fwd_bf16_kernel<3, false>), dim3(N / 16), dim3(256), bytes, s, a);
   }
   return hipGetLastError() == hipSuccess ? 0 : 2;
 }
