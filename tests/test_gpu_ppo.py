@@ -54,7 +54,9 @@ def test_on_device_ppo_iteration(kind):
 
 @pytest.mark.parametrize("T,N,n_in,hid,prec", [(7, 16, 35, 48, "f32"), (33, 40, 48, 48, "f32"), (5, 3, 35, 32, "f32"), (12, 64, 20, 64, "f32"),
                                                 (7, 16, 35, 48, "bf16x6"), (33, 40, 48, 48, "bf16x6"), (34, 48, 35, 48, "bf16x6"), (1, 16, 20, 48, "bf16x6"),
-                                                (7, 16, 35, 48, "bf16x3"), (33, 40, 48, 48, "bf16x3"), (34, 48, 35, 48, "bf16x3")])
+                                                (7, 16, 35, 48, "bf16x3"), (33, 40, 48, 48, "bf16x3"), (34, 48, 35, 48, "bf16x3"),
+                                                # around the forward kernel's loader wave (8 steps of rows in flight): sequences shorter than, equal to and just past its depth
+                                                (2, 16, 35, 48, "bf16x3"), (8, 32, 48, 48, "bf16x3"), (9, 16, 35, 48, "bf16x3"), (10, 16, 48, 48, "bf16x6")])
 def test_fused_lstm_sequence_matches_eager_definition(T, N, n_in, hid, prec, monkeypatch):
     """Persistent MFMA LSTM kernels (forward + BPTT) against the eager stable-baselines definition (SBLstm.sequence),
     same f32 inputs: outputs, final state and every gradient -- the exact-f32 kernels ("f32") and the bf16 matrix-core kernels with
