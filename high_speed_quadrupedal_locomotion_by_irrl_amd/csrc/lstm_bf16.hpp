@@ -245,206 +245,6 @@ lstm_seq_fwd_bf16_kernel(const LstmFwdBf16Args a) {
   }
 }
 
-// ---- forward, BOTH LAYERS OF A STACK IN ONE LAUNCH (round 5, last addition) -----------------------------------------------------------
-// What the loader wave could not remove from the forward kernel is the loading itself; half of it is layer 1 reading layer 0's h rows back from
-// memory.  Here a workgroup owns its 16 envs for BOTH layers: waves 0-2 run layer 0, waves 3-5 layer 1 one step behind (layer 1's step t needs
-// h0_t), wave 6 loads layer 0's x rows and the mask rows.  Layer 0 leaves the planes of its raw h_t in the x part of layer 1's A tile next to the
-// (masked) planes it writes for its own next step: layer 1 loads nothing.  One barrier per tick (T + 1 ticks).  Per layer the arithmetic, its
-// order and everything stored are lstm_seq_fwd_bf16_kernel's: outputs bit-identical to two launches.  Seven waves of 224 registers: one workgroup
-// per CU, so a stack's launch has the chip to itself (the two stacks' launches follow each other instead of sharing the CUs).
-struct LstmFwd2Bf16Args {
-  const float *x, *masks;
-  const float *wx_p[2], *b_p[2], *wh_p[2], *state0[2];
-  float *gates[2], *cseq[2], *hseq[2], *state_out[2];
-  int T, N, n_in;                                  // n_in: layer 0's input width (layer 1's is the hidden width)
-};
-template <int NS> constexpr int lstm_fwd2_bf16_lds_bytes() { return 2 * 2 * NS * 16 * LBF_FROW * 2 + 4 * 16 * 4; }
-template <int NS, bool STORE_GC = true>
-__global__ void __launch_bounds__(448)
-lstm_seq_fwd2_bf16_kernel(const LstmFwd2Bf16Args a) {
-  constexpr int HID = LBF_HID, KC = LBF_KF / 32, XD = LBF_FWD_XD;
-  using PR = BfProducts<NS>;
-  extern __shared__ __attribute__((aligned(16))) unsigned short lds_f[];
-  // At(layer, buf, plane, env, k)
-  auto At = [&](int ly, int buf, int p, int env, int k) -> unsigned short * { return lds_f + ((((size_t)(ly * 2 + buf) * NS + p) * 16 + env) * LBF_FROW + k); };
-  float *mring = (float *)(lds_f + 2 * 2 * NS * 16 * LBF_FROW);        // [4 slots][16 envs]: slot t & 3 holds the masks of step t
-  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-  const int col = l & 15, rq = l >> 4;
-  const int e0 = blockIdx.x * 16;
-  const int T = a.T, N = a.N, n_in = a.n_in;
-
-  if (w == 6) {
-    // ---------------- the loader wave (lstm_seq_fwd_bf16_kernel's, for layer 0's rows; T + 1 ticks) ----------------
-    const int xe = l >> 2, xq = l & 3;
-    auto load_x = [&](int t, float (&dst)[12]) {
-      const float *row = a.x + ((size_t)t * N + e0 + xe) * n_in;
-#pragma unroll
-      for (int g4 = 0; g4 < 3; g4++) {
-        const int k0 = 12 * xq + 4 * g4;
-        if (k0 + 3 < n_in) {
-          const f32x4u v = *(const f32x4u *)&row[k0];
-          dst[4 * g4] = v[0]; dst[4 * g4 + 1] = v[1]; dst[4 * g4 + 2] = v[2]; dst[4 * g4 + 3] = v[3];
-        } else if (k0 < n_in) {
-#pragma unroll
-          for (int i = 0; i < 4; i++) dst[4 * g4 + i] = row[k0 + i < n_in ? k0 + i : n_in - 1];
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; i++) dst[4 * g4 + i] = 0.0f;
-        }
-      }
-    };
-    auto stage_x = [&](int buf, const float (&src)[12]) {
-#pragma unroll
-      for (int g4 = 0; g4 < 3; g4++) {
-        u16x4_t pk[NS];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const int k = 12 * xq + 4 * g4 + i;
-          unsigned short pl[NS];
-          bf_split<NS>(k < n_in ? src[4 * g4 + i] : 0.0f, pl);
-#pragma unroll
-          for (int p = 0; p < NS; p++) pk[p][i] = pl[p];
-        }
-#pragma unroll
-        for (int p = 0; p < NS; p++) *(u16x4_t *)At(0, buf, p, xe, HID + 12 * xq + 4 * g4) = pk[p];
-      }
-    };
-    auto load_m = [&](int t) -> float { const int tc = t < T ? t : T - 1; return a.masks[(size_t)tc * N + e0 + (l & 15)]; };
-    float xr[XD][12], mr[XD];
-    load_x(0, xr[0]);
-    stage_x(0, xr[0]);
-#pragma unroll
-    for (int d = 0; d < XD; d++) {
-      if (d + 1 < T) load_x(d + 1, xr[d]);
-      mr[d] = load_m(d + 2);
-    }
-    __syncthreads();
-    for (int t = 0; t <= T; t += XD) {
-#pragma unroll
-      for (int d = 0; d < XD; d++) {
-        const int tt = t + d;
-        if (tt <= T) {
-          if (tt < T) {
-            if (tt + 1 < T) stage_x((tt + 1) & 1, xr[d]);
-            if (l < 16) mring[((tt + 2) & 3) * 16 + l] = mr[d];
-            if (tt + 1 + XD < T) load_x(tt + 1 + XD, xr[d]);
-            mr[d] = load_m(tt + 2 + XD);
-          }
-          __syncthreads();
-        }
-      }
-    }
-    return;
-  }
-
-  // ---------------- waves 0-2: layer 0; waves 3-5: layer 1, one tick behind ----------------
-  const int ly = w / 3, ws = w - 3 * ly;
-  const int u = 16 * ws + col;
-  const int nk = ly == 0 ? n_in : HID;              // width of this layer's input
-  const float *wh_p = a.wh_p[ly], *wx_p = a.wx_p[ly];
-  u16x8_t Bf[KC][4][NS];
-#pragma unroll
-  for (int kc = 0; kc < KC; kc++)
-#pragma unroll
-    for (int g = 0; g < 4; g++)
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        const int k = 32 * kc + 8 * rq + i;
-        float v;
-        if (k < HID) v = wh_p[((size_t)k * HID + u) * 4 + g];
-        else v = (k - HID < nk) ? wx_p[((size_t)(k - HID) * HID + u) * 4 + g] : 0.0f;
-        unsigned short pl[NS];
-        bf_split<NS>(v, pl);
-#pragma unroll
-        for (int p = 0; p < NS; p++) Bf[kc][g][p][i] = pl[p];
-      }
-  const f32x4 bias = *(const f32x4 *)&a.b_p[ly][u * 4];
-  auto stage_h = [&](int buf, const float (&h)[4], const float (&keep)[4]) {
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      unsigned short pl[NS];
-      bf_split<NS>(h[j] * keep[j], pl);
-#pragma unroll
-      for (int p = 0; p < NS; p++) *At(ly, buf, p, 4 * rq + j, u) = pl[p];
-    }
-  };
-  float c[4], hlast[4], mk_cur[4], mk_nxt[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int e = e0 + 4 * rq + j;
-    c[j] = a.state0[ly][(size_t)e * 2 * HID + u];
-    hlast[j] = a.state0[ly][(size_t)e * 2 * HID + HID + u];
-    mk_cur[j] = a.masks[e];
-    mk_nxt[j] = a.masks[(size_t)(T > 1 ? 1 : 0) * N + e];
-  }
-  {
-    float keep0[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) keep0[j] = 1.0f - mk_cur[j];
-    stage_h(0, hlast, keep0);
-  }
-  float *gates = a.gates[ly], *cseq = a.cseq[ly], *hseq = a.hseq[ly];
-  __syncthreads();
-  for (int tick = 0; tick <= T; tick++) {
-    const int t = tick - ly;
-    if (t >= 0 && t < T) {
-      const int buf = t & 1;
-      u16x8_t av[KC][NS];
-#pragma unroll
-      for (int kc = 0; kc < KC; kc++)
-#pragma unroll
-        for (int p = 0; p < NS; p++) av[kc][p] = *(const u16x8_t *)At(ly, buf, p, col, 32 * kc + 8 * rq);
-      if (t > 0) {      // the masks of step t + 1 (published by the loader wave at tick t - 1; the slot is rewritten at tick t + 3)
-        const f32x4 m4 = *(const f32x4 *)&mring[((t + 1) & 3) * 16 + 4 * rq];
-        mk_nxt[0] = m4[0]; mk_nxt[1] = m4[1]; mk_nxt[2] = m4[2]; mk_nxt[3] = m4[3];
-      }
-      f32x4 acc[4];
-#pragma unroll
-      for (int g = 0; g < 4; g++) acc[g] = (f32x4){bias[g], bias[g], bias[g], bias[g]};
-#pragma unroll
-      for (int kc = KC - 1; kc >= 0; kc--)
-#pragma unroll
-        for (int q = 0; q < PR::N; q++)
-#pragma unroll
-          for (int g = 0; g < 4; g++) acc[g] = BF_MFMA32(av[kc][PR::A[q]], Bf[kc][g][PR::B[q]], acc[g]);
-      float keepn[4];
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const float keepC = 1.0f - mk_cur[j];
-        const float ig = fast_sigmoid(acc[0][j]), fg = fast_sigmoid(acc[1][j]), og = fast_sigmoid(acc[2][j]), gg = fast_tanh(acc[3][j]);
-        const float cn = fg * (c[j] * keepC) + ig * gg;
-        const float hn = og * fast_tanh(cn);
-        c[j] = cn;
-        hlast[j] = hn;
-        const size_t row = (size_t)t * N + e0 + 4 * rq + j;
-        if (STORE_GC) *(f32x4 *)&gates[(row * HID + u) * 4] = (f32x4){ig, fg, og, gg};
-        if (STORE_GC) cseq[row * HID + u] = cn;
-        hseq[row * HID + u] = hn;
-        keepn[j] = 1.0f - mk_nxt[j];
-      }
-      if (t + 1 < T) stage_h(buf ^ 1, hlast, keepn);
-      if (ly == 0) {      // layer 1's input of ITS step t: the planes of the raw h
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          unsigned short pl[NS];
-          bf_split<NS>(hlast[j], pl);
-#pragma unroll
-          for (int p = 0; p < NS; p++) *At(1, buf, p, 4 * rq + j, HID + u) = pl[p];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; j++) mk_cur[j] = mk_nxt[j];
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int e = e0 + 4 * rq + j;
-    a.state_out[ly][(size_t)e * 2 * HID + u] = c[j];
-    a.state_out[ly][(size_t)e * 2 * HID + HID + u] = hlast[j];
-  }
-}
-
 // ---- backward --------------------------------------------------------------------------------------------------------------------
 struct LstmBwdBf16Args {
   const float *gates, *cseq, *hseq, *x, *masks, *state0, *dh_in, *wh_p, *wx_p;

@@ -1311,32 +1311,6 @@ int irrl_lstm_seq_forward_bf16(int nsplit, int hid, int T, int N, int n_in, cons
   return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
-// both layers of a stack in ONE launch (lstm_seq_fwd2_bf16_kernel): layer 1 takes layer 0's h rows out of LDS.  Tensors per layer as in
-// irrl_lstm_seq_forward_bf16 (layer 1's input width is hid); gates0 == NULL selects the inference form for both layers.
-int irrl_lstm_seq_forward2_bf16(int nsplit, int hid, int T, int N, int n_in, const float *x, const float *masks, const float *wx0_p, const float *b0_p,
-                                const float *wh0_p, const float *state0_0, const float *wx1_p, const float *b1_p, const float *wh1_p, const float *state0_1,
-                                float *gates0, float *cseq0, float *hseq0, float *state_out0, float *gates1, float *cseq1, float *hseq1, float *state_out1,
-                                void *hip_stream) {
-  if (N <= 0 || T <= 0 || (N % 16) != 0 || n_in <= 0 || n_in > LBF_KX || hid != LBF_HID || (nsplit != 2 && nsplit != 3)) return 1;
-  const bool train = gates0 != nullptr;
-  if (train != (cseq0 != nullptr) || train != (gates1 != nullptr) || train != (cseq1 != nullptr) || !hseq0 || !hseq1) return 1;
-  LstmFwd2Bf16Args a;
-  a.x = x; a.masks = masks; a.T = T; a.N = N; a.n_in = n_in;
-  a.wx_p[0] = wx0_p; a.b_p[0] = b0_p; a.wh_p[0] = wh0_p; a.state0[0] = state0_0; a.gates[0] = gates0; a.cseq[0] = cseq0; a.hseq[0] = hseq0; a.state_out[0] = state_out0;
-  a.wx_p[1] = wx1_p; a.b_p[1] = b1_p; a.wh_p[1] = wh1_p; a.state0[1] = state0_1; a.gates[1] = gates1; a.cseq[1] = cseq1; a.hseq[1] = hseq1; a.state_out[1] = state_out1;
-  hipStream_t s = (hipStream_t)hip_stream;
-  if (nsplit == 2) {
-    constexpr int bytes = lstm_fwd2_bf16_lds_bytes<2>();
-    if (train) hipLaunchKernelGGL((lstm_seq_fwd2_bf16_kernel<2, true>), dim3(N / 16), dim3(448), bytes, s, a);
-    else hipLaunchKernelGGL((lstm_seq_fwd2_bf16_kernel<2, false>), dim3(N / 16), dim3(448), bytes, s, a);
-  } else {
-    constexpr int bytes = lstm_fwd2_bf16_lds_bytes<3>();
-    if (train) hipLaunchKernelGGL((lstm_seq_fwd2_bf16_kernel<3, true>), dim3(N / 16), dim3(448), bytes, s, a);
-    else hipLaunchKernelGGL((lstm_seq_fwd2_bf16_kernel<3, false>), dim3(N / 16), dim3(448), bytes, s, a);
-  }
-  return hipGetLastError() == hipSuccess ? 0 : 2;
-}
-
 int irrl_lstm_seq_backward_bf16(int nsplit, int hid, int T, int N, int n_in, const float *gates, const float *cseq, const float *hseq, const float *x,
                                 const float *masks, const float *state0, const float *dh_in, const float *wh_p, const float *wx_p, float *dx,
                                 float *dwx_part, float *dwh_part, float *db_part, void *hip_stream) {

@@ -115,28 +115,9 @@ def tall_linear(x, w, b):
     return _TallLinearFn.apply(x, w, b)
 
 
-# BOTH LAYERS OF A STACK IN ONE LAUNCH (round 5; csrc/lstm_bf16.hpp lstm_seq_fwd2_bf16_kernel).  The policy's stack loop announces the NEXT layer in
-# front of a layer's call (`stack_lookahead`); the first layer's forward then launches the two-layer kernel and parks the second layer's outputs,
-# and the second layer's forward -- called with the first one's h rows as its input -- picks them up instead of launching.  The autograd graph,
-# what each node saves and the backward kernels stay as they are.  IRRL_LSTM_FUSE_STACK=0 switches it off (same results, bit for bit).
-FUSE_STACK = os.environ.get("IRRL_LSTM_FUSE_STACK", "1") != "0"
-_LOOKAHEAD = None
-_PENDING = None
-
-
-def stack_lookahead(wx, wh, b, state0):
-    """the layer that follows the next `lstm_sequence` call on the next call's output (same masks)"""
-    global _LOOKAHEAD
-    _LOOKAHEAD = (wx, wh, b, state0) if FUSE_STACK else None
-
-
 class _LstmSeqFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, wx, wh, b, state0, masks, no_grad=False):
-        global _LOOKAHEAD, _PENDING
-        look, _LOOKAHEAD = _LOOKAHEAD, None
-        pend, _PENDING = _PENDING, None
-        state0_arg = state0
         lib = _lib.load()
         T, N, n_in = x.shape
         hid = wh.shape[0]
@@ -164,29 +145,7 @@ class _LstmSeqFn(torch.autograd.Function):
         state_out = torch.empty(Np, 2 * hid, device=x.device, dtype=torch.float32)
         stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
         ctx.nsplit = nsplit
-        hit = (pend is not None and nsplit == pend["nsplit"] and infer == pend["infer"] and pad == 0 and x.data_ptr() == pend["x_ptr"] and tuple(x.shape) == pend["x_shape"]
-               and wx.data_ptr() == pend["wx"] and wh.data_ptr() == pend["wh"] and b.data_ptr() == pend["b"] and state0_arg.data_ptr() == pend["state0"]
-               and tuple(state0_arg.shape) == pend["state0_shape"] and masks.data_ptr() == pend["masks_ptr"])
-        if hit:
-            # this layer was computed by the launch of the layer below it: take its outputs
-            gates, cseq, hseq, state_out = pend["gates"], pend["cseq"], pend["hseq"], pend["state_out"]
-            rc = 0
-        elif (nsplit and look is not None and pad == 0 and tuple(look[1].shape) == (hid, 4 * hid) and tuple(look[0].shape) == (hid, 4 * hid)
-              and look[3].shape == state0.shape):
-            wx1, wh1, b1, st1 = look
-            wx1_p, wh1_p, b1_p = _permuted_weights(wx1, wh1, b1, perm)
-            st1_k = st1.contiguous()
-            gates1 = None if infer else torch.empty(T, Np, hid, 4, device=x.device, dtype=torch.float32)
-            cseq1 = None if infer else torch.empty(T, Np, hid, device=x.device, dtype=torch.float32)
-            hseq1 = torch.empty(T, Np, hid, device=x.device, dtype=torch.float32)
-            state_out1 = torch.empty(Np, 2 * hid, device=x.device, dtype=torch.float32)
-            rc = lib.irrl_lstm_seq_forward2_bf16(nsplit, hid, T, Np, n_in, _ptr(x_k), _ptr(masks_k), _ptr(wx_p), _ptr(b_p), _ptr(wh_p), _ptr(state0_k),
-                                                 _ptr(wx1_p), _ptr(b1_p), _ptr(wh1_p), _ptr(st1_k),
-                                                 None if infer else _ptr(gates), None if infer else _ptr(cseq), _ptr(hseq), _ptr(state_out),
-                                                 None if infer else _ptr(gates1), None if infer else _ptr(cseq1), _ptr(hseq1), _ptr(state_out1), stream)
-            _PENDING = dict(nsplit=nsplit, infer=infer, x_ptr=hseq.data_ptr(), x_shape=tuple(hseq.shape), wx=wx1.data_ptr(), wh=wh1.data_ptr(), b=b1.data_ptr(), state0=st1.data_ptr(), state0_shape=tuple(st1.shape),
-                            masks_ptr=masks.data_ptr(), gates=gates1, cseq=cseq1, hseq=hseq1, state_out=state_out1)
-        elif nsplit:
+        if nsplit:
             rc = lib.irrl_lstm_seq_forward_bf16(nsplit, hid, T, Np, n_in, _ptr(x_k), _ptr(wx_p), _ptr(b_p), _ptr(wh_p), _ptr(masks_k), _ptr(state0_k),
                                                 None if infer else _ptr(gates), None if infer else _ptr(cseq), _ptr(hseq), _ptr(state_out), stream)
         elif n_in <= 48 and FUSE_INPUT_PROJECTION:

@@ -155,12 +155,7 @@ class CustomLSTMPolicy(ActorCriticPolicy):
 
     def _stack(self, layers, x, parts, masks_seq):
         new = []
-        for i, (l, st) in enumerate(zip(layers, parts)):
-            if i + 1 < len(layers) and x.is_cuda and SBLstm.use_fused:
-                # the layer above runs in the same launch (lstm_fused: both layers of a stack in one kernel)
-                from . import lstm_fused
-                nxt = layers[i + 1]
-                lstm_fused.stack_lookahead(nxt.wx, nxt.wh, nxt.b, parts[i + 1])
+        for l, st in zip(layers, parts):
             x, s = l.sequence(x, st, masks_seq)
             new.append(s)
         return x, new

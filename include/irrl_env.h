@@ -283,14 +283,6 @@ int irrl_lstm_seq_backward_x(int hid, int T, int N, int n_in, const float *gates
 /* (forward: gates == NULL and cseq == NULL selects the INFERENCE form -- only hseq and state_out are written: the critic pass behind an actor-only rollout) */
 int irrl_lstm_seq_forward_bf16(int nsplit, int hid, int T, int N, int n_in, const float *x, const float *wx_p, const float *b_p, const float *wh_p,
                                const float *masks, const float *state0, float *gates, float *cseq, float *hseq, float *state_out, void *hip_stream);
-/* BOTH LAYERS OF A STACK IN ONE LAUNCH (round 5): a workgroup runs layer 1 one step behind layer 0 and hands layer 0's h rows over in LDS -- layer 1
- * loads nothing.  Per layer: the tensors of irrl_lstm_seq_forward_bf16 (layer 1's input width is hid); every output bit-identical to two launches.
- * gates0 == NULL (then cseq0, gates1, cseq1 NULL too): inference form (only the h rows and the final states are written).  Replaces two calls of `CustomerLstmNN`'s layer unroll
- * (run_bp_v5.py:143-176) per stack. */
-int irrl_lstm_seq_forward2_bf16(int nsplit, int hid, int T, int N, int n_in, const float *x, const float *masks, const float *wx0_p, const float *b0_p,
-                                const float *wh0_p, const float *state0_0, const float *wx1_p, const float *b1_p, const float *wh1_p, const float *state0_1,
-                                float *gates0, float *cseq0, float *hseq0, float *state_out0, float *gates1, float *cseq1, float *hseq1, float *state_out1,
-                                void *hip_stream);
 int irrl_lstm_seq_backward_bf16(int nsplit, int hid, int T, int N, int n_in, const float *gates, const float *cseq, const float *hseq, const float *x,
                                 const float *masks, const float *state0, const float *dh_in, const float *wh_p, const float *wx_p, float *dx,
                                 float *dwx_part, float *dwh_part, float *db_part, void *hip_stream);
