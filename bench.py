@@ -81,6 +81,12 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+def launched_by_torchrun():
+    """A launcher's env:// rendezvous is COMPLETE: WORLD_SIZE, RANK and MASTER_PORT all set, as torch.distributed.run exports them.  A box that
+    merely exports WORLD_SIZE=1 is not a launcher: the process stays single (or starts its own ranks for --gpus N)."""
+    return all(k in os.environ for k in ("WORLD_SIZE", "RANK", "MASTER_PORT"))
+
+
 def launch_ranks(args):
     """`--gpus N` outside a launcher: start N fresh rank processes and relay their output.  This parent has not imported
     torch and never touches the GPU (a process that has initialised the GPU must not be replaced / must not fork ranks)."""
@@ -182,9 +188,12 @@ def worker(args):
     from high_speed_quadrupedal_locomotion_by_irrl_amd import _lib
     from high_speed_quadrupedal_locomotion_by_irrl_amd.flexible_robot import FlexibleGymEnv
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    launched = launched_by_torchrun()
+    rank = int(os.environ.get("RANK", "0")) if launched else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if launched else 0
+    world = int(os.environ.get("WORLD_SIZE", "1")) if launched else 1
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the env kernels have no CPU path")
     # IRRL_BENCH_BACKEND=gloo + IRRL_BENCH_ONE_DEVICE=1 let the multi-rank control flow be exercised on a 1-GPU box
@@ -196,8 +205,8 @@ def worker(args):
     dev = torch.device("cuda", local_rank)
     dist = None
     ranks_seen = 1
-    if world > 1 or "WORLD_SIZE" in os.environ:
-        # under a launcher (WORLD_SIZE set), ALSO with one rank: the job then runs its barrier / reductions / PPO collectives over RCCL
+    if launched:
+        # under a launcher, ALSO with one rank: the job then runs its barrier / reductions / PPO collectives over RCCL
         # on device tensors like an N-GPU job does -- the way to exercise the nccl path on a 1-GPU box
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -557,7 +566,7 @@ def worker(args):
 
 def main():
     args = parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if args.gpus > 1 and not launched_by_torchrun():
         raise SystemExit(launch_ranks(args))
     worker(args)
 

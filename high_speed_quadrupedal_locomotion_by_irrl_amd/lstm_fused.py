@@ -27,7 +27,17 @@ FUSE_INPUT_PROJECTION = True   # module switch (benchmarks / tests compare the t
 #   "f32"     v_mfma_f32_16x16x4_f32, bitwise an fmaf chain (rounds 1-3), update 158 ms
 # (csrc/lstm_bf16.hpp; IRRL_LSTM_PRECISION overrides the default)
 PRECISION = os.environ.get("IRRL_LSTM_PRECISION", "bf16x3")
-_NSPLIT = {"bf16x3": 2, "bf16x6": 3}
+_NSPLIT = {"bf16x3": 2, "bf16x6": 3, "f32": 0}
+
+
+def check_precision(name, what="lstm_fused.PRECISION / IRRL_LSTM_PRECISION"):
+    """A typo must not fall through to some other arithmetic silently."""
+    if name not in _NSPLIT:
+        raise ValueError("%s is one of %s, not %r" % (what, sorted(_NSPLIT), name))
+    return name
+
+
+check_precision(PRECISION)
 
 
 def _perm(hid, device):
@@ -117,7 +127,7 @@ def tall_linear(x, w, b):
 
 class _LstmSeqFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, wx, wh, b, state0, masks, no_grad=False):
+    def forward(ctx, x, wx, wh, b, state0, masks, no_grad=False, precision=None):
         lib = _lib.load()
         T, N, n_in = x.shape
         hid = wh.shape[0]
@@ -134,7 +144,7 @@ class _LstmSeqFn(torch.autograd.Function):
         else:
             x_k, masks_k, state0_k = x, masks, state0
         Np = N + pad
-        nsplit = _NSPLIT.get(PRECISION, 0) if (hid == 48 and n_in <= 48 and FUSE_INPUT_PROJECTION and FUSE_WEIGHT_GRADIENTS) else 0
+        nsplit = _NSPLIT[check_precision(precision if precision is not None else PRECISION)] if (hid == 48 and n_in <= 48 and FUSE_INPUT_PROJECTION and FUSE_WEIGHT_GRADIENTS) else 0
         # no gradient will be asked for (the caller ran under torch.no_grad(): the critic pass behind an actor-only rollout): the bf16 kernels'
         # inference form keeps neither the gates nor the c rows -- a third of the stores.  (`no_grad` comes from the caller: inside forward()
         # autograd has switched grad mode off whatever the caller's was.)
@@ -204,7 +214,7 @@ class _LstmSeqFn(torch.autograd.Function):
                 if lib.irrl_sum_rows(_ptr(part), rows, out.numel(), hid, _ptr(out), stream) != 0:
                     raise RuntimeError("irrl_sum_rows failed")
             dx = dx_k[:, :N] if dx_k is not None else None
-            return dx, dwx, dwh, db, None, None, None
+            return dx, dwx, dwh, db, None, None, None, None
         dz = torch.empty(T, Np, hid, 4, device=x_k.device, dtype=torch.float32)
         rc = lib.irrl_lstm_seq_backward(hid, T, Np, _ptr(gates), _ptr(cseq), _ptr(masks_k), _ptr(state0_k), _ptr(dh_seq), _ptr(wh_p),
                                         _ptr(dz), stream)
@@ -219,12 +229,13 @@ class _LstmSeqFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = (dzf @ wx_p.t()).reshape(T, Np, n_in)[:, :N]
-        return dx, dwx, dwh, db, None, None, None
+        return dx, dwx, dwh, db, None, None, None, None
 
 
-def lstm_sequence(x, wx, wh, b, state0, masks):
-    """x [T,N,n_in], state0 [N,2H] = [c|h], masks [T,N] -> (h_seq [T,N,H], final state [N,2H]) on the MI355X."""
-    return _LstmSeqFn.apply(x, wx, wh, b, state0, masks, not torch.is_grad_enabled())
+def lstm_sequence(x, wx, wh, b, state0, masks, precision=None):
+    """x [T,N,n_in], state0 [N,2H] = [c|h], masks [T,N] -> (h_seq [T,N,H], final state [N,2H]) on the MI355X.
+    precision: arithmetic of this call's kernels ("bf16x3" | "bf16x6" | "f32"); None = the module default PRECISION, read at call time."""
+    return _LstmSeqFn.apply(x, wx, wh, b, state0, masks, not torch.is_grad_enabled(), precision)
 
 
 def supported(x, hid):

@@ -31,6 +31,7 @@ class SBLstm(nn.Module):
     """One stable-baselines lstm layer (see module docstring)."""
 
     use_fused = True   # class-wide switch (tests flip it to compare the kernels with this eager definition)
+    precision = None   # arithmetic of this layer's sequence kernels; None = lstm_fused.PRECISION (CustomLSTMPolicy sets it per stack)
 
     def __init__(self, n_in, n_hidden):
         super().__init__()
@@ -58,16 +59,18 @@ class SBLstm(nn.Module):
         h = torch.sigmoid(o) * torch.tanh(c)
         return c, h
 
-    def sequence(self, x, state, masks):
+    def sequence(self, x, state, masks, precision=None):
         """x [T,N,n_in], state [N,2h] = [c,h], masks [T,N] -> outputs [T,N,h], final state [N,2h].
-        The input projection of the whole sequence is one GEMM; only h @ wh stays sequential."""
+        The input projection of the whole sequence is one GEMM; only h @ wh stays sequential.
+        precision: arithmetic of the fused kernels for this call (overrides the layer's / the module's default)."""
         T, N, _ = x.shape
         n = self.n_hidden
         if x.is_cuda and self.use_fused:
             from . import lstm_fused
             if lstm_fused.supported(x, n):
                 # persistent MFMA kernel: the whole sequence in one launch (csrc/lstm_kernels.hip)
-                return lstm_fused.lstm_sequence(x, self.wx, self.wh, self.b, state, masks)
+                return lstm_fused.lstm_sequence(x, self.wx, self.wh, self.b, state, masks,
+                                                precision=precision if precision is not None else self.precision)
         zx = (x.reshape(T * N, -1) @ self.wx + self.b).reshape(T, N, 4 * n)
         c, h = state[:, :n], state[:, n:]
         m = masks.unsqueeze(-1)
@@ -127,6 +130,14 @@ class CustomLSTMPolicy(ActorCriticPolicy):
         self.logstd = nn.Parameter(torch.zeros(1, act_dim))
         self.q = SBLinear(dims[-1], act_dim)  # created by proba_distribution_from_latent, never used
         self.state_dim = sum(self.n_lstm) * 2 * 2  # run_bp_v5.py:136-137
+        # per-stack arithmetic of the update's sequence kernels (A/B runs that separate the actor's from the critic's): IRRL_LSTM_PRECISION_PI /
+        # IRRL_LSTM_PRECISION_V; unset = lstm_fused.PRECISION for both
+        import os
+        for stack, key in ((self.lstm_pi, "IRRL_LSTM_PRECISION_PI"), (self.lstm_v, "IRRL_LSTM_PRECISION_V")):
+            if os.environ.get(key):
+                from . import lstm_fused
+                for l in stack:
+                    l.precision = lstm_fused.check_precision(os.environ[key], key)
 
     two_streams = True
     _streams = {}
@@ -153,10 +164,10 @@ class CustomLSTMPolicy(ActorCriticPolicy):
         sizes = [2 * k for k in (self.n_lstm + self.n_lstm)]  # run_bp_v5.py:139-140
         return list(torch.split(states, sizes, dim=1))
 
-    def _stack(self, layers, x, parts, masks_seq):
+    def _stack(self, layers, x, parts, masks_seq, precision=None):
         new = []
         for l, st in zip(layers, parts):
-            x, s = l.sequence(x, st, masks_seq)
+            x, s = l.sequence(x, st, masks_seq, precision=precision)
             new.append(s)
         return x, new
 

@@ -174,6 +174,8 @@ class _FusedHeadsLoss(torch.autograd.Function):
 # arithmetic of the critic's sequence kernels when the rollout's values are computed after the rollout (Runner._critic_pass): the f32 level
 # ("bf16x6": three bf16 planes per operand, ~2^-24 per product; "f32": the exact-f32 MFMA kernels), whatever the update itself uses
 CRITIC_PASS_PRECISION = os.environ.get("IRRL_CRITIC_PASS_PRECISION", "bf16x6")
+if CRITIC_PASS_PRECISION not in ("bf16x6", "f32"):
+    raise ValueError("IRRL_CRITIC_PASS_PRECISION is 'bf16x6' or 'f32' (the f32 level), not %r" % (CRITIC_PASS_PRECISION,))
 
 # arithmetic of the MlpPolicy gradient kernels: "bf16x3" = every product as three bf16 plane products on the matrix cores (two planes per
 # operand, f32 accumulation, ~2^-16 relative per product; csrc/mlp_bf16.hpp), "f32" = v_mfma_f32_16x16x4_f32 (csrc/mlp_update.hpp)
@@ -554,16 +556,10 @@ class Runner(object):
         recorded observations [T, N, 35] from its state in front of the rollout, masks = the recorded dones (the state is cleared where an
         episode ended before step t, run_bp_v5.py:143-176) -- the sequence kernels of the update, at CRITIC_PASS_PRECISION -- then the
         value head; writes mb_values and the critic's half of the carried LSTM state."""
-        from . import lstm_fused
         pol = self.model.policy
         k = len(pol.n_lstm)
         parts = pol._split(states0)
-        keep = lstm_fused.PRECISION
-        lstm_fused.PRECISION = CRITIC_PASS_PRECISION
-        try:
-            latent_v, new_v = pol._stack(pol.lstm_v, self.mb_obs, parts[k:], self.mb_dones.to(self.mb_obs.dtype))
-        finally:
-            lstm_fused.PRECISION = keep
+        latent_v, new_v = pol._stack(pol.lstm_v, self.mb_obs, parts[k:], self.mb_dones.to(self.mb_obs.dtype), precision=CRITIC_PASS_PRECISION)
         self.mb_values.copy_(pol.vf(latent_v).squeeze(-1))
         off = sum(2 * h for h in pol.n_lstm)
         self.states[:, off:].copy_(torch.cat(new_v, 1))

@@ -49,6 +49,7 @@ def parse_args(argv):
     p.add_argument("--policy", choices=["lstm", "mlp"], default="lstm", help="lstm = CustomLSTMPolicy (bp5), mlp = MlpPolicy")
     p.add_argument("--num_envs", type=int, default=None, help="override environment.num_envs (per GPU)")
     p.add_argument("--eval_every_n", type=int, default=100)
+    p.add_argument("--seed", type=int, default=None, help="override the yaml's seeds: `seed` (policy init, sampling noise) and environment.seedd (env RNG)")
     # --test (run_bp_v5.py:61-108 flag_fix_cmd, delay, vel_filter_freq, act_filter_freq)
     p.add_argument("--cmd", dest="flag_fix_cmd", type=float, default=1.0, help="fixed forward-velocity command of --test [m/s]")
     p.add_argument("--steps", type=int, default=1500, help="control steps of --test")
@@ -132,15 +133,26 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    launched = world > 1 or "WORLD_SIZE" in os.environ      # under a launcher, also with one rank: the collectives run over RCCL
+    # under a launcher (complete env:// rendezvous: WORLD_SIZE, RANK, MASTER_PORT), also with one rank: the collectives run over RCCL.
+    # A shell that merely exports WORLD_SIZE=1 stays single-process.
+    launched = all(k in os.environ for k in ("WORLD_SIZE", "RANK", "MASTER_PORT"))
+    if world > 1 and not launched:
+        raise SystemExit("WORLD_SIZE=%d but RANK / MASTER_PORT are not set: start the ranks with torch.distributed.run" % world)
     if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
+        backend = os.environ.get("IRRL_BACKEND", "nccl")          # "gloo": CPU-side collectives (tests, one-device multi-rank runs)
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
+        else:
+            torch.distributed.init_process_group(backend)
     if not args.train and not args.flag_output:
         return run_test(args, cfg)
     if args.num_envs:
         cfg["environment"]["num_envs"] = args.num_envs
+    if args.seed is not None:
+        cfg["seed"] = int(args.seed)
+        cfg["environment"]["seedd"] = int(args.seed)
     # rank r owns the global env ids r * num_envs .. of the one big pool: same seed everywhere, results independent of the GPU count
     cfg["environment"]["EnvIdOffset"] = rank * int(cfg["environment"]["num_envs"])
     # run_bp_v5.py:205-207: the environment sub-tree is dumped to a string and parsed again on the native side

@@ -49,5 +49,8 @@ class HipVecEnv(object):
     def get_state(self):
         return self.impl.get_state()
 
+    def set_contact_coeff(self, coeff):
+        self.impl.SetContactCoefficient(np.ascontiguousarray(coeff, np.float32))
+
     def set_state(self, st):
         self.impl.set_state(st)

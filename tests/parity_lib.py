@@ -11,6 +11,8 @@ Tolerances (fp32 kernels vs f64 oracle; the north-star asks for "a stated fp32 t
 Discrete outcomes (done flags, contact sets, RNG draws) must match exactly except where a threshold sits
 within rounding distance, which the fixed seeds below avoid.
 """
+import math
+
 import numpy as np
 
 import oracle as O
@@ -315,12 +317,13 @@ def closed_loop_reference_policy(env, cfg, cmd_vx, steps, fixture="actor_bp5_155
 class BatchedNumpyActor(object):
     """The two-layer LSTM actor of a fixture (tests/golden/actor_*.npz) for a batch of envs, float64 numpy."""
 
-    def __init__(self, fixture, n):
+    def __init__(self, fixture, n, clip=True):
         import os
         z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fixture))
         self.w = {k: z[k].astype(np.float64) for k in z.files}
         self.c = [np.zeros((n, 48)), np.zeros((n, 48))]
         self.h = [np.zeros((n, 48)), np.zeros((n, 48))]
+        self.clip = clip      # the rollout clips the sampled action (ppo2.py:533); the evaluation script hands the mean over as it is
 
     def act(self, ob, done):
         sig = lambda v: 1.0 / (1.0 + np.exp(-v))
@@ -334,7 +337,8 @@ class BatchedNumpyActor(object):
             self.c[i] = fg * self.c[i] + ig * g
             self.h[i] = og * np.tanh(self.c[i])
             x = self.h[i]
-        return np.clip(x @ self.w["pi_w"] + self.w["pi_b"], -1.0, 1.0).astype(np.float32)
+        a = x @ self.w["pi_w"] + self.w["pi_b"]
+        return (np.clip(a, -1.0, 1.0) if self.clip else a).astype(np.float32)
 
 
 def closed_loop_training_mode(env, fixture, steps):
@@ -351,3 +355,187 @@ def closed_loop_training_mode(env, fixture, steps):
         vx.append(np.abs(env.get_state()[:, S["GV"]]).mean())
         n_done += int(done.sum())
     return dict(reward=float(np.mean(rew)), speed=float(np.mean(vx)), terminations=n_done)
+
+
+# ---- the reference's simulator logs (tests/golden/raisim_body_logs.json <- tools/gen_raisim_log_fixture.py) ----
+def body_log_statistics(frames, window=None):
+    """Twin of tools/gen_raisim_log_fixture.py `summary`: frames [n, 13] = base x y z, quaternion wxyz, world linear velocity, world angular
+    velocity at 500 Hz -> the statistics the fixture holds for each RaiSim log."""
+    d = np.asarray(frames, np.float64)
+    h = window if window is not None else slice(0, len(d))
+    w, x, y, z = d[:, 3], d[:, 4], d[:, 5], d[:, 6]
+    R = np.zeros((len(d), 3, 3))
+    R[:, 0, 0] = 1 - 2 * (y * y + z * z); R[:, 0, 1] = 2 * (x * y - w * z); R[:, 0, 2] = 2 * (w * y + x * z)
+    R[:, 1, 0] = 2 * (x * y + w * z); R[:, 1, 1] = 1 - 2 * (x * x + z * z); R[:, 1, 2] = 2 * (y * z - w * x)
+    R[:, 2, 0] = 2 * (x * z - w * y); R[:, 2, 1] = 2 * (w * x + y * z); R[:, 2, 2] = 1 - 2 * (x * x + y * y)
+    vb = np.einsum("nji,nj->ni", R, d[:, 7:10])
+    wb = np.einsum("nji,nj->ni", R, d[:, 10:13])
+    roll = np.arctan2(2 * (w * x + y * z), 1 - 2 * (x * x + y * y))
+    pitch = np.arcsin(np.clip(2 * (w * y - x * z), -1, 1))
+    return {"vx_body_mean": float(vb[h, 0].mean()), "vx_body_std": float(vb[h, 0].std()), "vy_body_mean": float(vb[h, 1].mean()),
+            "z_mean": float(d[h, 2].mean()), "z_std": float(d[h, 2].std()), "roll_std": float(roll[h].std()),
+            "pitch_mean": float(pitch[h].mean()), "pitch_std": float(pitch[h].std()), "yaw_rate_mean": float(d[h, 12].mean()),
+            "roll_rate_body_std": float(wb[h, 0].std()), "pitch_rate_body_std": float(wb[h, 1].std()), "vz_std": float(d[h, 9].std()),
+            "vx_body": vb[:, 0]}
+
+
+def closed_loop_log_conditions(env, cfg, conds, fixture="actor_bp5_155.npz", cmd_hz=1.0, mu_warm=0.8, record_torque=False):
+    """One Manual-mode env per condition of the reference's RaiSim logs, all driven by the bp5_155 actor the way the evaluation script drives it
+    (run_bp_v5.py:300-470: command low-passed at 1 Hz from zero and written into obs[0:3], observation delay line = DelayTool.py:5-21, material
+    through SetContactCoefficient like run_bp_v5.py:317-318).  conds[i] = dict(cmd, mu, delay [control steps], warm [steps before the recording
+    starts; the condition's mu is installed there, mu_warm before], frames).  -> list of [frames_i, 13] recordings (layout of the logs), falls,
+    and with record_torque the per-step joint torques / rates [frames_i, 12] each."""
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.helper import obs_normalisation
+    n = env.n
+    assert n == len(conds)
+    actor = BatchedNumpyActor(fixture, n, clip=True)       # CustomerLstmNN.predict clips its output to [-1, 1] (NN:133-134)
+    mean, std, _, _ = obs_normalisation(cfg)
+    dt = float(cfg["control_dt"])
+    a_cmd = 2 * math.pi * dt * cmd_hz / (2 * math.pi * dt * cmd_hz + 1.0)
+    target = np.zeros((n, 3)); target[:, 0] = [c["cmd"] for c in conds]
+    delay = np.array([int(c.get("delay", 0)) for c in conds])
+    warm = np.array([int(c.get("warm", 0)) for c in conds])
+    frames = np.array([int(c["frames"]) for c in conds])
+    steps = int((warm + frames).max())
+    coeff = np.zeros((n, 3), np.float32); coeff[:, 0] = mu_warm; coeff[:, 1] = 0.2; coeff[:, 2] = 0.01      # run_bp_v5.py:317
+    for i, c in enumerate(conds):
+        if warm[i] == 0:
+            coeff[i, 0] = c["mu"]
+    env.set_contact_coeff(coeff)
+    ob = env.reset()
+    depth = int(delay.max()) + 1
+    hist = np.repeat(np.asarray(ob, np.float64)[None], depth, 0)          # "the first sample fills the line"
+    cmd = np.zeros((n, 3))
+    done = np.zeros(n, bool)
+    falls = np.zeros(n, int)
+    rec = np.zeros((steps, n, 13))
+    tq = np.zeros((steps, n, 12)); qd = np.zeros((steps, n, 12))
+    rows = np.arange(n)
+    for t in range(steps):
+        switch = np.nonzero((warm == t) & (warm > 0))[0]
+        if len(switch):
+            for i in switch:
+                coeff[i, 0] = conds[i]["mu"]
+            env.set_contact_coeff(coeff)
+        cmd = (1 - a_cmd) * cmd + a_cmd * target
+        hist[t % depth] = np.asarray(ob, np.float64)
+        o = hist[(t - delay) % depth, rows].copy()
+        o[:, 0:3] = (cmd - mean[0:3]) / std[0:3]
+        ob, _, done, _ = env.step(actor.act(o, done))
+        st = env.get_state()
+        rec[t, :, 0:7] = st[:, S["GC"]:S["GC"] + 7]
+        rec[t, :, 7:13] = st[:, S["GV"]:S["GV"] + 6]
+        if record_torque:
+            tq[t] = st[:, S["TQ"]:S["TQ"] + 12]
+            qd[t] = st[:, S["GV"] + 6:S["GV"] + 18]
+        falls += done
+        cmd[done] = 0.0                                                    # the env restarted from rest
+    out = [rec[warm[i]:warm[i] + frames[i], i] for i in range(n)]
+    if record_torque:
+        return out, falls, [tq[warm[i]:warm[i] + frames[i], i] for i in range(n)], [qd[warm[i]:warm[i] + frames[i], i] for i in range(n)]
+    return out, falls
+
+
+# Tolerances of the comparison with the RaiSim logs.  They are set from the LOGS' OWN scatter, not from this build's results: the reference
+# recorded delay 3 twice (2 s window / last half of a 20 s run): v_x 4.773 / 4.802 m/s (0.6 %), height 0.2771 / 0.2761 m (1.0 mm), mean pitch
+# 0.0152 / 0.0168 rad, roll std 0.0080 / 0.0083; delay 4 twice: 4.679 / 4.424 m/s (5.6 %, the 20 s run carries `roll_dot_noise`), delay 5 twice:
+# 4.066 / 3.975 m/s.  The bounds are ~3x that scatter for the well-behaved conditions and wider at the stability edge (delay 5).
+RAISIM_LOG_TOL = {"vx_rel": 0.02, "z_abs": 0.004, "pitch_mean_abs": 0.004, "std_rel": 0.30, "std_abs": 0.0006}
+RAISIM_LOG_TOL_EDGE = {"vx_rel": 0.08, "z_abs": 0.006, "pitch_mean_abs": 0.012, "std_rel": 1.2, "std_abs": 0.002}
+
+
+def raisim_log_conditions(fixture_logs, max_frames=4000):
+    """The logs this build can reproduce the set-up of: bp5_155 at the logged command, friction coefficient and observation delay.
+    Excluded (returned separately with the reason): the two recordings of another policy (`bp5_158`, running in -x; its weights are not in the
+    repository), and the run with `Bw: 1000, vel_filter: 50` (keys of the authors' harness, which is
+    not in the repository; read as the script's action / rate low-passes they do not reproduce the logged 4.375 m/s)."""
+    use, skipped = [], []
+    for l in fixture_logs:
+        p = l["params"]
+        if not str(p["policy_name"]).endswith("bp5_155"):
+            skipped.append((l["name"], "policy %s (runs in -x at %.2f m/s) is not in the repository: only bp5_155's weights are (script/pkl, script/model)"
+                            % (p["policy_name"], abs(l["stats"]["vx_body_mean"]))))
+            continue
+        if float(p.get("Bw_Min", 5000)) < 5000 or float(p.get("vel_filter", 5000)) < 5000:
+            skipped.append((l["name"], "Bw %s / vel_filter %s: harness keys without a definition in the repository" % (p.get("Bw_Min"), p.get("vel_filter"))))
+            continue
+        rest = l["family"] == "start_from_rest_20s"
+        # the recordings that do not start from rest begin ~6 m down the track at full speed: a warm-up ran before them.  Its length and
+        # material are not logged; 1000 steps (2 s) on the script's default material (mu 0.8, run_bp_v5.py:317) reach the same state, and the
+        # run on mu = 0.05 could not have reached 4.95 m/s otherwise (mu g = 0.5 m/s^2)
+        use.append(dict(name=l["name"], family=l["family"], cmd=float(p["V_Max"]) if not rest else 5.0, mu=float(p["Mu_Min"]), delay=int(p.get("delay", 0)),
+                        warm=0 if rest else 1000, frames=min(int(l["frames"]), max_frames), log=l))
+    return use, skipped
+
+
+def compare_with_raisim_logs(env_factory, cfg_loader, fixture, max_frames=4000):
+    """-> (rows, skipped): per usable log dict(name, family, mu, delay, falls, ref = the log's statistics, got = this physics', window)"""
+    conds, skipped = raisim_log_conditions(fixture["logs"], max_frames)
+    cfg = cfg_loader("bp5_manual_eval.yaml", num_envs=len(conds))
+    env = env_factory(cfg)
+    rec, falls = closed_loop_log_conditions(env, cfg, conds)
+    rows = []
+    for c, r, f in zip(conds, rec, falls):
+        n = len(r)
+        window = slice(0, n) if c["family"] == "steady_2s" else slice(n // 2, n)
+        got = body_log_statistics(r, window)
+        row = dict(name=c["name"], family=c["family"], mu=c["mu"], delay=c["delay"], falls=int(f), ref=c["log"]["stats"], got=got)
+        if c["family"] == "start_from_rest_20s":
+            vb = got["vx_body"]
+            row["rise_t"] = c["log"]["rise"]["t"]
+            row["rise_ref"] = c["log"]["rise"]["vx_body"]
+            row["rise_got"] = [float(vb[int(t / 0.002) - 25:int(t / 0.002) + 25].mean()) for t in row["rise_t"]]
+            above = np.nonzero(np.convolve(vb, np.ones(100) / 100, "same") >= 0.9 * got["vx_body_mean"])[0]
+            row["t90_ref"], row["t90_got"] = c["log"]["time_to_90_percent_s"], float(above[0] * 0.002)
+        rows.append(row)
+    return rows, skipped
+
+
+def raisim_log_table(rows, skipped, engine):
+    keys = ("vx_body_mean", "vx_body_std", "z_mean", "z_std", "roll_std", "pitch_mean", "pitch_std", "yaw_rate_mean")
+    out = ["# reference RaiSim log (Exp_Raw_Data/body-center-<date>.bin) vs this build's physics (%s), bp5_155 closed loop, command 5 m/s" % engine,
+           "# cells: RaiSim log / this physics", "%-20s %-5s %-5s %-5s " % ("log", "mu", "delay", "falls") + " ".join("%-19s" % k for k in keys)]
+    for r in rows:
+        out.append("%-20s %-5s %-5d %-5d " % (r["name"], r["mu"], r["delay"], r["falls"]) + " ".join("%+8.4f /%+8.4f  " % (r["ref"][k], r["got"][k]) for k in keys))
+    for r in rows:
+        if "rise_t" in r:
+            out.append("# start from rest, delay %d: t [s] %s" % (r["delay"], " ".join("%5.2f" % t for t in r["rise_t"])))
+            out.append("#    RaiSim v_x      %s   90 %% of the final speed after %.2f s" % (" ".join("%5.2f" % v for v in r["rise_ref"]), r["t90_ref"]))
+            out.append("#    this physics    %s   90 %% of the final speed after %.2f s" % (" ".join("%5.2f" % v for v in r["rise_got"]), r["t90_got"]))
+    for name, why in skipped:
+        out.append("# not compared: %s -- %s" % (name, why))
+    return "\n".join(out)
+
+
+def assert_raisim_log_rows(rows):
+    """The stated bounds (RAISIM_LOG_TOL; *_EDGE at delay 5, where RaiSim's own two recordings already differ by 2-15 %)."""
+    worst = {}
+    for r in rows:
+        assert r["falls"] == 0, r["name"]
+        tol = RAISIM_LOG_TOL_EDGE if r["delay"] >= 5 else RAISIM_LOG_TOL
+        noisy = r["family"] == "start_from_rest_20s" and r["delay"] >= 4    # `roll_dot_noise` / `x_dot_noise` of these runs: undefined harness keys,
+        ref, got = r["ref"], r["got"]                                        # and RaiSim's delay-4 pair differs by 5.6 % between them
+        if noisy and r["delay"] == 4:
+            tol = RAISIM_LOG_TOL_EDGE
+        e = abs(got["vx_body_mean"] - ref["vx_body_mean"]) / abs(ref["vx_body_mean"])
+        assert e < tol["vx_rel"], (r["name"], "vx", got["vx_body_mean"], ref["vx_body_mean"])
+        worst["vx_rel"] = max(worst.get("vx_rel", 0), e) if r["delay"] < 4 else worst.get("vx_rel", 0)
+        e = abs(got["z_mean"] - ref["z_mean"])
+        assert e < tol["z_abs"], (r["name"], "z", got["z_mean"], ref["z_mean"])
+        worst["z_abs"] = max(worst.get("z_abs", 0), e)
+        if noisy and r["delay"] == 4:
+            # RaiSim's own pair at this delay: mean pitch +0.0124 (2 s recording, no noise keys) against -0.0010 (this 20 s recording with
+            # `roll_dot_noise: 0.5`), roll std 0.0097 against 0.0136 -- attitude is compared on the noise-free recording only
+            continue
+        e = abs(got["pitch_mean"] - ref["pitch_mean"])
+        assert e < tol["pitch_mean_abs"], (r["name"], "pitch", got["pitch_mean"], ref["pitch_mean"])
+        worst["pitch_mean_abs"] = max(worst.get("pitch_mean_abs", 0), e)
+        for k in ("roll_std", "pitch_std", "z_std", "vx_body_std"):
+            scale = 20.0 if k == "vx_body_std" else 1.0          # v_x ripple is ~0.07 m/s: same relative bound, absolute floor scaled
+            assert abs(got[k] - ref[k]) < tol["std_rel"] * ref[k] + tol["std_abs"] * scale, (r["name"], k, got[k], ref[k])
+        if r["delay"] >= 5:
+            assert got["yaw_rate_mean"] > 0.15 and ref["yaw_rate_mean"] > 0.15     # both simulators: the delayed loop drifts into a left turn
+            assert got["pitch_mean"] < -0.02 and ref["pitch_mean"] < -0.02          # ... nose down
+        if "t90_ref" in r:
+            assert abs(r["t90_got"] - r["t90_ref"]) < 0.35, (r["name"], r["t90_got"], r["t90_ref"])
+    return worst

@@ -57,13 +57,14 @@ def test_action_stream_depends_only_on_seed_env_and_step():
 
 def test_bench_gpus_n_launches_n_ranks_by_itself(monkeypatch):
     """`python bench.py --gpus N` outside a launcher starts torch.distributed.run with N ranks on 127.0.0.1 and relays its exit
-    code; under a launcher (WORLD_SIZE set) it runs the worker instead."""
+    code; under a launcher (WORLD_SIZE, RANK and MASTER_PORT set) it runs the worker instead."""
     sys.path.insert(0, ROOT)
     import bench
     calls = []
     monkeypatch.setattr(bench.subprocess, "call", lambda cmd, env=None: calls.append((cmd, env)) or 0)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5"])
-    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    for k in ("WORLD_SIZE", "RANK", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
     try:
         bench.main()
     except SystemExit as e:
@@ -77,9 +78,27 @@ def test_bench_gpus_n_launches_n_ranks_by_itself(monkeypatch):
     calls.clear()
     ran = []
     monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("MASTER_PORT", "29500")
     monkeypatch.setattr(bench, "worker", lambda args: ran.append(args.gpus))
     bench.main()
     assert ran == [4] and not calls
+    # a shell that merely exports WORLD_SIZE (no RANK / MASTER_PORT) is NOT a launcher: one process stays single ...
+    monkeypatch.delenv("RANK")
+    monkeypatch.delenv("MASTER_PORT")
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    assert not bench.launched_by_torchrun()
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    ran.clear()
+    bench.main()
+    assert ran == [1] and not calls
+    # ... and --gpus 4 still starts its own ranks
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
+    try:
+        bench.main()
+    except SystemExit as e:
+        assert e.code == 0
+    assert len(calls) == 1
 
 
 def test_baseline_config1_plumbing_runs_through_the_training_script_on_cpu():

@@ -1,0 +1,73 @@
+"""SURVEY 8a-6 held to the only simulator output the reference repository contains: the authors' RaiSim recordings of the bp5_155 policy
+(`Exp_Raw_Data/body-center-*.bin`, decoded by tools/gen_raisim_log_fixture.py into tests/golden/raisim_body_logs.json -- numbers only).
+The same closed loop (same actor weights, command, friction coefficient, observation delay) runs in this build's physics; steady-state speed,
+height, attitude and their ripple must agree with the logs within the bounds stated in parity_lib.RAISIM_LOG_TOL.  Not a state-level pin
+(the harness that made the logs is not in the repository: its warm-up, command ramp and initial state are unknown) -- a statistical one, on
+eleven recordings spanning mu = 0.05 .. 0.8 and 0 .. 5 control steps of observation delay."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+import parity_lib as PL
+from conftest import load_env_cfg
+
+FIXTURE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "raisim_body_logs.json")
+
+
+def _fixture():
+    with open(FIXTURE) as f:
+        return json.load(f)
+
+
+def test_fixture_is_a_consistent_decoding_of_the_logs():
+    """What the generator checked while decoding (Figure3.py:27-45 layout): unit quaternions, and the logged position is the integral of the
+    logged velocity at the 2 ms frame period the figure scripts use -- a wrong segment layout or frame rate breaks both."""
+    fx = _fixture()
+    assert fx["frame_dt"] == 0.002 and len(fx["logs"]) == 14 and len(fx["param_files_without_a_recording"]) == 8
+    for l in fx["logs"]:
+        c = l["check"]
+        assert abs(c["quat_norm_min"] - 1) < 1e-6 and abs(c["quat_norm_max"] - 1) < 1e-6
+        assert abs(c["x_travel"] - c["x_travel_from_logged_vx"]) < 2e-3 * max(1.0, abs(c["x_travel"]))
+        assert l["params"]["policy_name"].endswith("bp5_155") != l["runs_in_minus_x"]      # the two runs in -x are another policy (bp5_158)
+        # the trot's stride: 5 Hz (period 0.2 s) or its harmonics / sub-harmonics dominate the height spectrum
+        f0 = l["z_spectrum_hz_amp"][0][0]
+        assert min(abs(f0 / 5.0 - k) for k in (0.2, 0.3, 0.5, 1, 2, 3, 4)) < 0.06, (l["name"], f0)
+    # the power log saturates exactly at the motor model of the evaluation config (bp5_test.yaml: 18 N m; knee gear 1.55): ENV:1273-1312
+    pw = fx["power"]
+    assert pw["substeps_per_frame"] == 8
+    assert max(pw["torque_absmax"][1::3]) == pytest.approx(18.0, abs=1e-4) and max(pw["torque_absmax"][2::3]) <= 18.0 * 1.55 + 1e-3
+
+
+def test_oracle_physics_reproduces_the_raisim_logs():
+    """f64 oracle, CPU: eleven RaiSim recordings, statistics within the stated bounds (measured: speed within 1.3 % for delays 0-3 and all
+    frictions -- 5.1341 vs 5.1342 m/s at mu 0.4, 4.969 vs 4.975 on mu 0.05 ice -- height within 1.3 mm, mean pitch within 0.002 rad)."""
+    rows, skipped = PL.compare_with_raisim_logs(O.OracleVecEnv, load_env_cfg, _fixture())
+    print(PL.raisim_log_table(rows, skipped, "f64 oracle"))
+    assert len(rows) == 11 and len(skipped) == 3
+    worst = PL.assert_raisim_log_rows(rows)
+    print("worst gaps:", worst)
+
+
+def test_friction_dependence_follows_the_logs():
+    """The logs' speed is NOT monotone in mu (4.975 on mu 0.05, 5.134 on 0.4, 4.979 on 0.8): a contact model with the wrong sliding rule
+    misses that ordering (ContactSolver 2, the build's first rule, does -- round 3 replaced it with the published rule for that reason)."""
+    fx = _fixture()
+    by_mu = {l["params"]["Mu_Min"]: l["stats"]["vx_body_mean"] for l in fx["logs"] if l["family"] != "start_from_rest_20s" and not l["runs_in_minus_x"]
+             and l["params"].get("delay", 0) == 0 and float(l["params"].get("vel_filter", 5000)) >= 5000}
+    assert by_mu[0.4] > by_mu[0.8] > by_mu[0.05]
+    rows, _ = PL.compare_with_raisim_logs(O.OracleVecEnv, load_env_cfg, fx, max_frames=3000)
+    got = {r["mu"]: r["got"]["vx_body_mean"] for r in rows if r["delay"] == 0 and r["family"] != "start_from_rest_20s"}
+    assert got[0.4] > got[0.8] > got[0.05]
+
+
+@pytest.mark.gpu
+def test_hip_physics_reproduces_the_raisim_logs():
+    """The same comparison through the C-ABI on the MI355X (fp32 kernels): one Manual-mode env per recording in one pool."""
+    from hip_env import HipVecEnv
+    rows, skipped = PL.compare_with_raisim_logs(HipVecEnv, load_env_cfg, _fixture())
+    print(PL.raisim_log_table(rows, skipped, "HIP kernels, fp32"))
+    worst = PL.assert_raisim_log_rows(rows)
+    print("worst gaps:", worst)

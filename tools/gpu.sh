@@ -23,8 +23,8 @@
 #   terrain        BASELINE config 5 on one GPU: 4096 envs on the Perlin height field with per-episode friction / mass / COM randomisation and the
 #                  command process, LSTM policy, 200 updates from scratch + evaluation of the result
 #   train200       the reference's command line (200 envs, 2e8 samples), headless evaluation of the result
-#   abprec         item 2 of the round-4 verdict: config 3 trained 300 updates from the SAME seeds with the LSTM update's arithmetic at bf16x3 (default),
-#                  bf16x6 and f32; every update's reward / explained variance kept (tools/ab_precision_table.py overlays them)
+#   abprec         config 3 trained 300 updates per (seed, arm): arms = the LSTM update's arithmetic (bf16x3, bf16x6, f32; ABPREC_ARMS can set the
+#                  actor's and the critic's stacks apart), ABPREC_SEEDS seeds each (default 1 2 3); tools/ab_precision_table.py tabulates mean +- spread
 #   variants       A/B of every csrc/_variants/libirrl_env_*.so (tools/build_variants.py) on this one box, interleaved
 #   ablstm         same-box A/B of the PPO-LSTM update (bf16x3 and bf16x6) over every csrc/_variants/libirrl_env_*.so
 #   abmlp          same-box A/B of the PPO-MLP update with / without the packed sample records (IRRL_MLP_RECORDS)
@@ -129,10 +129,14 @@ while [ $# -gt 0 ]; do
         timeout 300 python scripts/run_bp_v5.py --test --model $O/irrl/stage1_final.pkl --cmd $c --steps 2000 2>&1 | grep "^test:" >> $O/irrl/eval.log
       done ;;
     abprec)
+      # verdict r5 item 1: >= 3 seeds per arm.  Arms: the update's arithmetic (IRRL_LSTM_PRECISION) and, to bisect, actor / critic stacks apart
+      # (IRRL_LSTM_PRECISION_PI / _V).  ABPREC_ARMS="name:pi:v ...", ABPREC_SEEDS="1 2 3"; every update's reward / explained variance kept.
       RS=high_speed_quadrupedal_locomotion_by_irrl_amd/rsc; mkdir -p $O/abprec; rm -f $O/abprec/*
-      for p in bf16x3 bf16x6 f32; do
-        IRRL_LSTM_PRECISION=$p timeout 900 python scripts/run_bp_v5.py --train --save 0 --cfg $RS/default_cfg.yaml --num_envs 4096 --l 0.001 --max_iter $((4096*750*${ABPREC_UPDATES:-300})) --eval_every_n 0 2>&1 > $O/abprec/raw_$p.log; grep -E "nupdates" $O/abprec/raw_$p.log | cut -c1-400 > $O/abprec/train_$p.log; tail -5 $O/abprec/raw_$p.log > $O/abprec/tail_$p.log; rm -f $O/abprec/raw_$p.log
-      done ;;
+      for seed in ${ABPREC_SEEDS:-1 2 3}; do for arm in ${ABPREC_ARMS:-bf16x3:bf16x3:bf16x3 bf16x6:bf16x6:bf16x6 f32:f32:f32}; do
+        name=${arm%%:*}; rest=${arm#*:}; ppi=${rest%%:*}; pv=${rest#*:}
+        IRRL_LSTM_PRECISION_PI=$ppi IRRL_LSTM_PRECISION_V=$pv timeout 900 python scripts/run_bp_v5.py --train --save 0 --seed $seed --cfg $RS/default_cfg.yaml --num_envs 4096 --l 0.001 --max_iter $((4096*750*${ABPREC_UPDATES:-300})) --eval_every_n 0 2>&1 > $O/abprec/raw.log
+        grep -E "nupdates" $O/abprec/raw.log | cut -c1-400 > $O/abprec/train_${name}_s$seed.log; tail -3 $O/abprec/raw.log > $O/abprec/tail_${name}_s$seed.log; rm -f $O/abprec/raw.log
+      done; done ;;
     variants)
       V=high_speed_quadrupedal_locomotion_by_irrl_amd/csrc/_variants; rm -f $O/variants.log
       for r in 1 2; do for f in $V/libirrl_env_*.so; do
