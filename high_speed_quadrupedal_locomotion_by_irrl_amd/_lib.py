@@ -86,6 +86,7 @@ SIGNATURES = {
     "irrl_mlp_policy_step": (C.c_int, [C.c_int] * 4 + [vp] * 9 + [C.c_int, C.c_uint, C.c_longlong, vp, C.c_int] + [vp] * 4 + [C.c_longlong] + [vp] * 8),
     "irrl_lstm_policy_step": (C.c_int, [C.c_int] * 4 + [vp] * 11 + [C.c_int, C.c_uint, C.c_longlong, vp, C.c_int] + [vp] * 4 + [C.c_longlong] + [vp] * 8),
     "irrl_mlp_rollout": (C.c_int, [vp] + [C.c_int] * 4 + [vp] * 9 + [C.c_int, C.c_uint, C.c_longlong, vp, C.c_int] + [vp] * 4 + [C.c_longlong] + [vp] * 8 + [C.c_int, vp]),
+    "irrl_lstm_rollout_supports": (C.c_int, [vp, C.c_int, C.c_int]),
     "irrl_lstm_rollout": (C.c_int, [vp] + [C.c_int] * 4 + [vp] * 11 + [C.c_int, C.c_uint, C.c_longlong, vp, C.c_int] + [vp] * 4 + [C.c_longlong] + [vp] * 8 + [C.c_int, vp]),
 }
 

@@ -310,6 +310,16 @@ int irrl_env_step_rows_persistent_out(irrl_env *h, int count, const float *actio
   return step_rows_persistent_impl(h, count, action_rows, n_rows, first_row, ob_rows, reward_rows, done_rows, extra_rows, 1, "irrl_env_step_rows_persistent_out");
 }
 
+// which `fuse` modes of irrl_lstm_rollout exist for THIS pool and network: 1 = the mode runs as described, 0 = it does not (fuse 1 / 2 then fall
+// back to two launches per step inside the call; fuse 3 is refused -- its caller must evaluate the critic itself, so it has to know beforehand)
+static bool rollout_one_tile(const irrl_env *h, int hid) { return h->lanes == 16 && !h->P.crutial && h->P.contact_rule && hid == 48; }
+int irrl_lstm_rollout_supports(irrl_env *h, int hid, int fuse) {
+  if (!h) { g_err = "irrl_lstm_rollout_supports: NULL handle"; return -1; }
+  if (fuse == 0) return 1;
+  if (fuse < 0 || fuse > 3) return 0;
+  return rollout_one_tile(h, hid) ? 1 : 0;
+}
+
 int irrl_lstm_rollout(irrl_env *h, int steps, int hid, int ob_dim, int act_dim, float *obs, uint8_t *dones, const float *states_in,
                       float *states_out, const float *const *lstm_w, const float *pi_w, const float *pi_b, const float *vf_w,
                       const float *vf_b, const float *logstd, const float *noise, int rng_on, unsigned rng_seed, long long rng_step,
@@ -332,7 +342,7 @@ int irrl_lstm_rollout(irrl_env *h, int steps, int hid, int ob_dim, int act_dim, 
   // fuse != 0: one launch per step, env.step k together with the policy step k + 1 (16-lane layout = one MFMA M-tile per four env
   // waves, the reference's 48-unit network, pools without the meteorite).  Bit-identical to the two-launch sequence, and measured
   // SLOWER on MI355X (62.9 against 58.2 us per step at 4096 envs): kept as an option, not the default.
-  const bool one_tile = h->lanes == 16 && !h->P.crutial && h->P.contact_rule && hid == 48;   // what the combined kernels are instantiated for
+  const bool one_tile = rollout_one_tile(h, hid);   // what the combined kernels are instantiated for
   // fuse == 2: THE WHOLE ROLLOUT AS ONE PERSISTENT LAUNCH (irrl_rollout_persistent_kernel_l16): a workgroup loops over all steps for its
   // 16 robots -- no grid-wide boundary between steps, layer-0 weights fetched into LDS once.  Same device code per step as the
   // other two paths, bit-identical buffers.
@@ -869,12 +879,10 @@ static int mlp_bf16_launch(const char *who, int kind, bool use_rec, size_t n, in
   if (n == 0 || n_blocks <= 0) { g_err = std::string(who) + ": empty batch"; return 1; }
   if (kind != 0 && kind != 1) { g_err = std::string(who) + ": kind is 0 (policy network) or 1 (value network)"; return 1; }
   // the opt-in belongs to the CURRENT device (a process may drive several GPUs): remembered per device ordinal
-  static int allowed_on[IRRL_MAX_DEVICES];
-  static bool allowed_init = false;
-  if (!allowed_init) { for (int i = 0; i < IRRL_MAX_DEVICES; i++) allowed_on[i] = -1; allowed_init = true; }
+  static IrrlPerDeviceFlag allowed_on;     // function-local static with a constructor: initialised once, thread-safe (C++11)
   int dev_ = 0;
   if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= IRRL_MAX_DEVICES) { g_err = std::string(who) + ": no current device"; return 1; }
-  int &allowed = allowed_on[dev_];
+  int &allowed = allowed_on.v[dev_];
   if (allowed < 0) {   // the weight planes and the waves' images exceed the 64 KB a kernel gets without asking (gfx950 has 160 KB per CU)
     const void *ks[4] = {(const void *)irrl_mlp_ppo_bf16_kernel<0, false>, (const void *)irrl_mlp_ppo_bf16_kernel<1, false>,
                          (const void *)irrl_mlp_ppo_bf16_kernel<0, true>, (const void *)irrl_mlp_ppo_bf16_kernel<1, true>};

@@ -1285,6 +1285,13 @@ int irrl_mlp_policy_step(int hid, int ob_dim, int act_dim, int N, const float *o
 #ifndef IRRL_MAX_DEVICES
 #define IRRL_MAX_DEVICES 64
 #endif
+// "has this device granted the kernels' LDS size": -1 = not asked yet, 0 = yes, otherwise the error.  A function-local static of this type is
+// constructed exactly once under the C++11 guarantee; filling a slot later is idempotent (every thread that finds -1 asks the same question and
+// stores the same answer).
+struct IrrlPerDeviceFlag {
+  int v[IRRL_MAX_DEVICES];
+  IrrlPerDeviceFlag() { for (int i = 0; i < IRRL_MAX_DEVICES; i++) v[i] = -1; }
+};
 // returns 0 on success; 1 = unsupported shape, 2 = launch error
 static int lstm_bf16_allow_lds(const void *kernel, int bytes) {
   // the tiles exceed the 64 KB a kernel gets without asking (gfx950 has 160 KB per CU)
@@ -1320,12 +1327,10 @@ int irrl_lstm_seq_backward_bf16(int nsplit, int hid, int T, int N, int n_in, con
   a.dx = dx; a.dwx_part = dwx_part; a.dwh_part = dwh_part; a.db_part = db_part; a.T = T; a.N = N; a.n_in = n_in;
   hipStream_t s = (hipStream_t)hip_stream;
   // the opt-in belongs to the CURRENT device (a process may drive several GPUs): remembered per device ordinal
-  static int allowed_on[IRRL_MAX_DEVICES];
-  static bool allowed_init = false;
-  if (!allowed_init) { for (int i = 0; i < IRRL_MAX_DEVICES; i++) allowed_on[i] = -1; allowed_init = true; }
+  static IrrlPerDeviceFlag allowed_on;     // function-local static with a constructor: initialised once, thread-safe (C++11)
   int dev_ = 0;
   if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= IRRL_MAX_DEVICES) return 2;
-  int &allowed = allowed_on[dev_];
+  int &allowed = allowed_on.v[dev_];
   if (allowed < 0) {
     allowed = lstm_bf16_allow_lds((const void *)lstm_seq_bwd_bf16_kernel<2, true>, lstm_bwd_bf16_lds_bytes<2>()) |
               lstm_bf16_allow_lds((const void *)lstm_seq_bwd_bf16_kernel<2, false>, lstm_bwd_bf16_lds_bytes<2>()) |

@@ -180,7 +180,8 @@ if CRITIC_PASS_PRECISION not in ("bf16x6", "f32"):
 # arithmetic of the MlpPolicy gradient kernels: "bf16x3" = every product as three bf16 plane products on the matrix cores (two planes per
 # operand, f32 accumulation, ~2^-16 relative per product; csrc/mlp_bf16.hpp), "f32" = v_mfma_f32_16x16x4_f32 (csrc/mlp_update.hpp)
 MLP_PRECISION = os.environ.get("IRRL_MLP_PRECISION", "bf16x3")
-# the update's samples as packed 256-byte records (csrc/mlp_update.hpp IRRL_MLP_REC; bf16x3 kernels): IRRL_MLP_RECORDS=0 reads the five arrays instead
+# the update's samples as packed 256-byte records (csrc/mlp_update.hpp IRRL_MLP_REC; bf16x3 kernels): OFF by default (the five arrays are read as they
+# lie); IRRL_MLP_RECORDS=1 enables the records -- bit-identical gradients, same time
 MLP_RECORDS = os.environ.get("IRRL_MLP_RECORDS", "0") != "0"
 
 
@@ -564,6 +565,21 @@ class Runner(object):
         off = sum(2 * h for h in pol.n_lstm)
         self.states[:, off:].copy_(torch.cat(new_v, 1))
 
+    def _actor_only_supported(self):
+        """irrl_lstm_rollout_supports(pool, hid, fuse = 3), asked once per runner: the persistent actor-only kernel exists for 16 lanes per
+        robot, 48 hidden units, Crutial off and the published contact rule; MlpPolicy has no critic stack to take off the path."""
+        if not hasattr(self, "_actor_only_ok"):
+            pol = self.model.policy
+            ok = False
+            if hasattr(pol, "lstm_v") and hasattr(getattr(self.env, "wrapper", None), "_h"):
+                from . import _lib
+                rc = _lib.load().irrl_lstm_rollout_supports(self.env.wrapper._h, int(pol.n_lstm[0]), 3)
+                if rc < 0:
+                    _lib.check(1)
+                ok = rc == 1
+            self._actor_only_ok = ok
+        return self._actor_only_ok
+
     def _fused_step(self, t):
         """Rollout step t as two launches: the whole policy step (sample, clip, buffer rows incl. the previous reward) and
         the env step, which writes obs / reward / dones straight into the runner's tensors."""
@@ -681,17 +697,11 @@ class Runner(object):
                              mb_neglogpacs=self.mb_neglogpacs, mb_dones=self.mb_dones, mb_rewards=self.mb_rewards),
                         self._out, self.rew, self.env.extra)
                 mode = self.rollout_one_launch_per_step
-                if mode == 3 and hasattr(pol, "lstm_v") and not getattr(self, "_actor_only_refused", False):
-                    try:
-                        pol.fused_rollout(*args, noise_all=self.noise_all, fused=3)
-                        self._critic_pass(mb_states)
-                    except RuntimeError as exc:      # the actor-only kernel is not instantiated for this pool / network: nothing was launched
-                        if "fuse = 3" not in str(exc):
-                            raise
-                        self._actor_only_refused = True
-                        pol.fused_rollout(*args, noise_all=self.noise_all, fused=2)
-                else:
-                    pol.fused_rollout(*args, noise_all=self.noise_all, fused=2 if mode == 3 else mode)
+                if mode == 3 and not self._actor_only_supported():
+                    mode = 2      # the actor-only kernel is not instantiated for this pool / network (asked through the C-ABI, nothing was launched)
+                pol.fused_rollout(*args, noise_all=self.noise_all, fused=mode)
+                if mode == 3:
+                    self._critic_pass(mb_states)
             elif self._graph is not None:
                 self._graph.replay()
             else:
@@ -769,6 +779,18 @@ class PPO2(object):
         if hasattr(self.policy, "prepare") and hasattr(self.optimizer, "register_step_post_hook"):
             self.optimizer.register_step_post_hook(lambda *_a, **_k: self.policy.prepare())
         self.loss_names = ['policy_loss', 'value_loss', 'policy_entropy', 'approxkl', 'clipfrac']
+        # replicas: identical seeds give identical initial weights, but nothing else guarantees it (a rank-local `load`, a different torch
+        # build on one node) -- rank 0's parameters and Adam moments are broadcast once here and after every `load_parameters`, and
+        # `check_replicas` compares a checksum across the ranks every REPLICA_CHECK_EVERY updates of `learn`
+        self.sync_replicas()
+        if self.collective:
+            # the minibatch permutations and the sampling-noise key derive from `seed`: ranks that disagree on it would cut DIFFERENT global
+            # minibatches while their replicas stay bit-identical -- a wrong gradient no checksum can see
+            sd = torch.tensor([self.seed, -self.seed], dtype=torch.int64, device=self._collective_device())
+            torch.distributed.all_reduce(sd, op=torch.distributed.ReduceOp.MAX)
+            if int(sd[0]) != -int(sd[1]):
+                raise ValueError("PPO2: the ranks were given different seeds (%d .. %d): the seed must be the same on every rank (the ranks' "
+                                 "data differs by EnvIdOffset, not by seed)" % (-int(sd[1]), int(sd[0])))
         self.fused_loss = True   # single-launch loss forward + backward on the GPU (tests flip it to compare with the eager graph)
         self.fused_mlp = True    # MlpPolicy: forward + loss + every gradient in one launch per network (tests flip it likewise)
         self.fused_heads = True  # ... including the policy / value heads and their gradients (LSTM policy, 48-unit latents)
@@ -1076,6 +1098,8 @@ class PPO2(object):
                             if new_file:
                                 f.write(",".join(row.keys()) + "\n")
                             f.write(",".join(repr(v) for v in row.values()) + "\n")
+            if self.collective and (update % self.REPLICA_CHECK_EVERY == 0 or update == nupdates):
+                self.check_replicas()
             if callback is not None and callback(locals(), globals()) is False:
                 break
 
@@ -1132,6 +1156,70 @@ class PPO2(object):
                     raise ValueError("PPO2: ranks own overlapping global env ids %s -- give rank r's pool EnvIdOffset = r * num_envs "
                                      "(cfg['environment']['EnvIdOffset']), otherwise every rank draws the same random streams" % (spans,))
 
+    # -- replica consistency of the N-rank learner (no counterpart in the single-process reference) --
+    REPLICA_CHECK_EVERY = 50
+
+    def _collective_device(self):
+        return self.device if torch.distributed.get_backend() == "nccl" else torch.device("cpu")
+
+    def sync_replicas(self, src=0):
+        """Rank `src`'s parameters, Adam moments and step counts to every rank (broadcasts of the flat buffers + one small integer vector); the
+        LSTM kernels' permuted weight copies are rebuilt.  A no-op outside a process group."""
+        if not self.collective:
+            return
+        fl = self.flat
+        cdev = self._collective_device()
+        st0 = self.optimizer.state.get(fl.params[0])
+        meta = torch.tensor([fl.step, int(st0["step"]) if st0 else 0, 1 if st0 else 0], dtype=torch.int64, device=cdev)
+        torch.distributed.broadcast(meta, src)
+        fl.step = int(meta[0])
+
+        def bcast(buf):
+            tmp = buf if buf.device == cdev else buf.to(cdev)
+            torch.distributed.broadcast(tmp, src)
+            if tmp is not buf:
+                buf.copy_(tmp)
+
+        for buf in (fl.theta, fl.m, fl.v):
+            bcast(buf)
+        # the eager optimizer (CPU path; what the tests compare the flat-buffer kernel with) keeps its moments per parameter
+        if int(meta[2]):
+            for key in ("m", "v"):
+                flat_state = torch.cat([(self.optimizer.state[p][key] if self.optimizer.state.get(p) else torch.zeros_like(p)).reshape(-1)
+                                        for p in fl.params])
+                bcast(flat_state)
+                o = 0
+                for p in fl.params:
+                    st = self.optimizer.state[p]
+                    if not st:
+                        st["step"], st["m"], st["v"] = 0, torch.zeros_like(p), torch.zeros_like(p)
+                    st[key].copy_(flat_state[o:o + p.numel()].view_as(p))
+                    st["step"] = int(meta[1])
+                    o += p.numel()
+        else:
+            self.optimizer.state.clear()
+        if hasattr(self.policy, "prepare"):
+            self.policy.prepare()
+
+    def replica_checksum(self):
+        """64-bit checksum of this rank's parameters: the float32 words of the flat buffer read as integers, summed (wrapping)."""
+        return self.flat.theta.view(torch.int32).to(torch.int64).sum()
+
+    def check_replicas(self):
+        """All ranks hold bit-identical parameters, or RuntimeError: ONE all-reduce (MAX) of (checksum, -checksum) -> max and -min over the
+        ranks.  Data-parallel PPO keeps the replicas identical by construction (same averaged gradient, same Adam step on every rank); a
+        silent divergence -- a rank-local load, a rank that skipped a collective -- otherwise only shows up as a bad policy hours later."""
+        if not self.collective:
+            return True
+        cs = self.replica_checksum().to(self._collective_device())
+        pair = torch.stack([cs, -cs])
+        torch.distributed.all_reduce(pair, op=torch.distributed.ReduceOp.MAX)
+        if int(pair[0]) != -int(pair[1]):
+            raise RuntimeError("PPO2: the ranks' policy parameters differ (checksum max %d, min %d; this rank %d of %d: %d) -- replicas have "
+                               "diverged; call sync_replicas() after any rank-local change of the parameters"
+                               % (int(pair[0]), -int(pair[1]), self.rank, self.world, int(cs)))
+        return True
+
     # -- checkpoints (ppo2.py:452-476): (data dict, parameter list in stable-baselines order) --
     def _data(self):
         return {"gamma": self.gamma, "n_steps": self.n_steps, "vf_coef": self.vf_coef, "ent_coef": self.ent_coef,
@@ -1161,6 +1249,7 @@ class PPO2(object):
                 a = torch.as_tensor(np.asarray(a), dtype=p.dtype)
                 assert tuple(a.shape) == tuple(p.shape), (tuple(a.shape), tuple(p.shape))
                 p.copy_(a.to(p.device))
+        self.sync_replicas()      # several ranks: rank 0's copy is THE copy (a no-op for identical files, a repair for a rank-local one)
 
     @classmethod
     def load(cls, load_path, env=None, device=None, **kwargs):
@@ -1168,7 +1257,17 @@ class PPO2(object):
         decoded without tensorflow / stable_baselines / gym by a stub unpickler) -- the IRRL stage-2 warm start
         (run_bp_v5.py:244-249, readme.md:66-70)."""
         from .checkpoint import read_checkpoint
-        data, params = read_checkpoint(load_path)
+        dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+        if dist_on:
+            # run_bp_v5.py:245-248 under a launcher: rank 0 reads the file, every rank gets its content (the other ranks need not see the path)
+            box = [read_checkpoint(load_path) if torch.distributed.get_rank() == 0 else None]
+            kw = {}
+            if torch.distributed.get_backend() == "nccl":
+                kw["device"] = torch.device("cuda", torch.cuda.current_device())
+            torch.distributed.broadcast_object_list(box, 0, **kw)
+            data, params = box[0]
+        else:
+            data, params = read_checkpoint(load_path)
         pk = data.get("policy_kwargs") or {}
         n_lstm = pk.get("n_lstm", [48, 48])
         is_lstm = len(params) == 19 or data.get("policy") in ("CustomLSTMPolicy",)

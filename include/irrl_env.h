@@ -330,6 +330,11 @@ int irrl_lstm_rollout(irrl_env *env, int steps, int hid, int ob_dim, int act_dim
                       float *mb_actions, float *mb_values, float *mb_neglogp, uint8_t *mb_dones, float *mb_rewards,
                       float *env_reward, float *env_extra, int fuse, void *hip_stream);
 
+/* Which `fuse` modes of irrl_lstm_rollout exist for THIS pool and a network of `hid` units per LSTM layer: 1 = the mode runs as described above,
+ * 0 = it does not (fuse 1 / 2 then run as two launches per step inside the call; fuse 3 is refused with an error, because its caller has to
+ * evaluate the critic itself and must know beforehand), -1 = bad handle.  Callers branch on this, not on the text of irrl_last_error(). */
+int irrl_lstm_rollout_supports(irrl_env *env, int hid, int fuse);
+
 /* the same single-launch rollout step for MlpPolicy (flex_gym/archi/policies.py:430-446: separate pi / vf nets of two tanh
  * layers of `hid` = 64 units).  mlp_w: HOST array of 8 device pointers pi_w1 [ob][hid], pi_b1, pi_w2 [hid][hid], pi_b2,
  * vf_w1, vf_b1, vf_w2, vf_b2; heads, sampling, outputs and rollout rows as above; act <= 15. */

@@ -739,7 +739,7 @@ def test_graph_capture_warmup_leaves_no_trace_and_setters_invalidate_the_graph()
         runner.rollout_one_launch_per_step = {"one_launch": 1, "persistent": 2, "persistent_actor": 3, "persistent_actor_wg": 3}.get(mode, 0)
         b1 = {k: v.clone() for k, v in runner.run().items() if torch.is_tensor(v)}
         assert (runner._graph is not None) == (mode == "graph")
-        assert not getattr(runner, "_actor_only_refused", False)
+        assert runner._actor_only_supported() or mode not in ("persistent_actor", "persistent_actor_wg")   # asked through the C-ABI, not parsed from an error text
         env.wrapper.setSeed(77)                       # new noise / command streams from the next reset on
         b2 = {k: v.clone() for k, v in runner.run().items() if torch.is_tensor(v)}
         b3 = {k: v.clone() for k, v in runner.run().items() if torch.is_tensor(v)}
@@ -938,7 +938,7 @@ def test_wave_pair_mlp_gradient_kernels_equal_the_four_wave_kernels_bit_for_bit(
 
 
 def test_mlp_update_through_packed_records_equals_the_update_through_the_arrays(monkeypatch):
-    """PPO2.update of the shipped MlpPolicy configuration (4 minibatches x 3 epochs here) with the packed records (the default) and without
+    """PPO2.update of the shipped MlpPolicy configuration (4 minibatches x 3 epochs here) with the packed records (off by default; IRRL_MLP_RECORDS=1 / ppo2.MLP_RECORDS enables them) and without
     (`ppo2.MLP_RECORDS = False`): the same parameters and statistics, bit for bit."""
     from high_speed_quadrupedal_locomotion_by_irrl_amd import ppo2 as P2
     from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import MlpPolicy
@@ -1015,3 +1015,33 @@ def test_random_permutation_kernel_is_a_permutation_and_equals_its_numpy_twin(n)
         _lib.check(lib.irrl_random_permutation(n, 987654321, 6, C.c_void_p(out.data_ptr()), stream))
         assert float((out.cpu().numpy() != got).mean()) > 0.99
         assert abs(float(np.corrcoef(np.arange(n), got)[0, 1])) < 0.05
+
+
+def test_actor_only_rollout_is_chosen_by_a_capability_query_not_by_an_error_text(monkeypatch):
+    """the runner asks `irrl_lstm_rollout_supports(pool, hid, 3)` before it launches.  A 16-lane pool has the actor-only persistent
+    kernel, a 4-lane pool has not: there the default mode (3) silently becomes 2 -- two launches per step inside the C call -- with the same
+    rollout as the eager reference path, and an explicit fuse = 3 call is still refused by the C-ABI with rc != 0."""
+    import torch
+    from high_speed_quadrupedal_locomotion_by_irrl_amd import _lib
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.policies import CustomLSTMPolicy
+    from high_speed_quadrupedal_locomotion_by_irrl_amd.ppo2 import PPO2, Runner
+    lib = _lib.load()
+    env16 = _env(64)
+    assert env16.wrapper.lanes_per_robot == 16
+    assert [lib.irrl_lstm_rollout_supports(env16.wrapper._h, 48, f) for f in (0, 1, 2, 3, 4)] == [1, 1, 1, 1, 0]
+    assert lib.irrl_lstm_rollout_supports(env16.wrapper._h, 64, 3) == 0            # the combined kernels are instantiated for 48 units
+    monkeypatch.setenv("IRRL_LANES_PER_ROBOT", "4")
+    outs = {}
+    for mode in ("default", "eager"):
+        env4 = _env(64)
+        assert env4.wrapper.lanes_per_robot == 4
+        assert lib.irrl_lstm_rollout_supports(env4.wrapper._h, 48, 3) == 0 and lib.irrl_lstm_rollout_supports(env4.wrapper._h, 48, 0) == 1
+        model = PPO2(policy=CustomLSTMPolicy, env=env4, n_steps=12, nminibatches=1, noptepochs=1, seed=4)
+        runner = Runner(env4, model, 12, 0.99, 0.998, use_graph=False)
+        if mode == "eager":
+            runner.rollout_launch = "graph"          # with use_graph False: the per-step Python loop
+        else:
+            assert runner.rollout_one_launch_per_step == 3 and not runner._actor_only_supported()
+        outs[mode] = {k: v.clone() for k, v in runner.run().items() if torch.is_tensor(v)}
+    for k in ("obs", "actions", "values", "true_reward", "masks", "neglogpacs", "returns"):
+        assert torch.equal(outs["default"][k], outs["eager"][k]), k
