@@ -255,7 +255,8 @@ constexpr int LBF_GC = 4 * LBF_HID;         // gate columns
 constexpr int LBF_RROW = LBF_GC + 8;        // dz tile [env][gate column]: padded row, 400 bytes (16-byte aligned)
 constexpr int LBF_CROW = 16 + 4;            // [gate column | unit | input][env]: padded row, 40 bytes (8-byte aligned)
 template <int NS> constexpr int lstm_bwd_bf16_lds_elems_per_buf() { return NS * (16 * LBF_RROW + LBF_HID * LBF_CROW + LBF_KX * LBF_CROW); }
-template <int NS> constexpr int lstm_bwd_bf16_lds_bytes() { return 2 * lstm_bwd_bf16_lds_elems_per_buf<NS>() * 2; }
+template <int NS> constexpr int lbf_total_bytes();
+template <int NS> constexpr int lstm_bwd_bf16_lds_bytes() { return 2 * lstm_bwd_bf16_lds_elems_per_buf<NS>() * 2 + lbf_total_bytes<NS>(); }
 
 // the weight-gradient products of one step for NCI gate-column tiles (first one: ci0) against all six M-tiles (0-2: hidden rows of dwh, 3-5: input
 // rows of dwx); `bufbase` = the step's LDS buffer.  Per accumulator tile the plane products arrive in the same order whoever owns the tile.
@@ -308,6 +309,41 @@ LSTM_DEV void lbf_store_weight_grads(const f32x4 (&accW)[6][NCI], const LstmBwdB
   }
 }
 
+// TWO-LEVEL ACCUMULATION OF THE WEIGHT GRADIENTS (round 6; three planes = the f32-level arithmetic only).  A tile's accumulator takes the plane
+// products of every step: T x PR::N matrix-core additions into ONE f32 value each, every one rounded at the magnitude the running sum has
+// reached -- at T = 750 that rounding walk, not the operand splits, is what bf16x6's weight-gradient error consisted of (4.1e-6 / 5.6e-6 of the
+// largest entry on dwx / dwh against 1.7e-6 / 2.6e-6 of the exact-f32 kernels, which add 4 instead of 6 products per step and tile;
+// profiles/r05_pytest_gpu.log).  So the register accumulators only ever hold LBF_FLUSH steps: every LBF_FLUSH steps they are added (vector ALU,
+// round to nearest) to the tile's running total, which lives in LDS -- 72 tiles x 1 KB behind the operand buffers, each element read and written
+// by the one lane that owns it: no synchronisation, one ds_read_b128 + ds_write_b128 per tile and flush -- and cleared.  The products of a block
+// meet an accumulator that is LBF_FLUSH / T as large; the T / LBF_FLUSH block sums are ordinary f32 additions.  (Two planes: the 2^-16 of the
+// dropped plane products dominates, nothing to gain; that kernel is unchanged and has no register to spare.)
+#ifndef IRRL_LBF_FLUSH
+#define IRRL_LBF_FLUSH 32
+#endif
+template <int NS> constexpr int lbf_flush_steps() { return NS == 3 ? IRRL_LBF_FLUSH : 0; }      // 0: one accumulation over all T steps (rounds 4-5)
+template <int NS> constexpr int lbf_total_bytes() { return lbf_flush_steps<NS>() > 0 ? 72 * 256 * 4 : 0; }
+// acc -> total (and cleared), or, behind the last step, total -> acc (what lbf_store_weight_grads then writes out)
+template <int NCI>
+LSTM_DEV void lbf_flush_weight_grads(f32x4 (&accW)[6][NCI], float *tot, int ci0, int l, bool last) {
+#pragma unroll
+  for (int ci = 0; ci < NCI; ci++)
+#pragma unroll
+    for (int mt = 0; mt < 6; mt++) {
+      f32x4 *p = (f32x4 *)(tot + ((size_t)((ci0 + ci) * 6 + mt) * 256 + 4 * l));
+      const f32x4 sum = *p + accW[mt][ci];
+      if (last) accW[mt][ci] = sum;
+      else { *p = sum; accW[mt][ci] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; }
+    }
+}
+template <int NCI>
+LSTM_DEV void lbf_clear_totals(float *tot, int ci0, int l) {
+#pragma unroll
+  for (int ci = 0; ci < NCI; ci++)
+#pragma unroll
+    for (int mt = 0; mt < 6; mt++) *(f32x4 *)(tot + ((size_t)((ci0 + ci) * 6 + mt) * 256 + 4 * l)) = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+}
+
 template <int NS, bool NEED_DX>
 __global__ void __launch_bounds__(256)
 lstm_seq_bwd_bf16_kernel(const LstmBwdBf16Args a) {
@@ -342,6 +378,14 @@ lstm_seq_bwd_bf16_kernel(const LstmBwdBf16Args a) {
   constexpr int MAIN_CI = (NS == 3) ? 3 : 2;
 #endif
   constexpr int HELP_PARTS = (12 - 3 * MAIN_CI) / 3;     // the helper wave's tiles in parts of three
+  constexpr int FLUSH = lbf_flush_steps<NS>();           // two-level accumulation of the weight gradients (above); 0 = off
+  float *totals = (float *)(lds_b + 2 * (size_t)PER_BUF);   // [72 tiles][256]: only touched when FLUSH > 0 (the launch then asks for the bytes)
+  if (FLUSH > 0) {      // every wave clears the tiles it owns; nobody else ever touches them
+    if (main_wave) lbf_clear_totals<MAIN_CI>(totals, MAIN_CI * w, l);
+    else
+#pragma unroll
+      for (int hf = 0; hf < HELP_PARTS; hf++) lbf_clear_totals<3>(totals, 3 * MAIN_CI + 3 * hf, l);
+  }
   // The 72 weight-gradient tiles (12 gate-column tiles x 6 M-tiles): waves 0-2, which also carry the gate arithmetic and the recurrence, own
   // gate-column tiles 2 w, 2 w + 1 (12 accumulator tiles, 36 MFMAs per step); wave 3, which otherwise only stages x_t^T, owns tiles 6 .. 11 (36
   // accumulator tiles, 108 MFMAs per step).  (Shared out evenly -- 18 tiles each -- the main waves were the step's critical path.)
@@ -386,10 +430,17 @@ lstm_seq_bwd_bf16_kernel(const LstmBwdBf16Args a) {
         __syncthreads();
 #pragma unroll
         for (int hf = 0; hf < HELP_PARTS; hf++) lbf_weight_grads<NS, 3>(accH[hf], lds_b + (size_t)(tt & 1) * PER_BUF, 3 * MAIN_CI + 3 * hf, col, rq);
+        if (FLUSH > 0 && tt > 0 && (T - tt) % FLUSH == 0) {      // FLUSH steps are in the accumulators (wave-uniform)
+#pragma unroll
+          for (int hf = 0; hf < HELP_PARTS; hf++) lbf_flush_weight_grads<3>(accH[hf], totals, 3 * MAIN_CI + 3 * hf, l, false);
+        }
       }
     }
 #pragma unroll
-    for (int hf = 0; hf < HELP_PARTS; hf++) lbf_store_weight_grads<3>(accH[hf], a, 3 * MAIN_CI + 3 * hf, col, rq);
+    for (int hf = 0; hf < HELP_PARTS; hf++) {
+      if (FLUSH > 0) lbf_flush_weight_grads<3>(accH[hf], totals, 3 * MAIN_CI + 3 * hf, l, true);
+      lbf_store_weight_grads<3>(accH[hf], a, 3 * MAIN_CI + 3 * hf, col, rq);
+    }
     return;
   }
   // ---- waves 0-2 ----
@@ -503,6 +554,7 @@ lstm_seq_bwd_bf16_kernel(const LstmBwdBf16Args a) {
       for (int j = 0; j < 4; j++) a.dx[((size_t)t * N + e0 + 4 * rq + j) * n_in + u] = accx[j];
     }
     lbf_weight_grads<NS, MAIN_CI>(accW, lds_b + (size_t)buf * PER_BUF, MAIN_CI * w, col, rq);
+    if (FLUSH > 0 && t > 0 && (T - t) % FLUSH == 0) lbf_flush_weight_grads<MAIN_CI>(accW, totals, MAIN_CI * w, l, false);
   };
   StepOps ops[DEPTH];
 #pragma unroll
@@ -513,6 +565,7 @@ lstm_seq_bwd_bf16_kernel(const LstmBwdBf16Args a) {
     for (int d = 0; d < DEPTH; d++)
       if (t - d >= 0) step(t - d, ops[d]);
   }
+  if (FLUSH > 0) lbf_flush_weight_grads<MAIN_CI>(accW, totals, MAIN_CI * w, l, true);
   lbf_store_weight_grads<MAIN_CI>(accW, a, MAIN_CI * w, col, rq);
   const size_t blk = blockIdx.x;
 #pragma unroll

@@ -97,7 +97,10 @@ def test_lstm_sequence_kernels_hold_their_error_bounds_at_the_training_shape(pre
     (48 -> 48), forward + full-length BPTT, against FLOAT64 autograd of the eager stable-baselines definition (run_bp_v5.py:143-176),
     per tensor relative to its largest entry.  Bounds = what profiles/r04_lstm_precision_error_and_time.log measured, with headroom:
       bf16x3 (the learner's default: two bf16 planes, ~2^-16 per product)   h, state, dx <= 2e-5;  dwx, dwh, db <= 1e-5
-      bf16x6 / f32 (the f32 level)                                          h, state, dx <= 2e-6;  dwx, dwh, db <= 1e-5
+      bf16x6 / f32 (the f32 level)                                          h, state, dx <= 2e-6;  dwx, dwh, db <= 3e-6
+    (round 6, verdict r5 item 1c: the weight-gradient bound is per arithmetic -- rounds 4-5 held all three to 1e-5, 6x what the f32 kernels
+    measure -- and bf16x6, whose 750 x 6 matrix-core additions per accumulator measured 4.1e-6 / 5.6e-6, accumulates in two levels now,
+    csrc/lstm_bf16.hpp `lbf_flush_weight_grads`.)
     For scale: PyTorch's eager f32 graph itself reaches 1.6e-5 on dwx at this shape (its reduction order)."""
     import copy
     from high_speed_quadrupedal_locomotion_by_irrl_amd import lstm_fused
@@ -134,8 +137,9 @@ def test_lstm_sequence_kernels_hold_their_error_bounds_at_the_training_shape(pre
     for name, a, b in zip(["h_seq", "state", "dx", "dwx", "dwh", "db"], out, ref):
         errs[name] = float((a.double() - b).abs().max()) / (float(b.abs().max()) + 1e-30)
     print("\n[lstm kernels %s, T 750 x N 4096] max |kernel - float64| / max |float64|: %s" % (prec, {k: "%.2e" % v for k, v in errs.items()}))
+    wgrad_tol = 1e-5 if prec == "bf16x3" else 3e-6
     for name, e in errs.items():
-        assert e <= (act_tol if name in ("h_seq", "state", "dx") else 1e-5), (prec, name, e)
+        assert e <= (act_tol if name in ("h_seq", "state", "dx") else wgrad_tol), (prec, name, e)
 
 
 @pytest.mark.parametrize("prec", ["bf16x3", "bf16x6"])

@@ -29,6 +29,7 @@
 #   ablstm         same-box A/B of the PPO-LSTM update (bf16x3 and bf16x6) over every csrc/_variants/libirrl_env_*.so
 #   abmlp          same-box A/B of the PPO-MLP update with / without the packed sample records (IRRL_MLP_RECORDS)
 #   abmlpw         same-box A/B of the MlpPolicy gradient kernels, four waves against producer / consumer wave pairs (IRRL_MLP_WAVES)
+#   graderr        LSTM sequence kernels vs float64 autograd at 750 x 4096 (every arithmetic), shipped library + every variant library
 #   spread         per-wave durations of the step kernel (needs the `prof` variant library)
 #   ab <cmd...>    run the rest of the line verbatim (one-off A/B)
 cd "$GRAFT_REPO_ROOT" || exit 1
@@ -154,6 +155,15 @@ while [ $# -gt 0 ]; do
       for r in 1 2; do for f in $V/libirrl_env_*.so; do for prec in bf16x3 bf16x6; do
         IRRL_ENV_LIB=$PWD/$f timeout 300 python tools/ppo_bench.py --policy lstm --envs 4096 --iters 4 --precision $prec 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$(basename $f .so) $prec rollout', round(d['rollout_s']*1e3,2), 'ms update', round(d['update_s']*1e3,2), 'ms', round(d['ppo_iters_per_sec'],3), 'it/s')" >> $O/ablstm.log
       done; done; done ;;
+    graderr)
+      # error of the LSTM sequence kernels against float64 autograd at the training shape (tools/lstm_grad_error.py 750 4096 48), for the shipped
+      # library and every csrc/_variants/libirrl_env_*.so
+      V=high_speed_quadrupedal_locomotion_by_irrl_amd/csrc/_variants; rm -f $O/graderr.log
+      echo "== shipped library" >> $O/graderr.log; timeout 600 python tools/lstm_grad_error.py 750 4096 48 2>/dev/null >> $O/graderr.log
+      for f in $V/libirrl_env_*.so; do
+        [ -e "$f" ] || continue
+        echo "== $(basename $f .so)" >> $O/graderr.log; IRRL_ENV_LIB=$PWD/$f timeout 600 python tools/lstm_grad_error.py 750 4096 48 2>/dev/null >> $O/graderr.log
+      done ;;
     abmlp)
       # same-box A/B of the MlpPolicy update with / without the packed sample records, interleaved, three rounds
       rm -f $O/abmlp.log
