@@ -2205,6 +2205,7 @@ IRRL_DEV void step_compute(const EnvParams &P, EnvLane &L, vi env, vi leg, vm va
 #ifdef IRRL_PROFILE_WAVES
   L.prof_ranksteps = 0; L.prof_flags = 0;
 #endif
+  IRRL_MARK("step_prologue");
   vu envu = to_u(env) + P.env_id_offset;   // RNG address: the GLOBAL env id
   // ENV:700-708
   vf pT[3];
@@ -2292,6 +2293,7 @@ IRRL_DEV void step_compute(const EnvParams &P, EnvLane &L, vi env, vi leg, vm va
   }
   before_substeps();
   for (int i = 0; i < P.loop_count; i++) physics_substep<RULE>(P, L, pT);
+  IRRL_MARK("epi_noise");
   // The epilogue is per-leg work: with four sub-lanes per leg it would be executed four times over.  Only sub-lane 0
   // (the lane that owns the stores) runs it -- same issue time, a quarter of the active lanes, which is what the
   // power-limited clock of a fully occupied chip responds to.  All cross-leg DPP traffic below is between sub-lanes 0.
@@ -2307,9 +2309,11 @@ IRRL_DEV void step_compute(const EnvParams &P, EnvLane &L, vi env, vi leg, vm va
   const StepNoise *pre = nullptr;
 #endif
   IRRL_SUB0_ONLY_BEGIN
+  IRRL_MARK("epi_obs");
 #ifndef IRRL_AB_NO_OBS
   update_observation(P, L, envu, pre);
 #endif
+  IRRL_MARK("epi_reward");
   vf extra[6];
 #ifndef IRRL_AB_NO_REWARD
   vf rew = reward_update(P, L, extra);
@@ -2317,6 +2321,7 @@ IRRL_DEV void step_compute(const EnvParams &P, EnvLane &L, vi env, vi leg, vm va
   vf rew = L.pos.z;
   for (int j = 0; j < 6; j++) extra[j] = L.pos.z;
 #endif
+  IRRL_MARK("epi_reset");
   // VEC:358-371: termination is decided on the post-physics state (the command / reference update below does not touch what it reads)
   vm done = (L.pos.z < 0.15f) | (L.pos.z > 0.65f) | (L.ob_post[2] < 0.5f);
 #ifdef IRRL_AB_NO_RESET
@@ -2331,6 +2336,7 @@ IRRL_DEV void step_compute(const EnvParams &P, EnvLane &L, vi env, vi leg, vm va
     select_lane(done, Rn, L);
     rew = vsel(done, rew + P.c_term, rew);
   }
+  IRRL_MARK("epi_cmd_gait");
   // the end of a step (ENV:784-785) and the end of a reset (ENV:627-629) are the same three statements: once for everybody
 #ifndef IRRL_AB_NO_CMD
   reset_lane_tail(P, L, envu);
@@ -2338,6 +2344,7 @@ IRRL_DEV void step_compute(const EnvParams &P, EnvLane &L, vi env, vi leg, vm va
   contact_obs_update(P, L);
   L.frame = L.frame + 1;
 #endif
+  IRRL_MARK("epi_observe");
   observe_lane(P, env, leg, valid, L, ob_out);
   vm lead = valid & (leg == 0);
   IRRL_MASKED_BEGIN(lead)
@@ -2349,14 +2356,17 @@ IRRL_DEV void step_compute(const EnvParams &P, EnvLane &L, vi env, vi leg, vm va
   stm(extra_out, env * 6 + 3, (float)L.prof_ranksteps); stm(extra_out, env * 6 + 4, (float)L.prof_flags);
 #endif
   IRRL_MASKED_END
+  IRRL_MARK("epi_store_context");
   tail(L, rew, done);      // (the step's reward and termination flag next to the final context)
   IRRL_SUB0_ONLY_END
+  IRRL_MARK("end");
 }
 
 template <int RULE, class Hook = NoStepHook>
 IRRL_DEV void step_body(const EnvParams &P, const EnvState &S, vi env, vi leg, vm valid, const float *action, float *ob_out,
                         float *reward_out, uint8_t *done_out, float *extra_out, Hook before_substeps = Hook()) {
   EnvLane L;
+  IRRL_MARK("load_context");
   load_lane(P, S, env, leg, L, true);
   step_compute<RULE>(P, L, env, leg, valid, ActionRow{action}, ob_out, reward_out, done_out, extra_out, before_substeps,
                      [&](const EnvLane &Lf, vf, vm) { store_lane(P, S, env, leg, valid, Lf, P.randomize_per_episode != 0); });
