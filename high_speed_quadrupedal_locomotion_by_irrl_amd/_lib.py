@@ -75,7 +75,7 @@ SIGNATURES = {
     "irrl_adv_moments_rec": (C.c_int, [C.c_size_t, vp, vp, vp, C.c_int, vp, vp, vp]),
     "irrl_sum_rows": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     "irrl_lstm_seq_forward_bf16": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] + [vp] * 11),
-    "irrl_lstm_seq_backward_bf16": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] + [vp] * 14),
+    "irrl_lstm_seq_backward_bf16": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int] + [vp] * 15),
     "irrl_clip_adam": (C.c_int, [C.c_int, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_longlong, vp, vp]),
     "irrl_sum_rows_scatter": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     "irrl_random_permutation": (C.c_int, [C.c_longlong, C.c_uint, C.c_uint, vp, vp]),

@@ -55,8 +55,9 @@ struct LstmFwdBf16Args {
 constexpr int LBF_HID = 48, LBF_KX = 48, LBF_KF = LBF_HID + LBF_KX;   // forward contraction: [h | x], 96 = 3 chunks of 32
 constexpr int LBF_FROW = LBF_KF + 8;                                    // padded A-tile row (bf16 elements; 208 bytes: 16-byte aligned)
 
-// STORE_GC: the gates and c rows are kept for the backward kernel (the update).  false = INFERENCE (round 5: the critic pass behind an actor-only
-// rollout, ppo2.Runner._critic_pass): only h and the final state leave the kernel -- 384 instead of 1152 bytes stored per env and step.
+// STORE: what leaves the kernel per env and step.  2 = gates + c + h (1152 bytes: the backward kernel that LOADS its gates -- three planes);
+// 1 = c + h (384 bytes; round 6: the two-plane backward kernel recomputes the gates from h_{t-1} and x_t, lstm_seq_bwd_bf16_rc_kernel);
+// 0 = INFERENCE (round 5: the critic pass behind an actor-only rollout, ppo2.Runner._critic_pass): h and the final state only, 192 bytes.
 //
 // ROUND 5, LAST CHANGE: A FOURTH WAVE THAT DOES ALL THE LOADING, WITH FEW, WIDE LOADS.  Rounds 4-5 measured the symptom -- a pair of forward launches
 // "bound by its stores" at 3.5 TB/s although the same store mix alone streams at 5.9 -- and a probe found the cause
@@ -70,7 +71,7 @@ constexpr int LBF_FROW = LBF_KF + 8;                                    // padde
 #endif
 constexpr int LBF_FWD_XD = IRRL_LBF_FWD_XD;                             // steps of x / mask rows the loader wave has in flight
 template <int NS> constexpr int lstm_fwd_bf16_lds_bytes() { return 2 * NS * 16 * LBF_FROW * 2 + 4 * 16 * 4; }      // two A tiles + the mask ring
-template <int NS, bool STORE_GC = true>
+template <int NS, int STORE = 2>
 __global__ void __launch_bounds__(256)
 lstm_seq_fwd_bf16_kernel(const LstmFwdBf16Args a) {
   constexpr int HID = LBF_HID, KC = LBF_KF / 32, XD = LBF_FWD_XD;
@@ -224,10 +225,10 @@ lstm_seq_fwd_bf16_kernel(const LstmFwdBf16Args a) {
       hlast[j] = hn;
       const size_t row = (size_t)t * N + e0 + 4 * rq + j;
 #ifndef IRRL_LBF_AB_NO_GATE_STORES      /* A/B switches of tools/build_variants.py (wrong results): which of the forward kernel's stores cost what */
-      if (STORE_GC) *(f32x4 *)&a.gates[(row * HID + u) * 4] = (f32x4){ig, fg, og, gg};
+      if (STORE == 2) *(f32x4 *)&a.gates[(row * HID + u) * 4] = (f32x4){ig, fg, og, gg};
 #endif
 #ifndef IRRL_LBF_AB_NO_CH_STORES
-      if (STORE_GC) a.cseq[row * HID + u] = cn;
+      if (STORE >= 1) a.cseq[row * HID + u] = cn;
       a.hseq[row * HID + u] = hn;
 #endif
       keepn[j] = 1.0f - mk_nxt[j];
@@ -247,7 +248,7 @@ lstm_seq_fwd_bf16_kernel(const LstmFwdBf16Args a) {
 
 // ---- backward --------------------------------------------------------------------------------------------------------------------
 struct LstmBwdBf16Args {
-  const float *gates, *cseq, *hseq, *x, *masks, *state0, *dh_in, *wh_p, *wx_p;
+  const float *gates, *cseq, *hseq, *x, *masks, *state0, *dh_in, *wh_p, *wx_p, *b_p;      // gates NULL + b_p: the recomputing kernel (two planes)
   float *dx, *dwx_part, *dwh_part, *db_part;
   int T, N, n_in;
 };
@@ -486,7 +487,11 @@ lstm_seq_bwd_bf16_kernel(const LstmBwdBf16Args a) {
       const int e = e0 + 4 * rq + j;
       const size_t row = (size_t)t * N + e;
       o.mk[j] = a.masks[row];
+#ifdef IRRL_LBF_AB_RECOMPUTE_PROBE      /* A/B probe of tools/build_variants.py (WRONG results): what "recompute the gates instead of loading them" would cost here */
+      o.g[j] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#else
       o.g[j] = *(const f32x4 *)&a.gates[(row * HID + u) * 4];
+#endif
       o.ct[j] = a.cseq[row * HID + u];
       o.cp[j] = (t > 0) ? a.cseq[(row - N) * HID + u] : a.state0[(size_t)e * 2 * HID + u];
       o.hp[j] = (t > 0) ? a.hseq[(row - N) * HID + u] : a.state0[(size_t)e * 2 * HID + HID + u];
@@ -500,6 +505,28 @@ lstm_seq_bwd_bf16_kernel(const LstmBwdBf16Args a) {
 #pragma unroll
     for (int j = 0; j < 4; j++) { keepC[j] = 1.0f - o.mk[j]; g4[j] = o.g[j]; ct[j] = o.ct[j]; cpv[j] = o.cp[j]; dhv[j] = o.dh[j]; hpv[j] = o.hp[j] * keepC[j]; }
     if (t - DEPTH >= 0) fetch(t - DEPTH, o);
+#ifdef IRRL_LBF_AB_RECOMPUTE_PROBE
+    {
+      // the forward kernel's matrix-core stage for this wave's 16 units x 4 gates (PR::N x 3 chunks x 4 gates MFMAs over K = 96) on whatever lies in
+      // the other buffer's tile, then the four activations per (env, unit): the instruction mix of a real recompute, not its values
+      u16x8_t ap[3][NS];
+#pragma unroll
+      for (int kc = 0; kc < 3; kc++)
+#pragma unroll
+        for (int p = 0; p < NS; p++) ap[kc][p] = *(const u16x8_t *)Zr(buf ^ 1, p, col, 32 * kc + 8 * rq);
+      f32x4 zacc[4];
+#pragma unroll
+      for (int g = 0; g < 4; g++) zacc[g] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int kc = 0; kc < 3; kc++)
+#pragma unroll
+        for (int q = 0; q < PR::N; q++)
+#pragma unroll
+          for (int g = 0; g < 4; g++) zacc[g] = BF_MFMA32(ap[kc][PR::A[q]], Bh[(kc + g) % KC][PR::B[q]], zacc[g]);
+#pragma unroll
+      for (int j = 0; j < 4; j++) g4[j] = (f32x4){fast_sigmoid(zacc[0][j]), fast_sigmoid(zacc[1][j]), fast_sigmoid(zacc[2][j]), fast_tanh(zacc[3][j])};
+    }
+#endif
     // (h_{t-1} keep_t)^T for the weight gradients: Ht[plane][unit u][env 4 rq .. 4 rq + 3]
     {
       u16x4_t pk[NS];
@@ -587,4 +614,366 @@ lstm_seq_bwd_bf16_kernel(const LstmBwdBf16Args a) {
   const size_t blk = blockIdx.x;
 #pragma unroll
   for (int g = 0; g < 4; g++) a.db_part[(blk * 4 + rq) * GC + u * 4 + g] = dbtot[g] + dbacc[g];
+}
+
+// ---- backward with the gates RECOMPUTED (round 6, verdict r5 item 2; two planes = bf16x3, the learner's default) ---------------------------------
+// The forward kernel's gate stores are 2/3 of its bytes (768 of 1152 per env and step) and the backward kernel's gate loads half of its own.
+// z_t = b + [h_{t-1} keep_t | x_t] [wh ; wx] depends on nothing the backward recurrence produces, and both of its operands are already on their way
+// through this kernel: (h_{t-1} keep_t)^T and x_t^T are staged in LDS for the weight gradients.  So the kernel forms z_t itself -- the forward kernel's
+// matrix-core stage, instruction for instruction (same operand planes, same products, same order: the recomputed gates ARE the forward's, bit for
+// bit) -- and the forward kernel of a two-plane update stores c and h only.
+//   * A operand ([env][k] rows, k = 32 kc + 8 rq ..) straight out of the TRANSPOSED tiles the weight gradients read: two ds_read_b64_tr_b16 per
+//     (chunk, plane) turn four k-rows x 16 envs into four k-values of one env per lane -- no second, row-major copy of h / x.  For that the tiles
+//     of step t must be complete BEFORE step t's gate arithmetic: h / x are staged ONE STEP AHEAD (step t + 1 stages the tiles of step t), which
+//     needs a third buffer for them (the weight gradients of step t + 1 are still reading theirs).  The dz tile stays double-buffered.
+//   * B operand: the forward kernel's weight fragments, 96 registers + the bias -- the room the gates' three register sets left (48) plus what the
+//     block-structured step loop freed (profiles/r06_ab_lstm_bwd_two_level_accumulation.log).
+//   * MEASURED, AND NOT THE DEFAULT.  A probe that issued a recompute's matrix-core and activation mix on stale data (no staging, no tile reads, the
+//     weight fragments it needed already in registers) had promised 96.3 -> 88.0 ms per update (79.5 with the gate stores gone and the backward kernel
+//     unchanged).  The real kernel -- bit-identical to the loading one in every output, tests/test_gpu_ppo.py -- takes the forward pairs from 3.2 to 2.1 ms
+//     per epoch and the four backward launches from 5.7 to ~7.5: update 94.4 -> 106.4 ms (same box).  Placing the recompute behind the previous step's
+//     barrier instead of in front of the gate arithmetic changes nothing (106.2 / 106.5): the step is not waiting on that chain, the main waves are
+//     issue-bound, and the recompute adds ~1 100 clocks of tile reads, fragment reads and transcendentals per step to them.  With the forward fragments
+//     in registers instead (IRRL_LBF_RC_BF_REGS) the kernel sits at 512 registers and the update at 118-120 ms.  lstm_fused.RECOMPUTE_GATES /
+//     IRRL_LSTM_RECOMPUTE=1 selects it (profiles/r06_ab_lstm_recompute_same_box.log).
+// Three planes keep the loading kernel in any case: 72 more MFMAs per wave and step (probe: 129.3 -> 133.3 ms).
+constexpr int LBF_RC_Z = 16 * LBF_RROW;                       // per plane: dz tile [env][gate column]
+constexpr int LBF_RC_HX = (LBF_HID + LBF_KX) * LBF_CROW;      // per plane: [k = 0..47: unit | 48..95: input][env]
+// One set of weight fragments does not fit the register file beside the others (all three: 512 + spills, 240 register-file moves per step): the
+// forward fragments live in LDS -- every lane's own 16 bytes per (chunk, gate, plane), written once, read back by the same lane each step (24
+// ds_read_b128): update 106 ms.  IRRL_LBF_RC_BF_REGS (A/B): the forward fragments in registers and the dx fragments in LDS instead (12 reads per step
+// in the layer-1 launches, none in the others): 120 ms -- what costs is the register file, not the LDS reads (profiles/r06_ab_lstm_recompute_same_box.log).
+#ifndef IRRL_LBF_RC_BF_REGS
+constexpr int LBF_RC_BF = 3 * (LBF_KF / 32) * 4 * 64 * 8;     // per plane: [wave][chunk][gate][lane] x 8 bf16
+#else
+constexpr int LBF_RC_BF = 3 * (LBF_GC / 32) * 64 * 8;         // per plane: the dx fragments, [wave][chunk][lane] x 8 bf16
+#endif
+template <int NS> constexpr int lstm_bwd_bf16_rc_lds_bytes() { return (2 * NS * LBF_RC_Z + 3 * NS * LBF_RC_HX + NS * LBF_RC_BF) * 2; }
+
+template <int NS, int NCI>
+LSTM_DEV void lbf_weight_grads_rc(f32x4 (&accW)[6][NCI], const unsigned short *zbase, const unsigned short *hxbase, int ci0, int col, int rq) {
+  using PR = BfProducts<NS>;
+  u16x4_t bz[NCI][NS], am[6][NS];
+  const int tr_off = (4 * rq + (col >> 2)) * LBF_RROW + 4 * (col & 3);
+#pragma unroll
+  for (int p = 0; p < NS; p++) {
+#pragma unroll
+    for (int ci = 0; ci < NCI; ci++) {
+      typedef short lbf_s16x4 __attribute__((ext_vector_type(4)));
+      const lbf_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lbf_s16x4 __attribute__((address_space(3))) *)(zbase + (size_t)p * LBF_RC_Z + tr_off + 16 * (ci0 + ci)));
+      bz[ci][p] = __builtin_bit_cast(u16x4_t, v);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 6; mt++) am[mt][p] = *(const u16x4_t *)(hxbase + (size_t)p * LBF_RC_HX + (16 * mt + col) * LBF_CROW + 4 * rq);      // rows 0-47: h, 48-95: x
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int q = 0; q < PR::N; q++)
+#pragma unroll
+    for (int mt = 0; mt < 6; mt++)
+#pragma unroll
+      for (int ci = 0; ci < NCI; ci++) accW[mt][ci] = BF_MFMA16(am[mt][PR::A[q]], bz[ci][PR::B[q]], accW[mt][ci]);
+}
+
+template <bool NEED_DX>
+__global__ void __launch_bounds__(256)
+lstm_seq_bwd_bf16_rc_kernel(const LstmBwdBf16Args a) {
+  constexpr int NS = 2, HID = LBF_HID, GC = LBF_GC, KX = LBF_KX, KC = GC / 32, KF = LBF_KF / 32, MAIN_CI = 2, HELP_PARTS = 2;
+  constexpr int DEPTH = 3;      // steps of operand loads in flight: 20 registers per step (the gates are not among the operands any more)
+  using PR = BfProducts<NS>;
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds_rc[];
+  unsigned short *const zt = lds_rc, *const hx = lds_rc + 2 * NS * LBF_RC_Z, *const bfl = hx + 3 * NS * LBF_RC_HX;
+  auto Zr = [&](int buf, int p, int env, int c) -> unsigned short * { return zt + ((size_t)(buf * NS + p) * 16 + env) * LBF_RROW + c; };
+  auto HX = [&](int hb, int p, int k, int env) -> unsigned short * { return hx + ((size_t)(hb * NS + p) * (HID + KX) + k) * LBF_CROW + env; };
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  const int col = l & 15, rq = l >> 4;
+  const int e0 = blockIdx.x * 16;
+  const int T = a.T, N = a.N, n_in = a.n_in;
+  if (w == 3) {
+    // ---- wave 3: stages x^T ONE STEP AHEAD (rows 48.. of the h / x tile) and owns gate-column tiles 6 .. 11 of the weight gradients ----
+    constexpr int HD = DEPTH + 1;
+    float xr[HD][12];
+    auto load_x = [&](int t, float (&dst)[12]) {
+#pragma unroll
+      for (int r = 0; r < 12; r++) {
+        const int idx = 64 * r + l, env = idx / KX, i = idx % KX;
+        dst[r] = a.x[((size_t)t * N + e0 + env) * n_in + (i < n_in ? i : n_in - 1)];
+      }
+    };
+    auto stage_x = [&](int hb, const float (&src)[12]) {
+#pragma unroll
+      for (int r = 0; r < 12; r++) {
+        const int idx = 64 * r + l, env = idx / KX, i = idx % KX;
+        unsigned short pl[NS];
+        bf_split<NS>(i < n_in ? src[r] : 0.0f, pl);
+#pragma unroll
+        for (int p = 0; p < NS; p++) *HX(hb, p, HID + i, env) = pl[p];
+      }
+    };
+    f32x4 accH[HELP_PARTS][6][3];
+#pragma unroll
+    for (int hf = 0; hf < HELP_PARTS; hf++)
+#pragma unroll
+      for (int mt = 0; mt < 6; mt++)
+#pragma unroll
+        for (int ci = 0; ci < 3; ci++) accH[hf][mt][ci] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    {
+      float x0[12];
+      load_x(T - 1, x0);
+#pragma unroll
+      for (int d = 0; d < HD; d++)
+        if (T - 2 - d >= 0) load_x(T - 2 - d, xr[d]);      // xr[d] holds x of the step BEHIND the one slot d processes
+      stage_x((T - 1) % 3, x0);
+    }
+    __syncthreads();
+    int hb = (T - 1) % 3;      // tile of the step being processed; the step behind it goes into (hb + 2) % 3
+#pragma unroll 1
+    for (int t = T - 1; t >= 0; t -= HD) {
+#pragma unroll
+      for (int d = 0; d < HD; d++) {
+        const int tt = t - d;
+        if (tt < 0) break;
+        const int hb_next = hb == 0 ? 2 : hb - 1;
+        if (tt - 1 >= 0) stage_x(hb_next, xr[d]);
+        if (tt - 1 - HD >= 0) load_x(tt - 1 - HD, xr[d]);
+        __syncthreads();
+#pragma unroll
+        for (int hf = 0; hf < HELP_PARTS; hf++)
+          lbf_weight_grads_rc<NS, 3>(accH[hf], zt + (size_t)(tt & 1) * NS * LBF_RC_Z, hx + (size_t)hb * NS * LBF_RC_HX, 3 * MAIN_CI + 3 * hf, col, rq);
+        hb = hb_next;
+      }
+    }
+#pragma unroll
+    for (int hf = 0; hf < HELP_PARTS; hf++) lbf_store_weight_grads<3>(accH[hf], a, 3 * MAIN_CI + 3 * hf, col, rq);
+    return;
+  }
+  // ---- waves 0-2: units 16 w .. 16 w + 15 ----
+  const int u = 16 * w + col;
+  // recurrence / dx fragments over K = gate column (as in lstm_seq_bwd_bf16_kernel)
+#ifndef IRRL_LBF_RC_BF_REGS
+  constexpr bool BX_LDS = false;
+#else
+  constexpr bool BX_LDS = true;
+#endif
+  auto BxL = [&](int kc, int p) -> u16x8_t * { return (u16x8_t *)(bfl + (((size_t)p * 3 + w) * KC + kc) * 64 * 8 + (size_t)l * 8); };
+  u16x8_t Bh[KC][NS], Bx[(NEED_DX && !BX_LDS) ? KC : 1][NS];
+#pragma unroll
+  for (int kc = 0; kc < KC; kc++) {
+    u16x8_t fx[NS];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int cidx = 32 * kc + 8 * rq + i;
+      unsigned short pl[NS];
+      bf_split<NS>(a.wh_p[(size_t)u * GC + cidx], pl);
+#pragma unroll
+      for (int p = 0; p < NS; p++) Bh[kc][p][i] = pl[p];
+      if (NEED_DX) {
+        bf_split<NS>((u < n_in) ? a.wx_p[(size_t)u * GC + cidx] : 0.0f, pl);
+#pragma unroll
+        for (int p = 0; p < NS; p++) fx[p][i] = pl[p];
+      }
+    }
+    if (NEED_DX) {
+#pragma unroll
+      for (int p = 0; p < NS; p++) {
+        if (BX_LDS) *BxL(kc, p) = fx[p];
+        else Bx[kc][p] = fx[p];
+      }
+    }
+  }
+  // the forward kernel's fragments over K = [h | x]: B[k = 32 kc + 8 rq + i][unit u, gate g].  They live in LDS, every lane's own 16 bytes per
+  // (chunk, gate, plane) -- written once here, read back by the same lane each step (24 ds_read_b128 per lane and step): in registers (96) the
+  // kernel sat at 490-512 with 240 register-file moves per step and ran 45-65 % longer than the kernel that loads its gates
+  // (profiles/r06_ab_lstm_recompute_same_box.log)
+  auto BfL = [&](int kc, int g, int p) -> u16x8_t * { return (u16x8_t *)(bfl + ((((size_t)p * 3 + w) * KF + kc) * 4 + g) * 64 * 8 + (size_t)l * 8); };
+  u16x8_t Bf[BX_LDS ? KF : 1][4][NS];
+#pragma unroll
+  for (int kc = 0; kc < KF; kc++)
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      u16x8_t fr[NS];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const int k = 32 * kc + 8 * rq + i;
+        float v;
+        if (k < HID) v = a.wh_p[((size_t)k * HID + u) * 4 + g];
+        else v = (k - HID < n_in) ? a.wx_p[((size_t)(k - HID) * HID + u) * 4 + g] : 0.0f;
+        unsigned short pl[NS];
+        bf_split<NS>(v, pl);
+#pragma unroll
+        for (int p = 0; p < NS; p++) fr[p][i] = pl[p];
+      }
+#pragma unroll
+      for (int p = 0; p < NS; p++) {
+        if (BX_LDS) Bf[kc][g][p] = fr[p];
+        else *BfL(kc, g, p) = fr[p];
+      }
+    }
+  const f32x4 bias = *(const f32x4 *)&a.b_p[u * 4];
+  float dbacc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  float dc[4] = {0.0f, 0.0f, 0.0f, 0.0f}, dhrec[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  f32x4 accW[6][MAIN_CI];
+#pragma unroll
+  for (int mt = 0; mt < 6; mt++)
+#pragma unroll
+    for (int ci = 0; ci < MAIN_CI; ci++) accW[mt][ci] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+  struct StepOps { float ct[4], cp[4], dh[4], mk[4], hp[4]; };
+  auto fetch = [&](int t, StepOps &o) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int e = e0 + 4 * rq + j;
+      const size_t row = (size_t)t * N + e;
+      o.mk[j] = a.masks[row];
+      o.ct[j] = a.cseq[row * HID + u];
+      o.cp[j] = (t > 0) ? a.cseq[(row - N) * HID + u] : a.state0[(size_t)e * 2 * HID + u];
+      o.hp[j] = (t > 0) ? a.hseq[(row - N) * HID + u] : a.state0[(size_t)e * 2 * HID + HID + u];
+      o.dh[j] = a.dh_in[row * HID + u];
+    }
+  };
+  // (h_{t-1} keep_t)^T of the step whose operands are `o`: rows 0 .. 47 of tile hb, [unit u][env 4 rq .. 4 rq + 3]
+  auto stage_h = [&](int hb, const StepOps &o) {
+    u16x4_t pk[NS];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      unsigned short pl[NS];
+      bf_split<NS>(o.hp[j] * (1.0f - o.mk[j]), pl);
+#pragma unroll
+      for (int p = 0; p < NS; p++) pk[p][j] = pl[p];
+    }
+#pragma unroll
+    for (int p = 0; p < NS; p++) *(u16x4_t *)HX(hb, p, u, 4 * rq) = pk[p];
+  };
+  // z of one step: the forward kernel's products, same planes, same order (x chunks first, then small plane products first, then the gates), from
+  // the COMPLETE h / x tile hb.  It runs BEHIND the barrier of the step before (where the tile becomes complete) -- in the stretch whose matrix-core
+  // work the vector ALU otherwise only waits for -- and hands its gates to the next step in 16 registers (g4c): in front of the gate arithmetic, where
+  // the first version had it, tile reads, 36 dependent-free MFMAs and 16 transcendental chains were all on the step's serial chain (update 106 ms
+  // against 96 for the kernel that loads its gates; profiles/r06_ab_lstm_recompute_same_box.log)
+  f32x4 g4c[4];
+  auto recompute = [&](const int hb) {
+    typedef short lbf_s16x4 __attribute__((ext_vector_type(4)));
+    u16x8_t av[KF][NS];
+#pragma unroll
+    for (int kc = 0; kc < KF; kc++)
+#pragma unroll
+      for (int p = 0; p < NS; p++) {
+        // lane 4 q + p4 of the 16-lane group rq addresses k-row 32 kc + 8 rq + 4 h + q, envs 4 p4 .. 4 p4 + 3; lane i receives env i of the four rows
+        const unsigned short *base = HX(hb, p, 32 * kc + 8 * rq + (col >> 2), 4 * (col & 3));
+        const lbf_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lbf_s16x4 __attribute__((address_space(3))) *)base);
+        const lbf_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lbf_s16x4 __attribute__((address_space(3))) *)(base + 4 * LBF_CROW));
+        av[kc][p] = __builtin_bit_cast(u16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));      // (a register pair next to a register pair: no moves)
+      }
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) acc[g] = (f32x4){bias[g], bias[g], bias[g], bias[g]};
+#pragma unroll
+    for (int kc = KF - 1; kc >= 0; kc--) {
+      u16x8_t bf[4][NS];
+#pragma unroll
+      for (int g = 0; g < 4; g++)
+#pragma unroll
+        for (int p = 0; p < NS; p++) bf[g][p] = BX_LDS ? Bf[kc][g][p] : *BfL(kc, g, p);
+#pragma unroll
+      for (int q = 0; q < PR::N; q++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) acc[g] = BF_MFMA32(av[kc][PR::A[q]], bf[g][PR::B[q]], acc[g]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) g4c[j] = (f32x4){fast_sigmoid(acc[0][j]), fast_sigmoid(acc[1][j]), fast_sigmoid(acc[2][j]), fast_tanh(acc[3][j])};
+  };
+  auto step = [&](int t, StepOps &o, const StepOps &onext, const int hb, const int hb_next) {      // hb = t % 3, hb_next = (t - 1) % 3: fixed per slot (DEPTH == 3 tiles)
+    const int buf = t & 1;
+    float keepC[4], ct[4], cpv[4], dhv[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { keepC[j] = 1.0f - o.mk[j]; ct[j] = o.ct[j]; cpv[j] = o.cp[j]; dhv[j] = o.dh[j]; }
+    if (t - DEPTH >= 0) fetch(t - DEPTH, o);
+    // the h tile of the NEXT step (its operands arrived at least two steps ago)
+    if (t - 1 >= 0) stage_h(hb_next, onext);
+    f32x4 g4[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) g4[j] = g4c[j];
+    // gate arithmetic -> dz (env 4 rq + j, unit u, gates i f o g) into the [env][gate column] tile
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float cprev = cpv[j] * keepC[j];
+      const float dh = dhv[j] + dhrec[j];
+      const float ig = g4[j][0], fg = g4[j][1], og = g4[j][2], gg = g4[j][3];
+      const float tc = fast_tanh(ct[j]);
+      const float d_o = dh * tc;
+      const float dct = dc[j] + dh * og * (1.0f - tc * tc);
+      const float d_i = dct * gg, d_g = dct * ig, d_f = dct * cprev;
+      dc[j] = dct * fg * keepC[j];
+      const float dz4[4] = {d_i * ig * (1.0f - ig), d_f * fg * (1.0f - fg), d_o * og * (1.0f - og), d_g * (1.0f - gg * gg)};
+      u16x4_t zr[NS];
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        dbacc[g] += dz4[g];
+        unsigned short pl[NS];
+        bf_split<NS>(dz4[g], pl);
+#pragma unroll
+        for (int p = 0; p < NS; p++) zr[p][g] = pl[p];
+      }
+#pragma unroll
+      for (int p = 0; p < NS; p++) *(u16x4_t *)Zr(buf, p, 4 * rq + j, 4 * u) = zr[p];
+    }
+    __syncthreads();      // dz_t and the h / x tiles of step t - 1 of every wave are visible
+    u16x8_t az[KC][NS];
+#pragma unroll
+    for (int kc = 0; kc < KC; kc++)
+#pragma unroll
+      for (int p = 0; p < NS; p++) az[kc][p] = *(const u16x8_t *)Zr(buf, p, col, 32 * kc + 8 * rq);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}, accx = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    if (NEED_DX && BX_LDS) {
+      // the recurrence first (its result starts the next step's chain), then dx with its fragments out of LDS; same products, same order per accumulator
+#pragma unroll
+      for (int q = 0; q < PR::N; q++)
+#pragma unroll
+        for (int kc = 0; kc < KC; kc++) acc = BF_MFMA32(az[kc][PR::A[q]], Bh[kc][PR::B[q]], acc);
+      // (plane products in the loading kernel's order per accumulator: q outer, chunks inner -- the fragments of all six chunks are live for that)
+      u16x8_t bx[KC][NS];
+#pragma unroll
+      for (int kc = 0; kc < KC; kc++)
+#pragma unroll
+        for (int p = 0; p < NS; p++) bx[kc][p] = *BxL(kc, p);
+#pragma unroll
+      for (int q = 0; q < PR::N; q++)
+#pragma unroll
+        for (int kc = 0; kc < KC; kc++) accx = BF_MFMA32(az[kc][PR::A[q]], bx[kc][PR::B[q]], accx);
+    } else {
+#pragma unroll
+      for (int q = 0; q < PR::N; q++)
+#pragma unroll
+        for (int kc = 0; kc < KC; kc++) {
+          acc = BF_MFMA32(az[kc][PR::A[q]], Bh[kc][PR::B[q]], acc);
+          if (NEED_DX) accx = BF_MFMA32(az[kc][PR::A[q]], Bx[kc][PR::B[q]], accx);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) dhrec[j] = acc[j] * keepC[j];
+    if (NEED_DX && u < n_in) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) a.dx[((size_t)t * N + e0 + 4 * rq + j) * n_in + u] = accx[j];
+    }
+    lbf_weight_grads_rc<NS, MAIN_CI>(accW, zt + (size_t)buf * NS * LBF_RC_Z, hx + (size_t)hb * NS * LBF_RC_HX, MAIN_CI * w, col, rq);
+    if (t - 1 >= 0) recompute(hb_next);      // the gates of step t - 1 (its tile is complete since this step's barrier)
+  };
+  StepOps ops[DEPTH];
+#pragma unroll
+  for (int d = 0; d < DEPTH; d++)
+    if (T - 1 - d >= 0) fetch(T - 1 - d, ops[d]);
+  static_assert(DEPTH == 3, "slot d of a group always works on h / x tile (hb0 - d) mod 3: the groups advance by as many steps as there are tiles");
+  const int hb0 = (T - 1) % 3;
+  stage_h(hb0, ops[0]);
+  __syncthreads();
+  recompute(hb0);
+#pragma unroll 1
+  for (int t = T - 1; t >= 0; t -= DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++)
+      if (t - d >= 0) step(t - d, ops[d], ops[(d + 1) % DEPTH], (hb0 + 3 - d) % 3, (hb0 + 5 - d) % 3);
+  }
+  lbf_store_weight_grads<MAIN_CI>(accW, a, MAIN_CI * w, col, rq);
+  const size_t blk = blockIdx.x;
+#pragma unroll
+  for (int g = 0; g < 4; g++) a.db_part[(blk * 4 + rq) * GC + u * 4 + g] = dbacc[g];
 }

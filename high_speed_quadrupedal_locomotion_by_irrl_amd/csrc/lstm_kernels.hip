@@ -1304,26 +1304,24 @@ int irrl_lstm_seq_forward_bf16(int nsplit, int hid, int T, int N, int n_in, cons
   a.x = x; a.wx_p = wx_p; a.b_p = b_p; a.wh_p = wh_p; a.masks = masks; a.state0 = state0;
   a.gates = gates; a.cseq = cseq; a.hseq = hseq; a.state_out = state_out; a.T = T; a.N = N; a.n_in = n_in;
   hipStream_t s = (hipStream_t)hip_stream;
-  const bool train = gates != nullptr && cseq != nullptr;     // both NULL: inference -- only hseq and state_out are written
-  if (!train && (gates != nullptr || cseq != nullptr)) return 1;
-  if (nsplit == 2) {
-    constexpr int bytes = lstm_fwd_bf16_lds_bytes<2>();
-    if (train) hipLaunchKernelGGL((lstm_seq_fwd_bf16_kernel<2, true>), dim3(N / 16), dim3(256), bytes, s, a);
-    else hipLaunchKernelGGL((lstm_seq_fwd_bf16_kernel<2, false>), dim3(N / 16), dim3(256), bytes, s, a);
-  } else {
-    constexpr int bytes = lstm_fwd_bf16_lds_bytes<3>();
-    if (train) hipLaunchKernelGGL((lstm_seq_fwd_bf16_kernel<3, true>), dim3(N / 16), dim3(256), bytes, s, a);
-    else hipLaunchKernelGGL((lstm_seq_fwd_bf16_kernel<3, false>), dim3(N / 16), dim3(256), bytes, s, a);
-  }
+  // what is kept for a backward pass: gates + c (the kernel that loads its gates), c alone (gates NULL: the kernel that recomputes them, two
+  // planes), nothing (both NULL: inference -- only hseq and state_out are written)
+  if (gates != nullptr && cseq == nullptr) return 1;
+  const int store = gates != nullptr ? 2 : (cseq != nullptr ? 1 : 0);
+#define IRRL_FF(NS, ST) hipLaunchKernelGGL((lstm_seq_fwd_bf16_kernel<NS, ST>), dim3(N / 16), dim3(256), lstm_fwd_bf16_lds_bytes<NS>(), s, a)
+  if (nsplit == 2) { if (store == 2) IRRL_FF(2, 2); else if (store == 1) IRRL_FF(2, 1); else IRRL_FF(2, 0); }
+  else { if (store == 2) IRRL_FF(3, 2); else if (store == 1) IRRL_FF(3, 1); else IRRL_FF(3, 0); }
+#undef IRRL_FF
   return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
 int irrl_lstm_seq_backward_bf16(int nsplit, int hid, int T, int N, int n_in, const float *gates, const float *cseq, const float *hseq, const float *x,
-                                const float *masks, const float *state0, const float *dh_in, const float *wh_p, const float *wx_p, float *dx,
-                                float *dwx_part, float *dwh_part, float *db_part, void *hip_stream) {
+                                const float *masks, const float *state0, const float *dh_in, const float *wh_p, const float *wx_p, const float *b_p,
+                                float *dx, float *dwx_part, float *dwh_part, float *db_part, void *hip_stream) {
   if (N <= 0 || T <= 0 || (N % 16) != 0 || n_in <= 0 || n_in > LBF_KX || hid != LBF_HID || (nsplit != 2 && nsplit != 3)) return 1;
+  if (gates == nullptr && (nsplit != 2 || b_p == nullptr)) return 1;      // the recomputing kernel: two planes, needs the bias
   LstmBwdBf16Args a;
-  a.gates = gates; a.cseq = cseq; a.hseq = hseq; a.x = x; a.masks = masks; a.state0 = state0; a.dh_in = dh_in; a.wh_p = wh_p; a.wx_p = wx_p;
+  a.gates = gates; a.cseq = cseq; a.hseq = hseq; a.x = x; a.masks = masks; a.state0 = state0; a.dh_in = dh_in; a.wh_p = wh_p; a.wx_p = wx_p; a.b_p = b_p;
   a.dx = dx; a.dwx_part = dwx_part; a.dwh_part = dwh_part; a.db_part = db_part; a.T = T; a.N = N; a.n_in = n_in;
   hipStream_t s = (hipStream_t)hip_stream;
   // the opt-in belongs to the CURRENT device (a process may drive several GPUs): remembered per device ordinal
@@ -1335,9 +1333,16 @@ int irrl_lstm_seq_backward_bf16(int nsplit, int hid, int T, int N, int n_in, con
     allowed = lstm_bf16_allow_lds((const void *)lstm_seq_bwd_bf16_kernel<2, true>, lstm_bwd_bf16_lds_bytes<2>()) |
               lstm_bf16_allow_lds((const void *)lstm_seq_bwd_bf16_kernel<2, false>, lstm_bwd_bf16_lds_bytes<2>()) |
               lstm_bf16_allow_lds((const void *)lstm_seq_bwd_bf16_kernel<3, true>, lstm_bwd_bf16_lds_bytes<3>()) |
-              lstm_bf16_allow_lds((const void *)lstm_seq_bwd_bf16_kernel<3, false>, lstm_bwd_bf16_lds_bytes<3>());
+              lstm_bf16_allow_lds((const void *)lstm_seq_bwd_bf16_kernel<3, false>, lstm_bwd_bf16_lds_bytes<3>()) |
+              lstm_bf16_allow_lds((const void *)lstm_seq_bwd_bf16_rc_kernel<true>, lstm_bwd_bf16_rc_lds_bytes<2>()) |
+              lstm_bf16_allow_lds((const void *)lstm_seq_bwd_bf16_rc_kernel<false>, lstm_bwd_bf16_rc_lds_bytes<2>());
   }
   if (allowed != 0) return 2;
+  if (gates == nullptr) {
+    if (dx) hipLaunchKernelGGL((lstm_seq_bwd_bf16_rc_kernel<true>), dim3(N / 16), dim3(256), lstm_bwd_bf16_rc_lds_bytes<2>(), s, a);
+    else hipLaunchKernelGGL((lstm_seq_bwd_bf16_rc_kernel<false>), dim3(N / 16), dim3(256), lstm_bwd_bf16_rc_lds_bytes<2>(), s, a);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+  }
 #define IRRL_BB(NS, D) hipLaunchKernelGGL((lstm_seq_bwd_bf16_kernel<NS, D>), dim3(N / 16), dim3(256), lstm_bwd_bf16_lds_bytes<NS>(), s, a)
   if (nsplit == 2 && dx) IRRL_BB(2, true);
   else if (nsplit == 2) IRRL_BB(2, false);

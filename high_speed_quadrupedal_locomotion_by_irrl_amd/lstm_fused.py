@@ -28,6 +28,12 @@ FUSE_INPUT_PROJECTION = True   # module switch (benchmarks / tests compare the t
 # (csrc/lstm_bf16.hpp; IRRL_LSTM_PRECISION overrides the default)
 PRECISION = os.environ.get("IRRL_LSTM_PRECISION", "bf16x3")
 _NSPLIT = {"bf16x3": 2, "bf16x6": 3, "f32": 0}
+# bf16x3, OPT-IN (round 6, verdict r5 item 2 -- built, bit-identical, measured slower): IRRL_LSTM_RECOMPUTE=1 makes the forward kernel of the update keep
+# c and h only and the backward kernel RECOMPUTE the gates from the h / x tiles it stages for the weight gradients anyway (csrc/lstm_bf16.hpp
+# lstm_seq_bwd_bf16_rc_kernel): 2/3 of the forward kernel's stores and half of the backward kernel's loads gone, forward pairs 3.2 -> 2.1 ms per epoch, the
+# four backward launches 5.7 -> ~7.5 ms: update 94.4 -> 106.4 ms on the same box (profiles/r06_ab_lstm_recompute_same_box.log).  Default: the gates are
+# stored and loaded as in rounds 4-5.
+RECOMPUTE_GATES = os.environ.get("IRRL_LSTM_RECOMPUTE", "0") != "0"
 
 
 def check_precision(name, what="lstm_fused.PRECISION / IRRL_LSTM_PRECISION"):
@@ -149,7 +155,8 @@ class _LstmSeqFn(torch.autograd.Function):
         # inference form keeps neither the gates nor the c rows -- a third of the stores.  (`no_grad` comes from the caller: inside forward()
         # autograd has switched grad mode off whatever the caller's was.)
         infer = bool(nsplit) and bool(no_grad)
-        gates = None if infer else torch.empty(T, Np, hid, 4, device=x.device, dtype=torch.float32)
+        recompute = nsplit == 2 and RECOMPUTE_GATES and not infer
+        gates = None if (infer or recompute) else torch.empty(T, Np, hid, 4, device=x.device, dtype=torch.float32)
         cseq = None if infer else torch.empty(T, Np, hid, device=x.device, dtype=torch.float32)
         hseq = torch.empty(T, Np, hid, device=x.device, dtype=torch.float32)
         state_out = torch.empty(Np, 2 * hid, device=x.device, dtype=torch.float32)
@@ -157,7 +164,7 @@ class _LstmSeqFn(torch.autograd.Function):
         ctx.nsplit = nsplit
         if nsplit:
             rc = lib.irrl_lstm_seq_forward_bf16(nsplit, hid, T, Np, n_in, _ptr(x_k), _ptr(wx_p), _ptr(b_p), _ptr(wh_p), _ptr(masks_k), _ptr(state0_k),
-                                                None if infer else _ptr(gates), None if infer else _ptr(cseq), _ptr(hseq), _ptr(state_out), stream)
+                                                None if gates is None else _ptr(gates), None if infer else _ptr(cseq), _ptr(hseq), _ptr(state_out), stream)
         elif n_in <= 48 and FUSE_INPUT_PROJECTION:
             # x wx + b inside the sequence kernel: no [T*N, 4H] zx round trip through HBM
             rc = lib.irrl_lstm_seq_forward_x(hid, T, Np, n_in, _ptr(x_k), _ptr(wx_p), _ptr(b_p), _ptr(wh_p), _ptr(masks_k), _ptr(state0_k),
@@ -169,7 +176,7 @@ class _LstmSeqFn(torch.autograd.Function):
         if rc != 0:
             raise RuntimeError("irrl_lstm_seq_forward failed (rc=%d, hid=%d, T=%d, N=%d)" % (rc, hid, T, Np))
         if not infer:
-            ctx.save_for_backward(x_k, wx_p, wh_p, gates, cseq, hseq, masks_k, state0_k)
+            ctx.save_for_backward(x_k, wx_p, wh_p, gates, cseq, hseq, masks_k, state0_k, b_p)
         ctx.dims = (T, N, Np, n_in, hid)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(state_out)
@@ -178,7 +185,7 @@ class _LstmSeqFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dh_seq, _dstate):
         lib = _lib.load()
-        x_k, wx_p, wh_p, gates, cseq, hseq, masks_k, state0_k = ctx.saved_tensors
+        x_k, wx_p, wh_p, gates, cseq, hseq, masks_k, state0_k, b_p = ctx.saved_tensors
         T, N, Np, n_in, hid = ctx.dims
         perm, inv = _perm(hid, x_k.device)
         if dh_seq is None:
@@ -196,8 +203,9 @@ class _LstmSeqFn(torch.autograd.Function):
             dwh_part = torch.empty(nb, hid, 4 * hid, device=dev, dtype=torch.float32)
             db_part = torch.empty(nb * 4, 4 * hid, device=dev, dtype=torch.float32)
             if getattr(ctx, "nsplit", 0):
-                rc = lib.irrl_lstm_seq_backward_bf16(ctx.nsplit, hid, T, Np, n_in, _ptr(gates), _ptr(cseq), _ptr(hseq), _ptr(x_k), _ptr(masks_k), _ptr(state0_k),
-                                                     _ptr(dh_seq), _ptr(wh_p), _ptr(wx_p), _ptr(dx_k) if dx_k is not None else None,
+                rc = lib.irrl_lstm_seq_backward_bf16(ctx.nsplit, hid, T, Np, n_in, _ptr(gates) if gates is not None else None, _ptr(cseq), _ptr(hseq), _ptr(x_k),
+                                                     _ptr(masks_k), _ptr(state0_k), _ptr(dh_seq), _ptr(wh_p), _ptr(wx_p), _ptr(b_p),
+                                                     _ptr(dx_k) if dx_k is not None else None,
                                                      _ptr(dwx_part), _ptr(dwh_part), _ptr(db_part), stream)
             else:
                 rc = lib.irrl_lstm_seq_backward_x(hid, T, Np, n_in, _ptr(gates), _ptr(cseq), _ptr(hseq), _ptr(x_k), _ptr(masks_k), _ptr(state0_k),

@@ -280,12 +280,16 @@ int irrl_lstm_seq_backward_x(int hid, int T, int N, int n_in, const float *gates
  * n_in <= 48): every operand is split into nsplit bf16 planes (2: ~2^-16 relative product error, 3: ~2^-24, the f32 level) and a product is the
  * sum of the plane products above that weight (3 resp. 6 MFMAs); v_mfma_f32_16x16x32_bf16 covers 32 units of K in half the time the exact-f32
  * v_mfma_f32_16x16x4_f32 needs for 4.  Tensors, layouts and return codes as irrl_lstm_seq_forward_x / irrl_lstm_seq_backward_x. */
-/* (forward: gates == NULL and cseq == NULL selects the INFERENCE form -- only hseq and state_out are written: the critic pass behind an actor-only rollout) */
+/* (forward: gates == NULL and cseq == NULL selects the INFERENCE form -- only hseq and state_out are written: the critic pass behind an actor-only rollout;
+ * gates == NULL with cseq given: c and h are kept, the gates are not -- the forward half of a backward pass that RECOMPUTES them.
+ * backward: gates == NULL (nsplit 2 only; b_p = the layer's permuted bias, otherwise unused and may be NULL) runs the kernel that forms
+ * z_t = b + [h_{t-1} keep_t | x_t] [wh ; wx] itself from the h / x tiles it stages for the weight gradients anyway -- the forward kernel's products,
+ * plane for plane and in its order, so every output equals the gate-loading kernel's bit for bit; round 6) */
 int irrl_lstm_seq_forward_bf16(int nsplit, int hid, int T, int N, int n_in, const float *x, const float *wx_p, const float *b_p, const float *wh_p,
                                const float *masks, const float *state0, float *gates, float *cseq, float *hseq, float *state_out, void *hip_stream);
 int irrl_lstm_seq_backward_bf16(int nsplit, int hid, int T, int N, int n_in, const float *gates, const float *cseq, const float *hseq, const float *x,
-                                const float *masks, const float *state0, const float *dh_in, const float *wh_p, const float *wx_p, float *dx,
-                                float *dwx_part, float *dwh_part, float *db_part, void *hip_stream);
+                                const float *masks, const float *state0, const float *dh_in, const float *wh_p, const float *wx_p, const float *b_p,
+                                float *dx, float *dwx_part, float *dwh_part, float *db_part, void *hip_stream);
 
 /* ---- one ROLLOUT step of CustomLSTMPolicy in a single launch (run_bp_v5.py:178-185 `step`; the runner's clip and
  * buffer rows, ppo2.py:521-535).  Two stacks (actor, critic) of two LSTM layers of `hid` units, heads pi [hid,act],

@@ -10,9 +10,17 @@
  *     termination, reset order): restated from the reference's open C++ and pinned against
  *     golden vectors captured from the reference's importable Python twins (tests/golden/).
  *   - rigid-body physics + contact (the reference calls closed-source RaiSim, ENV:768):
- *     PARITY UNPINNED.  The formulation below is this build's own (documented in DESIGN.md);
- *     it is pinned against first-principles invariants (tests/test_oracle_physics.py) and is the
- *     f64 checker the f32 HIP kernels are compared with.
+ *     NO STATE-LEVEL PIN (RaiSim cannot be built or run here, no oracle/_ref).  The formulation below
+ *     is this build's own (documented in DESIGN.md); it is pinned against first-principles
+ *     invariants (tests/test_oracle_physics.py), against an independent implementation of RaiSim's
+ *     published per-contact rule (tests/test_contact_model_gap.py) and -- round 6 -- against the
+ *     reference repository's own RaiSim recordings of the bp5_155 policy (Exp_Raw_Data/
+ *     body-center-*.bin, decoded into tests/golden/raisim_body_logs.json by
+ *     tools/gen_raisim_log_fixture.py): eleven closed-loop trajectories whose steady-state speed,
+ *     height, attitude and ripple this oracle reproduces within the bounds of
+ *     tests/parity_lib.py RAISIM_LOG_TOL (tests/test_raisim_logs.py).  A statistical pin, not a
+ *     trajectory one: the harness that made the recordings is not in the repository.
+ *     It is the f64 checker the f32 HIP kernels are compared with.
  *
  * Reference aliases (paths under /root/reference/IRRL/FlexibleRobotRaisimGym/flex_gym/env):
  *   ENV = env/BlackPanther_V55/Environment.hpp, VEC = VectorizedEnvironment.hpp,

@@ -29,6 +29,7 @@
 #   ablstm         same-box A/B of the PPO-LSTM update (bf16x3 and bf16x6) over every csrc/_variants/libirrl_env_*.so
 #   abmlp          same-box A/B of the PPO-MLP update with / without the packed sample records (IRRL_MLP_RECORDS)
 #   abmlpw         same-box A/B of the MlpPolicy gradient kernels, four waves against producer / consumer wave pairs (IRRL_MLP_WAVES)
+#   abrecomp       same-box A/B of the PPO-LSTM update (bf16x3) with the recomputing backward kernel on / off (IRRL_LSTM_RECOMPUTE)
 #   graderr        LSTM sequence kernels vs float64 autograd at 750 x 4096 (every arithmetic), shipped library + every variant library
 #   spread         per-wave durations of the step kernel (needs the `prof` variant library)
 #   ab <cmd...>    run the rest of the line verbatim (one-off A/B)
@@ -155,6 +156,12 @@ while [ $# -gt 0 ]; do
       for r in 1 2; do for f in $V/libirrl_env_*.so; do for prec in bf16x3 bf16x6; do
         IRRL_ENV_LIB=$PWD/$f timeout 300 python tools/ppo_bench.py --policy lstm --envs 4096 --iters 4 --precision $prec 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$(basename $f .so) $prec rollout', round(d['rollout_s']*1e3,2), 'ms update', round(d['update_s']*1e3,2), 'ms', round(d['ppo_iters_per_sec'],3), 'it/s')" >> $O/ablstm.log
       done; done; done ;;
+    abrecomp)
+      # same-box A/B of the PPO-LSTM update at bf16x3: the backward kernel recomputes the gates (IRRL_LSTM_RECOMPUTE=1, default) / loads stored ones (0)
+      rm -f $O/abrecomp.log
+      for r in 1 2 3; do for rc in 1 0; do
+        IRRL_LSTM_RECOMPUTE=$rc timeout 300 python tools/ppo_bench.py --policy lstm --envs 4096 --iters 4 --precision bf16x3 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('IRRL_LSTM_RECOMPUTE=$rc rollout', round(d['rollout_s']*1e3,2), 'ms update', round(d['update_s']*1e3,2), 'ms', round(d['ppo_iters_per_sec'],3), 'it/s')" >> $O/abrecomp.log
+      done; done ;;
     graderr)
       # error of the LSTM sequence kernels against float64 autograd at the training shape (tools/lstm_grad_error.py 750 4096 48), for the shipped
       # library and every csrc/_variants/libirrl_env_*.so
