@@ -345,8 +345,13 @@ LSTM_DEV void lbf_clear_totals(float *tot, int ci0, int l) {
     for (int mt = 0; mt < 6; mt++) *(f32x4 *)(tot + ((size_t)((ci0 + ci) * 6 + mt) * 256 + 4 * l)) = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 }
 
+#ifdef IRRL_LBF_AB_OCC2      /* A/B probe of tools/build_variants.py: at most 256 registers, so that the two stacks' launches can share a CU (two waves per SIMD) */
+#define LBF_BWD_BOUNDS __launch_bounds__(256, 2)
+#else
+#define LBF_BWD_BOUNDS __launch_bounds__(256)
+#endif
 template <int NS, bool NEED_DX>
-__global__ void __launch_bounds__(256)
+__global__ void LBF_BWD_BOUNDS
 lstm_seq_bwd_bf16_kernel(const LstmBwdBf16Args a) {
   constexpr int HID = LBF_HID, GC = LBF_GC, KX = LBF_KX, KC = GC / 32;
 #ifdef IRRL_LBF_DEPTH      /* A/B switch of tools/build_variants.py */
