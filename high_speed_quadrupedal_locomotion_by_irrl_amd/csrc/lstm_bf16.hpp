@@ -399,10 +399,11 @@ lstm_seq_bwd_bf16_kernel(const LstmBwdBf16Args a) {
     // ---- wave 3: stages x_t^T for the weight gradients (coalesced row reads, two steps ahead) and takes its share of them ----
     float xr[DEPTH + 1][12];
     auto load_x = [&](int t, float (&dst)[12]) {
+      const float *x_t = a.x + (size_t)t * N * n_in;      // uniform row pointer + 32-bit lane index
 #pragma unroll
       for (int r = 0; r < 12; r++) {
         const int idx = 64 * r + l, env = idx / KX, i = idx % KX;
-        dst[r] = a.x[((size_t)t * N + e0 + env) * n_in + (i < n_in ? i : n_in - 1)];
+        dst[r] = x_t[(unsigned)(e0 + env) * (unsigned)n_in + (unsigned)(i < n_in ? i : n_in - 1)];
       }
     };
     auto stage_x = [&](int buf, const float (&src)[12]) {
@@ -486,21 +487,33 @@ lstm_seq_bwd_bf16_kernel(const LstmBwdBf16Args a) {
 #pragma unroll
     for (int ci = 0; ci < MAIN_CI; ci++) accW[mt][ci] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
   struct StepOps { f32x4 g[4]; float ct[4], cp[4], dh[4], mk[4], hp[4]; };
+  // Addresses as UNIFORM row pointer (scalar registers, advanced per step by the scalar ALU) + a 32-bit per-lane element index: the loads take the
+  // `global_load v, v_offset, s[base]` form.  Written with 64-bit per-lane indices ((size_t) t * N + e) * HID + u, every one of a step's 24 loads
+  // carried its own 64-bit multiply-add chain on the vector ALU -- ~80 of the main waves' 438 vector instructions per step, on the waves whose
+  // issue rate IS the step (round 6; profiles/r06_ab_lstm_scalar_row_pointers_same_box.log).
   auto fetch = [&](int t, StepOps &o) {
+    const size_t trow = (size_t)t * N;
+    const float *mk_t = a.masks + trow, *ct_t = a.cseq + trow * HID, *dh_t = a.dh_in + trow * HID;
+#ifndef IRRL_LBF_AB_RECOMPUTE_PROBE
+    const float *g_t = a.gates + trow * HID * 4;
+#endif
+    // c_{t-1} / h_{t-1}: the rows of step t - 1, or (t == 0, uniform) the initial state [env][c | h]
+    const float *cp_t = t > 0 ? a.cseq + (trow - N) * HID : a.state0;
+    const float *hp_t = t > 0 ? a.hseq + (trow - N) * HID : a.state0 + HID;
+    const unsigned pstride = t > 0 ? (unsigned)HID : 2u * HID;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const int e = e0 + 4 * rq + j;
-      const size_t row = (size_t)t * N + e;
-      o.mk[j] = a.masks[row];
+      const unsigned e = (unsigned)(e0 + 4 * rq + j);
+      o.mk[j] = mk_t[e];
 #ifdef IRRL_LBF_AB_RECOMPUTE_PROBE      /* A/B probe of tools/build_variants.py (WRONG results): what "recompute the gates instead of loading them" would cost here */
       o.g[j] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 #else
-      o.g[j] = *(const f32x4 *)&a.gates[(row * HID + u) * 4];
+      o.g[j] = *(const f32x4 *)&g_t[(e * HID + u) * 4u];
 #endif
-      o.ct[j] = a.cseq[row * HID + u];
-      o.cp[j] = (t > 0) ? a.cseq[(row - N) * HID + u] : a.state0[(size_t)e * 2 * HID + u];
-      o.hp[j] = (t > 0) ? a.hseq[(row - N) * HID + u] : a.state0[(size_t)e * 2 * HID + HID + u];
-      o.dh[j] = a.dh_in[row * HID + u];
+      o.ct[j] = ct_t[e * HID + u];
+      o.cp[j] = cp_t[e * pstride + u];
+      o.hp[j] = hp_t[e * pstride + u];
+      o.dh[j] = dh_t[e * HID + u];
     }
   };
   auto step = [&](int t, StepOps &o) {
@@ -588,8 +601,9 @@ lstm_seq_bwd_bf16_kernel(const LstmBwdBf16Args a) {
 #pragma unroll
     for (int j = 0; j < 4; j++) dhrec[j] = acc[j] * keepC[j];
     if (NEED_DX && u < n_in) {
+      float *dx_t = a.dx + (size_t)t * N * n_in;      // uniform row pointer
 #pragma unroll
-      for (int j = 0; j < 4; j++) a.dx[((size_t)t * N + e0 + 4 * rq + j) * n_in + u] = accx[j];
+      for (int j = 0; j < 4; j++) dx_t[(unsigned)(e0 + 4 * rq + j) * (unsigned)n_in + u] = accx[j];
     }
     lbf_weight_grads<NS, MAIN_CI>(accW, lds_b + (size_t)buf * PER_BUF, MAIN_CI * w, col, rq);
   };
@@ -699,10 +713,11 @@ lstm_seq_bwd_bf16_rc_kernel(const LstmBwdBf16Args a) {
     constexpr int HD = DEPTH + 1;
     float xr[HD][12];
     auto load_x = [&](int t, float (&dst)[12]) {
+      const float *x_t = a.x + (size_t)t * N * n_in;      // uniform row pointer + 32-bit lane index
 #pragma unroll
       for (int r = 0; r < 12; r++) {
         const int idx = 64 * r + l, env = idx / KX, i = idx % KX;
-        dst[r] = a.x[((size_t)t * N + e0 + env) * n_in + (i < n_in ? i : n_in - 1)];
+        dst[r] = x_t[(unsigned)(e0 + env) * (unsigned)n_in + (unsigned)(i < n_in ? i : n_in - 1)];
       }
     };
     auto stage_x = [&](int hb, const float (&src)[12]) {
@@ -823,16 +838,20 @@ lstm_seq_bwd_bf16_rc_kernel(const LstmBwdBf16Args a) {
 #pragma unroll
     for (int ci = 0; ci < MAIN_CI; ci++) accW[mt][ci] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
   struct StepOps { float ct[4], cp[4], dh[4], mk[4], hp[4]; };
-  auto fetch = [&](int t, StepOps &o) {
+  auto fetch = [&](int t, StepOps &o) {      // uniform row pointers + 32-bit lane indices (see lstm_seq_bwd_bf16_kernel)
+    const size_t trow = (size_t)t * N;
+    const float *mk_t = a.masks + trow, *ct_t = a.cseq + trow * HID, *dh_t = a.dh_in + trow * HID;
+    const float *cp_t = t > 0 ? a.cseq + (trow - N) * HID : a.state0;
+    const float *hp_t = t > 0 ? a.hseq + (trow - N) * HID : a.state0 + HID;
+    const unsigned pstride = t > 0 ? (unsigned)HID : 2u * HID;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const int e = e0 + 4 * rq + j;
-      const size_t row = (size_t)t * N + e;
-      o.mk[j] = a.masks[row];
-      o.ct[j] = a.cseq[row * HID + u];
-      o.cp[j] = (t > 0) ? a.cseq[(row - N) * HID + u] : a.state0[(size_t)e * 2 * HID + u];
-      o.hp[j] = (t > 0) ? a.hseq[(row - N) * HID + u] : a.state0[(size_t)e * 2 * HID + HID + u];
-      o.dh[j] = a.dh_in[row * HID + u];
+      const unsigned e = (unsigned)(e0 + 4 * rq + j);
+      o.mk[j] = mk_t[e];
+      o.ct[j] = ct_t[e * HID + u];
+      o.cp[j] = cp_t[e * pstride + u];
+      o.hp[j] = hp_t[e * pstride + u];
+      o.dh[j] = dh_t[e * HID + u];
     }
   };
   // (h_{t-1} keep_t)^T of the step whose operands are `o`: rows 0 .. 47 of tile hb, [unit u][env 4 rq .. 4 rq + 3]
@@ -956,8 +975,9 @@ lstm_seq_bwd_bf16_rc_kernel(const LstmBwdBf16Args a) {
 #pragma unroll
     for (int j = 0; j < 4; j++) dhrec[j] = acc[j] * keepC[j];
     if (NEED_DX && u < n_in) {
+      float *dx_t = a.dx + (size_t)t * N * n_in;      // uniform row pointer
 #pragma unroll
-      for (int j = 0; j < 4; j++) a.dx[((size_t)t * N + e0 + 4 * rq + j) * n_in + u] = accx[j];
+      for (int j = 0; j < 4; j++) dx_t[(unsigned)(e0 + 4 * rq + j) * (unsigned)n_in + u] = accx[j];
     }
     lbf_weight_grads_rc<NS, MAIN_CI>(accW, zt + (size_t)buf * NS * LBF_RC_Z, hx + (size_t)hb * NS * LBF_RC_HX, MAIN_CI * w, col, rq);
     if (t - 1 >= 0) recompute(hb_next);      // the gates of step t - 1 (its tile is complete since this step's barrier)
