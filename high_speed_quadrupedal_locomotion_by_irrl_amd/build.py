@@ -89,7 +89,10 @@ COMMON_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unu
 # Env kernels only (measured on MI355X, 4096 envs, same box): the SLP vectorizer's packed-f32 pairs cost more v_mov than
 # they save in this scalar-per-lane code (56.6 -> 51.4 us per step without it), and the single resident wave per SIMD
 # wants ILP-first scheduling (-> 50.1 us).
-ENV_FLAGS = ["-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+# Round 6: `iterative-ilp` instead of `max-ilp` -- same-box A/B of the five strategies the back end offers on the persistent step kernel: max-ilp 31.7-32.0 us,
+# max-memory-clause 31.9, iterative-maxocc 31.6-31.7, the default 31.6, iterative-minreg 33.1, iterative-ilp 31.1-31.5 (profiles/r06_ab_env_sched_strategy_same_box.log).
+# Scheduling only: results bit-identical.
+ENV_FLAGS = ["-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
 
 
 def llvm_bin():

@@ -10,8 +10,20 @@ for spec in sys.argv[1:]:
     name, _, flags = spec.partition("=")
     flags = [f for f in flags.split(",") if f]
     objs = []
+    # "envsched:<strategy>" replaces the env kernels' scheduling strategy (build.ENV_FLAGS: max-ilp); "envnosched" drops it
+    env_flags = list(B.ENV_FLAGS)
+    for f in list(flags):
+        if f.startswith("envsched:"):
+            flags.remove(f)
+            env_flags = [x for x in env_flags if not x.startswith("-amdgpu-sched-strategy")]
+            env_flags[env_flags.index("-mllvm") + 1:env_flags.index("-mllvm") + 1] = ["-amdgpu-sched-strategy=" + f.split(":", 1)[1]]
+        elif f == "envnosched":
+            flags.remove(f)
+            i = env_flags.index("-mllvm")
+            del env_flags[i:i + 2]
+    B_ENV = env_flags
     common = list(B.COMMON_FLAGS) + flags
-    for src, fl, obj in (("env_kernels.hip", ["-DIRRL_LANES_PER_ROBOT=16"] + B.ENV_FLAGS, "l16"), ("env_kernels.hip", ["-DIRRL_LANES_PER_ROBOT=4"] + B.ENV_FLAGS, "l4"),
+    for src, fl, obj in (("env_kernels.hip", ["-DIRRL_LANES_PER_ROBOT=16"] + B_ENV, "l16"), ("env_kernels.hip", ["-DIRRL_LANES_PER_ROBOT=4"] + B_ENV, "l4"),
                          ("irrl_env_abi.hip", [], "abi")):
         o = os.path.join(out, f"{name}_{obj}.o")
         objs.append(o)
