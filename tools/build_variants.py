@@ -10,7 +10,7 @@ for spec in sys.argv[1:]:
     name, _, flags = spec.partition("=")
     flags = [f for f in flags.split(",") if f]
     objs = []
-    # "envsched:<strategy>" replaces the env kernels' scheduling strategy (build.ENV_FLAGS: max-ilp); "envnosched" drops it
+    # "envsched:<strategy>" replaces the env kernels' scheduling strategy (build.ENV_FLAGS: iterative-ilp); "envnosched" drops it
     env_flags = list(B.ENV_FLAGS)
     for f in list(flags):
         if f.startswith("envsched:"):

@@ -14,7 +14,7 @@ if "--kernel" in sys.argv:
     kernel = sys.argv[i + 1]
     del sys.argv[i:i + 2]
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-fno-signed-zeros",
-       "-DIRRL_LANES_PER_ROBOT=16", "-DIRRL_MARKS", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-S", "--cuda-device-only", "-o", out, src] + sys.argv[1:]
+       "-DIRRL_LANES_PER_ROBOT=16", "-DIRRL_MARKS", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-S", "--cuda-device-only", "-o", out, src] + sys.argv[1:]
 subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
 sec, counts, order = None, collections.OrderedDict(), []
 inside = False
