@@ -42,8 +42,8 @@ def test_fixture_is_a_consistent_decoding_of_the_logs():
 
 
 def test_oracle_physics_reproduces_the_raisim_logs():
-    """f64 oracle, CPU: eleven RaiSim recordings, statistics within the stated bounds (measured: speed within 1.3 % for delays 0-3 and all
-    frictions -- 5.1341 vs 5.1342 m/s at mu 0.4, 4.969 vs 4.975 on mu 0.05 ice -- height within 1.3 mm, mean pitch within 0.002 rad)."""
+    """f64 oracle, CPU: eleven RaiSim recordings, statistics within the stated bounds (measured: speed within 1.7 % for delays 0-3 and all
+    frictions -- 5.1341 vs 5.1342 m/s at mu 0.4, 4.969 vs 4.975 on mu 0.05 ice -- height within 2.2 mm, mean pitch within 0.002 rad)."""
     rows, skipped = PL.compare_with_raisim_logs(O.OracleVecEnv, load_env_cfg, _fixture())
     print(PL.raisim_log_table(rows, skipped, "f64 oracle"))
     assert len(rows) == 11 and len(skipped) == 3
