@@ -67,6 +67,23 @@ __device__ __forceinline__ int irrl_xcd_block() {
   const bool valid_ = env_ < P.n_envs;                         \
   if (!valid_) env_ = P.n_envs - 1; /* idle quads shadow the last robot; their stores are masked */
 #endif
+// P / S of a kernel body: the by-value arguments named in the kernarg segment (lanes_hip*.hpp: their fields are read where they are used,
+// with scalar loads, instead of all at the kernel's entry) -- or, A/B switch of tools/build_variants.py, the arguments themselves
+#ifndef IRRL_NO_PARAMS_KERNARG
+#define IRRL_BIND_ARGS                                         \
+  const EnvParams &P = irrl_kernarg<EnvParams>(0);             \
+  const EnvState &S = irrl_kernarg<EnvState>((unsigned)((sizeof(EnvParams) + alignof(EnvState) - 1) / alignof(EnvState) * alignof(EnvState)));
+#define IRRL_PARAMS_REFRESH(P) irrl_refresh(P)          /* once per step of the multi-step kernels */
+// the rollout kernels' PolicyStepArgs (behind P, S and the four output pointers): A0 names it, a step's own copy is taken from it per step
+#define IRRL_KERNARG_ALIGN(off, T) (((off) + alignof(T) - 1) / alignof(T) * alignof(T))
+#define IRRL_BIND_POLICY_ARGS(A0, A_)                                                                                              \
+  const PolicyStepArgs &A0 = irrl_kernarg<PolicyStepArgs>((unsigned)IRRL_KERNARG_ALIGN(                                            \
+      IRRL_KERNARG_ALIGN(sizeof(EnvParams), EnvState) + sizeof(EnvState) + 4 * sizeof(void *), PolicyStepArgs));
+#else
+#define IRRL_BIND_ARGS const EnvParams &P = P_; const EnvState &S = S_;
+#define IRRL_PARAMS_REFRESH(P) (P)
+#define IRRL_BIND_POLICY_ARGS(A0, A_) const PolicyStepArgs &A0 = A_;
+#endif
 #define IRRL_LANE_PROLOGUE IRRL_LANE_PROLOGUE_B(irrl_xcd_block())          /* the stand-alone lane kernels */
 #define IRRL_LANE_PROLOGUE_IDENTITY IRRL_LANE_PROLOGUE_B((int)blockIdx.x)  /* kernels whose policy part addresses robots by blockIdx */
 
@@ -78,7 +95,8 @@ extern "C" {
 // per-substep constants were live across the sweep loop and the allocator paid for them in AGPR copies.)
 #define IRRL_STEP_KERNEL(NAME, NS, RULE)                                                                                           \
   __global__ void __launch_bounds__(256, 1)                                                                                        \
-  IRRL_K(NAME)(EnvParams P, EnvState S, const float *action, float *ob, float *reward, uint8_t *done, float *extra) {               \
+  IRRL_K(NAME)(EnvParams P_, EnvState S_, const float *action, float *ob, float *reward, uint8_t *done, float *extra) {             \
+    IRRL_BIND_ARGS                                                                                                                 \
     IRRL_LANE_PROLOGUE                                                                                                             \
     NS::step_body<RULE>(P, S, env_, leg_, valid_, action, ob, reward, done, extra);                                                \
   }
@@ -88,7 +106,8 @@ IRRL_STEP_KERNEL(irrl_step_kernel_dir, irrl_plain, 0)
 
 // the default pool: no meteorite, published rule
 __global__ void __launch_bounds__(256, 1)
-IRRL_K(irrl_step_kernel)(EnvParams P, EnvState S, const float *action, float *ob, float *reward, uint8_t *done, float *extra) {
+IRRL_K(irrl_step_kernel)(EnvParams P_, EnvState S_, const float *action, float *ob, float *reward, uint8_t *done, float *extra) {
+  IRRL_BIND_ARGS
   IRRL_LANE_PROLOGUE
 #ifdef IRRL_PROFILE_WAVES   /* diagnostic build (tools/wave_spread.py): extra[env][5] <- this wave's duration in 100 MHz ticks */
   const unsigned long long t0_ = wall_clock64();
@@ -111,7 +130,8 @@ IRRL_K(irrl_step_kernel)(EnvParams P, EnvState S, const float *action, float *ob
 // robot, and four waves (three of them with two virtual waves of MFMA work each) take 18.5 us for what the stand-alone kernel's
 // six waves do in 14.1.  Bit-identical results; an OPTION of irrl_lstm_rollout (fuse = 1), not the default.  (HID 48, ob 35.)
 __global__ void __launch_bounds__(256, 1)
-irrl_step_policy_kernel_l16(EnvParams P, EnvState S, const float *action, float *ob, float *reward, uint8_t *done, float *extra, PolicyStepArgs a) {
+irrl_step_policy_kernel_l16(EnvParams P_, EnvState S_, const float *action, float *ob, float *reward, uint8_t *done, float *extra, PolicyStepArgs a) {
+  IRRL_BIND_ARGS
   __shared__ float hbuf[2][16 * 49];
   __shared__ float terms[16][17];
   __shared__ float head_w[48 * 17];
@@ -145,7 +165,8 @@ irrl_step_policy_kernel_l16(EnvParams P, EnvState S, const float *action, float 
 // bit-identical to the two-launch sequence.  Within a workgroup every global array is written and re-read by the same CU: the
 // vector L1 is coherent at workgroup scope (non-tgsplit), the barriers' waits on the memory counters order the accesses.
 __global__ void __launch_bounds__(256, 1)
-irrl_rollout_persistent_kernel_l16(EnvParams P, EnvState S, float *ob, float *reward, uint8_t *done, float *extra, PolicyStepArgs a, int steps) {
+irrl_rollout_persistent_kernel_l16(EnvParams P_, EnvState S_, float *ob, float *reward, uint8_t *done, float *extra, PolicyStepArgs a, int steps) {
+  IRRL_BIND_ARGS
   __shared__ float hbuf[2][16 * 49];
   __shared__ float terms[16][17];
   __shared__ float head_w[48 * 17];
@@ -180,7 +201,7 @@ irrl_rollout_persistent_kernel_l16(EnvParams P, EnvState S, float *ob, float *re
       const int leg_ = (lane_ >> 2) & 3;
       const bool valid_ = (env_ < P.n_envs) && ((lane_ & 3) == 0);
       if (env_ >= P.n_envs) env_ = P.n_envs - 1;
-      irrl_plain::step_body<1>(P, S, env_, leg_, valid_, (const float *)a.clipped, ob, reward, done, extra);
+      irrl_plain::step_body<1>(IRRL_PARAMS_REFRESH(P), IRRL_PARAMS_REFRESH(S), env_, leg_, valid_, (const float *)a.clipped, ob, reward, done, extra);
     }
     IRRL_PP_STAMP(2);   // env step of this wave's four robots
     __syncthreads();   // obs / dones / reward of step k are stored and visible: the next policy step reads them
@@ -204,7 +225,8 @@ irrl_rollout_persistent_kernel_l16(EnvParams P, EnvState S, float *ob, float *re
 // once.  Same device functions and per-element arithmetic as the full kernel above: actions, clipped actions, neglogp, observations,
 // rewards, dones and the actor's LSTM state are bit-identical to every other rollout mode; `value` / `mb_values` are not written.
 __global__ void __launch_bounds__(256, 1)
-irrl_rollout_persistent_actor_kernel_l16(EnvParams P, EnvState S, float *ob, float *reward, uint8_t *done, float *extra, PolicyStepArgs a, int steps) {
+irrl_rollout_persistent_actor_kernel_l16(EnvParams P_, EnvState S_, float *ob, float *reward, uint8_t *done, float *extra, PolicyStepArgs a, int steps) {
+  IRRL_BIND_ARGS
   __shared__ float hbuf[2][16 * 49];
   __shared__ float terms[16][17];
   __shared__ float head_w[48 * 17];
@@ -239,9 +261,9 @@ irrl_rollout_persistent_actor_kernel_l16(EnvParams P, EnvState S, float *ob, flo
       asm volatile("" : "+v"(env_));
 #ifndef IRRL_ACTOR_NO_CARRY
       if (k > 0) irrl_plain::lane_carry(L);
-      irrl_plain::step_compute<1>(P, L, env_, leg0_, valid0_, irrl_plain::ActionRow{(const float *)a.clipped}, ob, reward, done, extra);
+      irrl_plain::step_compute<1>(IRRL_PARAMS_REFRESH(P), L, env_, leg0_, valid0_, irrl_plain::ActionRow{(const float *)a.clipped}, ob, reward, done, extra);
 #else
-      irrl_plain::step_body<1>(P, S, env_, leg0_, valid0_, (const float *)a.clipped, ob, reward, done, extra);
+      irrl_plain::step_body<1>(IRRL_PARAMS_REFRESH(P), IRRL_PARAMS_REFRESH(S), env_, leg0_, valid0_, (const float *)a.clipped, ob, reward, done, extra);
 #endif
     }
     __syncthreads();   // obs / dones / reward of step k are stored and visible: the next policy step reads them
@@ -249,7 +271,7 @@ irrl_rollout_persistent_actor_kernel_l16(EnvParams P, EnvState S, float *ob, flo
 #ifndef IRRL_ACTOR_NO_CARRY
   if (steps > 0) {
     IRRL_SUB0_ONLY_BEGIN
-    irrl_plain::store_lane(P, S, env0_, leg0_, valid0_, L, P.randomize_per_episode != 0);
+    irrl_plain::store_lane(IRRL_PARAMS_REFRESH(P), IRRL_PARAMS_REFRESH(S), env0_, leg0_, valid0_, L, P.randomize_per_episode != 0);
     IRRL_SUB0_ONLY_END
   }
 #endif
@@ -265,7 +287,9 @@ irrl_rollout_persistent_actor_kernel_l16(EnvParams P, EnvState S, float *ob, flo
 // scratch next to the stores to memory -- no workgroup barrier and no load behind a store inside the step loop.  Actions, neglogp,
 // observations, rewards, dones and the actor's final LSTM state are bit-identical to every other rollout mode.
 __global__ void __launch_bounds__(256, 1)
-irrl_rollout_persistent_actor_wave_kernel_l16(EnvParams P, EnvState S, float *ob, float *reward, uint8_t *done, float *extra, PolicyStepArgs a, int steps) {
+irrl_rollout_persistent_actor_wave_kernel_l16(EnvParams P_, EnvState S_, float *ob, float *reward, uint8_t *done, float *extra, PolicyStepArgs a_, int steps) {
+  IRRL_BIND_ARGS
+  IRRL_BIND_POLICY_ARGS(a, a_)
   constexpr int HID = 48, NG = HID / 16, SD = 8 * HID;
   typedef LstmWaveLds<HID> LAY;
   __shared__ __attribute__((aligned(16))) float wsl[4][LAY::FLOATS];
@@ -318,9 +342,10 @@ irrl_rollout_persistent_actor_wave_kernel_l16(EnvParams P, EnvState S, float *ob
   for (int k = 0; k < steps; k++) {
     int lane = lane0_;
     asm volatile("" : "+v"(lane));
-    a.row = row0 + k; a.rng_step = rng0 + k;
-    a.noise = noise0 ? noise0 + (size_t)k * noise_stride : nullptr;
-    lstm_actor_wave_body<HID>(a, e4_, ws, lds_w, head_w, lane, cst, bias);
+    PolicyStepArgs ak = IRRL_PARAMS_REFRESH(a);
+    ak.row = row0 + k; ak.rng_step = rng0 + k;
+    ak.noise = noise0 ? noise0 + (size_t)k * noise_stride : nullptr;
+    lstm_actor_wave_body<HID>(ak, e4_, ws, lds_w, head_w, lane, cst, bias);
     PS_WAVE_SYNC();    // this wave's clipped actions are in its scratch
     {
       int env_ = env0_;
@@ -330,7 +355,7 @@ irrl_rollout_persistent_actor_wave_kernel_l16(EnvParams P, EnvState S, float *ob
 #pragma unroll
       for (int j = 0; j < 3; j++) act.a[j] = ws[LAY::ACT + rl_ * 12 + leg0_ * 3 + j];
       irrl_plain::step_compute<1, irrl_plain::NoStepHook>(
-          P, L, env_, leg0_, valid0_, act, ob, reward, done, extra, irrl_plain::NoStepHook(),
+          IRRL_PARAMS_REFRESH(P), L, env_, leg0_, valid0_, act, ob, reward, done, extra, irrl_plain::NoStepHook(),
           [&](const irrl_plain::EnvLane &Lf, float rew, bool dn) {
             irrl_plain::observe_write(P, rl_, leg0_, valid0_, Lf, ws + LAY::X);
             if (valid0_ && leg0_ == 0) { ws[LAY::REW + rl_] = rew; ws[LAY::DON + rl_] = dn ? 1.0f : 0.0f; }
@@ -340,7 +365,7 @@ irrl_rollout_persistent_actor_wave_kernel_l16(EnvParams P, EnvState S, float *ob
   }
   if (steps > 0) {
     IRRL_SUB0_ONLY_BEGIN
-    irrl_plain::store_lane(P, S, env0_, leg0_, valid0_, L, P.randomize_per_episode != 0);
+    irrl_plain::store_lane(IRRL_PARAMS_REFRESH(P), IRRL_PARAMS_REFRESH(S), env0_, leg0_, valid0_, L, P.randomize_per_episode != 0);
     IRRL_SUB0_ONLY_END
     if (pok_) {      // the actor's LSTM state behind the last step (the critic's half is the caller's: ppo2.Runner._critic_pass)
 #pragma unroll
@@ -363,7 +388,9 @@ irrl_rollout_persistent_actor_wave_kernel_l16(EnvParams P, EnvState S, float *ob
 // of the 1024 env waves: since the second half of round 5 the policy of a wave's four robots is that wave's own work (see inside).
 // Same device functions, same order: the buffers are bit-identical to the two-launch sequence.
 __global__ void __launch_bounds__(256, 1)
-irrl_rollout_persistent_mlp_kernel_l16(EnvParams P, EnvState S, float *ob, float *reward, uint8_t *done, float *extra, PolicyStepArgs a, int steps) {
+irrl_rollout_persistent_mlp_kernel_l16(EnvParams P_, EnvState S_, float *ob, float *reward, uint8_t *done, float *extra, PolicyStepArgs a_, int steps) {
+  IRRL_BIND_ARGS
+  IRRL_BIND_POLICY_ARGS(a, a_)
   __shared__ __attribute__((aligned(16))) float wsl[4][MlpWaveLds<64>::FLOATS];      // per wave: its four robots' scratch (policy_step.hpp)
   __shared__ float head_w[64 * 17];
   __shared__ __attribute__((aligned(16))) float wl[MlpLdsImage<64>::FLOATS];
@@ -400,9 +427,10 @@ irrl_rollout_persistent_mlp_kernel_l16(EnvParams P, EnvState S, float *ob, float
   for (int k = 0; k < steps; k++) {
     int lane = lane0_;
     asm volatile("" : "+v"(lane));     // (see irrl_rollout_persistent_kernel_l16: keeps the per-lane addresses inside the loop)
-    a.row = row0 + k; a.rng_step = rng0 + k;
-    a.noise = noise0 ? noise0 + (size_t)k * noise_stride : nullptr;
-    mlp_policy_wave_body<64, true, true>(a, e4_, ws, wl, head_w, lane);
+    PolicyStepArgs ak = IRRL_PARAMS_REFRESH(a);
+    ak.row = row0 + k; ak.rng_step = rng0 + k;
+    ak.noise = noise0 ? noise0 + (size_t)k * noise_stride : nullptr;
+    mlp_policy_wave_body<64, true, true>(ak, e4_, ws, wl, head_w, lane);
     PS_WAVE_SYNC();    // this wave's clipped actions are in its scratch
     {
       int env_ = env0_;
@@ -412,7 +440,7 @@ irrl_rollout_persistent_mlp_kernel_l16(EnvParams P, EnvState S, float *ob, float
 #pragma unroll
       for (int j = 0; j < 3; j++) act.a[j] = ws[MlpWaveLds<64>::ACT + rl_ * 12 + leg0_ * 3 + j];
       irrl_plain::step_compute<1, irrl_plain::NoStepHook>(
-          P, L, env_, leg0_, valid0_, act, ob, reward, done, extra, irrl_plain::NoStepHook(),
+          IRRL_PARAMS_REFRESH(P), L, env_, leg0_, valid0_, act, ob, reward, done, extra, irrl_plain::NoStepHook(),
           [&](const irrl_plain::EnvLane &Lf, float rew, bool dn) {
             // (inside the epilogue's sub-lane-0 region) the scaled observation row, the reward and the done flag once more, into the scratch
             irrl_plain::observe_write(P, rl_, leg0_, valid0_, Lf, ws + MlpWaveLds<64>::X);
@@ -423,7 +451,7 @@ irrl_rollout_persistent_mlp_kernel_l16(EnvParams P, EnvState S, float *ob, float
   }
   if (steps > 0) {
     IRRL_SUB0_ONLY_BEGIN
-    irrl_plain::store_lane(P, S, env0_, leg0_, valid0_, L, P.randomize_per_episode != 0);
+    irrl_plain::store_lane(IRRL_PARAMS_REFRESH(P), IRRL_PARAMS_REFRESH(S), env0_, leg0_, valid0_, L, P.randomize_per_episode != 0);
     IRRL_SUB0_ONLY_END
   }
 }
@@ -438,8 +466,9 @@ irrl_rollout_persistent_mlp_kernel_l16(EnvParams P, EnvState S, float *ob, float
 // order): states and outputs are bit-identical to `count` launches.  Default pool kind only (no meteorite, published rule); the launcher
 // falls back otherwise.
 __global__ void __launch_bounds__(256, 1)
-IRRL_K(irrl_steps_persistent_kernel)(EnvParams P, EnvState S, const float *action_rows, int n_rows, int first_row, int count, float *ob, float *reward,
+IRRL_K(irrl_steps_persistent_kernel)(EnvParams P_, EnvState S_, const float *action_rows, int n_rows, int first_row, int count, float *ob, float *reward,
                                      uint8_t *done, float *extra, int out_rows) {
+  IRRL_BIND_ARGS
   const int blk = irrl_xcd_block();
   const size_t row = (size_t)P.n_envs * 12;
   // out_rows != 0: the outputs are [count, N, .] tables and step k fills row k -- the trajectory `count` step() calls of the reference
@@ -478,38 +507,43 @@ IRRL_K(irrl_steps_persistent_kernel)(EnvParams P, EnvState S, const float *actio
       act_next.a[0] = an[0]; act_next.a[1] = an[1]; act_next.a[2] = an[2];
     }
     irrl_plain::step_compute<1, irrl_plain::NoStepHook, irrl_plain::NoStepTail, irrl_plain::ActionRegs>(
-        P, L, env_, leg0_, valid0_, act, ob + orow * 35 * (size_t)k, reward + orow * (size_t)k, done + orow * (size_t)k, extra + orow * 6 * (size_t)k);
+        IRRL_PARAMS_REFRESH(P), L, env_, leg0_, valid0_, act, ob + orow * 35 * (size_t)k, reward + orow * (size_t)k, done + orow * (size_t)k, extra + orow * 6 * (size_t)k);
   }
   if (count > 0) {
     IRRL_SUB0_ONLY_BEGIN
-    irrl_plain::store_lane(P, S, env0_, leg0_, valid0_, L, P.randomize_per_episode != 0);
+    irrl_plain::store_lane(IRRL_PARAMS_REFRESH(P), IRRL_PARAMS_REFRESH(S), env0_, leg0_, valid0_, L, P.randomize_per_episode != 0);
     IRRL_SUB0_ONLY_END
   }
 }
 
-__global__ void __launch_bounds__(256, 1) IRRL_K(irrl_init_kernel)(EnvParams P, EnvState S) {
+__global__ void __launch_bounds__(256, 1) IRRL_K(irrl_init_kernel)(EnvParams P_, EnvState S_) {
+  IRRL_BIND_ARGS
   IRRL_LANE_PROLOGUE
   irrl::init_body(P, S, env_, leg_, valid_);
 }
 
-__global__ void __launch_bounds__(256, 1) IRRL_K(irrl_reset_kernel)(EnvParams P, EnvState S, float *ob) {
+__global__ void __launch_bounds__(256, 1) IRRL_K(irrl_reset_kernel)(EnvParams P_, EnvState S_, float *ob) {
+  IRRL_BIND_ARGS
   IRRL_LANE_PROLOGUE
   irrl::reset_body(P, S, env_, leg_, valid_, ob);
 }
 
-__global__ void __launch_bounds__(256, 1) IRRL_K(irrl_observe_kernel)(EnvParams P, EnvState S, float *ob) {
+__global__ void __launch_bounds__(256, 1) IRRL_K(irrl_observe_kernel)(EnvParams P_, EnvState S_, float *ob) {
+  IRRL_BIND_ARGS
   IRRL_LANE_PROLOGUE
   irrl::observe_body(P, S, env_, leg_, valid_, ob);
 }
 
-__global__ void __launch_bounds__(256, 1) IRRL_K(irrl_probe_kernel)(EnvParams P, EnvState S, float *minv, float *nonlin) {
+__global__ void __launch_bounds__(256, 1) IRRL_K(irrl_probe_kernel)(EnvParams P_, EnvState S_, float *minv, float *nonlin) {
+  IRRL_BIND_ARGS
   IRRL_LANE_PROLOGUE
   irrl::dynamics_probe_body(P, S, env_, leg_, valid_, minv, nonlin);
 }
 
 #if IRRL_LANES_PER_ROBOT == 16
 // isTerminalState (ENV:1553-1578) on the stored state; one thread per robot (layout independent: emitted once)
-__global__ void irrl_terminal_kernel(EnvParams P, EnvState S, uint8_t *done) {
+__global__ void irrl_terminal_kernel(EnvParams P_, EnvState S_, uint8_t *done) {
+  IRRL_BIND_ARGS
   int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (e >= P.n_envs) return;
   float z = S.gc[e * 19 + 2], up = S.ob[e * 35 + 31];

@@ -17,6 +17,23 @@
 #define IRRL_OPAQUE(x) asm volatile("" : "+v"(x))
 #define IRRL_L16 1
 
+// KERNEL ARGUMENTS READ WHERE THEY ARE USED (round 6).  EnvParams (92 words) + EnvState (27 pointers) + a kernel's own pointers are more than the
+// 102 SGPRs.  Read as by-value arguments, every field is an invariant load that the optimizer hoists to the kernel's entry, and what does not
+// fit is parked in VGPR lanes: a v_writelane up front and a v_readlane -- a VALU issue slot of the one resident wave -- at every use (step
+// kernel: 119 spilled SGPRs, 217 v_readlane; multi-step kernel: 217 / 605).  irrl_kernarg<T>(off) names the argument in the kernarg segment
+// itself (constant address space: s_load_dword[xN] where the field is used), irrl_refresh() makes that pointer opaque once per step of the
+// multi-step kernels so that the loads of step k stay inside step k.  Same values, same arithmetic: results are bit-identical.
+#define IRRL_CONST_AS __attribute__((address_space(4)))
+template <class T> IRRL_DEV const T &irrl_kernarg(unsigned off) {
+  const IRRL_CONST_AS char *p = (const IRRL_CONST_AS char *)__builtin_amdgcn_kernarg_segment_ptr() + off;
+  return *(const T *)(const IRRL_CONST_AS T *)p;
+}
+template <class T> IRRL_DEV const T &irrl_refresh(const T &r) {
+  const IRRL_CONST_AS T *p = (const IRRL_CONST_AS T *)&r;
+  asm volatile("" : "+s"(p));
+  return *(const T *)p;
+}
+
 typedef float vf;
 typedef int32_t vi;
 typedef uint32_t vu;

@@ -94,7 +94,7 @@ def test_verifier_fails_closed():
 
 def test_verifier_on_the_real_env_kernel_assembly_of_both_lane_layouts():
     """the assembly the product library was built from (csrc/_obj/env_kernels_l{16,4}.s): every DPP instruction of every kernel
-    -- hand-placed and compiler-generated -- is hazard-free; the compiler's raw output of the 16-lane layout is not"""
+    -- hand-placed and compiler-generated -- is hazard-free; the same assembly without its wait states is not"""
     import pytest
     build.build()
     if not all(os.path.exists(os.path.join(build.CSRC, "_obj", "env_kernels_l%d.s" % l)) for l in (16, 4)):
@@ -102,9 +102,11 @@ def test_verifier_on_the_real_env_kernel_assembly_of_both_lane_layouts():
     for lanes, min_dpp in ((16, 2000), (4, 1000)):
         fixed = open(os.path.join(build.CSRC, "_obj", "env_kernels_l%d.s" % lanes)).readlines()
         assert isa_pass.verify(fixed) >= min_dpp
-    raw = open(os.path.join(build.CSRC, "_obj", "env_kernels_l16.raw.s")).readlines()
+    # ... and the verifier does see a hazard in that assembly once the wait states are taken out again (the compiler's raw output itself may or
+    # may not need any of the pass's: that depends on where its scheduler happens to put the hand-placed instructions)
+    fixed = open(os.path.join(build.CSRC, "_obj", "env_kernels_l16.s")).readlines()
     with pytest.raises(isa_pass.HazardError):
-        isa_pass.verify(raw)
+        isa_pass.verify([l for l in fixed if not l.strip().startswith("s_nop")])
 
 
 def test_product_build_contains_the_hand_placed_instructions_and_is_hazard_free():

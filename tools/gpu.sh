@@ -40,7 +40,7 @@ mkdir -p "$O"
 line() { python3 -c "import sys,json
 for l in sys.stdin:
     if l.startswith('{') and 'metric' in l:
-        d=json.loads(l); print('$1', round(d['value']/1e6,2), 'M env-steps/s', round(d['roofline']['avg_step_us'],2), 'us per step', 'fp32_frac', round(d['roofline']['frac'],4))"; }
+        d=json.loads(l); print('$1', round(d['value']/1e6,2), 'M env-steps/s', round(d['roofline']['avg_step_us'],2), 'us per step', 'fp32_frac', round(d['roofline']['frac'],4), *(('persistent', round(d['launch_modes']['persistent']['us_per_step'],2), 'per-step launch', round(d['launch_modes']['rows']['us_per_step'],2)) if 'rows' in d.get('launch_modes', {}) else ()))"; }
 while [ $# -gt 0 ]; do
   stage=$1; shift
   case $stage in
