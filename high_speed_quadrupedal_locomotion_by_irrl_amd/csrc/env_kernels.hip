@@ -1,8 +1,9 @@
-// env_kernels.hip -- __global__ wrappers of the lane bodies in env_core.hpp (gfx950 only).
-// Launch shape: 64-thread workgroups = one wave = 16 robots (one DPP quad each); grid = ceil(N / 16).
-// At N = 4096 that is 256 workgroups -> one wave on each of the 256 CUs; the kernel keeps the whole
-// robot state in VGPRs across the 8 substeps (no LDS, no scratch), so __launch_bounds__(256, 1) lets the
-// allocator use the full 512-register budget of a SIMD that hosts a single wave.
+// env_kernels.hip -- __global__ wrappers of the lane bodies in env_core.hpp (gfx950 only); compiled once per lane layout (build.py).
+// Launch shape of the lane kernels: 64-thread workgroups = one wave = 4 robots (16 lanes per robot, one DPP row each: pools <= 6144) or 16 robots
+// (4 lanes per robot, one DPP quad each).  At N = 4096 the 16-lane layout is 1024 workgroups -> one wave on every SIMD of the 256 CUs; the kernels
+// keep the whole robot state in registers across the 8 substeps (no LDS; scratch only in the reset branch), so __launch_bounds__(256, 1) lets the
+// allocator use the full 512-register budget of a SIMD that hosts a single wave.  The rollout kernels (policy in the same launch) run 256-thread
+// workgroups: four env waves = 16 robots per workgroup.
 #ifndef IRRL_LANES_PER_ROBOT
 #define IRRL_LANES_PER_ROBOT 16
 #endif

@@ -15,6 +15,7 @@
 #   profppo        rocprofv3 --kernel-trace --stats of 2 PPO iterations x 2 epochs (LSTM)
 #   profmlp        rocprofv3 --kernel-trace --stats of 3 PPO iterations with the MlpPolicy learner (config 2)
 #   pmc            PMC passes of the env step kernel (separate --pmc runs, no trace domains besides kernel-trace)
+#   pmcsum         tools/pmc_summarize.py on the box (name: PMC_NAME), copies of the two JSON files into gpurun_out/
 #   pmclstm        PMC passes of the LSTM sequence kernels
 #   pmcmlp         PMC passes of the MlpPolicy gradient kernels
 #   ppo            tools/ppo_bench.py lstm + mlp, 3 iterations each
@@ -40,7 +41,7 @@ mkdir -p "$O"
 line() { python3 -c "import sys,json
 for l in sys.stdin:
     if l.startswith('{') and 'metric' in l:
-        d=json.loads(l); print('$1', round(d['value']/1e6,2), 'M env-steps/s', round(d['roofline']['avg_step_us'],2), 'us per step', 'fp32_frac', round(d['roofline']['frac'],4), *(('persistent', round(d['launch_modes']['persistent']['us_per_step'],2), 'per-step launch', round(d['launch_modes']['rows']['us_per_step'],2)) if 'rows' in d.get('launch_modes', {}) else ()))"; }
+        d=json.loads(l); print('$1', round(d['value']/1e6,2), 'M env-steps/s', round(d['roofline']['avg_step_us'],2), 'us per step', 'fp32_frac', round(d['roofline']['frac'],4), *(('persistent', round(d['launch_modes']['persistent']['us_per_step'],2), 'per-step launch', round(d['launch_modes']['rows']['us_per_step'],2)) if 'rows' in (d.get('launch_modes') or {}) else ()))"; }
 while [ $# -gt 0 ]; do
   stage=$1; shift
   case $stage in
@@ -88,6 +89,8 @@ while [ $# -gt 0 ]; do
          tag=$(echo $grp | tr ' ' '_' | cut -c1-40)
          timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/pmc_env_$tag -- python3 $R/tools/pmc_workload.py 300 4096 > $O/pmc_env_$tag.log 2>&1
        done) ;;      # then, back in the build container: python tools/pmc_summarize.py r03_pmc_summary
+    pmcsum)   # behind `pmc`, in front of `bench` in the same call: the summary (with this library's hash) is there when bench.py looks for `traffic`
+      python3 tools/pmc_summarize.py ${PMC_NAME:-pmc_summary} > $O/pmcsum.log 2>&1; cp profiles/${PMC_NAME:-pmc_summary}.json profiles/pmc_summary_latest.json $O/ 2>/dev/null ;;
     pmclstm)
       rm -rf $O/pmc_lstm_*
       (cd /tmp && export TMPDIR=/tmp

@@ -13,8 +13,9 @@ if "--kernel" in sys.argv:
     i = sys.argv.index("--kernel")
     kernel = sys.argv[i + 1]
     del sys.argv[i:i + 2]
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-fno-signed-zeros",
-       "-DIRRL_LANES_PER_ROBOT=16", "-DIRRL_MARKS", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-S", "--cuda-device-only", "-o", out, src] + sys.argv[1:]
+sys.path.insert(0, root)
+from high_speed_quadrupedal_locomotion_by_irrl_amd import build as B   # the product build's own flag lists
+cmd = [B.hipcc()] + B.COMMON_FLAGS + ["-DIRRL_LANES_PER_ROBOT=16", "-DIRRL_MARKS"] + B.ENV_FLAGS + ["-S", "--cuda-device-only", "-o", out, src] + sys.argv[1:]
 subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
 sec, counts, order = None, collections.OrderedDict(), []
 inside = False
@@ -38,14 +39,18 @@ for line in open(out):
     counts[sec][kind] += 1
     if op.endswith("_dpp") or "_dpp" in t:
         counts[sec]["dpp"] += 1
+    if op in ("v_readlane_b32", "v_writelane_b32"):
+        counts[sec]["lane"] += 1
+    if op.startswith("v_accvgpr"):
+        counts[sec]["acc"] += 1
     if op.startswith("v_pk_"):
         counts[sec]["pk"] += 1
     if op in ("v_mov_b32_e32", "v_mov_b32_dpp", "v_accvgpr_read_b32", "v_accvgpr_write_b32", "v_cndmask_b32_e32", "v_cndmask_b32_e64"):
         counts[sec]["mov_sel"] += 1
 tot = collections.Counter()
-print("%-14s %6s %6s %5s %5s %5s %7s" % ("section", "valu", "salu", "mem", "dpp", "pk", "mov/sel"))
+print("%-17s %6s %6s %5s %5s %5s %7s %9s %8s" % ("section", "valu", "salu", "mem", "dpp", "pk", "mov/sel", "sgpr<->v", "agpr<->v"))
 for k, c in counts.items():
-    print("%-14s %6d %6d %5d %5d %5d %7d" % (k, c["valu"], c["salu"], c["mem"], c["dpp"], c["pk"], c["mov_sel"]))
+    print("%-17s %6d %6d %5d %5d %5d %7d %9d %8d" % (k, c["valu"], c["salu"], c["mem"], c["dpp"], c["pk"], c["mov_sel"], c["lane"], c["acc"]))
     tot.update(c)
-print("%-14s %6d %6d %5d %5d %5d %7d" % ("total", tot["valu"], tot["salu"], tot["mem"], tot["dpp"], tot["pk"], tot["mov_sel"]))
-print("(gs = ONE Gauss-Seidel rank-step loop body + convergence check; it runs (sweeps x ranks) times per substep)")
+print("%-17s %6d %6d %5d %5d %5d %7d %9d %8d" % ("total", tot["valu"], tot["salu"], tot["mem"], tot["dpp"], tot["pk"], tot["mov_sel"], tot["lane"], tot["acc"]))
+print("(gs = the sweep loops of both solvers, static: the simultaneous-sweep loop that runs by default is ~220 of them per sweep;\n sgpr<->v: v_readlane / v_writelane of spilled SGPRs, agpr<->v: v_accvgpr moves -- both are VALU issue slots)")
