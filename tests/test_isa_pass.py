@@ -118,3 +118,34 @@ def test_product_build_contains_the_hand_placed_instructions_and_is_hazard_free(
     assert text.count("v_fmac_f32_dpp") >= 100                       # the 16-lane step kernel's exchanges ride on the FMAs
     out, st = isa_pass.run(text.splitlines(keepends=True))
     assert st["asm_dpp"] == text.count("v_fmac_f32_dpp") and st["wait_states_added"] == 0   # idempotent: nothing left to fix
+
+
+def test_kernarg_offsets_the_kernels_assume_are_the_ones_the_compiler_laid_out():
+    """IRRL_BIND_ARGS / IRRL_BIND_POLICY_ARGS (csrc/env_kernels.hip) name EnvParams, EnvState and PolicyStepArgs by their byte offsets in the
+    kernarg segment: arguments in declaration order, each at its natural alignment.  The code object's own metadata says where the compiler
+    put them -- checked for every kernel of both lane layouts in the assembly the product library was built from."""
+    import yaml
+    build.build()
+    if not all(os.path.exists(os.path.join(build.CSRC, "_obj", "env_kernels_l%d.s" % l)) for l in (16, 4)):
+        build.build(force=True)
+    seen_policy = 0
+    for lanes in (16, 4):
+        lines = open(os.path.join(build.CSRC, "_obj", "env_kernels_l%d.s" % lanes)).read().split("\n")
+        a = next(i for i, l in enumerate(lines) if l.strip() == ".amdgpu_metadata")
+        b = next(i for i, l in enumerate(lines) if l.strip() == ".end_amdgpu_metadata")
+        meta = yaml.safe_load("\n".join(lines[a + 1:b]))
+        kernels = meta["amdhsa.kernels"]
+        assert len(kernels) >= 9
+        for k in kernels:
+            args = [a for a in k[".args"] if not a[".value_kind"].startswith("hidden_")]
+            if not (len(args) >= 2 and args[0][".value_kind"] == "by_value" and args[1][".value_kind"] == "by_value"):
+                continue
+            p, s = args[0], args[1]
+            assert p[".offset"] == 0 and p[".size"] % 4 == 0 and p[".size"] >= 92 * 4, k[".name"]       # EnvParams first
+            assert s[".size"] == 26 * 8 and s[".offset"] == (p[".size"] + 7) // 8 * 8, k[".name"]      # EnvState: 26 pointers, 8-aligned behind it
+            if k[".name"] in ("irrl_rollout_persistent_actor_wave_kernel_l16", "irrl_rollout_persistent_mlp_kernel_l16"):
+                # the kernels that take a step's PolicyStepArgs from the kernarg segment: four output pointers, then the struct
+                assert [a[".value_kind"] for a in args[2:7]] == ["global_buffer"] * 4 + ["by_value"], k[".name"]
+                assert args[6][".size"] > 200 and args[6][".offset"] == (s[".offset"] + s[".size"] + 4 * 8 + 7) // 8 * 8, k[".name"]
+                seen_policy += 1
+    assert seen_policy == 2
