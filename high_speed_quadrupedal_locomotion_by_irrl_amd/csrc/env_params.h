@@ -5,7 +5,7 @@
 // Configuration scalars the kernels need, derived from the `environment:` YAML sub-tree
 // (reference keys: Environment.hpp:1594-1659, VectorizedEnvironment.hpp:136-171).  Passed BY VALUE as
 // a kernel argument; the env kernels name it in the kernarg segment and read a field with a scalar load
-// where it is used (IRRL_BIND_ARGS, env_kernels.hip) -- 92 words + EnvState's 27 pointers do not fit the SGPRs.
+// where it is used (IRRL_BIND_ARGS, env_kernels.hip) -- 92 words + EnvState's 26 pointers do not fit the SGPRs.
 struct EnvParams {
   int32_t n_envs;
   int32_t loop_count;      // int(control_dt / simulation_dt + 1e-10), Environment.hpp:711

@@ -17,7 +17,7 @@
 // value made opaque to the optimizer (no instruction): what comes out is "some register", not the expression that produced it
 #define IRRL_OPAQUE(x) asm volatile("" : "+v"(x))
 
-// KERNEL ARGUMENTS READ WHERE THEY ARE USED (round 6).  EnvParams (92 words) + EnvState (27 pointers) + a kernel's own pointers are more than the
+// KERNEL ARGUMENTS READ WHERE THEY ARE USED (round 6).  EnvParams (92 words) + EnvState (26 pointers) + a kernel's own pointers are more than the
 // 102 SGPRs.  Read as by-value arguments, every field is an invariant load that the optimizer hoists to the kernel's entry, and what does not
 // fit is parked in VGPR lanes: a v_writelane up front and a v_readlane -- a VALU issue slot of the one resident wave -- at every use (step
 // kernel: 119 spilled SGPRs, 217 v_readlane; multi-step kernel: 217 / 605).  irrl_kernarg<T>(off) names the argument in the kernarg segment
