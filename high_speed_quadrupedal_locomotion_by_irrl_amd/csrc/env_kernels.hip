@@ -75,15 +75,17 @@ __device__ __forceinline__ int irrl_xcd_block() {
   const EnvParams &P = irrl_kernarg<EnvParams>(0);             \
   const EnvState &S = irrl_kernarg<EnvState>((unsigned)((sizeof(EnvParams) + alignof(EnvState) - 1) / alignof(EnvState) * alignof(EnvState)));
 #define IRRL_PARAMS_REFRESH(P) irrl_refresh(P)          /* once per step of the multi-step kernels */
-// the rollout kernels' PolicyStepArgs (behind P, S and the four output pointers): A0 names it, a step's own copy is taken from it per step
+// the rollout kernels' PolicyStepArgs (behind P, S and NPTR pointers): A0 names it, the multi-step kernels take a step's own copy from it per step
 #define IRRL_KERNARG_ALIGN(off, T) (((off) + alignof(T) - 1) / alignof(T) * alignof(T))
-#define IRRL_BIND_POLICY_ARGS(A0, A_)                                                                                              \
+#define IRRL_BIND_POLICY_ARGS_N(A0, A_, NPTR)                                                                                      \
   const PolicyStepArgs &A0 = irrl_kernarg<PolicyStepArgs>((unsigned)IRRL_KERNARG_ALIGN(                                            \
-      IRRL_KERNARG_ALIGN(sizeof(EnvParams), EnvState) + sizeof(EnvState) + 4 * sizeof(void *), PolicyStepArgs));
+      IRRL_KERNARG_ALIGN(sizeof(EnvParams), EnvState) + sizeof(EnvState) + (NPTR) * sizeof(void *), PolicyStepArgs));
+#define IRRL_BIND_POLICY_ARGS(A0, A_) IRRL_BIND_POLICY_ARGS_N(A0, A_, 4)
 #else
 #define IRRL_BIND_ARGS const EnvParams &P = P_; const EnvState &S = S_;
 #define IRRL_PARAMS_REFRESH(P) (P)
-#define IRRL_BIND_POLICY_ARGS(A0, A_) const PolicyStepArgs &A0 = A_;
+#define IRRL_BIND_POLICY_ARGS_N(A0, A_, NPTR) const PolicyStepArgs &A0 = A_;
+#define IRRL_BIND_POLICY_ARGS(A0, A_) IRRL_BIND_POLICY_ARGS_N(A0, A_, 4)
 #endif
 #define IRRL_LANE_PROLOGUE IRRL_LANE_PROLOGUE_B(irrl_xcd_block())          /* the stand-alone lane kernels */
 #define IRRL_LANE_PROLOGUE_IDENTITY IRRL_LANE_PROLOGUE_B((int)blockIdx.x)  /* kernels whose policy part addresses robots by blockIdx */
@@ -131,8 +133,9 @@ IRRL_K(irrl_step_kernel)(EnvParams P_, EnvState S_, const float *action, float *
 // robot, and four waves (three of them with two virtual waves of MFMA work each) take 18.5 us for what the stand-alone kernel's
 // six waves do in 14.1.  Bit-identical results; an OPTION of irrl_lstm_rollout (fuse = 1), not the default.  (HID 48, ob 35.)
 __global__ void __launch_bounds__(256, 1)
-irrl_step_policy_kernel_l16(EnvParams P_, EnvState S_, const float *action, float *ob, float *reward, uint8_t *done, float *extra, PolicyStepArgs a) {
+irrl_step_policy_kernel_l16(EnvParams P_, EnvState S_, const float *action, float *ob, float *reward, uint8_t *done, float *extra, PolicyStepArgs a_) {
   IRRL_BIND_ARGS
+  IRRL_BIND_POLICY_ARGS_N(a, a_, 5)
   __shared__ float hbuf[2][16 * 49];
   __shared__ float terms[16][17];
   __shared__ float head_w[48 * 17];
@@ -166,8 +169,9 @@ irrl_step_policy_kernel_l16(EnvParams P_, EnvState S_, const float *action, floa
 // bit-identical to the two-launch sequence.  Within a workgroup every global array is written and re-read by the same CU: the
 // vector L1 is coherent at workgroup scope (non-tgsplit), the barriers' waits on the memory counters order the accesses.
 __global__ void __launch_bounds__(256, 1)
-irrl_rollout_persistent_kernel_l16(EnvParams P_, EnvState S_, float *ob, float *reward, uint8_t *done, float *extra, PolicyStepArgs a, int steps) {
+irrl_rollout_persistent_kernel_l16(EnvParams P_, EnvState S_, float *ob, float *reward, uint8_t *done, float *extra, PolicyStepArgs a_, int steps) {
   IRRL_BIND_ARGS
+  IRRL_BIND_POLICY_ARGS(a, a_)
   __shared__ float hbuf[2][16 * 49];
   __shared__ float terms[16][17];
   __shared__ float head_w[48 * 17];
@@ -188,10 +192,11 @@ irrl_rollout_persistent_kernel_l16(EnvParams P_, EnvState S_, float *ob, float *
     // optimizer, the loop-invariant addresses of both parts -- hundreds of 64-bit values -- are hoisted and spilled)
     int tid = (int)threadIdx.x;
     asm volatile("" : "+v"(tid));
-    a.row = row0 + k; a.rng_step = rng0 + k;
-    a.noise = noise0 ? noise0 + (size_t)k * noise_stride : nullptr;
-    a.states_in = k == 0 ? states_first : a.states_out;
-    policy_step_body<48, 9, 2, 256, true>(a, (int)blockIdx.x * 16, hbuf, terms, head_w, lds_w, 0, 0, tid);
+    PolicyStepArgs ak = IRRL_PARAMS_REFRESH(a);
+    ak.row = row0 + k; ak.rng_step = rng0 + k;
+    ak.noise = noise0 ? noise0 + (size_t)k * noise_stride : nullptr;
+    ak.states_in = k == 0 ? states_first : a.states_out;
+    policy_step_body<48, 9, 2, 256, true>(ak, (int)blockIdx.x * 16, hbuf, terms, head_w, lds_w, 0, 0, tid);
     IRRL_PP_STAMP(0);   // policy step
     __syncthreads();   // this workgroup's clipped actions (and the rollout rows) are stored and visible to its own loads
     IRRL_PP_STAMP(1);   // barrier behind the policy step
@@ -202,7 +207,7 @@ irrl_rollout_persistent_kernel_l16(EnvParams P_, EnvState S_, float *ob, float *
       const int leg_ = (lane_ >> 2) & 3;
       const bool valid_ = (env_ < P.n_envs) && ((lane_ & 3) == 0);
       if (env_ >= P.n_envs) env_ = P.n_envs - 1;
-      irrl_plain::step_body<1>(IRRL_PARAMS_REFRESH(P), IRRL_PARAMS_REFRESH(S), env_, leg_, valid_, (const float *)a.clipped, ob, reward, done, extra);
+      irrl_plain::step_body<1>(IRRL_PARAMS_REFRESH(P), IRRL_PARAMS_REFRESH(S), env_, leg_, valid_, (const float *)ak.clipped, ob, reward, done, extra);
     }
     IRRL_PP_STAMP(2);   // env step of this wave's four robots
     __syncthreads();   // obs / dones / reward of step k are stored and visible: the next policy step reads them
@@ -226,8 +231,9 @@ irrl_rollout_persistent_kernel_l16(EnvParams P_, EnvState S_, float *ob, float *
 // once.  Same device functions and per-element arithmetic as the full kernel above: actions, clipped actions, neglogp, observations,
 // rewards, dones and the actor's LSTM state are bit-identical to every other rollout mode; `value` / `mb_values` are not written.
 __global__ void __launch_bounds__(256, 1)
-irrl_rollout_persistent_actor_kernel_l16(EnvParams P_, EnvState S_, float *ob, float *reward, uint8_t *done, float *extra, PolicyStepArgs a, int steps) {
+irrl_rollout_persistent_actor_kernel_l16(EnvParams P_, EnvState S_, float *ob, float *reward, uint8_t *done, float *extra, PolicyStepArgs a_, int steps) {
   IRRL_BIND_ARGS
+  IRRL_BIND_POLICY_ARGS(a, a_)
   __shared__ float hbuf[2][16 * 49];
   __shared__ float terms[16][17];
   __shared__ float head_w[48 * 17];
@@ -252,19 +258,20 @@ irrl_rollout_persistent_actor_kernel_l16(EnvParams P_, EnvState S_, float *ob, f
   for (int k = 0; k < steps; k++) {
     int tid = (int)threadIdx.x;
     asm volatile("" : "+v"(tid));     // (see irrl_rollout_persistent_kernel_l16: keeps the per-lane addresses inside the loop)
-    a.row = row0 + k; a.rng_step = rng0 + k;
-    a.noise = noise0 ? noise0 + (size_t)k * noise_stride : nullptr;
-    a.states_in = k == 0 ? states_first : a.states_out;
-    policy_step_body<48, 9, 1, 256, true, true>(a, (int)blockIdx.x * 16, hbuf, terms, head_w, lds_w, 0, 0, tid);
+    PolicyStepArgs ak = IRRL_PARAMS_REFRESH(a);
+    ak.row = row0 + k; ak.rng_step = rng0 + k;
+    ak.noise = noise0 ? noise0 + (size_t)k * noise_stride : nullptr;
+    ak.states_in = k == 0 ? states_first : a.states_out;
+    policy_step_body<48, 9, 1, 256, true, true>(ak, (int)blockIdx.x * 16, hbuf, terms, head_w, lds_w, 0, 0, tid);
     __syncthreads();   // this workgroup's clipped actions (and the rollout rows) are stored and visible to its own loads
     {
       int env_ = env0_;
       asm volatile("" : "+v"(env_));
 #ifndef IRRL_ACTOR_NO_CARRY
       if (k > 0) irrl_plain::lane_carry(L);
-      irrl_plain::step_compute<1>(IRRL_PARAMS_REFRESH(P), L, env_, leg0_, valid0_, irrl_plain::ActionRow{(const float *)a.clipped}, ob, reward, done, extra);
+      irrl_plain::step_compute<1>(IRRL_PARAMS_REFRESH(P), L, env_, leg0_, valid0_, irrl_plain::ActionRow{(const float *)ak.clipped}, ob, reward, done, extra);
 #else
-      irrl_plain::step_body<1>(IRRL_PARAMS_REFRESH(P), IRRL_PARAMS_REFRESH(S), env_, leg0_, valid0_, (const float *)a.clipped, ob, reward, done, extra);
+      irrl_plain::step_body<1>(IRRL_PARAMS_REFRESH(P), IRRL_PARAMS_REFRESH(S), env_, leg0_, valid0_, (const float *)ak.clipped, ob, reward, done, extra);
 #endif
     }
     __syncthreads();   // obs / dones / reward of step k are stored and visible: the next policy step reads them

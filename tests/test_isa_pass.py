@@ -143,9 +143,12 @@ def test_kernarg_offsets_the_kernels_assume_are_the_ones_the_compiler_laid_out()
             p, s = args[0], args[1]
             assert p[".offset"] == 0 and p[".size"] % 4 == 0 and p[".size"] >= 92 * 4, k[".name"]       # EnvParams first
             assert s[".size"] == 26 * 8 and s[".offset"] == (p[".size"] + 7) // 8 * 8, k[".name"]      # EnvState: 26 pointers, 8-aligned behind it
-            if k[".name"] in ("irrl_rollout_persistent_actor_wave_kernel_l16", "irrl_rollout_persistent_mlp_kernel_l16"):
-                # the kernels that take a step's PolicyStepArgs from the kernarg segment: four output pointers, then the struct
-                assert [a[".value_kind"] for a in args[2:7]] == ["global_buffer"] * 4 + ["by_value"], k[".name"]
-                assert args[6][".size"] > 200 and args[6][".offset"] == (s[".offset"] + s[".size"] + 4 * 8 + 7) // 8 * 8, k[".name"]
+            nptr = {"irrl_rollout_persistent_actor_wave_kernel_l16": 4, "irrl_rollout_persistent_mlp_kernel_l16": 4, "irrl_rollout_persistent_kernel_l16": 4,
+                    "irrl_rollout_persistent_actor_kernel_l16": 4, "irrl_step_policy_kernel_l16": 5}.get(k[".name"])
+            if nptr:
+                # the kernels that read PolicyStepArgs from the kernarg segment: `nptr` pointers behind EnvState, then the struct
+                assert [a[".value_kind"] for a in args[2:3 + nptr]] == ["global_buffer"] * nptr + ["by_value"], k[".name"]
+                pa = args[2 + nptr]
+                assert pa[".size"] > 200 and pa[".offset"] == (s[".offset"] + s[".size"] + nptr * 8 + 7) // 8 * 8, k[".name"]
                 seen_policy += 1
-    assert seen_policy == 2
+    assert seen_policy == 5
