@@ -21,6 +21,7 @@ SIGNATURES = {
     "irrl_env_set_stream": (C.c_int, [vp, vp]),
     "irrl_env_num_envs": (C.c_int, [vp]),
     "irrl_env_lanes_per_robot": (C.c_int, [vp]),
+    "irrl_env_waves_per_simd": (C.c_int, [vp]),
     "irrl_env_ob_dim": (C.c_int, [vp]),
     "irrl_env_action_dim": (C.c_int, [vp]),
     "irrl_env_extra_dim": (C.c_int, [vp]),

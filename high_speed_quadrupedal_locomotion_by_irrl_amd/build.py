@@ -93,6 +93,10 @@ COMMON_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unu
 # max-memory-clause 31.9, iterative-maxocc 31.6-31.7, the default 31.6, iterative-minreg 33.1, iterative-ilp 31.1-31.5 (profiles/r06_ab_env_sched_strategy_same_box.log).
 # Scheduling only: results bit-identical.
 ENV_FLAGS = ["-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
+# the 4-lane layout's build for two waves per SIMD (env_kernels.hip: _l4w2, pools of more than 16 384 robots): 256 registers per wave, so the
+# strategy that schedules for register pressure first measures best there -- 131 072 envs 483 -> 490 M env-steps/s, 32 768 envs 450 -> 454 M
+# (iterative-minreg 488 / 454, the default 484 / 448; profiles/r06_ab_l4_two_waves_per_simd_same_box.log)
+ENV_FLAGS_W2 = ["-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"]
 
 
 def llvm_bin():
@@ -145,7 +149,7 @@ def source_hash(extra_flags=(), csrc=None, header=None):
         h.update(b"\0")
     with open(header or HEADER, "rb") as f:
         h.update(b"irrl_env.h\0" + f.read())
-    h.update(("\0".join(COMMON_FLAGS + ["|"] + ENV_FLAGS + ["|"] + list(extra_flags))).encode())
+    h.update(("\0".join(COMMON_FLAGS + ["|"] + ENV_FLAGS + ["|"] + ENV_FLAGS_W2 + ["|"] + list(extra_flags))).encode())
     return h.hexdigest()[:16]
 
 
@@ -176,10 +180,11 @@ def build(force=False, verbose=False, extra_flags=()):
     common = COMMON_FLAGS + list(extra_flags)
     objdir = os.path.join(_HERE, "csrc", "_obj")
     os.makedirs(objdir, exist_ok=True)
-    # the env kernels in both lane layouts (same source, different lane-primitive header) through the ISA pass, then the
-    # C-ABI + LSTM kernels through the plain driver
+    # the env kernels in both lane layouts (same source, different lane-primitive header; the 4-lane layout once more for two waves per
+    # SIMD) through the ISA pass, then the C-ABI + LSTM kernels through the plain driver
     units = [("env_kernels.hip", ["-DIRRL_LANES_PER_ROBOT=16"] + ENV_FLAGS, "env_kernels_l16.o"),
              ("env_kernels.hip", ["-DIRRL_LANES_PER_ROBOT=4"] + ENV_FLAGS, "env_kernels_l4.o"),
+             ("env_kernels.hip", ["-DIRRL_LANES_PER_ROBOT=4", "-DIRRL_L4_WAVES2"] + ENV_FLAGS_W2, "env_kernels_l4w2.o"),
              ("irrl_env_abi.hip", ['-DIRRL_SRC_HASH="%s"' % want], "irrl_env_abi.o")]
     from concurrent.futures import ThreadPoolExecutor
     def one(u):
@@ -191,7 +196,7 @@ def build(force=False, verbose=False, extra_flags=()):
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
-    with ThreadPoolExecutor(3) as ex:
+    with ThreadPoolExecutor(4) as ex:
         list(ex.map(one, units))
     link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + [os.path.join(objdir, u[2]) for u in units] + ["-o", LIB]
     if verbose:

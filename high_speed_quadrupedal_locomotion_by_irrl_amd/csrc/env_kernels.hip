@@ -28,9 +28,15 @@
 #include "policy_step.hpp"   // the LSTM policy's rollout step (device code shared with lstm_kernels.hip)
 #endif
 
-// This file is compiled twice (build.py): once per lane layout, kernel names suffixed _l16 / _l4.
+// This file is compiled three times (build.py): once per lane layout, kernel names suffixed _l16 / _l4, and the 4-lane layout once more for
+// TWO waves per SIMD (_l4w2, -DIRRL_L4_WAVES2: 256 registers per wave, ~130-220 of the step kernels' values in scratch).  Pools of more than
+// 16 384 robots are more 4-lane waves than the chip has SIMDs; two resident waves issue 1.35 x what one does (HISTORY.md Appendix C, 2a), which
+// pays for the spills: 32 768 envs 394 -> 450 M env-steps/s, 131 072 envs 394 -> 482 M, 16 384 envs (one wave per SIMD either way) 393 -> 386 M
+// -- the launcher takes _l4w2 above 16 384 robots only (profiles/r06_ab_l4_two_waves_per_simd_same_box.log).  Same source, same arithmetic.
 #if IRRL_LANES_PER_ROBOT == 16
 #define IRRL_K(name) name##_l16
+#elif defined(IRRL_L4_WAVES2)
+#define IRRL_K(name) name##_l4w2
 #else
 #define IRRL_K(name) name##_l4
 #endif
@@ -90,6 +96,13 @@ __device__ __forceinline__ int irrl_xcd_block() {
 #define IRRL_LANE_PROLOGUE IRRL_LANE_PROLOGUE_B(irrl_xcd_block())          /* the stand-alone lane kernels */
 #define IRRL_LANE_PROLOGUE_IDENTITY IRRL_LANE_PROLOGUE_B((int)blockIdx.x)  /* kernels whose policy part addresses robots by blockIdx */
 
+// one wave per SIMD and its whole register file -- or (_l4w2, above) two waves per SIMD at 256 registers each
+#if defined(IRRL_L4_WAVES2) && IRRL_LANES_PER_ROBOT == 4
+#define IRRL_ENV_BOUNDS __launch_bounds__(256, 2)
+#else
+#define IRRL_ENV_BOUNDS __launch_bounds__(256, 1)
+#endif
+
 extern "C" {
 
 // The step kernel exists once per (Crutial, per-contact rule): the launcher picks by EnvParams::crutial / ::contact_rule.  Suffix
@@ -97,7 +110,7 @@ extern "C" {
 // first sliding rule.  (One kernel deciding by a run-time flag cost the OTHER rule's path 6 us of a 37 us step: both rules'
 // per-substep constants were live across the sweep loop and the allocator paid for them in AGPR copies.)
 #define IRRL_STEP_KERNEL(NAME, NS, RULE)                                                                                           \
-  __global__ void __launch_bounds__(256, 1)                                                                                        \
+  __global__ void IRRL_ENV_BOUNDS                                                                                        \
   IRRL_K(NAME)(EnvParams P_, EnvState S_, const float *action, float *ob, float *reward, uint8_t *done, float *extra) {             \
     IRRL_BIND_ARGS                                                                                                                 \
     IRRL_LANE_PROLOGUE                                                                                                             \
@@ -108,7 +121,7 @@ IRRL_STEP_KERNEL(irrl_step_kernel_crutial_md, irrl, 1)
 IRRL_STEP_KERNEL(irrl_step_kernel_dir, irrl_plain, 0)
 
 // the default pool: no meteorite, published rule
-__global__ void __launch_bounds__(256, 1)
+__global__ void IRRL_ENV_BOUNDS
 IRRL_K(irrl_step_kernel)(EnvParams P_, EnvState S_, const float *action, float *ob, float *reward, uint8_t *done, float *extra) {
   IRRL_BIND_ARGS
   IRRL_LANE_PROLOGUE
@@ -132,7 +145,7 @@ IRRL_K(irrl_step_kernel)(EnvParams P_, EnvState S_, const float *action, float *
 // tools/rollout_phases.py): the launch ends with its slowest workgroup, which pays the whole policy part behind its slowest
 // robot, and four waves (three of them with two virtual waves of MFMA work each) take 18.5 us for what the stand-alone kernel's
 // six waves do in 14.1.  Bit-identical results; an OPTION of irrl_lstm_rollout (fuse = 1), not the default.  (HID 48, ob 35.)
-__global__ void __launch_bounds__(256, 1)
+__global__ void IRRL_ENV_BOUNDS
 irrl_step_policy_kernel_l16(EnvParams P_, EnvState S_, const float *action, float *ob, float *reward, uint8_t *done, float *extra, PolicyStepArgs a_) {
   IRRL_BIND_ARGS
   IRRL_BIND_POLICY_ARGS_N(a, a_, 5)
@@ -168,7 +181,7 @@ irrl_step_policy_kernel_l16(EnvParams P_, EnvState S_, const float *action, floa
 // step is the fused kernel's above (same device functions, same order): obs / dones / states / clipped actions / rollout rows are
 // bit-identical to the two-launch sequence.  Within a workgroup every global array is written and re-read by the same CU: the
 // vector L1 is coherent at workgroup scope (non-tgsplit), the barriers' waits on the memory counters order the accesses.
-__global__ void __launch_bounds__(256, 1)
+__global__ void IRRL_ENV_BOUNDS
 irrl_rollout_persistent_kernel_l16(EnvParams P_, EnvState S_, float *ob, float *reward, uint8_t *done, float *extra, PolicyStepArgs a_, int steps) {
   IRRL_BIND_ARGS
   IRRL_BIND_POLICY_ARGS(a, a_)
@@ -230,7 +243,7 @@ irrl_rollout_persistent_kernel_l16(EnvParams P_, EnvState S_, float *ob, float *
 // layer-0 operands now holds the actor's layer-1 operands -- NO weight fetched from L2 inside the step loop; the head weights are staged
 // once.  Same device functions and per-element arithmetic as the full kernel above: actions, clipped actions, neglogp, observations,
 // rewards, dones and the actor's LSTM state are bit-identical to every other rollout mode; `value` / `mb_values` are not written.
-__global__ void __launch_bounds__(256, 1)
+__global__ void IRRL_ENV_BOUNDS
 irrl_rollout_persistent_actor_kernel_l16(EnvParams P_, EnvState S_, float *ob, float *reward, uint8_t *done, float *extra, PolicyStepArgs a_, int steps) {
   IRRL_BIND_ARGS
   IRRL_BIND_POLICY_ARGS(a, a_)
@@ -294,7 +307,7 @@ irrl_rollout_persistent_actor_kernel_l16(EnvParams P_, EnvState S_, float *ob, f
 // the whole rollout, and hands observations / reward / done flag / clipped actions between its env step and its policy step through that
 // scratch next to the stores to memory -- no workgroup barrier and no load behind a store inside the step loop.  Actions, neglogp,
 // observations, rewards, dones and the actor's final LSTM state are bit-identical to every other rollout mode.
-__global__ void __launch_bounds__(256, 1)
+__global__ void IRRL_ENV_BOUNDS
 irrl_rollout_persistent_actor_wave_kernel_l16(EnvParams P_, EnvState S_, float *ob, float *reward, uint8_t *done, float *extra, PolicyStepArgs a_, int steps) {
   IRRL_BIND_ARGS
   IRRL_BIND_POLICY_ARGS(a, a_)
@@ -395,7 +408,7 @@ irrl_rollout_persistent_actor_wave_kernel_l16(EnvParams P_, EnvState S_, float *
 // against 8.7 us for the stand-alone launch, whose life is launch + weight fetch), and a step costs a WAVE its own time instead of the slowest
 // of the 1024 env waves: since the second half of round 5 the policy of a wave's four robots is that wave's own work (see inside).
 // Same device functions, same order: the buffers are bit-identical to the two-launch sequence.
-__global__ void __launch_bounds__(256, 1)
+__global__ void IRRL_ENV_BOUNDS
 irrl_rollout_persistent_mlp_kernel_l16(EnvParams P_, EnvState S_, float *ob, float *reward, uint8_t *done, float *extra, PolicyStepArgs a_, int steps) {
   IRRL_BIND_ARGS
   IRRL_BIND_POLICY_ARGS(a, a_)
@@ -473,7 +486,7 @@ irrl_rollout_persistent_mlp_kernel_l16(EnvParams P_, EnvState S_, float *ob, flo
 // behind a round trip of ~90 stores and ~90 loads per lane through the L2.  The body of a step is the step kernel's (step_compute, same
 // order): states and outputs are bit-identical to `count` launches.  Default pool kind only (no meteorite, published rule); the launcher
 // falls back otherwise.
-__global__ void __launch_bounds__(256, 1)
+__global__ void IRRL_ENV_BOUNDS
 IRRL_K(irrl_steps_persistent_kernel)(EnvParams P_, EnvState S_, const float *action_rows, int n_rows, int first_row, int count, float *ob, float *reward,
                                      uint8_t *done, float *extra, int out_rows) {
   IRRL_BIND_ARGS
@@ -524,25 +537,25 @@ IRRL_K(irrl_steps_persistent_kernel)(EnvParams P_, EnvState S_, const float *act
   }
 }
 
-__global__ void __launch_bounds__(256, 1) IRRL_K(irrl_init_kernel)(EnvParams P_, EnvState S_) {
+__global__ void IRRL_ENV_BOUNDS IRRL_K(irrl_init_kernel)(EnvParams P_, EnvState S_) {
   IRRL_BIND_ARGS
   IRRL_LANE_PROLOGUE
   irrl::init_body(P, S, env_, leg_, valid_);
 }
 
-__global__ void __launch_bounds__(256, 1) IRRL_K(irrl_reset_kernel)(EnvParams P_, EnvState S_, float *ob) {
+__global__ void IRRL_ENV_BOUNDS IRRL_K(irrl_reset_kernel)(EnvParams P_, EnvState S_, float *ob) {
   IRRL_BIND_ARGS
   IRRL_LANE_PROLOGUE
   irrl::reset_body(P, S, env_, leg_, valid_, ob);
 }
 
-__global__ void __launch_bounds__(256, 1) IRRL_K(irrl_observe_kernel)(EnvParams P_, EnvState S_, float *ob) {
+__global__ void IRRL_ENV_BOUNDS IRRL_K(irrl_observe_kernel)(EnvParams P_, EnvState S_, float *ob) {
   IRRL_BIND_ARGS
   IRRL_LANE_PROLOGUE
   irrl::observe_body(P, S, env_, leg_, valid_, ob);
 }
 
-__global__ void __launch_bounds__(256, 1) IRRL_K(irrl_probe_kernel)(EnvParams P_, EnvState S_, float *minv, float *nonlin) {
+__global__ void IRRL_ENV_BOUNDS IRRL_K(irrl_probe_kernel)(EnvParams P_, EnvState S_, float *minv, float *nonlin) {
   IRRL_BIND_ARGS
   IRRL_LANE_PROLOGUE
   irrl::dynamics_probe_body(P, S, env_, leg_, valid_, minv, nonlin);

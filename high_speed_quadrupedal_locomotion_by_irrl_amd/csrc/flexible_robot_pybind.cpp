@@ -195,6 +195,7 @@ class VecEnv {
     check(irrl_env_set_state_host(h_, st.data()));
   }
   int lanes_per_robot() const { return irrl_env_lanes_per_robot(h_); }
+  int waves_per_simd() const { return irrl_env_waves_per_simd(h_); }
   size_t handle() const { return reinterpret_cast<size_t>(h_); }
 
  private:
@@ -242,5 +243,6 @@ PYBIND11_MODULE(_flexible_robot, m) {
       .def("get_state", &VecEnv::get_state)
       .def("set_state", &VecEnv::set_state, nc("state"))
       .def_property_readonly("lanes_per_robot", &VecEnv::lanes_per_robot)
+      .def_property_readonly("waves_per_simd", &VecEnv::waves_per_simd)
       .def_property_readonly("handle", &VecEnv::handle);
 }

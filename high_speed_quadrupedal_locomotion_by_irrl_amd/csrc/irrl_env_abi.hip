@@ -17,6 +17,7 @@
 //   _l16  16 lanes per robot (lanes_hip16.hpp): 4 robots per wave -- fills all 1024 SIMDs at 4096 robots, shortest step
 //   _l4    4 lanes per robot (lanes_hip.hpp):  16 robots per wave -- 2.3x fewer instructions per robot, the better
 //          throughput once the pool is large enough to occupy the chip on its own
+//   _l4w2  the same, compiled for two waves per SIMD (256 registers each): pools with more 4-lane waves than SIMDs (> 16 384 robots)
 #define IRRL_DECLARE_KERNELS(sfx)                                                                                            \
   extern "C" __global__ void irrl_step_kernel##sfx(EnvParams, EnvState, const float *, float *, float *, uint8_t *, float *);   \
   extern "C" __global__ void irrl_step_kernel_dir##sfx(EnvParams, EnvState, const float *, float *, float *, uint8_t *, float *); \
@@ -29,6 +30,7 @@
   extern "C" __global__ void irrl_probe_kernel##sfx(EnvParams, EnvState, float *, float *);
 IRRL_DECLARE_KERNELS(_l16)
 IRRL_DECLARE_KERNELS(_l4)
+IRRL_DECLARE_KERNELS(_l4w2)
 extern "C" __global__ void irrl_terminal_kernel(EnvParams, EnvState, uint8_t *);
 extern "C" __global__ void irrl_step_policy_kernel_l16(EnvParams, EnvState, const float *, float *, float *, uint8_t *, float *, PolicyStepArgs);
 extern "C" __global__ void irrl_rollout_persistent_kernel_l16(EnvParams, EnvState, float *, float *, uint8_t *, float *, PolicyStepArgs, int);
@@ -78,6 +80,7 @@ struct irrl_env {
   size_t pinned_bytes = 0;
   bool initialised = false;
   int lanes = 16;  // lanes per robot of the kernels this pool launches (16 or 4)
+  int waves2 = 0;  // 4-lane layout only: launch the kernels compiled for two waves per SIMD (_l4w2)
   std::string resource_dir;
 };
 
@@ -102,9 +105,19 @@ static int pick_lanes(int n_envs) {
   if (e) { int v = atoi(e); if (v == 4 || v == 16) return v; }
   return (n_envs <= 6144) ? 16 : 4;
 }
+// 4-lane pools: two waves per SIMD once there are more waves than SIMDs (16 robots per wave, 4 SIMDs per CU); IRRL_L4_WAVES=1|2 overrides
+// (used by the tests to run the _l4w2 kernels on small pools)
+static int pick_waves2(int n_envs, int device) {
+  const char *e = getenv("IRRL_L4_WAVES");
+  if (e) { int v = atoi(e); if (v == 1 || v == 2) return v == 2; }
+  int cus = 256;
+  hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+  return (n_envs + 15) / 16 > cus * 4;
+}
 #define IRRL_LAUNCH(h, name, grid, ...)                                                                                   \
   do {                                                                                                                    \
     if ((h)->lanes == 16) hipLaunchKernelGGL(name##_l16, grid, quad_block(), 0, (h)->stream, __VA_ARGS__);                 \
+    else if ((h)->waves2) hipLaunchKernelGGL(name##_l4w2, grid, quad_block(), 0, (h)->stream, __VA_ARGS__);                \
     else hipLaunchKernelGGL(name##_l4, grid, quad_block(), 0, (h)->stream, __VA_ARGS__);                                   \
   } while (0)
 
@@ -149,6 +162,7 @@ irrl_env *irrl_env_create(const char *resource_dir, const char *cfg_yaml, int de
   if (!h->cfg.parse(cfg_yaml, g_err) || !irrl_host::build_params(h->cfg, h->P, g_err)) { delete h; return nullptr; }
   h->pool = irrl_host::StatePool(h->P.n_envs);
   h->lanes = pick_lanes(h->P.n_envs);
+  h->waves2 = (h->lanes == 4) ? pick_waves2(h->P.n_envs, device) : 0;
   const size_t n = (size_t)h->P.n_envs;
   bool ok = hipSetDevice(device) == hipSuccess && hipMalloc(&h->d_pool, h->pool.bytes) == hipSuccess &&
             hipMemset(h->d_pool, 0, h->pool.bytes) == hipSuccess && hipMalloc((void **)&h->d_action, n * 12 * 4) == hipSuccess &&
@@ -235,6 +249,7 @@ int irrl_env_init(irrl_env *h) {
 
 int irrl_env_num_envs(const irrl_env *h) { return h->P.n_envs; }
 int irrl_env_lanes_per_robot(const irrl_env *h) { return h->lanes; }
+int irrl_env_waves_per_simd(const irrl_env *h) { return h->waves2 ? 2 : 1; }
 int irrl_env_ob_dim(const irrl_env *) { return IRRL_OB_DIM; }
 int irrl_env_action_dim(const irrl_env *) { return IRRL_ACTION_DIM; }
 int irrl_env_extra_dim(const irrl_env *) { return IRRL_EXTRA_DIM; }

@@ -82,6 +82,10 @@ class FlexibleGymEnv(object):
     def lanes_per_robot(self):
         return self._lib.irrl_env_lanes_per_robot(self._h)
 
+    @property
+    def waves_per_simd(self):
+        return self._lib.irrl_env_waves_per_simd(self._h)
+
     # -- raisim_gym.cpp:17-46 --
     def init(self):
         _lib.check(self._lib.irrl_env_init(self._h))

@@ -297,10 +297,58 @@ def test_both_lane_layouts_match_oracle_on_gpu(lanes, monkeypatch):
 
 def test_layout_is_chosen_by_pool_size(monkeypatch):
     monkeypatch.delenv("IRRL_LANES_PER_ROBOT", raising=False)
-    assert _hip(load_env_cfg("default_cfg.yaml", num_envs=4096)).impl.lanes_per_robot == 16
+    monkeypatch.delenv("IRRL_L4_WAVES", raising=False)
+    small = _hip(load_env_cfg("default_cfg.yaml", num_envs=4096)).impl
+    assert small.lanes_per_robot == 16 and small.waves_per_simd == 1
     big = _hip(load_env_cfg("default_cfg.yaml", num_envs=16384))
-    assert big.impl.lanes_per_robot == 4
+    assert big.impl.lanes_per_robot == 4 and big.impl.waves_per_simd == 1      # 1024 waves of 16 robots = one per SIMD of the MI355X
     PL.check_invariants(big, steps=20)
+    bigger = _hip(load_env_cfg("default_cfg.yaml", num_envs=16400))
+    assert bigger.impl.lanes_per_robot == 4 and bigger.impl.waves_per_simd == 2  # more waves than SIMDs: the two-waves-per-SIMD build
+    PL.check_invariants(bigger, steps=20)
+
+
+@pytest.mark.parametrize("name,extra", [("default_cfg.yaml", {}), ("bp5_terrain.yaml", {}), ("bp5_imitation.yaml", {"Crutial": True, "CubeNum": 3, "period": 0.05}),
+                                        ("bp5_imitation.yaml", {"ContactSolver": 0})])
+def test_the_two_waves_per_simd_build_of_the_4_lane_kernels_equals_the_one_wave_build_bit_for_bit(name, extra, monkeypatch):
+    """Pools of more than 16 384 robots launch the 4-lane kernels compiled for two resident waves per SIMD (`_l4w2`: 256 registers per wave,
+    130-220 values of the step kernels in scratch).  Same source, same arithmetic (-ffp-contract=on): forced onto a small pool
+    (IRRL_L4_WAVES), every step's outputs and the final pool equal the one-wave build's bit for bit -- one launch per step and the
+    multi-step launch, noise, forced resets through falls, rough ground with per-episode randomisation, the meteorite, the other solver."""
+    import torch
+    monkeypatch.setenv("IRRL_LANES_PER_ROBOT", "4")
+    n, steps = 80, 90
+    rng = np.random.default_rng(11)
+    acts = np.clip(0.6 * rng.standard_normal((steps, n, 12)), -1, 1).astype(np.float32)
+    res = {}
+    for waves in (1, 2):
+        monkeypatch.setenv("IRRL_L4_WAVES", str(waves))
+        env = _hip(load_env_cfg(name, num_envs=n, **extra))
+        assert env.impl.lanes_per_robot == 4 and env.impl.waves_per_simd == waves
+        env.reset()
+        outs = []
+        for k, a in enumerate(acts[:steps // 2]):                              # one launch per step (host boundary)
+            if k % 6 == 5:                                                     # some robots below the termination height (ENV:1560): in-step resets
+                st = env.get_state()
+                st[k % n::9, PL.S["GC"] + 2] = 0.14
+                env.set_state(st)
+            outs.append(env.step(a))
+        st = env.get_state()
+        st[3::11, PL.S["GC"] + 2] = 0.14                                       # ... and inside the multi-step launch
+        env.set_state(st)
+        ob = torch.zeros(steps - steps // 2, n, 35, device="cuda"); rew = torch.zeros(steps - steps // 2, n, device="cuda")
+        done = torch.zeros(steps - steps // 2, n, dtype=torch.bool, device="cuda"); ext = torch.zeros(steps - steps // 2, n, 6, device="cuda")
+        table = torch.from_numpy(acts[steps // 2:]).cuda()
+        env.impl.step_rows(steps - steps // 2, table, 0, ob, rew, done, ext, persistent=True)   # the multi-step kernel
+        torch.cuda.synchronize()
+        res[waves] = (outs, ob.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy(), ext.cpu().numpy(), env.get_state())
+    a, b = res[1], res[2]
+    assert sum(int(o[2].sum()) for o in a[0]) + int(a[3].sum()) > 0            # episodes did end on the way
+    for (o1, o2) in zip(a[0], b[0]):
+        for x, y in zip(o1, o2):
+            assert np.array_equal(x, y)
+    for x, y in zip(a[1:], b[1:]):
+        assert np.array_equal(x, y)
 
 
 def test_reference_trajectory_mode_from_csv(tmp_path):

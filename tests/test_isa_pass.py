@@ -93,14 +93,14 @@ def test_verifier_fails_closed():
 
 
 def test_verifier_on_the_real_env_kernel_assembly_of_both_lane_layouts():
-    """the assembly the product library was built from (csrc/_obj/env_kernels_l{16,4}.s): every DPP instruction of every kernel
+    """the assembly the product library was built from (csrc/_obj/env_kernels_l{16,4,4w2}.s): every DPP instruction of every kernel
     -- hand-placed and compiler-generated -- is hazard-free; the same assembly without its wait states is not"""
     import pytest
     build.build()
-    if not all(os.path.exists(os.path.join(build.CSRC, "_obj", "env_kernels_l%d.s" % l)) for l in (16, 4)):
+    if not all(os.path.exists(os.path.join(build.CSRC, "_obj", "env_kernels_l%s.s" % l)) for l in (16, 4, "4w2")):
         build.build(force=True)
-    for lanes, min_dpp in ((16, 2000), (4, 1000)):
-        fixed = open(os.path.join(build.CSRC, "_obj", "env_kernels_l%d.s" % lanes)).readlines()
+    for lanes, min_dpp in ((16, 2000), (4, 1000), ("4w2", 1000)):
+        fixed = open(os.path.join(build.CSRC, "_obj", "env_kernels_l%s.s" % lanes)).readlines()
         assert isa_pass.verify(fixed) >= min_dpp
     # ... and the verifier does see a hazard in that assembly once the wait states are taken out again (the compiler's raw output itself may or
     # may not need any of the pass's: that depends on where its scheduler happens to put the hand-placed instructions)
@@ -126,11 +126,11 @@ def test_kernarg_offsets_the_kernels_assume_are_the_ones_the_compiler_laid_out()
     put them -- checked for every kernel of both lane layouts in the assembly the product library was built from."""
     import yaml
     build.build()
-    if not all(os.path.exists(os.path.join(build.CSRC, "_obj", "env_kernels_l%d.s" % l)) for l in (16, 4)):
+    if not all(os.path.exists(os.path.join(build.CSRC, "_obj", "env_kernels_l%s.s" % l)) for l in (16, 4, "4w2")):
         build.build(force=True)
     seen_policy = 0
-    for lanes in (16, 4):
-        lines = open(os.path.join(build.CSRC, "_obj", "env_kernels_l%d.s" % lanes)).read().split("\n")
+    for lanes in (16, 4, "4w2"):
+        lines = open(os.path.join(build.CSRC, "_obj", "env_kernels_l%s.s" % lanes)).read().split("\n")
         a = next(i for i, l in enumerate(lines) if l.strip() == ".amdgpu_metadata")
         b = next(i for i, l in enumerate(lines) if l.strip() == ".end_amdgpu_metadata")
         meta = yaml.safe_load("\n".join(lines[a + 1:b]))

@@ -12,6 +12,7 @@ for spec in sys.argv[1:]:
     objs = []
     # "envsched:<strategy>" replaces the env kernels' scheduling strategy (build.ENV_FLAGS: iterative-ilp); "envnosched" drops it
     env_flags = list(B.ENV_FLAGS)
+    swapped = any(f.startswith("envsched:") or f == "envnosched" for f in flags)    # (then the two-waves unit takes the same strategy as the others)
     for f in list(flags):
         if f.startswith("envsched:"):
             flags.remove(f)
@@ -24,6 +25,7 @@ for spec in sys.argv[1:]:
     B_ENV = env_flags
     common = list(B.COMMON_FLAGS) + flags
     for src, fl, obj in (("env_kernels.hip", ["-DIRRL_LANES_PER_ROBOT=16"] + B_ENV, "l16"), ("env_kernels.hip", ["-DIRRL_LANES_PER_ROBOT=4"] + B_ENV, "l4"),
+                         ("env_kernels.hip", ["-DIRRL_LANES_PER_ROBOT=4", "-DIRRL_L4_WAVES2"] + (B_ENV if swapped else list(B.ENV_FLAGS_W2)), "l4w2"),
                          ("irrl_env_abi.hip", [], "abi")):
         o = os.path.join(out, f"{name}_{obj}.o")
         objs.append(o)
