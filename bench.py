@@ -495,7 +495,7 @@ def worker(args):
                                    "%d-step untimed pre-roll before the warm-up, %d more untimed steps straight in front of the bracket's opening synchronize"
                                    % (n, args.cfg, (" with " + ", ".join(args.set)) if args.set else "", preroll, HOT_STEPS),
                        "envs_per_gpu": n, "global_envs": n * world, "parallelism": "env-sharded x%d" % world,
-                       "lanes_per_robot": env.lanes_per_robot, "preroll": preroll, "hot_steps_before_bracket": HOT_STEPS,
+                       "lanes_per_robot": env.lanes_per_robot, "waves_per_simd": env.waves_per_simd, "preroll": preroll, "hot_steps_before_bracket": HOT_STEPS,
                        "launch": mode,
                        "launch_what": {"persistent": "ONE launch: every wave walks its own robots through the %d steps (irrl_env_step_rows_persistent_out; "
                                                      "robots never interact, VEC:273 -- no grid-wide boundary between steps)" % args.steps,
@@ -508,7 +508,8 @@ def worker(args):
             # `traffic` = HBM bytes of one launch of the timed kernel from the PMC passes (hash-gated file under profiles/)
             "roofline": {"bound": "valu_fp32", "achieved": ach_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP32_PEAK_TFLOPS,
                          "traffic": traffic,
-                         "kernel": ("irrl_steps_persistent_kernel_l%d" if mode == "persistent" else "irrl_step_kernel_l%d") % env.lanes_per_robot,
+                         "kernel": ("irrl_steps_persistent_kernel_l%d" if mode == "persistent" else "irrl_step_kernel_l%d") % env.lanes_per_robot
+                                   + ("w2" if env.waves_per_simd == 2 else ""),
                          "steps_per_launch": spl, "avg_launch_us": kernel_ms * 1e3 * spl, "avg_step_us": kernel_ms * 1e3,
                          "algorithmic_flops_per_launch": ALG_FLOPS_PER_ENV_STEP * n * spl, "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n * spl,
                          "valu_issue": issue,

@@ -98,21 +98,26 @@ static inline dim3 lane_grid(const irrl_env *h, int n) {
   const int per_block = (64 / h->lanes) * waves_per_block();
   return dim3((unsigned)((n + per_block - 1) / per_block));
 }
-// layout choice: 16 lanes per robot while that still fits ~1.5 waves per SIMD, 4 lanes per robot beyond;
-// IRRL_LANES_PER_ROBOT=4|16 overrides (used by the tests to cover both layouts on small pools)
-static int pick_lanes(int n_envs) {
+// layout choice: 16 lanes per robot (4 robots per wave) while the pool's waves fit the device's SIMDs -- one resident wave each: the kernels take
+// 335-363 registers --, 4 lanes per robot (16 robots per wave) beyond: 4096 robots on an MI355X.  (Rounds 2-5 drew the line at 6144 robots; measured in
+// round 6, 4097-6144 robots ran a second round of 16-lane waves: 59.3 us per step against 41.2 us in the 4-lane layout,
+// profiles/r06_lane_layout_threshold.log.)  IRRL_LANES_PER_ROBOT=4|16 overrides (used by the tests to cover both layouts on small pools)
+static int device_simds(int device) {
+  int cus = 256;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+  return cus * 4;
+}
+static int pick_lanes(int n_envs, int device) {
   const char *e = getenv("IRRL_LANES_PER_ROBOT");
   if (e) { int v = atoi(e); if (v == 4 || v == 16) return v; }
-  return (n_envs <= 6144) ? 16 : 4;
+  return ((n_envs + 3) / 4 <= device_simds(device)) ? 16 : 4;
 }
-// 4-lane pools: two waves per SIMD once there are more waves than SIMDs (16 robots per wave, 4 SIMDs per CU); IRRL_L4_WAVES=1|2 overrides
-// (used by the tests to run the _l4w2 kernels on small pools)
+// 4-lane pools: two waves per SIMD once there are more waves than SIMDs (16 robots per wave: 16 384 robots on an MI355X); IRRL_L4_WAVES=1|2
+// overrides (used by the tests to run the _l4w2 kernels on small pools)
 static int pick_waves2(int n_envs, int device) {
   const char *e = getenv("IRRL_L4_WAVES");
   if (e) { int v = atoi(e); if (v == 1 || v == 2) return v == 2; }
-  int cus = 256;
-  hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-  return (n_envs + 15) / 16 > cus * 4;
+  return (n_envs + 15) / 16 > device_simds(device);
 }
 #define IRRL_LAUNCH(h, name, grid, ...)                                                                                   \
   do {                                                                                                                    \
@@ -161,7 +166,7 @@ irrl_env *irrl_env_create(const char *resource_dir, const char *cfg_yaml, int de
   h->resource_dir = resource_dir ? resource_dir : "";
   if (!h->cfg.parse(cfg_yaml, g_err) || !irrl_host::build_params(h->cfg, h->P, g_err)) { delete h; return nullptr; }
   h->pool = irrl_host::StatePool(h->P.n_envs);
-  h->lanes = pick_lanes(h->P.n_envs);
+  h->lanes = pick_lanes(h->P.n_envs, device);
   h->waves2 = (h->lanes == 4) ? pick_waves2(h->P.n_envs, device) : 0;
   const size_t n = (size_t)h->P.n_envs;
   bool ok = hipSetDevice(device) == hipSuccess && hipMalloc(&h->d_pool, h->pool.bytes) == hipSuccess &&

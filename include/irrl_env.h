@@ -53,8 +53,8 @@ int irrl_env_set_stream(irrl_env *h, void *hip_stream);
 
 /* PYB:28-31 */
 int irrl_env_num_envs(const irrl_env *h);
-/* lane layout of this pool's kernels: 16 (<= 6144 envs: one DPP row per robot) or 4 (larger pools: one DPP quad per
- * robot); build-defined, overridable with the environment variable IRRL_LANES_PER_ROBOT */
+/* lane layout of this pool's kernels: 16 (one DPP row per robot: while the pool's waves of four robots fit the device's SIMDs, <= 4096 envs
+ * on an MI355X) or 4 (larger pools: one DPP quad per robot); build-defined, overridable with the environment variable IRRL_LANES_PER_ROBOT */
 int irrl_env_lanes_per_robot(const irrl_env *h);
 /* resident waves per SIMD the pool's kernels are compiled for: 1 (the whole register file of a SIMD for one wave), or 2 for 4-lane pools
  * with more waves than the device has SIMDs (> 16 384 envs on an MI355X); build-defined, overridable with IRRL_L4_WAVES=1|2 */

@@ -63,7 +63,7 @@ def test_persistent_multi_step_launch_equals_back_to_back_launches(n, cfg_name, 
     from hip_env import HipVecEnv
     K, rows = 400, 64
     a, b = HipVecEnv(load_env_cfg(cfg_name, num_envs=n, **over)), HipVecEnv(load_env_cfg(cfg_name, num_envs=n, **over))
-    assert a.impl.lanes_per_robot == (4 if n > 6144 else 16)
+    assert a.impl.lanes_per_robot == (4 if n > 4096 else 16)
     g = torch.Generator(device="cuda").manual_seed(5)
     table = (0.5 * torch.randn(rows, n, 12, device="cuda", generator=g)).clamp(-1, 1)
     outs = [(torch.zeros(n, 35, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(n, dtype=torch.bool, device="cuda"), torch.zeros(n, 6, device="cuda"))

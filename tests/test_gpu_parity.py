@@ -284,7 +284,7 @@ def test_terrain_and_per_episode_randomisation_config5():
 
 @pytest.mark.parametrize("lanes", [4, 16])
 def test_both_lane_layouts_match_oracle_on_gpu(lanes, monkeypatch):
-    """The library carries the env kernels in two lane layouts (16 lanes per robot for pools <= 6144, 4 beyond);
+    """The library carries the env kernels in two lane layouts (16 lanes per robot while the waves fit the SIMDs: <= 4096 robots on an MI355X, 4 beyond);
     IRRL_LANES_PER_ROBOT forces one so that both are checked on a small pool."""
     monkeypatch.setenv("IRRL_LANES_PER_ROBOT", str(lanes))
     cfg = load_env_cfg("default_cfg.yaml", num_envs=48)
@@ -299,7 +299,9 @@ def test_layout_is_chosen_by_pool_size(monkeypatch):
     monkeypatch.delenv("IRRL_LANES_PER_ROBOT", raising=False)
     monkeypatch.delenv("IRRL_L4_WAVES", raising=False)
     small = _hip(load_env_cfg("default_cfg.yaml", num_envs=4096)).impl
-    assert small.lanes_per_robot == 16 and small.waves_per_simd == 1
+    assert small.lanes_per_robot == 16 and small.waves_per_simd == 1                # 1024 waves of four robots = one per SIMD of the MI355X
+    mid = _hip(load_env_cfg("default_cfg.yaml", num_envs=4100)).impl
+    assert mid.lanes_per_robot == 4 and mid.waves_per_simd == 1                     # a second round of 16-lane waves would cost a whole step more
     big = _hip(load_env_cfg("default_cfg.yaml", num_envs=16384))
     assert big.impl.lanes_per_robot == 4 and big.impl.waves_per_simd == 1      # 1024 waves of 16 robots = one per SIMD of the MI355X
     PL.check_invariants(big, steps=20)

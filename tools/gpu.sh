@@ -62,7 +62,7 @@ while [ $# -gt 0 ]; do
       done ;;
     sweep)
       rm -f $O/sweep.log
-      for n in 1024 4096 8192 16384 32768 131072; do
+      for n in 1024 4096 6144 8192 16384 32768 131072; do
         timeout 300 python bench.py --cpu-seconds 0 --ppo-iters 0 --steps 1000 --warmup 100 --check-steps 0 --envs $n --launch rows 2>/dev/null | line "envs=$n, one launch per step:" >> $O/sweep.log
         timeout 300 python bench.py --cpu-seconds 0 --ppo-iters 0 --steps 1000 --warmup 100 --check-steps 0 --envs $n --launch persistent 2>/dev/null | line "envs=$n, ONE persistent launch:" >> $O/sweep.log
       done
