@@ -41,6 +41,13 @@ using namespace lanes;
 // ---------------------------------------------------------------------------------------------
 // small vector helpers
 // ---------------------------------------------------------------------------------------------
+// RULE, the template parameter of the step's device functions: bit 0 = the per-contact rule (EnvParams::contact_rule: 1 = the published one),
+// bit 1 = THE SHIPPED SOLVER SETTINGS AS COMPILE-TIME CONSTANTS (ContactSolver bit 1 = simultaneous sweeps, ContactExit = 1: what every shipped
+// configuration runs).  The sweep loop then carries neither the other solver's loop nor the per-sweep tests of two run-time flags: same
+// arithmetic, bit-identical results, multi-step kernel 30.0 -> 29.3 us per step (profiles/r06_ab_default_solver_compile_time_same_box.log).
+// The launcher takes the RULE = 3 kernels when the pool's settings are those and the RULE = 1 / 0 kernels otherwise (irrl_env_abi.hip).
+#define IRRL_SOLVER_FIXED(RULE) (((RULE) & 2) != 0)
+#define IRRL_RULE_SHIPPED 3
 #define IRRL_UNLIKELY(x) __builtin_expect(!!(x), 0)   /* rare wave-uniform branches: laid out off the hot path */
 struct v3 { vf x, y, z; };
 struct sym3 { vf xx, xy, xz, yy, yz, zz; };
@@ -1287,7 +1294,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     // rank of this contact among the robot's active contacts (leg order FR,FL,HR,HL)
     vi rank = 0;
     int nrank = 1;   // (this block only runs when some toe of the wave touches)
-    if (P.contact_jacobi == 0) {
+    if (!IRRL_SOLVER_FIXED(RULE) && P.contact_jacobi == 0) {
       vi leg = leg_id();
       vi act_i = vsel_i(active, 1, 0);
       vi a0i = legs_bcast_i<0>(act_i), a1i = legs_bcast_i<1>(act_i), a2i = legs_bcast_i<2>(act_i), a3i = legs_bcast_i<3>(act_i);
@@ -1299,7 +1306,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     // fraction of the diagonal ones), so this converges almost as fast as Gauss-Seidel (measured on the oracle: 2.4 vs 2.2
     // sweeps per substep, p99 5 vs 4, same fixed point), and the step no longer lasts as long as the wave whose robots
     // happen to have the most feet on the ground (tools/wave_spread.py).
-    const bool jacobi = P.contact_jacobi != 0;
+    const bool jacobi = IRRL_SOLVER_FIXED(RULE) || P.contact_jacobi != 0;
     const float tol2 = P.contact_tol * P.contact_tol;
     // row r of the partner legs' coupling sum_p G_lp v_p for a 3-vector v every leg holds (lam or its last change): three independent
     // accumulation chains (one per partner leg), then two adds -- the single resident wave issues a DEPENDENT VALU instruction every
@@ -1314,7 +1321,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
       // (answer_norm2*) -- it is also the PREDICTION of how far that sweep would move the impulses: with contact_exit the loop is
       // left before a sweep that would change them by less than the tolerance, instead of after a sweep that did (the
       // confirming sweep: one solve of ~130-200 VALU instructions per substep, against ~25 for the prediction).
-      const bool predicted = P.contact_exit != 0;
+      const bool predicted = IRRL_SOLVER_FIXED(RULE) || P.contact_exit != 0;
       const vf cvr0 = IRRL_COUPLING_ROW(lam, cfree_r);
       v3 cv = mk3(sub_bcast<0>(cvr0), sub_bcast<1>(cvr0), sub_bcast<2>(cvr0));
       for (int it = 0; it < P.contact_iters; it++) {
@@ -1542,7 +1549,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     vi a0i = legs_bcast_i<0>(act_i), a1i = legs_bcast_i<1>(act_i), a2i = legs_bcast_i<2>(act_i);
     vi rank = vsel_i(leg == 0, 0, vsel_i(leg == 1, a0i, vsel_i(leg == 2, a0i + a1i, a0i + a1i + a2i)));
     int nrank = wave_max_small(legs_sum_i(act_i));
-    const bool jacobi = P.contact_jacobi != 0;   // ContactSolver bit 1: simultaneous updates (see the 16-lane instantiation)
+    const bool jacobi = IRRL_SOLVER_FIXED(RULE) || P.contact_jacobi != 0;   // ContactSolver bit 1: simultaneous updates (see the 16-lane instantiation)
     const float tol2 = P.contact_tol * P.contact_tol;
     // velocity at this contact from the OTHER legs' 3-vectors v (impulses, or their last change): Y_l (z - Y_l^T v_l), z = sum_legs
     // Y_l^T v_l (G_{l,p} = Y_l Y_p^T).  One 6-vector reduction per solve instead of round 1's explicit partner blocks (4 x 9 x 6 FMAs
@@ -1558,7 +1565,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
     };
     if (jacobi) {
       // one loop for both exit rules, contact-point velocity carried from sweep to sweep (see the 16-lane instantiation)
-      const bool predicted = P.contact_exit != 0;
+      const bool predicted = IRRL_SOLVER_FIXED(RULE) || P.contact_exit != 0;
       v3 cv = coupling(lam, mk3(cfree[0], cfree[1], cfree[2]));
       if (nrank > 0)
       for (int it = 0; it < P.contact_iters; it++) {

@@ -119,6 +119,7 @@ extern "C" {
 IRRL_STEP_KERNEL(irrl_step_kernel_crutial, irrl, 0)
 IRRL_STEP_KERNEL(irrl_step_kernel_crutial_md, irrl, 1)
 IRRL_STEP_KERNEL(irrl_step_kernel_dir, irrl_plain, 0)
+IRRL_STEP_KERNEL(irrl_step_kernel_md, irrl_plain, 1)   // the published rule under the other solver settings (Gauss-Seidel order / confirming exit)
 
 // the default pool: no meteorite, published rule
 __global__ void IRRL_ENV_BOUNDS
@@ -128,7 +129,7 @@ IRRL_K(irrl_step_kernel)(EnvParams P_, EnvState S_, const float *action, float *
 #ifdef IRRL_PROFILE_WAVES   /* diagnostic build (tools/wave_spread.py): extra[env][5] <- this wave's duration in 100 MHz ticks */
   const unsigned long long t0_ = wall_clock64();
 #endif
-  irrl_plain::step_body<1>(P, S, env_, leg_, valid_, action, ob, reward, done, extra);
+  irrl_plain::step_body<IRRL_RULE_SHIPPED>(P, S, env_, leg_, valid_, action, ob, reward, done, extra);
 #ifdef IRRL_PROFILE_WAVES
   const unsigned long long t1_ = wall_clock64();
   if (valid_ && leg_ == 0) extra[env_ * 6 + 5] = (float)(t1_ - t0_);
@@ -160,7 +161,7 @@ irrl_step_policy_kernel_l16(EnvParams P_, EnvState S_, const float *action, floa
     IRRL_LANE_PROLOGUE_IDENTITY
     // the env part keeps no LDS and, between its prologue and its epilogue, issues no global load (flat ground): the layer-0
     // policy weights travel L2 -> LDS underneath the eight substeps
-    irrl_plain::step_body<1>(P, S, env_, leg_, valid_, action, ob, reward, done, extra, [&]() { policy_prefetch_lds<48, 256>(a, lds_w); });
+    irrl_plain::step_body<IRRL_RULE_SHIPPED>(P, S, env_, leg_, valid_, action, ob, reward, done, extra, [&]() { policy_prefetch_lds<48, 256>(a, lds_w); });
   }
 #ifdef IRRL_PROFILE_POLICY
   const unsigned long long pt1_ = wall_clock64();
@@ -220,7 +221,7 @@ irrl_rollout_persistent_kernel_l16(EnvParams P_, EnvState S_, float *ob, float *
       const int leg_ = (lane_ >> 2) & 3;
       const bool valid_ = (env_ < P.n_envs) && ((lane_ & 3) == 0);
       if (env_ >= P.n_envs) env_ = P.n_envs - 1;
-      irrl_plain::step_body<1>(IRRL_PARAMS_REFRESH(P), IRRL_PARAMS_REFRESH(S), env_, leg_, valid_, (const float *)ak.clipped, ob, reward, done, extra);
+      irrl_plain::step_body<IRRL_RULE_SHIPPED>(IRRL_PARAMS_REFRESH(P), IRRL_PARAMS_REFRESH(S), env_, leg_, valid_, (const float *)ak.clipped, ob, reward, done, extra);
     }
     IRRL_PP_STAMP(2);   // env step of this wave's four robots
     __syncthreads();   // obs / dones / reward of step k are stored and visible: the next policy step reads them
@@ -282,9 +283,9 @@ irrl_rollout_persistent_actor_kernel_l16(EnvParams P_, EnvState S_, float *ob, f
       asm volatile("" : "+v"(env_));
 #ifndef IRRL_ACTOR_NO_CARRY
       if (k > 0) irrl_plain::lane_carry(L);
-      irrl_plain::step_compute<1>(IRRL_PARAMS_REFRESH(P), L, env_, leg0_, valid0_, irrl_plain::ActionRow{(const float *)ak.clipped}, ob, reward, done, extra);
+      irrl_plain::step_compute<IRRL_RULE_SHIPPED>(IRRL_PARAMS_REFRESH(P), L, env_, leg0_, valid0_, irrl_plain::ActionRow{(const float *)ak.clipped}, ob, reward, done, extra);
 #else
-      irrl_plain::step_body<1>(IRRL_PARAMS_REFRESH(P), IRRL_PARAMS_REFRESH(S), env_, leg0_, valid0_, (const float *)ak.clipped, ob, reward, done, extra);
+      irrl_plain::step_body<IRRL_RULE_SHIPPED>(IRRL_PARAMS_REFRESH(P), IRRL_PARAMS_REFRESH(S), env_, leg0_, valid0_, (const float *)ak.clipped, ob, reward, done, extra);
 #endif
     }
     __syncthreads();   // obs / dones / reward of step k are stored and visible: the next policy step reads them
@@ -375,7 +376,7 @@ irrl_rollout_persistent_actor_wave_kernel_l16(EnvParams P_, EnvState S_, float *
       irrl_plain::ActionRegs act;
 #pragma unroll
       for (int j = 0; j < 3; j++) act.a[j] = ws[LAY::ACT + rl_ * 12 + leg0_ * 3 + j];
-      irrl_plain::step_compute<1, irrl_plain::NoStepHook>(
+      irrl_plain::step_compute<IRRL_RULE_SHIPPED, irrl_plain::NoStepHook>(
           IRRL_PARAMS_REFRESH(P), L, env_, leg0_, valid0_, act, ob, reward, done, extra, irrl_plain::NoStepHook(),
           [&](const irrl_plain::EnvLane &Lf, float rew, bool dn) {
             irrl_plain::observe_write(P, rl_, leg0_, valid0_, Lf, ws + LAY::X);
@@ -460,7 +461,7 @@ irrl_rollout_persistent_mlp_kernel_l16(EnvParams P_, EnvState S_, float *ob, flo
       irrl_plain::ActionRegs act;
 #pragma unroll
       for (int j = 0; j < 3; j++) act.a[j] = ws[MlpWaveLds<64>::ACT + rl_ * 12 + leg0_ * 3 + j];
-      irrl_plain::step_compute<1, irrl_plain::NoStepHook>(
+      irrl_plain::step_compute<IRRL_RULE_SHIPPED, irrl_plain::NoStepHook>(
           IRRL_PARAMS_REFRESH(P), L, env_, leg0_, valid0_, act, ob, reward, done, extra, irrl_plain::NoStepHook(),
           [&](const irrl_plain::EnvLane &Lf, float rew, bool dn) {
             // (inside the epilogue's sub-lane-0 region) the scaled observation row, the reward and the done flag once more, into the scratch
@@ -527,7 +528,7 @@ IRRL_K(irrl_steps_persistent_kernel)(EnvParams P_, EnvState S_, const float *act
       const float *an = action_rows + row * (size_t)((first_row + kn) % n_rows) + (size_t)env_ * 12 + leg0_ * 3;
       act_next.a[0] = an[0]; act_next.a[1] = an[1]; act_next.a[2] = an[2];
     }
-    irrl_plain::step_compute<1, irrl_plain::NoStepHook, irrl_plain::NoStepTail, irrl_plain::ActionRegs>(
+    irrl_plain::step_compute<IRRL_RULE_SHIPPED, irrl_plain::NoStepHook, irrl_plain::NoStepTail, irrl_plain::ActionRegs>(
         IRRL_PARAMS_REFRESH(P), L, env_, leg0_, valid0_, act, ob + orow * 35 * (size_t)k, reward + orow * (size_t)k, done + orow * (size_t)k, extra + orow * 6 * (size_t)k);
   }
   if (count > 0) {

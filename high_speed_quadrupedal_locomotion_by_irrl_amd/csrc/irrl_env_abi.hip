@@ -21,6 +21,7 @@
 #define IRRL_DECLARE_KERNELS(sfx)                                                                                            \
   extern "C" __global__ void irrl_step_kernel##sfx(EnvParams, EnvState, const float *, float *, float *, uint8_t *, float *);   \
   extern "C" __global__ void irrl_step_kernel_dir##sfx(EnvParams, EnvState, const float *, float *, float *, uint8_t *, float *); \
+  extern "C" __global__ void irrl_step_kernel_md##sfx(EnvParams, EnvState, const float *, float *, float *, uint8_t *, float *); \
   extern "C" __global__ void irrl_step_kernel_crutial##sfx(EnvParams, EnvState, const float *, float *, float *, uint8_t *, float *); \
   extern "C" __global__ void irrl_step_kernel_crutial_md##sfx(EnvParams, EnvState, const float *, float *, float *, uint8_t *, float *); \
   extern "C" __global__ void irrl_steps_persistent_kernel##sfx(EnvParams, EnvState, const float *, int, int, int, float *, float *, uint8_t *, float *, int); \
@@ -126,13 +127,19 @@ static int pick_waves2(int n_envs, int device) {
     else hipLaunchKernelGGL(name##_l4, grid, quad_block(), 0, (h)->stream, __VA_ARGS__);                                   \
   } while (0)
 
-// the step kernel: one instantiation per (Crutial, per-contact rule) -- env_kernels.hip
+// the step kernel: one instantiation per (Crutial, per-contact rule) -- env_kernels.hip -- and, for the default pool kind (no meteorite, published
+// rule), one with the shipped solver settings compiled in (simultaneous sweeps + predicted exit: env_core.hpp IRRL_SOLVER_FIXED) next to the
+// one that reads them from EnvParams; the multi-step and rollout kernels exist for the former only (the launchers fall back)
+static inline bool shipped_solver(const irrl_env *h) { return h->P.contact_jacobi != 0 && h->P.contact_exit != 0; }
 #define IRRL_LAUNCH_STEP(h, grid, ...)                                                                                      \
   do {                                                                                                                    \
     if ((h)->P.crutial) {                                                                                                   \
       if ((h)->P.contact_rule) IRRL_LAUNCH(h, irrl_step_kernel_crutial_md, grid, __VA_ARGS__);                               \
       else IRRL_LAUNCH(h, irrl_step_kernel_crutial, grid, __VA_ARGS__);                                                      \
-    } else if ((h)->P.contact_rule) IRRL_LAUNCH(h, irrl_step_kernel, grid, __VA_ARGS__);                                     \
+    } else if ((h)->P.contact_rule) {                                                                                       \
+      if (shipped_solver(h)) IRRL_LAUNCH(h, irrl_step_kernel, grid, __VA_ARGS__);                                           \
+      else IRRL_LAUNCH(h, irrl_step_kernel_md, grid, __VA_ARGS__);                                                          \
+    }                                                                                                                       \
     else IRRL_LAUNCH(h, irrl_step_kernel_dir, grid, __VA_ARGS__);                                                            \
   } while (0)
 
@@ -306,7 +313,7 @@ static int step_rows_persistent_impl(irrl_env *h, int count, const float *action
   if (need_init(h)) return 1;
   if (count < 0 || n_rows <= 0 || first_row < 0) { g_err = std::string(who) + ": count >= 0, n_rows > 0, first_row >= 0"; return 1; }
   if (!action_rows || !ob || !reward || !done || !extra) { g_err = std::string(who) + ": NULL argument"; return 1; }
-  if (h->P.crutial || !h->P.contact_rule) return step_rows_impl(h, count, action_rows, n_rows, first_row, ob, reward, done, extra, out_rows, who);
+  if (h->P.crutial || !h->P.contact_rule || !shipped_solver(h)) return step_rows_impl(h, count, action_rows, n_rows, first_row, ob, reward, done, extra, out_rows, who);
   if (use_device(h)) return 1;
   if (count > 0) IRRL_LAUNCH(h, irrl_steps_persistent_kernel, lane_grid(h, h->P.n_envs), h->P, h->S, action_rows, n_rows, first_row, count, ob, reward, done, extra, out_rows);
   HIP_TRY(hipGetLastError());
@@ -332,7 +339,7 @@ int irrl_env_step_rows_persistent_out(irrl_env *h, int count, const float *actio
 
 // which `fuse` modes of irrl_lstm_rollout exist for THIS pool and network: 1 = the mode runs as described, 0 = it does not (fuse 1 / 2 then fall
 // back to two launches per step inside the call; fuse 3 is refused -- its caller must evaluate the critic itself, so it has to know beforehand)
-static bool rollout_one_tile(const irrl_env *h, int hid) { return h->lanes == 16 && !h->P.crutial && h->P.contact_rule && hid == 48; }
+static bool rollout_one_tile(const irrl_env *h, int hid) { return h->lanes == 16 && !h->P.crutial && h->P.contact_rule && shipped_solver(h) && hid == 48; }
 int irrl_lstm_rollout_supports(irrl_env *h, int hid, int fuse) {
   if (!h) { g_err = "irrl_lstm_rollout_supports: NULL handle"; return -1; }
   if (fuse == 0) return 1;
@@ -444,7 +451,7 @@ int irrl_mlp_rollout(irrl_env *h, int steps, int hid, int ob_dim, int act_dim, f
   h->stream = (hipStream_t)hip_stream;
   const int n = h->P.n_envs;
   auto noise_at = [&](int k) { return noise ? noise + (size_t)k * (size_t)n * (size_t)act_dim : nullptr; };
-  const bool one_tile = h->lanes == 16 && !h->P.crutial && h->P.contact_rule;
+  const bool one_tile = h->lanes == 16 && !h->P.crutial && h->P.contact_rule && shipped_solver(h);
   if (fuse == 2 && one_tile && steps > 0) {
     if (!mb_rewards) { g_err = "irrl_mlp_rollout: the persistent path writes the reward rows (mb_rewards is mandatory)"; return 1; }
     PolicyStepArgs a;
