@@ -2,7 +2,7 @@
 Builds csrc/env_kernels.hip to assembly with -DIRRL_MARKS (section markers + scheduling barriers at the section borders, so
 the total is a few percent above the production build) and counts VALU / SALU / other instructions between markers.
 usage: python tools/isa_sections.py [--kernel NAME] [extra -D flags]   (default kernel: irrl_step_kernel_l16 = the published contact rule;
-irrl_step_kernel_dir_l16 = the build's first rule)"""
+irrl_step_kernel_dir_l16 = the build's first rule, irrl_step_kernel_md_l16 = the published rule with the solver settings read at run time)"""
 import os, re, subprocess, sys, tempfile, collections
 
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
@@ -53,4 +53,4 @@ for k, c in counts.items():
     print("%-17s %6d %6d %5d %5d %5d %7d %9d %8d" % (k, c["valu"], c["salu"], c["mem"], c["dpp"], c["pk"], c["mov_sel"], c["lane"], c["acc"]))
     tot.update(c)
 print("%-17s %6d %6d %5d %5d %5d %7d %9d %8d" % ("total", tot["valu"], tot["salu"], tot["mem"], tot["dpp"], tot["pk"], tot["mov_sel"], tot["lane"], tot["acc"]))
-print("(gs = the sweep loops of both solvers, static: the simultaneous-sweep loop that runs by default is ~220 of them per sweep;\n sgpr<->v: v_readlane / v_writelane of spilled SGPRs, agpr<->v: v_accvgpr moves -- both are VALU issue slots)")
+print("(gs = the sweep loop, static -- the default pool's kernels carry the simultaneous-sweep loop only, irrl_step_kernel_md_l16 both solvers' loops;\n sgpr<->v: v_readlane / v_writelane of spilled SGPRs, agpr<->v: v_accvgpr moves -- both are VALU issue slots)")
