@@ -42,9 +42,10 @@ using namespace lanes;
 // small vector helpers
 // ---------------------------------------------------------------------------------------------
 // RULE, the template parameter of the step's device functions: bit 0 = the per-contact rule (EnvParams::contact_rule: 1 = the published one),
-// bit 1 = THE SHIPPED SOLVER SETTINGS AS COMPILE-TIME CONSTANTS (ContactSolver bit 1 = simultaneous sweeps, ContactExit = 1: what every shipped
-// configuration runs).  The sweep loop then carries neither the other solver's loop nor the per-sweep tests of two run-time flags: same
-// arithmetic, bit-identical results, multi-step kernel 30.0 -> 29.3 us per step (profiles/r06_ab_default_solver_compile_time_same_box.log).
+// bit 1 = THE SHIPPED SOLVER SETTINGS AS COMPILE-TIME CONSTANTS (ContactSolver bit 1 = simultaneous sweeps, ContactExit = 1, a ContactTolerance
+// above zero: what every shipped configuration runs).  The sweep loop then carries neither the other solver's loop nor the per-sweep tests of two run-time flags: same
+// arithmetic, bit-identical results, multi-step kernel 30.0 -> 29.3 -> 29.0 us per step, one launch per step 40.5 -> 40.1 -> 39.1 us
+// (profiles/r06_ab_default_solver_compile_time_same_box.log).
 // The launcher takes the RULE = 3 kernels when the pool's settings are those and the RULE = 1 / 0 kernels otherwise (irrl_env_abi.hip).
 #define IRRL_SOLVER_FIXED(RULE) (((RULE) & 2) != 0)
 #define IRRL_RULE_SHIPPED 3
@@ -1333,7 +1334,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
         lam = lam + dl;
         if (it + 1 >= P.contact_iters) break;
         vf l2 = 0.0f;
-        if (tol2 > 0.0f) {
+        if (IRRL_SOLVER_FIXED(RULE) || tol2 > 0.0f) {
           l2 = legs_sum(vsel(active, dot(lam, lam), 0.0f));
           if (!predicted) {
             vm unconverged = legs_sum(dot(dl, dl)) > tol2 * l2 + 1e-20f;
@@ -1344,7 +1345,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
         const v3 dc = mk3(sub_bcast<0>(dcr), sub_bcast<1>(dcr), sub_bcast<2>(dcr));
         // (asking only when the last change was below 100 tolerances -- a cheap necessary condition in front of the ~25 instructions of
         // the prediction -- was measured and dropped: 18.0 instead of 16.1 sweeps per step, the wave 0.75 us slower, same box)
-        if (predicted && tol2 > 0.0f) {
+        if (predicted && (IRRL_SOLVER_FIXED(RULE) || tol2 > 0.0f)) {
           const vf p2 = RULE ? answer_norm2_md(CM, dc, nB) : answer_norm2(CB, dc);
           vm unconverged = legs_sum(vsel(active, p2, 0.0f)) > tol2 * l2 + 1e-20f;
           if (!wave_any(unconverged)) break;
@@ -1574,7 +1575,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
         lam = lam + dl;
         if (it + 1 >= P.contact_iters) break;
         vf l2 = 0.0f;
-        if (tol2 > 0.0f) {
+        if (IRRL_SOLVER_FIXED(RULE) || tol2 > 0.0f) {
           l2 = legs_sum(vsel(active, dot(lam, lam), 0.0f));
           if (!predicted) {
             vm unconverged = legs_sum(dot(dl, dl)) > tol2 * l2 + 1e-20f;
@@ -1582,7 +1583,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
           }
         }
         const v3 dc = coupling(dl, mk3(0.0f, 0.0f, 0.0f));
-        if (predicted && tol2 > 0.0f) {
+        if (predicted && (IRRL_SOLVER_FIXED(RULE) || tol2 > 0.0f)) {
           const vf p2 = RULE ? answer_norm2_md(CM, dc, nB) : answer_norm2(CB, dc);
           vm unconverged = legs_sum(vsel(active, p2, 0.0f)) > tol2 * l2 + 1e-20f;
           if (!wave_any(unconverged)) break;
