@@ -43,8 +43,8 @@ using namespace lanes;
 // ---------------------------------------------------------------------------------------------
 // RULE, the template parameter of the step's device functions: bit 0 = the per-contact rule (EnvParams::contact_rule: 1 = the published one),
 // bit 1 = THE SHIPPED SOLVER SETTINGS AS COMPILE-TIME CONSTANTS (ContactSolver bit 1 = simultaneous sweeps, ContactExit = 1, a ContactTolerance
-// above zero: what every shipped configuration runs).  The sweep loop then carries neither the other solver's loop nor the per-sweep tests of two run-time flags: same
-// arithmetic, bit-identical results, multi-step kernel 30.0 -> 29.3 -> 29.0 us per step, one launch per step 40.5 -> 40.1 -> 39.1 us
+// above zero, ContactIterations = 6: what every shipped configuration runs).  The sweep loop then carries neither the other solver's loop nor the per-sweep tests of two run-time flags: same
+// arithmetic, bit-identical results, multi-step kernel 30.0 -> 29.3 -> 29.0 -> 28.7 us per step, one launch per step 40.5 -> 40.1 -> 39.1 -> 38.5 us
 // (profiles/r06_ab_default_solver_compile_time_same_box.log).
 // The launcher takes the RULE = 3 kernels when the pool's settings are those and the RULE = 1 / 0 kernels otherwise (irrl_env_abi.hip).
 #define IRRL_SOLVER_FIXED(RULE) (((RULE) & 2) != 0)
@@ -1325,14 +1325,16 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
       const bool predicted = IRRL_SOLVER_FIXED(RULE) || P.contact_exit != 0;
       const vf cvr0 = IRRL_COUPLING_ROW(lam, cfree_r);
       v3 cv = mk3(sub_bcast<0>(cvr0), sub_bcast<1>(cvr0), sub_bcast<2>(cvr0));
-      for (int it = 0; it < P.contact_iters; it++) {
+      const int sweep_cap = IRRL_SOLVER_FIXED(RULE) ? IRRL_SHIPPED_SWEEP_CAP : P.contact_iters;
+_Pragma("unroll 1")
+      for (int it = 0; it < sweep_cap; it++) {
 #ifdef IRRL_PROFILE_WAVES
         L.prof_ranksteps += 1; L.prof_flags += 256;
 #endif
         v3 ln = RULE ? solve_contact_md(CM, cv, nB, vstar, L.m.mu, active) : solve_contact(CB, cv, nB, vstar, L.m.mu, active);
         v3 dl = mk3(vsel(active, ln.x - lam.x, 0.0f), vsel(active, ln.y - lam.y, 0.0f), vsel(active, ln.z - lam.z, 0.0f));
         lam = lam + dl;
-        if (it + 1 >= P.contact_iters) break;
+        if (it + 1 >= sweep_cap) break;
         vf l2 = 0.0f;
         if (IRRL_SOLVER_FIXED(RULE) || tol2 > 0.0f) {
           l2 = legs_sum(vsel(active, dot(lam, lam), 0.0f));
@@ -1569,11 +1571,13 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
       const bool predicted = IRRL_SOLVER_FIXED(RULE) || P.contact_exit != 0;
       v3 cv = coupling(lam, mk3(cfree[0], cfree[1], cfree[2]));
       if (nrank > 0)
-      for (int it = 0; it < P.contact_iters; it++) {
+      const int sweep_cap = IRRL_SOLVER_FIXED(RULE) ? IRRL_SHIPPED_SWEEP_CAP : P.contact_iters;
+_Pragma("unroll 1")
+      for (int it = 0; it < sweep_cap; it++) {
         v3 ln = RULE ? solve_contact_md(CM, cv, nB, vstar, L.m.mu, active) : solve_contact(CB, cv, nB, vstar, L.m.mu, active);
         v3 dl = mk3(vsel(active, ln.x - lam.x, 0.0f), vsel(active, ln.y - lam.y, 0.0f), vsel(active, ln.z - lam.z, 0.0f));
         lam = lam + dl;
-        if (it + 1 >= P.contact_iters) break;
+        if (it + 1 >= sweep_cap) break;
         vf l2 = 0.0f;
         if (IRRL_SOLVER_FIXED(RULE) || tol2 > 0.0f) {
           l2 = legs_sum(vsel(active, dot(lam, lam), 0.0f));

@@ -91,6 +91,10 @@ struct EnvState {
   uint32_t *contact_count;  // [N,4]
 };
 
+// ContactIterations of every shipped configuration (and the default when the key is absent): a compile-time constant of the default pool's kernels
+// (env_core.hpp IRRL_SOLVER_FIXED; the launcher checks the pool's value against it, irrl_env_abi.hip shipped_solver)
+#define IRRL_SHIPPED_SWEEP_CAP 6
+
 // RNG purposes -- (purpose, slot) addresses every random draw; identical table in the oracle.
 enum {
   IRRL_P_DR_MATERIAL = 1, IRRL_P_DR_MASS = 2, IRRL_P_DR_COM = 6, IRRL_P_DR_THIGH = 16,

@@ -128,9 +128,11 @@ static int pick_waves2(int n_envs, int device) {
   } while (0)
 
 // the step kernel: one instantiation per (Crutial, per-contact rule) -- env_kernels.hip -- and, for the default pool kind (no meteorite, published
-// rule), one with the shipped solver settings compiled in (simultaneous sweeps + predicted exit + a tolerance above zero: env_core.hpp IRRL_SOLVER_FIXED) next to the
+// rule), one with the shipped solver settings compiled in (simultaneous sweeps + predicted exit + a tolerance above zero + at most six sweeps: env_core.hpp IRRL_SOLVER_FIXED) next to the
 // one that reads them from EnvParams; the multi-step and rollout kernels exist for the former only (the launchers fall back)
-static inline bool shipped_solver(const irrl_env *h) { return h->P.contact_jacobi != 0 && h->P.contact_exit != 0 && h->P.contact_tol > 0.0f; }
+static inline bool shipped_solver(const irrl_env *h) {
+  return h->P.contact_jacobi != 0 && h->P.contact_exit != 0 && h->P.contact_tol > 0.0f && h->P.contact_iters == IRRL_SHIPPED_SWEEP_CAP;
+}
 #define IRRL_LAUNCH_STEP(h, grid, ...)                                                                                      \
   do {                                                                                                                    \
     if ((h)->P.crutial) {                                                                                                   \
