@@ -470,7 +470,7 @@ def worker(args):
                         pd = pp["derived"]
                         issue = {"valu_insts_per_wave_per_step": pd["valu_insts_per_wave_per_step"], "cycles_per_valu_inst": pd["cycles_per_valu_inst"],
                                  "frac_of_single_wave_issue_peak": 4.0 / pd["cycles_per_valu_inst"], "l2_hit_rate": pd["l2_hit_rate"],
-                                 "source": "profiles/pmc_summary_latest.json (irrl_steps_persistent_kernel_l16, launches of %d steps, every step's outputs kept)" % pp["steps_per_launch"]}
+                                 "source": "profiles/pmc_summary_latest.json (irrl_steps_persistent_kernel_flat_l16, launches of %d steps, every step's outputs kept)" % pp["steps_per_launch"]}
                     else:
                         pmc_note = "profiles/pmc_summary_latest.json has no counters of the persistent kernel with every step's outputs kept"
                 else:
@@ -508,8 +508,8 @@ def worker(args):
             # `traffic` = HBM bytes of one launch of the timed kernel from the PMC passes (hash-gated file under profiles/)
             "roofline": {"bound": "valu_fp32", "achieved": ach_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP32_PEAK_TFLOPS,
                          "traffic": traffic,
-                         "kernel": ("irrl_steps_persistent_kernel_l%d" if mode == "persistent" else "irrl_step_kernel_l%d") % env.lanes_per_robot
-                                   + ("w2" if env.waves_per_simd == 2 else ""),
+                         "kernel": ("irrl_steps_persistent_kernel" if mode == "persistent" else "irrl_step_kernel") + ("" if env_cfg.get("Terrain") else "_flat")
+                                   + "_l%d" % env.lanes_per_robot + ("w2" if env.waves_per_simd == 2 else ""),
                          "steps_per_launch": spl, "avg_launch_us": kernel_ms * 1e3 * spl, "avg_step_us": kernel_ms * 1e3,
                          "algorithmic_flops_per_launch": ALG_FLOPS_PER_ENV_STEP * n * spl, "algorithmic_bytes_per_launch": ALG_BYTES_PER_ENV_STEP * n * spl,
                          "valu_issue": issue,

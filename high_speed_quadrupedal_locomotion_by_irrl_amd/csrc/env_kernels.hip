@@ -119,6 +119,7 @@ extern "C" {
 IRRL_STEP_KERNEL(irrl_step_kernel_crutial, irrl, 0)
 IRRL_STEP_KERNEL(irrl_step_kernel_crutial_md, irrl, 1)
 IRRL_STEP_KERNEL(irrl_step_kernel_dir, irrl_plain, 0)
+IRRL_STEP_KERNEL(irrl_step_kernel_flat, irrl_plain, IRRL_RULE_SHIPPED_FLAT)   // the default pool on flat ground (env_core.hpp IRRL_FLAT_GROUND)
 IRRL_STEP_KERNEL(irrl_step_kernel_md, irrl_plain, 1)   // the published rule under the other solver settings (Gauss-Seidel order / confirming exit)
 
 // the default pool: no meteorite, published rule
@@ -487,9 +488,11 @@ irrl_rollout_persistent_mlp_kernel_l16(EnvParams P_, EnvState S_, float *ob, flo
 // behind a round trip of ~90 stores and ~90 loads per lane through the L2.  The body of a step is the step kernel's (step_compute, same
 // order): states and outputs are bit-identical to `count` launches.  Default pool kind only (no meteorite, published rule); the launcher
 // falls back otherwise.
-__global__ void IRRL_ENV_BOUNDS
-IRRL_K(irrl_steps_persistent_kernel)(EnvParams P_, EnvState S_, const float *action_rows, int n_rows, int first_row, int count, float *ob, float *reward,
-                                     uint8_t *done, float *extra, int out_rows) {
+}  // extern "C"
+template <int RULE>
+__device__ __forceinline__ void irrl_steps_persistent_body(const EnvParams &P_, const EnvState &S_, const float *action_rows, int n_rows, int first_row, int count,
+                                                           float *ob, float *reward, uint8_t *done, float *extra, int out_rows) {
+  (void)P_; (void)S_;   // (IRRL_BIND_ARGS names the kernel's first two arguments in the kernarg segment; the by-value copies serve the A/B build only)
   IRRL_BIND_ARGS
   const int blk = irrl_xcd_block();
   const size_t row = (size_t)P.n_envs * 12;
@@ -528,7 +531,7 @@ IRRL_K(irrl_steps_persistent_kernel)(EnvParams P_, EnvState S_, const float *act
       const float *an = action_rows + row * (size_t)((first_row + kn) % n_rows) + (size_t)env_ * 12 + leg0_ * 3;
       act_next.a[0] = an[0]; act_next.a[1] = an[1]; act_next.a[2] = an[2];
     }
-    irrl_plain::step_compute<IRRL_RULE_SHIPPED, irrl_plain::NoStepHook, irrl_plain::NoStepTail, irrl_plain::ActionRegs>(
+    irrl_plain::step_compute<RULE, irrl_plain::NoStepHook, irrl_plain::NoStepTail, irrl_plain::ActionRegs>(
         IRRL_PARAMS_REFRESH(P), L, env_, leg0_, valid0_, act, ob + orow * 35 * (size_t)k, reward + orow * (size_t)k, done + orow * (size_t)k, extra + orow * 6 * (size_t)k);
   }
   if (count > 0) {
@@ -536,6 +539,18 @@ IRRL_K(irrl_steps_persistent_kernel)(EnvParams P_, EnvState S_, const float *act
     irrl_plain::store_lane(IRRL_PARAMS_REFRESH(P), IRRL_PARAMS_REFRESH(S), env0_, leg0_, valid0_, L, P.randomize_per_episode != 0);
     IRRL_SUB0_ONLY_END
   }
+}
+extern "C" {
+// the multi-step kernel once with the run-time terrain test (rough ground) and once with flat ground compiled in (the launcher picks)
+__global__ void IRRL_ENV_BOUNDS
+IRRL_K(irrl_steps_persistent_kernel)(EnvParams P_, EnvState S_, const float *action_rows, int n_rows, int first_row, int count, float *ob, float *reward,
+                                     uint8_t *done, float *extra, int out_rows) {
+  irrl_steps_persistent_body<IRRL_RULE_SHIPPED>(P_, S_, action_rows, n_rows, first_row, count, ob, reward, done, extra, out_rows);
+}
+__global__ void IRRL_ENV_BOUNDS
+IRRL_K(irrl_steps_persistent_kernel_flat)(EnvParams P_, EnvState S_, const float *action_rows, int n_rows, int first_row, int count, float *ob, float *reward,
+                                          uint8_t *done, float *extra, int out_rows) {
+  irrl_steps_persistent_body<IRRL_RULE_SHIPPED_FLAT>(P_, S_, action_rows, n_rows, first_row, count, ob, reward, done, extra, out_rows);
 }
 
 __global__ void IRRL_ENV_BOUNDS IRRL_K(irrl_init_kernel)(EnvParams P_, EnvState S_) {

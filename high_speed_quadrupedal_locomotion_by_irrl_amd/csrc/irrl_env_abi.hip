@@ -25,6 +25,8 @@
   extern "C" __global__ void irrl_step_kernel_crutial##sfx(EnvParams, EnvState, const float *, float *, float *, uint8_t *, float *); \
   extern "C" __global__ void irrl_step_kernel_crutial_md##sfx(EnvParams, EnvState, const float *, float *, float *, uint8_t *, float *); \
   extern "C" __global__ void irrl_steps_persistent_kernel##sfx(EnvParams, EnvState, const float *, int, int, int, float *, float *, uint8_t *, float *, int); \
+  extern "C" __global__ void irrl_steps_persistent_kernel_flat##sfx(EnvParams, EnvState, const float *, int, int, int, float *, float *, uint8_t *, float *, int); \
+  extern "C" __global__ void irrl_step_kernel_flat##sfx(EnvParams, EnvState, const float *, float *, float *, uint8_t *, float *);   \
   extern "C" __global__ void irrl_init_kernel##sfx(EnvParams, EnvState);                                                       \
   extern "C" __global__ void irrl_reset_kernel##sfx(EnvParams, EnvState, float *);                                             \
   extern "C" __global__ void irrl_observe_kernel##sfx(EnvParams, EnvState, float *);                                           \
@@ -130,6 +132,16 @@ static int pick_waves2(int n_envs, int device) {
 // the step kernel: one instantiation per (Crutial, per-contact rule) -- env_kernels.hip -- and, for the default pool kind (no meteorite, published
 // rule), one with the shipped solver settings compiled in (simultaneous sweeps + predicted exit + a tolerance above zero + at most six sweeps: env_core.hpp IRRL_SOLVER_FIXED) next to the
 // one that reads them from EnvParams; the multi-step and rollout kernels exist for the former only (the launchers fall back)
+// flat ground compiled in (env_core.hpp IRRL_FLAT_GROUND): the step kernel and the multi-step kernel exist in that form too.  (Not in the
+// instrumented build of tools/wave_spread.py, whose per-wave clock sits in irrl_step_kernel.)
+static inline bool flat_kernels(const irrl_env *h) {
+#ifdef IRRL_PROFILE_WAVES
+  (void)h;
+  return false;
+#else
+  return !h->P.terrain;
+#endif
+}
 static inline bool shipped_solver(const irrl_env *h) {
   return h->P.contact_jacobi != 0 && h->P.contact_exit != 0 && h->P.contact_tol > 0.0f && h->P.contact_iters == IRRL_SHIPPED_SWEEP_CAP;
 }
@@ -139,7 +151,8 @@ static inline bool shipped_solver(const irrl_env *h) {
       if ((h)->P.contact_rule) IRRL_LAUNCH(h, irrl_step_kernel_crutial_md, grid, __VA_ARGS__);                               \
       else IRRL_LAUNCH(h, irrl_step_kernel_crutial, grid, __VA_ARGS__);                                                      \
     } else if ((h)->P.contact_rule) {                                                                                       \
-      if (shipped_solver(h)) IRRL_LAUNCH(h, irrl_step_kernel, grid, __VA_ARGS__);                                           \
+      if (shipped_solver(h) && flat_kernels(h)) IRRL_LAUNCH(h, irrl_step_kernel_flat, grid, __VA_ARGS__);                   \
+      else if (shipped_solver(h)) IRRL_LAUNCH(h, irrl_step_kernel, grid, __VA_ARGS__);                                      \
       else IRRL_LAUNCH(h, irrl_step_kernel_md, grid, __VA_ARGS__);                                                          \
     }                                                                                                                       \
     else IRRL_LAUNCH(h, irrl_step_kernel_dir, grid, __VA_ARGS__);                                                            \
@@ -317,7 +330,10 @@ static int step_rows_persistent_impl(irrl_env *h, int count, const float *action
   if (!action_rows || !ob || !reward || !done || !extra) { g_err = std::string(who) + ": NULL argument"; return 1; }
   if (h->P.crutial || !h->P.contact_rule || !shipped_solver(h)) return step_rows_impl(h, count, action_rows, n_rows, first_row, ob, reward, done, extra, out_rows, who);
   if (use_device(h)) return 1;
-  if (count > 0) IRRL_LAUNCH(h, irrl_steps_persistent_kernel, lane_grid(h, h->P.n_envs), h->P, h->S, action_rows, n_rows, first_row, count, ob, reward, done, extra, out_rows);
+  if (count > 0) {
+    if (flat_kernels(h)) IRRL_LAUNCH(h, irrl_steps_persistent_kernel_flat, lane_grid(h, h->P.n_envs), h->P, h->S, action_rows, n_rows, first_row, count, ob, reward, done, extra, out_rows);
+    else IRRL_LAUNCH(h, irrl_steps_persistent_kernel, lane_grid(h, h->P.n_envs), h->P, h->S, action_rows, n_rows, first_row, count, ob, reward, done, extra, out_rows);
+  }
   HIP_TRY(hipGetLastError());
   return 0;
 }

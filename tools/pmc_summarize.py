@@ -51,7 +51,7 @@ if pers:      # the multi-step persistent kernel: tools/pmc_workload.py issues l
     PERSIST_STEPS = 100
     pm = {c: statistics.median(v) for c, v in pers.items()}
     prd, pwr = pm["FETCH_SIZE"] * 1024.0 * cal["fetch_correction"], pm["WRITE_SIZE"] * 1024.0 * cal["write_correction"]
-    out["persistent"] = {"kernel": "irrl_steps_persistent_kernel_l16", "steps_per_launch": PERSIST_STEPS, "launches": len(pers["FETCH_SIZE"]),
+    out["persistent"] = {"kernel": "irrl_steps_persistent_kernel_flat_l16", "steps_per_launch": PERSIST_STEPS, "launches": len(pers["FETCH_SIZE"]),
                          "outputs_kept": True,   # tools/pmc_workload.py: every step's ob / reward / done / extraInfo stored to its own row (173 B per env-step)
                          "hbm_bytes_per_launch": {"read": prd, "written": pwr, "total": prd + pwr},
                          "hbm_bytes_per_step": {"read": prd / PERSIST_STEPS, "written": pwr / PERSIST_STEPS, "total": (prd + pwr) / PERSIST_STEPS, "algorithmic": 1521 * 4096},
