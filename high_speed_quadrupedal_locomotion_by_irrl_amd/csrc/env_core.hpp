@@ -1575,8 +1575,8 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
       // one loop for both exit rules, contact-point velocity carried from sweep to sweep (see the 16-lane instantiation)
       const bool predicted = IRRL_SOLVER_FIXED(RULE) || P.contact_exit != 0;
       v3 cv = coupling(lam, mk3(cfree[0], cfree[1], cfree[2]));
-      if (nrank > 0)
       const int sweep_cap = IRRL_SOLVER_FIXED(RULE) ? IRRL_SHIPPED_SWEEP_CAP : P.contact_iters;
+      if (nrank > 0)
 _Pragma("unroll 1")
       for (int it = 0; it < sweep_cap; it++) {
         v3 ln = RULE ? solve_contact_md(CM, cv, nB, vstar, L.m.mu, active) : solve_contact(CB, cv, nB, vstar, L.m.mu, active);
