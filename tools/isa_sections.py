@@ -1,7 +1,7 @@
 """Instruction-count breakdown of one physics substep of the step kernel (16-lane layout) by source section.
 Builds csrc/env_kernels.hip to assembly with -DIRRL_MARKS (section markers + scheduling barriers at the section borders, so
 the total is a few percent above the production build) and counts VALU / SALU / other instructions between markers.
-usage: python tools/isa_sections.py [--kernel NAME] [extra -D flags]   (default kernel: irrl_step_kernel_l16 = the published contact rule;
+usage: python tools/isa_sections.py [--kernel NAME] [extra -D flags]   (default kernel: irrl_step_kernel_l16 = the published contact rule, shipped solver settings compiled in, run-time terrain test -- irrl_step_kernel_flat_l16: flat ground compiled in;
 irrl_step_kernel_dir_l16 = the build's first rule, irrl_step_kernel_md_l16 = the published rule with the solver settings read at run time)"""
 import os, re, subprocess, sys, tempfile, collections
 
