@@ -1331,7 +1331,9 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
       const vf cvr0 = IRRL_COUPLING_ROW(lam, cfree_r);
       v3 cv = mk3(sub_bcast<0>(cvr0), sub_bcast<1>(cvr0), sub_bcast<2>(cvr0));
       const int sweep_cap = IRRL_SOLVER_FIXED(RULE) ? IRRL_SHIPPED_SWEEP_CAP : P.contact_iters;
-_Pragma("unroll 1")
+// (unrolled by two -- the back end emits the same code for 2, 3 and 6 with the cap a constant --: the common one- and two-sweep substeps run through
+      // fewer taken branches; multi-step kernel 28.4 -> 27.9 us per step, one launch per step 38.3 -> 37.5 us, same box; the 4-lane layout keeps its loop)
+_Pragma("unroll 2")
       for (int it = 0; it < sweep_cap; it++) {
 #ifdef IRRL_PROFILE_WAVES
         L.prof_ranksteps += 1; L.prof_flags += 256;
