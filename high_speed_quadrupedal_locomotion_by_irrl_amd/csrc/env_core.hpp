@@ -43,7 +43,7 @@ using namespace lanes;
 // ---------------------------------------------------------------------------------------------
 // RULE, the template parameter of the step's device functions: bit 0 = the per-contact rule (EnvParams::contact_rule: 1 = the published one),
 // bit 1 = THE SHIPPED SOLVER SETTINGS AS COMPILE-TIME CONSTANTS (ContactSolver bit 1 = simultaneous sweeps, ContactExit = 1, a ContactTolerance
-// above zero, ContactIterations = 6: what every shipped configuration runs).  The sweep loop then carries neither the other solver's loop nor the per-sweep tests of two run-time flags: same
+// above zero, ContactIterations = 6, eight substeps per control step: what every shipped configuration runs).  The sweep loop then carries neither the other solver's loop nor the per-sweep tests of two run-time flags: same
 // arithmetic, bit-identical results, multi-step kernel 30.0 -> 29.3 -> 29.0 -> 28.7 us per step, one launch per step 40.5 -> 40.1 -> 39.1 -> 38.5 us
 // (profiles/r06_ab_default_solver_compile_time_same_box.log).
 // The launcher takes the RULE = 3 kernels when the pool's settings are those and the RULE = 1 / 0 kernels otherwise (irrl_env_abi.hip).
@@ -1332,7 +1332,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
       v3 cv = mk3(sub_bcast<0>(cvr0), sub_bcast<1>(cvr0), sub_bcast<2>(cvr0));
       const int sweep_cap = IRRL_SOLVER_FIXED(RULE) ? IRRL_SHIPPED_SWEEP_CAP : P.contact_iters;
 // (unrolled by two -- the back end emits the same code for 2, 3 and 6 with the cap a constant --: the common one- and two-sweep substeps run through
-      // fewer taken branches; multi-step kernel 28.4 -> 27.9 us per step, one launch per step 38.3 -> 37.5 us, same box; the 4-lane layout keeps its loop)
+      // fewer taken branches; multi-step kernel 28.4 -> 27.9 us per step, one launch per step 38.3 -> 37.5 us, same box; the 4-lane layout's loop too: -1 ... -2 %)
 _Pragma("unroll 2")
       for (int it = 0; it < sweep_cap; it++) {
 #ifdef IRRL_PROFILE_WAVES
@@ -1579,7 +1579,7 @@ IRRL_DEV void physics_substep(const EnvParams &P, EnvLane &L, const vf pT[3]) {
       v3 cv = coupling(lam, mk3(cfree[0], cfree[1], cfree[2]));
       const int sweep_cap = IRRL_SOLVER_FIXED(RULE) ? IRRL_SHIPPED_SWEEP_CAP : P.contact_iters;
       if (nrank > 0)
-_Pragma("unroll 1")
+_Pragma("unroll 2")
       for (int it = 0; it < sweep_cap; it++) {
         v3 ln = RULE ? solve_contact_md(CM, cv, nB, vstar, L.m.mu, active) : solve_contact(CB, cv, nB, vstar, L.m.mu, active);
         v3 dl = mk3(vsel(active, ln.x - lam.x, 0.0f), vsel(active, ln.y - lam.y, 0.0f), vsel(active, ln.z - lam.z, 0.0f));
@@ -2311,7 +2311,11 @@ IRRL_DEV void step_compute(const EnvParams &P, EnvLane &L, vi env, vi leg, vm va
     }
   }
   before_substeps();
-  for (int i = 0; i < P.loop_count; i++) physics_substep<RULE>(P, L, pT);
+  // (the shipped settings' kernels: eight substeps as a constant, the loop unrolled by two -- the end of a substep and the start of the next
+  // share basic blocks: multi-step kernel 27.9 -> 27.66 us per step, same box)
+  const int n_substeps = IRRL_SOLVER_FIXED(RULE) ? IRRL_SHIPPED_SUBSTEPS : P.loop_count;
+_Pragma("unroll 2")
+  for (int i = 0; i < n_substeps; i++) physics_substep<RULE>(P, L, pT);
   IRRL_MARK("epi_noise");
   // The epilogue is per-leg work: with four sub-lanes per leg it would be executed four times over.  Only sub-lane 0
   // (the lane that owns the stores) runs it -- same issue time, a quarter of the active lanes, which is what the

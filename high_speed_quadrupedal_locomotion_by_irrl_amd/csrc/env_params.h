@@ -94,6 +94,7 @@ struct EnvState {
 // ContactIterations of every shipped configuration (and the default when the key is absent): a compile-time constant of the default pool's kernels
 // (env_core.hpp IRRL_SOLVER_FIXED; the launcher checks the pool's value against it, irrl_env_abi.hip shipped_solver)
 #define IRRL_SHIPPED_SWEEP_CAP 6
+#define IRRL_SHIPPED_SUBSTEPS 8    /* control_dt / simulation_dt of every shipped configuration (Environment.hpp:711) */
 
 // RNG purposes -- (purpose, slot) addresses every random draw; identical table in the oracle.
 enum {

@@ -130,7 +130,7 @@ static int pick_waves2(int n_envs, int device) {
   } while (0)
 
 // the step kernel: one instantiation per (Crutial, per-contact rule) -- env_kernels.hip -- and, for the default pool kind (no meteorite, published
-// rule), one with the shipped solver settings compiled in (simultaneous sweeps + predicted exit + a tolerance above zero + at most six sweeps: env_core.hpp IRRL_SOLVER_FIXED) next to the
+// rule), one with the shipped solver settings compiled in (simultaneous sweeps + predicted exit + a tolerance above zero + at most six sweeps + eight substeps per control step: env_core.hpp IRRL_SOLVER_FIXED) next to the
 // one that reads them from EnvParams; the multi-step and rollout kernels exist for the former only (the launchers fall back)
 // flat ground compiled in (env_core.hpp IRRL_FLAT_GROUND): the step kernel and the multi-step kernel exist in that form too.  (Not in the
 // instrumented build of tools/wave_spread.py, whose per-wave clock sits in irrl_step_kernel.)
@@ -143,7 +143,8 @@ static inline bool flat_kernels(const irrl_env *h) {
 #endif
 }
 static inline bool shipped_solver(const irrl_env *h) {
-  return h->P.contact_jacobi != 0 && h->P.contact_exit != 0 && h->P.contact_tol > 0.0f && h->P.contact_iters == IRRL_SHIPPED_SWEEP_CAP;
+  return h->P.contact_jacobi != 0 && h->P.contact_exit != 0 && h->P.contact_tol > 0.0f && h->P.contact_iters == IRRL_SHIPPED_SWEEP_CAP &&
+         h->P.loop_count == IRRL_SHIPPED_SUBSTEPS;
 }
 #define IRRL_LAUNCH_STEP(h, grid, ...)                                                                                      \
   do {                                                                                                                    \
