@@ -54,11 +54,13 @@ def test_step_rows_equals_the_same_steps_one_by_one():
 
 
 @pytest.mark.parametrize("n,cfg_name,over", [(4096, "bp5_imitation.yaml", {}), (330, "default_cfg.yaml", {}), (8192, "bp5_terrain.yaml", {}),
-                                             (96, "default_cfg.yaml", {"Crutial": True})])
+                                             (96, "default_cfg.yaml", {"Crutial": True}), (96, "default_cfg.yaml", {"ContactSolver": 1}),
+                                             (96, "default_cfg.yaml", {"ContactIterations": 5}), (96, "bp5_imitation.yaml", {"ContactTolerance": 0.0})])
 def test_persistent_multi_step_launch_equals_back_to_back_launches(n, cfg_name, over):
     """irrl_env_step_rows_persistent (ONE launch: every wave walks its own robots through all K steps, no grid-wide boundary between
     steps) leaves the pool and the outputs bit-identical to irrl_env_step_rows (K launches): 400 steps with in-step resets, in the
-    16-lane layout (4096 and a ragged 330), the 4-lane layout (8192 envs, rough ground) and a Crutial pool (the launcher's fallback)."""
+    16-lane layout (4096 and a ragged 330), the 4-lane layout (8192 envs, rough ground), a Crutial pool and pools whose solver settings are not the
+    ones compiled into the multi-step kernel (Gauss-Seidel order, another sweep cap, no tolerance): the launcher's fallback to one launch per step."""
     import torch
     from hip_env import HipVecEnv
     K, rows = 400, 64
